@@ -1,0 +1,1029 @@
+// orb_oracle.cpp -- CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+//
+// This file is a plain, scalar, single-threaded CPU restatement of the per-frame ORB feature
+// front end of AlejandroSilvestri/os1 (ORB-SLAM2 fork).  It exists only so that tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg can check / time the HIP product
+// (os1_amd/).  NOTHING under os1_amd/ may include, link, load or call it.
+//
+// PARITY STATUS: ** parity unpinned **.
+//   The reference ships no tests / golden vectors and its pixel arithmetic is
+//   split with an un-vendored, un-pinned OpenCV 4 (reference .cproject:40,58-64) that is not
+//   present in this image, so the reference cannot be built here and there is nothing of the
+//   reference's own to pin this oracle against.  What IS pinned:
+//     * everything the reference source spells out itself (cell loop, quadtree, IC-angle,
+//       rBRIEF sampling, grid, the searches, Hamming) follows the cited lines one-to-one;
+//     * the OpenCV-side primitives (cv::FAST, cv::resize INTER_LINEAR 8u, cv::GaussianBlur 8u
+//       7x7 s=2, cv::fastAtan2, cvRound/cvFloor/cvCeil) restate OpenCV 4.x's *published
+//       generic (non-IPP, non-FMA) algorithms*; the variant chosen is:
+//         - GaussianBlur: 8.8 fixed-point kernel, error-diffused rounding (OpenCV >= 4.1.1):
+//           [18,34,48,56,48,34,18]/256, reflect-101, (S + 32768) >> 16;
+//         - resize: INTER_RESIZE_COEF_BITS = 11 fixed-point bilinear;
+//         - fastAtan2: 7th-order odd polynomial, float32, no FMA contraction;
+//         - cosf/sinf: this image's glibc (2.35) float routines;
+//       they are pinned by first-principles known-answer tests in tests/test_oracle_kat.py.
+//   Hazard H1: the reference breaks ties between equal-sized quadtree nodes by
+//   heap address (ORBextractor.cc:716); this oracle uses node creation order instead
+//   (later-created node == "larger pointer").
+//
+// Build: g++ -O3 -std=gnu++17 -ffp-contract=off (mirrors the reference's -O3, no arch flags;
+// contraction off so x*b+y*a and the atan polynomial round like separate mul/add).
+//
+// Citations "ORBextractor.cc:NNN" etc. are relative to /root/reference/src.
+
+#include <algorithm>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <list>
+#include <utility>
+#include <vector>
+
+extern "C" {
+// Same 28-byte layout as cv::KeyPoint (pt.x, pt.y, size, angle, response, octave, class_id).
+typedef struct {
+  float x, y, size, angle, response;
+  int32_t octave, class_id;
+} OrcKeyPoint;
+}
+
+using std::ptrdiff_t;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// OpenCV rounding helpers.  cvRound = round-half-to-even.
+// ---------------------------------------------------------------------------------------------
+inline int cv_round(float v) { return (int)lrintf(v); }
+inline int cv_round(double v) { return (int)lrint(v); }
+inline int cv_floor(float v) { int i = (int)v; return i - (i > v); }
+inline int cv_ceil(float v) { int i = (int)v; return i + (i < v); }
+inline short sat_short(int v) { return (short)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); }
+
+struct View {  // borrowed u8 image view
+  const uint8_t* p;
+  int w, h;
+  ptrdiff_t stride;
+  const uint8_t* row(int y) const { return p + (ptrdiff_t)y * stride; }
+};
+
+struct Image {  // owned, tightly packed
+  std::vector<uint8_t> d;
+  int w = 0, h = 0;
+  void alloc(int W, int H) { w = W; h = H; d.assign((size_t)W * H, 0); }
+  View view() const { return View{d.data(), w, h, (ptrdiff_t)w}; }
+  uint8_t* row(int y) { return d.data() + (size_t)y * w; }
+};
+
+// ---------------------------------------------------------------------------------------------
+// cv::resize(src, dst, dsize, 0, 0, INTER_LINEAR) for 8UC1 -- SURVEY.md Appendix B.2.
+// Call site: ORBextractor.cc:984.
+// ---------------------------------------------------------------------------------------------
+void resize_linear_u8(const View& s, uint8_t* dst, int dw, int dh, ptrdiff_t dstride) {
+  const int sw = s.w, sh = s.h;
+  const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+  const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+  std::vector<int> xofs(dw), yofs(dh);
+  std::vector<short> alpha(2 * (size_t)dw), beta(2 * (size_t)dh);
+  int xmax = dw;
+  for (int dx = 0; dx < dw; dx++) {
+    float fx = (float)((dx + 0.5) * scale_x - 0.5);
+    int sx = cv_floor(fx);
+    fx -= sx;
+    if (sx < 0) { fx = 0; sx = 0; }
+    if (sx + 1 >= sw) {
+      xmax = std::min(xmax, dx);
+      if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+    }
+    xofs[dx] = sx;
+    alpha[2 * dx] = sat_short(cv_round((1.f - fx) * 2048));
+    alpha[2 * dx + 1] = sat_short(cv_round(fx * 2048));
+  }
+  for (int dy = 0; dy < dh; dy++) {
+    float fy = (float)((dy + 0.5) * scale_y - 0.5);
+    int sy = cv_floor(fy);
+    fy -= sy;
+    yofs[dy] = sy;
+    beta[2 * dy] = sat_short(cv_round((1.f - fy) * 2048));
+    beta[2 * dy + 1] = sat_short(cv_round(fy * 2048));
+  }
+  auto clip = [](int x, int a, int b) { return x >= a ? (x < b ? x : b - 1) : a; };
+  std::vector<int> h0(dw), h1(dw);
+  auto hline = [&](const uint8_t* S, std::vector<int>& D) {
+    int dx = 0;
+    for (; dx < xmax; dx++) {
+      int sx = xofs[dx];
+      D[dx] = S[sx] * alpha[2 * dx] + S[sx + 1] * alpha[2 * dx + 1];
+    }
+    for (; dx < dw; dx++) D[dx] = S[xofs[dx]] * 2048;
+  };
+  for (int dy = 0; dy < dh; dy++) {
+    const int sy0 = clip(yofs[dy], 0, sh), sy1 = clip(yofs[dy] + 1, 0, sh);
+    hline(s.row(sy0), h0);
+    hline(s.row(sy1), h1);
+    const int b0 = beta[2 * dy], b1 = beta[2 * dy + 1];
+    uint8_t* D = dst + (ptrdiff_t)dy * dstride;
+    for (int x = 0; x < dw; x++)
+      D[x] = (uint8_t)((((b0 * (h0[x] >> 4)) >> 16) + ((b1 * (h1[x] >> 4)) >> 16) + 2) >> 2);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// cv::GaussianBlur(u8, Size(7,7), 2, 2, BORDER_REFLECT_101) -- SURVEY.md Appendix B.3.
+// Call site: ORBextractor.cc:950 (on a clone of the level, so the border is the level's own).
+// ---------------------------------------------------------------------------------------------
+// 8.8 fixed-point kernel by error diffusion from the ends to the centre; centre takes the rest.
+void gauss_kernel_fixed_ed(int n, double sigma, int out[]) {
+  std::vector<double> k(n);
+  double sum = 0;
+  for (int i = 0; i < n; i++) {
+    double x = i - (n - 1) * 0.5;
+    k[i] = std::exp(-0.5 * x * x / (sigma * sigma));
+    sum += k[i];
+  }
+  for (int i = 0; i < n; i++) k[i] /= sum;
+  double err = 0;
+  int isum = 0;
+  for (int i = 0; i < n / 2; i++) {
+    double adj = k[i] * 256.0 + err;
+    int v = cv_round(adj);
+    err = adj - v;
+    out[i] = out[n - 1 - i] = v;
+    isum += v;
+  }
+  out[n / 2] = 256 - 2 * isum;
+}
+
+inline int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+  return i;
+}
+
+void gauss7_u8(const View& s, uint8_t* dst, ptrdiff_t dstride) {
+  int k[7];
+  gauss_kernel_fixed_ed(7, 2.0, k);
+  const int w = s.w, h = s.h;
+  std::vector<uint16_t> hb((size_t)w * h);
+  for (int y = 0; y < h; y++) {
+    const uint8_t* S = s.row(y);
+    for (int x = 0; x < w; x++) {
+      unsigned acc = 0;
+      for (int t = 0; t < 7; t++) acc += (unsigned)k[t] * S[reflect101(x + t - 3, w)];
+      hb[(size_t)y * w + x] = (uint16_t)acc;  // <= 255*256, no saturation
+    }
+  }
+  for (int y = 0; y < h; y++) {
+    uint8_t* D = dst + (ptrdiff_t)y * dstride;
+    for (int x = 0; x < w; x++) {
+      uint32_t acc = 0;
+      for (int t = 0; t < 7; t++) acc += (uint32_t)k[t] * hb[(size_t)reflect101(y + t - 3, h) * w + x];
+      D[x] = (uint8_t)((acc + 32768u) >> 16);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// cv::FAST(roi, kps, threshold, nonmaxSuppression=true), FAST-9/16 -- SURVEY.md Appendix B.1.
+// Call sites: ORBextractor.cc:848,854.
+// ---------------------------------------------------------------------------------------------
+const int kRingDx[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+const int kRingDy[16] = {3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1, 0, 1, 2, 3};
+
+// Is the centre a FAST-9 corner at threshold t (strict compares)?
+bool fast_is_corner(const int d[16], int t) {  // d[k] = centre - ring[k]
+  for (int pol = 0; pol < 2; pol++) {
+    int run = 0;
+    for (int k = 0; k < 16 + 8; k++) {  // wrap: a run of 9 starting anywhere
+      int v = pol ? -d[k & 15] : d[k & 15];
+      run = (v > t) ? run + 1 : 0;
+      if (run >= 9) return true;
+    }
+  }
+  return false;
+}
+
+// cornerScore<16>: the largest threshold for which the pixel is still a corner, given it is
+// one at `threshold`: max(threshold, max_arc min(d), max_arc min(-d)) - 1.
+int fast_corner_score(const int d[16], int threshold) {
+  int a0 = threshold;
+  for (int k = 0; k < 16; k++) {
+    int mn = INT_MAX, mx = INT_MIN;
+    for (int j = 0; j < 9; j++) {
+      int v = d[(k + j) & 15];
+      mn = std::min(mn, v);
+      mx = std::max(mx, v);
+    }
+    a0 = std::max(a0, mn);   // all ring darker than centre by more than mn-1
+    a0 = std::max(a0, -mx);  // all ring brighter
+  }
+  return a0 - 1;
+}
+
+struct RoiKp { int x, y, score; };
+
+void fast9_roi(const View& roi, int threshold, bool nms, std::vector<RoiKp>& out) {
+  out.clear();
+  threshold = std::min(std::max(threshold, 0), 255);
+  const int w = roi.w, h = roi.h;
+  if (w < 7 || h < 7) return;
+  std::vector<uint8_t> score((size_t)w * h, 0);  // 0 outside [3,w-4]x[3,h-4] and at non-corners
+  std::vector<uint8_t> corner((size_t)w * h, 0);
+  for (int y = 3; y < h - 3; y++) {
+    for (int x = 3; x < w - 3; x++) {
+      const int v = roi.row(y)[x];
+      int d[16];
+      for (int k = 0; k < 16; k++) d[k] = v - roi.row(y + kRingDy[k])[x + kRingDx[k]];
+      if (!fast_is_corner(d, threshold)) continue;
+      corner[(size_t)y * w + x] = 1;
+      score[(size_t)y * w + x] = (uint8_t)fast_corner_score(d, threshold);
+    }
+  }
+  for (int y = 3; y < h - 3; y++) {
+    for (int x = 3; x < w - 3; x++) {
+      if (!corner[(size_t)y * w + x]) continue;
+      const int s = score[(size_t)y * w + x];
+      if (nms) {
+        bool keep = true;
+        for (int dy = -1; dy <= 1 && keep; dy++)
+          for (int dx = -1; dx <= 1; dx++) {
+            if (!dx && !dy) continue;
+            if (!(s > score[(size_t)(y + dy) * w + x + dx])) { keep = false; break; }
+          }
+        if (!keep) continue;
+      }
+      out.push_back(RoiKp{x, y, s});
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// cv::fastAtan2(y, x) in degrees -- SURVEY.md Appendix B.4.  Call site: ORBextractor.cc:112.
+// ---------------------------------------------------------------------------------------------
+const float kAtanP1 = 0.9997878412794807f * (float)(180 / 3.1415926535897932384626433832795);
+const float kAtanP3 = -0.3258083974640975f * (float)(180 / 3.1415926535897932384626433832795);
+const float kAtanP5 = 0.1555786518463281f * (float)(180 / 3.1415926535897932384626433832795);
+const float kAtanP7 = -0.04432655554792128f * (float)(180 / 3.1415926535897932384626433832795);
+
+float fast_atan2(float y, float x) {
+  float ax = std::fabs(x), ay = std::fabs(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = ay / (ax + (float)DBL_EPSILON);
+    c2 = c * c;
+    a = (((kAtanP7 * c2 + kAtanP5) * c2 + kAtanP3) * c2 + kAtanP1) * c;
+  } else {
+    c = ax / (ay + (float)DBL_EPSILON);
+    c2 = c * c;
+    a = 90.f - (((kAtanP7 * c2 + kAtanP5) * c2 + kAtanP3) * c2 + kAtanP1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Reference constants.  ORBextractor.cc:73-79.
+// ---------------------------------------------------------------------------------------------
+const int PATCH_SIZE = 31;
+const int HALF_PATCH_SIZE = 15;
+const int EDGE_THRESHOLD = 19;
+
+const int8_t kBriefPattern[256 * 4] = {
+#include "brief_pattern.inc"
+};
+
+// IC_Angle -- ORBextractor.cc:86-113.  `img` is the UNBLURRED level.
+float ic_angle(const View& img, float ptx, float pty, const std::vector<int>& u_max) {
+  int m_01 = 0, m_10 = 0;
+  const uint8_t* center = img.row(cv_round(pty)) + cv_round(ptx);
+  for (int u = -HALF_PATCH_SIZE; u <= HALF_PATCH_SIZE; ++u) m_10 += u * center[u];
+  const ptrdiff_t step = img.stride;
+  for (int v = 1; v <= HALF_PATCH_SIZE; ++v) {
+    int v_sum = 0;
+    int d = u_max[v];
+    for (int u = -d; u <= d; ++u) {
+      int val_plus = center[u + v * step], val_minus = center[u - v * step];
+      v_sum += (val_plus - val_minus);
+      m_10 += u * (val_plus + val_minus);
+    }
+    m_01 += v * v_sum;
+  }
+  return fast_atan2((float)m_01, (float)m_10);
+}
+
+// computeOrbDescriptor -- ORBextractor.cc:120,132-171.  `img` is the BLURRED level.
+const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+
+void orb_descriptor(const OrcKeyPoint& kpt, const View& img, uint8_t* desc) {
+  float angle = (float)kpt.angle * factorPI;
+  float a = (float)cosf(angle), b = (float)sinf(angle);  // std::cos(float)/std::sin(float)
+  const uint8_t* center = img.row(cv_round(kpt.y)) + cv_round(kpt.x);
+  const ptrdiff_t step = img.stride;
+  const int8_t* pat = kBriefPattern;
+  auto get = [&](int idx) -> int {
+    const float px = (float)pat[2 * idx], py = (float)pat[2 * idx + 1];
+    return center[cv_round(px * b + py * a) * step + cv_round(px * a - py * b)];
+  };
+  for (int i = 0; i < 32; ++i, pat += 32) {
+    int val = 0;
+    for (int k = 0; k < 8; k++) {
+      int t0 = get(2 * k), t1 = get(2 * k + 1);
+      val |= (t0 < t1) << k;
+    }
+    desc[i] = (uint8_t)val;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// ExtractorNode / DivideNode -- ORBextractor.h:44-92, ORBextractor.cc:513-569.
+// ---------------------------------------------------------------------------------------------
+struct Node {
+  std::vector<OrcKeyPoint> keys;
+  int ULx, ULy, URx, URy, BLx, BLy, BRx, BRy;
+  std::list<Node>::iterator lit;
+  bool noMore = false;
+  long seq = 0;  // creation order: stands in for the heap address in the (size, ptr) sort (H1)
+
+  void divide(Node& n1, Node& n2, Node& n3, Node& n4) const {
+    const int halfX = (int)std::ceil(static_cast<float>(URx - ULx) / 2);
+    const int halfY = (int)std::ceil(static_cast<float>(BRy - ULy) / 2);
+    n1.ULx = ULx; n1.ULy = ULy;
+    n1.URx = ULx + halfX; n1.URy = ULy;
+    n1.BLx = ULx; n1.BLy = ULy + halfY;
+    n1.BRx = ULx + halfX; n1.BRy = ULy + halfY;
+    n2.ULx = n1.URx; n2.ULy = n1.URy;
+    n2.URx = URx; n2.URy = URy;
+    n2.BLx = n1.BRx; n2.BLy = n1.BRy;
+    n2.BRx = URx; n2.BRy = ULy + halfY;
+    n3.ULx = n1.BLx; n3.ULy = n1.BLy;
+    n3.URx = n1.BRx; n3.URy = n1.BRy;
+    n3.BLx = BLx; n3.BLy = BLy;
+    n3.BRx = n1.BRx; n3.BRy = BLy;
+    n4.ULx = n3.URx; n4.ULy = n3.URy;
+    n4.URx = n2.BRx; n4.URy = n2.BRy;
+    n4.BLx = n3.BRx; n4.BLy = n3.BRy;
+    n4.BRx = BRx; n4.BRy = BRy;
+    for (size_t i = 0; i < keys.size(); i++) {
+      const OrcKeyPoint& kp = keys[i];
+      if (kp.x < n1.URx) {
+        if (kp.y < n1.BRy) n1.keys.push_back(kp); else n3.keys.push_back(kp);
+      } else if (kp.y < n1.BRy) n2.keys.push_back(kp);
+      else n4.keys.push_back(kp);
+    }
+    if (n1.keys.size() == 1) n1.noMore = true;
+    if (n2.keys.size() == 1) n2.noMore = true;
+    if (n3.keys.size() == 1) n3.noMore = true;
+    if (n4.keys.size() == 1) n4.noMore = true;
+  }
+};
+
+// DistributeOctTree -- ORBextractor.cc:571-795.
+std::vector<OrcKeyPoint> distribute_octtree(const std::vector<OrcKeyPoint>& vToDistributeKeys, int minX,
+                                            int maxX, int minY, int maxY, int N) {
+  long seq = 0;
+  const int nIni = (int)std::round(static_cast<float>(maxX - minX) / (maxY - minY));
+  const float hX = static_cast<float>(maxX - minX) / nIni;
+  std::list<Node> lNodes;
+  std::vector<Node*> vpIniNodes(nIni > 0 ? nIni : 0);
+  for (int i = 0; i < nIni; i++) {
+    Node ni;
+    ni.ULx = (int)(hX * static_cast<float>(i)); ni.ULy = 0;
+    ni.URx = (int)(hX * static_cast<float>(i + 1)); ni.URy = 0;
+    ni.BLx = ni.ULx; ni.BLy = maxY - minY;
+    ni.BRx = ni.URx; ni.BRy = maxY - minY;
+    ni.seq = seq++;
+    lNodes.push_back(ni);
+    vpIniNodes[i] = &lNodes.back();
+  }
+  for (size_t i = 0; i < vToDistributeKeys.size(); i++) {
+    const OrcKeyPoint& kp = vToDistributeKeys[i];
+    vpIniNodes[(size_t)(kp.x / hX)]->keys.push_back(kp);
+  }
+  for (auto lit = lNodes.begin(); lit != lNodes.end();) {
+    if (lit->keys.size() == 1) { lit->noMore = true; ++lit; }
+    else if (lit->keys.empty()) lit = lNodes.erase(lit);
+    else ++lit;
+  }
+
+  bool bFinish = false;
+  typedef std::pair<int, Node*> SizeNode;
+  auto by_size_then_age = [](const SizeNode& a, const SizeNode& b) {
+    return a.first != b.first ? a.first < b.first : a.second->seq < b.second->seq;
+  };
+  std::vector<SizeNode> vSizeAndPointerToNode;
+
+  // push children n1..n4 to the front (those with keys), recording the ones with >1 key
+  auto push_children = [&](Node* ch[4], int& nToExpand) {
+    for (int c = 0; c < 4; c++) {
+      Node& n = *ch[c];
+      if (n.keys.size() > 0) {
+        n.seq = seq++;
+        lNodes.push_front(n);
+        if (n.keys.size() > 1) {
+          nToExpand++;
+          vSizeAndPointerToNode.push_back(std::make_pair((int)n.keys.size(), &lNodes.front()));
+          lNodes.front().lit = lNodes.begin();
+        }
+      }
+    }
+  };
+
+  while (!bFinish) {
+    int prevSize = (int)lNodes.size();
+    auto lit = lNodes.begin();
+    int nToExpand = 0;
+    vSizeAndPointerToNode.clear();
+    while (lit != lNodes.end()) {
+      if (lit->noMore) { ++lit; continue; }
+      Node n1, n2, n3, n4;
+      lit->divide(n1, n2, n3, n4);
+      Node* ch[4] = {&n1, &n2, &n3, &n4};
+      push_children(ch, nToExpand);
+      lit = lNodes.erase(lit);
+    }
+    if ((int)lNodes.size() >= N || (int)lNodes.size() == prevSize) {
+      bFinish = true;
+    } else if (((int)lNodes.size() + nToExpand * 3) > N) {
+      while (!bFinish) {
+        prevSize = (int)lNodes.size();
+        std::vector<SizeNode> vPrev = vSizeAndPointerToNode;
+        vSizeAndPointerToNode.clear();
+        std::sort(vPrev.begin(), vPrev.end(), by_size_then_age);
+        for (int j = (int)vPrev.size() - 1; j >= 0; j--) {
+          Node n1, n2, n3, n4;
+          vPrev[j].second->divide(n1, n2, n3, n4);
+          Node* ch[4] = {&n1, &n2, &n3, &n4};
+          int dummy = 0;
+          push_children(ch, dummy);
+          lNodes.erase(vPrev[j].second->lit);
+          if ((int)lNodes.size() >= N) break;
+        }
+        if ((int)lNodes.size() >= N || (int)lNodes.size() == prevSize) bFinish = true;
+      }
+    }
+  }
+
+  std::vector<OrcKeyPoint> vResultKeys;
+  vResultKeys.reserve(lNodes.size());
+  for (auto lit = lNodes.begin(); lit != lNodes.end(); ++lit) {
+    const std::vector<OrcKeyPoint>& vNodeKeys = lit->keys;
+    const OrcKeyPoint* pKP = &vNodeKeys[0];
+    float maxResponse = pKP->response;
+    for (size_t k = 1; k < vNodeKeys.size(); k++)
+      if (vNodeKeys[k].response > maxResponse) { pKP = &vNodeKeys[k]; maxResponse = vNodeKeys[k].response; }
+    vResultKeys.push_back(*pKP);
+  }
+  return vResultKeys;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ORBextractor -- ORBextractor.cc:442-502 (ctor), 797-895, 907-996.
+// ---------------------------------------------------------------------------------------------
+struct Extractor {
+  int nfeatures;
+  double scaleFactor;
+  int nlevels, iniThFAST, minThFAST;
+  std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+  std::vector<int> mnFeaturesPerLevel, umax;
+  std::vector<Image> pyramid;                         // mvImagePyramid (without the dead 19-px border)
+  std::vector<std::vector<OrcKeyPoint>> lastCandidates;  // per level, pre-quadtree (for stage tests)
+  std::vector<Image> lastBlurred;
+
+  Extractor(int nf, float sf, int nl, int ini, int mn)
+      : nfeatures(nf), scaleFactor(sf), nlevels(nl), iniThFAST(ini), minThFAST(mn) {
+    mvScaleFactor.resize(nlevels);
+    mvLevelSigma2.resize(nlevels);
+    mvScaleFactor[0] = 1.0f;
+    mvLevelSigma2[0] = 1.0f;
+    for (int i = 1; i < nlevels; i++) {
+      mvScaleFactor[i] = mvScaleFactor[i - 1] * scaleFactor;
+      mvLevelSigma2[i] = mvScaleFactor[i] * mvScaleFactor[i];
+    }
+    mvInvScaleFactor.resize(nlevels);
+    mvInvLevelSigma2.resize(nlevels);
+    for (int i = 0; i < nlevels; i++) {
+      mvInvScaleFactor[i] = 1.0f / mvScaleFactor[i];
+      mvInvLevelSigma2[i] = 1.0f / mvLevelSigma2[i];
+    }
+    pyramid.resize(nlevels);
+    mnFeaturesPerLevel.resize(nlevels);
+    float factor = 1.0f / scaleFactor;
+    float nDesiredFeaturesPerScale =
+        nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels));
+    int sumFeatures = 0;
+    for (int level = 0; level < nlevels - 1; level++) {
+      mnFeaturesPerLevel[level] = cv_round(nDesiredFeaturesPerScale);
+      sumFeatures += mnFeaturesPerLevel[level];
+      nDesiredFeaturesPerScale *= factor;
+    }
+    mnFeaturesPerLevel[nlevels - 1] = std::max(nfeatures - sumFeatures, 0);
+
+    umax.resize(HALF_PATCH_SIZE + 1);
+    int v, v0, vmax = cv_floor(HALF_PATCH_SIZE * sqrtf(2.f) / 2 + 1);
+    int vmin = cv_ceil(HALF_PATCH_SIZE * sqrtf(2.f) / 2);
+    const double hp2 = HALF_PATCH_SIZE * HALF_PATCH_SIZE;
+    for (v = 0; v <= vmax; ++v) umax[v] = cv_round(sqrt(hp2 - v * v));
+    for (v = HALF_PATCH_SIZE, v0 = 0; v >= vmin; --v) {
+      while (umax[v0] == umax[v0 + 1]) ++v0;
+      umax[v] = v0;
+      ++v0;
+    }
+  }
+
+  // ComputePyramid -- ORBextractor.cc:971-996
+  void computePyramid(const View& image) {
+    for (int level = 0; level < nlevels; ++level) {
+      float scale = mvInvScaleFactor[level];
+      int sw = cv_round((float)image.w * scale), sh = cv_round((float)image.h * scale);
+      pyramid[level].alloc(sw, sh);
+      if (level != 0) {
+        resize_linear_u8(pyramid[level - 1].view(), pyramid[level].d.data(), sw, sh, sw);
+      } else {
+        for (int y = 0; y < sh; y++) memcpy(pyramid[0].row(y), image.row(y), sw);
+      }
+    }
+  }
+
+  // ComputeKeyPointsOctTree -- ORBextractor.cc:797-895
+  void computeKeyPointsOctTree(std::vector<std::vector<OrcKeyPoint>>& allKeypoints) {
+    allKeypoints.resize(nlevels);
+    lastCandidates.assign(nlevels, {});
+    const float W = 30;
+    std::vector<RoiKp> vKeysCell;
+    for (int level = 0; level < nlevels; ++level) {
+      const View img = pyramid[level].view();
+      const int minBorderX = EDGE_THRESHOLD - 3;
+      const int minBorderY = minBorderX;
+      const int maxBorderX = img.w - EDGE_THRESHOLD + 3;
+      const int maxBorderY = img.h - EDGE_THRESHOLD + 3;
+      std::vector<OrcKeyPoint> vToDistributeKeys;
+      vToDistributeKeys.reserve(nfeatures * 10);
+      const float width = (maxBorderX - minBorderX);
+      const float height = (maxBorderY - minBorderY);
+      const int nCols = width / W;
+      const int nRows = height / W;
+      const int wCell = std::ceil(width / nCols);
+      const int hCell = std::ceil(height / nRows);
+      for (int i = 0; i < nRows; i++) {
+        const float iniY = minBorderY + i * hCell;
+        float maxY = iniY + hCell + 6;
+        if (iniY >= maxBorderY - 3) continue;
+        if (maxY > maxBorderY) maxY = maxBorderY;
+        for (int j = 0; j < nCols; j++) {
+          const float iniX = minBorderX + j * wCell;
+          float maxX = iniX + wCell + 6;
+          if (iniX >= maxBorderX - 6) continue;
+          if (maxX > maxBorderX) maxX = maxBorderX;
+          const int y0 = (int)iniY, y1 = (int)maxY, x0 = (int)iniX, x1 = (int)maxX;
+          View roi{img.row(y0) + x0, x1 - x0, y1 - y0, img.stride};
+          fast9_roi(roi, iniThFAST, true, vKeysCell);
+          if (vKeysCell.empty()) fast9_roi(roi, minThFAST, true, vKeysCell);
+          for (const RoiKp& k : vKeysCell) {
+            OrcKeyPoint kp;  // cv::KeyPoint(x, y, 7.f, -1, score)
+            kp.x = (float)k.x; kp.y = (float)k.y; kp.size = 7.f; kp.angle = -1.f;
+            kp.response = (float)k.score; kp.octave = 0; kp.class_id = -1;
+            kp.x += j * wCell;
+            kp.y += i * hCell;
+            vToDistributeKeys.push_back(kp);
+          }
+        }
+      }
+      lastCandidates[level] = vToDistributeKeys;
+      std::vector<OrcKeyPoint>& keypoints = allKeypoints[level];
+      keypoints = distribute_octtree(vToDistributeKeys, minBorderX, maxBorderX, minBorderY, maxBorderY,
+                                     mnFeaturesPerLevel[level]);
+      const int scaledPatchSize = PATCH_SIZE * mvScaleFactor[level];
+      for (OrcKeyPoint& kp : keypoints) {
+        kp.x += minBorderX;
+        kp.y += minBorderY;
+        kp.octave = level;
+        kp.size = scaledPatchSize;
+      }
+    }
+    for (int level = 0; level < nlevels; ++level) {
+      const View img = pyramid[level].view();
+      for (OrcKeyPoint& kp : allKeypoints[level]) kp.angle = ic_angle(img, kp.x, kp.y, umax);
+    }
+  }
+
+  // operator() -- ORBextractor.cc:907-969.  Returns keypoints; desc gets 32 B per keypoint.
+  void extract(const View& image, std::vector<OrcKeyPoint>& kps, std::vector<uint8_t>& desc) {
+    kps.clear();
+    desc.clear();
+    if (image.w <= 0 || image.h <= 0 || !image.p) return;
+    computePyramid(image);
+    std::vector<std::vector<OrcKeyPoint>> allKeypoints;
+    computeKeyPointsOctTree(allKeypoints);
+    int nkeypoints = 0;
+    for (int level = 0; level < nlevels; ++level) nkeypoints += (int)allKeypoints[level].size();
+    desc.assign((size_t)nkeypoints * 32, 0);
+    kps.reserve(nkeypoints);
+    lastBlurred.assign(nlevels, Image());
+    int offset = 0;
+    for (int level = 0; level < nlevels; ++level) {
+      std::vector<OrcKeyPoint>& keypoints = allKeypoints[level];
+      int nkeypointsLevel = (int)keypoints.size();
+      if (nkeypointsLevel == 0) continue;
+      Image& working = lastBlurred[level];
+      working.alloc(pyramid[level].w, pyramid[level].h);
+      gauss7_u8(pyramid[level].view(), working.d.data(), working.w);
+      const View wv = working.view();
+      for (int i = 0; i < nkeypointsLevel; i++) orb_descriptor(keypoints[i], wv, &desc[(size_t)(offset + i) * 32]);
+      offset += nkeypointsLevel;
+      if (level != 0) {
+        float scale = mvScaleFactor[level];
+        for (OrcKeyPoint& kp : keypoints) { kp.x *= scale; kp.y *= scale; }
+      }
+      kps.insert(kps.end(), keypoints.begin(), keypoints.end());
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Hamming -- ORBmatcher.cc:1605-1621.
+// ---------------------------------------------------------------------------------------------
+int descriptor_distance(const uint8_t* a, const uint8_t* b) {
+  int dist = 0;
+  for (int i = 0; i < 8; i++) {
+    uint32_t wa, wb;
+    memcpy(&wa, a + 4 * i, 4);
+    memcpy(&wb, b + 4 * i, 4);
+    unsigned int v = wa ^ wb;
+    v = v - ((v >> 1) & 0x55555555);
+    v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+    dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+  }
+  return dist;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Frame grid -- Frame.h:36-37, Frame.cc:98-99,114-129,209-274.
+// ---------------------------------------------------------------------------------------------
+const int FRAME_GRID_ROWS = 48, FRAME_GRID_COLS = 64;
+
+struct FrameGrid {
+  const OrcKeyPoint* kpsUn;
+  int N;
+  float mnMinX, mnMaxX, mnMinY, mnMaxY, mfGridElementWidthInv, mfGridElementHeightInv;
+  std::vector<size_t> mGrid[FRAME_GRID_COLS][FRAME_GRID_ROWS];
+
+  FrameGrid(const OrcKeyPoint* k, int n, const float bounds[4]) : kpsUn(k), N(n) {
+    mnMinX = bounds[0]; mnMaxX = bounds[1]; mnMinY = bounds[2]; mnMaxY = bounds[3];
+    mfGridElementWidthInv = static_cast<float>(FRAME_GRID_COLS) / static_cast<float>(mnMaxX - mnMinX);
+    mfGridElementHeightInv = static_cast<float>(FRAME_GRID_ROWS) / static_cast<float>(mnMaxY - mnMinY);
+    for (int i = 0; i < N; i++) {  // AssignFeaturesToGrid
+      int gx, gy;
+      if (posInGrid(kpsUn[i], gx, gy)) mGrid[gx][gy].push_back(i);
+    }
+  }
+  bool posInGrid(const OrcKeyPoint& kp, int& posX, int& posY) const {
+    posX = (int)roundf((kp.x - mnMinX) * mfGridElementWidthInv);
+    posY = (int)roundf((kp.y - mnMinY) * mfGridElementHeightInv);
+    if (posX < 0 || posX >= FRAME_GRID_COLS || posY < 0 || posY >= FRAME_GRID_ROWS) return false;
+    return true;
+  }
+  std::vector<size_t> getFeaturesInArea(const float& x, const float& y, const float& r, const int minLevel,
+                                        const int maxLevel) const {
+    std::vector<size_t> vIndices;
+    const int nMinCellX = std::max(0, (int)floorf((x - mnMinX - r) * mfGridElementWidthInv));
+    if (nMinCellX >= FRAME_GRID_COLS) return vIndices;
+    const int nMaxCellX = std::min((int)FRAME_GRID_COLS - 1, (int)ceilf((x - mnMinX + r) * mfGridElementWidthInv));
+    if (nMaxCellX < 0) return vIndices;
+    const int nMinCellY = std::max(0, (int)floorf((y - mnMinY - r) * mfGridElementHeightInv));
+    if (nMinCellY >= FRAME_GRID_ROWS) return vIndices;
+    const int nMaxCellY = std::min((int)FRAME_GRID_ROWS - 1, (int)ceilf((y - mnMinY + r) * mfGridElementHeightInv));
+    if (nMaxCellY < 0) return vIndices;
+    const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+    for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+      for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+        const std::vector<size_t>& vCell = mGrid[ix][iy];
+        for (size_t j = 0, jend = vCell.size(); j < jend; j++) {
+          const OrcKeyPoint& kpUn = kpsUn[vCell[j]];
+          if (bCheckLevels) {
+            if (kpUn.octave < minLevel) continue;
+            if (maxLevel >= 0)
+              if (kpUn.octave > maxLevel) continue;
+          }
+          const float distx = kpUn.x - x;
+          const float disty = kpUn.y - y;
+          if (fabsf(distx) < r && fabsf(disty) < r) vIndices.push_back(vCell[j]);
+        }
+      }
+    }
+    return vIndices;
+  }
+};
+
+const int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;  // ORBmatcher.cc:37-39
+
+// ComputeThreeMaxima -- ORBmatcher.cc:1554-1595
+void compute_three_maxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3) {
+  int max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < L; i++) {
+    const int s = (int)histo[i].size();
+    if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+    else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+    else if (s > max3) { max3 = s; ind3 = i; }
+  }
+  if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+  else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+int rot_bin(float a1, float a2) {  // ORBmatcher.cc:470-475
+  const float factor = 1.0f / HISTO_LENGTH;
+  float rot = a1 - a2;
+  if (rot < 0.0) rot += 360.0f;
+  int bin = (int)roundf(rot * factor);
+  if (bin == HISTO_LENGTH) bin = 0;
+  return bin;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI used by the tests / bench (ctypes).
+// =============================================================================================
+extern "C" {
+
+int orc_cv_round_f(float v) { return cv_round(v); }
+float orc_fast_atan2(float y, float x) { return fast_atan2(y, x); }
+void orc_sincos_host(float angle_deg, float* a, float* b) {
+  float ang = angle_deg * factorPI;
+  *a = cosf(ang);
+  *b = sinf(ang);
+}
+void orc_gauss_kernel(int n, double sigma, int* out) { gauss_kernel_fixed_ed(n, sigma, out); }
+
+void orc_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh,
+                          int dstride) {
+  resize_linear_u8(View{src, sw, sh, sstride}, dst, dw, dh, dstride);
+}
+void orc_gauss7_u8(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride) {
+  gauss7_u8(View{src, w, h, sstride}, dst, dstride);
+}
+// cv::FAST on a ROI.  out_xys: triples (x, y, score).  Returns count (<= cap written).
+int orc_fast9(const uint8_t* img, int w, int h, int stride, int threshold, int nms, int* out_xys, int cap) {
+  std::vector<RoiKp> k;
+  fast9_roi(View{img, w, h, stride}, threshold, nms != 0, k);
+  for (int i = 0; i < (int)k.size() && i < cap; i++) {
+    out_xys[3 * i] = k[i].x; out_xys[3 * i + 1] = k[i].y; out_xys[3 * i + 2] = k[i].score;
+  }
+  return (int)k.size();
+}
+// brute-force definition of the score: largest t for which the pixel is still a corner (-1: never)
+int orc_fast_score_bruteforce(const uint8_t* img, int stride, int x, int y) {
+  int d[16];
+  const int v = img[(ptrdiff_t)y * stride + x];
+  for (int k = 0; k < 16; k++) d[k] = v - img[(ptrdiff_t)(y + kRingDy[k]) * stride + x + kRingDx[k]];
+  int best = -1;
+  for (int t = 0; t < 256; t++)
+    if (fast_is_corner(d, t)) best = t;
+  return best;
+}
+
+int orc_distribute_octtree(const OrcKeyPoint* in, int n, int minX, int maxX, int minY, int maxY, int N,
+                           OrcKeyPoint* out, int cap) {
+  std::vector<OrcKeyPoint> v(in, in + n);
+  std::vector<OrcKeyPoint> r = distribute_octtree(v, minX, maxX, minY, maxY, N);
+  for (int i = 0; i < (int)r.size() && i < cap; i++) out[i] = r[i];
+  return (int)r.size();
+}
+
+void* orc_extractor_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST) {
+  return new Extractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST);
+}
+void orc_extractor_destroy(void* h) { delete (Extractor*)h; }
+void orc_extractor_tables(void* h, float* sf, float* isf, float* s2, float* is2, int* nfeat, int* umax16) {
+  Extractor* e = (Extractor*)h;
+  for (int i = 0; i < e->nlevels; i++) {
+    if (sf) sf[i] = e->mvScaleFactor[i];
+    if (isf) isf[i] = e->mvInvScaleFactor[i];
+    if (s2) s2[i] = e->mvLevelSigma2[i];
+    if (is2) is2[i] = e->mvInvLevelSigma2[i];
+    if (nfeat) nfeat[i] = e->mnFeaturesPerLevel[i];
+  }
+  if (umax16) for (int i = 0; i < 16; i++) umax16[i] = e->umax[i];
+}
+// Returns number of keypoints (writes at most cap).
+int orc_extract(void* h, const uint8_t* gray, int rows, int cols, int stride, OrcKeyPoint* kps, uint8_t* desc,
+                int cap) {
+  Extractor* e = (Extractor*)h;
+  std::vector<OrcKeyPoint> k;
+  std::vector<uint8_t> d;
+  e->extract(View{gray, cols, rows, stride}, k, d);
+  int n = (int)k.size();
+  int m = std::min(n, cap);
+  if (m > 0) {
+    memcpy(kps, k.data(), (size_t)m * sizeof(OrcKeyPoint));
+    memcpy(desc, d.data(), (size_t)m * 32);
+  }
+  return n;
+}
+// Stage accessors (valid after orc_extract).
+void orc_level_size(void* h, int level, int* w, int* hgt) {
+  Extractor* e = (Extractor*)h;
+  *w = e->pyramid[level].w; *hgt = e->pyramid[level].h;
+}
+void orc_level_copy(void* h, int level, int blurred, uint8_t* out) {
+  Extractor* e = (Extractor*)h;
+  const Image& im = blurred ? e->lastBlurred[level] : e->pyramid[level];
+  if (!im.d.empty()) memcpy(out, im.d.data(), im.d.size());
+}
+int orc_level_candidates(void* h, int level, OrcKeyPoint* out, int cap) {
+  Extractor* e = (Extractor*)h;
+  const auto& c = e->lastCandidates[level];
+  for (int i = 0; i < (int)c.size() && i < cap; i++) out[i] = c[i];
+  return (int)c.size();
+}
+
+int orc_hamming(const uint8_t* a, const uint8_t* b) { return descriptor_distance(a, b); }
+
+int orc_get_features_in_area(const OrcKeyPoint* kpsUn, int n, const float bounds[4], float x, float y, float r,
+                             int minLevel, int maxLevel, int* out, int cap) {
+  FrameGrid g(kpsUn, n, bounds);
+  std::vector<size_t> v = g.getFeaturesInArea(x, y, r, minLevel, maxLevel);
+  for (int i = 0; i < (int)v.size() && i < cap; i++) out[i] = (int)v[i];
+  return (int)v.size();
+}
+
+// ORBmatcher::SearchForInitialization -- ORBmatcher.cc:400-515.  prev_xy: in/out (vbPrevMatched).
+int orc_search_for_initialization(const OrcKeyPoint* kps1, const uint8_t* desc1, int n1, const OrcKeyPoint* kps2,
+                                  const uint8_t* desc2, int n2, const float bounds[4], float* prev_xy,
+                                  int* vnMatches12, int windowSize, float mfNNratio, int mbCheckOrientation) {
+  FrameGrid F2(kps2, n2, bounds);
+  int nmatches = 0;
+  for (int i = 0; i < n1; i++) vnMatches12[i] = -1;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  std::vector<int> vMatchedDistance(n2, INT_MAX);
+  std::vector<int> vnMatches21(n2, -1);
+  for (size_t i1 = 0, iend1 = n1; i1 < iend1; i1++) {
+    const OrcKeyPoint& kp1 = kps1[i1];
+    int level1 = kp1.octave;
+    if (level1 > 0) continue;
+    std::vector<size_t> vIndices2 =
+        F2.getFeaturesInArea(prev_xy[2 * i1], prev_xy[2 * i1 + 1], windowSize, level1, level1);
+    if (vIndices2.empty()) continue;
+    const uint8_t* d1 = desc1 + 32 * i1;
+    int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+    for (size_t i2 : vIndices2) {
+      int dist = descriptor_distance(d1, desc2 + 32 * i2);
+      if (vMatchedDistance[i2] <= dist) continue;
+      if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = (int)i2; }
+      else if (dist < bestDist2) { bestDist2 = dist; }
+    }
+    if (bestDist <= TH_LOW) {
+      if (bestDist < (float)bestDist2 * mfNNratio) {
+        if (vnMatches21[bestIdx2] >= 0) { vnMatches12[vnMatches21[bestIdx2]] = -1; nmatches--; }
+        vnMatches12[i1] = bestIdx2;
+        vnMatches21[bestIdx2] = (int)i1;
+        vMatchedDistance[bestIdx2] = bestDist;
+        nmatches++;
+        if (mbCheckOrientation) rotHist[rot_bin(kps1[i1].angle, kps2[bestIdx2].angle)].push_back((int)i1);
+      }
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    compute_three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+        int idx1 = rotHist[i][j];
+        if (vnMatches12[idx1] >= 0) { vnMatches12[idx1] = -1; nmatches--; }
+      }
+    }
+  }
+  for (size_t i1 = 0, iend1 = n1; i1 < iend1; i1++)
+    if (vnMatches12[i1] >= 0) {
+      prev_xy[2 * i1] = kps2[vnMatches12[i1]].x;
+      prev_xy[2 * i1 + 1] = kps2[vnMatches12[i1]].y;
+    }
+  return nmatches;
+}
+
+// ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) -- ORBmatcher.cc:45-132.
+// MapPoint fields are passed as flat arrays (the reference reads them through pMP->...):
+//   mp_flags bit0 = mbTrackInView, bit1 = isBad(), bit2 = plCandidato, bit3 = Observations()>0.
+// kp_occupied[idx] in: 1 iff F.mvpMapPoints[idx] != NULL && ->Observations()>0 at call time.
+// kp_assigned[idx] out: index of the MapPoint written to F.mvpMapPoints[idx] (last writer), -1 if untouched.
+int orc_search_by_projection(const OrcKeyPoint* kpsUn, const uint8_t* desc, int n, const float bounds[4],
+                             const float* mvScaleFactors, const uint8_t* kp_occupied, const float* mp_proj_xy,
+                             const int* mp_level, const float* mp_viewcos, const uint8_t* mp_flags,
+                             const uint8_t* mp_desc, int n_mp, float th, float mfNNratio, int* kp_assigned) {
+  FrameGrid F(kpsUn, n, bounds);
+  std::vector<uint8_t> occ(kp_occupied, kp_occupied + n);
+  for (int i = 0; i < n; i++) kp_assigned[i] = -1;
+  int nmatches = 0;
+  const bool bFactor = th != 1.0;
+  for (int iMP = 0; iMP < n_mp; iMP++) {
+    const uint8_t fl = mp_flags[iMP];
+    if (!(fl & 1)) continue;
+    if (fl & 2) continue;
+    const int nPredictedLevel = mp_level[iMP];
+    float r = (fl & 4) ? 4.0 : (mp_viewcos[iMP] > 0.998 ? 2.5 : 4.0);
+    if (bFactor) r *= th;
+    const std::vector<size_t> vIndices =
+        F.getFeaturesInArea(mp_proj_xy[2 * iMP], mp_proj_xy[2 * iMP + 1], r * mvScaleFactors[nPredictedLevel],
+                            nPredictedLevel - 1, nPredictedLevel);
+    if (vIndices.empty()) continue;
+    const uint8_t* MPdescriptor = mp_desc + 32 * (size_t)iMP;
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (size_t idx : vIndices) {
+      if (occ[idx]) continue;
+      const int dist = descriptor_distance(MPdescriptor, desc + 32 * idx);
+      if (dist < bestDist) {
+        bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel;
+        bestLevel = kpsUn[idx].octave; bestIdx = (int)idx;
+      } else if (dist < bestDist2) {
+        bestLevel2 = kpsUn[idx].octave; bestDist2 = dist;
+      }
+    }
+    if (bestDist <= TH_HIGH) {
+      if (bestLevel == bestLevel2 && bestDist > mfNNratio * bestDist2) continue;
+      kp_assigned[bestIdx] = iMP;
+      occ[bestIdx] = (fl & 8) ? 1 : 0;
+      nmatches++;
+    }
+  }
+  return nmatches;
+}
+
+// ORBmatcher::SearchByProjection(Frame&, const Frame&, th) -- ORBmatcher.cc:1292-1423 and
+// (Frame&, KeyFrame*, set, th, ORBdist) -- :1425-1552, from the projection onwards: the caller has
+// already projected each source point to (u,v) (float cv::Mat arithmetic, :1326-1336 / :1451-1459),
+// applied the reference's rejections, and passes src_valid=0 for rejected / absent points.
+//   src_level: nLastOctave (:1345) resp. nPredictedLevel (:1477); window levels [l-1, l+1].
+//   max_dist: TH_HIGH (:1381) resp. ORBdist (:1506).
+//   skip_any_occupied: 0 => skip kps whose MapPoint has Observations()>0 (:1364-1366);
+//                      1 => skip kps with any MapPoint (:1493-1494).
+//   src_flags bit3: Observations()>0 of the source MapPoint (needed for occupancy replay, mode 0).
+// kp_assigned out as above; pruned slots (rotation check) are reported as -2 ("set to NULL").
+int orc_search_by_projection_uv(const OrcKeyPoint* kpsUn, const uint8_t* desc, int n, const float bounds[4],
+                                const float* mvScaleFactors, const uint8_t* kp_occupied, const float* src_uv,
+                                const int* src_level, const float* src_angle, const uint8_t* src_flags,
+                                const uint8_t* src_valid, const uint8_t* src_desc, int n_src, float th,
+                                int max_dist, int skip_any_occupied, int mbCheckOrientation, int* kp_assigned) {
+  FrameGrid F(kpsUn, n, bounds);
+  std::vector<uint8_t> occ(kp_occupied, kp_occupied + n);
+  for (int i = 0; i < n; i++) kp_assigned[i] = -1;
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  for (int i = 0; i < n_src; i++) {
+    if (!src_valid[i]) continue;
+    const int lvl = src_level[i];
+    const float radius = th * mvScaleFactors[lvl];
+    std::vector<size_t> vIndices2 = F.getFeaturesInArea(src_uv[2 * i], src_uv[2 * i + 1], radius, lvl - 1, lvl + 1);
+    if (vIndices2.empty()) continue;
+    const uint8_t* dMP = src_desc + 32 * (size_t)i;
+    int bestDist = 256, bestIdx2 = -1;
+    for (size_t i2 : vIndices2) {
+      if (occ[i2]) continue;
+      const int dist = descriptor_distance(dMP, desc + 32 * i2);
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = (int)i2; }
+    }
+    if (bestDist <= max_dist) {
+      kp_assigned[bestIdx2] = i;
+      occ[bestIdx2] = skip_any_occupied ? 1 : ((src_flags[i] & 8) ? 1 : 0);
+      nmatches++;
+      if (mbCheckOrientation) rotHist[rot_bin(src_angle[i], kpsUn[bestIdx2].angle)].push_back(bestIdx2);
+    }
+  }
+  if (mbCheckOrientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    compute_three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i != ind1 && i != ind2 && i != ind3) {
+        for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) {
+          kp_assigned[rotHist[i][j]] = -2;
+          nmatches--;
+        }
+      }
+    }
+  }
+  return nmatches;
+}
+
+// Frame::antidistorsionarProyeccionEquidistante -- Frame.cc:355-384 (os1's equidistant fisheye, modo 1).
+// K = [fx 0 cx; 0 fy cy; 0 0 1] as floats; points in/out as float pairs.
+void orc_undistort_equidistant(float* xy, int n, float fx, float fy, float cx, float cy) {
+  const double f0 = fx, f1 = fy, c0 = cx, c1 = cy;
+  for (int i = 0; i < n; i++) {
+    double pi0 = xy[2 * i], pi1 = xy[2 * i + 1];
+    double pw0 = (pi0 - c0) / f0, pw1 = (pi1 - c1) / f1;
+    double theta_d = sqrt(pw0 * pw0 + pw1 * pw1);
+    double scale = theta_d > 1e-8 ? std::tan(theta_d) / theta_d : 1.0;
+    double pu0 = pw0 * scale, pu1 = pw1 * scale;
+    // pr = K(float 3x3) * Vec3d(pu, 1): Matx33f * Vec3d promotes to double
+    double pr0 = (double)fx * pu0 + 0.0 * pu1 + (double)cx * 1.0;
+    double pr1 = 0.0 * pu0 + (double)fy * pu1 + (double)cy * 1.0;
+    double pr2 = 0.0 * pu0 + 0.0 * pu1 + 1.0 * 1.0;
+    xy[2 * i] = (float)(pr0 / pr2);
+    xy[2 * i + 1] = (float)(pr1 / pr2);
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,215 @@
+"""ctypes binding of the CPU oracle (oracle/liborb_oracle.so).  TEST INFRASTRUCTURE ONLY:
+importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never from os1_amd/."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, 'liborb_oracle.so')
+
+KP_DTYPE = np.dtype([('x', 'f4'), ('y', 'f4'), ('size', 'f4'), ('angle', 'f4'), ('response', 'f4'),
+                     ('octave', 'i4'), ('class_id', 'i4')])
+assert KP_DTYPE.itemsize == 28
+
+
+def build():
+    subprocess.check_call(['make', '-s', '-C', _HERE])
+
+
+def _p(a, t=C.c_void_p):
+    return a.ctypes.data_as(t)
+
+
+class Oracle:
+    def __init__(self):
+        if not os.path.exists(_SO):
+            build()
+        L = self.L = C.CDLL(_SO)
+        L.orc_fast_atan2.restype = C.c_float
+        L.orc_fast_atan2.argtypes = [C.c_float, C.c_float]
+        L.orc_cv_round_f.argtypes = [C.c_float]
+        L.orc_sincos_host.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.orc_extractor_create.restype = C.c_void_p
+        L.orc_extractor_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        L.orc_extractor_destroy.argtypes = [C.c_void_p]
+        L.orc_extractor_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        L.orc_extract.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_level_size.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_level_copy.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.orc_level_candidates.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.orc_gauss_kernel.argtypes = [C.c_int, C.c_double, C.c_void_p]
+        L.orc_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orc_gauss7_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_fast9.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_fast_score_bruteforce.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.orc_distribute_octtree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_void_p, C.c_int]
+        L.orc_hamming.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_get_features_in_area.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float,
+                                               C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_search_for_initialization.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_int]
+        L.orc_search_by_projection.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                               C.c_float, C.c_float, C.c_void_p]
+        L.orc_search_by_projection_uv.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
+                                                  C.c_void_p]
+        L.orc_undistort_equidistant.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
+
+    # ---- primitives -------------------------------------------------------------------------
+    def fast_atan2(self, y, x):
+        return float(self.L.orc_fast_atan2(y, x))
+
+    def sincos(self, angle_deg):
+        a, b = C.c_float(), C.c_float()
+        self.L.orc_sincos_host(angle_deg, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def gauss_kernel(self, n=7, sigma=2.0):
+        k = np.zeros(n, np.int32)
+        self.L.orc_gauss_kernel(n, sigma, _p(k))
+        return k
+
+    def resize(self, src, dw, dh):
+        src = np.ascontiguousarray(src, np.uint8)
+        dst = np.zeros((dh, dw), np.uint8)
+        self.L.orc_resize_linear_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dw, dh, dw)
+        return dst
+
+    def gauss7(self, src):
+        src = np.ascontiguousarray(src, np.uint8)
+        dst = np.zeros_like(src)
+        self.L.orc_gauss7_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dst.strides[0])
+        return dst
+
+    def fast9(self, img, threshold, nms=True):
+        img = np.ascontiguousarray(img, np.uint8)
+        cap = img.size
+        out = np.zeros((max(cap, 1), 3), np.int32)
+        n = self.L.orc_fast9(_p(img), img.shape[1], img.shape[0], img.strides[0], threshold, int(nms), _p(out), cap)
+        return out[:n].copy()
+
+    def fast_score_bruteforce(self, img, x, y):
+        img = np.ascontiguousarray(img, np.uint8)
+        return self.L.orc_fast_score_bruteforce(_p(img), img.strides[0], x, y)
+
+    def distribute_octtree(self, kps, minX, maxX, minY, maxY, N):
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        out = np.zeros(max(len(kps), 1), KP_DTYPE)
+        n = self.L.orc_distribute_octtree(_p(kps), len(kps), minX, maxX, minY, maxY, N, _p(out), len(out))
+        return out[:n].copy()
+
+    def hamming(self, a, b):
+        a = np.ascontiguousarray(a, np.uint8)
+        b = np.ascontiguousarray(b, np.uint8)
+        return self.L.orc_hamming(_p(a), _p(b))
+
+    def get_features_in_area(self, kps, bounds, x, y, r, minLevel, maxLevel):
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        b = np.asarray(bounds, np.float32)
+        out = np.zeros(max(len(kps), 1), np.int32)
+        n = self.L.orc_get_features_in_area(_p(kps), len(kps), _p(b), x, y, r, minLevel, maxLevel, _p(out), len(out))
+        return out[:n].copy()
+
+    def search_for_initialization(self, kps1, desc1, kps2, desc2, bounds, prev_xy, window=100, nnratio=0.9,
+                                  check_ori=True):
+        kps1 = np.ascontiguousarray(kps1, KP_DTYPE)
+        kps2 = np.ascontiguousarray(kps2, KP_DTYPE)
+        desc1 = np.ascontiguousarray(desc1, np.uint8)
+        desc2 = np.ascontiguousarray(desc2, np.uint8)
+        b = np.asarray(bounds, np.float32)
+        prev = np.ascontiguousarray(prev_xy, np.float32).copy()
+        m12 = np.full(max(len(kps1), 1), -1, np.int32)
+        n = self.L.orc_search_for_initialization(_p(kps1), _p(desc1), len(kps1), _p(kps2), _p(desc2), len(kps2),
+                                                 _p(b), _p(prev), _p(m12), window, nnratio, int(check_ori))
+        return n, m12[:len(kps1)], prev
+
+    def search_by_projection(self, kps, desc, bounds, scale_factors, kp_occupied, mp_xy, mp_level, mp_viewcos,
+                             mp_flags, mp_desc, th, nnratio):
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        b = np.asarray(bounds, np.float32)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        occ = np.ascontiguousarray(kp_occupied, np.uint8)
+        mp_xy = np.ascontiguousarray(mp_xy, np.float32)
+        mp_level = np.ascontiguousarray(mp_level, np.int32)
+        mp_viewcos = np.ascontiguousarray(mp_viewcos, np.float32)
+        mp_flags = np.ascontiguousarray(mp_flags, np.uint8)
+        mp_desc = np.ascontiguousarray(mp_desc, np.uint8)
+        assigned = np.full(max(len(kps), 1), -1, np.int32)
+        n = self.L.orc_search_by_projection(_p(kps), _p(desc), len(kps), _p(b), _p(sf), _p(occ), _p(mp_xy),
+                                            _p(mp_level), _p(mp_viewcos), _p(mp_flags), _p(mp_desc), len(mp_level),
+                                            th, nnratio, _p(assigned))
+        return n, assigned[:len(kps)]
+
+    def search_by_projection_uv(self, kps, desc, bounds, scale_factors, kp_occupied, src_uv, src_level, src_angle,
+                                src_flags, src_valid, src_desc, th, max_dist, skip_any_occupied, check_ori):
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        b = np.asarray(bounds, np.float32)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        occ = np.ascontiguousarray(kp_occupied, np.uint8)
+        src_uv = np.ascontiguousarray(src_uv, np.float32)
+        src_level = np.ascontiguousarray(src_level, np.int32)
+        src_angle = np.ascontiguousarray(src_angle, np.float32)
+        src_flags = np.ascontiguousarray(src_flags, np.uint8)
+        src_valid = np.ascontiguousarray(src_valid, np.uint8)
+        src_desc = np.ascontiguousarray(src_desc, np.uint8)
+        assigned = np.full(max(len(kps), 1), -1, np.int32)
+        n = self.L.orc_search_by_projection_uv(_p(kps), _p(desc), len(kps), _p(b), _p(sf), _p(occ), _p(src_uv),
+                                               _p(src_level), _p(src_angle), _p(src_flags), _p(src_valid),
+                                               _p(src_desc), len(src_level), th, max_dist, int(skip_any_occupied),
+                                               int(check_ori), _p(assigned))
+        return n, assigned[:len(kps)]
+
+    def undistort_equidistant(self, xy, fx, fy, cx, cy):
+        xy = np.ascontiguousarray(xy, np.float32).copy()
+        self.L.orc_undistort_equidistant(_p(xy), len(xy), fx, fy, cx, cy)
+        return xy
+
+
+class OracleExtractor:
+    def __init__(self, nfeatures=1000, scale=1.2, nlevels=8, ini_th=20, min_th=7, oracle=None):
+        self.o = oracle or Oracle()
+        self.nlevels = nlevels
+        self.nfeatures = nfeatures
+        self.h = self.o.L.orc_extractor_create(nfeatures, scale, nlevels, ini_th, min_th)
+
+    def __del__(self):
+        try:
+            self.o.L.orc_extractor_destroy(self.h)
+        except Exception:
+            pass
+
+    def tables(self):
+        n = self.nlevels
+        sf, isf, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        nf = np.zeros(n, np.int32)
+        um = np.zeros(16, np.int32)
+        self.o.L.orc_extractor_tables(self.h, _p(sf), _p(isf), _p(s2), _p(is2), _p(nf), _p(um))
+        return dict(sf=sf, isf=isf, s2=s2, is2=is2, nfeat=nf, umax=um)
+
+    def extract(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        cap = self.nfeatures + 8 * self.nlevels + 64
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = self.o.L.orc_extract(self.h, _p(img), img.shape[0], img.shape[1], img.strides[0], _p(kps), _p(desc), cap)
+        assert n <= cap
+        return kps[:n].copy(), desc[:n].copy()
+
+    def level(self, level, blurred=False):
+        w, h = C.c_int(), C.c_int()
+        self.o.L.orc_level_size(self.h, level, C.byref(w), C.byref(h))
+        out = np.zeros((h.value, w.value), np.uint8)
+        self.o.L.orc_level_copy(self.h, level, int(blurred), _p(out))
+        return out
+
+    def candidates(self, level):
+        n = self.o.L.orc_level_candidates(self.h, level, None, 0)
+        out = np.zeros(max(n, 1), KP_DTYPE)
+        self.o.L.orc_level_candidates(self.h, level, _p(out), n)
+        return out[:n].copy()
