@@ -1,0 +1,196 @@
+/* orbfe.h -- C ABI of the MI355X-native ORB feature front end (liborbfe.so).
+ *
+ * Drop-in boundary for the per-frame hot path of AlejandroSilvestri/os1 (ORB-SLAM2 fork):
+ * ORBextractor::operator() and the windowed Hamming searches of ORBmatcher.  Each entry point
+ * names the reference interface it replaces (paths relative to the reference root).  The C++
+ * facade in include/orbfe/ORBextractor.h / ORBmatcher.h reproduces the ORB_SLAM2:: signatures
+ * on top of this ABI; INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C, POD structs, caller-allocated outputs, no exceptions;
+ *   - every function returns ORBFE_OK (0) or a negative error code; orbfe_last_error() returns a
+ *     thread-local human-readable message for the last failure on the calling thread;
+ *   - a handle is single-threaded (like the reference's ORBextractor instance, which mutates
+ *     mvImagePyramid and is only ever called from the Tracking thread); use one handle per
+ *     GPU / host thread;
+ *   - there is NO CPU fallback: if no gfx950 device is usable, create() fails with
+ *     ORBFE_ERR_NO_DEVICE.
+ */
+#ifndef ORBFE_H_
+#define ORBFE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORBFE_OK 0
+#define ORBFE_ERR_INVALID (-1)   /* bad argument (null pointer, non-positive size, cap too small) */
+#define ORBFE_ERR_NO_DEVICE (-2) /* no usable HIP device / wrong architecture                      */
+#define ORBFE_ERR_HIP (-3)       /* a HIP runtime call failed; see orbfe_last_error()              */
+#define ORBFE_ERR_TOO_SMALL (-4) /* image too small: some pyramid level has <1 FAST cell column/row
+                                    (the reference divides by zero there, ORBextractor.cc:820-823) */
+#define ORBFE_ERR_OVERFLOW (-5)  /* an output capacity was exceeded (outputs truncated)            */
+
+/* Same 28-byte layout as cv::KeyPoint: pt.x, pt.y, size, angle, response, octave, class_id. */
+typedef struct OrbfeKeyPoint {
+  float x, y;      /* pt, in level-0 pixel units (level coords * scale, ORBextractor.cc:959-965) */
+  float size;      /* (float)(int)(31 * scale[octave])                    (ORBextractor.cc:879,888) */
+  float angle;     /* IC-angle in degrees [0,360)                         (ORBextractor.cc:86-113)  */
+  float response;  /* FAST score                                                                    */
+  int32_t octave;  /* pyramid level                                                                 */
+  int32_t class_id; /* always -1                                                                    */
+} OrbfeKeyPoint;
+
+typedef struct orbfe_extractor orbfe_extractor;
+typedef struct orbfe_matcher orbfe_matcher;
+
+const char* orbfe_last_error(void);
+/* Number of visible HIP devices (0 if none / runtime unusable). Does not create a context. */
+int orbfe_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Extractor.  Replaces ORB_SLAM2::ORBextractor (include/ORBextractor.h:155-373).
+ * ------------------------------------------------------------------------------------------- */
+
+/* ORBextractor::ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST,
+ * int minThFAST)  (include/ORBextractor.h:164-165, src/ORBextractor.cc:442-502).
+ * device_id: HIP device ordinal the handle is bound to. */
+int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST,
+                           int device_id, orbfe_extractor** out);
+void orbfe_extractor_destroy(orbfe_extractor* h);
+
+/* GetLevels / GetScaleFactor (include/ORBextractor.h:194-207). */
+int orbfe_extractor_levels(const orbfe_extractor* h);
+float orbfe_extractor_scale_factor(const orbfe_extractor* h);
+/* GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares / GetInverseScaleSigmaSquares
+ * (include/ORBextractor.h:213-239).  Each output has nlevels floats; any may be NULL. */
+int orbfe_extractor_scale_tables(const orbfe_extractor* h, float* scale, float* inv_scale, float* sigma2,
+                                 float* inv_sigma2);
+/* mnFeaturesPerLevel (src/ORBextractor.cc:467-478); nlevels ints. */
+int orbfe_extractor_features_per_level(const orbfe_extractor* h, int32_t* out);
+/* Upper bound on keypoints one frame can return: nfeatures + 2*nlevels (each level may overshoot
+ * its quota by <= 2). Size `cap` with it. */
+int orbfe_extractor_max_keypoints(const orbfe_extractor* h);
+
+/* void ORBextractor::operator()(InputArray image, InputArray mask, vector<KeyPoint>& keypoints,
+ *                               OutputArray descriptors)
+ * (include/ORBextractor.h:185-187, src/ORBextractor.cc:907-969).
+ *   gray/rows/cols/stride_bytes : CV_8UC1 image in HOST memory (mask is ignored by the reference);
+ *   kps  [cap]                  : keypoints, level-major, quadtree list order inside a level;
+ *   desc [cap*32]               : descriptors, row i belongs to kps[i] (CV_8U, 32-byte rows);
+ *   *n_out                      : number of keypoints produced.
+ * rows==0 || cols==0 || gray==NULL: returns ORBFE_OK with *n_out = 0 and outputs untouched
+ * (the reference returns silently, ORBextractor.cc:910-911). */
+int orbfe_extract(orbfe_extractor* h, const uint8_t* gray, int rows, int cols, size_t stride_bytes,
+                  OrbfeKeyPoint* kps, uint8_t* desc, int cap, int* n_out);
+
+/* Batched form of the same call for independent frames of one size (throughput path: one
+ * kernel launch sequence for all frames).  gray[i] points to frame i; in_device_memory != 0
+ * means the frame pointers are DEVICE pointers on the handle's GPU (frames already resident in
+ * HBM).  kps: nframes*cap entries, desc: nframes*cap*32 bytes, n_out: nframes ints. */
+int orbfe_extract_batch(orbfe_extractor* h, int nframes, const uint8_t* const* gray, int in_device_memory,
+                        int rows, int cols, size_t stride_bytes, OrbfeKeyPoint* kps, uint8_t* desc, int cap,
+                        int* n_out);
+
+/* Stage accessors for the parity tests (state of the LAST extract call, frame index in batch). */
+int orbfe_debug_level_size(const orbfe_extractor* h, int level, int* w, int* hgt);
+int orbfe_debug_level_copy(orbfe_extractor* h, int frame, int level, uint8_t* out /* w*h, tight */);
+/* FAST candidates of one level BEFORE the quadtree, reference order (cell-row-major, row-major in
+ * a cell): triples (x, y, score) with x,y relative to (minBorderX,minBorderY) = (16,16) as in
+ * vToDistributeKeys (ORBextractor.cc:861-866). */
+int orbfe_debug_candidates(orbfe_extractor* h, int frame, int level, int32_t* xys, int cap, int* n_out);
+/* Per-stage wall/GPU milliseconds of the last call: [0]=upload+pyramid+FAST+compaction (GPU),
+ * [1]=D2H candidates, [2]=host quadtree, [3]=orientation+blur+rBRIEF (GPU) incl. H2D/D2H, [4]=total. */
+int orbfe_debug_stage_ms(const orbfe_extractor* h, float out[5]);
+/* Device-side restatement of (cosf, sinf)(angle_deg * pi/180) used by the rBRIEF kernel, evaluated
+ * on the GPU for n angles (parity test against host libm). */
+int orbfe_debug_sincos(orbfe_extractor* h, const float* angle_deg, int n, float* cos_out, float* sin_out);
+
+/* Host-only test hooks (no GPU needed): the product's own quadtree (DistributeOctTree,
+ * src/ORBextractor.cc:571-795) on candidate triples (x, y relative to (minX,minY); score), returning
+ * the indices of the retained candidates in list order; and the (cosf,sinf) restatement compiled
+ * for the host, compared against libm over the float bit patterns [lo_bits, hi_bits] step `step`
+ * (returns the number of mismatching values in *mismatches). */
+int orbfe_debug_quadtree(const int16_t* x, const int16_t* y, const uint8_t* score, int n, int min_x, int max_x,
+                         int min_y, int max_y, int n_target, int32_t* out_idx, int cap, int* n_out);
+int orbfe_debug_sincos_host_check(uint32_t lo_bits, uint32_t hi_bits, uint32_t step, long long* mismatches);
+
+/* ---------------------------------------------------------------------------------------------
+ * Matcher.  Replaces the hot subset of ORB_SLAM2::ORBmatcher (include/ORBmatcher.h:71-270).
+ * ------------------------------------------------------------------------------------------- */
+
+/* static int ORBmatcher::DescriptorDistance(const cv::Mat&, const cv::Mat&)
+ * (include/ORBmatcher.h:74, src/ORBmatcher.cc:1605-1621): Hamming distance of two 256-bit rows.
+ * Scalar host helper (callers such as MapPoint.cc:266 use it on single pairs). */
+int orbfe_hamming(const uint8_t a[32], const uint8_t b[32]);
+
+int orbfe_matcher_create(int device_id, orbfe_matcher** out);
+void orbfe_matcher_destroy(orbfe_matcher* m);
+
+/* int ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, vector<cv::Point2f>& vbPrevMatched,
+ *                                         vector<int>& vnMatches12, int windowSize)
+ * (include/ORBmatcher.h:193, src/ORBmatcher.cc:400-515) with ORBmatcher(nnratio, checkOri).
+ *   kps1/desc1/n1   : F1.mvKeysUn, F1.mDescriptors
+ *   kps2/desc2/n2   : F2.mvKeysUn, F2.mDescriptors
+ *   bounds          : {Frame::mnMinX, mnMaxX, mnMinY, mnMaxY} (static image bounds, Frame.cc:322-353)
+ *   prev_xy [2*n1]  : vbPrevMatched, in/out
+ *   matches12 [n1]  : vnMatches12, out (-1 = none)
+ *   *nmatches       : return value of the reference function */
+int orbfe_search_for_initialization(orbfe_matcher* m, const OrbfeKeyPoint* kps1, const uint8_t* desc1, int n1,
+                                    const OrbfeKeyPoint* kps2, const uint8_t* desc2, int n2,
+                                    const float bounds[4], float* prev_xy, int32_t* matches12, int window_size,
+                                    float nnratio, int check_orientation, int* nmatches);
+
+/* MapPoint flag bits for the searches below. */
+#define ORBFE_MP_IN_VIEW 1u    /* MapPoint::mbTrackInView                                   */
+#define ORBFE_MP_BAD 2u        /* MapPoint::isBad()                                         */
+#define ORBFE_MP_CANDIDATO 4u  /* MapPoint::plCandidato (os1 far-point extension)           */
+#define ORBFE_MP_OBSERVED 8u   /* MapPoint::Observations() > 0                              */
+
+/* int ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, const float th)
+ * (include/ORBmatcher.h:93, src/ORBmatcher.cc:45-132) with ORBmatcher(nnratio).
+ * The facade snapshots the MapPoint fields (under the reference's accessors) into flat arrays:
+ *   mp_proj_xy [2*n_mp] : mTrackProjX, mTrackProjY       mp_level [n_mp] : mnTrackScaleLevel
+ *   mp_viewcos [n_mp]   : mTrackViewCos                  mp_flags [n_mp] : ORBFE_MP_* bits
+ *   mp_desc [32*n_mp]   : GetDescriptor()
+ *   kp_occupied [n]     : 1 iff F.mvpMapPoints[i] != NULL && ->Observations() > 0 at call time
+ *   kp_assigned [n] out : index into vpMapPoints written to F.mvpMapPoints[i] (last writer), -1 = untouched
+ *   scale_factors       : F.mvScaleFactors (nlevels floats) */
+int orbfe_search_by_projection(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, const uint8_t* desc, int n,
+                               const float bounds[4], const float* scale_factors, int nlevels,
+                               const uint8_t* kp_occupied, const float* mp_proj_xy, const int32_t* mp_level,
+                               const float* mp_viewcos, const uint8_t* mp_flags, const uint8_t* mp_desc, int n_mp,
+                               float th, float nnratio, int32_t* kp_assigned, int* nmatches);
+
+/* int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th)
+ * (include/ORBmatcher.h:118, src/ORBmatcher.cc:1292-1423) and
+ * int ORBmatcher::SearchByProjection(Frame&, KeyFrame*, const set<MapPoint*>&, const float th, const int ORBdist)
+ * (include/ORBmatcher.h:133, src/ORBmatcher.cc:1425-1552), from the projection onwards: the facade
+ * projects each source MapPoint exactly as the reference does (float cv::Mat arithmetic,
+ * ORBmatcher.cc:1326-1343 / 1451-1477) and passes
+ *   src_uv [2*n_src], src_level (nLastOctave resp. nPredictedLevel), src_angle (source keypoint angle),
+ *   src_flags (ORBFE_MP_OBSERVED), src_valid (0 = absent / outlier / rejected), src_desc;
+ *   max_dist = TH_HIGH (100) resp. ORBdist; skip_any_occupied = 0 (skip kps whose MapPoint has
+ *   observations, :1364-1366) resp. 1 (skip kps with any MapPoint, :1493-1494).
+ * kp_assigned out: source index per keypoint, -1 untouched, -2 = reset to NULL by the rotation check. */
+int orbfe_search_by_projection_uv(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, const uint8_t* desc, int n,
+                                  const float bounds[4], const float* scale_factors, int nlevels,
+                                  const uint8_t* kp_occupied, const float* src_uv, const int32_t* src_level,
+                                  const float* src_angle, const uint8_t* src_flags, const uint8_t* src_valid,
+                                  const uint8_t* src_desc, int n_src, float th, int max_dist,
+                                  int skip_any_occupied, int check_orientation, int32_t* kp_assigned,
+                                  int* nmatches);
+
+/* Frame::GetFeaturesInArea (src/Frame.cc:209-262) evaluated by the GPU candidate kernel, for the
+ * parity tests: indices in reference order.  out[cap]. */
+int orbfe_debug_features_in_area(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, int n, const float bounds[4],
+                                 float x, float y, float r, int min_level, int max_level, int32_t* out, int cap,
+                                 int* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBFE_H_ */

@@ -1,0 +1,298 @@
+"""ctypes binding of liborbfe.so (include/orbfe.h).  Mirrors the reference's operator interface:
+Extractor(...)(image) ~ ORBextractor::operator(), Matcher.search_for_initialization(...) ~
+ORBmatcher::SearchForInitialization, Matcher.search_by_projection(...) ~ SearchByProjection.
+No compute happens in Python and there is no fallback: if the library or a GPU is missing the
+constructors raise."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, 'liborbfe.so')
+
+KP_DTYPE = np.dtype([('x', 'f4'), ('y', 'f4'), ('size', 'f4'), ('angle', 'f4'), ('response', 'f4'),
+                     ('octave', 'i4'), ('class_id', 'i4')])
+
+MP_IN_VIEW, MP_BAD, MP_CANDIDATO, MP_OBSERVED = 1, 2, 4, 8
+
+
+class OrbfeError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__('orbfe error %d: %s' % (code, msg))
+        self.code = code
+
+
+def lib_path():
+    return _SO
+
+
+def build_library(force=False):
+    """Compile liborbfe.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ['make', '-s', '-C', os.path.join(_HERE, 'csrc')]
+    if force:
+        subprocess.check_call(args + ['clean'])
+    subprocess.check_call(args)
+    return _SO
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise OrbfeError(-2, 'liborbfe.so is not built (run __graft_entry__.build() or make -C os1_amd/csrc)')
+    L = C.CDLL(_SO)
+    vp, ci, cf = C.c_void_p, C.c_int, C.c_float
+    L.orbfe_last_error.restype = C.c_char_p
+    L.orbfe_device_count.restype = ci
+    L.orbfe_extractor_create.argtypes = [ci, cf, ci, ci, ci, ci, C.POINTER(vp)]
+    L.orbfe_extractor_destroy.argtypes = [vp]
+    L.orbfe_extractor_destroy.restype = None
+    L.orbfe_extractor_levels.argtypes = [vp]
+    L.orbfe_extractor_scale_factor.argtypes = [vp]
+    L.orbfe_extractor_scale_factor.restype = cf
+    L.orbfe_extractor_scale_tables.argtypes = [vp, vp, vp, vp, vp]
+    L.orbfe_extractor_features_per_level.argtypes = [vp, vp]
+    L.orbfe_extractor_max_keypoints.argtypes = [vp]
+    L.orbfe_extract.argtypes = [vp, vp, ci, ci, C.c_size_t, vp, vp, ci, C.POINTER(ci)]
+    L.orbfe_extract_batch.argtypes = [vp, ci, vp, ci, ci, ci, C.c_size_t, vp, vp, ci, vp]
+    L.orbfe_debug_level_size.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(ci)]
+    L.orbfe_debug_level_copy.argtypes = [vp, ci, ci, vp]
+    L.orbfe_debug_candidates.argtypes = [vp, ci, ci, vp, ci, C.POINTER(ci)]
+    L.orbfe_debug_stage_ms.argtypes = [vp, vp]
+    L.orbfe_debug_sincos.argtypes = [vp, vp, ci, vp, vp]
+    L.orbfe_hamming.argtypes = [vp, vp]
+    L.orbfe_matcher_create.argtypes = [ci, C.POINTER(vp)]
+    L.orbfe_matcher_destroy.argtypes = [vp]
+    L.orbfe_matcher_destroy.restype = None
+    L.orbfe_search_for_initialization.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, ci, cf, ci, C.POINTER(ci)]
+    L.orbfe_search_by_projection.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp,
+                                             C.POINTER(ci)]
+    L.orbfe_search_by_projection_uv.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, ci,
+                                                ci, ci, vp, C.POINTER(ci)]
+    L.orbfe_debug_features_in_area.argtypes = [vp, vp, ci, vp, cf, cf, cf, ci, ci, vp, ci, C.POINTER(ci)]
+    L.orbfe_debug_quadtree.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, ci, C.POINTER(ci)]
+    L.orbfe_debug_sincos_host_check.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_longlong)]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _check(rc):
+    if rc != 0:
+        raise OrbfeError(rc, load_library().orbfe_last_error().decode('utf-8', 'replace'))
+
+
+def device_count():
+    return load_library().orbfe_device_count()
+
+
+def hamming(a, b):
+    a = np.ascontiguousarray(a, np.uint8)
+    b = np.ascontiguousarray(b, np.uint8)
+    return load_library().orbfe_hamming(_p(a), _p(b))
+
+
+class Extractor:
+    """ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST) on one GPU."""
+
+    def __init__(self, nfeatures=1000, scale=1.2, nlevels=8, ini_th=20, min_th=7, device=0):
+        self.L = load_library()
+        h = C.c_void_p()
+        _check(self.L.orbfe_extractor_create(nfeatures, scale, nlevels, ini_th, min_th, device, C.byref(h)))
+        self.h = h
+        self.nlevels = nlevels
+        self.cap = self.L.orbfe_extractor_max_keypoints(h)
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.L.orbfe_extractor_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def tables(self):
+        n = self.nlevels
+        sf, isf, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        nf = np.zeros(n, np.int32)
+        _check(self.L.orbfe_extractor_scale_tables(self.h, _p(sf), _p(isf), _p(s2), _p(is2)))
+        _check(self.L.orbfe_extractor_features_per_level(self.h, _p(nf)))
+        return dict(sf=sf, isf=isf, s2=s2, is2=is2, nfeat=nf)
+
+    def __call__(self, image):
+        """image: (H, W) uint8 host array -> (keypoints[KP_DTYPE], descriptors[n,32] uint8)."""
+        image = np.asarray(image)
+        if image.size == 0:
+            n = C.c_int(0)
+            _check(self.L.orbfe_extract(self.h, None, 0, 0, 0, None, None, 0, C.byref(n)))
+            return np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
+        assert image.dtype == np.uint8 and image.ndim == 2 and image.strides[1] == 1
+        kps = np.zeros(self.cap, KP_DTYPE)
+        desc = np.zeros((self.cap, 32), np.uint8)
+        n = C.c_int(0)
+        _check(self.L.orbfe_extract(self.h, _p(image), image.shape[0], image.shape[1], image.strides[0], _p(kps),
+                                    _p(desc), self.cap, C.byref(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def extract_batch_ptrs(self, ptrs, rows, cols, stride, on_device, kps=None, desc=None):
+        """ptrs: sequence of raw addresses (host or device).  Returns (kps[B,cap], desc[B,cap,32], n[B])."""
+        B = len(ptrs)
+        arr = (C.c_void_p * B)(*ptrs)
+        if kps is None:
+            kps = np.zeros((B, self.cap), KP_DTYPE)
+        if desc is None:
+            desc = np.zeros((B, self.cap, 32), np.uint8)
+        n = np.zeros(B, np.int32)
+        _check(self.L.orbfe_extract_batch(self.h, B, arr, int(on_device), rows, cols, stride, _p(kps), _p(desc),
+                                          self.cap, _p(n)))
+        return kps, desc, n
+
+    def extract_batch(self, images):
+        images = [np.ascontiguousarray(im, np.uint8) for im in images]
+        rows, cols = images[0].shape
+        assert all(im.shape == (rows, cols) for im in images)
+        kps, desc, n = self.extract_batch_ptrs([im.ctypes.data for im in images], rows, cols, cols, False)
+        return [(kps[i, :n[i]].copy(), desc[i, :n[i]].copy()) for i in range(len(images))]
+
+    # ---- stage accessors (parity tests) -------------------------------------------------------
+    def level(self, level, frame=0):
+        w, h = C.c_int(), C.c_int()
+        _check(self.L.orbfe_debug_level_size(self.h, level, C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value), np.uint8)
+        _check(self.L.orbfe_debug_level_copy(self.h, frame, level, _p(out)))
+        return out
+
+    def candidates(self, level, frame=0):
+        n = C.c_int(0)
+        _check(self.L.orbfe_debug_candidates(self.h, frame, level, None, 0, C.byref(n)))
+        out = np.zeros((max(n.value, 1), 3), np.int32)
+        _check(self.L.orbfe_debug_candidates(self.h, frame, level, _p(out), n.value, C.byref(n)))
+        return out[:n.value].copy()
+
+    def stage_ms(self):
+        out = np.zeros(5, np.float32)
+        _check(self.L.orbfe_debug_stage_ms(self.h, _p(out)))
+        return out
+
+    def sincos(self, angle_deg):
+        a = np.ascontiguousarray(angle_deg, np.float32)
+        c = np.zeros_like(a)
+        s = np.zeros_like(a)
+        _check(self.L.orbfe_debug_sincos(self.h, _p(a), a.size, _p(c), _p(s)))
+        return c, s
+
+
+class Matcher:
+    """Hot subset of ORBmatcher on one GPU."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        h = C.c_void_p()
+        _check(self.L.orbfe_matcher_create(device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.L.orbfe_matcher_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def search_for_initialization(self, kps1, desc1, kps2, desc2, bounds, prev_xy, window=100, nnratio=0.9,
+                                  check_ori=True):
+        kps1 = np.ascontiguousarray(kps1, KP_DTYPE)
+        kps2 = np.ascontiguousarray(kps2, KP_DTYPE)
+        desc1 = np.ascontiguousarray(desc1, np.uint8)
+        desc2 = np.ascontiguousarray(desc2, np.uint8)
+        b = np.asarray(bounds, np.float32)
+        prev = np.ascontiguousarray(prev_xy, np.float32).copy()
+        m12 = np.full(max(len(kps1), 1), -1, np.int32)
+        n = C.c_int(0)
+        _check(self.L.orbfe_search_for_initialization(self.h, _p(kps1), _p(desc1), len(kps1), _p(kps2), _p(desc2),
+                                                      len(kps2), _p(b), _p(prev), _p(m12), window, nnratio,
+                                                      int(check_ori), C.byref(n)))
+        return n.value, m12[:len(kps1)], prev
+
+    def search_by_projection(self, kps, desc, bounds, scale_factors, kp_occupied, mp_xy, mp_level, mp_viewcos,
+                             mp_flags, mp_desc, th, nnratio):
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        b = np.asarray(bounds, np.float32)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        occ = np.ascontiguousarray(kp_occupied, np.uint8)
+        mp_xy = np.ascontiguousarray(mp_xy, np.float32)
+        mp_level = np.ascontiguousarray(mp_level, np.int32)
+        mp_viewcos = np.ascontiguousarray(mp_viewcos, np.float32)
+        mp_flags = np.ascontiguousarray(mp_flags, np.uint8)
+        mp_desc = np.ascontiguousarray(mp_desc, np.uint8)
+        assigned = np.full(max(len(kps), 1), -1, np.int32)
+        n = C.c_int(0)
+        _check(self.L.orbfe_search_by_projection(self.h, _p(kps), _p(desc), len(kps), _p(b), _p(sf), len(sf), _p(occ),
+                                                 _p(mp_xy), _p(mp_level), _p(mp_viewcos), _p(mp_flags), _p(mp_desc),
+                                                 len(mp_level), th, nnratio, _p(assigned), C.byref(n)))
+        return n.value, assigned[:len(kps)]
+
+    def search_by_projection_uv(self, kps, desc, bounds, scale_factors, kp_occupied, src_uv, src_level, src_angle,
+                                src_flags, src_valid, src_desc, th, max_dist, skip_any_occupied, check_ori):
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        b = np.asarray(bounds, np.float32)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        occ = np.ascontiguousarray(kp_occupied, np.uint8)
+        src_uv = np.ascontiguousarray(src_uv, np.float32)
+        src_level = np.ascontiguousarray(src_level, np.int32)
+        src_angle = np.ascontiguousarray(src_angle, np.float32)
+        src_flags = np.ascontiguousarray(src_flags, np.uint8)
+        src_valid = np.ascontiguousarray(src_valid, np.uint8)
+        src_desc = np.ascontiguousarray(src_desc, np.uint8)
+        assigned = np.full(max(len(kps), 1), -1, np.int32)
+        n = C.c_int(0)
+        _check(self.L.orbfe_search_by_projection_uv(self.h, _p(kps), _p(desc), len(kps), _p(b), _p(sf), len(sf),
+                                                    _p(occ), _p(src_uv), _p(src_level), _p(src_angle), _p(src_flags),
+                                                    _p(src_valid), _p(src_desc), len(src_level), th, max_dist,
+                                                    int(skip_any_occupied), int(check_ori), _p(assigned),
+                                                    C.byref(n)))
+        return n.value, assigned[:len(kps)]
+
+    def get_features_in_area(self, kps, bounds, x, y, r, min_level, max_level):
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        b = np.asarray(bounds, np.float32)
+        out = np.zeros(max(len(kps), 1), np.int32)
+        n = C.c_int(0)
+        _check(self.L.orbfe_debug_features_in_area(self.h, _p(kps), len(kps), _p(b), x, y, r, min_level, max_level,
+                                                   _p(out), len(out), C.byref(n)))
+        return out[:n.value].copy()
+
+
+def quadtree(x, y, score, min_x, max_x, min_y, max_y, n_target):
+    """Product host quadtree (no GPU needed): indices of the retained candidates, list order."""
+    x = np.ascontiguousarray(x, np.int16)
+    y = np.ascontiguousarray(y, np.int16)
+    score = np.ascontiguousarray(score, np.uint8)
+    out = np.zeros(max(len(x), 1), np.int32)
+    n = C.c_int(0)
+    _check(load_library().orbfe_debug_quadtree(_p(x), _p(y), _p(score), len(x), min_x, max_x, min_y, max_y, n_target,
+                                               _p(out), len(out), C.byref(n)))
+    return out[:n.value].copy()
+
+
+def sincos_host_mismatches(lo_bits, hi_bits, step=1):
+    bad = C.c_longlong(0)
+    _check(load_library().orbfe_debug_sincos_host_check(lo_bits, hi_bits, step, C.byref(bad)))
+    return bad.value

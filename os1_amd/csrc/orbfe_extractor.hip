@@ -1,0 +1,601 @@
+// orbfe_extractor.hip -- host engine + C ABI of the extractor (include/orbfe.h).
+//
+// Behaviour contract: ORB_SLAM2::ORBextractor of the reference (src/ORBextractor.cc:442-502 ctor,
+// :907-969 operator(), :971-996 ComputePyramid, :797-895 ComputeKeyPointsOctTree).  The pixel work
+// runs in the kernels of orbfe_kernels.hip; the serial, order-defining quadtree runs on the host
+// (quadtree.h).  There is no CPU fallback for the kernels.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/orbfe.h"
+#include "glibc_sincosf.h"
+#include "orbfe_internal.h"
+#include "quadtree.h"
+
+namespace orbfe {
+void launch_pyramid(const PyramidParams& P, int nframes, hipStream_t st);
+void launch_detect(const PyramidParams& P, int nframes, hipStream_t st);
+void launch_describe(const PyramidParams& P, const SelKp* sel, int nsel, float* angle, uint8_t* desc,
+                     hipStream_t st);
+void launch_sincos(const float* deg, int n, float* c, float* s, hipStream_t st);
+
+thread_local std::string g_err;
+void set_err(const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+}  // namespace orbfe
+
+using namespace orbfe;
+
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);    \
+      return ORBFE_ERR_HIP;                                                                  \
+    }                                                                                        \
+  } while (0)
+
+namespace {
+inline int cv_round_f(float v) { return (int)lrintf(v); }
+inline int cv_floor_f(float v) { int i = (int)v; return i - (i > v); }
+inline short sat_short(int v) { return (short)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); }
+inline long long align_up(long long v, long long a) { return (v + a - 1) / a * a; }
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  int ensure(size_t count) {
+    if (count <= n) return ORBFE_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+    HIP_TRY(hipMalloc((void**)&p, count * sizeof(T)));
+    n = count;
+    return ORBFE_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+template <class T>
+struct PinBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  int ensure(size_t count) {
+    if (count <= n) return ORBFE_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    n = 0;
+    HIP_TRY(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault));
+    n = count;
+    return ORBFE_OK;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
+};
+}  // namespace
+
+struct orbfe_extractor {
+  int nfeatures, nlevels, iniTh, minTh, device;
+  double scaleFactor;  // the reference keeps the float ctor argument in a double member (ORBextractor.h:313)
+  std::vector<float> sf, isf, sigma2, isigma2;
+  std::vector<int> nfeat;
+  hipStream_t stream = nullptr;
+
+  int rows = 0, cols = 0, batchCap = 0;
+  PyramidParams P{};
+  DevBuf<uint8_t> d_tables, d_slab, d_in;
+  DevBuf<uint32_t> d_cellCount, d_cellOff, d_slots, d_cand, d_levelStart;
+  DevBuf<const uint8_t*> d_frame0;
+  DevBuf<SelKp> d_sel;
+  DevBuf<float> d_angle, d_f32tmp;
+  DevBuf<uint8_t> d_desc;
+  PinBuf<const uint8_t*> h_frame0;
+  PinBuf<uint32_t> h_levelStart, h_cand;
+  PinBuf<SelKp> h_sel;
+  PinBuf<float> h_angle;
+  PinBuf<uint8_t> h_desc;
+  long long inPitch = 0;
+  int lastFrames = 0;
+  float stageMs[5] = {0, 0, 0, 0, 0};
+
+  QuadTree qt;
+  std::vector<int16_t> qx, qy;
+  std::vector<uint8_t> qs;
+  std::vector<int> qsel;
+  struct Meta { int16_t x, y; uint8_t score, level; };
+  std::vector<Meta> meta;
+  std::vector<int> frameKpStart;
+
+  ~orbfe_extractor() {
+    (void)hipSetDevice(device);
+    d_tables.release(); d_slab.release(); d_in.release(); d_cellCount.release(); d_cellOff.release();
+    d_slots.release(); d_cand.release(); d_levelStart.release(); d_frame0.release(); d_sel.release();
+    d_angle.release(); d_f32tmp.release(); d_desc.release();
+    h_frame0.release(); h_levelStart.release(); h_cand.release(); h_sel.release(); h_angle.release();
+    h_desc.release();
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+
+  // Level sizes, FAST cell grids, bilinear tables.  ORBextractor.cc:975-976 (sizes), :807-823 (cells).
+  int setGeometry(int r, int c) {
+    if (r == rows && c == cols) return ORBFE_OK;
+    if (c > 4095 || r > 4095) {
+      set_err("image %dx%d exceeds the 4095-pixel coordinate packing limit", c, r);
+      return ORBFE_ERR_INVALID;
+    }
+    PyramidParams Q{};
+    Q.nlevels = nlevels;
+    Q.iniTh = iniTh;
+    Q.minTh = minTh;
+    long long off = 0, slot = 0;
+    int cellBase = 0;
+    size_t tableBytes = 0;
+    for (int l = 0; l < nlevels; l++) {
+      LevelGeom& L = Q.lv[l];
+      L.w = cv_round_f((float)c * isf[l]);
+      L.h = cv_round_f((float)r * isf[l]);
+      const float width = (float)((L.w - kEdge + 3) - (kEdge - 3));
+      const float height = (float)((L.h - kEdge + 3) - (kEdge - 3));
+      L.nCols = (int)(width / 30.f);
+      L.nRows = (int)(height / 30.f);
+      if (L.nCols < 1 || L.nRows < 1) {
+        set_err("image %dx%d too small: level %d (%dx%d) has no FAST cell", c, r, l, L.w, L.h);
+        return ORBFE_ERR_TOO_SMALL;
+      }
+      L.wCell = (int)std::ceil(width / L.nCols);
+      L.hCell = (int)std::ceil(height / L.nRows);
+      L.cellBase = cellBase;
+      cellBase += L.nCols * L.nRows;
+      L.slotCap = ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2);
+      L.slotBase = slot;
+      slot += (long long)L.nCols * L.nRows * L.slotCap;
+      if (l >= 1) {
+        L.pitch = (int)align_up(L.w, 64);
+        L.off = off;
+        off += align_up((long long)L.pitch * L.h, 256);
+        tableBytes += align_up(L.w * 4, 16) + align_up(L.w * 4, 16) + align_up(L.h * 4, 16) + align_up(L.h * 4, 16);
+      }
+    }
+    Q.ncells = cellBase;
+    Q.slabBytes = off;
+    Q.slotsPerFrame = slot;
+    Q.candCap = slot;
+
+    // bilinear tables, SURVEY.md Appendix B.2 (float/double arithmetic exactly as cv::resize)
+    std::vector<uint8_t> tab(tableBytes);
+    int rc = d_tables.ensure(tableBytes);
+    if (rc) return rc;
+    size_t cur = 0;
+    for (int l = 1; l < nlevels; l++) {
+      LevelGeom& L = Q.lv[l];
+      const int sw = Q.lv[l - 1].w, sh = Q.lv[l - 1].h, dw = L.w, dh = L.h;
+      const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+      int* xofs = (int*)(tab.data() + cur);
+      L.xofs = (const int*)(d_tables.p + cur);
+      cur += align_up(dw * 4, 16);
+      short* xa = (short*)(tab.data() + cur);
+      L.xalpha = (const short*)(d_tables.p + cur);
+      cur += align_up(dw * 4, 16);
+      int* yofs = (int*)(tab.data() + cur);
+      L.yofs = (const int*)(d_tables.p + cur);
+      cur += align_up(dh * 4, 16);
+      short* yb = (short*)(tab.data() + cur);
+      L.ybeta = (const short*)(d_tables.p + cur);
+      cur += align_up(dh * 4, 16);
+      for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = cv_floor_f(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        xofs[dx] = sx;
+        xa[2 * dx] = sat_short(cv_round_f((1.f - fx) * 2048));
+        xa[2 * dx + 1] = sat_short(cv_round_f(fx * 2048));
+      }
+      for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = cv_floor_f(fy);
+        fy -= sy;
+        yofs[dy] = sy;
+        yb[2 * dy] = sat_short(cv_round_f((1.f - fy) * 2048));
+        yb[2 * dy + 1] = sat_short(cv_round_f(fy * 2048));
+      }
+    }
+    HIP_TRY(hipMemcpyAsync(d_tables.p, tab.data(), tableBytes, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    P = Q;
+    rows = r;
+    cols = c;
+    batchCap = 0;
+    return ORBFE_OK;
+  }
+
+  int setBatch(int nframes, bool hostInput) {
+    int rc;
+    if (nframes > batchCap) {
+      if ((rc = d_slab.ensure((size_t)P.slabBytes * nframes))) return rc;
+      if ((rc = d_cellCount.ensure((size_t)P.ncells * nframes))) return rc;
+      if ((rc = d_cellOff.ensure((size_t)P.ncells * nframes))) return rc;
+      if ((rc = d_slots.ensure((size_t)P.slotsPerFrame * nframes))) return rc;
+      if ((rc = d_cand.ensure((size_t)P.candCap * nframes))) return rc;
+      if ((rc = d_levelStart.ensure((size_t)(kMaxLevels + 1) * nframes))) return rc;
+      if ((rc = d_frame0.ensure(nframes))) return rc;
+      if ((rc = h_frame0.ensure(nframes))) return rc;
+      if ((rc = h_levelStart.ensure((size_t)(kMaxLevels + 1) * nframes))) return rc;
+      const size_t maxKp = (size_t)(nfeatures + 2 * nlevels) * nframes;
+      if ((rc = d_sel.ensure(maxKp))) return rc;
+      if ((rc = h_sel.ensure(maxKp))) return rc;
+      if ((rc = d_angle.ensure(maxKp))) return rc;
+      if ((rc = h_angle.ensure(maxKp))) return rc;
+      if ((rc = d_desc.ensure(maxKp * 32))) return rc;
+      if ((rc = h_desc.ensure(maxKp * 32))) return rc;
+      batchCap = nframes;
+    }
+    if (hostInput) {
+      inPitch = align_up(cols, 256);
+      if ((rc = d_in.ensure((size_t)inPitch * rows * nframes))) return rc;
+    }
+    P.slab = d_slab.p;
+    P.cellCount = d_cellCount.p;
+    P.cellOff = d_cellOff.p;
+    P.slots = d_slots.p;
+    P.cand = d_cand.p;
+    P.levelStart = d_levelStart.p;
+    P.frame0 = d_frame0.p;
+    return ORBFE_OK;
+  }
+
+  int run(int nframes, const uint8_t* const* gray, bool onDevice, int r, int c, size_t stride, OrbfeKeyPoint* kps,
+          uint8_t* desc, int cap, int* n_out) {
+    HIP_TRY(hipSetDevice(device));
+    int rc;
+    if ((rc = setGeometry(r, c))) return rc;
+    if ((rc = setBatch(nframes, !onDevice))) return rc;
+    const double t0 = now_ms();
+    // ---- stage 1: upload, pyramid, FAST, ordered compaction --------------------------------
+    for (int f = 0; f < nframes; f++) {
+      if (!gray[f]) { set_err("frame %d is NULL", f); return ORBFE_ERR_INVALID; }
+      if (onDevice) {
+        h_frame0.p[f] = gray[f];
+      } else {
+        uint8_t* dst = d_in.p + (size_t)inPitch * rows * f;
+        HIP_TRY(hipMemcpy2DAsync(dst, inPitch, gray[f], stride, c, r, hipMemcpyHostToDevice, stream));
+        h_frame0.p[f] = dst;
+      }
+    }
+    P.stride0 = onDevice ? (long long)stride : inPitch;
+    HIP_TRY(hipMemcpyAsync(d_frame0.p, h_frame0.p, sizeof(void*) * nframes, hipMemcpyHostToDevice, stream));
+    launch_pyramid(P, nframes, stream);
+    launch_detect(P, nframes, stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h_levelStart.p, d_levelStart.p, sizeof(uint32_t) * (kMaxLevels + 1) * nframes,
+                           hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    const double t1 = now_ms();
+    // ---- D2H of the candidates (exact sizes) ---------------------------------------------
+    size_t totalCand = 0;
+    std::vector<size_t> candStart(nframes + 1, 0);
+    for (int f = 0; f < nframes; f++) {
+      candStart[f] = totalCand;
+      totalCand += h_levelStart.p[(size_t)f * (kMaxLevels + 1) + nlevels];
+    }
+    candStart[nframes] = totalCand;
+    if ((rc = h_cand.ensure(totalCand + 1))) return rc;
+    for (int f = 0; f < nframes; f++) {
+      const size_t n = candStart[f + 1] - candStart[f];
+      if (n)
+        HIP_TRY(hipMemcpyAsync(h_cand.p + candStart[f], d_cand.p + (size_t)P.candCap * f, n * sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, stream));
+    }
+    HIP_TRY(hipStreamSynchronize(stream));
+    const double t2 = now_ms();
+    // ---- host quadtree per (frame, level): DistributeOctTree, ORBextractor.cc:876-877 -------
+    meta.clear();
+    frameKpStart.assign(nframes + 1, 0);
+    int nsel = 0;
+    for (int f = 0; f < nframes; f++) {
+      frameKpStart[f] = nsel;
+      const uint32_t* ls = h_levelStart.p + (size_t)f * (kMaxLevels + 1);
+      for (int l = 0; l < nlevels; l++) {
+        const int n = (int)(ls[l + 1] - ls[l]);
+        if (n <= 0) continue;
+        const uint32_t* cd = h_cand.p + candStart[f] + ls[l];
+        qx.resize(n); qy.resize(n); qs.resize(n);
+        for (int i = 0; i < n; i++) {
+          const uint32_t v = cd[i];
+          qx[i] = (int16_t)((int)(v & 0xfff) - kBorder);
+          qy[i] = (int16_t)((int)((v >> 12) & 0xfff) - kBorder);
+          qs[i] = (uint8_t)(v >> 24);
+        }
+        const LevelGeom& L = P.lv[l];
+        qt.distribute(qx.data(), qy.data(), qs.data(), n, kBorder, L.w - kBorder, kBorder, L.h - kBorder, nfeat[l], qsel);
+        for (int k : qsel) {
+          Meta m;
+          m.x = (int16_t)(qx[k] + kBorder);
+          m.y = (int16_t)(qy[k] + kBorder);
+          m.score = qs[k];
+          m.level = (uint8_t)l;
+          meta.push_back(m);
+          SelKp s;
+          s.xy = (uint32_t)m.x | ((uint32_t)m.y << 16);
+          s.lf = (uint32_t)l | ((uint32_t)f << 8);
+          h_sel.p[nsel++] = s;
+        }
+      }
+    }
+    frameKpStart[nframes] = nsel;
+    const double t3 = now_ms();
+    // ---- stage 2: orientation + blur + rBRIEF on the GPU -----------------------------------
+    if (nsel > 0) {
+      HIP_TRY(hipMemcpyAsync(d_sel.p, h_sel.p, sizeof(SelKp) * nsel, hipMemcpyHostToDevice, stream));
+      launch_describe(P, d_sel.p, nsel, d_angle.p, d_desc.p, stream);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(h_angle.p, d_angle.p, sizeof(float) * nsel, hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipMemcpyAsync(h_desc.p, d_desc.p, (size_t)32 * nsel, hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+    }
+    // ---- assemble cv::KeyPoint-compatible outputs (ORBextractor.cc:879-889, 959-967) --------
+    int status = ORBFE_OK;
+    for (int f = 0; f < nframes; f++) {
+      const int b = frameKpStart[f], n = frameKpStart[f + 1] - b;
+      n_out[f] = n;
+      if (n > cap) {
+        set_err("frame %d produced %d keypoints, cap is %d", f, n, cap);
+        status = ORBFE_ERR_OVERFLOW;
+      }
+      const int m = n < cap ? n : cap;
+      OrbfeKeyPoint* ko = kps + (size_t)f * cap;
+      for (int i = 0; i < m; i++) {
+        const Meta& mt = meta[b + i];
+        OrbfeKeyPoint kp;
+        kp.x = (float)mt.x;
+        kp.y = (float)mt.y;
+        if (mt.level != 0) {
+          const float scale = sf[mt.level];
+          kp.x *= scale;
+          kp.y *= scale;
+        }
+        kp.size = (float)(int)(31 * sf[mt.level]);
+        kp.angle = h_angle.p[b + i];
+        kp.response = (float)mt.score;
+        kp.octave = mt.level;
+        kp.class_id = -1;
+        ko[i] = kp;
+      }
+      if (m > 0) memcpy(desc + (size_t)f * cap * 32, h_desc.p + (size_t)b * 32, (size_t)m * 32);
+    }
+    const double t4 = now_ms();
+    stageMs[0] = (float)(t1 - t0);
+    stageMs[1] = (float)(t2 - t1);
+    stageMs[2] = (float)(t3 - t2);
+    stageMs[3] = (float)(t4 - t3);
+    stageMs[4] = (float)(t4 - t0);
+    lastFrames = nframes;
+    return status;
+  }
+};
+
+extern "C" {
+
+const char* orbfe_last_error(void) { return g_err.c_str(); }
+
+int orbfe_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device_id,
+                           orbfe_extractor** out) {
+  if (!out) { set_err("out is NULL"); return ORBFE_ERR_INVALID; }
+  *out = nullptr;
+  if (nfeatures <= 0 || nlevels < 1 || nlevels > kMaxLevels || !(scaleFactor > 1.0f) || iniThFAST < 1 ||
+      minThFAST < 1 || iniThFAST > 255 || minThFAST > 255) {
+    set_err("invalid extractor parameters (nfeatures=%d scale=%g nlevels=%d ini=%d min=%d; nlevels<=%d)", nfeatures,
+            scaleFactor, nlevels, iniThFAST, minThFAST, kMaxLevels);
+    return ORBFE_ERR_INVALID;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) {
+    set_err("no usable HIP device (count=%d, requested %d): this library has no CPU fallback", ndev, device_id);
+    return ORBFE_ERR_NO_DEVICE;
+  }
+  HIP_TRY(hipSetDevice(device_id));
+  orbfe_extractor* h = new orbfe_extractor();
+  h->nfeatures = nfeatures;
+  h->scaleFactor = scaleFactor;
+  h->nlevels = nlevels;
+  h->iniTh = iniThFAST;
+  h->minTh = minThFAST;
+  h->device = device_id;
+  // scale tables and per-level quotas, ORBextractor.cc:447-478
+  h->sf.resize(nlevels);
+  h->sigma2.resize(nlevels);
+  h->sf[0] = 1.0f;
+  h->sigma2[0] = 1.0f;
+  for (int i = 1; i < nlevels; i++) {
+    h->sf[i] = (float)(h->sf[i - 1] * h->scaleFactor);
+    h->sigma2[i] = h->sf[i] * h->sf[i];
+  }
+  h->isf.resize(nlevels);
+  h->isigma2.resize(nlevels);
+  for (int i = 0; i < nlevels; i++) {
+    h->isf[i] = 1.0f / h->sf[i];
+    h->isigma2[i] = 1.0f / h->sigma2[i];
+  }
+  h->nfeat.resize(nlevels);
+  const float factor = (float)(1.0f / h->scaleFactor);
+  float nDesired = nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels));
+  int sum = 0;
+  for (int l = 0; l < nlevels - 1; l++) {
+    h->nfeat[l] = cv_round_f(nDesired);
+    sum += h->nfeat[l];
+    nDesired *= factor;
+  }
+  h->nfeat[nlevels - 1] = nfeatures - sum > 0 ? nfeatures - sum : 0;
+  hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    set_err("hipStreamCreate failed: %s", hipGetErrorString(e));
+    delete h;
+    return ORBFE_ERR_HIP;
+  }
+  *out = h;
+  return ORBFE_OK;
+}
+
+void orbfe_extractor_destroy(orbfe_extractor* h) { delete h; }
+int orbfe_extractor_levels(const orbfe_extractor* h) { return h ? h->nlevels : 0; }
+float orbfe_extractor_scale_factor(const orbfe_extractor* h) { return h ? (float)h->scaleFactor : 0.f; }
+int orbfe_extractor_scale_tables(const orbfe_extractor* h, float* a, float* b, float* c, float* d) {
+  if (!h) { set_err("handle is NULL"); return ORBFE_ERR_INVALID; }
+  for (int i = 0; i < h->nlevels; i++) {
+    if (a) a[i] = h->sf[i];
+    if (b) b[i] = h->isf[i];
+    if (c) c[i] = h->sigma2[i];
+    if (d) d[i] = h->isigma2[i];
+  }
+  return ORBFE_OK;
+}
+int orbfe_extractor_features_per_level(const orbfe_extractor* h, int32_t* out) {
+  if (!h || !out) { set_err("NULL argument"); return ORBFE_ERR_INVALID; }
+  for (int i = 0; i < h->nlevels; i++) out[i] = h->nfeat[i];
+  return ORBFE_OK;
+}
+int orbfe_extractor_max_keypoints(const orbfe_extractor* h) { return h ? h->nfeatures + 2 * h->nlevels : 0; }
+
+int orbfe_extract_batch(orbfe_extractor* h, int nframes, const uint8_t* const* gray, int in_device_memory, int rows,
+                        int cols, size_t stride_bytes, OrbfeKeyPoint* kps, uint8_t* desc, int cap, int* n_out) {
+  if (!h || !n_out) { set_err("NULL argument"); return ORBFE_ERR_INVALID; }
+  if (nframes <= 0) return ORBFE_OK;
+  for (int f = 0; f < nframes; f++) n_out[f] = 0;
+  if (rows == 0 || cols == 0 || !gray) return ORBFE_OK;  // empty image: silent return (ORBextractor.cc:910-911)
+  if (rows < 0 || cols < 0 || stride_bytes < (size_t)cols || !kps || !desc || cap <= 0) {
+    set_err("invalid image / output arguments");
+    return ORBFE_ERR_INVALID;
+  }
+  return h->run(nframes, gray, in_device_memory != 0, rows, cols, stride_bytes, kps, desc, cap, n_out);
+}
+
+int orbfe_extract(orbfe_extractor* h, const uint8_t* gray, int rows, int cols, size_t stride_bytes, OrbfeKeyPoint* kps,
+                  uint8_t* desc, int cap, int* n_out) {
+  if (!n_out) { set_err("n_out is NULL"); return ORBFE_ERR_INVALID; }
+  *n_out = 0;
+  if (!gray || rows == 0 || cols == 0) return ORBFE_OK;
+  const uint8_t* frames[1] = {gray};
+  return orbfe_extract_batch(h, 1, frames, 0, rows, cols, stride_bytes, kps, desc, cap, n_out);
+}
+
+int orbfe_debug_level_size(const orbfe_extractor* h, int level, int* w, int* hgt) {
+  if (!h || level < 0 || level >= h->nlevels || h->rows == 0) { set_err("bad level / no frame yet"); return ORBFE_ERR_INVALID; }
+  *w = h->P.lv[level].w;
+  *hgt = h->P.lv[level].h;
+  return ORBFE_OK;
+}
+
+int orbfe_debug_level_copy(orbfe_extractor* h, int frame, int level, uint8_t* out) {
+  if (!h || level < 0 || level >= h->nlevels || frame < 0 || frame >= h->lastFrames) {
+    set_err("bad frame/level");
+    return ORBFE_ERR_INVALID;
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  const LevelGeom& L = h->P.lv[level];
+  const uint8_t* src;
+  size_t pitch;
+  if (level == 0) {
+    src = h->h_frame0.p[frame];
+    pitch = (size_t)h->P.stride0;
+  } else {
+    src = h->d_slab.p + (size_t)h->P.slabBytes * frame + L.off;
+    pitch = L.pitch;
+  }
+  HIP_TRY(hipMemcpy2D(out, L.w, src, pitch, L.w, L.h, hipMemcpyDeviceToHost));
+  return ORBFE_OK;
+}
+
+int orbfe_debug_candidates(orbfe_extractor* h, int frame, int level, int32_t* xys, int cap, int* n_out) {
+  if (!h || !n_out || level < 0 || level >= h->nlevels || frame < 0 || frame >= h->lastFrames) {
+    set_err("bad frame/level");
+    return ORBFE_ERR_INVALID;
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  const uint32_t* ls = h->h_levelStart.p + (size_t)frame * (kMaxLevels + 1);
+  const int n = (int)(ls[level + 1] - ls[level]);
+  *n_out = n;
+  if (n <= 0 || !xys) return ORBFE_OK;
+  std::vector<uint32_t> tmp(n);
+  HIP_TRY(hipMemcpy(tmp.data(), h->d_cand.p + (size_t)h->P.candCap * frame + ls[level], sizeof(uint32_t) * n,
+                    hipMemcpyDeviceToHost));
+  for (int i = 0; i < n && i < cap; i++) {
+    xys[3 * i] = (int)(tmp[i] & 0xfff) - kBorder;
+    xys[3 * i + 1] = (int)((tmp[i] >> 12) & 0xfff) - kBorder;
+    xys[3 * i + 2] = (int)(tmp[i] >> 24);
+  }
+  return ORBFE_OK;
+}
+
+int orbfe_debug_stage_ms(const orbfe_extractor* h, float out[5]) {
+  if (!h || !out) { set_err("NULL argument"); return ORBFE_ERR_INVALID; }
+  for (int i = 0; i < 5; i++) out[i] = h->stageMs[i];
+  return ORBFE_OK;
+}
+
+int orbfe_debug_sincos(orbfe_extractor* h, const float* angle_deg, int n, float* cos_out, float* sin_out) {
+  if (!h || !angle_deg || !cos_out || !sin_out || n < 0) { set_err("bad argument"); return ORBFE_ERR_INVALID; }
+  if (n == 0) return ORBFE_OK;
+  HIP_TRY(hipSetDevice(h->device));
+  int rc;
+  if ((rc = h->d_f32tmp.ensure((size_t)3 * n))) return rc;
+  float* d = h->d_f32tmp.p;
+  HIP_TRY(hipMemcpyAsync(d, angle_deg, sizeof(float) * n, hipMemcpyHostToDevice, h->stream));
+  launch_sincos(d, n, d + n, d + 2 * (size_t)n, h->stream);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(cos_out, d + n, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(sin_out, d + 2 * (size_t)n, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return ORBFE_OK;
+}
+
+int orbfe_debug_quadtree(const int16_t* x, const int16_t* y, const uint8_t* score, int n, int min_x, int max_x,
+                         int min_y, int max_y, int n_target, int32_t* out_idx, int cap, int* n_out) {
+  if (!n_out || n < 0 || (n && (!x || !y || !score))) { set_err("bad argument"); return ORBFE_ERR_INVALID; }
+  QuadTree qt;
+  std::vector<int> sel;
+  qt.distribute(x, y, score, n, min_x, max_x, min_y, max_y, n_target, sel);
+  *n_out = (int)sel.size();
+  for (int i = 0; i < (int)sel.size() && i < cap; i++) out_idx[i] = sel[i];
+  return ORBFE_OK;
+}
+
+int orbfe_debug_sincos_host_check(uint32_t lo_bits, uint32_t hi_bits, uint32_t step, long long* mismatches) {
+  if (!mismatches || step == 0) { set_err("bad argument"); return ORBFE_ERR_INVALID; }
+  long long bad = 0;
+  for (uint64_t u = lo_bits; u <= hi_bits; u += step) {
+    const uint32_t b = (uint32_t)u;
+    float f;
+    memcpy(&f, &b, 4);
+    volatile float vf = f;
+    float s, c;
+    sincosf_glibc(f, &s, &c);
+    const float s0 = sinf(vf), c0 = cosf(vf);
+    if (memcmp(&s, &s0, 4) || memcmp(&c, &c0, 4)) bad++;
+  }
+  *mismatches = bad;
+  return ORBFE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+// orbfe_internal.h -- structures shared by the host engine and the HIP kernels.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace orbfe {
+
+constexpr int kMaxLevels = 12;
+constexpr int kEdge = 19;        // EDGE_THRESHOLD  (reference src/ORBextractor.cc:79)
+constexpr int kBorder = 16;      // minBorderX/Y = EDGE_THRESHOLD-3 (ORBextractor.cc:807-808)
+constexpr int kHalfPatch = 15;   // HALF_PATCH_SIZE (ORBextractor.cc:76)
+constexpr int kBlurRad = 18;     // largest |cvRound| of a rotated rBRIEF offset
+constexpr int kRawRad = kBlurRad + 3;  // raw pixels needed to blur the 37x37 neighbourhood
+
+// Geometry of one pyramid level; identical for every frame of a batch.
+struct LevelGeom {
+  int w, h;                // level size in pixels
+  int pitch;               // row pitch in bytes inside the pyramid slab (levels >= 1)
+  long long off;           // byte offset of the level inside one frame's pyramid slab (levels >= 1)
+  int nCols, nRows;        // FAST cell grid (ORBextractor.cc:820-821)
+  int wCell, hCell;        // cell size (ORBextractor.cc:822-823)
+  int cellBase;            // index of this level's first cell in the per-frame cell arrays
+  int slotCap;             // candidate slots per cell = ceil(wCell/2)*ceil(hCell/2) (strict-local-max bound)
+  long long slotBase;      // first slot (u32 units) of this level in the per-frame slot array
+  // bilinear tables for producing THIS level from level-1 (device pointers; unused for level 0)
+  const int* xofs;         // [w]   source column
+  const short* xalpha;     // [2*w] 11-bit weights (a0,a1)
+  const int* yofs;         // [h]   source row (unclamped)
+  const short* ybeta;      // [2*h] 11-bit weights (b0,b1)
+};
+
+struct PyramidParams {
+  LevelGeom lv[kMaxLevels];
+  int nlevels;
+  int ncells;                       // cells per frame (all levels)
+  long long slabBytes;              // pyramid slab bytes per frame (levels >= 1)
+  long long slotsPerFrame;          // u32 slots per frame
+  long long candCap;                // candidate capacity per frame (u32 entries)
+  const uint8_t* const* frame0;     // [nframes] level-0 pointers (device memory)
+  long long stride0;                // level-0 row stride in bytes
+  uint8_t* slab;                    // [nframes][slabBytes]
+  uint32_t* cellCount;              // [nframes][ncells]
+  uint32_t* cellOff;                // [nframes][ncells]
+  uint32_t* slots;                  // [nframes][slotsPerFrame]
+  uint32_t* cand;                   // [nframes][candCap]  packed x | y<<12 | score<<24 (level coords)
+  uint32_t* levelStart;             // [nframes][kMaxLevels+1]
+  int iniTh, minTh;
+};
+
+// One selected keypoint handed to the orientation + descriptor kernel.
+struct SelKp {
+  uint32_t xy;     // x | y << 16 (level coordinates)
+  uint32_t lf;     // level | frame << 8
+};
+
+}  // namespace orbfe

@@ -1,0 +1,433 @@
+// orbfe_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the ORB front end.
+//
+// All arithmetic that decides an output bit is integer, or float32 with contraction OFF
+// (build flag -ffp-contract=off) so it rounds like the reference's separate mul/add on x86-64.
+//
+//   k_resize        cv::resize INTER_LINEAR 8u (level l <- level l-1), 11-bit fixed point
+//   k_fast_cells    per reference FAST cell: score map + 3x3 NMS + iniTh/minTh fallback (1 wave/cell)
+//   k_scan_cells    exclusive scan of per-cell counts -> reference candidate order
+//   k_gather        ordered compaction of the per-cell slots
+//   k_describe      per keypoint: IC-angle, 7x7 fixed-point Gaussian of the 37x37 neighbourhood,
+//                   steered BRIEF with __ballot packing (1 wave/keypoint)
+//   k_sincos        test hook for the device (cosf,sinf)
+#include <hip/hip_runtime.h>
+
+#include "glibc_sincosf.h"
+#include "orbfe_internal.h"
+
+namespace orbfe {
+
+// ------------------------------------------------------------------------------------------------
+// Pyramid: level l <- bilinear(level l-1).  Reference: ComputePyramid, src/ORBextractor.cc:971-996
+// (cv::resize call at :984); fixed-point semantics: SURVEY.md Appendix B.2.
+// Block 64x4 threads, 4 destination pixels per thread (one 32-bit store).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_resize(PyramidParams P, int level) {
+  const LevelGeom& D = P.lv[level];
+  const LevelGeom& S = P.lv[level - 1];
+  const int f = blockIdx.z;
+  const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
+  const int y = blockIdx.y * 4 + threadIdx.y;
+  if (x0 >= D.w || y >= D.h) return;
+  const uint8_t* src;
+  long long sstride;
+  if (level == 1) {
+    src = P.frame0[f];
+    sstride = P.stride0;
+  } else {
+    src = P.slab + (long long)f * P.slabBytes + S.off;
+    sstride = S.pitch;
+  }
+  uint8_t* dst = P.slab + (long long)f * P.slabBytes + D.off + (long long)y * D.pitch;
+  const int sy = D.yofs[y];
+  const int sy0 = min(max(sy, 0), S.h - 1), sy1 = min(max(sy + 1, 0), S.h - 1);
+  const int b0 = D.ybeta[2 * y], b1 = D.ybeta[2 * y + 1];
+  const uint8_t* r0 = src + (long long)sy0 * sstride;
+  const uint8_t* r1 = src + (long long)sy1 * sstride;
+  uint32_t packed = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int x = x0 + i;
+    if (x < D.w) {
+      const int sx = D.xofs[x];
+      const int a0 = D.xalpha[2 * x], a1 = D.xalpha[2 * x + 1];
+      const int sx1 = min(sx + 1, S.w - 1);  // a1 == 0 whenever sx+1 is out of range
+      const int h0 = r0[sx] * a0 + r0[sx1] * a1;
+      const int h1 = r1[sx] * a0 + r1[sx1] * a1;
+      const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+      packed |= (uint32_t)(v & 255) << (8 * i);
+    }
+  }
+  *reinterpret_cast<uint32_t*>(dst + x0) = packed;  // pitch is a multiple of 4: in-bounds
+}
+
+// ------------------------------------------------------------------------------------------------
+// FAST-9/16 per reference cell.  Reference: ComputeKeyPointsOctTree, src/ORBextractor.cc:797-870
+// (cv::FAST calls at :848,:854); cv::FAST semantics: SURVEY.md Appendix B.1.
+//
+// Formulation (DESIGN.md "FAST"): with S(p) = max(max_arc min(v-ring), max_arc min(ring-v)) a pixel
+// is a corner at threshold t iff S(p) > t and its OpenCV score is S(p)-1, independent of t.  The
+// cell's FAST(t, nms) output is therefore {p in emit region : s(p) >= t and s(p) > s(q) for the 8
+// neighbours q inside the SAME cell's emit region}, s = S-1 (0 where S-1 < min(iniTh,minTh)).
+// The emit region of cell (i,j) is [19+j*wCell, min(19+(j+1)*wCell, w-19)) x [19+i*hCell, ...).
+// One wave per cell: ROI -> LDS, score tile -> LDS, NMS, then the iniTh/minTh decision by
+// wave-wide ballot and an ordered (row-major) write of the survivors into the cell's slots.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool has_arc9(unsigned m) {  // 9 contiguous set bits in a circular 16-bit mask
+  m |= m << 16;
+  m &= m >> 1;
+  m &= m >> 2;
+  m &= m >> 4;
+  m &= m >> 1;
+  return m != 0;
+}
+
+// max over the 16 arcs of the minimum of 9 consecutive values (circular)
+__device__ __forceinline__ int max_arc_min9(const int d[16]) {
+  int m2[16], m4[16], m8[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) m2[k] = min(d[k], d[(k + 1) & 15]);
+#pragma unroll
+  for (int k = 0; k < 16; k++) m4[k] = min(m2[k], m2[(k + 2) & 15]);
+#pragma unroll
+  for (int k = 0; k < 16; k++) m8[k] = min(m4[k], m4[(k + 4) & 15]);
+  int best = -256;
+#pragma unroll
+  for (int k = 0; k < 16; k++) best = max(best, min(m8[k], d[(k + 8) & 15]));
+  return best;
+}
+
+__global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  const int cell = blockIdx.x;
+  const int f = blockIdx.y;
+  const int lane = threadIdx.x;
+  int level = 0;
+  while (level + 1 < P.nlevels && cell >= P.lv[level + 1].cellBase) level++;
+  const LevelGeom& L = P.lv[level];
+  const int local = cell - L.cellBase;
+  const int ci = local / L.nCols, cj = local - ci * L.nCols;
+  const int ex0 = kEdge + cj * L.wCell, ey0 = kEdge + ci * L.hCell;
+  const int ew = min(L.wCell, L.w - kEdge - ex0), eh = min(L.hCell, L.h - kEdge - ey0);
+  uint32_t* cnt = P.cellCount + (long long)f * P.ncells + cell;
+  if (ew <= 0 || eh <= 0) {
+    if (lane == 0) *cnt = 0;
+    return;
+  }
+  const uint8_t* img;
+  long long stride;
+  if (level == 0) {
+    img = P.frame0[f];
+    stride = P.stride0;
+  } else {
+    img = P.slab + (long long)f * P.slabBytes + L.off;
+    stride = L.pitch;
+  }
+  // LDS carve: ROI tile (ew+6)x(eh+6), score tile (ew+2)x(eh+2) with a zero ring, kept-score tile ew x eh
+  const int TP = (L.wCell + 6 + 3) & ~3;
+  const int SP = L.wCell + 2;
+  uint8_t* tile = lds;
+  uint8_t* sc = tile + TP * (L.hCell + 6);
+  uint8_t* kept = sc + SP * (L.hCell + 2);
+
+  const int rw = ew + 6, rh = eh + 6;
+  const uint8_t* roi = img + (long long)(ey0 - 3) * stride + (ex0 - 3);
+  for (int i = lane; i < rw * rh; i += 64) {
+    const int y = i / rw, x = i - y * rw;
+    tile[y * TP + x] = roi[(long long)y * stride + x];
+  }
+  for (int i = lane; i < SP * (eh + 2); i += 64) sc[i] = 0;
+  __syncthreads();
+
+  const int tlo = min(P.iniTh, P.minTh);
+  const int npx = ew * eh;
+  for (int i = lane; i < npx; i += 64) {
+    const int y = i / ew, x = i - y * ew;
+    const uint8_t* c = tile + (y + 3) * TP + (x + 3);
+    const int v = c[0];
+    int d[16];
+    d[0] = v - c[3 * TP];       d[1] = v - c[3 * TP + 1];   d[2] = v - c[2 * TP + 2];   d[3] = v - c[TP + 3];
+    d[4] = v - c[3];            d[5] = v - c[-TP + 3];      d[6] = v - c[-2 * TP + 2];  d[7] = v - c[-3 * TP + 1];
+    d[8] = v - c[-3 * TP];      d[9] = v - c[-3 * TP - 1];  d[10] = v - c[-2 * TP - 2]; d[11] = v - c[-TP - 3];
+    d[12] = v - c[-3];          d[13] = v - c[TP - 3];      d[14] = v - c[2 * TP - 2];  d[15] = v - c[3 * TP - 1];
+    unsigned mdark = 0, mbright = 0;  // ring darker than centre by > tlo / brighter by > tlo
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+      mdark |= (unsigned)(d[k] > tlo) << k;
+      mbright |= (unsigned)(d[k] < -tlo) << k;
+    }
+    int s = 0;
+    const bool pd = has_arc9(mdark), pb = has_arc9(mbright);
+    if (pd | pb) {
+      int S = 0;
+      if (pd) S = max_arc_min9(d);
+      if (pb) {
+        int nd[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) nd[k] = -d[k];
+        S = max(S, max_arc_min9(nd));
+      }
+      s = S - 1;  // > tlo - 1, <= 254
+    }
+    sc[(y + 1) * SP + (x + 1)] = (uint8_t)s;
+  }
+  __syncthreads();
+
+  bool anyIni = false;
+  for (int i0 = 0; i0 < npx; i0 += 64) {
+    const int i = i0 + lane;
+    int keep = 0;
+    if (i < npx) {
+      const int y = i / ew, x = i - y * ew;
+      const uint8_t* q = sc + (y + 1) * SP + (x + 1);
+      const int s = q[0];
+      if (s > 0 && s > q[-1] && s > q[1] && s > q[-SP - 1] && s > q[-SP] && s > q[-SP + 1] && s > q[SP - 1] &&
+          s > q[SP] && s > q[SP + 1])
+        keep = s;
+      kept[i] = (uint8_t)keep;
+    }
+    anyIni |= (__ballot(keep >= P.iniTh && keep > 0) != 0ull);
+  }
+  __syncthreads();
+
+  const int th = anyIni ? P.iniTh : P.minTh;
+  uint32_t* slot = P.slots + (long long)f * P.slotsPerFrame + L.slotBase + (long long)local * L.slotCap;
+  int base = 0;
+  for (int i0 = 0; i0 < npx; i0 += 64) {
+    const int i = i0 + lane;
+    int s = 0;
+    if (i < npx) s = kept[i];
+    const bool emit = s > 0 && s >= th;
+    const unsigned long long m = __ballot(emit);
+    if (emit) {
+      const int y = i / ew, x = i - y * ew;
+      const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+      slot[pos] = (uint32_t)(ex0 + x) | ((uint32_t)(ey0 + y) << 12) | ((uint32_t)s << 24);
+    }
+    base += __popcll(m);
+  }
+  if (lane == 0) *cnt = (uint32_t)base;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exclusive scan of the per-cell counts of one frame (cells are numbered level-major, cell-row-major:
+// exactly the order in which the reference appends to vToDistributeKeys, ORBextractor.cc:826-870).
+// One 1024-thread block per frame.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_scan_cells(PyramidParams P) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t carry;
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const uint32_t* cnt = P.cellCount + (long long)f * P.ncells;
+  uint32_t* off = P.cellOff + (long long)f * P.ncells;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < P.ncells; base += 1024) {
+    const int i = base + tid;
+    const uint32_t v = i < P.ncells ? cnt[i] : 0u;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < wv; w++) wbase += wsum[w];
+    const uint32_t c = carry;
+    if (i < P.ncells) off[i] = c + wbase + incl - v;
+    __syncthreads();
+    if (tid == 1023) carry = c + wbase + incl;
+    __syncthreads();
+  }
+  uint32_t* ls = P.levelStart + (long long)f * (kMaxLevels + 1);
+  if (tid < P.nlevels) ls[tid] = off[P.lv[tid].cellBase];
+  if (tid == 0) ls[P.nlevels] = carry;
+}
+
+__global__ __launch_bounds__(64) void k_gather(PyramidParams P) {
+  const int cell = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+  const uint32_t n = P.cellCount[(long long)f * P.ncells + cell];
+  if (n == 0) return;
+  int level = 0;
+  while (level + 1 < P.nlevels && cell >= P.lv[level + 1].cellBase) level++;
+  const LevelGeom& L = P.lv[level];
+  const uint32_t* slot =
+      P.slots + (long long)f * P.slotsPerFrame + L.slotBase + (long long)(cell - L.cellBase) * L.slotCap;
+  const uint32_t o = P.cellOff[(long long)f * P.ncells + cell];
+  uint32_t* dst = P.cand + (long long)f * P.candCap;
+  for (uint32_t i = lane; i < n; i += 64)
+    if (o + i < (uint32_t)P.candCap) dst[o + i] = slot[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Orientation + descriptor, one wave per selected keypoint.
+// Reference: IC_Angle (src/ORBextractor.cc:86-113, on the UNBLURRED level), GaussianBlur 7x7 s=2
+// reflect-101 (:949-950) and computeOrbDescriptor (:132-171, on the blurred level).
+// Only the 37x37 blurred neighbourhood a descriptor can touch is produced (rotated offsets have
+// |cvRound| <= 18), from the 43x43 raw neighbourhood, with the level's own reflect-101 border.
+// Fixed-point blur: horizontal sum(k*p) in 16 bits, vertical (sum(k*h) + 32768) >> 16, k =
+// [18,34,48,56,48,34,18].
+// ------------------------------------------------------------------------------------------------
+__constant__ int8_t c_pattern[1024] = {
+#include "brief_pattern.inc"
+};
+__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {  // cv::fastAtan2, SURVEY.md B.4
+  const float scale = (float)(180 / 3.1415926535897932384626433832795);
+  const float p1 = 0.9997878412794807f * scale, p3 = -0.3258083974640975f * scale,
+              p5 = 0.1555786518463281f * scale, p7 = -0.04432655554792128f * scale;
+  const float eps = (float)2.2204460492503131e-16;
+  const float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) {
+    c = ay / (ax + eps);
+    c2 = c * c;
+    a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  } else {
+    c = ax / (ay + eps);
+    c2 = c * c;
+    a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+  }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * n - 2 - i;
+  return i;
+}
+
+constexpr int kRawW = 2 * kRawRad + 1;   // 43
+constexpr int kBlurW = 2 * kBlurRad + 1; // 37
+constexpr int kRawP = 44, kHP = 38, kBP = 40;
+
+__global__ __launch_bounds__(64) void k_describe(PyramidParams P, const SelKp* __restrict__ sel, int nsel,
+                                                  float* __restrict__ angleOut, uint8_t* __restrict__ descOut) {
+  __shared__ __align__(16) uint8_t raw[kRawW * kRawP];
+  __shared__ __align__(16) uint16_t hb[kRawW * kHP];
+  __shared__ __align__(16) uint8_t bl[kBlurW * kBP];
+  const int k = blockIdx.x;
+  if (k >= nsel) return;
+  const int lane = threadIdx.x;
+  const SelKp s = sel[k];
+  const int cx = s.xy & 0xffff, cy = s.xy >> 16;
+  const int level = s.lf & 0xff, f = s.lf >> 8;
+  const LevelGeom& L = P.lv[level];
+  const uint8_t* img;
+  long long stride;
+  if (level == 0) {
+    img = P.frame0[f];
+    stride = P.stride0;
+  } else {
+    img = P.slab + (long long)f * P.slabBytes + L.off;
+    stride = L.pitch;
+  }
+  for (int i = lane; i < kRawW * kRawW; i += 64) {
+    const int y = i / kRawW, x = i - y * kRawW;
+    const int gx = reflect101(cx - kRawRad + x, L.w), gy = reflect101(cy - kRawRad + y, L.h);
+    raw[y * kRawP + x] = img[(long long)gy * stride + gx];
+  }
+  __syncthreads();
+
+  // IC-angle moments over the circular patch of radius 15 (749 pixels)
+  int m10 = 0, m01 = 0;
+  for (int i = lane; i < 31 * 31; i += 64) {
+    const int v = i / 31 - kHalfPatch, u = i - (v + kHalfPatch) * 31 - kHalfPatch;
+    if (abs(u) <= c_umax[abs(v)]) {
+      const int I = raw[(kRawRad + v) * kRawP + kRawRad + u];
+      m10 += u * I;
+      m01 += v * I;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    m10 += __shfl_xor(m10, o, 64);
+    m01 += __shfl_xor(m01, o, 64);
+  }
+  const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+  // horizontal 7-tap on the 43 rows x 37 columns that feed the 37x37 output
+  for (int i = lane; i < kRawW * kBlurW; i += 64) {
+    const int y = i / kBlurW, x = i - y * kBlurW;
+    const uint8_t* r = raw + y * kRawP + x;
+    hb[y * kHP + x] = (uint16_t)(18 * (r[0] + r[6]) + 34 * (r[1] + r[5]) + 48 * (r[2] + r[4]) + 56 * r[3]);
+  }
+  __syncthreads();
+  for (int i = lane; i < kBlurW * kBlurW; i += 64) {
+    const int y = i / kBlurW, x = i - y * kBlurW;
+    const uint16_t* c = hb + y * kHP + x;
+    const uint32_t acc = 18u * (c[0] + c[6 * kHP]) + 34u * (c[kHP] + c[5 * kHP]) + 48u * (c[2 * kHP] + c[4 * kHP]) +
+                         56u * c[3 * kHP];
+    bl[y * kBP + x] = (uint8_t)((acc + 32768u) >> 16);
+  }
+  __syncthreads();
+
+  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+  float a, b;
+  sincosf_glibc(angle * factorPI, &b, &a);  // a = cos, b = sin
+  const uint8_t* center = bl + kBlurRad * kBP + kBlurRad;
+  unsigned long long words[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int bit = j * 64 + lane;
+    const int8_t* p = &c_pattern[4 * bit];
+    const float x1 = (float)p[0], y1 = (float)p[1], x2 = (float)p[2], y2 = (float)p[3];
+    const int t0 = center[__float2int_rn(x1 * b + y1 * a) * kBP + __float2int_rn(x1 * a - y1 * b)];
+    const int t1 = center[__float2int_rn(x2 * b + y2 * a) * kBP + __float2int_rn(x2 * a - y2 * b)];
+    words[j] = __ballot(t0 < t1);
+  }
+  if (lane < 4) reinterpret_cast<unsigned long long*>(descOut + (long long)k * 32)[lane] = words[lane];
+  if (lane == 0) angleOut[k] = angle;
+}
+
+__global__ void k_sincos(const float* deg, int n, float* c, float* s) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+  sincosf_glibc(deg[i] * factorPI, &s[i], &c[i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Launchers (called by the host engine).
+// ------------------------------------------------------------------------------------------------
+void launch_pyramid(const PyramidParams& P, int nframes, hipStream_t st) {
+  for (int l = 1; l < P.nlevels; l++) {
+    dim3 grid((P.lv[l].w + 255) / 256, (P.lv[l].h + 3) / 4, nframes);
+    hipLaunchKernelGGL(k_resize, grid, dim3(64, 4, 1), 0, st, P, l);
+  }
+}
+
+size_t fast_lds_bytes(const PyramidParams& P) {
+  size_t mx = 0;
+  for (int l = 0; l < P.nlevels; l++) {
+    const LevelGeom& L = P.lv[l];
+    const size_t TP = (L.wCell + 6 + 3) & ~3;
+    const size_t b = TP * (L.hCell + 6) + (size_t)(L.wCell + 2) * (L.hCell + 2) + (size_t)L.wCell * L.hCell;
+    mx = b > mx ? b : mx;
+  }
+  return (mx + 15) & ~(size_t)15;
+}
+
+void launch_detect(const PyramidParams& P, int nframes, hipStream_t st) {
+  hipLaunchKernelGGL(k_fast_cells, dim3(P.ncells, nframes), dim3(64), fast_lds_bytes(P), st, P);
+  hipLaunchKernelGGL(k_scan_cells, dim3(nframes), dim3(1024), 0, st, P);
+  hipLaunchKernelGGL(k_gather, dim3(P.ncells, nframes), dim3(64), 0, st, P);
+}
+
+void launch_describe(const PyramidParams& P, const SelKp* sel, int nsel, float* angle, uint8_t* desc,
+                     hipStream_t st) {
+  if (nsel <= 0) return;
+  hipLaunchKernelGGL(k_describe, dim3(nsel), dim3(64), 0, st, P, sel, nsel, angle, desc);
+}
+
+void launch_sincos(const float* deg, int n, float* c, float* s, hipStream_t st) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_sincos, dim3((n + 255) / 256), dim3(256), 0, st, deg, n, c, s);
+}
+
+}  // namespace orbfe

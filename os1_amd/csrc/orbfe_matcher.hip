@@ -1,0 +1,558 @@
+// orbfe_matcher.hip -- windowed 256-bit Hamming search on the GPU + the reference's sequential
+// match bookkeeping on the host.  C ABI: include/orbfe.h (matcher section).
+//
+// Behaviour contract (reference, paths relative to its src/):
+//   Frame grid + window query      Frame.cc:98-99,114-129,209-274  (64x48 grid, FRAME_GRID_* Frame.h:36-37)
+//   DescriptorDistance             ORBmatcher.cc:1605-1621
+//   SearchForInitialization        ORBmatcher.cc:400-515
+//   SearchByProjection (MapPoints) ORBmatcher.cc:45-132
+//   SearchByProjection (Frame/KF)  ORBmatcher.cc:1292-1552 (from the projection onwards)
+//   ComputeThreeMaxima             ORBmatcher.cc:1554-1595
+//
+// Split of work: every search is "for each query, scan the grid window, compare
+// descriptors, keep best/second-best" wrapped in bookkeeping that later iterations read
+// (vMatchedDistance / vnMatches21, F.mvpMapPoints occupancy).  The data-parallel part -- window
+// test, level filter and Hamming distance for every (query, candidate) pair, emitted in exactly
+// the order Frame::GetFeaturesInArea would return them -- is one kernel (one wave per query,
+// ballot-ordered compaction).  The order-dependent bookkeeping is replayed on the host over those
+// short candidate lists, statement for statement.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/orbfe.h"
+
+namespace orbfe {
+void set_err(const char* fmt, ...);
+}
+using orbfe::set_err;
+
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);    \
+      return ORBFE_ERR_HIP;                                                                  \
+    }                                                                                        \
+  } while (0)
+
+namespace {
+
+constexpr int kGridCols = 64, kGridRows = 48;  // FRAME_GRID_COLS / FRAME_GRID_ROWS (Frame.h:36-37)
+constexpr int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;  // ORBmatcher.cc:37-39
+
+struct MatchParams {
+  // train frame, keypoints permuted into grid order (cell = ix*48+iy ascending, insertion order inside)
+  const float* sx;
+  const float* sy;
+  const int* soct;
+  const int* sidx;        // original keypoint index
+  const int* cellStart;   // [64*48+1]
+  const uint8_t* tdesc;   // [n][32], ORIGINAL order
+  float minX, minY, invW, invH;
+  // queries
+  const float* qx;
+  const float* qy;
+  const float* qr;        // < 0 : inactive query
+  const int* qminL;
+  const int* qmaxL;
+  const uint8_t* qdesc;   // [nq][32]
+  int nq;
+  // outputs
+  uint32_t* qcount;       // [nq]
+  uint32_t* qoff;         // [nq] offset into pool
+  uint32_t* pool;         // entries: idx | dist << 16, reference candidate order per query
+  uint32_t poolCap;
+  uint32_t* total;        // [1] pool entries claimed (may exceed poolCap: host retries with a larger pool)
+};
+
+__device__ __forceinline__ int hamming256(const uint32_t* __restrict__ a, const uint32_t q[8]) {
+  int d = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) d += __popc(a[i] ^ q[i]);
+  return d;
+}
+
+// One wave per query.  Window semantics: Frame::GetFeaturesInArea, Frame.cc:209-262.
+__global__ __launch_bounds__(64) void k_window_match(MatchParams M) {
+  const int q = blockIdx.x;
+  const int lane = threadIdx.x;
+  const float r = M.qr[q];
+  uint32_t count = 0;
+  int cx0 = 0, cx1 = -1, cy0 = 0, cy1 = -1;
+  const float x = M.qx[q], y = M.qy[q];
+  if (r >= 0.f) {
+    cx0 = max(0, (int)floorf((x - M.minX - r) * M.invW));
+    cx1 = min(kGridCols - 1, (int)ceilf((x - M.minX + r) * M.invW));
+    cy0 = max(0, (int)floorf((y - M.minY - r) * M.invH));
+    cy1 = min(kGridRows - 1, (int)ceilf((y - M.minY + r) * M.invH));
+    if (cx0 >= kGridCols || cx1 < 0 || cy0 >= kGridRows || cy1 < 0) cx1 = cx0 - 1;  // empty
+  }
+  const int minL = M.qminL[q], maxL = M.qmaxL[q];
+  const bool checkLevels = (minL > 0) || (maxL >= 0);
+  auto inWindow = [&](int e) -> bool {
+    if (checkLevels) {
+      const int o = M.soct[e];
+      if (o < minL) return false;
+      if (maxL >= 0 && o > maxL) return false;
+    }
+    const float dx = M.sx[e] - x, dy = M.sy[e] - y;
+    return fabsf(dx) < r && fabsf(dy) < r;
+  };
+  for (int ix = cx0; ix <= cx1; ix++) {
+    const int b = M.cellStart[ix * kGridRows + cy0], e1 = M.cellStart[ix * kGridRows + cy1 + 1];
+    for (int e0 = b; e0 < e1; e0 += 64) {
+      const int e = e0 + lane;
+      const bool ok = e < e1 && inWindow(e);
+      count += __popcll(__ballot(ok));
+    }
+  }
+  uint32_t off = 0;
+  if (lane == 0) {
+    if (count) off = atomicAdd(M.total, count);
+    M.qcount[q] = count;
+    M.qoff[q] = off;
+  }
+  if (count == 0) return;
+  off = __shfl(off, 0, 64);
+  uint32_t qd[8];
+  const uint32_t* qp = reinterpret_cast<const uint32_t*>(M.qdesc + (size_t)q * 32);
+#pragma unroll
+  for (int i = 0; i < 8; i++) qd[i] = qp[i];
+  uint32_t run = 0;
+  for (int ix = cx0; ix <= cx1; ix++) {
+    const int b = M.cellStart[ix * kGridRows + cy0], e1 = M.cellStart[ix * kGridRows + cy1 + 1];
+    for (int e0 = b; e0 < e1; e0 += 64) {
+      const int e = e0 + lane;
+      const bool ok = e < e1 && inWindow(e);
+      const unsigned long long m = __ballot(ok);
+      if (ok) {
+        const int idx = M.sidx[e];
+        const int d = hamming256(reinterpret_cast<const uint32_t*>(M.tdesc + (size_t)idx * 32), qd);
+        const uint32_t pos = off + run + __popcll(m & ((1ull << lane) - 1ull));
+        if (pos < M.poolCap) M.pool[pos] = (uint32_t)idx | ((uint32_t)d << 16);
+      }
+      run += __popcll(m);
+    }
+  }
+}
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  int ensure(size_t count) {
+    if (count <= n) return ORBFE_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr; n = 0;
+    HIP_TRY(hipMalloc((void**)&p, count * sizeof(T)));
+    n = count;
+    return ORBFE_OK;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+template <class T>
+struct PinBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  int ensure(size_t count) {
+    if (count <= n) return ORBFE_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; n = 0;
+    HIP_TRY(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault));
+    n = count;
+    return ORBFE_OK;
+  }
+  void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
+};
+
+inline size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
+
+void computeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3) {
+  int max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < L; i++) {
+    const int s = (int)histo[i].size();
+    if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+    else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+    else if (s > max3) { max3 = s; ind3 = i; }
+  }
+  if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+  else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+inline int rotBin(float a1, float a2) {  // ORBmatcher.cc:470-475 (factor = 1/HISTO_LENGTH quirk kept)
+  const float factor = 1.0f / HISTO_LENGTH;
+  float rot = a1 - a2;
+  if (rot < 0.0) rot += 360.0f;
+  int bin = (int)roundf(rot * factor);
+  if (bin == HISTO_LENGTH) bin = 0;
+  return bin;
+}
+
+}  // namespace
+
+struct orbfe_matcher {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  DevBuf<uint8_t> d_in;    // packed upload arena
+  PinBuf<uint8_t> h_in;
+  DevBuf<uint32_t> d_out;  // [total(1) pad][qcount nq][qoff nq]
+  PinBuf<uint32_t> h_out;
+  DevBuf<uint32_t> d_pool;
+  PinBuf<uint32_t> h_pool;
+  std::vector<int> cellOf, cellCnt, order;
+
+  ~orbfe_matcher() {
+    (void)hipSetDevice(device);
+    d_in.release(); h_in.release(); d_out.release(); h_out.release(); d_pool.release(); h_pool.release();
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+
+  // Runs the window kernel.  After return: h_out.p = [total, pad.., qcount[nq], qoff[nq]], h_pool.p = entries.
+  const uint32_t* qcount = nullptr;
+  const uint32_t* qoff = nullptr;
+
+  int candidates(const OrbfeKeyPoint* kps, const uint8_t* desc, int n, const float bounds[4], const float* qx,
+                 const float* qy, const float* qr, const int* qminL, const int* qmaxL, const uint8_t* qdesc, int nq) {
+    HIP_TRY(hipSetDevice(device));
+    int rc;
+    const float minX = bounds[0], maxX = bounds[1], minY = bounds[2], maxY = bounds[3];
+    const float invW = static_cast<float>(kGridCols) / static_cast<float>(maxX - minX);   // Frame.cc:98
+    const float invH = static_cast<float>(kGridRows) / static_cast<float>(maxY - minY);   // Frame.cc:99
+    const int ncell = kGridCols * kGridRows;
+    // AssignFeaturesToGrid / PosInGrid (Frame.cc:114-129, 264-274): stable counting sort by cell
+    cellOf.resize(n);
+    cellCnt.assign(ncell + 1, 0);
+    int ngrid = 0;
+    for (int i = 0; i < n; i++) {
+      const int px = (int)roundf((kps[i].x - minX) * invW);
+      const int py = (int)roundf((kps[i].y - minY) * invH);
+      if (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) { cellOf[i] = -1; continue; }
+      cellOf[i] = px * kGridRows + py;
+      cellCnt[cellOf[i] + 1]++;
+      ngrid++;
+    }
+    for (int c = 0; c < ncell; c++) cellCnt[c + 1] += cellCnt[c];
+    // arena layout
+    const size_t oSx = 0, oSy = oSx + al(4 * (size_t)ngrid), oOct = oSy + al(4 * (size_t)ngrid),
+                 oIdx = oOct + al(4 * (size_t)ngrid), oCell = oIdx + al(4 * (size_t)ngrid),
+                 oTd = oCell + al(4 * (size_t)(ncell + 1)), oQx = oTd + al(32 * (size_t)n),
+                 oQy = oQx + al(4 * (size_t)nq), oQr = oQy + al(4 * (size_t)nq), oQa = oQr + al(4 * (size_t)nq),
+                 oQb = oQa + al(4 * (size_t)nq), oQd = oQb + al(4 * (size_t)nq), total = oQd + al(32 * (size_t)nq);
+    if ((rc = h_in.ensure(total))) return rc;
+    if ((rc = d_in.ensure(total))) return rc;
+    uint8_t* H = h_in.p;
+    float* sx = (float*)(H + oSx);
+    float* sy = (float*)(H + oSy);
+    int* so = (int*)(H + oOct);
+    int* si = (int*)(H + oIdx);
+    memcpy(H + oCell, cellCnt.data(), 4 * (size_t)(ncell + 1));
+    order.assign(cellCnt.begin(), cellCnt.end() - 1);
+    for (int i = 0; i < n; i++) {
+      if (cellOf[i] < 0) continue;
+      const int p = order[cellOf[i]]++;
+      sx[p] = kps[i].x; sy[p] = kps[i].y; so[p] = kps[i].octave; si[p] = i;
+    }
+    memcpy(H + oTd, desc, 32 * (size_t)n);
+    memcpy(H + oQx, qx, 4 * (size_t)nq);
+    memcpy(H + oQy, qy, 4 * (size_t)nq);
+    memcpy(H + oQr, qr, 4 * (size_t)nq);
+    memcpy(H + oQa, qminL, 4 * (size_t)nq);
+    memcpy(H + oQb, qmaxL, 4 * (size_t)nq);
+    memcpy(H + oQd, qdesc, 32 * (size_t)nq);
+    HIP_TRY(hipMemcpyAsync(d_in.p, H, total, hipMemcpyHostToDevice, stream));
+
+    const size_t outWords = 64 + 2 * (size_t)nq;
+    if ((rc = d_out.ensure(outWords))) return rc;
+    if ((rc = h_out.ensure(outWords))) return rc;
+    size_t poolCap = d_pool.n ? d_pool.n : (size_t)std::max(1 << 16, nq * 32);
+    for (int attempt = 0; attempt < 2; attempt++) {
+      if ((rc = d_pool.ensure(poolCap))) return rc;
+      HIP_TRY(hipMemsetAsync(d_out.p, 0, 64 * sizeof(uint32_t), stream));
+      MatchParams M;
+      uint8_t* D = d_in.p;
+      M.sx = (const float*)(D + oSx); M.sy = (const float*)(D + oSy); M.soct = (const int*)(D + oOct);
+      M.sidx = (const int*)(D + oIdx); M.cellStart = (const int*)(D + oCell); M.tdesc = D + oTd;
+      M.minX = minX; M.minY = minY; M.invW = invW; M.invH = invH;
+      M.qx = (const float*)(D + oQx); M.qy = (const float*)(D + oQy); M.qr = (const float*)(D + oQr);
+      M.qminL = (const int*)(D + oQa); M.qmaxL = (const int*)(D + oQb); M.qdesc = D + oQd;
+      M.nq = nq;
+      M.total = d_out.p; M.qcount = d_out.p + 64; M.qoff = d_out.p + 64 + nq;
+      M.pool = d_pool.p; M.poolCap = (uint32_t)d_pool.n;
+      if (nq > 0) hipLaunchKernelGGL(k_window_match, dim3(nq), dim3(64), 0, stream, M);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipMemcpyAsync(h_out.p, d_out.p, outWords * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+      HIP_TRY(hipStreamSynchronize(stream));
+      const size_t tot = h_out.p[0];
+      if (tot <= d_pool.n) {
+        if ((rc = h_pool.ensure(tot + 1))) return rc;
+        if (tot) {
+          HIP_TRY(hipMemcpyAsync(h_pool.p, d_pool.p, tot * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+          HIP_TRY(hipStreamSynchronize(stream));
+        }
+        qcount = h_out.p + 64;
+        qoff = h_out.p + 64 + nq;
+        return ORBFE_OK;
+      }
+      poolCap = tot;  // pool too small: grow to the exact demand and rerun once
+    }
+    set_err("candidate pool sizing failed");
+    return ORBFE_ERR_HIP;
+  }
+};
+
+extern "C" {
+
+int orbfe_hamming(const uint8_t a[32], const uint8_t b[32]) {
+  int d = 0;
+  for (int i = 0; i < 4; i++) {
+    uint64_t x, y;
+    memcpy(&x, a + 8 * i, 8);
+    memcpy(&y, b + 8 * i, 8);
+    d += __builtin_popcountll(x ^ y);
+  }
+  return d;
+}
+
+int orbfe_matcher_create(int device_id, orbfe_matcher** out) {
+  if (!out) { set_err("out is NULL"); return ORBFE_ERR_INVALID; }
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) {
+    set_err("no usable HIP device (count=%d, requested %d): this library has no CPU fallback", ndev, device_id);
+    return ORBFE_ERR_NO_DEVICE;
+  }
+  HIP_TRY(hipSetDevice(device_id));
+  orbfe_matcher* m = new orbfe_matcher();
+  m->device = device_id;
+  hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    set_err("hipStreamCreate failed: %s", hipGetErrorString(e));
+    delete m;
+    return ORBFE_ERR_HIP;
+  }
+  *out = m;
+  return ORBFE_OK;
+}
+
+void orbfe_matcher_destroy(orbfe_matcher* m) { delete m; }
+
+int orbfe_debug_features_in_area(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, int n, const float bounds[4], float x,
+                                 float y, float r, int min_level, int max_level, int32_t* out, int cap, int* n_out) {
+  if (!m || !kps_un || !bounds || !n_out || n < 0) { set_err("bad argument"); return ORBFE_ERR_INVALID; }
+  std::vector<uint8_t> zdesc((size_t)std::max(n, 1) * 32, 0), qd(32, 0);
+  int rc = m->candidates(kps_un, zdesc.data(), n, bounds, &x, &y, &r, &min_level, &max_level, qd.data(), 1);
+  if (rc) return rc;
+  const int c = (int)m->qcount[0];
+  *n_out = c;
+  for (int i = 0; i < c && i < cap; i++) out[i] = (int)(m->h_pool.p[m->qoff[0] + i] & 0xffff);
+  return ORBFE_OK;
+}
+
+int orbfe_search_for_initialization(orbfe_matcher* m, const OrbfeKeyPoint* kps1, const uint8_t* desc1, int n1,
+                                    const OrbfeKeyPoint* kps2, const uint8_t* desc2, int n2, const float bounds[4],
+                                    float* prev_xy, int32_t* matches12, int window_size, float nnratio,
+                                    int check_orientation, int* nmatches) {
+  if (!m || !nmatches || n1 < 0 || n2 < 0 || n2 > 65535 || (n1 && (!kps1 || !desc1 || !prev_xy || !matches12)) ||
+      (n2 && (!kps2 || !desc2)) || !bounds) {
+    set_err("bad argument (note: at most 65535 keypoints per frame)");
+    return ORBFE_ERR_INVALID;
+  }
+  *nmatches = 0;
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  if (n1 == 0) return ORBFE_OK;
+  // queries: level-0 keypoints of F1, window centred on vbPrevMatched (ORBmatcher.cc:413-420)
+  std::vector<float> qx(n1), qy(n1), qr(n1);
+  std::vector<int> qa(n1), qb(n1);
+  for (int i = 0; i < n1; i++) {
+    const int level1 = kps1[i].octave;
+    qx[i] = prev_xy[2 * i];
+    qy[i] = prev_xy[2 * i + 1];
+    qr[i] = level1 > 0 ? -1.f : (float)window_size;
+    qa[i] = level1;
+    qb[i] = level1;
+  }
+  int rc = m->candidates(kps2, desc2, n2, bounds, qx.data(), qy.data(), qr.data(), qa.data(), qb.data(), desc1, n1);
+  if (rc) return rc;
+  const uint32_t* pool = m->h_pool.p;
+  // sequential bookkeeping, ORBmatcher.cc:402-512
+  int nm = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  std::vector<int> vMatchedDistance(n2, INT_MAX), vnMatches21(n2, -1);
+  for (int i1 = 0; i1 < n1; i1++) {
+    if (kps1[i1].octave > 0) continue;
+    const uint32_t cnt = m->qcount[i1];
+    if (cnt == 0) continue;
+    const uint32_t* cl = pool + m->qoff[i1];
+    int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+    for (uint32_t c = 0; c < cnt; c++) {
+      const int i2 = (int)(cl[c] & 0xffff), dist = (int)(cl[c] >> 16);
+      if (vMatchedDistance[i2] <= dist) continue;
+      if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+      else if (dist < bestDist2) { bestDist2 = dist; }
+    }
+    if (bestDist <= TH_LOW) {
+      if (bestDist < (float)bestDist2 * nnratio) {
+        if (vnMatches21[bestIdx2] >= 0) { matches12[vnMatches21[bestIdx2]] = -1; nm--; }
+        matches12[i1] = bestIdx2;
+        vnMatches21[bestIdx2] = i1;
+        vMatchedDistance[bestIdx2] = bestDist;
+        nm++;
+        if (check_orientation) rotHist[rotBin(kps1[i1].angle, kps2[bestIdx2].angle)].push_back(i1);
+      }
+    }
+  }
+  if (check_orientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    computeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (int idx1 : rotHist[i])
+        if (matches12[idx1] >= 0) { matches12[idx1] = -1; nm--; }
+    }
+  }
+  for (int i1 = 0; i1 < n1; i1++)
+    if (matches12[i1] >= 0) {
+      prev_xy[2 * i1] = kps2[matches12[i1]].x;
+      prev_xy[2 * i1 + 1] = kps2[matches12[i1]].y;
+    }
+  *nmatches = nm;
+  return ORBFE_OK;
+}
+
+int orbfe_search_by_projection(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, const uint8_t* desc, int n,
+                               const float bounds[4], const float* scale_factors, int nlevels,
+                               const uint8_t* kp_occupied, const float* mp_proj_xy, const int32_t* mp_level,
+                               const float* mp_viewcos, const uint8_t* mp_flags, const uint8_t* mp_desc, int n_mp,
+                               float th, float nnratio, int32_t* kp_assigned, int* nmatches) {
+  if (!m || !nmatches || n < 0 || n > 65535 || n_mp < 0 || !bounds || !scale_factors ||
+      (n && (!kps_un || !desc || !kp_occupied || !kp_assigned)) ||
+      (n_mp && (!mp_proj_xy || !mp_level || !mp_viewcos || !mp_flags || !mp_desc))) {
+    set_err("bad argument (note: at most 65535 keypoints per frame)");
+    return ORBFE_ERR_INVALID;
+  }
+  *nmatches = 0;
+  for (int i = 0; i < n; i++) kp_assigned[i] = -1;
+  if (n_mp == 0 || n == 0) return ORBFE_OK;
+  const bool bFactor = th != 1.0;
+  std::vector<float> qr(n_mp);
+  std::vector<float> qx(n_mp), qy(n_mp);
+  std::vector<int> qa(n_mp), qb(n_mp);
+  for (int i = 0; i < n_mp; i++) {
+    const uint8_t fl = mp_flags[i];
+    qx[i] = mp_proj_xy[2 * i];
+    qy[i] = mp_proj_xy[2 * i + 1];
+    const int lvl = mp_level[i];
+    qa[i] = lvl - 1;
+    qb[i] = lvl;
+    if (!(fl & ORBFE_MP_IN_VIEW) || (fl & ORBFE_MP_BAD)) { qr[i] = -1.f; continue; }
+    if (lvl < 0 || lvl >= nlevels) { set_err("MapPoint %d: level %d out of range", i, lvl); return ORBFE_ERR_INVALID; }
+    float r = (fl & ORBFE_MP_CANDIDATO) ? 4.0 : (mp_viewcos[i] > 0.998 ? 2.5 : 4.0);  // ORBmatcher.cc:63-65,126-132
+    if (bFactor) r *= th;
+    qr[i] = r * scale_factors[lvl];
+  }
+  int rc = m->candidates(kps_un, desc, n, bounds, qx.data(), qy.data(), qr.data(), qa.data(), qb.data(), mp_desc, n_mp);
+  if (rc) return rc;
+  const uint32_t* pool = m->h_pool.p;
+  std::vector<uint8_t> occ(kp_occupied, kp_occupied + n);
+  int nm = 0;
+  for (int iMP = 0; iMP < n_mp; iMP++) {
+    if (qr[iMP] < 0.f) continue;
+    const uint32_t cnt = m->qcount[iMP];
+    if (cnt == 0) continue;
+    const uint32_t* cl = pool + m->qoff[iMP];
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (uint32_t c = 0; c < cnt; c++) {
+      const int idx = (int)(cl[c] & 0xffff), dist = (int)(cl[c] >> 16);
+      if (occ[idx]) continue;
+      if (dist < bestDist) {
+        bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel;
+        bestLevel = kps_un[idx].octave; bestIdx = idx;
+      } else if (dist < bestDist2) {
+        bestLevel2 = kps_un[idx].octave; bestDist2 = dist;
+      }
+    }
+    if (bestDist <= TH_HIGH) {
+      if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+      kp_assigned[bestIdx] = iMP;
+      occ[bestIdx] = (mp_flags[iMP] & ORBFE_MP_OBSERVED) ? 1 : 0;
+      nm++;
+    }
+  }
+  *nmatches = nm;
+  return ORBFE_OK;
+}
+
+int orbfe_search_by_projection_uv(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, const uint8_t* desc, int n,
+                                  const float bounds[4], const float* scale_factors, int nlevels,
+                                  const uint8_t* kp_occupied, const float* src_uv, const int32_t* src_level,
+                                  const float* src_angle, const uint8_t* src_flags, const uint8_t* src_valid,
+                                  const uint8_t* src_desc, int n_src, float th, int max_dist, int skip_any_occupied,
+                                  int check_orientation, int32_t* kp_assigned, int* nmatches) {
+  if (!m || !nmatches || n < 0 || n > 65535 || n_src < 0 || !bounds || !scale_factors ||
+      (n && (!kps_un || !desc || !kp_occupied || !kp_assigned)) ||
+      (n_src && (!src_uv || !src_level || !src_angle || !src_flags || !src_valid || !src_desc))) {
+    set_err("bad argument (note: at most 65535 keypoints per frame)");
+    return ORBFE_ERR_INVALID;
+  }
+  *nmatches = 0;
+  for (int i = 0; i < n; i++) kp_assigned[i] = -1;
+  if (n_src == 0 || n == 0) return ORBFE_OK;
+  std::vector<float> qx(n_src), qy(n_src), qr(n_src);
+  std::vector<int> qa(n_src), qb(n_src);
+  for (int i = 0; i < n_src; i++) {
+    qx[i] = src_uv[2 * i];
+    qy[i] = src_uv[2 * i + 1];
+    const int lvl = src_level[i];
+    qa[i] = lvl - 1;
+    qb[i] = lvl + 1;
+    if (!src_valid[i]) { qr[i] = -1.f; continue; }
+    if (lvl < 0 || lvl >= nlevels) { set_err("source %d: level %d out of range", i, lvl); return ORBFE_ERR_INVALID; }
+    qr[i] = th * scale_factors[lvl];
+  }
+  int rc = m->candidates(kps_un, desc, n, bounds, qx.data(), qy.data(), qr.data(), qa.data(), qb.data(), src_desc, n_src);
+  if (rc) return rc;
+  const uint32_t* pool = m->h_pool.p;
+  std::vector<uint8_t> occ(kp_occupied, kp_occupied + n);
+  std::vector<int> rotHist[HISTO_LENGTH];
+  int nm = 0;
+  for (int i = 0; i < n_src; i++) {
+    if (qr[i] < 0.f) continue;
+    const uint32_t cnt = m->qcount[i];
+    if (cnt == 0) continue;
+    const uint32_t* cl = pool + m->qoff[i];
+    int bestDist = 256, bestIdx2 = -1;
+    for (uint32_t c = 0; c < cnt; c++) {
+      const int i2 = (int)(cl[c] & 0xffff), dist = (int)(cl[c] >> 16);
+      if (occ[i2]) continue;
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+    }
+    if (bestDist <= max_dist) {
+      kp_assigned[bestIdx2] = i;
+      occ[bestIdx2] = skip_any_occupied ? 1 : ((src_flags[i] & ORBFE_MP_OBSERVED) ? 1 : 0);
+      nm++;
+      if (check_orientation) rotHist[rotBin(src_angle[i], kps_un[bestIdx2].angle)].push_back(bestIdx2);
+    }
+  }
+  if (check_orientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    computeThreeMaxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i != ind1 && i != ind2 && i != ind3) {
+        for (int idx : rotHist[i]) {
+          kp_assigned[idx] = -2;
+          nm--;
+        }
+      }
+    }
+  }
+  *nmatches = nm;
+  return ORBFE_OK;
+}
+
+}  // extern "C"

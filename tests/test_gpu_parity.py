@@ -1,0 +1,224 @@
+"""-m gpu: the HIP path, called through the C ABI, against the CPU oracle -- bit-exact."""
+import numpy as np
+import pytest
+
+from oracle.pyoracle import OracleExtractor
+from os1_amd.synth import shifted, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def api():
+    from os1_amd import api as a
+    assert a.device_count() >= 1, 'no GPU visible: the product has no CPU fallback'
+    return a
+
+
+def _cmp_extract(got, want):
+    (gk, gd), (wk, wd) = got, want
+    assert len(gk) == len(wk), (len(gk), len(wk))
+    for f in gk.dtype.names:
+        assert (gk[f] == wk[f]).all(), f
+    assert gk.tobytes() == wk.tobytes()
+    assert gd.tobytes() == wd.tobytes()
+
+
+@pytest.mark.parametrize('cfg', [(1, 640, 480, 1000), (11, 752, 480, 500), (2, 1920, 1080, 2000)])
+def test_stages_and_extract_bit_exact(api, oracle, cfg):
+    seed, W, H, N = cfg
+    img = synth(seed, W, H)
+    ex = api.Extractor(N, 1.2, 8, 20, 7)
+    ox = OracleExtractor(N, 1.2, 8, 20, 7, oracle)
+    got = ex(img)
+    want = ox.extract(img)
+    t, ot = ex.tables(), ox.tables()
+    for k in ('sf', 'isf', 's2', 'is2', 'nfeat'):
+        assert (t[k] == ot[k]).all()
+    total = 0
+    for l in range(8):
+        assert (ex.level(l) == ox.level(l)).all(), 'pyramid level %d' % l
+        c, oc = ex.candidates(l), ox.candidates(l)
+        assert len(c) == len(oc), 'level %d candidate count' % l
+        assert (c[:, 0] == oc['x']).all() and (c[:, 1] == oc['y']).all() and (c[:, 2] == oc['response']).all()
+        total += len(c)
+    assert total >= 10 * N            # the quadtree actually saturates
+    _cmp_extract(got, want)
+    assert len(got[0]) >= N * 0.95
+
+
+def test_batch_device_input_and_strides(api, oracle):
+    import torch
+    imgs = [synth(20 + i, 800, 600) for i in range(3)]
+    ex = api.Extractor(800, 1.2, 8, 20, 7)
+    ox = OracleExtractor(800, 1.2, 8, 20, 7, oracle)
+    want = [ox.extract(im) for im in imgs]
+    for g, w in zip(ex.extract_batch(imgs), want):
+        _cmp_extract(g, w)
+    # frames already resident in HBM, with a row stride larger than the width
+    dev = torch.zeros((3, 600, 832), dtype=torch.uint8, device='cuda:0')
+    for i, im in enumerate(imgs):
+        dev[i, :, :800] = torch.from_numpy(im).cuda()
+    torch.cuda.synchronize()
+    kps, desc, n = ex.extract_batch_ptrs([dev[i].data_ptr() for i in range(3)], 600, 800, 832, True)
+    for i in range(3):
+        _cmp_extract((kps[i, :n[i]], desc[i, :n[i]]), want[i])
+    # host image with a padded stride (a ROI view)
+    big = np.zeros((600, 900), np.uint8)
+    big[:, 50:850] = imgs[0]
+    _cmp_extract(ex(big[:, 50:850]), want[0])
+    # changing the image size on the same handle
+    img2 = synth(5, 512, 384)
+    _cmp_extract(ex(img2), ox.extract(img2))
+
+
+def test_other_parameters(api, oracle):
+    img = synth(7, 960, 540)
+    for (N, sf, nl, ini, mn) in [(1500, 1.2, 8, 20, 7), (300, 1.5, 4, 30, 10), (1000, 1.1, 6, 12, 5), (50, 1.2, 3, 40, 40)]:
+        _cmp_extract(api.Extractor(N, sf, nl, ini, mn)(img), OracleExtractor(N, sf, nl, ini, mn, oracle).extract(img))
+
+
+def test_edge_cases(api, oracle):
+    ex = api.Extractor(500, 1.2, 8, 20, 7)
+    k, d = ex(np.zeros((0, 0), np.uint8))                       # empty image: silent, no output
+    assert len(k) == 0 and d.shape == (0, 32)
+    flat = np.full((480, 640), 77, np.uint8)                     # no corners anywhere
+    k, d = ex(flat)
+    assert len(k) == 0
+    ko, _ = OracleExtractor(500, 1.2, 8, 20, 7, oracle).extract(flat)
+    assert len(ko) == 0
+    with pytest.raises(api.OrbfeError) as e:                     # a level without a FAST cell
+        ex(np.zeros((120, 160), np.uint8))
+    assert e.value.code == -4
+    # low-contrast frame: every cell falls back to minThFAST
+    rng = np.random.default_rng(3)
+    low = (120 + rng.integers(0, 12, (480, 640))).astype(np.uint8)
+    _cmp_extract(ex(low), OracleExtractor(500, 1.2, 8, 20, 7, oracle).extract(low))
+    # hard-edged checkerboard: dense, highly tied scores
+    yy, xx = np.mgrid[0:480, 0:640]
+    chk = (((yy // 9) + (xx // 7)) % 2 * 200 + 20).astype(np.uint8)
+    _cmp_extract(ex(chk), OracleExtractor(500, 1.2, 8, 20, 7, oracle).extract(chk))
+    # saturated noise: maximum candidate density
+    noise = rng.integers(0, 256, (480, 640), dtype=np.uint8)
+    _cmp_extract(ex(noise), OracleExtractor(500, 1.2, 8, 20, 7, oracle).extract(noise))
+
+
+def test_device_sincos_matches_host_libm(api, oracle):
+    ex = api.Extractor(100, 1.2, 8, 20, 7)
+    rng = np.random.default_rng(0)
+    ang = np.concatenate([rng.uniform(0, 360, 2_000_000), np.arange(0, 360, 0.25), [0.0, 1e-4, 359.99997]]).astype(np.float32)
+    c, s = ex.sincos(ang)
+    rad = (ang * np.float32(np.pi / 180.0)).astype(np.float32)
+    import ctypes
+    libm = ctypes.CDLL('libm.so.6')
+    libm.cosf.restype = libm.sinf.restype = ctypes.c_float
+    libm.cosf.argtypes = libm.sinf.argtypes = [ctypes.c_float]
+    idx = rng.choice(len(ang), 20000, replace=False)
+    for i in idx:
+        assert c[i] == np.float32(libm.cosf(float(rad[i]))) and s[i] == np.float32(libm.sinf(float(rad[i])))
+    # and the whole array against the oracle's host evaluation of the reference expression on a subset
+    for i in idx[:2000]:
+        a, b = oracle.sincos(float(ang[i]))
+        assert c[i] == np.float32(a) and s[i] == np.float32(b)
+
+
+def _frames(api, oracle, W=1920, H=1080, N=2000, seed=3):
+    A = synth(seed, W, H)
+    B = shifted(A, -24, 3, seed)
+    ex = api.Extractor(N, 1.2, 8, 20, 7)
+    return ex, ex(A), ex(B), (0.0, float(W), 0.0, float(H))
+
+
+def test_search_for_initialization_parity(api, oracle):
+    ex, (k1, d1), (k2, d2), bounds = _frames(api, oracle)
+    m = api.Matcher()
+    prev = np.stack([k1['x'], k1['y']], 1)
+    for window, ratio, ori in [(100, 0.9, True), (100, 0.9, False), (10, 0.6, True), (300, 0.95, True)]:
+        n, m12, p = m.search_for_initialization(k1, d1, k2, d2, bounds, prev, window, ratio, ori)
+        on, om12, op = oracle.search_for_initialization(k1, d1, k2, d2, bounds, prev, window, ratio, ori)
+        assert n == on and (m12 == om12).all() and p.tobytes() == op.tobytes()
+    n, m12, p = m.search_for_initialization(k1, d1, k2, d2, bounds, prev, 100, 0.9, True)
+    assert n > 100                                     # the shifted pair really matches
+    good = m12 >= 0
+    dx = k2['x'][m12[good]] - k1['x'][good]
+    assert abs(np.median(dx) + 24) <= 1.0
+    # second round with the updated vbPrevMatched (Tracking.cc:384 keeps calling with it)
+    n2, m12b, p2 = m.search_for_initialization(k1, d1, k2, d2, bounds, p, 100, 0.9, True)
+    on2, om12b, op2 = oracle.search_for_initialization(k1, d1, k2, d2, bounds, p, 100, 0.9, True)
+    assert n2 == on2 and (m12b == om12b).all() and p2.tobytes() == op2.tobytes()
+    # empty / degenerate inputs
+    n0, m0, _ = m.search_for_initialization(k1[:0], d1[:0], k2, d2, bounds, prev[:0])
+    assert n0 == 0 and len(m0) == 0
+    n0, m0, _ = m.search_for_initialization(k1, d1, k2[:0], d2[:0], bounds, prev)
+    assert n0 == 0 and (m0 == -1).all()
+
+
+def test_get_features_in_area_parity(api, oracle):
+    ex, (k1, d1), _, bounds = _frames(api, oracle, 1280, 720, 1500, 8)
+    m = api.Matcher()
+    rng = np.random.default_rng(1)
+    for _ in range(60):
+        x, y = float(rng.uniform(-50, 1330)), float(rng.uniform(-50, 770))
+        r = float(rng.choice([1.0, 2.5, 4.0, 15.0, 100.0, 5000.0]))
+        lo, hi = [(-1, -1), (0, 0), (0, 3), (2, 3), (3, -1), (7, 7)][rng.integers(6)]
+        got = m.get_features_in_area(k1, bounds, x, y, r, lo, hi)
+        want = oracle.get_features_in_area(k1, bounds, x, y, r, lo, hi)
+        assert got.tolist() == want.tolist()
+    # undistorted (fisheye) bounds that do not start at zero
+    b2 = (-211.5, 1500.25, -80.0, 799.0)
+    for _ in range(20):
+        x, y, r = float(rng.uniform(0, 1280)), float(rng.uniform(0, 720)), float(rng.uniform(1, 60))
+        assert m.get_features_in_area(k1, b2, x, y, r, -1, -1).tolist() == \
+            oracle.get_features_in_area(k1, b2, x, y, r, -1, -1).tolist()
+
+
+def _mappoints(k, d, n_mp, rng):
+    src = rng.integers(0, len(k), n_mp)
+    desc = d[src].copy()
+    for i in range(n_mp):                                   # 0-40 random bit flips
+        for b in rng.integers(0, 256, rng.integers(0, 41)):
+            desc[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    xy = np.stack([k['x'][src], k['y'][src]], 1) + rng.uniform(-3, 3, (n_mp, 2)).astype(np.float32)
+    level = np.minimum(k['octave'][src] + rng.integers(0, 2, n_mp), 7).astype(np.int32)
+    viewcos = rng.uniform(0.9, 1.0, n_mp).astype(np.float32)
+    flags = np.full(n_mp, 1 | 8, np.uint8)
+    flags[rng.random(n_mp) < 0.02] |= 2                      # 2 % bad
+    flags[rng.random(n_mp) < 0.05] &= ~np.uint8(1)           # some not in view
+    flags[rng.random(n_mp) < 0.05] |= 4                      # plCandidato
+    flags[rng.random(n_mp) < 0.1] &= ~np.uint8(8)            # no observations yet
+    return xy.astype(np.float32), level, viewcos, flags, desc
+
+
+def test_search_by_projection_parity(api, oracle):
+    ex, (k, d), _, bounds = _frames(api, oracle, 1920, 1080, 2000, 12)
+    sf = ex.tables()['sf']
+    m = api.Matcher()
+    rng = np.random.default_rng(2)
+    xy, level, viewcos, flags, mdesc = _mappoints(k, d, 5000, rng)
+    occ = (rng.random(len(k)) < 0.1).astype(np.uint8)
+    for th, ratio in [(1.0, 0.8), (5.0, 0.8), (3.0, 0.6)]:
+        n, a = m.search_by_projection(k, d, bounds, sf, occ, xy, level, viewcos, flags, mdesc, th, ratio)
+        on, oa = oracle.search_by_projection(k, d, bounds, sf, occ, xy, level, viewcos, flags, mdesc, th, ratio)
+        assert n == on and (a == oa).all()
+        assert n > 500
+    n, a = m.search_by_projection(k, d, bounds, sf, occ, xy[:0], level[:0], viewcos[:0], flags[:0], mdesc[:0], 1.0, 0.8)
+    assert n == 0 and (a == -1).all()
+
+
+def test_search_by_projection_uv_parity(api, oracle):
+    ex, (k1, d1), (k2, d2), bounds = _frames(api, oracle, 1280, 720, 1500, 21)
+    sf = ex.tables()['sf']
+    m = api.Matcher()
+    rng = np.random.default_rng(4)
+    # "last frame" = frame 1: every keypoint with a MapPoint projects to its position shifted by (-24,+3)
+    uv = np.stack([k1['x'] - 24 + rng.uniform(-2, 2, len(k1)), k1['y'] + 3 + rng.uniform(-2, 2, len(k1))], 1).astype(np.float32)
+    valid = (rng.random(len(k1)) < 0.8).astype(np.uint8)
+    sflags = np.where(rng.random(len(k1)) < 0.9, 8, 0).astype(np.uint8)
+    occ = (rng.random(len(k2)) < 0.05).astype(np.uint8)
+    for th, maxd, skip_any, ori in [(15.0, 100, 0, True), (30.0, 100, 0, False), (10.0, 64, 1, True), (3.0, 100, 1, True)]:
+        n, a = m.search_by_projection_uv(k2, d2, bounds, sf, occ, uv, k1['octave'], k1['angle'], sflags, valid, d1,
+                                         th, maxd, skip_any, ori)
+        on, oa = oracle.search_by_projection_uv(k2, d2, bounds, sf, occ, uv, k1['octave'], k1['angle'], sflags, valid,
+                                                d1, th, maxd, skip_any, ori)
+        assert n == on and (a == oa).all()
+    assert n > 50

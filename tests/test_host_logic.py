@@ -1,0 +1,70 @@
+"""Host-side product logic that needs no GPU, checked against the oracle: the quadtree and the
+(cosf,sinf) restatement the rBRIEF kernel uses."""
+import numpy as np
+import pytest
+
+from oracle.pyoracle import KP_DTYPE, OracleExtractor
+from os1_amd import api
+from os1_amd.synth import synth
+
+
+def _as_kps(x, y, s):
+    k = np.zeros(len(x), KP_DTYPE)
+    k['x'], k['y'], k['response'], k['size'], k['angle'], k['class_id'] = x, y, s, 7, -1, -1
+    return k
+
+
+def _same(oracle, x, y, s, box, N):
+    want = oracle.distribute_octtree(_as_kps(x, y, s), box[0], box[1], box[2], box[3], N)
+    got = api.quadtree(x, y, s, box[0], box[1], box[2], box[3], N)
+    assert len(got) == len(want)
+    assert (x[got] == want['x']).all() and (y[got] == want['y']).all() and (s[got] == want['response']).all()
+    return len(got)
+
+
+def test_quadtree_on_real_candidates(oracle):
+    img = synth(1, 640, 480)
+    ex = OracleExtractor(1000, 1.2, 8, 20, 7, oracle)
+    ex.extract(img)
+    nf = ex.tables()['nfeat']
+    for l in range(8):
+        c = ex.candidates(l)
+        h, w = ex.level(l).shape
+        x, y, s = c['x'].astype(np.int16), c['y'].astype(np.int16), c['response'].astype(np.uint8)
+        for N in (int(nf[l]), 1, 7, 50, 100000):
+            _same(oracle, x, y, s, (16, w - 16, 16, h - 16), N)
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_quadtree_random(oracle, seed):
+    rng = np.random.default_rng(seed)
+    W, H = [(608, 448), (1888, 1048), (300, 900), (200, 130)][seed % 4]
+    n = int(rng.integers(1, 6000))
+    # distinct integer positions, reference order is irrelevant for the tree itself
+    pos = rng.choice(W * H, size=min(n, W * H), replace=False)
+    x, y = (pos % W).astype(np.int16), (pos // W).astype(np.int16)
+    s = rng.integers(7, 40 if seed % 2 else 255, len(x)).astype(np.uint8)    # many response ties
+    if W < H and round(W / H) == 0:
+        pytest.skip('nIni == 0: the reference divides by zero here')
+    for N in (1, 13, 200, 1000, 10 ** 6):
+        k = _same(oracle, x, y, s, (16, 16 + W, 16, 16 + H), N)
+        assert k <= max(N + 3, 4) or k <= len(x)
+
+
+def test_quadtree_edge_cases(oracle):
+    e = np.zeros(0, np.int16)
+    assert len(api.quadtree(e, e, e.astype(np.uint8), 16, 624, 16, 464, 100)) == 0
+    one = np.array([5], np.int16)
+    assert api.quadtree(one, one, np.array([9], np.uint8), 16, 624, 16, 464, 100).tolist() == [0]
+    # clustered points (all in one corner), forcing deep subdivision
+    rng = np.random.default_rng(99)
+    pos = rng.choice(40 * 40, 500, replace=False)
+    x, y = (pos % 40).astype(np.int16), (pos // 40).astype(np.int16)
+    s = rng.integers(7, 255, 500).astype(np.uint8)
+    _same(oracle, x, y, s, (16, 1904, 16, 1064), 434)
+
+
+def test_sincos_restatement_matches_libm_exhaustively():
+    # every float in [0, 6.3] (the rBRIEF argument is angle*pi/180 in [0, 2*pi)): bitwise equal to libm
+    hi = int(np.float32(6.3).view(np.uint32))
+    assert api.sincos_host_mismatches(0, hi, 1) == 0
