@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of the ORB front end (extract + match) on N MI355X GPUs of one node.
+
+Metric (BASELINE.json): frames/sec extract+match, 1920x1080 @ 2000 ORB features, 8 levels, 1.2.
+A "step" is one pass of the hot path over one batch of B synthetic frames of a seeded stream:
+ORBextractor::operator() on every frame (orbfe_extract_batch, frames already resident in HBM) and
+ORBmatcher::SearchForInitialization of every frame against its predecessor in the stream
+(window 100, nnratio 0.9, checkOrientation) -- BASELINE.json configs[1]+[2] on the stream of
+configs[3].  Keypoints / descriptors / match indices come back to host memory inside the timed
+region (they are the path's outputs).  Independent streams shard across GPUs (one process and one
+stream per GPU, no data-path collective; the only cross-rank traffic is the barrier and the
+max-over-ranks of the elapsed time, done over gloo).
+
+One JSON line on rank 0 (see the task's bench contract) with two extra objects:
+  roofline     -- dominant kernel (k_fast_cells): algorithmic bytes per launch / HIP-event duration
+  cpu_baseline -- the CPU oracle (scalar port, 1 core) on a bounded sample of the same frames
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+W, H, NFEAT, NLEVELS, SCALE, INI_TH, MIN_TH = 1920, 1080, 2000, 8, 1.2, 20, 7
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=16, help='frames per step and GPU')
+    ap.add_argument('--cpu-frames', type=int, default=24, help='frames of the CPU-oracle baseline sample (0 = skip)')
+    ap.add_argument('--no-match', action='store_true', help='extract only (configs[1])')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+
+    # torch first (it carries its own HIP runtime; loading it after liborbfe has initialised HIP
+    # leaves torch without devices), then the product library.
+    import numpy as np
+    import torch
+    have_torch_gpu = torch.cuda.is_available()
+    if have_torch_gpu:
+        torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        # control plane only (barrier + max of a scalar): gloo; the data path has no exchange step
+        dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+
+    from os1_amd import api
+    from os1_amd.synth import shifted, synth
+    if api.device_count() <= local_rank:
+        raise SystemExit('bench.py needs GPU %d (found %d): the product has no CPU fallback' % (local_rank, api.device_count()))
+
+    B = args.batch
+    seed = 100 + rank                       # config 4: stream g -> GPU g, seeds 100+g
+    frames = [synth(seed, W, H)]
+    for i in range(1, B):
+        frames.append(shifted(frames[-1], 2, 1, seed * 1000 + i))   # each frame = previous shifted by (2,1) px
+    dev = api.DeviceFrames(frames, local_rank)
+    ex = api.Extractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank)
+    mt = api.Matcher(local_rank)
+    kps = np.zeros((B, ex.cap), api.KP_DTYPE)
+    desc = np.zeros((B, ex.cap, 32), np.uint8)
+    bounds = (0.0, float(W), 0.0, float(H))
+    last = [None]
+    nmatch_total = [0]
+
+    def step():
+        _, _, n = ex.extract_batch_ptrs(dev.ptrs, H, W, dev.stride, True, kps, desc)
+        if args.no_match:
+            return
+        for i in range(B):
+            cur = (kps[i, :n[i]], desc[i, :n[i]])
+            prev = last[0] if i == 0 else (kps[i - 1, :n[i - 1]], desc[i - 1, :n[i - 1]])
+            if prev is not None:
+                pxy = np.stack([prev[0]['x'], prev[0]['y']], 1)       # vbPrevMatched := F1 keypoints (Tracking.cc:355-357)
+                nm, _, _ = mt.search_for_initialization(prev[0], prev[1], cur[0], cur[1], bounds, pxy, 100, 0.9, True)
+                nmatch_total[0] += nm
+        last[0] = (kps[B - 1, :n[B - 1]].copy(), desc[B - 1, :n[B - 1]].copy())
+
+    def sync():
+        api.device_synchronize(local_rank)
+        if have_torch_gpu:
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ex.kernel_ms(reset=True)
+    nmatch_total[0] = 0
+    sync()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kms, kbatches, kframes = ex.kernel_ms()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    if rank == 0:
+        frames_done = world * B * args.steps
+        fps = frames_done / elapsed
+        # roofline of the dominant kernel (DESIGN.md "Roofline"): k_fast_cells reads every pyramid pixel once
+        # (sum of level sizes) and writes 4 B per surviving candidate; algorithmic bytes per launch = that x B.
+        t = ex.tables()
+        px = 0
+        for l in range(NLEVELS):
+            lw = int(np.rint(np.float32(W) * t['isf'][l]))
+            lh = int(np.rint(np.float32(H) * t['isf'][l]))
+            px += lw * lh
+        ncand = sum(len(ex.candidates(l, 0)) for l in range(NLEVELS))
+        fast_bytes_per_frame = px + 4 * ncand
+        fast_ms_per_launch = kms[1] / max(kbatches, 1)
+        achieved = fast_bytes_per_frame * B / (fast_ms_per_launch * 1e-3) / 1e9 if fast_ms_per_launch > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')     # written from rocprofv3 --pmc passes (offline)
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get('k_fast_cells_bytes_per_launch_b%d' % B)
+            except Exception:
+                traffic = None
+        out = {
+            'metric': 'frames/sec extract+match, 1920x1080 @ 2000 ORB feats',
+            'value': round(fps, 2), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
+            'config': {'workload': '1080p_2000feat_8lv_1.2_extract%s_stream' % ('' if args.no_match else '+SearchForInitialization'),
+                       'frames_per_step_per_gpu': B, 'image': '%dx%d' % (W, H), 'nfeatures': NFEAT, 'nlevels': NLEVELS,
+                       'parallelism': 'independent streams, 1 per GPU' if world > 1 else 'single GPU',
+                       'matches_per_frame': round(nmatch_total[0] / max(B * args.steps, 1), 1),
+                       'input': 'frames resident in HBM; keypoints/descriptors/matches returned to host'},
+            'gpu_kernel_ms_per_frame': {k: round(v / max(kframes, 1), 5) for k, v in
+                                        zip(('pyramid', 'fast_cells', 'compaction', 'describe'), kms)},
+            'roofline': {'kernel': 'k_fast_cells', 'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
+                         'algorithmic_bytes_per_launch': fast_bytes_per_frame * B,
+                         'launch_ms': round(fast_ms_per_launch, 4)},
+        }
+        if world == 1 and args.cpu_frames > 0:
+            out['cpu_baseline'] = cpu_baseline(frames, args.cpu_frames, not args.no_match)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(frames, nframes, do_match):
+    """The CPU oracle (scalar C++ port of the reference path, g++ -O3, ONE core) on the same frames."""
+    import numpy as np
+    from oracle.pyoracle import Oracle, OracleExtractor
+    o = Oracle()
+    ox = OracleExtractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, o)
+    bounds = (0.0, float(W), 0.0, float(H))
+    ox.extract(frames[0])                                           # warm-up
+    prev = None
+    t0 = time.perf_counter()
+    for i in range(nframes):
+        k, d = ox.extract(frames[i % len(frames)])
+        if do_match and prev is not None:
+            pxy = np.stack([prev[0]['x'], prev[0]['y']], 1)
+            o.search_for_initialization(prev[0], prev[1], k, d, bounds, pxy, 100, 0.9, True)
+        prev = (k, d)
+    dt = time.perf_counter() - t0
+    return {'value': round(nframes / dt, 3), 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
+            'host_cores_available': os.cpu_count(),
+            'sample': '%d frames of the same 1920x1080 stream, extract%s, oracle/liborb_oracle.so (scalar C++ '
+                      'restatement, g++ -O3 -ffp-contract=off), %.1f s' % (nframes, '+SearchForInitialization' if do_match else '', dt)}
+
+
+if __name__ == '__main__':
+    main()

@@ -51,6 +51,14 @@ const char* orbfe_last_error(void);
 /* Number of visible HIP devices (0 if none / runtime unusable). Does not create a context. */
 int orbfe_device_count(void);
 
+/* Device-memory helpers so a caller without its own HIP code can keep frames resident in HBM
+ * (orbfe_extract_batch with in_device_memory != 0).  Plain hipMalloc/hipFree/hipMemcpy/
+ * hipDeviceSynchronize on the given device. */
+int orbfe_device_malloc(int device_id, size_t bytes, void** out);
+int orbfe_device_free(int device_id, void* ptr);
+int orbfe_device_upload(int device_id, void* dst_device, const void* src_host, size_t bytes);
+int orbfe_device_synchronize(int device_id);
+
 /* ---------------------------------------------------------------------------------------------
  * Extractor.  Replaces ORB_SLAM2::ORBextractor (include/ORBextractor.h:155-373).
  * ------------------------------------------------------------------------------------------- */
@@ -105,6 +113,10 @@ int orbfe_debug_candidates(orbfe_extractor* h, int frame, int level, int32_t* xy
 /* Per-stage wall/GPU milliseconds of the last call: [0]=upload+pyramid+FAST+compaction (GPU),
  * [1]=D2H candidates, [2]=host quadtree, [3]=orientation+blur+rBRIEF (GPU) incl. H2D/D2H, [4]=total. */
 int orbfe_debug_stage_ms(const orbfe_extractor* h, float out[5]);
+/* GPU time (HIP events recorded on the launch stream) accumulated per kernel group since the last
+ * reset: out_ms[0]=pyramid (k_resize x (nlevels-1)), [1]=k_fast_cells, [2]=k_scan_cells+k_gather,
+ * [3]=k_describe; *batches = launches of each group, *frames = frames processed. */
+int orbfe_debug_kernel_ms(orbfe_extractor* h, double out_ms[4], long long* batches, long long* frames, int reset);
 /* Device-side restatement of (cosf, sinf)(angle_deg * pi/180) used by the rBRIEF kernel, evaluated
  * on the GPU for n angles (parity test against host libm). */
 int orbfe_debug_sincos(orbfe_extractor* h, const float* angle_deg, int n, float* cos_out, float* sin_out);

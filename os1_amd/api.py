@@ -76,6 +76,11 @@ def load_library():
     L.orbfe_search_by_projection_uv.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, ci,
                                                 ci, ci, vp, C.POINTER(ci)]
     L.orbfe_debug_features_in_area.argtypes = [vp, vp, ci, vp, cf, cf, cf, ci, ci, vp, ci, C.POINTER(ci)]
+    L.orbfe_debug_kernel_ms.argtypes = [vp, vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), ci]
+    L.orbfe_device_malloc.argtypes = [ci, C.c_size_t, C.POINTER(vp)]
+    L.orbfe_device_free.argtypes = [ci, vp]
+    L.orbfe_device_upload.argtypes = [ci, vp, vp, C.c_size_t]
+    L.orbfe_device_synchronize.argtypes = [ci]
     L.orbfe_debug_quadtree.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, ci, C.POINTER(ci)]
     L.orbfe_debug_sincos_host_check.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_longlong)]
     _lib = L
@@ -185,6 +190,13 @@ class Extractor:
         out = np.zeros(5, np.float32)
         _check(self.L.orbfe_debug_stage_ms(self.h, _p(out)))
         return out
+
+    def kernel_ms(self, reset=False):
+        """(ms[4] = pyramid, fast, compaction, describe; batches; frames) accumulated GPU time from HIP events."""
+        ms = np.zeros(4, np.float64)
+        b, f = C.c_longlong(0), C.c_longlong(0)
+        _check(self.L.orbfe_debug_kernel_ms(self.h, _p(ms), C.byref(b), C.byref(f), int(reset)))
+        return ms, b.value, f.value
 
     def sincos(self, angle_deg):
         a = np.ascontiguousarray(angle_deg, np.float32)
@@ -296,3 +308,38 @@ def sincos_host_mismatches(lo_bits, hi_bits, step=1):
     bad = C.c_longlong(0)
     _check(load_library().orbfe_debug_sincos_host_check(lo_bits, hi_bits, step, C.byref(bad)))
     return bad.value
+
+
+class DeviceFrames:
+    """A stack of equally sized u8 frames resident in HBM (hipMalloc'd through the C ABI)."""
+
+    def __init__(self, frames, device=0, stride=None):
+        L = load_library()
+        self.device = device
+        self.rows, self.cols = frames[0].shape
+        self.stride = stride or self.cols
+        self.n = len(frames)
+        self.frame_bytes = self.rows * self.stride
+        p = C.c_void_p()
+        _check(L.orbfe_device_malloc(device, self.frame_bytes * self.n, C.byref(p)))
+        self.base = p.value
+        for i, f in enumerate(frames):
+            buf = np.zeros((self.rows, self.stride), np.uint8)
+            buf[:, :self.cols] = f
+            _check(L.orbfe_device_upload(device, C.c_void_p(self.base + i * self.frame_bytes), _p(buf), buf.size))
+        self.ptrs = [self.base + i * self.frame_bytes for i in range(self.n)]
+
+    def free(self):
+        if getattr(self, 'base', None):
+            load_library().orbfe_device_free(self.device, C.c_void_p(self.base))
+            self.base = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def device_synchronize(device=0):
+    _check(load_library().orbfe_device_synchronize(device))

@@ -10,18 +10,23 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/orbfe.h"
 #include "glibc_sincosf.h"
+#include "host_pool.h"
 #include "orbfe_internal.h"
 #include "quadtree.h"
 
 namespace orbfe {
 void launch_pyramid(const PyramidParams& P, int nframes, hipStream_t st);
-void launch_detect(const PyramidParams& P, int nframes, hipStream_t st);
+void launch_fast(const PyramidParams& P, int nframes, hipStream_t st);
+void launch_compact(const PyramidParams& P, int nframes, hipStream_t st);
 void launch_describe(const PyramidParams& P, const SelKp* sel, int nsel, float* angle, uint8_t* desc,
                      hipStream_t st);
 void launch_sincos(const float* deg, int n, float* c, float* s, hipStream_t st);
@@ -112,12 +117,20 @@ struct orbfe_extractor {
   long long inPitch = 0;
   int lastFrames = 0;
   float stageMs[5] = {0, 0, 0, 0, 0};
+  hipEvent_t ev[6] = {};
+  double kernMs[4] = {0, 0, 0, 0};
+  long long kernBatches = 0, kernFrames = 0;
 
-  QuadTree qt;
-  std::vector<int16_t> qx, qy;
-  std::vector<uint8_t> qs;
-  std::vector<int> qsel;
   struct Meta { int16_t x, y; uint8_t score, level; };
+  struct Worker {  // per-thread quadtree scratch
+    QuadTree qt;
+    std::vector<int16_t> qx, qy;
+    std::vector<uint8_t> qs;
+    std::vector<int> qsel;
+  };
+  std::unique_ptr<HostPool> pool;
+  std::vector<Worker> workers;
+  std::vector<std::vector<Meta>> taskOut;  // [frame*nlevels + level]
   std::vector<Meta> meta;
   std::vector<int> frameKpStart;
 
@@ -128,6 +141,7 @@ struct orbfe_extractor {
     d_angle.release(); d_f32tmp.release(); d_desc.release();
     h_frame0.release(); h_levelStart.release(); h_cand.release(); h_sel.release(); h_angle.release();
     h_desc.release();
+    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
   }
 
@@ -280,8 +294,13 @@ struct orbfe_extractor {
     }
     P.stride0 = onDevice ? (long long)stride : inPitch;
     HIP_TRY(hipMemcpyAsync(d_frame0.p, h_frame0.p, sizeof(void*) * nframes, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipEventRecord(ev[0], stream));
     launch_pyramid(P, nframes, stream);
-    launch_detect(P, nframes, stream);
+    HIP_TRY(hipEventRecord(ev[1], stream));
+    launch_fast(P, nframes, stream);
+    HIP_TRY(hipEventRecord(ev[2], stream));
+    launch_compact(P, nframes, stream);
+    HIP_TRY(hipEventRecord(ev[3], stream));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(h_levelStart.p, d_levelStart.p, sizeof(uint32_t) * (kMaxLevels + 1) * nframes,
                            hipMemcpyDeviceToHost, stream));
@@ -307,29 +326,42 @@ struct orbfe_extractor {
     // ---- host quadtree per (frame, level): DistributeOctTree, ORBextractor.cc:876-877 -------
     meta.clear();
     frameKpStart.assign(nframes + 1, 0);
+    const int ntasks = nframes * nlevels;
+    if ((int)taskOut.size() < ntasks) taskOut.resize(ntasks);
+    pool->parallelFor(ntasks, [&](int task, int wid) {
+      const int f = task / nlevels, l = task - f * nlevels;
+      std::vector<Meta>& out = taskOut[task];
+      out.clear();
+      const uint32_t* ls = h_levelStart.p + (size_t)f * (kMaxLevels + 1);
+      const int n = (int)(ls[l + 1] - ls[l]);
+      if (n <= 0) return;
+      Worker& w = workers[wid];
+      const uint32_t* cd = h_cand.p + candStart[f] + ls[l];
+      w.qx.resize(n); w.qy.resize(n); w.qs.resize(n);
+      for (int i = 0; i < n; i++) {
+        const uint32_t v = cd[i];
+        w.qx[i] = (int16_t)((int)(v & 0xfff) - kBorder);
+        w.qy[i] = (int16_t)((int)((v >> 12) & 0xfff) - kBorder);
+        w.qs[i] = (uint8_t)(v >> 24);
+      }
+      const LevelGeom& L = P.lv[l];
+      w.qt.distribute(w.qx.data(), w.qy.data(), w.qs.data(), n, kBorder, L.w - kBorder, kBorder, L.h - kBorder,
+                      nfeat[l], w.qsel);
+      out.reserve(w.qsel.size());
+      for (int k : w.qsel) {
+        Meta m;
+        m.x = (int16_t)(w.qx[k] + kBorder);
+        m.y = (int16_t)(w.qy[k] + kBorder);
+        m.score = w.qs[k];
+        m.level = (uint8_t)l;
+        out.push_back(m);
+      }
+    });
     int nsel = 0;
     for (int f = 0; f < nframes; f++) {
       frameKpStart[f] = nsel;
-      const uint32_t* ls = h_levelStart.p + (size_t)f * (kMaxLevels + 1);
       for (int l = 0; l < nlevels; l++) {
-        const int n = (int)(ls[l + 1] - ls[l]);
-        if (n <= 0) continue;
-        const uint32_t* cd = h_cand.p + candStart[f] + ls[l];
-        qx.resize(n); qy.resize(n); qs.resize(n);
-        for (int i = 0; i < n; i++) {
-          const uint32_t v = cd[i];
-          qx[i] = (int16_t)((int)(v & 0xfff) - kBorder);
-          qy[i] = (int16_t)((int)((v >> 12) & 0xfff) - kBorder);
-          qs[i] = (uint8_t)(v >> 24);
-        }
-        const LevelGeom& L = P.lv[l];
-        qt.distribute(qx.data(), qy.data(), qs.data(), n, kBorder, L.w - kBorder, kBorder, L.h - kBorder, nfeat[l], qsel);
-        for (int k : qsel) {
-          Meta m;
-          m.x = (int16_t)(qx[k] + kBorder);
-          m.y = (int16_t)(qy[k] + kBorder);
-          m.score = qs[k];
-          m.level = (uint8_t)l;
+        for (const Meta& m : taskOut[(size_t)f * nlevels + l]) {
           meta.push_back(m);
           SelKp s;
           s.xy = (uint32_t)m.x | ((uint32_t)m.y << 16);
@@ -343,11 +375,21 @@ struct orbfe_extractor {
     // ---- stage 2: orientation + blur + rBRIEF on the GPU -----------------------------------
     if (nsel > 0) {
       HIP_TRY(hipMemcpyAsync(d_sel.p, h_sel.p, sizeof(SelKp) * nsel, hipMemcpyHostToDevice, stream));
+      HIP_TRY(hipEventRecord(ev[4], stream));
       launch_describe(P, d_sel.p, nsel, d_angle.p, d_desc.p, stream);
+      HIP_TRY(hipEventRecord(ev[5], stream));
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipMemcpyAsync(h_angle.p, d_angle.p, sizeof(float) * nsel, hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipMemcpyAsync(h_desc.p, d_desc.p, (size_t)32 * nsel, hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));
+    }
+    {  // per-kernel GPU time of this batch (HIP events on the launch stream)
+      float ms = 0;
+      for (int i = 0; i < 3; i++)
+        if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) kernMs[i] += ms;
+      if (nsel > 0 && hipEventElapsedTime(&ms, ev[4], ev[5]) == hipSuccess) kernMs[3] += ms;
+      kernBatches++;
+      kernFrames += nframes;
     }
     // ---- assemble cv::KeyPoint-compatible outputs (ORBextractor.cc:879-889, 959-967) --------
     int status = ORBFE_OK;
@@ -398,6 +440,29 @@ int orbfe_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
+}
+
+int orbfe_device_malloc(int device_id, size_t bytes, void** out) {
+  if (!out || bytes == 0) { set_err("bad argument"); return ORBFE_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(device_id));
+  HIP_TRY(hipMalloc(out, bytes));
+  return ORBFE_OK;
+}
+int orbfe_device_free(int device_id, void* ptr) {
+  HIP_TRY(hipSetDevice(device_id));
+  HIP_TRY(hipFree(ptr));
+  return ORBFE_OK;
+}
+int orbfe_device_upload(int device_id, void* dst_device, const void* src_host, size_t bytes) {
+  if (!dst_device || !src_host) { set_err("bad argument"); return ORBFE_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(device_id));
+  HIP_TRY(hipMemcpy(dst_device, src_host, bytes, hipMemcpyHostToDevice));
+  return ORBFE_OK;
+}
+int orbfe_device_synchronize(int device_id) {
+  HIP_TRY(hipSetDevice(device_id));
+  HIP_TRY(hipDeviceSynchronize());
+  return ORBFE_OK;
 }
 
 int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device_id,
@@ -454,6 +519,16 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
     delete h;
     return ORBFE_ERR_HIP;
   }
+  for (auto& evn : h->ev) {
+    if (hipEventCreate(&evn) != hipSuccess) { set_err("hipEventCreate failed"); delete h; return ORBFE_ERR_HIP; }
+  }
+  // host workers for the per-(frame, level) quadtrees: ORBFE_HOST_THREADS, default min(cores, 16)
+  int nthreads = (int)std::thread::hardware_concurrency();
+  if (nthreads > 16) nthreads = 16;
+  if (const char* ev = getenv("ORBFE_HOST_THREADS")) nthreads = atoi(ev);
+  if (nthreads < 1) nthreads = 1;
+  h->pool.reset(new HostPool(nthreads));
+  h->workers.resize(nthreads);
   *out = h;
   return ORBFE_OK;
 }
@@ -551,6 +626,18 @@ int orbfe_debug_candidates(orbfe_extractor* h, int frame, int level, int32_t* xy
 int orbfe_debug_stage_ms(const orbfe_extractor* h, float out[5]) {
   if (!h || !out) { set_err("NULL argument"); return ORBFE_ERR_INVALID; }
   for (int i = 0; i < 5; i++) out[i] = h->stageMs[i];
+  return ORBFE_OK;
+}
+
+int orbfe_debug_kernel_ms(orbfe_extractor* h, double out_ms[4], long long* batches, long long* frames, int reset) {
+  if (!h) { set_err("handle is NULL"); return ORBFE_ERR_INVALID; }
+  for (int i = 0; i < 4; i++) if (out_ms) out_ms[i] = h->kernMs[i];
+  if (batches) *batches = h->kernBatches;
+  if (frames) *frames = h->kernFrames;
+  if (reset) {
+    for (double& v : h->kernMs) v = 0;
+    h->kernBatches = h->kernFrames = 0;
+  }
   return ORBFE_OK;
 }
 

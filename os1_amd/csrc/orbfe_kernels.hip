@@ -413,8 +413,11 @@ size_t fast_lds_bytes(const PyramidParams& P) {
   return (mx + 15) & ~(size_t)15;
 }
 
-void launch_detect(const PyramidParams& P, int nframes, hipStream_t st) {
+void launch_fast(const PyramidParams& P, int nframes, hipStream_t st) {
   hipLaunchKernelGGL(k_fast_cells, dim3(P.ncells, nframes), dim3(64), fast_lds_bytes(P), st, P);
+}
+
+void launch_compact(const PyramidParams& P, int nframes, hipStream_t st) {
   hipLaunchKernelGGL(k_scan_cells, dim3(nframes), dim3(1024), 0, st, P);
   hipLaunchKernelGGL(k_gather, dim3(P.ncells, nframes), dim3(64), 0, st, P);
 }
