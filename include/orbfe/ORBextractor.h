@@ -1,0 +1,57 @@
+// ORBextractor.h -- drop-in ORB_SLAM2::ORBextractor (reference include/ORBextractor.h:155-373) backed by
+// liborbfe.so.  Same constructor, operator() and getters, so Frame.cc:69-75,133 and Tracking.cc:65-67
+// compile unchanged.  Needs OpenCV headers (the signature uses cv:: types); orb_shim.hpp is the
+// OpenCV-free core.
+#pragma once
+#if !__has_include(<opencv2/core/core.hpp>)
+#error "include/orbfe/ORBextractor.h needs OpenCV headers; use include/orbfe/orb_shim.hpp (cv-free) instead"
+#else
+#include <opencv2/core/core.hpp>
+
+#include <vector>
+
+#include "orb_shim.hpp"
+
+namespace ORB_SLAM2 {
+
+class ORBextractor {
+ public:
+  ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
+      : impl_(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, /*device=*/0) {
+    mvImagePyramid.resize(nlevels);  // kept for source compatibility; the pyramid lives in HBM
+  }
+  ~ORBextractor() {}
+
+  // ORBextractor.cc:907-969.  `mask` is ignored, as in the reference.
+  void operator()(cv::InputArray _image, cv::InputArray /*mask*/, std::vector<cv::KeyPoint>& _keypoints,
+                  cv::OutputArray _descriptors) {
+    if (_image.empty()) return;
+    cv::Mat image = _image.getMat();
+    CV_Assert(image.type() == CV_8UC1);
+    impl_.extract(image.data, image.rows, image.cols, image.step, _keypoints, desc_);
+    const int n = (int)_keypoints.size();
+    if (n == 0) {
+      _descriptors.release();
+    } else {
+      _descriptors.create(n, 32, CV_8U);
+      cv::Mat d = _descriptors.getMat();
+      for (int i = 0; i < n; i++) std::memcpy(d.ptr(i), &desc_[(size_t)i * 32], 32);
+    }
+  }
+
+  int inline GetLevels() { return impl_.GetLevels(); }
+  float inline GetScaleFactor() { return impl_.GetScaleFactor(); }
+  std::vector<float> inline GetScaleFactors() { return impl_.GetScaleFactors(); }
+  std::vector<float> inline GetInverseScaleFactors() { return impl_.GetInverseScaleFactors(); }
+  std::vector<float> inline GetScaleSigmaSquares() { return impl_.GetScaleSigmaSquares(); }
+  std::vector<float> inline GetInverseScaleSigmaSquares() { return impl_.GetInverseScaleSigmaSquares(); }
+
+  std::vector<cv::Mat> mvImagePyramid;  // ORBextractor.h:245; no external reader in the reference
+
+ private:
+  orbfe::Extractor impl_;
+  std::vector<uint8_t> desc_;
+};
+
+}  // namespace ORB_SLAM2
+#endif

@@ -1,0 +1,169 @@
+// orb_shim.hpp -- header-only C++ host side above the C ABI (include/orbfe.h).
+//
+// Generic (duck-typed) so it compiles with or without OpenCV: the reference's own types
+// (cv::KeyPoint, cv::Mat, ORB_SLAM2::Frame, ORB_SLAM2::MapPoint) are template parameters and are
+// only touched through the member names the reference uses.  include/orbfe/ORBextractor.h binds the
+// extractor part to the exact ORB_SLAM2::ORBextractor signature when OpenCV headers are present;
+// INTEGRATION.md shows the three-line bodies that replace the hot ORBmatcher functions.
+//
+// Error behaviour mirrors the reference: no exceptions for data conditions (empty image => outputs
+// untouched, matchers return the match count); a failing GPU call throws std::runtime_error with
+// orbfe_last_error() because the reference has no channel to report it and continuing would
+// silently corrupt tracking.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../orbfe.h"
+
+namespace orbfe {
+
+inline void check(int rc) {
+  if (rc != ORBFE_OK) throw std::runtime_error(std::string("orbfe: ") + orbfe_last_error());
+}
+
+// ORBextractor (reference include/ORBextractor.h:155-373) minus the cv:: types.
+class Extractor {
+ public:
+  Extractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device = 0) {
+    check(orbfe_extractor_create(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device, &h_));
+    const int n = orbfe_extractor_levels(h_);
+    sf_.resize(n); isf_.resize(n); s2_.resize(n); is2_.resize(n);
+    check(orbfe_extractor_scale_tables(h_, sf_.data(), isf_.data(), s2_.data(), is2_.data()));
+    cap_ = orbfe_extractor_max_keypoints(h_);
+  }
+  ~Extractor() { orbfe_extractor_destroy(h_); }
+  Extractor(const Extractor&) = delete;
+  Extractor& operator=(const Extractor&) = delete;
+
+  // operator() core: KeyPointT must have cv::KeyPoint's 28-byte layout.
+  template <class KeyPointT>
+  void extract(const uint8_t* gray, int rows, int cols, size_t step, std::vector<KeyPointT>& keypoints,
+               std::vector<uint8_t>& descriptors) {
+    static_assert(sizeof(KeyPointT) == sizeof(OrbfeKeyPoint), "KeyPointT must match cv::KeyPoint's layout");
+    if (!gray || rows == 0 || cols == 0) return;  // reference: silent return, outputs untouched
+    kp_.resize(cap_);
+    desc_.resize((size_t)cap_ * 32);
+    int n = 0;
+    check(orbfe_extract(h_, gray, rows, cols, step, kp_.data(), desc_.data(), cap_, &n));
+    keypoints.clear();
+    keypoints.resize(n);
+    if (n) std::memcpy(static_cast<void*>(keypoints.data()), kp_.data(), (size_t)n * sizeof(OrbfeKeyPoint));
+    descriptors.assign(desc_.begin(), desc_.begin() + (size_t)n * 32);
+  }
+
+  int GetLevels() const { return (int)sf_.size(); }
+  float GetScaleFactor() const { return orbfe_extractor_scale_factor(h_); }
+  std::vector<float> GetScaleFactors() const { return sf_; }
+  std::vector<float> GetInverseScaleFactors() const { return isf_; }
+  std::vector<float> GetScaleSigmaSquares() const { return s2_; }
+  std::vector<float> GetInverseScaleSigmaSquares() const { return is2_; }
+  orbfe_extractor* handle() const { return h_; }
+  int capacity() const { return cap_; }
+
+ private:
+  orbfe_extractor* h_ = nullptr;
+  int cap_ = 0;
+  std::vector<float> sf_, isf_, s2_, is2_;
+  std::vector<OrbfeKeyPoint> kp_;
+  std::vector<uint8_t> desc_;
+};
+
+// One GPU matcher context per thread that runs searches (Tracking constructs ORBmatcher objects on
+// the stack per use, Tracking.cc:383,596,818; the context is the long-lived part).
+class MatcherContext {
+ public:
+  explicit MatcherContext(int device = 0) { check(orbfe_matcher_create(device, &m_)); }
+  ~MatcherContext() { orbfe_matcher_destroy(m_); }
+  MatcherContext(const MatcherContext&) = delete;
+  MatcherContext& operator=(const MatcherContext&) = delete;
+  orbfe_matcher* get() const { return m_; }
+
+ private:
+  orbfe_matcher* m_ = nullptr;
+};
+
+namespace detail {
+// rows of a CV_8U N x 32 descriptor matrix -> contiguous bytes (cv::Mat has public data/step/rows)
+template <class MatT>
+inline const uint8_t* packedDescriptors(const MatT& m, int n, std::vector<uint8_t>& tmp) {
+  if (n == 0) return nullptr;
+  if ((size_t)m.step == 32) return m.data;
+  tmp.resize((size_t)n * 32);
+  for (int i = 0; i < n; i++) std::memcpy(&tmp[(size_t)i * 32], m.data + (size_t)i * m.step, 32);
+  return tmp.data();
+}
+template <class FrameT>
+inline void frameBounds(const FrameT& F, float b[4]) {
+  b[0] = F.mnMinX; b[1] = F.mnMaxX; b[2] = F.mnMinY; b[3] = F.mnMaxY;
+}
+}  // namespace detail
+
+// int ORBmatcher::DescriptorDistance(const cv::Mat& a, const cv::Mat& b)   (ORBmatcher.cc:1605-1621)
+template <class MatT>
+inline int DescriptorDistance(const MatT& a, const MatT& b) { return orbfe_hamming(a.data, b.data); }
+
+// int ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, vector<cv::Point2f>& vbPrevMatched,
+//                                         vector<int>& vnMatches12, int windowSize)   (ORBmatcher.cc:400-515)
+template <class FrameT, class Point2fT>
+inline int SearchForInitialization(MatcherContext& ctx, float mfNNratio, bool mbCheckOrientation, FrameT& F1,
+                                   FrameT& F2, std::vector<Point2fT>& vbPrevMatched, std::vector<int>& vnMatches12,
+                                   int windowSize) {
+  static_assert(sizeof(Point2fT) == 8, "Point2fT must be two packed floats (cv::Point2f)");
+  const int n1 = (int)F1.mvKeysUn.size(), n2 = (int)F2.mvKeysUn.size();
+  vnMatches12.assign(n1, -1);
+  std::vector<uint8_t> t1, t2;
+  float b[4];
+  detail::frameBounds(F2, b);
+  int nmatches = 0;
+  check(orbfe_search_for_initialization(
+      ctx.get(), reinterpret_cast<const OrbfeKeyPoint*>(F1.mvKeysUn.data()),
+      detail::packedDescriptors(F1.mDescriptors, n1, t1), n1,
+      reinterpret_cast<const OrbfeKeyPoint*>(F2.mvKeysUn.data()), detail::packedDescriptors(F2.mDescriptors, n2, t2),
+      n2, b, reinterpret_cast<float*>(vbPrevMatched.data()), vnMatches12.data(), windowSize, mfNNratio,
+      mbCheckOrientation ? 1 : 0, &nmatches));
+  return nmatches;
+}
+
+// int ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, const float th)
+// (ORBmatcher.cc:45-124).  MapPoint fields are snapshotted through the reference's own accessors
+// (isBad(), GetDescriptor(), Observations() take the MapPoint mutexes, MapPoint.cc:126-129,294-298)
+// BEFORE the GPU call; assignments are written back to F.mvpMapPoints afterwards.
+template <class FrameT, class MapPointT>
+inline int SearchByProjection(MatcherContext& ctx, float mfNNratio, FrameT& F,
+                              const std::vector<MapPointT*>& vpMapPoints, const float th) {
+  const int n = (int)F.mvKeysUn.size(), nmp = (int)vpMapPoints.size();
+  std::vector<uint8_t> occ(n, 0), flags(nmp, 0), mdesc((size_t)nmp * 32, 0), tmp;
+  std::vector<float> xy((size_t)nmp * 2, 0.f), vcos(nmp, 0.f);
+  std::vector<int32_t> lvl(nmp, 0), assigned(n, -1);
+  for (int i = 0; i < n; i++)
+    if (F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations() > 0) occ[i] = 1;
+  for (int i = 0; i < nmp; i++) {
+    MapPointT* p = vpMapPoints[i];
+    if (!p->mbTrackInView) continue;
+    if (p->isBad()) { flags[i] = ORBFE_MP_IN_VIEW | ORBFE_MP_BAD; continue; }
+    flags[i] = ORBFE_MP_IN_VIEW | (p->plCandidato ? ORBFE_MP_CANDIDATO : 0) |
+               (p->Observations() > 0 ? ORBFE_MP_OBSERVED : 0);
+    xy[2 * i] = p->mTrackProjX;
+    xy[2 * i + 1] = p->mTrackProjY;
+    lvl[i] = p->mnTrackScaleLevel;
+    vcos[i] = p->mTrackViewCos;
+    const auto d = p->GetDescriptor();
+    std::memcpy(&mdesc[(size_t)i * 32], d.data, 32);
+  }
+  float b[4];
+  detail::frameBounds(F, b);
+  int nmatches = 0;
+  check(orbfe_search_by_projection(ctx.get(), reinterpret_cast<const OrbfeKeyPoint*>(F.mvKeysUn.data()),
+                                   detail::packedDescriptors(F.mDescriptors, n, tmp), n, b, F.mvScaleFactors.data(),
+                                   (int)F.mvScaleFactors.size(), occ.data(), xy.data(), lvl.data(), vcos.data(),
+                                   flags.data(), mdesc.data(), nmp, th, mfNNratio, assigned.data(), &nmatches));
+  for (int i = 0; i < n; i++)
+    if (assigned[i] >= 0) F.mvpMapPoints[i] = vpMapPoints[assigned[i]];
+  return nmatches;
+}
+
+}  // namespace orbfe

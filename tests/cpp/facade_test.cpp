@@ -1,0 +1,112 @@
+// facade_test.cpp -- drives include/orbfe/orb_shim.hpp the way the reference's Tracking/Frame code
+// would (Frame.cc:131-134, Tracking.cc:383-384, 818-824), with stand-in structs that expose the
+// member names the shim reads.  Inputs/outputs are raw binary files so tests/test_gpu_parity.py can
+// compare every result with the CPU oracle.
+//   usage: facade_test <dir>      reads <dir>/A.gray, <dir>/B.gray (W,H from <dir>/meta.txt)
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "orbfe/orb_shim.hpp"
+
+struct KeyPoint { float x, y, size, angle, response; int octave, class_id; };  // cv::KeyPoint layout
+struct Point2f { float x, y; };
+struct Mat {  // the three public cv::Mat members the shim touches
+  unsigned char* data = nullptr;
+  size_t step = 0;
+  int rows = 0;
+};
+struct MapPoint {
+  bool mbTrackInView = true, plCandidato = false, bad = false;
+  float mTrackProjX = 0, mTrackProjY = 0, mTrackViewCos = 1;
+  int mnTrackScaleLevel = 0, nObs = 1;
+  unsigned char desc[32];
+  bool isBad() { return bad; }
+  int Observations() { return nObs; }
+  Mat GetDescriptor() { Mat m; m.data = desc; m.step = 32; m.rows = 1; return m; }
+};
+struct Frame {
+  std::vector<KeyPoint> mvKeys, mvKeysUn;
+  std::vector<unsigned char> descStore;
+  Mat mDescriptors;
+  std::vector<MapPoint*> mvpMapPoints;
+  std::vector<float> mvScaleFactors;
+  static float mnMinX, mnMaxX, mnMinY, mnMaxY;
+};
+float Frame::mnMinX, Frame::mnMaxX, Frame::mnMinY, Frame::mnMaxY;
+
+static std::vector<unsigned char> readFile(const std::string& p) {
+  FILE* f = fopen(p.c_str(), "rb");
+  if (!f) { fprintf(stderr, "cannot open %s\n", p.c_str()); exit(2); }
+  fseek(f, 0, SEEK_END);
+  long n = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  std::vector<unsigned char> v(n);
+  if (fread(v.data(), 1, n, f) != (size_t)n) exit(2);
+  fclose(f);
+  return v;
+}
+static void writeFile(const std::string& p, const void* d, size_t n) {
+  FILE* f = fopen(p.c_str(), "wb");
+  fwrite(d, 1, n, f);
+  fclose(f);
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) return 2;
+  const std::string dir = argv[1];
+  int W = 0, H = 0, N = 0, nmp = 0;
+  {
+    FILE* f = fopen((dir + "/meta.txt").c_str(), "r");
+    if (!f || fscanf(f, "%d %d %d %d", &W, &H, &N, &nmp) != 4) return 2;
+    fclose(f);
+  }
+  orbfe::Extractor extractor(N, 1.2f, 8, 20, 7);           // Tracking.cc:65
+  orbfe::MatcherContext ctx;
+  Frame::mnMinX = 0; Frame::mnMaxX = (float)W; Frame::mnMinY = 0; Frame::mnMaxY = (float)H;  // Frame.cc:347-352
+  Frame F[2];
+  const char* names[2] = {"A", "B"};
+  for (int i = 0; i < 2; i++) {
+    std::vector<unsigned char> img = readFile(dir + "/" + names[i] + ".gray");
+    extractor.extract(img.data(), H, W, (size_t)W, F[i].mvKeys, F[i].descStore);  // Frame::ExtractORB
+    F[i].mvKeysUn = F[i].mvKeys;                                                 // no distortion
+    F[i].mDescriptors.data = F[i].descStore.data();
+    F[i].mDescriptors.step = 32;
+    F[i].mDescriptors.rows = (int)F[i].mvKeys.size();
+    F[i].mvpMapPoints.assign(F[i].mvKeys.size(), nullptr);
+    F[i].mvScaleFactors = extractor.GetScaleFactors();
+    writeFile(dir + "/" + names[i] + ".kps", F[i].mvKeys.data(), F[i].mvKeys.size() * sizeof(KeyPoint));
+    writeFile(dir + "/" + names[i] + ".desc", F[i].descStore.data(), F[i].descStore.size());
+  }
+  // Tracking::MonocularInitialization, Tracking.cc:355-357,383-384
+  std::vector<Point2f> vbPrevMatched(F[0].mvKeysUn.size());
+  for (size_t i = 0; i < F[0].mvKeysUn.size(); i++) vbPrevMatched[i] = Point2f{F[0].mvKeysUn[i].x, F[0].mvKeysUn[i].y};
+  std::vector<int> vnMatches12;
+  int nm = orbfe::SearchForInitialization(ctx, 0.9f, true, F[0], F[1], vbPrevMatched, vnMatches12, 100);
+  writeFile(dir + "/sfi.matches", vnMatches12.data(), vnMatches12.size() * sizeof(int));
+  writeFile(dir + "/sfi.prev", vbPrevMatched.data(), vbPrevMatched.size() * sizeof(Point2f));
+  // Tracking::SearchLocalPoints, Tracking.cc:818-824: MapPoints come from <dir>/mp.bin
+  //   per MapPoint: float x, y, viewcos; int level; uchar flags(inview|bad<<1|cand<<2|obs<<3); uchar desc[32]
+  std::vector<unsigned char> mpraw = readFile(dir + "/mp.bin");
+  const size_t rec = 12 + 4 + 1 + 32;
+  std::vector<MapPoint> mps(nmp);
+  std::vector<MapPoint*> vp(nmp);
+  for (int i = 0; i < nmp; i++) {
+    const unsigned char* r = &mpraw[i * rec];
+    MapPoint& p = mps[i];
+    memcpy(&p.mTrackProjX, r, 4); memcpy(&p.mTrackProjY, r + 4, 4); memcpy(&p.mTrackViewCos, r + 8, 4);
+    memcpy(&p.mnTrackScaleLevel, r + 12, 4);
+    const unsigned char fl = r[16];
+    p.mbTrackInView = fl & 1; p.bad = fl & 2; p.plCandidato = fl & 4; p.nObs = (fl & 8) ? 3 : 0;
+    memcpy(p.desc, r + 17, 32);
+    vp[i] = &p;
+  }
+  int nsbp = orbfe::SearchByProjection(ctx, 0.8f, F[1], vp, 1.0f);
+  std::vector<int> assigned(F[1].mvpMapPoints.size(), -1);
+  for (size_t i = 0; i < assigned.size(); i++)
+    if (F[1].mvpMapPoints[i]) assigned[i] = (int)(F[1].mvpMapPoints[i] - mps.data());
+  writeFile(dir + "/sbp.assigned", assigned.data(), assigned.size() * sizeof(int));
+  printf("%zu %zu %d %d\n", F[0].mvKeys.size(), F[1].mvKeys.size(), nm, nsbp);
+  return 0;
+}

@@ -1,0 +1,95 @@
+"""The header-only C++ host side (include/orbfe/orb_shim.hpp) used the way the reference's
+Frame/Tracking code uses ORBextractor/ORBmatcher.  CPU: it compiles and links against the C ABI.
+GPU: its outputs equal the oracle's."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _compile(out):
+    from os1_amd import api
+    if not os.path.exists(api.lib_path()):
+        api.build_library()
+    cmd = ['g++', '-std=c++17', '-O2', '-Wall', '-Werror', '-I' + os.path.join(ROOT, 'include'),
+           os.path.join(ROOT, 'tests', 'cpp', 'facade_test.cpp'), '-o', out, '-L' + os.path.join(ROOT, 'os1_amd'),
+           '-lorbfe', '-Wl,-rpath,' + os.path.join(ROOT, 'os1_amd'), '-Wl,-rpath-link,/opt/rocm/lib']
+    subprocess.check_call(cmd)
+
+
+def test_shim_compiles_and_links(tmp_path):
+    exe = str(tmp_path / 'facade_test')
+    _compile(exe)
+    assert os.path.exists(exe)
+
+
+def test_extractor_facade_is_guarded():
+    # the cv:: facade must refuse to compile without OpenCV instead of silently degrading
+    src = '#include "orbfe/ORBextractor.h"\nint main(){return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, 't.cpp')
+        open(p, 'w').write(src)
+        r = subprocess.run(['g++', '-std=c++17', '-fsyntax-only', '-I' + os.path.join(ROOT, 'include'), p],
+                           capture_output=True, text=True)
+        have_cv = subprocess.run(['g++', '-std=c++17', '-fsyntax-only', '-x', 'c++', '-'], input='#include <opencv2/core/core.hpp>\n',
+                                 capture_output=True, text=True).returncode == 0
+        assert (r.returncode == 0) == have_cv
+        if not have_cv:
+            assert 'needs OpenCV headers' in r.stderr
+
+
+@pytest.mark.gpu
+def test_facade_matches_oracle(tmp_path, oracle):
+    from oracle.pyoracle import KP_DTYPE, OracleExtractor
+    from os1_amd.synth import shifted, synth
+    exe = str(tmp_path / 'facade_test')
+    _compile(exe)
+    W, H, N, NMP = 960, 540, 1200, 3000
+    A = synth(31, W, H)
+    B = shifted(A, -10, 4, 31)
+    A.tofile(tmp_path / 'A.gray')
+    B.tofile(tmp_path / 'B.gray')
+    ox = OracleExtractor(N, 1.2, 8, 20, 7, oracle)
+    (k1, d1), (k2, d2) = ox.extract(A), ox.extract(B)
+    rng = np.random.default_rng(5)
+    src = rng.integers(0, len(k2), NMP)
+    mdesc = d2[src].copy()
+    for i in range(NMP):
+        for b in rng.integers(0, 256, rng.integers(0, 30)):
+            mdesc[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    xy = (np.stack([k2['x'][src], k2['y'][src]], 1) + rng.uniform(-2, 2, (NMP, 2))).astype(np.float32)
+    level = k2['octave'][src].astype(np.int32)
+    vcos = rng.uniform(0.9, 1.0, NMP).astype(np.float32)
+    flags = np.full(NMP, 1 | 8, np.uint8)
+    flags[rng.random(NMP) < 0.03] |= 2
+    flags[rng.random(NMP) < 0.05] |= 4
+    flags[rng.random(NMP) < 0.05] &= ~np.uint8(1)
+    flags[rng.random(NMP) < 0.1] &= ~np.uint8(8)
+    rec = np.zeros(NMP, np.dtype([('x', 'f4'), ('y', 'f4'), ('c', 'f4'), ('l', 'i4'), ('f', 'u1'), ('d', 'u1', 32)]))
+    rec['x'], rec['y'], rec['c'], rec['l'], rec['f'], rec['d'] = xy[:, 0], xy[:, 1], vcos, level, flags, mdesc
+    assert rec.dtype.itemsize == 49
+    rec.tofile(tmp_path / 'mp.bin')
+    open(tmp_path / 'meta.txt', 'w').write('%d %d %d %d\n' % (W, H, N, NMP))
+    out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    n1, n2, nm, nsbp = (int(v) for v in out.stdout.split())
+    gk1 = np.fromfile(tmp_path / 'A.kps', KP_DTYPE)
+    gk2 = np.fromfile(tmp_path / 'B.kps', KP_DTYPE)
+    assert gk1.tobytes() == k1.tobytes() and gk2.tobytes() == k2.tobytes()
+    assert np.fromfile(tmp_path / 'A.desc', np.uint8).tobytes() == d1.tobytes()
+    assert np.fromfile(tmp_path / 'B.desc', np.uint8).tobytes() == d2.tobytes()
+    bounds = (0.0, float(W), 0.0, float(H))
+    prev = np.stack([k1['x'], k1['y']], 1)
+    on, om12, op = oracle.search_for_initialization(k1, d1, k2, d2, bounds, prev, 100, 0.9, True)
+    assert nm == on and nm > 50
+    assert (np.fromfile(tmp_path / 'sfi.matches', np.int32) == om12).all()
+    assert np.fromfile(tmp_path / 'sfi.prev', np.float32).tobytes() == op.tobytes()
+    sf = ox.tables()['sf']
+    osn, oa = oracle.search_by_projection(k2, d2, bounds, sf, np.zeros(len(k2), np.uint8), xy, level, vcos, flags,
+                                          mdesc, 1.0, 0.8)
+    assert nsbp == osn and nsbp > 100
+    assert (np.fromfile(tmp_path / 'sbp.assigned', np.int32) == oa).all()

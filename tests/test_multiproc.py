@@ -1,0 +1,76 @@
+"""N>1 path on CPU: world_size 2 over gloo.  The data path has no exchange step (independent streams,
+one per rank); what N>1 adds is stream sharding (seed 100+rank), the barrier and the max-over-ranks
+of the elapsed time.  Each rank runs the CPU oracle on its own small stream (the checker standing in
+for the GPU worker, which cannot run here) and rank 0 aggregates exactly as bench.py does."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent('''
+    import hashlib, json, os, sys, time
+    sys.path.insert(0, %r)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from os1_amd.synth import shifted, synth
+    from oracle.pyoracle import Oracle, OracleExtractor
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+    seed = 100 + rank                                    # bench.py: stream g -> rank g
+    frames = [synth(seed, 320, 240)]
+    frames.append(shifted(frames[0], 2, 1, seed * 1000 + 1))
+    o = Oracle(); ox = OracleExtractor(300, 1.2, 8, 20, 7, o)
+    dist.barrier()
+    t0 = time.perf_counter()
+    h = hashlib.sha256()
+    nk = 0
+    for f in frames:
+        k, d = ox.extract(f)
+        h.update(k.tobytes()); h.update(d.tobytes()); nk += len(k)
+    dist.barrier()
+    el = time.perf_counter() - t0 + 0.01 * rank          # make the ranks' times differ
+    t = torch.tensor([el], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    digests = [None] * world
+    dist.all_gather_object(digests, (rank, seed, h.hexdigest(), nk, el))
+    if rank == 0:
+        print(json.dumps({'max_elapsed': float(t[0]), 'ranks': digests, 'frames': world * len(frames)}))
+    dist.destroy_process_group()
+''')
+
+
+def test_two_rank_gloo_sharding(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER % ROOT)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', str(port), str(script)]
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
+    res = json.loads(line)
+    ranks = sorted(res['ranks'])
+    assert [r[0] for r in ranks] == [0, 1] and [r[1] for r in ranks] == [100, 101]
+    assert ranks[0][2] != ranks[1][2]                     # different streams -> different outputs
+    assert all(r[3] > 100 for r in ranks)
+    assert abs(res['max_elapsed'] - max(r[4] for r in ranks)) < 1e-9   # MAX over ranks
+    assert res['frames'] == 4
+
+
+def test_bench_refuses_to_run_without_gpu():
+    from os1_amd import api
+    if api.device_count() > 0:
+        return
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '0', '--batch', '2'],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert 'no CPU fallback' in (out.stderr + out.stdout)

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the CPU oracle (regression pins for oracle AND product).
+
+NOTE: these are outputs of THIS repository's oracle, not of the reference -- the reference cannot be
+built here (no OpenCV) and ships no vectors, so parity stays "unpinned" (DESIGN.md s2).  The fixtures
+freeze the current agreed behaviour so that an accidental change to the oracle or to the synthetic
+generator is caught on CPU, and so the GPU path can be checked against committed numbers.
+Run:  python tools/gen_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle.pyoracle import Oracle, OracleExtractor  # noqa: E402
+from os1_amd.synth import shifted, synth  # noqa: E402
+
+o = Oracle()
+out = os.path.join(ROOT, 'tests', 'golden')
+os.makedirs(out, exist_ok=True)
+
+# config 1 (BASELINE.json configs[0]): 640x480, N=1000, seed 1 -- plus the SearchForInitialization pair
+A = synth(1, 640, 480)
+B = shifted(A, -24, 3, 1)
+ox = OracleExtractor(1000, 1.2, 8, 20, 7, o)
+k1, d1 = ox.extract(A)
+cand_counts = np.array([len(ox.candidates(l)) for l in range(8)], np.int32)
+k2, d2 = ox.extract(B)
+prev = np.stack([k1['x'], k1['y']], 1)
+n, m12, p = o.search_for_initialization(k1, d1, k2, d2, (0, 640, 0, 480), prev, 100, 0.9, True)
+np.savez_compressed(os.path.join(out, 'vga_seed1.npz'), kps1=k1, desc1=d1, kps2=k2, desc2=d2, cand_counts=cand_counts,
+                    nmatches=np.int32(n), matches12=m12, prev_out=p,
+                    frame_sha=np.frombuffer(__import__('hashlib').sha256(A.tobytes()).digest(), np.uint8))
+print('vga_seed1: %d/%d kps, %d matches' % (len(k1), len(k2), n))
