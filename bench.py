@@ -146,7 +146,7 @@ def main():
                        'matches_per_frame': round(nmatch_total[0] / max(B * args.steps, 1), 1),
                        'input': 'frames resident in HBM; keypoints/descriptors/matches returned to host'},
             'gpu_kernel_ms_per_frame': {k: round(v / max(kframes, 1), 5) for k, v in
-                                        zip(('pyramid', 'fast_cells', 'compaction', 'describe'), kms)},
+                                        zip(('pyramid', 'fast_cells', 'compaction', 'describe', 'quadtree'), kms)},
             'roofline': {'kernel': 'k_fast_cells', 'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
                          'algorithmic_bytes_per_launch': fast_bytes_per_frame * B,

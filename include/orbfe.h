@@ -110,13 +110,14 @@ int orbfe_debug_level_copy(orbfe_extractor* h, int frame, int level, uint8_t* ou
  * a cell): triples (x, y, score) with x,y relative to (minBorderX,minBorderY) = (16,16) as in
  * vToDistributeKeys (ORBextractor.cc:861-866). */
 int orbfe_debug_candidates(orbfe_extractor* h, int frame, int level, int32_t* xys, int cap, int* n_out);
-/* Per-stage wall/GPU milliseconds of the last call: [0]=upload+pyramid+FAST+compaction (GPU),
- * [1]=D2H candidates, [2]=host quadtree, [3]=orientation+blur+rBRIEF (GPU) incl. H2D/D2H, [4]=total. */
+/* Host wall-clock milliseconds of the last call: [0]=waiting for stage 1 (pyramid+FAST+compaction) and
+ * the candidate D2H, [1]=host quadtrees + selection packing, [2]=tail wait for stage 2
+ * (orientation+blur+rBRIEF), [3]=output assembly, [4]=total. */
 int orbfe_debug_stage_ms(const orbfe_extractor* h, float out[5]);
 /* GPU time (HIP events recorded on the launch stream) accumulated per kernel group since the last
  * reset: out_ms[0]=pyramid (k_resize x (nlevels-1)), [1]=k_fast_cells, [2]=k_scan_cells+k_gather,
- * [3]=k_describe; *batches = launches of each group, *frames = frames processed. */
-int orbfe_debug_kernel_ms(orbfe_extractor* h, double out_ms[4], long long* batches, long long* frames, int reset);
+ * [3]=k_describe, [4]=k_quadtree; *batches = launches of each group, *frames = frames processed. */
+int orbfe_debug_kernel_ms(orbfe_extractor* h, double out_ms[5], long long* batches, long long* frames, int reset);
 /* Device-side restatement of (cosf, sinf)(angle_deg * pi/180) used by the rBRIEF kernel, evaluated
  * on the GPU for n angles (parity test against host libm). */
 int orbfe_debug_sincos(orbfe_extractor* h, const float* angle_deg, int n, float* cos_out, float* sin_out);

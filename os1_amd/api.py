@@ -193,7 +193,7 @@ class Extractor:
 
     def kernel_ms(self, reset=False):
         """(ms[4] = pyramid, fast, compaction, describe; batches; frames) accumulated GPU time from HIP events."""
-        ms = np.zeros(4, np.float64)
+        ms = np.zeros(5, np.float64)
         b, f = C.c_longlong(0), C.c_longlong(0)
         _check(self.L.orbfe_debug_kernel_ms(self.h, _p(ms), C.byref(b), C.byref(f), int(reset)))
         return ms, b.value, f.value

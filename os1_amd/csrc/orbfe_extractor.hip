@@ -6,6 +6,7 @@
 // (quadtree.h).  There is no CPU fallback for the kernels.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -30,6 +31,9 @@ void launch_compact(const PyramidParams& P, int nframes, hipStream_t st);
 void launch_describe(const PyramidParams& P, const SelKp* sel, int nsel, float* angle, uint8_t* desc,
                      hipStream_t st);
 void launch_sincos(const float* deg, int n, float* c, float* s, hipStream_t st);
+void launch_describe_slots(const PyramidParams& P, const SelKp* sel, int nslots, float* angle, uint8_t* desc,
+                           const uint32_t* selCount, int selPerFrame, const int* selOff, hipStream_t st);
+void launch_quadtree(const QtParams& Q, int nframes, hipStream_t st);
 
 thread_local std::string g_err;
 void set_err(const char* fmt, ...) {
@@ -99,7 +103,27 @@ struct orbfe_extractor {
   double scaleFactor;  // the reference keeps the float ctor argument in a double member (ORBextractor.h:313)
   std::vector<float> sf, isf, sigma2, isigma2;
   std::vector<int> nfeat;
-  hipStream_t stream = nullptr;
+  static constexpr int kMaxSub = 4;
+  hipStream_t stream = nullptr;          // == streams[0]
+  hipStream_t streams[kMaxSub] = {};
+  int subBatches = 4;
+  hipEvent_t evFrame0 = nullptr, evS1[kMaxSub] = {};
+  int subSel[kMaxSub] = {};
+  size_t candHostCap = 0;
+  // GPU quadtree path (default): everything from the frame to descriptors in one stream submission
+  bool gpuQuadtree = true;
+  QtParams QP{};
+  int selOff[kMaxLevels + 1] = {};
+  int selPerFrame = 0;
+  DevBuf<uint32_t> d_idxA, d_idxB, d_rank, d_selCount;
+  DevBuf<uint16_t> d_ownA, d_ownB;
+  DevBuf<uint8_t> d_quad;
+  DevBuf<QtNode> d_nodesA, d_nodesB;
+  DevBuf<QtTmp> d_qtmp;
+  DevBuf<int> d_proc;
+  PinBuf<uint32_t> h_selCount;
+  hipEvent_t evQt[2] = {};
+  std::vector<int> frameKpBase, frameKpCount;
 
   int rows = 0, cols = 0, batchCap = 0;
   PyramidParams P{};
@@ -117,8 +141,8 @@ struct orbfe_extractor {
   long long inPitch = 0;
   int lastFrames = 0;
   float stageMs[5] = {0, 0, 0, 0, 0};
-  hipEvent_t ev[6] = {};
-  double kernMs[4] = {0, 0, 0, 0};
+  hipEvent_t ev[kMaxSub][6] = {};
+  double kernMs[5] = {0, 0, 0, 0, 0};
   long long kernBatches = 0, kernFrames = 0;
 
   struct Meta { int16_t x, y; uint8_t score, level; };
@@ -132,7 +156,6 @@ struct orbfe_extractor {
   std::vector<Worker> workers;
   std::vector<std::vector<Meta>> taskOut;  // [frame*nlevels + level]
   std::vector<Meta> meta;
-  std::vector<int> frameKpStart;
 
   ~orbfe_extractor() {
     (void)hipSetDevice(device);
@@ -141,8 +164,13 @@ struct orbfe_extractor {
     d_angle.release(); d_f32tmp.release(); d_desc.release();
     h_frame0.release(); h_levelStart.release(); h_cand.release(); h_sel.release(); h_angle.release();
     h_desc.release();
-    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
-    if (stream) (void)hipStreamDestroy(stream);
+    for (auto& es : ev) for (auto& e : es) if (e) (void)hipEventDestroy(e);
+    for (auto& e : evS1) if (e) (void)hipEventDestroy(e);
+    for (auto& e : evQt) if (e) (void)hipEventDestroy(e);
+    d_idxA.release(); d_idxB.release(); d_rank.release(); d_selCount.release(); d_ownA.release(); d_ownB.release();
+    d_quad.release(); d_nodesA.release(); d_nodesB.release(); d_qtmp.release(); d_proc.release(); h_selCount.release();
+    if (evFrame0) (void)hipEventDestroy(evFrame0);
+    for (auto& st : streams) if (st) (void)hipStreamDestroy(st);
   }
 
   // Level sizes, FAST cell grids, bilinear tables.  ORBextractor.cc:975-976 (sizes), :807-823 (cells).
@@ -251,14 +279,31 @@ struct orbfe_extractor {
       if ((rc = d_frame0.ensure(nframes))) return rc;
       if ((rc = h_frame0.ensure(nframes))) return rc;
       if ((rc = h_levelStart.ensure((size_t)(kMaxLevels + 1) * nframes))) return rc;
-      const size_t maxKp = (size_t)(nfeatures + 2 * nlevels) * nframes;
+      const size_t maxKp = (size_t)(nfeatures + 4 * nlevels + 8) * nframes;  // >= selPerFrame * nframes
       if ((rc = d_sel.ensure(maxKp))) return rc;
       if ((rc = h_sel.ensure(maxKp))) return rc;
       if ((rc = d_angle.ensure(maxKp))) return rc;
       if ((rc = h_angle.ensure(maxKp))) return rc;
       if ((rc = d_desc.ensure(maxKp * 32))) return rc;
       if ((rc = h_desc.ensure(maxKp * 32))) return rc;
+      if (gpuQuadtree) {
+        const size_t ce = (size_t)P.candCap * nframes, nn = (size_t)nframes * nlevels * kQtNodeCap;
+        if ((rc = d_idxA.ensure(ce))) return rc;
+        if ((rc = d_idxB.ensure(ce))) return rc;
+        if ((rc = d_rank.ensure(ce))) return rc;
+        if ((rc = d_ownA.ensure(ce))) return rc;
+        if ((rc = d_ownB.ensure(ce))) return rc;
+        if ((rc = d_quad.ensure(ce))) return rc;
+        if ((rc = d_nodesA.ensure(nn))) return rc;
+        if ((rc = d_nodesB.ensure(nn))) return rc;
+        if ((rc = d_qtmp.ensure(nn))) return rc;
+        if ((rc = d_proc.ensure(nn))) return rc;
+        if ((rc = d_selCount.ensure((size_t)nframes * kMaxLevels))) return rc;
+        if ((rc = h_selCount.ensure((size_t)nframes * kMaxLevels))) return rc;
+      }
       batchCap = nframes;
+      if (candHostCap == 0) candHostCap = 96 * 1024;
+      if ((rc = h_cand.ensure(candHostCap * (size_t)batchCap))) return rc;
     }
     if (hostInput) {
       inPitch = align_up(cols, 256);
@@ -274,6 +319,114 @@ struct orbfe_extractor {
     return ORBFE_OK;
   }
 
+  // GPU-quadtree path: frame -> pyramid -> FAST -> compaction -> quadtree -> orientation/blur/rBRIEF in ONE
+  // stream submission, one synchronisation, fixed-size D2H of the selection slots.
+  int runGpuQt(int nframes, const uint8_t* const* gray, bool onDevice, int r, int c, size_t stride, OrbfeKeyPoint* kps,
+               uint8_t* desc, int cap, int* n_out) {
+    HIP_TRY(hipSetDevice(device));
+    int rc;
+    if ((rc = setGeometry(r, c))) return rc;
+    if ((rc = setBatch(nframes, !onDevice))) return rc;
+    const double t0 = now_ms();
+    hipStream_t st = streams[0];
+    for (int f = 0; f < nframes; f++) {
+      if (!gray[f]) { set_err("frame %d is NULL", f); return ORBFE_ERR_INVALID; }
+      h_frame0.p[f] = onDevice ? gray[f] : d_in.p + (size_t)inPitch * rows * f;
+      if (!onDevice)
+        HIP_TRY(hipMemcpy2DAsync(const_cast<uint8_t*>(h_frame0.p[f]), inPitch, gray[f], stride, c, r,
+                                 hipMemcpyHostToDevice, st));
+    }
+    P.stride0 = onDevice ? (long long)stride : inPitch;
+    P.frameBase = 0;
+    HIP_TRY(hipMemcpyAsync(d_frame0.p, h_frame0.p, sizeof(void*) * nframes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipEventRecord(ev[0][0], st));
+    launch_pyramid(P, nframes, st);
+    HIP_TRY(hipEventRecord(ev[0][1], st));
+    launch_fast(P, nframes, st);
+    HIP_TRY(hipEventRecord(ev[0][2], st));
+    launch_compact(P, nframes, st);
+    HIP_TRY(hipEventRecord(ev[0][3], st));
+    QP.cand = d_cand.p; QP.levelStart = d_levelStart.p; QP.candCap = P.candCap; QP.nlevels = nlevels; QP.frameBase = 0;
+    QP.idxA = d_idxA.p; QP.idxB = d_idxB.p; QP.ownA = d_ownA.p; QP.ownB = d_ownB.p; QP.quad = d_quad.p; QP.rank = d_rank.p;
+    QP.nodesA = d_nodesA.p; QP.nodesB = d_nodesB.p; QP.tmp = d_qtmp.p; QP.proc = d_proc.p;
+    QP.sel = d_sel.p; QP.selCount = d_selCount.p; QP.selPerFrame = selPerFrame;
+    for (int l = 0; l < nlevels; l++) {
+      QP.levW[l] = P.lv[l].w; QP.levH[l] = P.lv[l].h; QP.nfeat[l] = nfeat[l]; QP.selOff[l] = selOff[l];
+    }
+    HIP_TRY(hipEventRecord(evQt[0], st));
+    launch_quadtree(QP, nframes, st);
+    HIP_TRY(hipEventRecord(evQt[1], st));
+    const int nslots = nframes * selPerFrame;
+    HIP_TRY(hipEventRecord(ev[0][4], st));
+    launch_describe_slots(P, d_sel.p, nslots, d_angle.p, d_desc.p, d_selCount.p, selPerFrame, selOff, st);
+    HIP_TRY(hipEventRecord(ev[0][5], st));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h_selCount.p, d_selCount.p, sizeof(uint32_t) * kMaxLevels * nframes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h_sel.p, d_sel.p, sizeof(SelKp) * nslots, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h_angle.p, d_angle.p, sizeof(float) * nslots, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h_desc.p, d_desc.p, (size_t)32 * nslots, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h_levelStart.p, d_levelStart.p, sizeof(uint32_t) * (kMaxLevels + 1) * nframes,
+                           hipMemcpyDeviceToHost, st));
+    const double t1 = now_ms();
+    HIP_TRY(hipStreamSynchronize(st));
+    const double t2 = now_ms();
+    {
+      float ms = 0;
+      for (int i = 0; i < 3; i++)
+        if (hipEventElapsedTime(&ms, ev[0][i], ev[0][i + 1]) == hipSuccess) kernMs[i] += ms;
+      if (hipEventElapsedTime(&ms, ev[0][4], ev[0][5]) == hipSuccess) kernMs[3] += ms;
+      if (hipEventElapsedTime(&ms, evQt[0], evQt[1]) == hipSuccess) kernMs[4] += ms;
+      kernBatches++;
+      kernFrames += nframes;
+    }
+    int status = ORBFE_OK;
+    for (int f = 0; f < nframes; f++) {
+      OrbfeKeyPoint* ko = kps + (size_t)f * cap;
+      uint8_t* dout = desc + (size_t)f * cap * 32;
+      int n = 0;
+      for (int l = 0; l < nlevels; l++) {
+        const int cnt = (int)h_selCount.p[(size_t)f * kMaxLevels + l];
+        const size_t base = (size_t)f * selPerFrame + selOff[l];
+        const float scale = sf[l];
+        const float size = (float)(int)(31 * sf[l]);
+        for (int i = 0; i < cnt; i++) {
+          if (n >= cap) { n++; continue; }
+          const SelKp s = h_sel.p[base + i];
+          OrbfeKeyPoint kp;
+          kp.x = (float)(s.xy & 0xffff);
+          kp.y = (float)(s.xy >> 16);
+          if (l != 0) { kp.x *= scale; kp.y *= scale; }
+          kp.size = size;
+          kp.angle = h_angle.p[base + i];
+          kp.response = (float)(s.lf >> 24);
+          kp.octave = l;
+          kp.class_id = -1;
+          ko[n] = kp;
+          memcpy(dout + (size_t)n * 32, h_desc.p + (base + i) * 32, 32);
+          n++;
+        }
+      }
+      n_out[f] = n;
+      if (n > cap) {
+        set_err("frame %d produced %d keypoints, cap is %d", f, n, cap);
+        status = ORBFE_ERR_OVERFLOW;
+      }
+    }
+    const double t3 = now_ms();
+    stageMs[0] = (float)(t1 - t0);   // enqueue
+    stageMs[1] = (float)(t2 - t1);   // GPU wait
+    stageMs[2] = 0;
+    stageMs[3] = (float)(t3 - t2);   // output assembly
+    stageMs[4] = (float)(t3 - t0);
+    lastFrames = nframes;
+    return status;
+  }
+
+  // One batch = up to kMaxSub sub-batches, each on its own HIP stream, software-pipelined so that the
+  // host-side work of sub-batch s (candidate D2H, quadtrees) overlaps the GPU work of the others:
+  //   all s : [upload] pyramid -> FAST -> compaction -> D2H level offsets        (enqueued up front)
+  //   per s : wait -> D2H candidates -> host quadtrees -> H2D selection -> describe -> D2H (async)
+  //   all s : wait, assemble cv::KeyPoint-compatible outputs.
   int run(int nframes, const uint8_t* const* gray, bool onDevice, int r, int c, size_t stride, OrbfeKeyPoint* kps,
           uint8_t* desc, int cap, int* n_out) {
     HIP_TRY(hipSetDevice(device));
@@ -281,120 +434,145 @@ struct orbfe_extractor {
     if ((rc = setGeometry(r, c))) return rc;
     if ((rc = setBatch(nframes, !onDevice))) return rc;
     const double t0 = now_ms();
-    // ---- stage 1: upload, pyramid, FAST, ordered compaction --------------------------------
+    const int nsub = std::min(nframes, std::min(kMaxSub, std::max(1, subBatches)));
+    const int maxKp = nfeatures + 2 * nlevels;
+    int subF0[kMaxSub + 1];
+    for (int s = 0; s <= nsub; s++) subF0[s] = (int)((long long)nframes * s / nsub);
+
     for (int f = 0; f < nframes; f++) {
       if (!gray[f]) { set_err("frame %d is NULL", f); return ORBFE_ERR_INVALID; }
-      if (onDevice) {
-        h_frame0.p[f] = gray[f];
-      } else {
-        uint8_t* dst = d_in.p + (size_t)inPitch * rows * f;
-        HIP_TRY(hipMemcpy2DAsync(dst, inPitch, gray[f], stride, c, r, hipMemcpyHostToDevice, stream));
-        h_frame0.p[f] = dst;
-      }
+      h_frame0.p[f] = onDevice ? gray[f] : d_in.p + (size_t)inPitch * rows * f;
     }
     P.stride0 = onDevice ? (long long)stride : inPitch;
-    HIP_TRY(hipMemcpyAsync(d_frame0.p, h_frame0.p, sizeof(void*) * nframes, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipEventRecord(ev[0], stream));
-    launch_pyramid(P, nframes, stream);
-    HIP_TRY(hipEventRecord(ev[1], stream));
-    launch_fast(P, nframes, stream);
-    HIP_TRY(hipEventRecord(ev[2], stream));
-    launch_compact(P, nframes, stream);
-    HIP_TRY(hipEventRecord(ev[3], stream));
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(h_levelStart.p, d_levelStart.p, sizeof(uint32_t) * (kMaxLevels + 1) * nframes,
-                           hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
-    const double t1 = now_ms();
-    // ---- D2H of the candidates (exact sizes) ---------------------------------------------
-    size_t totalCand = 0;
-    std::vector<size_t> candStart(nframes + 1, 0);
-    for (int f = 0; f < nframes; f++) {
-      candStart[f] = totalCand;
-      totalCand += h_levelStart.p[(size_t)f * (kMaxLevels + 1) + nlevels];
-    }
-    candStart[nframes] = totalCand;
-    if ((rc = h_cand.ensure(totalCand + 1))) return rc;
-    for (int f = 0; f < nframes; f++) {
-      const size_t n = candStart[f + 1] - candStart[f];
-      if (n)
-        HIP_TRY(hipMemcpyAsync(h_cand.p + candStart[f], d_cand.p + (size_t)P.candCap * f, n * sizeof(uint32_t),
-                               hipMemcpyDeviceToHost, stream));
-    }
-    HIP_TRY(hipStreamSynchronize(stream));
-    const double t2 = now_ms();
-    // ---- host quadtree per (frame, level): DistributeOctTree, ORBextractor.cc:876-877 -------
-    meta.clear();
-    frameKpStart.assign(nframes + 1, 0);
-    const int ntasks = nframes * nlevels;
-    if ((int)taskOut.size() < ntasks) taskOut.resize(ntasks);
-    pool->parallelFor(ntasks, [&](int task, int wid) {
-      const int f = task / nlevels, l = task - f * nlevels;
-      std::vector<Meta>& out = taskOut[task];
-      out.clear();
-      const uint32_t* ls = h_levelStart.p + (size_t)f * (kMaxLevels + 1);
-      const int n = (int)(ls[l + 1] - ls[l]);
-      if (n <= 0) return;
-      Worker& w = workers[wid];
-      const uint32_t* cd = h_cand.p + candStart[f] + ls[l];
-      w.qx.resize(n); w.qy.resize(n); w.qs.resize(n);
-      for (int i = 0; i < n; i++) {
-        const uint32_t v = cd[i];
-        w.qx[i] = (int16_t)((int)(v & 0xfff) - kBorder);
-        w.qy[i] = (int16_t)((int)((v >> 12) & 0xfff) - kBorder);
-        w.qs[i] = (uint8_t)(v >> 24);
-      }
-      const LevelGeom& L = P.lv[l];
-      w.qt.distribute(w.qx.data(), w.qy.data(), w.qs.data(), n, kBorder, L.w - kBorder, kBorder, L.h - kBorder,
-                      nfeat[l], w.qsel);
-      out.reserve(w.qsel.size());
-      for (int k : w.qsel) {
-        Meta m;
-        m.x = (int16_t)(w.qx[k] + kBorder);
-        m.y = (int16_t)(w.qy[k] + kBorder);
-        m.score = w.qs[k];
-        m.level = (uint8_t)l;
-        out.push_back(m);
-      }
-    });
-    int nsel = 0;
-    for (int f = 0; f < nframes; f++) {
-      frameKpStart[f] = nsel;
-      for (int l = 0; l < nlevels; l++) {
-        for (const Meta& m : taskOut[(size_t)f * nlevels + l]) {
-          meta.push_back(m);
-          SelKp s;
-          s.xy = (uint32_t)m.x | ((uint32_t)m.y << 16);
-          s.lf = (uint32_t)l | ((uint32_t)f << 8);
-          h_sel.p[nsel++] = s;
-        }
-      }
-    }
-    frameKpStart[nframes] = nsel;
-    const double t3 = now_ms();
-    // ---- stage 2: orientation + blur + rBRIEF on the GPU -----------------------------------
-    if (nsel > 0) {
-      HIP_TRY(hipMemcpyAsync(d_sel.p, h_sel.p, sizeof(SelKp) * nsel, hipMemcpyHostToDevice, stream));
-      HIP_TRY(hipEventRecord(ev[4], stream));
-      launch_describe(P, d_sel.p, nsel, d_angle.p, d_desc.p, stream);
-      HIP_TRY(hipEventRecord(ev[5], stream));
+    HIP_TRY(hipMemcpyAsync(d_frame0.p, h_frame0.p, sizeof(void*) * nframes, hipMemcpyHostToDevice, streams[0]));
+    HIP_TRY(hipEventRecord(evFrame0, streams[0]));
+    // ---- stage 1 for every sub-batch -----------------------------------------------------
+    for (int s = 0; s < nsub; s++) {
+      hipStream_t st = streams[s];
+      const int f0 = subF0[s], nf = subF0[s + 1] - f0;
+      if (s) HIP_TRY(hipStreamWaitEvent(st, evFrame0, 0));
+      if (!onDevice)
+        for (int f = f0; f < f0 + nf; f++)
+          HIP_TRY(hipMemcpy2DAsync(const_cast<uint8_t*>(h_frame0.p[f]), inPitch, gray[f], stride, c, r,
+                                   hipMemcpyHostToDevice, st));
+      PyramidParams Q = P;
+      Q.frameBase = f0;
+      HIP_TRY(hipEventRecord(ev[s][0], st));
+      launch_pyramid(Q, nf, st);
+      HIP_TRY(hipEventRecord(ev[s][1], st));
+      launch_fast(Q, nf, st);
+      HIP_TRY(hipEventRecord(ev[s][2], st));
+      launch_compact(Q, nf, st);
+      HIP_TRY(hipEventRecord(ev[s][3], st));
       HIP_TRY(hipGetLastError());
-      HIP_TRY(hipMemcpyAsync(h_angle.p, d_angle.p, sizeof(float) * nsel, hipMemcpyDeviceToHost, stream));
-      HIP_TRY(hipMemcpyAsync(h_desc.p, d_desc.p, (size_t)32 * nsel, hipMemcpyDeviceToHost, stream));
-      HIP_TRY(hipStreamSynchronize(stream));
+      HIP_TRY(hipMemcpyAsync(h_levelStart.p + (size_t)f0 * (kMaxLevels + 1), d_levelStart.p + (size_t)f0 * (kMaxLevels + 1),
+                             sizeof(uint32_t) * (kMaxLevels + 1) * nf, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipEventRecord(evS1[s], st));
     }
-    {  // per-kernel GPU time of this batch (HIP events on the launch stream)
+    // ---- per sub-batch: candidates to the host, quadtrees, stage 2 ----------------------------
+    double tHostQt = 0, tWait = 0;
+    meta.assign((size_t)nframes * maxKp, Meta{});
+    frameKpCount.assign(nframes, 0);
+    frameKpBase.assign(nframes, 0);
+    if ((int)taskOut.size() < nframes * nlevels) taskOut.resize((size_t)nframes * nlevels);
+    for (int s = 0; s < nsub; s++) {
+      hipStream_t st = streams[s];
+      const int f0 = subF0[s], nf = subF0[s + 1] - f0;
+      double ta = now_ms();
+      HIP_TRY(hipEventSynchronize(evS1[s]));
+      // candidates: per-frame host regions of candHostCap entries (grown on demand)
+      uint32_t need = 0;
+      for (int f = f0; f < f0 + nf; f++) need = std::max(need, h_levelStart.p[(size_t)f * (kMaxLevels + 1) + nlevels]);
+      if (need > candHostCap) {
+        for (int q = 0; q < nsub; q++) HIP_TRY(hipStreamSynchronize(streams[q]));  // nobody may be writing h_cand
+        // sub-batches < s are already consumed, later ones have not copied yet: nothing to preserve
+        candHostCap = (size_t)need + need / 4 + 1024;
+        if ((rc = h_cand.ensure(candHostCap * (size_t)batchCap))) return rc;
+      }
+      for (int f = f0; f < f0 + nf; f++) {
+        const size_t n = h_levelStart.p[(size_t)f * (kMaxLevels + 1) + nlevels];
+        if (n)
+          HIP_TRY(hipMemcpyAsync(h_cand.p + candHostCap * f, d_cand.p + (size_t)P.candCap * f, n * sizeof(uint32_t),
+                                 hipMemcpyDeviceToHost, st));
+      }
+      HIP_TRY(hipStreamSynchronize(st));
+      double tb = now_ms();
+      tWait += tb - ta;
+      // host quadtree per (frame, level): DistributeOctTree, ORBextractor.cc:876-877
+      pool->parallelFor(nf * nlevels, [&](int task, int wid) {
+        const int f = f0 + task / nlevels, l = task % nlevels;
+        std::vector<Meta>& out = taskOut[(size_t)f * nlevels + l];
+        out.clear();
+        const uint32_t* ls = h_levelStart.p + (size_t)f * (kMaxLevels + 1);
+        const int n = (int)(ls[l + 1] - ls[l]);
+        if (n <= 0) return;
+        Worker& w = workers[wid];
+        const uint32_t* cd = h_cand.p + candHostCap * f + ls[l];
+        w.qx.resize(n); w.qy.resize(n); w.qs.resize(n);
+        for (int i = 0; i < n; i++) {
+          const uint32_t v = cd[i];
+          w.qx[i] = (int16_t)((int)(v & 0xfff) - kBorder);
+          w.qy[i] = (int16_t)((int)((v >> 12) & 0xfff) - kBorder);
+          w.qs[i] = (uint8_t)(v >> 24);
+        }
+        const LevelGeom& L = P.lv[l];
+        w.qt.distribute(w.qx.data(), w.qy.data(), w.qs.data(), n, kBorder, L.w - kBorder, kBorder, L.h - kBorder,
+                        nfeat[l], w.qsel);
+        out.reserve(w.qsel.size());
+        for (int k : w.qsel) {
+          Meta m;
+          m.x = (int16_t)(w.qx[k] + kBorder);
+          m.y = (int16_t)(w.qy[k] + kBorder);
+          m.score = w.qs[k];
+          m.level = (uint8_t)l;
+          out.push_back(m);
+        }
+      });
+      // selection of this sub-batch, packed from entry f0*maxKp
+      const int selBase = f0 * maxKp;
+      int nsel = 0;
+      for (int f = f0; f < f0 + nf; f++) {
+        frameKpBase[f] = selBase + nsel;
+        for (int l = 0; l < nlevels; l++) {
+          for (const Meta& m : taskOut[(size_t)f * nlevels + l]) {
+            meta[selBase + nsel] = m;
+            SelKp sk;
+            sk.xy = (uint32_t)m.x | ((uint32_t)m.y << 16);
+            sk.lf = (uint32_t)l | ((uint32_t)f << 8);
+            h_sel.p[selBase + nsel++] = sk;
+          }
+        }
+        frameKpCount[f] = selBase + nsel - frameKpBase[f];
+      }
+      subSel[s] = nsel;
+      tHostQt += now_ms() - tb;
+      // stage 2: orientation + blur + rBRIEF for this sub-batch (asynchronous)
+      if (nsel > 0) {
+        HIP_TRY(hipMemcpyAsync(d_sel.p + selBase, h_sel.p + selBase, sizeof(SelKp) * nsel, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipEventRecord(ev[s][4], st));
+        launch_describe(P, d_sel.p + selBase, nsel, d_angle.p + selBase, d_desc.p + (size_t)selBase * 32, st);
+        HIP_TRY(hipEventRecord(ev[s][5], st));
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h_angle.p + selBase, d_angle.p + selBase, sizeof(float) * nsel, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h_desc.p + (size_t)selBase * 32, d_desc.p + (size_t)selBase * 32, (size_t)32 * nsel,
+                               hipMemcpyDeviceToHost, st));
+      }
+    }
+    const double t3 = now_ms();
+    for (int s = 0; s < nsub; s++) HIP_TRY(hipStreamSynchronize(streams[s]));
+    const double t4 = now_ms();
+    for (int s = 0; s < nsub; s++) {  // per-kernel GPU time (HIP events on the launch streams)
       float ms = 0;
       for (int i = 0; i < 3; i++)
-        if (hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) kernMs[i] += ms;
-      if (nsel > 0 && hipEventElapsedTime(&ms, ev[4], ev[5]) == hipSuccess) kernMs[3] += ms;
+        if (hipEventElapsedTime(&ms, ev[s][i], ev[s][i + 1]) == hipSuccess) kernMs[i] += ms;
+      if (subSel[s] > 0 && hipEventElapsedTime(&ms, ev[s][4], ev[s][5]) == hipSuccess) kernMs[3] += ms;
       kernBatches++;
-      kernFrames += nframes;
     }
+    kernFrames += nframes;
     // ---- assemble cv::KeyPoint-compatible outputs (ORBextractor.cc:879-889, 959-967) --------
     int status = ORBFE_OK;
     for (int f = 0; f < nframes; f++) {
-      const int b = frameKpStart[f], n = frameKpStart[f + 1] - b;
+      const int b = frameKpBase[f], n = frameKpCount[f];
       n_out[f] = n;
       if (n > cap) {
         set_err("frame %d produced %d keypoints, cap is %d", f, n, cap);
@@ -421,12 +599,12 @@ struct orbfe_extractor {
       }
       if (m > 0) memcpy(desc + (size_t)f * cap * 32, h_desc.p + (size_t)b * 32, (size_t)m * 32);
     }
-    const double t4 = now_ms();
-    stageMs[0] = (float)(t1 - t0);
-    stageMs[1] = (float)(t2 - t1);
-    stageMs[2] = (float)(t3 - t2);
-    stageMs[3] = (float)(t4 - t3);
-    stageMs[4] = (float)(t4 - t0);
+    const double t5 = now_ms();
+    stageMs[0] = (float)tWait;          // waiting for stage 1 + candidate D2H
+    stageMs[1] = (float)tHostQt;        // host quadtrees + selection packing
+    stageMs[2] = (float)(t4 - t3);      // tail wait for stage 2
+    stageMs[3] = (float)(t5 - t4);      // output assembly
+    stageMs[4] = (float)(t5 - t0);
     lastFrames = nframes;
     return status;
   }
@@ -513,15 +691,35 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
     nDesired *= factor;
   }
   h->nfeat[nlevels - 1] = nfeatures - sum > 0 ? nfeatures - sum : 0;
-  hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
-  if (e != hipSuccess) {
-    set_err("hipStreamCreate failed: %s", hipGetErrorString(e));
-    delete h;
-    return ORBFE_ERR_HIP;
+  for (auto& st : h->streams) {
+    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      set_err("hipStreamCreate failed: %s", hipGetErrorString(e));
+      delete h;
+      return ORBFE_ERR_HIP;
+    }
   }
-  for (auto& evn : h->ev) {
-    if (hipEventCreate(&evn) != hipSuccess) { set_err("hipEventCreate failed"); delete h; return ORBFE_ERR_HIP; }
+  h->stream = h->streams[0];
+  bool evOk = hipEventCreate(&h->evFrame0) == hipSuccess;
+  for (auto& e : h->evS1) evOk = evOk && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+  for (auto& es : h->ev) for (auto& e : es) evOk = evOk && hipEventCreate(&e) == hipSuccess;
+  if (!evOk) { set_err("hipEventCreate failed"); delete h; return ORBFE_ERR_HIP; }
+  if (const char* sv = getenv("ORBFE_SUB_BATCHES")) h->subBatches = atoi(sv);
+  for (auto& e : h->evQt) evOk = evOk && hipEventCreate(&e) == hipSuccess;
+  if (!evOk) { set_err("hipEventCreate failed"); delete h; return ORBFE_ERR_HIP; }
+  if (const char* hv = getenv("ORBFE_HOST_QUADTREE")) h->gpuQuadtree = atoi(hv) == 0;
+  h->selPerFrame = 0;
+  for (int l = 0; l < nlevels; l++) {
+    h->selOff[l] = h->selPerFrame;
+    h->selPerFrame += h->nfeat[l] + 4;
+    if (h->gpuQuadtree && h->nfeat[l] + 4 > kQtNodeCap) {
+      set_err("nfeatures=%d puts %d features on level %d; the GPU quadtree handles at most %d per level "
+              "(set ORBFE_HOST_QUADTREE=1 for the host quadtree)", nfeatures, h->nfeat[l], l, kQtNodeCap - 4);
+      delete h;
+      return ORBFE_ERR_INVALID;
+    }
   }
+  h->selOff[nlevels] = h->selPerFrame;
   // host workers for the per-(frame, level) quadtrees: ORBFE_HOST_THREADS, default min(cores, 16)
   int nthreads = (int)std::thread::hardware_concurrency();
   if (nthreads > 16) nthreads = 16;
@@ -563,6 +761,7 @@ int orbfe_extract_batch(orbfe_extractor* h, int nframes, const uint8_t* const* g
     set_err("invalid image / output arguments");
     return ORBFE_ERR_INVALID;
   }
+  if (h->gpuQuadtree) return h->runGpuQt(nframes, gray, in_device_memory != 0, rows, cols, stride_bytes, kps, desc, cap, n_out);
   return h->run(nframes, gray, in_device_memory != 0, rows, cols, stride_bytes, kps, desc, cap, n_out);
 }
 
@@ -629,9 +828,9 @@ int orbfe_debug_stage_ms(const orbfe_extractor* h, float out[5]) {
   return ORBFE_OK;
 }
 
-int orbfe_debug_kernel_ms(orbfe_extractor* h, double out_ms[4], long long* batches, long long* frames, int reset) {
+int orbfe_debug_kernel_ms(orbfe_extractor* h, double out_ms[5], long long* batches, long long* frames, int reset) {
   if (!h) { set_err("handle is NULL"); return ORBFE_ERR_INVALID; }
-  for (int i = 0; i < 4; i++) if (out_ms) out_ms[i] = h->kernMs[i];
+  for (int i = 0; i < 5; i++) if (out_ms) out_ms[i] = h->kernMs[i];
   if (batches) *batches = h->kernBatches;
   if (frames) *frames = h->kernFrames;
   if (reset) {

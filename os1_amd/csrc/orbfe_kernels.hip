@@ -25,7 +25,7 @@ namespace orbfe {
 __global__ __launch_bounds__(256) void k_resize(PyramidParams P, int level) {
   const LevelGeom& D = P.lv[level];
   const LevelGeom& S = P.lv[level - 1];
-  const int f = blockIdx.z;
+  const int f = P.frameBase + blockIdx.z;
   const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
   const int y = blockIdx.y * 4 + threadIdx.y;
   if (x0 >= D.w || y >= D.h) return;
@@ -97,10 +97,28 @@ __device__ __forceinline__ int max_arc_min9(const int d[16]) {
   return best;
 }
 
+// Work decomposition inside the wave (all stages keep row-major order, so the final list is already
+// in cv::FAST's emission order):
+//   stage 1  every emit pixel: 4-point compass pre-test (a 9-arc always contains two ADJACENT compass
+//            points of the same polarity) -> ballot-compacted queue of survivors
+//   stage 2  queue: full 16-point arc test at tlo = min(iniTh, minTh) -> compacted in place
+//   stage 3  queue: score S-1 (only the polarity that passed) -> score tile
+//   stage 4  queue: 3x3 NMS against the score tile, iniTh/minTh decision by ballot, ordered write
+// Blocks are remapped so that the blocks an XCD receives (b, b+8, b+16, ...) are CONSECUTIVE cells:
+// neighbouring cells share ROI halos and cache lines in that XCD's L2.
+__device__ __forceinline__ void ring_diffs(const uint8_t* c, int TP, int v, int d[16]) {
+  d[0] = v - c[3 * TP];       d[1] = v - c[3 * TP + 1];   d[2] = v - c[2 * TP + 2];   d[3] = v - c[TP + 3];
+  d[4] = v - c[3];            d[5] = v - c[-TP + 3];      d[6] = v - c[-2 * TP + 2];  d[7] = v - c[-3 * TP + 1];
+  d[8] = v - c[-3 * TP];      d[9] = v - c[-3 * TP - 1];  d[10] = v - c[-2 * TP - 2]; d[11] = v - c[-TP - 3];
+  d[12] = v - c[-3];          d[13] = v - c[TP - 3];      d[14] = v - c[2 * TP - 2];  d[15] = v - c[3 * TP - 1];
+}
+
 __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
   extern __shared__ __align__(16) uint8_t lds[];
-  const int cell = blockIdx.x;
-  const int f = blockIdx.y;
+  const int chunk = (P.ncells + 7) >> 3;
+  const int cell = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (cell >= P.ncells) return;
+  const int f = P.frameBase + blockIdx.y;
   const int lane = threadIdx.x;
   int level = 0;
   while (level + 1 < P.nlevels && cell >= P.lv[level + 1].cellBase) level++;
@@ -123,62 +141,151 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
     img = P.slab + (long long)f * P.slabBytes + L.off;
     stride = L.pitch;
   }
-  // LDS carve: ROI tile (ew+6)x(eh+6), score tile (ew+2)x(eh+2) with a zero ring, kept-score tile ew x eh
-  const int TP = (L.wCell + 6 + 3) & ~3;
+  // LDS carve: ROI tile, score tile with a zero ring, queue (y<<8|x), kept score per queue entry
+  const int TP = (L.wCell + 6 + 3 + 3) & ~3;
   const int SP = L.wCell + 2;
   uint8_t* tile = lds;
   uint8_t* sc = tile + TP * (L.hCell + 6);
-  uint8_t* kept = sc + SP * (L.hCell + 2);
+  uint16_t* queue = reinterpret_cast<uint16_t*>(lds + ((TP * (L.hCell + 6) + SP * (L.hCell + 2) + 3) & ~3));
+  uint8_t* kept = reinterpret_cast<uint8_t*>(queue + L.wCell * L.hCell);
 
   const int rw = ew + 6, rh = eh + 6;
+  const float rcpEw = 1.0f / (float)ew;
   const uint8_t* roi = img + (long long)(ey0 - 3) * stride + (ex0 - 3);
-  for (int i = lane; i < rw * rh; i += 64) {
-    const int y = i / rw, x = i - y * rw;
-    tile[y * TP + x] = roi[(long long)y * stride + x];
+  // ROI -> LDS.  Loads are issued in batches of 8 per lane before the first LDS write so the wave
+  // waits for memory once per batch, not once per element.  Rows are fetched as aligned dwords when
+  // the row pitch allows it; `a` is the byte offset of the ROI inside its first dword.
+  const int a = (int)(reinterpret_cast<uintptr_t>(roi) & 3);
+  if ((stride & 3) == 0) {
+    const int ndw = (a + rw + 3) >> 2;
+    const float rcpNdw = 1.0f / (float)ndw;
+    const int total = ndw * rh;
+    const uint8_t* base = roi - a;
+    for (int i0 = lane; i0 < total; i0 += 64 * 8) {
+      uint32_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = i0 + u * 64;
+        v[u] = 0;
+        if (i < total) {
+          const int y = (int)(((float)i + 0.5f) * rcpNdw), c = i - y * ndw;
+          v[u] = *reinterpret_cast<const uint32_t*>(base + (long long)y * stride + 4 * c);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = i0 + u * 64;
+        if (i < total) {
+          const int y = (int)(((float)i + 0.5f) * rcpNdw), c = i - y * ndw;
+          *reinterpret_cast<uint32_t*>(tile + y * TP + 4 * c) = v[u];
+        }
+      }
+    }
+  } else {
+    const float rcpRw = 1.0f / (float)rw;
+    const int total = rw * rh;
+    for (int i0 = lane; i0 < total; i0 += 64 * 8) {
+      uint8_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = i0 + u * 64;
+        v[u] = 0;
+        if (i < total) {
+          const int y = (int)(((float)i + 0.5f) * rcpRw), x = i - y * rw;
+          v[u] = roi[(long long)y * stride + x];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = i0 + u * 64;
+        if (i < total) {
+          const int y = (int)(((float)i + 0.5f) * rcpRw), x = i - y * rw;
+          tile[y * TP + a + x] = v[u];
+        }
+      }
+    }
   }
+  tile += a;  // ROI pixel (x, y) lives at tile[y * TP + x]
   for (int i = lane; i < SP * (eh + 2); i += 64) sc[i] = 0;
   __syncthreads();
 
   const int tlo = min(P.iniTh, P.minTh);
   const int npx = ew * eh;
-  for (int i = lane; i < npx; i += 64) {
-    const int y = i / ew, x = i - y * ew;
-    const uint8_t* c = tile + (y + 3) * TP + (x + 3);
-    const int v = c[0];
-    int d[16];
-    d[0] = v - c[3 * TP];       d[1] = v - c[3 * TP + 1];   d[2] = v - c[2 * TP + 2];   d[3] = v - c[TP + 3];
-    d[4] = v - c[3];            d[5] = v - c[-TP + 3];      d[6] = v - c[-2 * TP + 2];  d[7] = v - c[-3 * TP + 1];
-    d[8] = v - c[-3 * TP];      d[9] = v - c[-3 * TP - 1];  d[10] = v - c[-2 * TP - 2]; d[11] = v - c[-TP - 3];
-    d[12] = v - c[-3];          d[13] = v - c[TP - 3];      d[14] = v - c[2 * TP - 2];  d[15] = v - c[3 * TP - 1];
-    unsigned mdark = 0, mbright = 0;  // ring darker than centre by > tlo / brighter by > tlo
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-      mdark |= (unsigned)(d[k] > tlo) << k;
-      mbright |= (unsigned)(d[k] < -tlo) << k;
-    }
-    int s = 0;
-    const bool pd = has_arc9(mdark), pb = has_arc9(mbright);
-    if (pd | pb) {
-      int S = 0;
-      if (pd) S = max_arc_min9(d);
-      if (pb) {
-        int nd[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) nd[k] = -d[k];
-        S = max(S, max_arc_min9(nd));
-      }
-      s = S - 1;  // > tlo - 1, <= 254
-    }
-    sc[(y + 1) * SP + (x + 1)] = (uint8_t)s;
-  }
-  __syncthreads();
-
-  bool anyIni = false;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  // ---- stage 1: compass pre-test -------------------------------------------------------------
+  int nq = 0;
   for (int i0 = 0; i0 < npx; i0 += 64) {
     const int i = i0 + lane;
-    int keep = 0;
+    bool pass = false;
+    int y = 0, x = 0;
     if (i < npx) {
-      const int y = i / ew, x = i - y * ew;
+      y = (int)(((float)i + 0.5f) * rcpEw);
+      x = i - y * ew;
+      const uint8_t* c = tile + (y + 3) * TP + (x + 3);
+      const int v = c[0];
+      const int d0 = v - c[3 * TP], d4 = v - c[3], d8 = v - c[-3 * TP], d12 = v - c[-3];
+      const bool k0 = d0 > tlo, k4 = d4 > tlo, k8 = d8 > tlo, k12 = d12 > tlo;
+      const bool b0 = d0 < -tlo, b4 = d4 < -tlo, b8 = d8 < -tlo, b12 = d12 < -tlo;
+      pass = (k0 & k4) | (k4 & k8) | (k8 & k12) | (k12 & k0) | (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0);
+    }
+    const unsigned long long m = __ballot(pass);
+    if (pass) queue[nq + __popcll(m & below)] = (uint16_t)((y << 8) | x);
+    nq += __popcll(m);
+  }
+  __syncthreads();
+  // ---- stage 2: full arc test, compacted in place; bit 15 / 7 carry the polarity ----------------
+  int nq2 = 0;
+  for (int i0 = 0; i0 < nq; i0 += 64) {
+    const int i = i0 + lane;
+    bool pass = false;
+    unsigned e = 0;
+    if (i < nq) {
+      e = queue[i];
+      const int y = e >> 8, x = e & 0xff;
+      const uint8_t* c = tile + (y + 3) * TP + (x + 3);
+      int d[16];
+      ring_diffs(c, TP, c[0], d);
+      unsigned mdark = 0, mbright = 0;
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        mdark |= (unsigned)(d[k] > tlo) << k;
+        mbright |= (unsigned)(d[k] < -tlo) << k;
+      }
+      const bool pd = has_arc9(mdark), pb = has_arc9(mbright);
+      pass = pd | pb;
+      e |= (pd ? 0x8000u : 0u) | (pb ? 0x80u : 0u);  // y, x < 64: bits 15 and 7 are free
+    }
+    // the ballot consumes every lane's queue read, so the in-place writes below cannot overtake them
+    const unsigned long long m = __ballot(pass);
+    if (pass) queue[nq2 + __popcll(m & below)] = (uint16_t)e;
+    nq2 += __popcll(m);
+  }
+  __syncthreads();
+  // ---- stage 3: scores -------------------------------------------------------------------------
+  for (int i = lane; i < nq2; i += 64) {
+    const unsigned e = queue[i];
+    const int y = (e >> 8) & 0x7f, x = e & 0x7f;
+    const uint8_t* c = tile + (y + 3) * TP + (x + 3);
+    int d[16];
+    ring_diffs(c, TP, c[0], d);
+    int S = 0;
+    if (e & 0x8000u) S = max_arc_min9(d);
+    if (e & 0x80u) {
+#pragma unroll
+      for (int k = 0; k < 16; k++) d[k] = -d[k];
+      S = max(S, max_arc_min9(d));
+    }
+    sc[(y + 1) * SP + (x + 1)] = (uint8_t)(S - 1);  // tlo <= S-1 <= 254
+  }
+  __syncthreads();
+  // ---- stage 4: NMS inside the emit region, threshold decision, ordered emission ----------------
+  bool anyIni = false;
+  for (int i0 = 0; i0 < nq2; i0 += 64) {
+    const int i = i0 + lane;
+    int keep = 0;
+    if (i < nq2) {
+      const unsigned e = queue[i];
+      const int y = (e >> 8) & 0x7f, x = e & 0x7f;
       const uint8_t* q = sc + (y + 1) * SP + (x + 1);
       const int s = q[0];
       if (s > 0 && s > q[-1] && s > q[1] && s > q[-SP - 1] && s > q[-SP] && s > q[-SP + 1] && s > q[SP - 1] &&
@@ -186,23 +293,25 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
         keep = s;
       kept[i] = (uint8_t)keep;
     }
-    anyIni |= (__ballot(keep >= P.iniTh && keep > 0) != 0ull);
+    anyIni |= (__ballot(keep > 0 && keep >= P.iniTh) != 0ull);
   }
   __syncthreads();
-
   const int th = anyIni ? P.iniTh : P.minTh;
   uint32_t* slot = P.slots + (long long)f * P.slotsPerFrame + L.slotBase + (long long)local * L.slotCap;
   int base = 0;
-  for (int i0 = 0; i0 < npx; i0 += 64) {
+  for (int i0 = 0; i0 < nq2; i0 += 64) {
     const int i = i0 + lane;
     int s = 0;
-    if (i < npx) s = kept[i];
+    unsigned e = 0;
+    if (i < nq2) {
+      s = kept[i];
+      e = queue[i];
+    }
     const bool emit = s > 0 && s >= th;
     const unsigned long long m = __ballot(emit);
     if (emit) {
-      const int y = i / ew, x = i - y * ew;
-      const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-      slot[pos] = (uint32_t)(ex0 + x) | ((uint32_t)(ey0 + y) << 12) | ((uint32_t)s << 24);
+      const int y = (e >> 8) & 0x7f, x = e & 0x7f;
+      slot[base + __popcll(m & below)] = (uint32_t)(ex0 + x) | ((uint32_t)(ey0 + y) << 12) | ((uint32_t)s << 24);
     }
     base += __popcll(m);
   }
@@ -217,7 +326,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
 __global__ __launch_bounds__(1024) void k_scan_cells(PyramidParams P) {
   __shared__ uint32_t wsum[16];
   __shared__ uint32_t carry;
-  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int f = P.frameBase + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const uint32_t* cnt = P.cellCount + (long long)f * P.ncells;
   uint32_t* off = P.cellOff + (long long)f * P.ncells;
   if (tid == 0) carry = 0;
@@ -247,7 +356,7 @@ __global__ __launch_bounds__(1024) void k_scan_cells(PyramidParams P) {
 }
 
 __global__ __launch_bounds__(64) void k_gather(PyramidParams P) {
-  const int cell = blockIdx.x, f = blockIdx.y, lane = threadIdx.x;
+  const int cell = blockIdx.x, f = P.frameBase + blockIdx.y, lane = threadIdx.x;
   const uint32_t n = P.cellCount[(long long)f * P.ncells + cell];
   if (n == 0) return;
   int level = 0;
@@ -306,17 +415,35 @@ constexpr int kRawW = 2 * kRawRad + 1;   // 43
 constexpr int kBlurW = 2 * kBlurRad + 1; // 37
 constexpr int kRawP = 44, kHP = 38, kBP = 40;
 
+// Slot mode (GPU quadtree): `sel` is laid out [frame][selPerFrame] with per-level sub-regions; slot k is
+// live iff its index inside its level region is below selCount[frame][level].  Dense mode (host
+// quadtree): selCount == nullptr and every k < nsel is live.
+struct SlotInfo {
+  const uint32_t* selCount;  // [nframes][kMaxLevels] or nullptr
+  int selPerFrame;
+  int selOff[kMaxLevels + 1];
+  int nlevels;
+};
+
 __global__ __launch_bounds__(64) void k_describe(PyramidParams P, const SelKp* __restrict__ sel, int nsel,
-                                                  float* __restrict__ angleOut, uint8_t* __restrict__ descOut) {
+                                                  float* __restrict__ angleOut, uint8_t* __restrict__ descOut,
+                                                  SlotInfo SI) {
   __shared__ __align__(16) uint8_t raw[kRawW * kRawP];
   __shared__ __align__(16) uint16_t hb[kRawW * kHP];
   __shared__ __align__(16) uint8_t bl[kBlurW * kBP];
   const int k = blockIdx.x;
   if (k >= nsel) return;
+  if (SI.selCount) {
+    const int fr = k / SI.selPerFrame, within = k - fr * SI.selPerFrame;
+    int l = 0;
+    while (l + 1 < SI.nlevels && within >= SI.selOff[l + 1]) l++;
+    const int frameAbs = P.frameBase + fr;
+    if ((uint32_t)(within - SI.selOff[l]) >= SI.selCount[(long long)frameAbs * kMaxLevels + l]) return;
+  }
   const int lane = threadIdx.x;
   const SelKp s = sel[k];
   const int cx = s.xy & 0xffff, cy = s.xy >> 16;
-  const int level = s.lf & 0xff, f = s.lf >> 8;
+  const int level = s.lf & 0xff, f = (s.lf >> 8) & 0xffff;
   const LevelGeom& L = P.lv[level];
   const uint8_t* img;
   long long stride;
@@ -327,10 +454,27 @@ __global__ __launch_bounds__(64) void k_describe(PyramidParams P, const SelKp* _
     img = P.slab + (long long)f * P.slabBytes + L.off;
     stride = L.pitch;
   }
-  for (int i = lane; i < kRawW * kRawW; i += 64) {
-    const int y = i / kRawW, x = i - y * kRawW;
-    const int gx = reflect101(cx - kRawRad + x, L.w), gy = reflect101(cy - kRawRad + y, L.h);
-    raw[y * kRawP + x] = img[(long long)gy * stride + gx];
+  // 43x43 raw patch -> LDS, loads batched 8 deep per lane (one memory wait per batch)
+  for (int i0 = lane; i0 < kRawW * kRawW; i0 += 64 * 8) {
+    uint8_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int i = i0 + u * 64;
+      v[u] = 0;
+      if (i < kRawW * kRawW) {
+        const int y = i / kRawW, x = i - y * kRawW;
+        const int gx = reflect101(cx - kRawRad + x, L.w), gy = reflect101(cy - kRawRad + y, L.h);
+        v[u] = img[(long long)gy * stride + gx];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int i = i0 + u * 64;
+      if (i < kRawW * kRawW) {
+        const int y = i / kRawW, x = i - y * kRawW;
+        raw[y * kRawP + x] = v[u];
+      }
+    }
   }
   __syncthreads();
 
@@ -406,15 +550,16 @@ size_t fast_lds_bytes(const PyramidParams& P) {
   size_t mx = 0;
   for (int l = 0; l < P.nlevels; l++) {
     const LevelGeom& L = P.lv[l];
-    const size_t TP = (L.wCell + 6 + 3) & ~3;
-    const size_t b = TP * (L.hCell + 6) + (size_t)(L.wCell + 2) * (L.hCell + 2) + (size_t)L.wCell * L.hCell;
+    const size_t TP = (L.wCell + 6 + 3 + 3) & ~3;
+    const size_t b = ((TP * (L.hCell + 6) + (size_t)(L.wCell + 2) * (L.hCell + 2) + 3) & ~(size_t)3) +
+                     3 * (size_t)L.wCell * L.hCell;  // tile + score tile + u16 queue + u8 kept
     mx = b > mx ? b : mx;
   }
   return (mx + 15) & ~(size_t)15;
 }
 
 void launch_fast(const PyramidParams& P, int nframes, hipStream_t st) {
-  hipLaunchKernelGGL(k_fast_cells, dim3(P.ncells, nframes), dim3(64), fast_lds_bytes(P), st, P);
+  hipLaunchKernelGGL(k_fast_cells, dim3(8 * ((P.ncells + 7) / 8), nframes), dim3(64), fast_lds_bytes(P), st, P);
 }
 
 void launch_compact(const PyramidParams& P, int nframes, hipStream_t st) {
@@ -425,7 +570,21 @@ void launch_compact(const PyramidParams& P, int nframes, hipStream_t st) {
 void launch_describe(const PyramidParams& P, const SelKp* sel, int nsel, float* angle, uint8_t* desc,
                      hipStream_t st) {
   if (nsel <= 0) return;
-  hipLaunchKernelGGL(k_describe, dim3(nsel), dim3(64), 0, st, P, sel, nsel, angle, desc);
+  SlotInfo si{};
+  si.selCount = nullptr;
+  hipLaunchKernelGGL(k_describe, dim3(nsel), dim3(64), 0, st, P, sel, nsel, angle, desc, si);
+}
+
+// sel/angle/desc point at the first slot of frame P.frameBase; nslots = nframes * selPerFrame
+void launch_describe_slots(const PyramidParams& P, const SelKp* sel, int nslots, float* angle, uint8_t* desc,
+                           const uint32_t* selCount, int selPerFrame, const int* selOff, hipStream_t st) {
+  if (nslots <= 0) return;
+  SlotInfo si{};
+  si.selCount = selCount;
+  si.selPerFrame = selPerFrame;
+  si.nlevels = P.nlevels;
+  for (int l = 0; l <= P.nlevels; l++) si.selOff[l] = selOff[l];
+  hipLaunchKernelGGL(k_describe, dim3(nslots), dim3(64), 0, st, P, sel, nslots, angle, desc, si);
 }
 
 void launch_sincos(const float* deg, int n, float* c, float* s, hipStream_t st) {

@@ -218,3 +218,22 @@ def test_search_by_projection_uv_parity(api, oracle):
                                                 d1, th, maxd, skip_any, ori)
         assert n == on and (a == oa).all()
     assert n > 50
+
+
+def test_host_and_gpu_quadtree_paths_agree(api, oracle, monkeypatch):
+    """The extractor has two thinning back ends (GPU-resident k_quadtree, default; host quadtree.h);
+    both must reproduce the oracle on awkward inputs."""
+    rng = np.random.default_rng(17)
+    imgs = [synth(40, 1280, 720), rng.integers(0, 256, (600, 800), dtype=np.uint8),
+            (((np.mgrid[0:480, 0:640][0] // 9) + (np.mgrid[0:480, 0:640][1] // 7)) % 2 * 200 + 20).astype(np.uint8)]
+    for N in (2000, 137, 4000):
+        ox = OracleExtractor(N, 1.2, 8, 20, 7, oracle)
+        monkeypatch.setenv('ORBFE_HOST_QUADTREE', '1')
+        ex_host = api.Extractor(N, 1.2, 8, 20, 7)
+        monkeypatch.setenv('ORBFE_HOST_QUADTREE', '0')
+        ex_gpu = api.Extractor(N, 1.2, 8, 20, 7)
+        for im in imgs:
+            want = ox.extract(im)
+            _cmp_extract(ex_host(im), want)
+            _cmp_extract(ex_gpu(im), want)
+    monkeypatch.delenv('ORBFE_HOST_QUADTREE')

@@ -22,5 +22,7 @@ for it in range(R):
     _, _, n = ex.extract_batch_ptrs(ptrs, H, W, W, True, kps, desc)
     acc += ex.stage_ms()
 dt = time.time() - t
-print('B=%d  %.2f ms/batch  %.1f fps  stages(ms) gpu1=%.2f d2h=%.2f quadtree=%.2f gpu2=%.2f total=%.2f  n=%s' % (
+km, kb, kf = ex.kernel_ms()
+print('gpu us/frame: pyramid %.1f fast %.1f compact %.1f describe %.1f quadtree %.1f' % tuple(km / kf * 1e3))
+print('B=%d  %.2f ms/batch  %.1f fps  host(ms) wait1=%.2f quadtree=%.2f wait2=%.2f assemble=%.2f total=%.2f  n=%s' % (
     B, dt / R * 1e3, B * R / dt, *(acc / R), n[:4]))
