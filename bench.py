@@ -37,6 +37,7 @@ def main():
     ap.add_argument('--batch', type=int, default=16, help='frames per step and GPU')
     ap.add_argument('--cpu-frames', type=int, default=24, help='frames of the CPU-oracle baseline sample (0 = skip)')
     ap.add_argument('--no-match', action='store_true', help='extract only (configs[1])')
+    ap.add_argument('--depth', type=int, default=2, help='extraction batches in flight (one extractor handle each)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -63,11 +64,13 @@ def main():
 
     B = args.batch
     seed = 100 + rank                       # config 4: stream g -> GPU g, seeds 100+g
-    frames = [synth(seed, W, H)]
-    for i in range(1, B):
-        frames.append(shifted(frames[-1], 2, 1, seed * 1000 + i))   # each frame = previous shifted by (2,1) px
+    base = synth(seed, W, H)
+    # frame i = the scene translated by (2i, i) px with fresh +-4 sensor noise ("each frame = previous shifted
+    # by (2,1) px"; derived from the base frame so that noise does not accumulate along the stream)
+    frames = [base] + [shifted(base, 2 * i, i, seed * 1000 + i) for i in range(1, B)]
     dev = api.DeviceFrames(frames, local_rank)
-    ex = api.Extractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank)
+    exs = [api.Extractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank) for _ in range(max(1, args.depth))]
+    ex = exs[0]
     mt = api.Matcher(local_rank)
     kps = np.zeros((B, ex.cap), api.KP_DTYPE)
     desc = np.zeros((B, ex.cap, 32), np.uint8)
@@ -75,39 +78,63 @@ def main():
     last = [None]
     nmatch_total = [0]
 
-    def step():
-        _, _, n = ex.extract_batch_ptrs(dev.ptrs, H, W, dev.stride, True, kps, desc)
-        if args.no_match:
-            return
+    def match(n):
+        pairs = []
         for i in range(B):
             cur = (kps[i, :n[i]], desc[i, :n[i]])
             prev = last[0] if i == 0 else (kps[i - 1, :n[i - 1]], desc[i - 1, :n[i - 1]])
             if prev is not None:
-                pxy = np.stack([prev[0]['x'], prev[0]['y']], 1)       # vbPrevMatched := F1 keypoints (Tracking.cc:355-357)
-                nm, _, _ = mt.search_for_initialization(prev[0], prev[1], cur[0], cur[1], bounds, pxy, 100, 0.9, True)
-                nmatch_total[0] += nm
+                pxy = np.empty((len(prev[0]), 2), np.float32)         # vbPrevMatched := F1 keypoints (Tracking.cc:355-357)
+                pxy[:, 0] = prev[0]['x']
+                pxy[:, 1] = prev[0]['y']
+                pairs.append((prev[0], prev[1], cur[0], cur[1], pxy))
+        # one GPU submission for all pairs of the step (orbfe_search_for_initialization_batch)
+        for nm, _, _ in mt.search_for_initialization_batch(pairs, bounds, 100, 0.9, True):
+            nmatch_total[0] += nm
         last[0] = (kps[B - 1, :n[B - 1]].copy(), desc[B - 1, :n[B - 1]].copy())
+
+    def run(nsteps):
+        """nsteps passes of the hot path.  The extraction of batch k+1 is submitted (asynchronously, on the
+        extractor's stream) before batch k is matched, so GPU extraction overlaps host-side match bookkeeping;
+        every submit, collect and match of the nsteps batches happens inside this call.  `--depth` extractor
+        handles keep that many batches in flight."""
+        if nsteps <= 0:
+            return
+        D = len(exs)
+        for j in range(min(D, nsteps)):
+            exs[j].submit_ptrs(dev.ptrs, H, W, dev.stride, True)
+        for k in range(nsteps):
+            h = exs[k % D]
+            _, _, n = h.collect(kps, desc)
+            if k + D < nsteps:
+                h.submit_ptrs(dev.ptrs, H, W, dev.stride, True)
+            if not args.no_match:
+                match(n)
 
     def sync():
         api.device_synchronize(local_rank)
         if have_torch_gpu:
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    ex.kernel_ms(reset=True)
+    run(args.warmup)
+    for e in exs:
+        e.kernel_ms(reset=True)
     nmatch_total[0] = 0
     sync()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run(args.steps)
     sync()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    kms, kbatches, kframes = ex.kernel_ms()
+    kms, kbatches, kframes = np.zeros(5), 0, 0
+    for e in exs:
+        a, b_, c_ = e.kernel_ms()
+        kms += a
+        kbatches += b_
+        kframes += c_
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -103,6 +103,15 @@ int orbfe_extract_batch(orbfe_extractor* h, int nframes, const uint8_t* const* g
                         int rows, int cols, size_t stride_bytes, OrbfeKeyPoint* kps, uint8_t* desc, int cap,
                         int* n_out);
 
+/* Asynchronous form of orbfe_extract_batch: _submit enqueues the whole extractor for the batch on the
+ * handle's stream and returns at once; _collect waits for it and fills the outputs exactly as
+ * orbfe_extract_batch does.  One batch may be outstanding per handle; the frames (and, for host input,
+ * the host buffers) must stay valid until _collect returns.  Lets a caller overlap the GPU extraction of
+ * batch k+1 with the matching of batch k. */
+int orbfe_extract_batch_submit(orbfe_extractor* h, int nframes, const uint8_t* const* gray, int in_device_memory,
+                               int rows, int cols, size_t stride_bytes);
+int orbfe_extract_batch_collect(orbfe_extractor* h, OrbfeKeyPoint* kps, uint8_t* desc, int cap, int* n_out);
+
 /* Stage accessors for the parity tests (state of the LAST extract call, frame index in batch). */
 int orbfe_debug_level_size(const orbfe_extractor* h, int level, int* w, int* hgt);
 int orbfe_debug_level_copy(orbfe_extractor* h, int frame, int level, uint8_t* out /* w*h, tight */);
@@ -156,6 +165,16 @@ int orbfe_search_for_initialization(orbfe_matcher* m, const OrbfeKeyPoint* kps1,
                                     const OrbfeKeyPoint* kps2, const uint8_t* desc2, int n2,
                                     const float bounds[4], float* prev_xy, int32_t* matches12, int window_size,
                                     float nnratio, int check_orientation, int* nmatches);
+
+/* Batched form for throughput callers: npairs independent (F1, F2) pairs, one upload + one kernel launch +
+ * one download for all of them, bookkeeping of the pairs resolved in parallel on the host.  Arrays of
+ * per-pair pointers/sizes; bounds are shared (same camera). nmatches: npairs ints. */
+int orbfe_search_for_initialization_batch(orbfe_matcher* m, int npairs, const OrbfeKeyPoint* const* kps1,
+                                          const uint8_t* const* desc1, const int* n1,
+                                          const OrbfeKeyPoint* const* kps2, const uint8_t* const* desc2,
+                                          const int* n2, const float bounds[4], float* const* prev_xy,
+                                          int32_t* const* matches12, int window_size, float nnratio,
+                                          int check_orientation, int* nmatches);
 
 /* MapPoint flag bits for the searches below. */
 #define ORBFE_MP_IN_VIEW 1u    /* MapPoint::mbTrackInView                                   */

@@ -61,6 +61,8 @@ def load_library():
     L.orbfe_extractor_max_keypoints.argtypes = [vp]
     L.orbfe_extract.argtypes = [vp, vp, ci, ci, C.c_size_t, vp, vp, ci, C.POINTER(ci)]
     L.orbfe_extract_batch.argtypes = [vp, ci, vp, ci, ci, ci, C.c_size_t, vp, vp, ci, vp]
+    L.orbfe_extract_batch_submit.argtypes = [vp, ci, vp, ci, ci, ci, C.c_size_t]
+    L.orbfe_extract_batch_collect.argtypes = [vp, vp, vp, ci, vp]
     L.orbfe_debug_level_size.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(ci)]
     L.orbfe_debug_level_copy.argtypes = [vp, ci, ci, vp]
     L.orbfe_debug_candidates.argtypes = [vp, ci, ci, vp, ci, C.POINTER(ci)]
@@ -71,6 +73,7 @@ def load_library():
     L.orbfe_matcher_destroy.argtypes = [vp]
     L.orbfe_matcher_destroy.restype = None
     L.orbfe_search_for_initialization.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, ci, cf, ci, C.POINTER(ci)]
+    L.orbfe_search_for_initialization_batch.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, cf, ci, vp]
     L.orbfe_search_by_projection.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp,
                                              C.POINTER(ci)]
     L.orbfe_search_by_projection_uv.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, ci,
@@ -164,6 +167,23 @@ class Extractor:
                                           self.cap, _p(n)))
         return kps, desc, n
 
+    def submit_ptrs(self, ptrs, rows, cols, stride, on_device):
+        """Enqueue a batch (returns immediately); collect() waits for it."""
+        B = len(ptrs)
+        self._pending = (C.c_void_p * B)(*ptrs)          # keep the pointer array alive
+        self._pendingB = B
+        _check(self.L.orbfe_extract_batch_submit(self.h, B, self._pending, int(on_device), rows, cols, stride))
+
+    def collect(self, kps=None, desc=None):
+        B = self._pendingB
+        if kps is None:
+            kps = np.zeros((B, self.cap), KP_DTYPE)
+        if desc is None:
+            desc = np.zeros((B, self.cap, 32), np.uint8)
+        n = np.zeros(B, np.int32)
+        _check(self.L.orbfe_extract_batch_collect(self.h, _p(kps), _p(desc), self.cap, _p(n)))
+        return kps, desc, n
+
     def extract_batch(self, images):
         images = [np.ascontiguousarray(im, np.uint8) for im in images]
         rows, cols = images[0].shape
@@ -240,6 +260,26 @@ class Matcher:
                                                       len(kps2), _p(b), _p(prev), _p(m12), window, nnratio,
                                                       int(check_ori), C.byref(n)))
         return n.value, m12[:len(kps1)], prev
+
+    def search_for_initialization_batch(self, pairs, bounds, window=100, nnratio=0.9, check_ori=True):
+        """pairs: list of (kps1, desc1, kps2, desc2, prev_xy) with C-contiguous arrays.  Returns
+        [(nmatches, matches12, prev_xy_out)] per pair; one GPU submission for all pairs."""
+        P = len(pairs)
+        k1 = [np.ascontiguousarray(p[0], KP_DTYPE) for p in pairs]
+        d1 = [np.ascontiguousarray(p[1], np.uint8) for p in pairs]
+        k2 = [np.ascontiguousarray(p[2], KP_DTYPE) for p in pairs]
+        d2 = [np.ascontiguousarray(p[3], np.uint8) for p in pairs]
+        prev = [np.ascontiguousarray(p[4], np.float32).copy() for p in pairs]
+        m12 = [np.full(max(len(k), 1), -1, np.int32) for k in k1]
+        arr = lambda xs: (C.c_void_p * P)(*[x.ctypes.data for x in xs])
+        n1 = np.array([len(k) for k in k1], np.int32)
+        n2 = np.array([len(k) for k in k2], np.int32)
+        b = np.asarray(bounds, np.float32)
+        nm = np.zeros(max(P, 1), np.int32)
+        _check(self.L.orbfe_search_for_initialization_batch(self.h, P, arr(k1), arr(d1), _p(n1), arr(k2), arr(d2),
+                                                            _p(n2), _p(b), arr(prev), arr(m12), window, nnratio,
+                                                            int(check_ori), _p(nm)))
+        return [(int(nm[i]), m12[i][:len(k1[i])], prev[i]) for i in range(P)]
 
     def search_by_projection(self, kps, desc, bounds, scale_factors, kp_occupied, mp_xy, mp_level, mp_viewcos,
                              mp_flags, mp_desc, th, nnratio):

@@ -323,6 +323,16 @@ struct orbfe_extractor {
   // stream submission, one synchronisation, fixed-size D2H of the selection slots.
   int runGpuQt(int nframes, const uint8_t* const* gray, bool onDevice, int r, int c, size_t stride, OrbfeKeyPoint* kps,
                uint8_t* desc, int cap, int* n_out) {
+    int rc = submitGpuQt(nframes, gray, onDevice, r, c, stride);
+    if (rc) return rc;
+    return waitGpuQt(kps, desc, cap, n_out);
+  }
+
+  int pendingFrames = 0;   // frames of the submitted, not yet collected batch (0 = none)
+  double tSubmit0 = 0, tSubmit1 = 0;
+
+  int submitGpuQt(int nframes, const uint8_t* const* gray, bool onDevice, int r, int c, size_t stride) {
+    if (pendingFrames) { set_err("a submitted batch has not been collected yet"); return ORBFE_ERR_INVALID; }
     HIP_TRY(hipSetDevice(device));
     int rc;
     if ((rc = setGeometry(r, c))) return rc;
@@ -367,7 +377,20 @@ struct orbfe_extractor {
     HIP_TRY(hipMemcpyAsync(h_desc.p, d_desc.p, (size_t)32 * nslots, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(h_levelStart.p, d_levelStart.p, sizeof(uint32_t) * (kMaxLevels + 1) * nframes,
                            hipMemcpyDeviceToHost, st));
-    const double t1 = now_ms();
+    tSubmit0 = t0;
+    tSubmit1 = now_ms();
+    pendingFrames = nframes;
+    return ORBFE_OK;
+  }
+
+  int waitGpuQt(OrbfeKeyPoint* kps, uint8_t* desc, int cap, int* n_out) {
+    if (!pendingFrames) { set_err("no submitted batch to collect"); return ORBFE_ERR_INVALID; }
+    HIP_TRY(hipSetDevice(device));
+    const int nframes = pendingFrames;
+    pendingFrames = 0;
+    hipStream_t st = streams[0];
+    const double t0 = tSubmit0, t1 = tSubmit1;
+    const double t1b = now_ms();
     HIP_TRY(hipStreamSynchronize(st));
     const double t2 = now_ms();
     {
@@ -414,7 +437,7 @@ struct orbfe_extractor {
     }
     const double t3 = now_ms();
     stageMs[0] = (float)(t1 - t0);   // enqueue
-    stageMs[1] = (float)(t2 - t1);   // GPU wait
+    stageMs[1] = (float)(t2 - t1b);  // GPU wait inside the collect call
     stageMs[2] = 0;
     stageMs[3] = (float)(t3 - t2);   // output assembly
     stageMs[4] = (float)(t3 - t0);
@@ -763,6 +786,21 @@ int orbfe_extract_batch(orbfe_extractor* h, int nframes, const uint8_t* const* g
   }
   if (h->gpuQuadtree) return h->runGpuQt(nframes, gray, in_device_memory != 0, rows, cols, stride_bytes, kps, desc, cap, n_out);
   return h->run(nframes, gray, in_device_memory != 0, rows, cols, stride_bytes, kps, desc, cap, n_out);
+}
+
+int orbfe_extract_batch_submit(orbfe_extractor* h, int nframes, const uint8_t* const* gray, int in_device_memory,
+                               int rows, int cols, size_t stride_bytes) {
+  if (!h || !gray || nframes <= 0 || rows <= 0 || cols <= 0 || stride_bytes < (size_t)cols) {
+    set_err("invalid arguments");
+    return ORBFE_ERR_INVALID;
+  }
+  if (!h->gpuQuadtree) { set_err("asynchronous submission needs the GPU quadtree path"); return ORBFE_ERR_INVALID; }
+  return h->submitGpuQt(nframes, gray, in_device_memory != 0, rows, cols, stride_bytes);
+}
+
+int orbfe_extract_batch_collect(orbfe_extractor* h, OrbfeKeyPoint* kps, uint8_t* desc, int cap, int* n_out) {
+  if (!h || !kps || !desc || !n_out || cap <= 0) { set_err("invalid arguments"); return ORBFE_ERR_INVALID; }
+  return h->waitGpuQt(kps, desc, cap, n_out);
 }
 
 int orbfe_extract(orbfe_extractor* h, const uint8_t* gray, int rows, int cols, size_t stride_bytes, OrbfeKeyPoint* kps,

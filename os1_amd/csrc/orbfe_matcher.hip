@@ -18,14 +18,19 @@
 // short candidate lists, statement for statement.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <climits>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/orbfe.h"
+#include "host_pool.h"
 
 namespace orbfe {
 void set_err(const char* fmt, ...);
@@ -46,16 +51,25 @@ namespace {
 constexpr int kGridCols = 64, kGridRows = 48;  // FRAME_GRID_COLS / FRAME_GRID_ROWS (Frame.h:36-37)
 constexpr int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;  // ORBmatcher.cc:37-39
 
+// One "pair" = one train frame (grid-sorted keypoints + descriptors) and a run of queries against it.
+struct PairInfo {
+  int trainOff;    // first entry of the pair in sx/sy/soct/sidx
+  int cellOff;     // first entry of the pair's cellStart table ([64*48+1] ints)
+  int tdescOff;    // first descriptor row of the pair's train frame in tdesc
+  float minX, minY, invW, invH;
+};
+
 struct MatchParams {
-  // train frame, keypoints permuted into grid order (cell = ix*48+iy ascending, insertion order inside)
+  // train frames, keypoints permuted into grid order (cell = ix*48+iy ascending, insertion order inside)
   const float* sx;
   const float* sy;
   const int* soct;
-  const int* sidx;        // original keypoint index
-  const int* cellStart;   // [64*48+1]
-  const uint8_t* tdesc;   // [n][32], ORIGINAL order
-  float minX, minY, invW, invH;
-  // queries
+  const int* sidx;        // original keypoint index inside its frame
+  const int* cellStart;   // per pair [64*48+1], values relative to the pair's trainOff
+  const uint8_t* tdesc;   // descriptor rows, ORIGINAL order per frame
+  const PairInfo* pairs;
+  // queries (all pairs concatenated)
+  const int* qpair;       // pair of each query
   const float* qx;
   const float* qy;
   const float* qr;        // < 0 : inactive query
@@ -83,29 +97,36 @@ __global__ __launch_bounds__(64) void k_window_match(MatchParams M) {
   const int q = blockIdx.x;
   const int lane = threadIdx.x;
   const float r = M.qr[q];
+  const PairInfo pi = M.pairs[M.qpair[q]];
+  const float* sx = M.sx + pi.trainOff;
+  const float* sy = M.sy + pi.trainOff;
+  const int* soct = M.soct + pi.trainOff;
+  const int* sidx = M.sidx + pi.trainOff;
+  const int* cellStart = M.cellStart + pi.cellOff;
+  const uint8_t* tdesc = M.tdesc + (size_t)pi.tdescOff * 32;
   uint32_t count = 0;
   int cx0 = 0, cx1 = -1, cy0 = 0, cy1 = -1;
   const float x = M.qx[q], y = M.qy[q];
   if (r >= 0.f) {
-    cx0 = max(0, (int)floorf((x - M.minX - r) * M.invW));
-    cx1 = min(kGridCols - 1, (int)ceilf((x - M.minX + r) * M.invW));
-    cy0 = max(0, (int)floorf((y - M.minY - r) * M.invH));
-    cy1 = min(kGridRows - 1, (int)ceilf((y - M.minY + r) * M.invH));
+    cx0 = max(0, (int)floorf((x - pi.minX - r) * pi.invW));
+    cx1 = min(kGridCols - 1, (int)ceilf((x - pi.minX + r) * pi.invW));
+    cy0 = max(0, (int)floorf((y - pi.minY - r) * pi.invH));
+    cy1 = min(kGridRows - 1, (int)ceilf((y - pi.minY + r) * pi.invH));
     if (cx0 >= kGridCols || cx1 < 0 || cy0 >= kGridRows || cy1 < 0) cx1 = cx0 - 1;  // empty
   }
   const int minL = M.qminL[q], maxL = M.qmaxL[q];
   const bool checkLevels = (minL > 0) || (maxL >= 0);
   auto inWindow = [&](int e) -> bool {
     if (checkLevels) {
-      const int o = M.soct[e];
+      const int o = soct[e];
       if (o < minL) return false;
       if (maxL >= 0 && o > maxL) return false;
     }
-    const float dx = M.sx[e] - x, dy = M.sy[e] - y;
+    const float dx = sx[e] - x, dy = sy[e] - y;
     return fabsf(dx) < r && fabsf(dy) < r;
   };
   for (int ix = cx0; ix <= cx1; ix++) {
-    const int b = M.cellStart[ix * kGridRows + cy0], e1 = M.cellStart[ix * kGridRows + cy1 + 1];
+    const int b = cellStart[ix * kGridRows + cy0], e1 = cellStart[ix * kGridRows + cy1 + 1];
     for (int e0 = b; e0 < e1; e0 += 64) {
       const int e = e0 + lane;
       const bool ok = e < e1 && inWindow(e);
@@ -126,14 +147,14 @@ __global__ __launch_bounds__(64) void k_window_match(MatchParams M) {
   for (int i = 0; i < 8; i++) qd[i] = qp[i];
   uint32_t run = 0;
   for (int ix = cx0; ix <= cx1; ix++) {
-    const int b = M.cellStart[ix * kGridRows + cy0], e1 = M.cellStart[ix * kGridRows + cy1 + 1];
+    const int b = cellStart[ix * kGridRows + cy0], e1 = cellStart[ix * kGridRows + cy1 + 1];
     for (int e0 = b; e0 < e1; e0 += 64) {
       const int e = e0 + lane;
       const bool ok = e < e1 && inWindow(e);
       const unsigned long long m = __ballot(ok);
       if (ok) {
-        const int idx = M.sidx[e];
-        const int d = hamming256(reinterpret_cast<const uint32_t*>(M.tdesc + (size_t)idx * 32), qd);
+        const int idx = sidx[e];
+        const int d = hamming256(reinterpret_cast<const uint32_t*>(tdesc + (size_t)idx * 32), qd);
         const uint32_t pos = off + run + __popcll(m & ((1ull << lane) - 1ull));
         if (pos < M.poolCap) M.pool[pos] = (uint32_t)idx | ((uint32_t)d << 16);
       }
@@ -205,72 +226,94 @@ struct orbfe_matcher {
   PinBuf<uint32_t> h_out;
   DevBuf<uint32_t> d_pool;
   PinBuf<uint32_t> h_pool;
-  std::vector<int> cellOf, cellCnt, order;
-
   ~orbfe_matcher() {
     (void)hipSetDevice(device);
     d_in.release(); h_in.release(); d_out.release(); h_out.release(); d_pool.release(); h_pool.release();
     if (stream) (void)hipStreamDestroy(stream);
   }
 
-  // Runs the window kernel.  After return: h_out.p = [total, pad.., qcount[nq], qoff[nq]], h_pool.p = entries.
+  // One search job: a train frame and a run of queries against it (host pointers).
+  struct Job {
+    const OrbfeKeyPoint* kps; const uint8_t* desc; int n; const float* bounds;
+    const float* qx; const float* qy; const float* qr; const int* qminL; const int* qmaxL; const uint8_t* qdesc; int nq;
+  };
+  // Results of the last candidates() call: per job the first query index; per query count/offset; pool.
+  std::vector<int> jobQ0;
   const uint32_t* qcount = nullptr;
   const uint32_t* qoff = nullptr;
 
-  int candidates(const OrbfeKeyPoint* kps, const uint8_t* desc, int n, const float bounds[4], const float* qx,
-                 const float* qy, const float* qr, const int* qminL, const int* qmaxL, const uint8_t* qdesc, int nq) {
+  // Runs the window kernel for all jobs in ONE upload + ONE launch.
+  int candidates(const Job* jobs, int njobs) {
     HIP_TRY(hipSetDevice(device));
     int rc;
-    const float minX = bounds[0], maxX = bounds[1], minY = bounds[2], maxY = bounds[3];
-    const float invW = static_cast<float>(kGridCols) / static_cast<float>(maxX - minX);   // Frame.cc:98
-    const float invH = static_cast<float>(kGridRows) / static_cast<float>(maxY - minY);   // Frame.cc:99
     const int ncell = kGridCols * kGridRows;
-    // AssignFeaturesToGrid / PosInGrid (Frame.cc:114-129, 264-274): stable counting sort by cell
-    cellOf.resize(n);
-    cellCnt.assign(ncell + 1, 0);
-    int ngrid = 0;
-    for (int i = 0; i < n; i++) {
-      const int px = (int)roundf((kps[i].x - minX) * invW);
-      const int py = (int)roundf((kps[i].y - minY) * invH);
-      if (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) { cellOf[i] = -1; continue; }
-      cellOf[i] = px * kGridRows + py;
-      cellCnt[cellOf[i] + 1]++;
-      ngrid++;
+    jobQ0.assign(njobs + 1, 0);
+    size_t nTrain = 0, nDesc = 0, nq = 0;
+    std::vector<size_t> trainOff(njobs), descOff(njobs);
+    for (int j = 0; j < njobs; j++) {
+      trainOff[j] = nTrain; descOff[j] = nDesc; jobQ0[j] = (int)nq;
+      nTrain += jobs[j].n; nDesc += jobs[j].n; nq += jobs[j].nq;
     }
-    for (int c = 0; c < ncell; c++) cellCnt[c + 1] += cellCnt[c];
-    // arena layout
-    const size_t oSx = 0, oSy = oSx + al(4 * (size_t)ngrid), oOct = oSy + al(4 * (size_t)ngrid),
-                 oIdx = oOct + al(4 * (size_t)ngrid), oCell = oIdx + al(4 * (size_t)ngrid),
-                 oTd = oCell + al(4 * (size_t)(ncell + 1)), oQx = oTd + al(32 * (size_t)n),
-                 oQy = oQx + al(4 * (size_t)nq), oQr = oQy + al(4 * (size_t)nq), oQa = oQr + al(4 * (size_t)nq),
-                 oQb = oQa + al(4 * (size_t)nq), oQd = oQb + al(4 * (size_t)nq), total = oQd + al(32 * (size_t)nq);
+    jobQ0[njobs] = (int)nq;
+    // arena layout (one H2D copy)
+    const size_t oSx = 0, oSy = oSx + al(4 * nTrain), oOct = oSy + al(4 * nTrain), oIdx = oOct + al(4 * nTrain),
+                 oCell = oIdx + al(4 * nTrain), oTd = oCell + al(4 * (size_t)(ncell + 1) * njobs),
+                 oPair = oTd + al(32 * nDesc), oQp = oPair + al(sizeof(PairInfo) * (size_t)njobs),
+                 oQx = oQp + al(4 * nq), oQy = oQx + al(4 * nq), oQr = oQy + al(4 * nq), oQa = oQr + al(4 * nq),
+                 oQb = oQa + al(4 * nq), oQd = oQb + al(4 * nq), total = oQd + al(32 * nq);
     if ((rc = h_in.ensure(total))) return rc;
     if ((rc = d_in.ensure(total))) return rc;
     uint8_t* H = h_in.p;
-    float* sx = (float*)(H + oSx);
-    float* sy = (float*)(H + oSy);
-    int* so = (int*)(H + oOct);
-    int* si = (int*)(H + oIdx);
-    memcpy(H + oCell, cellCnt.data(), 4 * (size_t)(ncell + 1));
-    order.assign(cellCnt.begin(), cellCnt.end() - 1);
-    for (int i = 0; i < n; i++) {
-      if (cellOf[i] < 0) continue;
-      const int p = order[cellOf[i]]++;
-      sx[p] = kps[i].x; sy[p] = kps[i].y; so[p] = kps[i].octave; si[p] = i;
-    }
-    memcpy(H + oTd, desc, 32 * (size_t)n);
-    memcpy(H + oQx, qx, 4 * (size_t)nq);
-    memcpy(H + oQy, qy, 4 * (size_t)nq);
-    memcpy(H + oQr, qr, 4 * (size_t)nq);
-    memcpy(H + oQa, qminL, 4 * (size_t)nq);
-    memcpy(H + oQb, qmaxL, 4 * (size_t)nq);
-    memcpy(H + oQd, qdesc, 32 * (size_t)nq);
+    // per job: AssignFeaturesToGrid / PosInGrid (Frame.cc:114-129, 264-274) as a stable counting sort by cell
+    pool->parallelFor(njobs, [&](int j, int) {
+      const Job& J = jobs[j];
+      const float minX = J.bounds[0], maxX = J.bounds[1], minY = J.bounds[2], maxY = J.bounds[3];
+      const float invW = static_cast<float>(kGridCols) / static_cast<float>(maxX - minX);   // Frame.cc:98
+      const float invH = static_cast<float>(kGridRows) / static_cast<float>(maxY - minY);   // Frame.cc:99
+      int* cellCnt = (int*)(H + oCell) + (size_t)(ncell + 1) * j;
+      std::vector<int> cellOf(J.n);
+      for (int c = 0; c <= ncell; c++) cellCnt[c] = 0;
+      for (int i = 0; i < J.n; i++) {
+        const int px = (int)roundf((J.kps[i].x - minX) * invW);
+        const int py = (int)roundf((J.kps[i].y - minY) * invH);
+        if (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) { cellOf[i] = -1; continue; }
+        cellOf[i] = px * kGridRows + py;
+        cellCnt[cellOf[i] + 1]++;
+      }
+      for (int c = 0; c < ncell; c++) cellCnt[c + 1] += cellCnt[c];
+      std::vector<int> order(cellCnt, cellCnt + ncell);
+      float* sx = (float*)(H + oSx) + trainOff[j];
+      float* sy = (float*)(H + oSy) + trainOff[j];
+      int* so = (int*)(H + oOct) + trainOff[j];
+      int* si = (int*)(H + oIdx) + trainOff[j];
+      for (int i = 0; i < J.n; i++) {
+        if (cellOf[i] < 0) continue;
+        const int p = order[cellOf[i]]++;
+        sx[p] = J.kps[i].x; sy[p] = J.kps[i].y; so[p] = J.kps[i].octave; si[p] = i;
+      }
+      if (J.n) memcpy(H + oTd + 32 * descOff[j], J.desc, 32 * (size_t)J.n);
+      PairInfo pi;
+      pi.trainOff = (int)trainOff[j]; pi.cellOff = (ncell + 1) * j; pi.tdescOff = (int)descOff[j];
+      pi.minX = minX; pi.minY = minY; pi.invW = invW; pi.invH = invH;
+      ((PairInfo*)(H + oPair))[j] = pi;
+      const size_t q0 = jobQ0[j];
+      int* qp = (int*)(H + oQp) + q0;
+      for (int q = 0; q < J.nq; q++) qp[q] = j;
+      if (J.nq) {
+        memcpy((float*)(H + oQx) + q0, J.qx, 4 * (size_t)J.nq);
+        memcpy((float*)(H + oQy) + q0, J.qy, 4 * (size_t)J.nq);
+        memcpy((float*)(H + oQr) + q0, J.qr, 4 * (size_t)J.nq);
+        memcpy((int*)(H + oQa) + q0, J.qminL, 4 * (size_t)J.nq);
+        memcpy((int*)(H + oQb) + q0, J.qmaxL, 4 * (size_t)J.nq);
+        memcpy(H + oQd + 32 * q0, J.qdesc, 32 * (size_t)J.nq);
+      }
+    });
     HIP_TRY(hipMemcpyAsync(d_in.p, H, total, hipMemcpyHostToDevice, stream));
 
-    const size_t outWords = 64 + 2 * (size_t)nq;
+    const size_t outWords = 64 + 2 * nq;
     if ((rc = d_out.ensure(outWords))) return rc;
     if ((rc = h_out.ensure(outWords))) return rc;
-    size_t poolCap = d_pool.n ? d_pool.n : (size_t)std::max(1 << 16, nq * 32);
+    size_t poolCap = d_pool.n ? d_pool.n : std::max<size_t>(1 << 16, nq * 32);
     for (int attempt = 0; attempt < 2; attempt++) {
       if ((rc = d_pool.ensure(poolCap))) return rc;
       HIP_TRY(hipMemsetAsync(d_out.p, 0, 64 * sizeof(uint32_t), stream));
@@ -278,23 +321,28 @@ struct orbfe_matcher {
       uint8_t* D = d_in.p;
       M.sx = (const float*)(D + oSx); M.sy = (const float*)(D + oSy); M.soct = (const int*)(D + oOct);
       M.sidx = (const int*)(D + oIdx); M.cellStart = (const int*)(D + oCell); M.tdesc = D + oTd;
-      M.minX = minX; M.minY = minY; M.invW = invW; M.invH = invH;
+      M.pairs = (const PairInfo*)(D + oPair); M.qpair = (const int*)(D + oQp);
       M.qx = (const float*)(D + oQx); M.qy = (const float*)(D + oQy); M.qr = (const float*)(D + oQr);
       M.qminL = (const int*)(D + oQa); M.qmaxL = (const int*)(D + oQb); M.qdesc = D + oQd;
-      M.nq = nq;
+      M.nq = (int)nq;
       M.total = d_out.p; M.qcount = d_out.p + 64; M.qoff = d_out.p + 64 + nq;
       M.pool = d_pool.p; M.poolCap = (uint32_t)d_pool.n;
-      if (nq > 0) hipLaunchKernelGGL(k_window_match, dim3(nq), dim3(64), 0, stream, M);
+      if (nq > 0) hipLaunchKernelGGL(k_window_match, dim3((unsigned)nq), dim3(64), 0, stream, M);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipMemcpyAsync(h_out.p, d_out.p, outWords * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+      // optimistic: fetch a generous prefix of the pool in the same round trip
+      const size_t guess = std::min<size_t>(d_pool.n, std::max<size_t>(lastTotal + lastTotal / 4 + 1024, 4096));
+      if ((rc = h_pool.ensure(guess + 1))) return rc;
+      HIP_TRY(hipMemcpyAsync(h_pool.p, d_pool.p, guess * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
       HIP_TRY(hipStreamSynchronize(stream));
       const size_t tot = h_out.p[0];
       if (tot <= d_pool.n) {
-        if ((rc = h_pool.ensure(tot + 1))) return rc;
-        if (tot) {
+        if (tot > guess) {
+          if ((rc = h_pool.ensure(tot + 1))) return rc;
           HIP_TRY(hipMemcpyAsync(h_pool.p, d_pool.p, tot * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
           HIP_TRY(hipStreamSynchronize(stream));
         }
+        lastTotal = tot;
         qcount = h_out.p + 64;
         qoff = h_out.p + 64 + nq;
         return ORBFE_OK;
@@ -304,91 +352,29 @@ struct orbfe_matcher {
     set_err("candidate pool sizing failed");
     return ORBFE_ERR_HIP;
   }
+
+  int candidates(const OrbfeKeyPoint* kps, const uint8_t* desc, int n, const float bounds[4], const float* qx,
+                 const float* qy, const float* qr, const int* qminL, const int* qmaxL, const uint8_t* qdesc, int nq) {
+    Job j{kps, desc, n, bounds, qx, qy, qr, qminL, qmaxL, qdesc, nq};
+    return candidates(&j, 1);
+  }
+  size_t lastTotal = 0;
+  std::unique_ptr<orbfe::HostPool> pool;
 };
 
-extern "C" {
-
-int orbfe_hamming(const uint8_t a[32], const uint8_t b[32]) {
-  int d = 0;
-  for (int i = 0; i < 4; i++) {
-    uint64_t x, y;
-    memcpy(&x, a + 8 * i, 8);
-    memcpy(&y, b + 8 * i, 8);
-    d += __builtin_popcountll(x ^ y);
-  }
-  return d;
-}
-
-int orbfe_matcher_create(int device_id, orbfe_matcher** out) {
-  if (!out) { set_err("out is NULL"); return ORBFE_ERR_INVALID; }
-  *out = nullptr;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) {
-    set_err("no usable HIP device (count=%d, requested %d): this library has no CPU fallback", ndev, device_id);
-    return ORBFE_ERR_NO_DEVICE;
-  }
-  HIP_TRY(hipSetDevice(device_id));
-  orbfe_matcher* m = new orbfe_matcher();
-  m->device = device_id;
-  hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
-  if (e != hipSuccess) {
-    set_err("hipStreamCreate failed: %s", hipGetErrorString(e));
-    delete m;
-    return ORBFE_ERR_HIP;
-  }
-  *out = m;
-  return ORBFE_OK;
-}
-
-void orbfe_matcher_destroy(orbfe_matcher* m) { delete m; }
-
-int orbfe_debug_features_in_area(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, int n, const float bounds[4], float x,
-                                 float y, float r, int min_level, int max_level, int32_t* out, int cap, int* n_out) {
-  if (!m || !kps_un || !bounds || !n_out || n < 0) { set_err("bad argument"); return ORBFE_ERR_INVALID; }
-  std::vector<uint8_t> zdesc((size_t)std::max(n, 1) * 32, 0), qd(32, 0);
-  int rc = m->candidates(kps_un, zdesc.data(), n, bounds, &x, &y, &r, &min_level, &max_level, qd.data(), 1);
-  if (rc) return rc;
-  const int c = (int)m->qcount[0];
-  *n_out = c;
-  for (int i = 0; i < c && i < cap; i++) out[i] = (int)(m->h_pool.p[m->qoff[0] + i] & 0xffff);
-  return ORBFE_OK;
-}
-
-int orbfe_search_for_initialization(orbfe_matcher* m, const OrbfeKeyPoint* kps1, const uint8_t* desc1, int n1,
-                                    const OrbfeKeyPoint* kps2, const uint8_t* desc2, int n2, const float bounds[4],
-                                    float* prev_xy, int32_t* matches12, int window_size, float nnratio,
-                                    int check_orientation, int* nmatches) {
-  if (!m || !nmatches || n1 < 0 || n2 < 0 || n2 > 65535 || (n1 && (!kps1 || !desc1 || !prev_xy || !matches12)) ||
-      (n2 && (!kps2 || !desc2)) || !bounds) {
-    set_err("bad argument (note: at most 65535 keypoints per frame)");
-    return ORBFE_ERR_INVALID;
-  }
-  *nmatches = 0;
-  for (int i = 0; i < n1; i++) matches12[i] = -1;
-  if (n1 == 0) return ORBFE_OK;
-  // queries: level-0 keypoints of F1, window centred on vbPrevMatched (ORBmatcher.cc:413-420)
-  std::vector<float> qx(n1), qy(n1), qr(n1);
-  std::vector<int> qa(n1), qb(n1);
-  for (int i = 0; i < n1; i++) {
-    const int level1 = kps1[i].octave;
-    qx[i] = prev_xy[2 * i];
-    qy[i] = prev_xy[2 * i + 1];
-    qr[i] = level1 > 0 ? -1.f : (float)window_size;
-    qa[i] = level1;
-    qb[i] = level1;
-  }
-  int rc = m->candidates(kps2, desc2, n2, bounds, qx.data(), qy.data(), qr.data(), qa.data(), qb.data(), desc1, n1);
-  if (rc) return rc;
+// sequential bookkeeping of SearchForInitialization, ORBmatcher.cc:402-512, over one job's candidate lists
+static int resolveSearchForInitialization(const orbfe_matcher* m, int q0, const OrbfeKeyPoint* kps1, int n1,
+                                          const OrbfeKeyPoint* kps2, int n2, float* prev_xy, int32_t* matches12,
+                                          float nnratio, int check_orientation) {
   const uint32_t* pool = m->h_pool.p;
-  // sequential bookkeeping, ORBmatcher.cc:402-512
   int nm = 0;
   std::vector<int> rotHist[HISTO_LENGTH];
   std::vector<int> vMatchedDistance(n2, INT_MAX), vnMatches21(n2, -1);
   for (int i1 = 0; i1 < n1; i1++) {
     if (kps1[i1].octave > 0) continue;
-    const uint32_t cnt = m->qcount[i1];
+    const uint32_t cnt = m->qcount[q0 + i1];
     if (cnt == 0) continue;
-    const uint32_t* cl = pool + m->qoff[i1];
+    const uint32_t* cl = pool + m->qoff[q0 + i1];
     int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
     for (uint32_t c = 0; c < cnt; c++) {
       const int i2 = (int)(cl[c] & 0xffff), dist = (int)(cl[c] >> 16);
@@ -421,8 +407,119 @@ int orbfe_search_for_initialization(orbfe_matcher* m, const OrbfeKeyPoint* kps1,
       prev_xy[2 * i1] = kps2[matches12[i1]].x;
       prev_xy[2 * i1 + 1] = kps2[matches12[i1]].y;
     }
-  *nmatches = nm;
+  return nm;
+}
+
+extern "C" {
+
+int orbfe_hamming(const uint8_t a[32], const uint8_t b[32]) {
+  int d = 0;
+  for (int i = 0; i < 4; i++) {
+    uint64_t x, y;
+    memcpy(&x, a + 8 * i, 8);
+    memcpy(&y, b + 8 * i, 8);
+    d += __builtin_popcountll(x ^ y);
+  }
+  return d;
+}
+
+int orbfe_matcher_create(int device_id, orbfe_matcher** out) {
+  if (!out) { set_err("out is NULL"); return ORBFE_ERR_INVALID; }
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) {
+    set_err("no usable HIP device (count=%d, requested %d): this library has no CPU fallback", ndev, device_id);
+    return ORBFE_ERR_NO_DEVICE;
+  }
+  HIP_TRY(hipSetDevice(device_id));
+  orbfe_matcher* m = new orbfe_matcher();
+  m->device = device_id;
+  hipError_t e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    set_err("hipStreamCreate failed: %s", hipGetErrorString(e));
+    delete m;
+    return ORBFE_ERR_HIP;
+  }
+  int nthreads = (int)std::thread::hardware_concurrency();
+  if (nthreads > 16) nthreads = 16;
+  if (const char* ev = getenv("ORBFE_HOST_THREADS")) nthreads = atoi(ev);
+  if (nthreads < 1) nthreads = 1;
+  m->pool.reset(new orbfe::HostPool(nthreads));
+  *out = m;
   return ORBFE_OK;
+}
+
+void orbfe_matcher_destroy(orbfe_matcher* m) { delete m; }
+
+int orbfe_debug_features_in_area(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, int n, const float bounds[4], float x,
+                                 float y, float r, int min_level, int max_level, int32_t* out, int cap, int* n_out) {
+  if (!m || !kps_un || !bounds || !n_out || n < 0) { set_err("bad argument"); return ORBFE_ERR_INVALID; }
+  std::vector<uint8_t> zdesc((size_t)std::max(n, 1) * 32, 0), qd(32, 0);
+  int rc = m->candidates(kps_un, zdesc.data(), n, bounds, &x, &y, &r, &min_level, &max_level, qd.data(), 1);
+  if (rc) return rc;
+  const int c = (int)m->qcount[0];
+  *n_out = c;
+  for (int i = 0; i < c && i < cap; i++) out[i] = (int)(m->h_pool.p[m->qoff[0] + i] & 0xffff);
+  return ORBFE_OK;
+}
+
+int orbfe_search_for_initialization_batch(orbfe_matcher* m, int npairs, const OrbfeKeyPoint* const* kps1,
+                                          const uint8_t* const* desc1, const int* n1,
+                                          const OrbfeKeyPoint* const* kps2, const uint8_t* const* desc2,
+                                          const int* n2, const float bounds[4], float* const* prev_xy,
+                                          int32_t* const* matches12, int window_size, float nnratio,
+                                          int check_orientation, int* nmatches) {
+  if (!m || !nmatches || npairs < 0 || !bounds || (npairs && (!kps1 || !desc1 || !n1 || !kps2 || !desc2 || !n2 ||
+                                                             !prev_xy || !matches12))) {
+    set_err("bad argument");
+    return ORBFE_ERR_INVALID;
+  }
+  size_t nqTot = 0;
+  for (int p = 0; p < npairs; p++) {
+    nmatches[p] = 0;
+    if (n1[p] < 0 || n2[p] < 0 || n2[p] > 65535 || (n1[p] && (!kps1[p] || !desc1[p] || !prev_xy[p] || !matches12[p])) ||
+        (n2[p] && (!kps2[p] || !desc2[p]))) {
+      set_err("bad argument in pair %d (note: at most 65535 keypoints per frame)", p);
+      return ORBFE_ERR_INVALID;
+    }
+    for (int i = 0; i < n1[p]; i++) matches12[p][i] = -1;
+    nqTot += n1[p];
+  }
+  if (nqTot == 0) return ORBFE_OK;
+  // queries: level-0 keypoints of F1, window centred on vbPrevMatched (ORBmatcher.cc:413-420)
+  std::vector<float> qx(nqTot), qy(nqTot), qr(nqTot);
+  std::vector<int> qa(nqTot), qb(nqTot);
+  std::vector<orbfe_matcher::Job> jobs(npairs);
+  size_t q0 = 0;
+  for (int p = 0; p < npairs; p++) {
+    for (int i = 0; i < n1[p]; i++) {
+      const int level1 = kps1[p][i].octave;
+      qx[q0 + i] = prev_xy[p][2 * i];
+      qy[q0 + i] = prev_xy[p][2 * i + 1];
+      qr[q0 + i] = level1 > 0 ? -1.f : (float)window_size;
+      qa[q0 + i] = level1;
+      qb[q0 + i] = level1;
+    }
+    jobs[p] = orbfe_matcher::Job{kps2[p], desc2[p], n2[p], bounds, qx.data() + q0, qy.data() + q0, qr.data() + q0,
+                                 qa.data() + q0, qb.data() + q0, desc1[p], n1[p]};
+    q0 += n1[p];
+  }
+  int rc = m->candidates(jobs.data(), npairs);
+  if (rc) return rc;
+  m->pool->parallelFor(npairs, [&](int p, int) {
+    nmatches[p] = resolveSearchForInitialization(m, m->jobQ0[p], kps1[p], n1[p], kps2[p], n2[p], prev_xy[p],
+                                                 matches12[p], nnratio, check_orientation);
+  });
+  return ORBFE_OK;
+}
+
+int orbfe_search_for_initialization(orbfe_matcher* m, const OrbfeKeyPoint* kps1, const uint8_t* desc1, int n1,
+                                    const OrbfeKeyPoint* kps2, const uint8_t* desc2, int n2, const float bounds[4],
+                                    float* prev_xy, int32_t* matches12, int window_size, float nnratio,
+                                    int check_orientation, int* nmatches) {
+  if (!nmatches) { set_err("nmatches is NULL"); return ORBFE_ERR_INVALID; }
+  return orbfe_search_for_initialization_batch(m, 1, &kps1, &desc1, &n1, &kps2, &desc2, &n2, bounds, &prev_xy,
+                                               &matches12, window_size, nnratio, check_orientation, nmatches);
 }
 
 int orbfe_search_by_projection(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, const uint8_t* desc, int n,

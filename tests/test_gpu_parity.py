@@ -237,3 +237,24 @@ def test_host_and_gpu_quadtree_paths_agree(api, oracle, monkeypatch):
             _cmp_extract(ex_host(im), want)
             _cmp_extract(ex_gpu(im), want)
     monkeypatch.delenv('ORBFE_HOST_QUADTREE')
+
+
+def test_search_for_initialization_batch_parity(api, oracle):
+    ex = api.Extractor(1000, 1.2, 8, 20, 7)
+    frames = [synth(50, 960, 540)]
+    for i in range(1, 5):
+        frames.append(shifted(frames[-1], 3, -2, 50 + i))
+    feats = [ex(f) for f in frames]
+    bounds = (0.0, 960.0, 0.0, 540.0)
+    pairs = []
+    for i in range(1, 5):
+        (k1, d1), (k2, d2) = feats[i - 1], feats[i]
+        pairs.append((k1, d1, k2, d2, np.stack([k1['x'], k1['y']], 1)))
+    pairs.append((feats[0][0][:0], feats[0][1][:0], feats[1][0], feats[1][1], np.zeros((0, 2), np.float32)))   # empty F1
+    pairs.append((feats[0][0], feats[0][1], feats[1][0][:0], feats[1][1][:0], np.stack([feats[0][0]['x'], feats[0][0]['y']], 1)))  # empty F2
+    got = api.Matcher().search_for_initialization_batch(pairs, bounds, 100, 0.9, True)
+    assert len(got) == len(pairs)
+    for (k1, d1, k2, d2, prev), (n, m12, p) in zip(pairs, got):
+        on, om12, op = oracle.search_for_initialization(k1, d1, k2, d2, bounds, prev, 100, 0.9, True)
+        assert n == on and (m12 == om12).all() and p.tobytes() == op.tobytes()
+    assert got[0][0] > 50
