@@ -72,17 +72,19 @@ def main():
     exs = [api.Extractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank) for _ in range(max(1, args.depth))]
     ex = exs[0]
     mt = api.Matcher(local_rank)
-    kps = np.zeros((B, ex.cap), api.KP_DTYPE)
-    desc = np.zeros((B, ex.cap, 32), np.uint8)
+    # two output buffer sets: the matcher thread reads set k%2 while the main thread collects batch k+1 into the other
+    kps_buf = [np.zeros((B, ex.cap), api.KP_DTYPE) for _ in range(2)]
+    desc_buf = [np.zeros((B, ex.cap, 32), np.uint8) for _ in range(2)]
     bounds = (0.0, float(W), 0.0, float(H))
-    last = [None]
     nmatch_total = [0]
+    last = [None]
 
-    def match(n):
+    def match(kps, desc, n, prev_last):
+        """SearchForInitialization of every frame of the batch against its predecessor in the stream."""
         pairs = []
         for i in range(B):
             cur = (kps[i, :n[i]], desc[i, :n[i]])
-            prev = last[0] if i == 0 else (kps[i - 1, :n[i - 1]], desc[i - 1, :n[i - 1]])
+            prev = prev_last if i == 0 else (kps[i - 1, :n[i - 1]], desc[i - 1, :n[i - 1]])
             if prev is not None:
                 pxy = np.empty((len(prev[0]), 2), np.float32)         # vbPrevMatched := F1 keypoints (Tracking.cc:355-357)
                 pxy[:, 0] = prev[0]['x']
@@ -91,25 +93,56 @@ def main():
         # one GPU submission for all pairs of the step (orbfe_search_for_initialization_batch)
         for nm, _, _ in mt.search_for_initialization_batch(pairs, bounds, 100, 0.9, True):
             nmatch_total[0] += nm
-        last[0] = (kps[B - 1, :n[B - 1]].copy(), desc[B - 1, :n[B - 1]].copy())
+
+    import queue
+    import threading
 
     def run(nsteps):
-        """nsteps passes of the hot path.  The extraction of batch k+1 is submitted (asynchronously, on the
-        extractor's stream) before batch k is matched, so GPU extraction overlaps host-side match bookkeeping;
-        every submit, collect and match of the nsteps batches happens inside this call.  `--depth` extractor
-        handles keep that many batches in flight."""
+        """nsteps passes of the hot path.  Two roles, as in the reference (Frame construction vs Tracking):
+        the main thread keeps `--depth` extraction batches in flight (asynchronous submit/collect on the
+        extractor streams); a matcher thread runs SearchForInitialization for batch k while batch k+1 is being
+        extracted.  Every submit, collect and match of the nsteps batches happens inside this call."""
         if nsteps <= 0:
             return
         D = len(exs)
+        jobs = queue.Queue(maxsize=1)
+        err = []
+
+        def matcher():
+            try:
+                while True:
+                    job = jobs.get()
+                    if job is None:
+                        return
+                    match(*job)
+            except BaseException as e:      # surface matcher failures in the main thread
+                err.append(e)
+                while jobs.get() is not None:
+                    pass
+
+        th = threading.Thread(target=matcher)
+        if not args.no_match:
+            th.start()
         for j in range(min(D, nsteps)):
             exs[j].submit_ptrs(dev.ptrs, H, W, dev.stride, True)
+        prev_last = last[0]
         for k in range(nsteps):
             h = exs[k % D]
+            kps, desc = kps_buf[k % 2], desc_buf[k % 2]
+            # buffer set k%2 was last read by match(k-2), which finished before match(k-1) was accepted
+            # by the depth-1 queue, i.e. before this point
             _, _, n = h.collect(kps, desc)
             if k + D < nsteps:
                 h.submit_ptrs(dev.ptrs, H, W, dev.stride, True)
             if not args.no_match:
-                match(n)
+                jobs.put((kps, desc, n.copy(), prev_last))
+            prev_last = (kps[B - 1, :n[B - 1]].copy(), desc[B - 1, :n[B - 1]].copy())
+        last[0] = prev_last
+        if not args.no_match:
+            jobs.put(None)
+            th.join()
+            if err:
+                raise err[0]
 
     def sync():
         api.device_synchronize(local_rank)

@@ -127,6 +127,9 @@ int orbfe_debug_stage_ms(const orbfe_extractor* h, float out[5]);
  * reset: out_ms[0]=pyramid (k_resize x (nlevels-1)), [1]=k_fast_cells, [2]=k_scan_cells+k_gather,
  * [3]=k_describe, [4]=k_quadtree; *batches = launches of each group, *frames = frames processed. */
 int orbfe_debug_kernel_ms(orbfe_extractor* h, double out_ms[5], long long* batches, long long* frames, int reset);
+/* k_fast_cells (the dominant kernel) is always timed; enable != 0 also times the other groups, at the
+ * price of an event (a few microseconds of stream gap) between them.  Env: ORBFE_PROFILE_KERNELS=1. */
+int orbfe_debug_set_profiling(orbfe_extractor* h, int enable);
 /* Device-side restatement of (cosf, sinf)(angle_deg * pi/180) used by the rBRIEF kernel, evaluated
  * on the GPU for n angles (parity test against host libm). */
 int orbfe_debug_sincos(orbfe_extractor* h, const float* angle_deg, int n, float* cos_out, float* sin_out);

@@ -80,6 +80,7 @@ def load_library():
                                                 ci, ci, vp, C.POINTER(ci)]
     L.orbfe_debug_features_in_area.argtypes = [vp, vp, ci, vp, cf, cf, cf, ci, ci, vp, ci, C.POINTER(ci)]
     L.orbfe_debug_kernel_ms.argtypes = [vp, vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), ci]
+    L.orbfe_debug_set_profiling.argtypes = [vp, ci]
     L.orbfe_device_malloc.argtypes = [ci, C.c_size_t, C.POINTER(vp)]
     L.orbfe_device_free.argtypes = [ci, vp]
     L.orbfe_device_upload.argtypes = [ci, vp, vp, C.c_size_t]
@@ -217,6 +218,9 @@ class Extractor:
         b, f = C.c_longlong(0), C.c_longlong(0)
         _check(self.L.orbfe_debug_kernel_ms(self.h, _p(ms), C.byref(b), C.byref(f), int(reset)))
         return ms, b.value, f.value
+
+    def set_profiling(self, enable=True):
+        _check(self.L.orbfe_debug_set_profiling(self.h, int(enable)))
 
     def sincos(self, angle_deg):
         a = np.ascontiguousarray(angle_deg, np.float32)

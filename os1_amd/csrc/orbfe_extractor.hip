@@ -115,29 +115,33 @@ struct orbfe_extractor {
   QtParams QP{};
   int selOff[kMaxLevels + 1] = {};
   int selPerFrame = 0;
-  DevBuf<uint32_t> d_idxA, d_idxB, d_rank, d_selCount;
+  DevBuf<uint32_t> d_idxA, d_idxB, d_rank;
   DevBuf<uint16_t> d_ownA, d_ownB;
   DevBuf<uint8_t> d_quad;
   DevBuf<QtNode> d_nodesA, d_nodesB;
   DevBuf<QtTmp> d_qtmp;
   DevBuf<int> d_proc;
-  PinBuf<uint32_t> h_selCount;
   hipEvent_t evQt[2] = {};
   std::vector<int> frameKpBase, frameKpCount;
 
   int rows = 0, cols = 0, batchCap = 0;
   PyramidParams P{};
   DevBuf<uint8_t> d_tables, d_slab, d_in;
-  DevBuf<uint32_t> d_cellCount, d_cellOff, d_slots, d_cand, d_levelStart;
+  DevBuf<uint32_t> d_cellCount, d_cellOff, d_slots, d_cand;
   DevBuf<const uint8_t*> d_frame0;
-  DevBuf<SelKp> d_sel;
-  DevBuf<float> d_angle, d_f32tmp;
-  DevBuf<uint8_t> d_desc;
+  // results leave the GPU in ONE copy: [levelStart][selCount][sel][angle][desc] carved from one arena
+  template <class T> struct View { T* p = nullptr; };
+  DevBuf<uint8_t> d_outArena;
+  PinBuf<uint8_t> h_outArena;
+  size_t outArenaBytes = 0;
+  View<uint32_t> d_levelStart, d_selCount, h_levelStart, h_selCount;
+  View<SelKp> d_sel, h_sel;
+  View<float> d_angle, h_angle;
+  View<uint8_t> d_desc, h_desc;
+  DevBuf<float> d_f32tmp;
+  bool profileKernels = false;  // HIP events around every kernel group (adds ~5-10 us of gaps per event)
   PinBuf<const uint8_t*> h_frame0;
-  PinBuf<uint32_t> h_levelStart, h_cand;
-  PinBuf<SelKp> h_sel;
-  PinBuf<float> h_angle;
-  PinBuf<uint8_t> h_desc;
+  PinBuf<uint32_t> h_cand;
   long long inPitch = 0;
   int lastFrames = 0;
   float stageMs[5] = {0, 0, 0, 0, 0};
@@ -160,15 +164,14 @@ struct orbfe_extractor {
   ~orbfe_extractor() {
     (void)hipSetDevice(device);
     d_tables.release(); d_slab.release(); d_in.release(); d_cellCount.release(); d_cellOff.release();
-    d_slots.release(); d_cand.release(); d_levelStart.release(); d_frame0.release(); d_sel.release();
-    d_angle.release(); d_f32tmp.release(); d_desc.release();
-    h_frame0.release(); h_levelStart.release(); h_cand.release(); h_sel.release(); h_angle.release();
-    h_desc.release();
+    d_slots.release(); d_cand.release(); d_frame0.release(); d_outArena.release(); h_outArena.release();
+    d_f32tmp.release();
+    h_frame0.release(); h_cand.release();
     for (auto& es : ev) for (auto& e : es) if (e) (void)hipEventDestroy(e);
     for (auto& e : evS1) if (e) (void)hipEventDestroy(e);
     for (auto& e : evQt) if (e) (void)hipEventDestroy(e);
-    d_idxA.release(); d_idxB.release(); d_rank.release(); d_selCount.release(); d_ownA.release(); d_ownB.release();
-    d_quad.release(); d_nodesA.release(); d_nodesB.release(); d_qtmp.release(); d_proc.release(); h_selCount.release();
+    d_idxA.release(); d_idxB.release(); d_rank.release(); d_ownA.release(); d_ownB.release();
+    d_quad.release(); d_nodesA.release(); d_nodesB.release(); d_qtmp.release(); d_proc.release();
     if (evFrame0) (void)hipEventDestroy(evFrame0);
     for (auto& st : streams) if (st) (void)hipStreamDestroy(st);
   }
@@ -257,6 +260,19 @@ struct orbfe_extractor {
         yb[2 * dy] = sat_short(cv_round_f((1.f - fy) * 2048));
         yb[2 * dy + 1] = sat_short(cv_round_f(fy * 2048));
       }
+      // largest source footprint of a 64x64 output tile (k_resize stages it in LDS)
+      int maxW = 1, maxH = 1;
+      for (int x0 = 0; x0 < dw; x0 += 64) {
+        const int x1 = std::min(x0 + 64, dw) - 1;
+        maxW = std::max(maxW, std::min(xofs[x1] + 1, sw - 1) - xofs[x0] + 1);
+      }
+      for (int y0 = 0; y0 < dh; y0 += 64) {
+        const int y1 = std::min(y0 + 64, dh) - 1;
+        const int r0 = std::min(std::max(yofs[y0], 0), sh - 1), r1 = std::min(std::max(yofs[y1] + 1, 0), sh - 1);
+        maxH = std::max(maxH, r1 - r0 + 1);
+      }
+      L.rzPitch = (maxW + 3 + 3) & ~3;
+      L.rzRows = maxH;
     }
     HIP_TRY(hipMemcpyAsync(d_tables.p, tab.data(), tableBytes, hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));
@@ -275,17 +291,24 @@ struct orbfe_extractor {
       if ((rc = d_cellOff.ensure((size_t)P.ncells * nframes))) return rc;
       if ((rc = d_slots.ensure((size_t)P.slotsPerFrame * nframes))) return rc;
       if ((rc = d_cand.ensure((size_t)P.candCap * nframes))) return rc;
-      if ((rc = d_levelStart.ensure((size_t)(kMaxLevels + 1) * nframes))) return rc;
       if ((rc = d_frame0.ensure(nframes))) return rc;
       if ((rc = h_frame0.ensure(nframes))) return rc;
-      if ((rc = h_levelStart.ensure((size_t)(kMaxLevels + 1) * nframes))) return rc;
       const size_t maxKp = (size_t)(nfeatures + 4 * nlevels + 8) * nframes;  // >= selPerFrame * nframes
-      if ((rc = d_sel.ensure(maxKp))) return rc;
-      if ((rc = h_sel.ensure(maxKp))) return rc;
-      if ((rc = d_angle.ensure(maxKp))) return rc;
-      if ((rc = h_angle.ensure(maxKp))) return rc;
-      if ((rc = d_desc.ensure(maxKp * 32))) return rc;
-      if ((rc = h_desc.ensure(maxKp * 32))) return rc;
+      {
+        auto al256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        const size_t oLs = 0, oSc = oLs + al256(sizeof(uint32_t) * (kMaxLevels + 1) * nframes),
+                     oSel = oSc + al256(sizeof(uint32_t) * kMaxLevels * nframes), oAng = oSel + al256(sizeof(SelKp) * maxKp),
+                     oDesc = oAng + al256(sizeof(float) * maxKp), total = oDesc + al256(32 * maxKp);
+        if ((rc = d_outArena.ensure(total))) return rc;
+        if ((rc = h_outArena.ensure(total))) return rc;
+        outArenaBytes = total;
+        uint8_t *D = d_outArena.p, *Hh = h_outArena.p;
+        d_levelStart.p = (uint32_t*)(D + oLs); h_levelStart.p = (uint32_t*)(Hh + oLs);
+        d_selCount.p = (uint32_t*)(D + oSc); h_selCount.p = (uint32_t*)(Hh + oSc);
+        d_sel.p = (SelKp*)(D + oSel); h_sel.p = (SelKp*)(Hh + oSel);
+        d_angle.p = (float*)(D + oAng); h_angle.p = (float*)(Hh + oAng);
+        d_desc.p = D + oDesc; h_desc.p = Hh + oDesc;
+      }
       if (gpuQuadtree) {
         const size_t ce = (size_t)P.candCap * nframes, nn = (size_t)nframes * nlevels * kQtNodeCap;
         if ((rc = d_idxA.ensure(ce))) return rc;
@@ -298,8 +321,6 @@ struct orbfe_extractor {
         if ((rc = d_nodesB.ensure(nn))) return rc;
         if ((rc = d_qtmp.ensure(nn))) return rc;
         if ((rc = d_proc.ensure(nn))) return rc;
-        if ((rc = d_selCount.ensure((size_t)nframes * kMaxLevels))) return rc;
-        if ((rc = h_selCount.ensure((size_t)nframes * kMaxLevels))) return rc;
       }
       batchCap = nframes;
       if (candHostCap == 0) candHostCap = 96 * 1024;
@@ -328,6 +349,7 @@ struct orbfe_extractor {
     return waitGpuQt(kps, desc, cap, n_out);
   }
 
+  bool submitProfiled = false;
   int pendingFrames = 0;   // frames of the submitted, not yet collected batch (0 = none)
   double tSubmit0 = 0, tSubmit1 = 0;
 
@@ -349,13 +371,14 @@ struct orbfe_extractor {
     P.stride0 = onDevice ? (long long)stride : inPitch;
     P.frameBase = 0;
     HIP_TRY(hipMemcpyAsync(d_frame0.p, h_frame0.p, sizeof(void*) * nframes, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipEventRecord(ev[0][0], st));
+    const bool prof = profileKernels;
+    if (prof) HIP_TRY(hipEventRecord(ev[0][0], st));
     launch_pyramid(P, nframes, st);
-    HIP_TRY(hipEventRecord(ev[0][1], st));
+    HIP_TRY(hipEventRecord(ev[0][1], st));   // the dominant kernel is always timed (bench.py roofline)
     launch_fast(P, nframes, st);
     HIP_TRY(hipEventRecord(ev[0][2], st));
     launch_compact(P, nframes, st);
-    HIP_TRY(hipEventRecord(ev[0][3], st));
+    if (prof) HIP_TRY(hipEventRecord(ev[0][3], st));
     QP.cand = d_cand.p; QP.levelStart = d_levelStart.p; QP.candCap = P.candCap; QP.nlevels = nlevels; QP.frameBase = 0;
     QP.idxA = d_idxA.p; QP.idxB = d_idxB.p; QP.ownA = d_ownA.p; QP.ownB = d_ownB.p; QP.quad = d_quad.p; QP.rank = d_rank.p;
     QP.nodesA = d_nodesA.p; QP.nodesB = d_nodesB.p; QP.tmp = d_qtmp.p; QP.proc = d_proc.p;
@@ -363,20 +386,16 @@ struct orbfe_extractor {
     for (int l = 0; l < nlevels; l++) {
       QP.levW[l] = P.lv[l].w; QP.levH[l] = P.lv[l].h; QP.nfeat[l] = nfeat[l]; QP.selOff[l] = selOff[l];
     }
-    HIP_TRY(hipEventRecord(evQt[0], st));
+    if (prof) HIP_TRY(hipEventRecord(evQt[0], st));
     launch_quadtree(QP, nframes, st);
-    HIP_TRY(hipEventRecord(evQt[1], st));
+    if (prof) HIP_TRY(hipEventRecord(evQt[1], st));
     const int nslots = nframes * selPerFrame;
-    HIP_TRY(hipEventRecord(ev[0][4], st));
+    if (prof) HIP_TRY(hipEventRecord(ev[0][4], st));
     launch_describe_slots(P, d_sel.p, nslots, d_angle.p, d_desc.p, d_selCount.p, selPerFrame, selOff, st);
-    HIP_TRY(hipEventRecord(ev[0][5], st));
+    if (prof) HIP_TRY(hipEventRecord(ev[0][5], st));
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(h_selCount.p, d_selCount.p, sizeof(uint32_t) * kMaxLevels * nframes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(h_sel.p, d_sel.p, sizeof(SelKp) * nslots, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(h_angle.p, d_angle.p, sizeof(float) * nslots, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(h_desc.p, d_desc.p, (size_t)32 * nslots, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(h_levelStart.p, d_levelStart.p, sizeof(uint32_t) * (kMaxLevels + 1) * nframes,
-                           hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h_outArena.p, d_outArena.p, outArenaBytes, hipMemcpyDeviceToHost, st));   // all results, one copy
+    submitProfiled = prof;
     tSubmit0 = t0;
     tSubmit1 = now_ms();
     pendingFrames = nframes;
@@ -395,10 +414,13 @@ struct orbfe_extractor {
     const double t2 = now_ms();
     {
       float ms = 0;
-      for (int i = 0; i < 3; i++)
-        if (hipEventElapsedTime(&ms, ev[0][i], ev[0][i + 1]) == hipSuccess) kernMs[i] += ms;
-      if (hipEventElapsedTime(&ms, ev[0][4], ev[0][5]) == hipSuccess) kernMs[3] += ms;
-      if (hipEventElapsedTime(&ms, evQt[0], evQt[1]) == hipSuccess) kernMs[4] += ms;
+      if (hipEventElapsedTime(&ms, ev[0][1], ev[0][2]) == hipSuccess) kernMs[1] += ms;
+      if (submitProfiled) {
+        if (hipEventElapsedTime(&ms, ev[0][0], ev[0][1]) == hipSuccess) kernMs[0] += ms;
+        if (hipEventElapsedTime(&ms, ev[0][2], ev[0][3]) == hipSuccess) kernMs[2] += ms;
+        if (hipEventElapsedTime(&ms, ev[0][4], ev[0][5]) == hipSuccess) kernMs[3] += ms;
+        if (hipEventElapsedTime(&ms, evQt[0], evQt[1]) == hipSuccess) kernMs[4] += ms;
+      }
       kernBatches++;
       kernFrames += nframes;
     }
@@ -731,6 +753,7 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
   for (auto& e : h->evQt) evOk = evOk && hipEventCreate(&e) == hipSuccess;
   if (!evOk) { set_err("hipEventCreate failed"); delete h; return ORBFE_ERR_HIP; }
   if (const char* hv = getenv("ORBFE_HOST_QUADTREE")) h->gpuQuadtree = atoi(hv) == 0;
+  if (const char* pv = getenv("ORBFE_PROFILE_KERNELS")) h->profileKernels = atoi(pv) != 0;
   h->selPerFrame = 0;
   for (int l = 0; l < nlevels; l++) {
     h->selOff[l] = h->selPerFrame;
@@ -875,6 +898,12 @@ int orbfe_debug_kernel_ms(orbfe_extractor* h, double out_ms[5], long long* batch
     for (double& v : h->kernMs) v = 0;
     h->kernBatches = h->kernFrames = 0;
   }
+  return ORBFE_OK;
+}
+
+int orbfe_debug_set_profiling(orbfe_extractor* h, int enable) {
+  if (!h) { set_err("handle is NULL"); return ORBFE_ERR_INVALID; }
+  h->profileKernels = enable != 0;
   return ORBFE_OK;
 }
 

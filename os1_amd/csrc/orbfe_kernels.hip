@@ -20,15 +20,21 @@ namespace orbfe {
 // ------------------------------------------------------------------------------------------------
 // Pyramid: level l <- bilinear(level l-1).  Reference: ComputePyramid, src/ORBextractor.cc:971-996
 // (cv::resize call at :984); fixed-point semantics: SURVEY.md Appendix B.2.
-// Block 64x4 threads, 4 destination pixels per thread (one 32-bit store).
+//
+// One 256-thread block produces a 64x64 output tile: the source footprint of the tile (about
+// 79x79 bytes at scale 1.2) is staged in LDS with aligned dword loads, every thread owns a 4x4 patch
+// of outputs (its 4 column and 4 row coefficient sets live in registers, so the tables are read
+// 1.5 times per output instead of 8), and each output row of the patch leaves as one dword store.
 // ------------------------------------------------------------------------------------------------
+constexpr int kRzTile = 64;
+
 __global__ __launch_bounds__(256) void k_resize(PyramidParams P, int level) {
+  extern __shared__ __align__(16) uint8_t rz[];
   const LevelGeom& D = P.lv[level];
   const LevelGeom& S = P.lv[level - 1];
   const int f = P.frameBase + blockIdx.z;
-  const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4;
-  const int y = blockIdx.y * 4 + threadIdx.y;
-  if (x0 >= D.w || y >= D.h) return;
+  const int tx0 = blockIdx.x * kRzTile, ty0 = blockIdx.y * kRzTile;
+  const int tx1 = min(tx0 + kRzTile, D.w) - 1, ty1 = min(ty0 + kRzTile, D.h) - 1;   // last column / row of the tile
   const uint8_t* src;
   long long sstride;
   if (level == 1) {
@@ -38,27 +44,81 @@ __global__ __launch_bounds__(256) void k_resize(PyramidParams P, int level) {
     src = P.slab + (long long)f * P.slabBytes + S.off;
     sstride = S.pitch;
   }
-  uint8_t* dst = P.slab + (long long)f * P.slabBytes + D.off + (long long)y * D.pitch;
-  const int sy = D.yofs[y];
-  const int sy0 = min(max(sy, 0), S.h - 1), sy1 = min(max(sy + 1, 0), S.h - 1);
-  const int b0 = D.ybeta[2 * y], b1 = D.ybeta[2 * y + 1];
-  const uint8_t* r0 = src + (long long)sy0 * sstride;
-  const uint8_t* r1 = src + (long long)sy1 * sstride;
-  uint32_t packed = 0;
+  // source footprint of the tile
+  const int rx0 = D.xofs[tx0], rx1 = min(D.xofs[tx1] + 1, S.w - 1);
+  const int ry0 = min(max(D.yofs[ty0], 0), S.h - 1), ry1 = min(max(D.yofs[ty1] + 1, 0), S.h - 1);
+  const int rw = rx1 - rx0 + 1, rh = ry1 - ry0 + 1;
+  const int LP = D.rzPitch;
+  const uint8_t* rbase = src + (long long)ry0 * sstride + rx0;
+  const int a = (int)(reinterpret_cast<uintptr_t>(rbase) & 3);
+  const int tid = threadIdx.x;
+  if ((sstride & 3) == 0) {
+    const int ndw = (a + rw + 3) >> 2;
+    const float rcp = 1.0f / (float)ndw;
+    const int total = ndw * rh;
+    const uint8_t* base = rbase - a;
+    for (int i0 = tid; i0 < total; i0 += 256 * 4) {
+      uint32_t v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = i0 + u * 256;
+        v[u] = 0;
+        if (i < total) {
+          const int y = (int)(((float)i + 0.5f) * rcp), c = i - y * ndw;
+          v[u] = *reinterpret_cast<const uint32_t*>(base + (long long)y * sstride + 4 * c);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = i0 + u * 256;
+        if (i < total) {
+          const int y = (int)(((float)i + 0.5f) * rcp), c = i - y * ndw;
+          *reinterpret_cast<uint32_t*>(rz + y * LP + 4 * c) = v[u];
+        }
+      }
+    }
+  } else {
+    const float rcp = 1.0f / (float)rw;
+    const int total = rw * rh;
+    for (int i = tid; i < total; i += 256) {
+      const int y = (int)(((float)i + 0.5f) * rcp), x = i - y * rw;
+      rz[y * LP + a + x] = rbase[(long long)y * sstride + x];
+    }
+  }
+  __syncthreads();
+  const uint8_t* tile = rz + a - rx0;  // tile[(sy - ry0) * LP + sx] is source pixel (sx, sy)
+
+  const int cx = tx0 + (tid & 15) * 4, cy = ty0 + (tid >> 4) * 4;   // this thread's 4x4 patch
+  if (cx > tx1 || cy > ty1) return;
+  int sx[4], sx1[4], a0[4], a1[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const int x = x0 + i;
-    if (x < D.w) {
-      const int sx = D.xofs[x];
-      const int a0 = D.xalpha[2 * x], a1 = D.xalpha[2 * x + 1];
-      const int sx1 = min(sx + 1, S.w - 1);  // a1 == 0 whenever sx+1 is out of range
-      const int h0 = r0[sx] * a0 + r0[sx1] * a1;
-      const int h1 = r1[sx] * a0 + r1[sx1] * a1;
+    const int x = min(cx + i, D.w - 1);
+    sx[i] = D.xofs[x];
+    sx1[i] = min(sx[i] + 1, S.w - 1);  // a1 == 0 whenever sx+1 is out of range
+    a0[i] = D.xalpha[2 * x];
+    a1[i] = D.xalpha[2 * x + 1];
+  }
+  uint8_t* dst = P.slab + (long long)f * P.slabBytes + D.off;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int y = cy + j;
+    if (y > ty1) break;
+    const int sy = D.yofs[y];
+    const int sy0 = min(max(sy, 0), S.h - 1) - ry0, sy1 = min(max(sy + 1, 0), S.h - 1) - ry0;
+    const int b0 = D.ybeta[2 * y], b1 = D.ybeta[2 * y + 1];
+    const uint8_t* r0 = tile + sy0 * LP;
+    const uint8_t* r1 = tile + sy1 * LP;
+    uint32_t packed = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int h0 = r0[sx[i]] * a0[i] + r0[sx1[i]] * a1[i];
+      const int h1 = r1[sx[i]] * a0[i] + r1[sx1[i]] * a1[i];
       const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
       packed |= (uint32_t)(v & 255) << (8 * i);
     }
+    *reinterpret_cast<uint32_t*>(dst + (long long)y * D.pitch + cx) = packed;  // pitch % 64 == 0: in bounds
   }
-  *reinterpret_cast<uint32_t*>(dst + x0) = packed;  // pitch is a multiple of 4: in-bounds
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -206,7 +266,11 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
     }
   }
   tile += a;  // ROI pixel (x, y) lives at tile[y * TP + x]
-  for (int i = lane; i < SP * (eh + 2); i += 64) sc[i] = 0;
+  {  // zero the score tile with dword stores (sc is 4-byte aligned: TP*(hCell+6) is a multiple of 4)
+    uint32_t* z = reinterpret_cast<uint32_t*>(sc);
+    const int nz = (SP * (eh + 2) + 3) >> 2;
+    for (int i = lane; i < nz; i += 64) z[i] = 0u;
+  }
   __syncthreads();
 
   const int tlo = min(P.iniTh, P.minTh);
@@ -223,10 +287,12 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
       x = i - y * ew;
       const uint8_t* c = tile + (y + 3) * TP + (x + 3);
       const int v = c[0];
-      const int d0 = v - c[3 * TP], d4 = v - c[3], d8 = v - c[-3 * TP], d12 = v - c[-3];
-      const bool k0 = d0 > tlo, k4 = d4 > tlo, k8 = d8 > tlo, k12 = d12 > tlo;
-      const bool b0 = d0 < -tlo, b4 = d4 < -tlo, b8 = d8 < -tlo, b12 = d12 < -tlo;
-      pass = (k0 & k4) | (k4 & k8) | (k8 & k12) | (k12 & k0) | (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0);
+      const int r0 = c[3 * TP], r4 = c[3], r8 = c[-3 * TP], r12 = c[-3];
+      // sign bit of k* set <=> ring darker than centre by more than tlo; of b* <=> brighter
+      const int kd = tlo - v, kb = v + tlo;
+      const int k0 = r0 + kd, k4 = r4 + kd, k8 = r8 + kd, k12 = r12 + kd;
+      const int b0 = kb - r0, b4 = kb - r4, b8 = kb - r8, b12 = kb - r12;
+      pass = (((k0 & k4) | (k4 & k8) | (k8 & k12) | (k12 & k0) | (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0)) < 0);
     }
     const unsigned long long m = __ballot(pass);
     if (pass) queue[nq + __popcll(m & below)] = (uint16_t)((y << 8) | x);
@@ -245,11 +311,13 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
       const uint8_t* c = tile + (y + 3) * TP + (x + 3);
       int d[16];
       ring_diffs(c, TP, c[0], d);
+      // one funnel shift per ring pixel and polarity: the sign of (tlo - d) / (d + tlo) is shifted into the
+      // mask (bit order is reversed, which does not matter for a circular run test)
       unsigned mdark = 0, mbright = 0;
 #pragma unroll
       for (int k = 0; k < 16; k++) {
-        mdark |= (unsigned)(d[k] > tlo) << k;
-        mbright |= (unsigned)(d[k] < -tlo) << k;
+        mdark = __builtin_amdgcn_alignbit(mdark, (unsigned)(tlo - d[k]), 31);
+        mbright = __builtin_amdgcn_alignbit(mbright, (unsigned)(d[k] + tlo), 31);
       }
       const bool pd = has_arc9(mdark), pb = has_arc9(mbright);
       pass = pd | pb;
@@ -541,8 +609,8 @@ __global__ void k_sincos(const float* deg, int n, float* c, float* s) {
 // ------------------------------------------------------------------------------------------------
 void launch_pyramid(const PyramidParams& P, int nframes, hipStream_t st) {
   for (int l = 1; l < P.nlevels; l++) {
-    dim3 grid((P.lv[l].w + 255) / 256, (P.lv[l].h + 3) / 4, nframes);
-    hipLaunchKernelGGL(k_resize, grid, dim3(64, 4, 1), 0, st, P, l);
+    dim3 grid((P.lv[l].w + kRzTile - 1) / kRzTile, (P.lv[l].h + kRzTile - 1) / kRzTile, nframes);
+    hipLaunchKernelGGL(k_resize, grid, dim3(256), (size_t)P.lv[l].rzPitch * P.lv[l].rzRows, st, P, l);
   }
 }
 

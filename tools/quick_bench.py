@@ -12,6 +12,7 @@ frames = [synth(100 + i, W, H) for i in range(min(B, 4))]
 dev = torch.stack([torch.from_numpy(frames[i % len(frames)]) for i in range(B)]).cuda()
 torch.cuda.synchronize()
 ex = api.Extractor(N, 1.2, 8, 20, 7)
+ex.set_profiling(len(sys.argv) > 2)
 ptrs = [dev[i].data_ptr() for i in range(B)]
 kps = np.zeros((B, ex.cap), api.KP_DTYPE); desc = np.zeros((B, ex.cap, 32), np.uint8)
 for it in range(3):
