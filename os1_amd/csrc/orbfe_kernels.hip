@@ -12,6 +12,8 @@
 //   k_sincos        test hook for the device (cosf,sinf)
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "glibc_sincosf.h"
 #include "orbfe_internal.h"
 
@@ -207,10 +209,9 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
   uint8_t* tile = lds;
   uint8_t* sc = tile + TP * (L.hCell + 6);
   uint16_t* queue = reinterpret_cast<uint16_t*>(lds + ((TP * (L.hCell + 6) + SP * (L.hCell + 2) + 3) & ~3));
-  uint8_t* kept = reinterpret_cast<uint8_t*>(queue + L.wCell * L.hCell);
+  uint8_t* kept = lds;  // stage 4 only: aliases the ROI tile, which is dead after stage 3 (TP*(hCell+6) >= wCell*hCell)
 
   const int rw = ew + 6, rh = eh + 6;
-  const float rcpEw = 1.0f / (float)ew;
   const uint8_t* roi = img + (long long)(ey0 - 3) * stride + (ex0 - 3);
   // ROI -> LDS.  Loads are issued in batches of 8 per lane before the first LDS write so the wave
   // waits for memory once per batch, not once per element.  Rows are fetched as aligned dwords when
@@ -274,29 +275,70 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
   __syncthreads();
 
   const int tlo = min(P.iniTh, P.minTh);
-  const int npx = ew * eh;
   const unsigned long long below = (1ull << lane) - 1ull;
-  // ---- stage 1: compass pre-test -------------------------------------------------------------
+  // ---- stage 1: compass pre-test, 4 horizontally adjacent pixels per lane -------------------------
+  // Lane item i = (row y, group g): pixels x = 4g..4g+3.  The 10 centre-row bytes and the 4 bytes of rows
+  // y-3 / y+3 come from aligned LDS dwords and one funnel shift each (the byte alignment `a` of the ROI
+  // is uniform for the cell, so it is a template constant of the loop body).
   int nq = 0;
-  for (int i0 = 0; i0 < npx; i0 += 64) {
-    const int i = i0 + lane;
-    bool pass = false;
-    int y = 0, x = 0;
-    if (i < npx) {
-      y = (int)(((float)i + 0.5f) * rcpEw);
-      x = i - y * ew;
-      const uint8_t* c = tile + (y + 3) * TP + (x + 3);
-      const int v = c[0];
-      const int r0 = c[3 * TP], r4 = c[3], r8 = c[-3 * TP], r12 = c[-3];
-      // sign bit of k* set <=> ring darker than centre by more than tlo; of b* <=> brighter
-      const int kd = tlo - v, kb = v + tlo;
-      const int k0 = r0 + kd, k4 = r4 + kd, k8 = r8 + kd, k12 = r12 + kd;
-      const int b0 = kb - r0, b4 = kb - r4, b8 = kb - r8, b12 = kb - r12;
-      pass = (((k0 & k4) | (k4 & k8) | (k8 & k12) | (k12 & k0) | (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0)) < 0);
+  const int G = (ew + 3) >> 2, nItems = G * eh;
+  const float rcpG = 1.0f / (float)G;
+  auto stage1 = [&](auto aTag) {
+    constexpr int A = decltype(aTag)::value;
+    for (int i0 = 0; i0 < nItems; i0 += 64) {
+      const int i = i0 + lane;
+      unsigned passBits = 0;
+      int y = 0, x = 0;
+      if (i < nItems) {
+        y = (int)(((float)i + 0.5f) * rcpG);
+        x = (i - y * G) << 2;
+        // aligned dword pointer of (row y+3, tile column x): tile already includes the +A shift
+        const uint32_t* cw = reinterpret_cast<const uint32_t*>(tile - A + (y + 3) * TP + x);
+        const uint32_t w0 = cw[0], w1 = cw[1], w2 = cw[2], w3 = cw[3];
+        const uint32_t* uw = reinterpret_cast<const uint32_t*>(tile - A + y * TP + x);         // row y-3 (+3 halo)
+        const uint32_t* dw = reinterpret_cast<const uint32_t*>(tile - A + (y + 6) * TP + x);   // row y+3
+        // byte windows: left = bytes [A, A+4), centre/up/down = [A+3, A+7), right = [A+6, A+10) of the row
+        const uint32_t L4 = __builtin_amdgcn_alignbyte(w1, w0, A);
+        const uint32_t C4 = (A + 3 < 4) ? __builtin_amdgcn_alignbyte(w1, w0, (A + 3) & 3)
+                                        : __builtin_amdgcn_alignbyte(w2, w1, (A + 3) & 3);
+        const uint32_t R4 = (A + 6 < 8) ? __builtin_amdgcn_alignbyte(w2, w1, (A + 6) & 3)
+                                        : __builtin_amdgcn_alignbyte(w3, w2, (A + 6) & 3);
+        const uint32_t U4 = (A + 3 < 4) ? __builtin_amdgcn_alignbyte(uw[1], uw[0], (A + 3) & 3)
+                                        : __builtin_amdgcn_alignbyte(uw[2], uw[1], (A + 3) & 3);
+        const uint32_t D4 = (A + 3 < 4) ? __builtin_amdgcn_alignbyte(dw[1], dw[0], (A + 3) & 3)
+                                        : __builtin_amdgcn_alignbyte(dw[2], dw[1], (A + 3) & 3);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const int v = (C4 >> (8 * j)) & 255;
+          const int r0 = (D4 >> (8 * j)) & 255, r4 = (R4 >> (8 * j)) & 255, r8 = (U4 >> (8 * j)) & 255,
+                    r12 = (L4 >> (8 * j)) & 255;
+          // sign bit of k* set <=> ring darker than centre by more than tlo; of b* <=> brighter
+          const int kd = tlo - v, kb = v + tlo;
+          const int k0 = r0 + kd, k4 = r4 + kd, k8 = r8 + kd, k12 = r12 + kd;
+          const int b0 = kb - r0, b4 = kb - r4, b8 = kb - r8, b12 = kb - r12;
+          const int e = (k0 & k4) | (k4 & k8) | (k8 & k12) | (k12 & k0) | (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0);
+          if (e < 0 && x + j < ew) passBits |= 1u << j;
+        }
+      }
+      int off = 0, tot = 0;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const unsigned long long m = __ballot((passBits >> j) & 1u);
+        off += __popcll(m & below);
+        tot += __popcll(m);
+      }
+      int pos = nq + off;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if ((passBits >> j) & 1u) queue[pos++] = (uint16_t)((y << 8) | (x + j));
+      nq += tot;
     }
-    const unsigned long long m = __ballot(pass);
-    if (pass) queue[nq + __popcll(m & below)] = (uint16_t)((y << 8) | x);
-    nq += __popcll(m);
+  };
+  switch (a) {
+    case 0: stage1(std::integral_constant<int, 0>{}); break;
+    case 1: stage1(std::integral_constant<int, 1>{}); break;
+    case 2: stage1(std::integral_constant<int, 2>{}); break;
+    default: stage1(std::integral_constant<int, 3>{}); break;
   }
   __syncthreads();
   // ---- stage 2: full arc test, compacted in place; bit 15 / 7 carry the polarity ----------------
@@ -620,7 +662,7 @@ size_t fast_lds_bytes(const PyramidParams& P) {
     const LevelGeom& L = P.lv[l];
     const size_t TP = (L.wCell + 6 + 3 + 3) & ~3;
     const size_t b = ((TP * (L.hCell + 6) + (size_t)(L.wCell + 2) * (L.hCell + 2) + 3) & ~(size_t)3) +
-                     3 * (size_t)L.wCell * L.hCell;  // tile + score tile + u16 queue + u8 kept
+                     2 * (size_t)L.wCell * L.hCell;  // tile (+ kept alias) + score tile + u16 queue
     mx = b > mx ? b : mx;
   }
   return (mx + 15) & ~(size_t)15;
