@@ -34,10 +34,10 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=16, help='frames per step and GPU')
+    ap.add_argument('--batch', type=int, default=32, help='frames per step and GPU')
     ap.add_argument('--cpu-frames', type=int, default=24, help='frames of the CPU-oracle baseline sample (0 = skip)')
     ap.add_argument('--no-match', action='store_true', help='extract only (configs[1])')
-    ap.add_argument('--depth', type=int, default=2, help='extraction batches in flight (one extractor handle each)')
+    ap.add_argument('--depth', type=int, default=2, help='extraction batches in flight inside the stream runner')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -69,80 +69,26 @@ def main():
     # by (2,1) px"; derived from the base frame so that noise does not accumulate along the stream)
     frames = [base] + [shifted(base, 2 * i, i, seed * 1000 + i) for i in range(1, B)]
     dev = api.DeviceFrames(frames, local_rank)
-    exs = [api.Extractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank) for _ in range(max(1, args.depth))]
-    ex = exs[0]
-    mt = api.Matcher(local_rank)
-    # two output buffer sets: the matcher thread reads set k%2 while the main thread collects batch k+1 into the other
-    kps_buf = [np.zeros((B, ex.cap), api.KP_DTYPE) for _ in range(2)]
-    desc_buf = [np.zeros((B, ex.cap, 32), np.uint8) for _ in range(2)]
+    # native stream runner: `depth` extractor handles + one matcher + two worker threads, all C++
+    st = api.Stream(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, local_rank, B, max(1, args.depth))
     bounds = (0.0, float(W), 0.0, float(H))
+    st.set_matching(bounds, 0 if args.no_match else 100, 0.9, True)   # window 100, nnratio 0.9, checkOrientation
     nmatch_total = [0]
-    last = [None]
-
-    def match(kps, desc, n, prev_last):
-        """SearchForInitialization of every frame of the batch against its predecessor in the stream."""
-        pairs = []
-        for i in range(B):
-            cur = (kps[i, :n[i]], desc[i, :n[i]])
-            prev = prev_last if i == 0 else (kps[i - 1, :n[i - 1]], desc[i - 1, :n[i - 1]])
-            if prev is not None:
-                pxy = np.empty((len(prev[0]), 2), np.float32)         # vbPrevMatched := F1 keypoints (Tracking.cc:355-357)
-                pxy[:, 0] = prev[0]['x']
-                pxy[:, 1] = prev[0]['y']
-                pairs.append((prev[0], prev[1], cur[0], cur[1], pxy))
-        # one GPU submission for all pairs of the step (orbfe_search_for_initialization_batch)
-        for nm, _, _ in mt.search_for_initialization_batch(pairs, bounds, 100, 0.9, True):
-            nmatch_total[0] += nm
-
-    import queue
-    import threading
 
     def run(nsteps):
-        """nsteps passes of the hot path.  Two roles, as in the reference (Frame construction vs Tracking):
-        the main thread keeps `--depth` extraction batches in flight (asynchronous submit/collect on the
-        extractor streams); a matcher thread runs SearchForInitialization for batch k while batch k+1 is being
-        extracted.  Every submit, collect and match of the nsteps batches happens inside this call."""
-        if nsteps <= 0:
-            return
-        D = len(exs)
-        jobs = queue.Queue(maxsize=1)
-        err = []
-
-        def matcher():
-            try:
-                while True:
-                    job = jobs.get()
-                    if job is None:
-                        return
-                    match(*job)
-            except BaseException as e:      # surface matcher failures in the main thread
-                err.append(e)
-                while jobs.get() is not None:
-                    pass
-
-        th = threading.Thread(target=matcher)
-        if not args.no_match:
-            th.start()
-        for j in range(min(D, nsteps)):
-            exs[j].submit_ptrs(dev.ptrs, H, W, dev.stride, True)
-        prev_last = last[0]
-        for k in range(nsteps):
-            h = exs[k % D]
-            kps, desc = kps_buf[k % 2], desc_buf[k % 2]
-            # buffer set k%2 was last read by match(k-2), which finished before match(k-1) was accepted
-            # by the depth-1 queue, i.e. before this point
-            _, _, n = h.collect(kps, desc)
-            if k + D < nsteps:
-                h.submit_ptrs(dev.ptrs, H, W, dev.stride, True)
-            if not args.no_match:
-                jobs.put((kps, desc, n.copy(), prev_last))
-            prev_last = (kps[B - 1, :n[B - 1]].copy(), desc[B - 1, :n[B - 1]].copy())
-        last[0] = prev_last
-        if not args.no_match:
-            jobs.put(None)
-            th.join()
-            if err:
-                raise err[0]
+        """nsteps passes of the hot path: push a batch (async extraction on the GPU, then SearchForInitialization
+        of every frame against its predecessor), pop its keypoints / descriptors / matches in host memory.
+        Up to depth+1 batches are in the pipeline; every push and pop of the nsteps batches is inside this call."""
+        pushed = 0
+        while pushed < min(args.depth + 1, nsteps):
+            st.push_ptrs(dev.ptrs, H, W, dev.stride, True)
+            pushed += 1
+        for _ in range(nsteps):
+            _, _, n, _, nm = st.pop()
+            nmatch_total[0] += int(nm.sum())
+            if pushed < nsteps:
+                st.push_ptrs(dev.ptrs, H, W, dev.stride, True)
+                pushed += 1
 
     def sync():
         api.device_synchronize(local_rank)
@@ -150,8 +96,7 @@ def main():
             torch.cuda.synchronize()
 
     run(args.warmup)
-    for e in exs:
-        e.kernel_ms(reset=True)
+    st.kernel_ms(reset=True)
     nmatch_total[0] = 0
     sync()
     if dist is not None:
@@ -162,12 +107,7 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    kms, kbatches, kframes = np.zeros(5), 0, 0
-    for e in exs:
-        a, b_, c_ = e.kernel_ms()
-        kms += a
-        kbatches += b_
-        kframes += c_
+    kms, kbatches, kframes = st.kernel_ms()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -178,12 +118,14 @@ def main():
         fps = frames_done / elapsed
         # roofline of the dominant kernel (DESIGN.md "Roofline"): k_fast_cells reads every pyramid pixel once
         # (sum of level sizes) and writes 4 B per surviving candidate; algorithmic bytes per launch = that x B.
+        ex = api.Extractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank)   # geometry + candidate count only
         t = ex.tables()
         px = 0
         for l in range(NLEVELS):
             lw = int(np.rint(np.float32(W) * t['isf'][l]))
             lh = int(np.rint(np.float32(H) * t['isf'][l]))
             px += lw * lh
+        ex.extract_batch_ptrs(dev.ptrs[:1], H, W, dev.stride, True)
         ncand = sum(len(ex.candidates(l, 0)) for l in range(NLEVELS))
         fast_bytes_per_frame = px + 4 * ncand
         fast_ms_per_launch = kms[1] / max(kbatches, 1)

@@ -144,6 +144,40 @@ int orbfe_debug_quadtree(const int16_t* x, const int16_t* y, const uint8_t* scor
 int orbfe_debug_sincos_host_check(uint32_t lo_bits, uint32_t hi_bits, uint32_t step, long long* mismatches);
 
 /* ---------------------------------------------------------------------------------------------
+ * Stream runner (throughput path; no counterpart class in the reference, whose Tracking thread drives
+ * ORBextractor / ORBmatcher one frame at a time -- System.cc:115-152, Tracking.cc:92-121,344-419).
+ * A stream owns `depth` extractor handles + one matcher on one GPU and two native worker threads:
+ * batches pushed with orbfe_stream_push are extracted (asynchronous submit/collect, `depth` batches in
+ * flight) and every frame is matched against its predecessor in the stream with
+ * SearchForInitialization (vbPrevMatched := predecessor keypoints, as Tracking.cc:355-357); results come
+ * back in push order from orbfe_stream_pop.  Identical results to calling orbfe_extract_batch and
+ * orbfe_search_for_initialization frame by frame.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct orbfe_stream orbfe_stream;
+/* batch = frames per push; depth = extraction batches in flight (1..8). */
+int orbfe_stream_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device_id,
+                        int batch, int depth, orbfe_stream** out);
+void orbfe_stream_destroy(orbfe_stream* s);
+/* bounds = {mnMinX, mnMaxX, mnMinY, mnMaxY}; window_size <= 0 disables matching (extract only). */
+int orbfe_stream_set_matching(orbfe_stream* s, const float bounds[4], int window_size, float nnratio,
+                              int check_orientation);
+/* Per-frame output capacity (keypoints) of the arrays returned by orbfe_stream_pop. */
+int orbfe_stream_capacity(const orbfe_stream* s);
+/* Enqueue one batch (`batch` frame pointers; device pointers if in_device_memory != 0).  Returns at once
+ * unless depth+3 batches are already queued.  The frames must stay valid until their batch is popped. */
+int orbfe_stream_push(orbfe_stream* s, const uint8_t* const* gray, int in_device_memory, int rows, int cols,
+                      size_t stride_bytes);
+/* Wait for the oldest batch.  Output pointers stay valid until the next pop:
+ *   kps [batch][cap], desc [batch][cap][32], n_kps [batch];
+ *   matches12 [batch][cap]: row i = vnMatches12 of (F1 = frame i-1 of the stream, F2 = frame i), indexed by
+ *   F1's keypoints (first n_kps[i-1] entries valid; row 0 uses the last frame of the previous batch);
+ *   nmatches [batch]: return values of the searches (0 for the very first frame of the stream). */
+int orbfe_stream_pop(orbfe_stream* s, const OrbfeKeyPoint** kps, const uint8_t** desc, const int** n_kps,
+                     const int32_t** matches12, const int** nmatches);
+/* Sum of orbfe_debug_kernel_ms over the stream's extractor handles. */
+int orbfe_stream_kernel_ms(orbfe_stream* s, double out_ms[5], long long* batches, long long* frames, int reset);
+
+/* ---------------------------------------------------------------------------------------------
  * Matcher.  Replaces the hot subset of ORB_SLAM2::ORBmatcher (include/ORBmatcher.h:71-270).
  * ------------------------------------------------------------------------------------------- */
 

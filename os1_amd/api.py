@@ -85,6 +85,14 @@ def load_library():
     L.orbfe_device_free.argtypes = [ci, vp]
     L.orbfe_device_upload.argtypes = [ci, vp, vp, C.c_size_t]
     L.orbfe_device_synchronize.argtypes = [ci]
+    L.orbfe_stream_create.argtypes = [ci, cf, ci, ci, ci, ci, ci, ci, C.POINTER(vp)]
+    L.orbfe_stream_destroy.argtypes = [vp]
+    L.orbfe_stream_destroy.restype = None
+    L.orbfe_stream_set_matching.argtypes = [vp, vp, ci, cf, ci]
+    L.orbfe_stream_capacity.argtypes = [vp]
+    L.orbfe_stream_push.argtypes = [vp, vp, ci, ci, ci, C.c_size_t]
+    L.orbfe_stream_pop.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.orbfe_stream_kernel_ms.argtypes = [vp, vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), ci]
     L.orbfe_debug_quadtree.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, ci, C.POINTER(ci)]
     L.orbfe_debug_sincos_host_check.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_longlong)]
     _lib = L
@@ -387,3 +395,56 @@ class DeviceFrames:
 
 def device_synchronize(device=0):
     _check(load_library().orbfe_device_synchronize(device))
+
+
+class Stream:
+    """Native stream runner (orbfe_stream_*): push batches of frames, pop (keypoints, descriptors, matches
+    against the predecessor frame) in order.  Orchestration (async extraction, matching thread) is C++."""
+
+    def __init__(self, nfeatures, scale, nlevels, ini_th, min_th, device, batch, depth=2):
+        self.L = load_library()
+        h = C.c_void_p()
+        _check(self.L.orbfe_stream_create(nfeatures, scale, nlevels, ini_th, min_th, device, batch, depth, C.byref(h)))
+        self.h = h
+        self.batch = batch
+        self.cap = self.L.orbfe_stream_capacity(h)
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.L.orbfe_stream_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_matching(self, bounds, window=100, nnratio=0.9, check_ori=True):
+        b = np.asarray(bounds, np.float32)
+        _check(self.L.orbfe_stream_set_matching(self.h, _p(b), window, nnratio, int(check_ori)))
+
+    def push_ptrs(self, ptrs, rows, cols, stride, on_device=True):
+        assert len(ptrs) == self.batch
+        arr = (C.c_void_p * self.batch)(*ptrs)
+        _check(self.L.orbfe_stream_push(self.h, arr, int(on_device), rows, cols, stride))
+
+    def pop(self, copy=False):
+        """-> (kps[B,cap], desc[B,cap,32], n[B], matches12[B,cap], nmatches[B]) as views valid until the next pop."""
+        pk, pd, pn, pm, pnm = (C.c_void_p() for _ in range(5))
+        _check(self.L.orbfe_stream_pop(self.h, C.byref(pk), C.byref(pd), C.byref(pn), C.byref(pm), C.byref(pnm)))
+        B, cap = self.batch, self.cap
+
+        def view(ptr, dtype, shape):
+            n = int(np.prod(shape))
+            buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr.value)
+            a = np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+            return a.copy() if copy else a
+        return (view(pk, KP_DTYPE, (B, cap)), view(pd, np.uint8, (B, cap, 32)), view(pn, np.int32, (B,)),
+                view(pm, np.int32, (B, cap)), view(pnm, np.int32, (B,)))
+
+    def kernel_ms(self, reset=False):
+        ms = np.zeros(5, np.float64)
+        b, f = C.c_longlong(0), C.c_longlong(0)
+        _check(self.L.orbfe_stream_kernel_ms(self.h, _p(ms), C.byref(b), C.byref(f), int(reset)))
+        return ms, b.value, f.value

@@ -1,0 +1,316 @@
+// orbfe_stream.cpp -- native frame-stream runner on top of the extractor / matcher C ABI.
+//
+// Role in the reference: the per-frame front end is driven by the Tracking thread, one frame at a
+// time (System::TrackMonocular -> Frame::Frame -> ORBextractor, then ORBmatcher).
+// For throughput over a stream (BASELINE.json config 4: independent streams, one per GPU) this
+// runner keeps the GPU fed without any per-frame host orchestration in the caller's language:
+//   push(batch of frames)  ->  [extract thread]  async submit on one of `depth` extractor handles,
+//                              collect in order
+//                          ->  [match thread]    SearchForInitialization of every frame against its
+//                              predecessor in the stream (one batched GPU submission)
+//   pop()                  ->  results of the oldest finished batch, in push order.
+// Everything the GPU computes goes through the same entry points a single-frame caller uses
+// (orbfe_extract_batch_submit/_collect, orbfe_search_for_initialization_batch), so results are
+// identical to calling those one by one.
+#include <algorithm>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/orbfe.h"
+
+namespace orbfe {
+void set_err(const char* fmt, ...);
+}
+using orbfe::set_err;
+
+namespace {
+struct Slot {
+  std::vector<const uint8_t*> frames;
+  int rows = 0, cols = 0;
+  size_t stride = 0;
+  int onDevice = 1;
+  std::vector<OrbfeKeyPoint> kps;
+  std::vector<uint8_t> desc;
+  std::vector<int> n;
+  std::vector<int32_t> m12;
+  std::vector<int> nm;
+  std::vector<float> prevxy;
+  int status = ORBFE_OK;
+  std::string err;
+};
+}  // namespace
+
+struct orbfe_stream {
+  int batch = 0, depth = 0, cap = 0, device = 0;
+  int window = 100, checkOri = 1;
+  float nnratio = 0.9f;
+  float bounds[4] = {0, 0, 0, 0};
+  std::vector<orbfe_extractor*> ext;
+  orbfe_matcher* matcher = nullptr;
+  std::vector<Slot> slots;
+
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<int> freeQ, extractQ, matchQ, doneQ;
+  int popped = -1;  // slot handed to the caller by the last pop (returned to freeQ on the next pop)
+  bool stop = false;
+  std::thread tExtract, tMatch;
+
+  // last frame of the previous batch (the predecessor of frame 0 of the next one)
+  std::vector<OrbfeKeyPoint> lastKps;
+  std::vector<uint8_t> lastDesc;
+  int lastN = -1;
+
+  void extractLoop() {
+    std::deque<std::pair<int, int>> inflight;  // (slot, extractor)
+    int nextExt = 0;
+    for (;;) {
+      int job = -1;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || !inflight.empty() || !extractQ.empty(); });
+        if (stop && inflight.empty() && extractQ.empty()) return;
+        if (!extractQ.empty() && (int)inflight.size() < depth) {
+          job = extractQ.front();
+          extractQ.pop_front();
+        }
+      }
+      if (job >= 0) {
+        Slot& s = slots[job];
+        orbfe_extractor* h = ext[nextExt];
+        s.status = orbfe_extract_batch_submit(h, batch, s.frames.data(), s.onDevice, s.rows, s.cols, s.stride);
+        if (s.status != ORBFE_OK) s.err = orbfe_last_error();
+        inflight.emplace_back(job, nextExt);
+        nextExt = (nextExt + 1) % depth;
+        continue;
+      }
+      if (inflight.empty()) continue;
+      const int slot = inflight.front().first, e = inflight.front().second;
+      inflight.pop_front();
+      Slot& s = slots[slot];
+      if (s.status == ORBFE_OK) {
+        s.status = orbfe_extract_batch_collect(ext[e], s.kps.data(), s.desc.data(), cap, s.n.data());
+        if (s.status != ORBFE_OK) s.err = orbfe_last_error();
+      }
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        matchQ.push_back(slot);
+      }
+      cv.notify_all();
+    }
+  }
+
+  void matchLoop() {
+    std::vector<const OrbfeKeyPoint*> k1, k2;
+    std::vector<const uint8_t*> d1, d2;
+    std::vector<int> n1, n2;
+    std::vector<float*> prev;
+    std::vector<int32_t*> m12;
+    std::vector<int> nm;
+    for (;;) {
+      int slot = -1;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || !matchQ.empty(); });
+        if (matchQ.empty()) {
+          if (stop) return;
+          continue;
+        }
+        slot = matchQ.front();
+        matchQ.pop_front();
+      }
+      Slot& s = slots[slot];
+      if (s.status == ORBFE_OK && window > 0) {
+        // pairs (predecessor, frame): Tracking::MonocularInitialization style, vbPrevMatched := F1 keypoints
+        k1.clear(); k2.clear(); d1.clear(); d2.clear(); n1.clear(); n2.clear(); prev.clear(); m12.clear();
+        std::vector<int> frameOfPair;
+        for (int i = 0; i < batch; i++) {
+          const OrbfeKeyPoint* pk;
+          const uint8_t* pd;
+          int pn;
+          if (i == 0) {
+            if (lastN < 0) {  // very first frame of the stream: no predecessor
+              s.nm[0] = 0;
+              std::fill(s.m12.begin(), s.m12.begin() + cap, -1);
+              continue;
+            }
+            pk = lastKps.data(); pd = lastDesc.data(); pn = lastN;
+          } else {
+            pk = s.kps.data() + (size_t)(i - 1) * cap; pd = s.desc.data() + (size_t)(i - 1) * cap * 32; pn = s.n[i - 1];
+          }
+          float* pxy = s.prevxy.data() + (size_t)i * cap * 2;
+          for (int j = 0; j < pn; j++) { pxy[2 * j] = pk[j].x; pxy[2 * j + 1] = pk[j].y; }
+          k1.push_back(pk); d1.push_back(pd); n1.push_back(pn);
+          k2.push_back(s.kps.data() + (size_t)i * cap); d2.push_back(s.desc.data() + (size_t)i * cap * 32); n2.push_back(s.n[i]);
+          prev.push_back(pxy);
+          m12.push_back(s.m12.data() + (size_t)i * cap);
+          frameOfPair.push_back(i);
+        }
+        nm.assign(k1.size(), 0);
+        if (!k1.empty()) {
+          s.status = orbfe_search_for_initialization_batch(matcher, (int)k1.size(), k1.data(), d1.data(), n1.data(), k2.data(),
+                                                           d2.data(), n2.data(), bounds, prev.data(), m12.data(), window,
+                                                           nnratio, checkOri, nm.data());
+          if (s.status != ORBFE_OK) s.err = orbfe_last_error();
+          for (size_t p = 0; p < frameOfPair.size(); p++) s.nm[frameOfPair[p]] = nm[p];
+        }
+      }
+      if (s.status == ORBFE_OK) {
+        lastN = s.n[batch - 1];
+        lastKps.assign(s.kps.begin() + (size_t)(batch - 1) * cap, s.kps.begin() + (size_t)(batch - 1) * cap + lastN);
+        lastDesc.assign(s.desc.begin() + (size_t)(batch - 1) * cap * 32, s.desc.begin() + ((size_t)(batch - 1) * cap + lastN) * 32);
+      }
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        doneQ.push_back(slot);
+      }
+      cv.notify_all();
+    }
+  }
+};
+
+extern "C" {
+
+int orbfe_stream_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device_id,
+                        int batch, int depth, orbfe_stream** out) {
+  if (!out || batch < 1 || depth < 1 || depth > 8) { set_err("invalid stream parameters"); return ORBFE_ERR_INVALID; }
+  *out = nullptr;
+  orbfe_stream* s = new orbfe_stream();
+  s->batch = batch;
+  s->depth = depth;
+  s->device = device_id;
+  for (int d = 0; d < depth; d++) {
+    orbfe_extractor* h = nullptr;
+    int rc = orbfe_extractor_create(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device_id, &h);
+    if (rc != ORBFE_OK) {
+      for (auto* e : s->ext) orbfe_extractor_destroy(e);
+      delete s;
+      return rc;
+    }
+    s->ext.push_back(h);
+  }
+  int rc = orbfe_matcher_create(device_id, &s->matcher);
+  if (rc != ORBFE_OK) {
+    for (auto* e : s->ext) orbfe_extractor_destroy(e);
+    delete s;
+    return rc;
+  }
+  s->cap = orbfe_extractor_max_keypoints(s->ext[0]);
+  const int nslots = depth + 3;
+  s->slots.resize(nslots);
+  for (int i = 0; i < nslots; i++) {
+    Slot& sl = s->slots[i];
+    sl.frames.resize(batch);
+    sl.kps.resize((size_t)batch * s->cap);
+    sl.desc.resize((size_t)batch * s->cap * 32);
+    sl.n.assign(batch, 0);
+    sl.m12.assign((size_t)batch * s->cap, -1);
+    sl.nm.assign(batch, 0);
+    sl.prevxy.resize((size_t)batch * s->cap * 2);
+    s->freeQ.push_back(i);
+  }
+  s->tExtract = std::thread([s] { s->extractLoop(); });
+  s->tMatch = std::thread([s] { s->matchLoop(); });
+  *out = s;
+  return ORBFE_OK;
+}
+
+void orbfe_stream_destroy(orbfe_stream* s) {
+  if (!s) return;
+  {
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->stop = true;
+  }
+  s->cv.notify_all();
+  if (s->tExtract.joinable()) s->tExtract.join();
+  if (s->tMatch.joinable()) s->tMatch.join();
+  for (auto* e : s->ext) orbfe_extractor_destroy(e);
+  orbfe_matcher_destroy(s->matcher);
+  delete s;
+}
+
+int orbfe_stream_set_matching(orbfe_stream* s, const float bounds[4], int window_size, float nnratio,
+                              int check_orientation) {
+  if (!s || (window_size > 0 && !bounds)) { set_err("invalid arguments"); return ORBFE_ERR_INVALID; }
+  std::lock_guard<std::mutex> lk(s->mu);
+  if (bounds) memcpy(s->bounds, bounds, sizeof s->bounds);
+  s->window = window_size;
+  s->nnratio = nnratio;
+  s->checkOri = check_orientation;
+  return ORBFE_OK;
+}
+
+int orbfe_stream_capacity(const orbfe_stream* s) { return s ? s->cap : 0; }
+
+int orbfe_stream_push(orbfe_stream* s, const uint8_t* const* gray, int in_device_memory, int rows, int cols,
+                      size_t stride_bytes) {
+  if (!s || !gray || rows <= 0 || cols <= 0 || stride_bytes < (size_t)cols) { set_err("invalid arguments"); return ORBFE_ERR_INVALID; }
+  int slot;
+  {
+    std::unique_lock<std::mutex> lk(s->mu);
+    s->cv.wait(lk, [&] { return !s->freeQ.empty(); });
+    slot = s->freeQ.front();
+    s->freeQ.pop_front();
+  }
+  Slot& sl = s->slots[slot];
+  for (int i = 0; i < s->batch; i++) sl.frames[i] = gray[i];
+  sl.rows = rows; sl.cols = cols; sl.stride = stride_bytes; sl.onDevice = in_device_memory;
+  sl.status = ORBFE_OK;
+  {
+    std::lock_guard<std::mutex> lk(s->mu);
+    s->extractQ.push_back(slot);
+  }
+  s->cv.notify_all();
+  return ORBFE_OK;
+}
+
+int orbfe_stream_pop(orbfe_stream* s, const OrbfeKeyPoint** kps, const uint8_t** desc, const int** n_kps,
+                     const int32_t** matches12, const int** nmatches) {
+  if (!s) { set_err("stream is NULL"); return ORBFE_ERR_INVALID; }
+  int slot;
+  {
+    std::unique_lock<std::mutex> lk(s->mu);
+    if (s->popped >= 0) {
+      s->freeQ.push_back(s->popped);
+      s->popped = -1;
+      s->cv.notify_all();
+    }
+    s->cv.wait(lk, [&] { return !s->doneQ.empty(); });
+    slot = s->doneQ.front();
+    s->doneQ.pop_front();
+    s->popped = slot;
+  }
+  Slot& sl = s->slots[slot];
+  if (kps) *kps = sl.kps.data();
+  if (desc) *desc = sl.desc.data();
+  if (n_kps) *n_kps = sl.n.data();
+  if (matches12) *matches12 = sl.m12.data();
+  if (nmatches) *nmatches = sl.nm.data();
+  if (sl.status != ORBFE_OK) set_err("%s", sl.err.c_str());
+  return sl.status;
+}
+
+int orbfe_stream_kernel_ms(orbfe_stream* s, double out_ms[5], long long* batches, long long* frames, int reset) {
+  if (!s) { set_err("stream is NULL"); return ORBFE_ERR_INVALID; }
+  double acc[5] = {0, 0, 0, 0, 0};
+  long long b = 0, f = 0;
+  for (auto* e : s->ext) {
+    double ms[5];
+    long long bb = 0, ff = 0;
+    orbfe_debug_kernel_ms(e, ms, &bb, &ff, reset);
+    for (int i = 0; i < 5; i++) acc[i] += ms[i];
+    b += bb;
+    f += ff;
+  }
+  if (out_ms) for (int i = 0; i < 5; i++) out_ms[i] = acc[i];
+  if (batches) *batches = b;
+  if (frames) *frames = f;
+  return ORBFE_OK;
+}
+
+}  // extern "C"

@@ -258,3 +258,34 @@ def test_search_for_initialization_batch_parity(api, oracle):
         on, om12, op = oracle.search_for_initialization(k1, d1, k2, d2, bounds, prev, 100, 0.9, True)
         assert n == on and (m12 == om12).all() and p.tobytes() == op.tobytes()
     assert got[0][0] > 50
+
+
+def test_stream_runner_parity(api, oracle):
+    """orbfe_stream_*: pushed batches come back in order with the same keypoints / descriptors / matches as
+    the oracle computes frame by frame (frame i matched against frame i-1 of the stream)."""
+    W, H, N, B = 800, 600, 800, 3
+    base = synth(60, W, H)
+    frames = [base] + [shifted(base, 3 * i, -2 * i, 600 + i) for i in range(1, 3 * B)]
+    dev = api.DeviceFrames(frames, 0)
+    st = api.Stream(N, 1.2, 8, 20, 7, 0, B, 2)
+    bounds = (0.0, float(W), 0.0, float(H))
+    st.set_matching(bounds, 100, 0.9, True)
+    ox = OracleExtractor(N, 1.2, 8, 20, 7, oracle)
+    want = [ox.extract(f) for f in frames]
+    for b in range(3):
+        st.push_ptrs(dev.ptrs[b * B:(b + 1) * B], H, W, dev.stride, True)
+    for b in range(3):
+        kps, desc, n, m12, nm = st.pop(copy=True)
+        for i in range(B):
+            g = b * B + i
+            wk, wd = want[g]
+            assert n[i] == len(wk)
+            assert kps[i, :n[i]].tobytes() == wk.tobytes() and desc[i, :n[i]].tobytes() == wd.tobytes()
+            if g == 0:
+                assert nm[i] == 0
+                continue
+            pk, pd = want[g - 1]
+            on, om12, _ = oracle.search_for_initialization(pk, pd, wk, wd, bounds, np.stack([pk['x'], pk['y']], 1), 100, 0.9, True)
+            assert nm[i] == on and (m12[i, :len(pk)] == om12).all()
+            assert on > 30
+    st.close()
