@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=60)
+    ap.add_argument('--warmup', type=int, default=6)
     ap.add_argument('--batch', type=int, default=32, help='frames per step and GPU')
     ap.add_argument('--cpu-frames', type=int, default=24, help='frames of the CPU-oracle baseline sample (0 = skip)')
     ap.add_argument('--no-match', action='store_true', help='extract only (configs[1])')
@@ -78,9 +78,9 @@ def main():
     def run(nsteps):
         """nsteps passes of the hot path: push a batch (async extraction on the GPU, then SearchForInitialization
         of every frame against its predecessor), pop its keypoints / descriptors / matches in host memory.
-        Up to depth+1 batches are in the pipeline; every push and pop of the nsteps batches is inside this call."""
+        Up to depth+2 batches are in the pipeline; every push and pop of the nsteps batches is inside this call."""
         pushed = 0
-        while pushed < min(args.depth + 1, nsteps):
+        while pushed < min(args.depth + 2, nsteps):
             st.push_ptrs(dev.ptrs, H, W, dev.stride, True)
             pushed += 1
         for _ in range(nsteps):

@@ -253,6 +253,10 @@ int orbfe_search_by_projection_uv(orbfe_matcher* m, const OrbfeKeyPoint* kps_un,
                                   int skip_any_occupied, int check_orientation, int32_t* kp_assigned,
                                   int* nmatches);
 
+/* Host wall-clock ms of the last search call: [0] grid sort + arena build, [1] upload + kernel + download,
+ * [2] sequential bookkeeping (resolve). */
+int orbfe_debug_matcher_ms(const orbfe_matcher* m, double out[3]);
+
 /* Frame::GetFeaturesInArea (src/Frame.cc:209-262) evaluated by the GPU candidate kernel, for the
  * parity tests: indices in reference order.  out[cap]. */
 int orbfe_debug_features_in_area(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, int n, const float bounds[4],

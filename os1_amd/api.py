@@ -78,6 +78,7 @@ def load_library():
                                              C.POINTER(ci)]
     L.orbfe_search_by_projection_uv.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, ci,
                                                 ci, ci, vp, C.POINTER(ci)]
+    L.orbfe_debug_matcher_ms.argtypes = [vp, vp]
     L.orbfe_debug_features_in_area.argtypes = [vp, vp, ci, vp, cf, cf, cf, ci, ci, vp, ci, C.POINTER(ci)]
     L.orbfe_debug_kernel_ms.argtypes = [vp, vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), ci]
     L.orbfe_debug_set_profiling.argtypes = [vp, ci]
@@ -333,6 +334,11 @@ class Matcher:
                                                     int(skip_any_occupied), int(check_ori), _p(assigned),
                                                     C.byref(n)))
         return n.value, assigned[:len(kps)]
+
+    def stage_ms(self):
+        out = np.zeros(3, np.float64)
+        _check(self.L.orbfe_debug_matcher_ms(self.h, _p(out)))
+        return out
 
     def get_features_in_area(self, kps, bounds, x, y, r, min_level, max_level):
         kps = np.ascontiguousarray(kps, KP_DTYPE)

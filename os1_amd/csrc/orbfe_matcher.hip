@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -92,11 +93,21 @@ __device__ __forceinline__ int hamming256(const uint32_t* __restrict__ a, const 
   return d;
 }
 
-// One wave per query.  Window semantics: Frame::GetFeaturesInArea, Frame.cc:209-262.
+// One wave per query, one LANE per grid column of the window.  Window semantics:
+// Frame::GetFeaturesInArea, Frame.cc:209-262: columns ix ascending, rows iy ascending inside a column,
+// insertion order inside a cell -- i.e. for column ix the contiguous run
+// [cellStart[ix*48+cy0], cellStart[ix*48+cy1+1]) of the cell-sorted keypoint table.  Lane l walks the
+// run of column cx0+l (a handful of entries), a wave prefix sum over the per-lane hit counts gives
+// every lane its output offset, so the candidate list comes out in exactly the reference order in a
+// single pass with all columns in flight at once.
 __global__ __launch_bounds__(64) void k_window_match(MatchParams M) {
   const int q = blockIdx.x;
   const int lane = threadIdx.x;
   const float r = M.qr[q];
+  if (!(r >= 0.f)) {  // inactive query
+    if (lane == 0) { M.qcount[q] = 0; M.qoff[q] = 0; }
+    return;
+  }
   const PairInfo pi = M.pairs[M.qpair[q]];
   const float* sx = M.sx + pi.trainOff;
   const float* sy = M.sy + pi.trainOff;
@@ -104,18 +115,20 @@ __global__ __launch_bounds__(64) void k_window_match(MatchParams M) {
   const int* sidx = M.sidx + pi.trainOff;
   const int* cellStart = M.cellStart + pi.cellOff;
   const uint8_t* tdesc = M.tdesc + (size_t)pi.tdescOff * 32;
-  uint32_t count = 0;
-  int cx0 = 0, cx1 = -1, cy0 = 0, cy1 = -1;
   const float x = M.qx[q], y = M.qy[q];
-  if (r >= 0.f) {
-    cx0 = max(0, (int)floorf((x - pi.minX - r) * pi.invW));
-    cx1 = min(kGridCols - 1, (int)ceilf((x - pi.minX + r) * pi.invW));
-    cy0 = max(0, (int)floorf((y - pi.minY - r) * pi.invH));
-    cy1 = min(kGridRows - 1, (int)ceilf((y - pi.minY + r) * pi.invH));
-    if (cx0 >= kGridCols || cx1 < 0 || cy0 >= kGridRows || cy1 < 0) cx1 = cx0 - 1;  // empty
-  }
+  int cx0 = max(0, (int)floorf((x - pi.minX - r) * pi.invW));
+  int cx1 = min(kGridCols - 1, (int)ceilf((x - pi.minX + r) * pi.invW));
+  const int cy0 = max(0, (int)floorf((y - pi.minY - r) * pi.invH));
+  const int cy1 = min(kGridRows - 1, (int)ceilf((y - pi.minY + r) * pi.invH));
+  if (cx0 >= kGridCols || cx1 < 0 || cy0 >= kGridRows || cy1 < 0) cx1 = cx0 - 1;  // empty window
   const int minL = M.qminL[q], maxL = M.qmaxL[q];
   const bool checkLevels = (minL > 0) || (maxL >= 0);
+  const int ix = cx0 + lane;  // at most 64 columns exist, so one lane per column always suffices
+  int b = 0, e1 = 0;
+  if (ix <= cx1) {
+    b = cellStart[ix * kGridRows + cy0];
+    e1 = cellStart[ix * kGridRows + cy1 + 1];
+  }
   auto inWindow = [&](int e) -> bool {
     if (checkLevels) {
       const int o = soct[e];
@@ -125,14 +138,16 @@ __global__ __launch_bounds__(64) void k_window_match(MatchParams M) {
     const float dx = sx[e] - x, dy = sy[e] - y;
     return fabsf(dx) < r && fabsf(dy) < r;
   };
-  for (int ix = cx0; ix <= cx1; ix++) {
-    const int b = cellStart[ix * kGridRows + cy0], e1 = cellStart[ix * kGridRows + cy1 + 1];
-    for (int e0 = b; e0 < e1; e0 += 64) {
-      const int e = e0 + lane;
-      const bool ok = e < e1 && inWindow(e);
-      count += __popcll(__ballot(ok));
-    }
+  // pass 1: hits per column
+  int hits = 0;
+  for (int e = b; e < e1; e++) hits += inWindow(e) ? 1 : 0;
+  int incl = hits;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
   }
+  const uint32_t count = (uint32_t)__shfl(incl, 63, 64);
   uint32_t off = 0;
   if (lane == 0) {
     if (count) off = atomicAdd(M.total, count);
@@ -141,25 +156,19 @@ __global__ __launch_bounds__(64) void k_window_match(MatchParams M) {
   }
   if (count == 0) return;
   off = __shfl(off, 0, 64);
+  if (hits == 0) return;
   uint32_t qd[8];
   const uint32_t* qp = reinterpret_cast<const uint32_t*>(M.qdesc + (size_t)q * 32);
 #pragma unroll
   for (int i = 0; i < 8; i++) qd[i] = qp[i];
-  uint32_t run = 0;
-  for (int ix = cx0; ix <= cx1; ix++) {
-    const int b = cellStart[ix * kGridRows + cy0], e1 = cellStart[ix * kGridRows + cy1 + 1];
-    for (int e0 = b; e0 < e1; e0 += 64) {
-      const int e = e0 + lane;
-      const bool ok = e < e1 && inWindow(e);
-      const unsigned long long m = __ballot(ok);
-      if (ok) {
-        const int idx = sidx[e];
-        const int d = hamming256(reinterpret_cast<const uint32_t*>(tdesc + (size_t)idx * 32), qd);
-        const uint32_t pos = off + run + __popcll(m & ((1ull << lane) - 1ull));
-        if (pos < M.poolCap) M.pool[pos] = (uint32_t)idx | ((uint32_t)d << 16);
-      }
-      run += __popcll(m);
-    }
+  // pass 2: distances, written at the lane's offset in column order
+  uint32_t pos = off + (uint32_t)(incl - hits);
+  for (int e = b; e < e1; e++) {
+    if (!inWindow(e)) continue;
+    const int idx = sidx[e];
+    const int d = hamming256(reinterpret_cast<const uint32_t*>(tdesc + (size_t)idx * 32), qd);
+    if (pos < M.poolCap) M.pool[pos] = (uint32_t)idx | ((uint32_t)d << 16);
+    pos++;
   }
 }
 
@@ -242,8 +251,14 @@ struct orbfe_matcher {
   const uint32_t* qcount = nullptr;
   const uint32_t* qoff = nullptr;
 
+  double stageMs[4] = {0, 0, 0, 0};  // arena build, upload+kernel+download, (resolve: filled by callers), total
+  static double nowMs() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  }
+
   // Runs the window kernel for all jobs in ONE upload + ONE launch.
   int candidates(const Job* jobs, int njobs) {
+    const double tA = nowMs();
     HIP_TRY(hipSetDevice(device));
     int rc;
     const int ncell = kGridCols * kGridRows;
@@ -308,6 +323,8 @@ struct orbfe_matcher {
         memcpy(H + oQd + 32 * q0, J.qdesc, 32 * (size_t)J.nq);
       }
     });
+    const double tB = nowMs();
+    stageMs[0] = tB - tA;
     HIP_TRY(hipMemcpyAsync(d_in.p, H, total, hipMemcpyHostToDevice, stream));
 
     const size_t outWords = 64 + 2 * nq;
@@ -343,6 +360,7 @@ struct orbfe_matcher {
           HIP_TRY(hipStreamSynchronize(stream));
         }
         lastTotal = tot;
+        stageMs[1] = nowMs() - tB;
         qcount = h_out.p + 64;
         qoff = h_out.p + 64 + nq;
         return ORBFE_OK;
@@ -451,6 +469,12 @@ int orbfe_matcher_create(int device_id, orbfe_matcher** out) {
 
 void orbfe_matcher_destroy(orbfe_matcher* m) { delete m; }
 
+int orbfe_debug_matcher_ms(const orbfe_matcher* m, double out[3]) {
+  if (!m || !out) { set_err("NULL argument"); return ORBFE_ERR_INVALID; }
+  for (int i = 0; i < 3; i++) out[i] = m->stageMs[i];
+  return ORBFE_OK;
+}
+
 int orbfe_debug_features_in_area(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, int n, const float bounds[4], float x,
                                  float y, float r, int min_level, int max_level, int32_t* out, int cap, int* n_out) {
   if (!m || !kps_un || !bounds || !n_out || n < 0) { set_err("bad argument"); return ORBFE_ERR_INVALID; }
@@ -506,10 +530,12 @@ int orbfe_search_for_initialization_batch(orbfe_matcher* m, int npairs, const Or
   }
   int rc = m->candidates(jobs.data(), npairs);
   if (rc) return rc;
+  const double tR = orbfe_matcher::nowMs();
   m->pool->parallelFor(npairs, [&](int p, int) {
     nmatches[p] = resolveSearchForInitialization(m, m->jobQ0[p], kps1[p], n1[p], kps2[p], n2[p], prev_xy[p],
                                                  matches12[p], nnratio, check_orientation);
   });
+  m->stageMs[2] = orbfe_matcher::nowMs() - tR;
   return ORBFE_OK;
 }
 

@@ -20,6 +20,7 @@ for _ in range(3): r = mt.search_for_initialization_batch(pairs, bounds)
 t = time.time(); R = 20
 for _ in range(R): r = mt.search_for_initialization_batch(pairs, bounds)
 dt = (time.time() - t) / R
+print('stages ms (arena, gpu, resolve):', mt.stage_ms())
 print('batch of %d pairs: %.3f ms  (%.1f us/pair)  matches %s' % (B, dt * 1e3, dt / B * 1e6, [x[0] for x in r][:6]))
 t = time.time()
 for _ in range(R):
