@@ -3,7 +3,7 @@
  * Drop-in boundary for the per-frame hot path of AlejandroSilvestri/os1 (ORB-SLAM2 fork):
  * ORBextractor::operator() and the windowed Hamming searches of ORBmatcher.  Each entry point
  * names the reference interface it replaces (paths relative to the reference root).  The C++
- * facade in include/orbfe/ORBextractor.h / ORBmatcher.h reproduces the ORB_SLAM2:: signatures
+ * host side in include/orbfe/ORBextractor.h and include/orbfe/orb_shim.hpp reproduces the ORB_SLAM2:: interfaces
  * on top of this ABI; INTEGRATION.md shows the binding a reference maintainer would add.
  *
  * Conventions
