@@ -19,6 +19,10 @@
 
 namespace orbfe {
 
+// Index arithmetic of these kernels stays far below 2^23, so every product is a full-rate 24-bit
+// multiply (v_mul_i32_i24 / v_mad_i32_i24) instead of the quarter-rate v_mul_lo_u32 / 64-bit mads.
+__device__ __forceinline__ int m24(int a, int b) { return __mul24(a, b); }
+
 // ------------------------------------------------------------------------------------------------
 // Pyramid: level l <- bilinear(level l-1).  Reference: ComputePyramid, src/ORBextractor.cc:971-996
 // (cv::resize call at :984); fixed-point semantics: SURVEY.md Appendix B.2.
@@ -51,6 +55,7 @@ __global__ __launch_bounds__(256) void k_resize(PyramidParams P, int level) {
   const int ry0 = min(max(D.yofs[ty0], 0), S.h - 1), ry1 = min(max(D.yofs[ty1] + 1, 0), S.h - 1);
   const int rw = rx1 - rx0 + 1, rh = ry1 - ry0 + 1;
   const int LP = D.rzPitch;
+  const int istr = (int)sstride;
   const uint8_t* rbase = src + (long long)ry0 * sstride + rx0;
   const int a = (int)(reinterpret_cast<uintptr_t>(rbase) & 3);
   const int tid = threadIdx.x;
@@ -66,16 +71,16 @@ __global__ __launch_bounds__(256) void k_resize(PyramidParams P, int level) {
         const int i = i0 + u * 256;
         v[u] = 0;
         if (i < total) {
-          const int y = (int)(((float)i + 0.5f) * rcp), c = i - y * ndw;
-          v[u] = *reinterpret_cast<const uint32_t*>(base + (long long)y * sstride + 4 * c);
+          const int y = (int)(((float)i + 0.5f) * rcp), c = i - m24(y, ndw);
+          v[u] = *reinterpret_cast<const uint32_t*>(base + m24(y, istr) + 4 * c);
         }
       }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int i = i0 + u * 256;
         if (i < total) {
-          const int y = (int)(((float)i + 0.5f) * rcp), c = i - y * ndw;
-          *reinterpret_cast<uint32_t*>(rz + y * LP + 4 * c) = v[u];
+          const int y = (int)(((float)i + 0.5f) * rcp), c = i - m24(y, ndw);
+          *reinterpret_cast<uint32_t*>(rz + m24(y, LP) + 4 * c) = v[u];
         }
       }
     }
@@ -83,8 +88,8 @@ __global__ __launch_bounds__(256) void k_resize(PyramidParams P, int level) {
     const float rcp = 1.0f / (float)rw;
     const int total = rw * rh;
     for (int i = tid; i < total; i += 256) {
-      const int y = (int)(((float)i + 0.5f) * rcp), x = i - y * rw;
-      rz[y * LP + a + x] = rbase[(long long)y * sstride + x];
+      const int y = (int)(((float)i + 0.5f) * rcp), x = i - m24(y, rw);
+      rz[m24(y, LP) + a + x] = rbase[m24(y, istr) + x];
     }
   }
   __syncthreads();
@@ -109,17 +114,17 @@ __global__ __launch_bounds__(256) void k_resize(PyramidParams P, int level) {
     const int sy = D.yofs[y];
     const int sy0 = min(max(sy, 0), S.h - 1) - ry0, sy1 = min(max(sy + 1, 0), S.h - 1) - ry0;
     const int b0 = D.ybeta[2 * y], b1 = D.ybeta[2 * y + 1];
-    const uint8_t* r0 = tile + sy0 * LP;
-    const uint8_t* r1 = tile + sy1 * LP;
+    const uint8_t* r0 = tile + m24(sy0, LP);
+    const uint8_t* r1 = tile + m24(sy1, LP);
     uint32_t packed = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const int h0 = r0[sx[i]] * a0[i] + r0[sx1[i]] * a1[i];
-      const int h1 = r1[sx[i]] * a0[i] + r1[sx1[i]] * a1[i];
-      const int v = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+      const int h0 = m24(r0[sx[i]], a0[i]) + m24(r0[sx1[i]], a1[i]);
+      const int h1 = m24(r1[sx[i]], a0[i]) + m24(r1[sx1[i]], a1[i]);
+      const int v = (((m24(b0, h0 >> 4)) >> 16) + ((m24(b1, h1 >> 4)) >> 16) + 2) >> 2;
       packed |= (uint32_t)(v & 255) << (8 * i);
     }
-    *reinterpret_cast<uint32_t*>(dst + (long long)y * D.pitch + cx) = packed;  // pitch % 64 == 0: in bounds
+    *reinterpret_cast<uint32_t*>(dst + m24(y, D.pitch) + cx) = packed;  // pitch % 64 == 0: in bounds
   }
 }
 
@@ -212,6 +217,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
   uint8_t* kept = lds;  // stage 4 only: aliases the ROI tile, which is dead after stage 3 (TP*(hCell+6) >= wCell*hCell)
 
   const int rw = ew + 6, rh = eh + 6;
+  const int istr = (int)stride;
   const uint8_t* roi = img + (long long)(ey0 - 3) * stride + (ex0 - 3);
   // ROI -> LDS.  Loads are issued in batches of 8 per lane before the first LDS write so the wave
   // waits for memory once per batch, not once per element.  Rows are fetched as aligned dwords when
@@ -229,16 +235,16 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
         const int i = i0 + u * 64;
         v[u] = 0;
         if (i < total) {
-          const int y = (int)(((float)i + 0.5f) * rcpNdw), c = i - y * ndw;
-          v[u] = *reinterpret_cast<const uint32_t*>(base + (long long)y * stride + 4 * c);
+          const int y = (int)(((float)i + 0.5f) * rcpNdw), c = i - m24(y, ndw);
+          v[u] = *reinterpret_cast<const uint32_t*>(base + m24(y, istr) + 4 * c);
         }
       }
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const int i = i0 + u * 64;
         if (i < total) {
-          const int y = (int)(((float)i + 0.5f) * rcpNdw), c = i - y * ndw;
-          *reinterpret_cast<uint32_t*>(tile + y * TP + 4 * c) = v[u];
+          const int y = (int)(((float)i + 0.5f) * rcpNdw), c = i - m24(y, ndw);
+          *reinterpret_cast<uint32_t*>(tile + m24(y, TP) + 4 * c) = v[u];
         }
       }
     }
@@ -252,16 +258,16 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
         const int i = i0 + u * 64;
         v[u] = 0;
         if (i < total) {
-          const int y = (int)(((float)i + 0.5f) * rcpRw), x = i - y * rw;
-          v[u] = roi[(long long)y * stride + x];
+          const int y = (int)(((float)i + 0.5f) * rcpRw), x = i - m24(y, rw);
+          v[u] = roi[m24(y, istr) + x];
         }
       }
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const int i = i0 + u * 64;
         if (i < total) {
-          const int y = (int)(((float)i + 0.5f) * rcpRw), x = i - y * rw;
-          tile[y * TP + a + x] = v[u];
+          const int y = (int)(((float)i + 0.5f) * rcpRw), x = i - m24(y, rw);
+          tile[m24(y, TP) + a + x] = v[u];
         }
       }
     }
@@ -291,12 +297,12 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
       int y = 0, x = 0;
       if (i < nItems) {
         y = (int)(((float)i + 0.5f) * rcpG);
-        x = (i - y * G) << 2;
+        x = (i - m24(y, G)) << 2;
         // aligned dword pointer of (row y+3, tile column x): tile already includes the +A shift
-        const uint32_t* cw = reinterpret_cast<const uint32_t*>(tile - A + (y + 3) * TP + x);
+        const uint32_t* cw = reinterpret_cast<const uint32_t*>(tile - A + m24(y + 3, TP) + x);
         const uint32_t w0 = cw[0], w1 = cw[1], w2 = cw[2], w3 = cw[3];
-        const uint32_t* uw = reinterpret_cast<const uint32_t*>(tile - A + y * TP + x);         // row y-3 (+3 halo)
-        const uint32_t* dw = reinterpret_cast<const uint32_t*>(tile - A + (y + 6) * TP + x);   // row y+3
+        const uint32_t* uw = reinterpret_cast<const uint32_t*>(tile - A + m24(y, TP) + x);         // row y-3 (+3 halo)
+        const uint32_t* dw = reinterpret_cast<const uint32_t*>(tile - A + m24(y + 6, TP) + x);   // row y+3
         // byte windows: left = bytes [A, A+4), centre/up/down = [A+3, A+7), right = [A+6, A+10) of the row
         const uint32_t L4 = __builtin_amdgcn_alignbyte(w1, w0, A);
         const uint32_t C4 = (A + 3 < 4) ? __builtin_amdgcn_alignbyte(w1, w0, (A + 3) & 3)
@@ -350,7 +356,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
     if (i < nq) {
       e = queue[i];
       const int y = e >> 8, x = e & 0xff;
-      const uint8_t* c = tile + (y + 3) * TP + (x + 3);
+      const uint8_t* c = tile + m24(y + 3, TP) + (x + 3);
       int d[16];
       ring_diffs(c, TP, c[0], d);
       // one funnel shift per ring pixel and polarity: the sign of (tlo - d) / (d + tlo) is shifted into the
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
   for (int i = lane; i < nq2; i += 64) {
     const unsigned e = queue[i];
     const int y = (e >> 8) & 0x7f, x = e & 0x7f;
-    const uint8_t* c = tile + (y + 3) * TP + (x + 3);
+    const uint8_t* c = tile + m24(y + 3, TP) + (x + 3);
     int d[16];
     ring_diffs(c, TP, c[0], d);
     int S = 0;
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
       for (int k = 0; k < 16; k++) d[k] = -d[k];
       S = max(S, max_arc_min9(d));
     }
-    sc[(y + 1) * SP + (x + 1)] = (uint8_t)(S - 1);  // tlo <= S-1 <= 254
+    sc[m24(y + 1, SP) + (x + 1)] = (uint8_t)(S - 1);  // tlo <= S-1 <= 254
   }
   __syncthreads();
   // ---- stage 4: NMS inside the emit region, threshold decision, ordered emission ----------------
@@ -396,7 +402,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
     if (i < nq2) {
       const unsigned e = queue[i];
       const int y = (e >> 8) & 0x7f, x = e & 0x7f;
-      const uint8_t* q = sc + (y + 1) * SP + (x + 1);
+      const uint8_t* q = sc + m24(y + 1, SP) + (x + 1);
       const int s = q[0];
       if (s > 0 && s > q[-1] && s > q[1] && s > q[-SP - 1] && s > q[-SP] && s > q[-SP + 1] && s > q[SP - 1] &&
           s > q[SP] && s > q[SP + 1])
@@ -574,7 +580,7 @@ __global__ __launch_bounds__(64) void k_describe(PyramidParams P, const SelKp* _
       if (i < kRawW * kRawW) {
         const int y = i / kRawW, x = i - y * kRawW;
         const int gx = reflect101(cx - kRawRad + x, L.w), gy = reflect101(cy - kRawRad + y, L.h);
-        v[u] = img[(long long)gy * stride + gx];
+        v[u] = img[m24(gy, (int)stride) + gx];
       }
     }
 #pragma unroll
