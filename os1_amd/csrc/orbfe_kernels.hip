@@ -529,7 +529,30 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 
 constexpr int kRawW = 2 * kRawRad + 1;   // 43
 constexpr int kBlurW = 2 * kBlurRad + 1; // 37
-constexpr int kRawP = 44, kHP = 38, kBP = 40;
+constexpr int kRawP = 48, kHP = 38, kBP = 40;   // raw pitch holds alignment offset (<=3) + 43 bytes
+
+// (u, v) offsets of the circular IC-angle patch, rows v = -15..15, |u| <= umax[|v|] (749 entries;
+// umax from ORBextractor.cc:486-501 equals floor(sqrt(240 - v*v)), checked by static_assert below)
+constexpr int kIcCount = 749;
+struct IcTab { uint16_t e[kIcCount + 3]; };
+constexpr IcTab make_ic_tab() {
+  IcTab t{};
+  const int um[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+  int n = 0;
+  for (int v = -15; v <= 15; v++) {
+    const int d = um[v < 0 ? -v : v];
+    for (int u = -d; u <= d; u++) t.e[n++] = (uint16_t)(((unsigned)(uint8_t)(int8_t)u) | (((unsigned)(uint8_t)(int8_t)v) << 8));
+  }
+  return t;
+}
+constexpr int ic_count() {
+  const int um[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+  int n = 2 * um[0] + 1;
+  for (int v = 1; v <= 15; v++) n += 2 * (2 * um[v] + 1);
+  return n;
+}
+static_assert(ic_count() == kIcCount, "circular patch must have 749 pixels");
+__constant__ IcTab c_icTab = make_ic_tab();
 
 // Slot mode (GPU quadtree): `sel` is laid out [frame][selPerFrame] with per-level sub-regions; slot k is
 // live iff its index inside its level region is below selCount[frame][level].  Dense mode (host
@@ -570,39 +593,70 @@ __global__ __launch_bounds__(64) void k_describe(PyramidParams P, const SelKp* _
     img = P.slab + (long long)f * P.slabBytes + L.off;
     stride = L.pitch;
   }
-  // 43x43 raw patch -> LDS, loads batched 8 deep per lane (one memory wait per batch)
-  for (int i0 = lane; i0 < kRawW * kRawW; i0 += 64 * 8) {
-    uint8_t v[8];
+  // 43x43 raw patch -> LDS.  Interior keypoints (all but those within 21 px of the level border): aligned
+  // dword loads, 9 in flight per lane, the patch keeps the byte alignment `pa` of its first pixel.
+  // Border keypoints: byte loads with the level's own reflect-101 indexing (GaussianBlur's border).
+  int pa = 0;
+  const int istr = (int)stride;
+  if (cx >= kRawRad && cy >= kRawRad && cx + kRawRad < L.w && cy + kRawRad < L.h && (stride & 3) == 0) {
+    const uint8_t* rbase = img + m24(cy - kRawRad, istr) + (cx - kRawRad);
+    pa = (int)(reinterpret_cast<uintptr_t>(rbase) & 3);
+    const int ndw = (pa + kRawW + 3) >> 2;  // 11 or 12
+    const float rcp = 1.0f / (float)ndw;
+    const int total = ndw * kRawW;            // <= 516
+    const uint8_t* base = rbase - pa;
+    uint32_t v[9];
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int i = i0 + u * 64;
+    for (int u = 0; u < 9; u++) {
+      const int i = lane + u * 64;
       v[u] = 0;
-      if (i < kRawW * kRawW) {
-        const int y = i / kRawW, x = i - y * kRawW;
-        const int gx = reflect101(cx - kRawRad + x, L.w), gy = reflect101(cy - kRawRad + y, L.h);
-        v[u] = img[m24(gy, (int)stride) + gx];
+      if (i < total) {
+        const int y = (int)(((float)i + 0.5f) * rcp), c = i - m24(y, ndw);
+        v[u] = *reinterpret_cast<const uint32_t*>(base + m24(y, istr) + 4 * c);
       }
     }
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int i = i0 + u * 64;
-      if (i < kRawW * kRawW) {
-        const int y = i / kRawW, x = i - y * kRawW;
-        raw[y * kRawP + x] = v[u];
+    for (int u = 0; u < 9; u++) {
+      const int i = lane + u * 64;
+      if (i < total) {
+        const int y = (int)(((float)i + 0.5f) * rcp), c = i - m24(y, ndw);
+        *reinterpret_cast<uint32_t*>(raw + m24(y, kRawP) + 4 * c) = v[u];
+      }
+    }
+  } else {
+    for (int i0 = lane; i0 < kRawW * kRawW; i0 += 64 * 8) {
+      uint8_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = i0 + u * 64;
+        v[u] = 0;
+        if (i < kRawW * kRawW) {
+          const int y = i / kRawW, x = i - y * kRawW;
+          const int gx = reflect101(cx - kRawRad + x, L.w), gy = reflect101(cy - kRawRad + y, L.h);
+          v[u] = img[m24(gy, istr) + gx];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = i0 + u * 64;
+        if (i < kRawW * kRawW) {
+          const int y = i / kRawW, x = i - y * kRawW;
+          raw[y * kRawP + x] = v[u];
+        }
       }
     }
   }
   __syncthreads();
+  const uint8_t* rawp = raw + pa;  // raw pixel (x, y) of the 43x43 patch lives at rawp[y * kRawP + x]
 
-  // IC-angle moments over the circular patch of radius 15 (749 pixels)
+  // IC-angle moments over the circular patch of radius 15: the 749 (u, v) offsets come from a table
   int m10 = 0, m01 = 0;
-  for (int i = lane; i < 31 * 31; i += 64) {
-    const int v = i / 31 - kHalfPatch, u = i - (v + kHalfPatch) * 31 - kHalfPatch;
-    if (abs(u) <= c_umax[abs(v)]) {
-      const int I = raw[(kRawRad + v) * kRawP + kRawRad + u];
-      m10 += u * I;
-      m01 += v * I;
-    }
+  for (int i = lane; i < kIcCount; i += 64) {
+    const int uv = c_icTab.e[i];
+    const int u = (int)(int8_t)(uv & 0xff), v = (int)(int8_t)(uv >> 8);
+    const int I = rawp[m24(kRawRad + v, kRawP) + kRawRad + u];
+    m10 += m24(u, I);
+    m01 += m24(v, I);
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -614,7 +668,7 @@ __global__ __launch_bounds__(64) void k_describe(PyramidParams P, const SelKp* _
   // horizontal 7-tap on the 43 rows x 37 columns that feed the 37x37 output
   for (int i = lane; i < kRawW * kBlurW; i += 64) {
     const int y = i / kBlurW, x = i - y * kBlurW;
-    const uint8_t* r = raw + y * kRawP + x;
+    const uint8_t* r = rawp + y * kRawP + x;
     hb[y * kHP + x] = (uint16_t)(18 * (r[0] + r[6]) + 34 * (r[1] + r[5]) + 48 * (r[2] + r[4]) + 56 * r[3]);
   }
   __syncthreads();
