@@ -122,6 +122,9 @@ struct orbfe_extractor {
   DevBuf<QtTmp> d_qtmp;
   DevBuf<int> d_proc;
   hipEvent_t evQt[2] = {};
+  hipStream_t qtStream = nullptr;       // high-priority stream for the latency-bound quadtree kernel
+  hipEvent_t evQtIn = nullptr, evQtOut = nullptr;
+  bool qtOwnStream = false;  // measured slower on MI355X (cross-stream event waits cost more than the overlap gains); ORBFE_QT_STREAM=1 enables
   std::vector<int> frameKpBase, frameKpCount;
 
   int rows = 0, cols = 0, batchCap = 0;
@@ -170,6 +173,9 @@ struct orbfe_extractor {
     for (auto& es : ev) for (auto& e : es) if (e) (void)hipEventDestroy(e);
     for (auto& e : evS1) if (e) (void)hipEventDestroy(e);
     for (auto& e : evQt) if (e) (void)hipEventDestroy(e);
+    if (evQtIn) (void)hipEventDestroy(evQtIn);
+    if (evQtOut) (void)hipEventDestroy(evQtOut);
+    if (qtStream) (void)hipStreamDestroy(qtStream);
     d_idxA.release(); d_idxB.release(); d_rank.release(); d_ownA.release(); d_ownB.release();
     d_quad.release(); d_nodesA.release(); d_nodesB.release(); d_qtmp.release(); d_proc.release();
     if (evFrame0) (void)hipEventDestroy(evFrame0);
@@ -386,9 +392,21 @@ struct orbfe_extractor {
     for (int l = 0; l < nlevels; l++) {
       QP.levW[l] = P.lv[l].w; QP.levH[l] = P.lv[l].h; QP.nfeat[l] = nfeat[l]; QP.selOff[l] = selOff[l];
     }
-    if (prof) HIP_TRY(hipEventRecord(evQt[0], st));
-    launch_quadtree(QP, nframes, st);
-    if (prof) HIP_TRY(hipEventRecord(evQt[1], st));
+    // k_quadtree is latency-bound (dependent scans, one block per (frame, level)) and leaves most issue
+    // slots idle, so it runs on its own high-priority stream: with two batches in flight it overlaps the
+    // other batch's VALU-bound kernels instead of queueing behind them.
+    hipStream_t qs = qtOwnStream ? qtStream : st;
+    if (qtOwnStream) {
+      HIP_TRY(hipEventRecord(evQtIn, st));
+      HIP_TRY(hipStreamWaitEvent(qs, evQtIn, 0));
+    }
+    if (prof) HIP_TRY(hipEventRecord(evQt[0], qs));
+    launch_quadtree(QP, nframes, qs);
+    if (prof) HIP_TRY(hipEventRecord(evQt[1], qs));
+    if (qtOwnStream) {
+      HIP_TRY(hipEventRecord(evQtOut, qs));
+      HIP_TRY(hipStreamWaitEvent(st, evQtOut, 0));
+    }
     const int nslots = nframes * selPerFrame;
     if (prof) HIP_TRY(hipEventRecord(ev[0][4], st));
     launch_describe_slots(P, d_sel.p, nslots, d_angle.p, d_desc.p, d_selCount.p, selPerFrame, selOff, st);
@@ -752,6 +770,15 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
   if (const char* sv = getenv("ORBFE_SUB_BATCHES")) h->subBatches = atoi(sv);
   for (auto& e : h->evQt) evOk = evOk && hipEventCreate(&e) == hipSuccess;
   if (!evOk) { set_err("hipEventCreate failed"); delete h; return ORBFE_ERR_HIP; }
+  {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (const char* qv = getenv("ORBFE_QT_STREAM")) h->qtOwnStream = atoi(qv) != 0;
+    evOk = hipStreamCreateWithPriority(&h->qtStream, hipStreamNonBlocking, greatest) == hipSuccess &&
+           hipEventCreateWithFlags(&h->evQtIn, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&h->evQtOut, hipEventDisableTiming) == hipSuccess;
+    if (!evOk) { set_err("creating the quadtree stream failed"); delete h; return ORBFE_ERR_HIP; }
+  }
   if (const char* hv = getenv("ORBFE_HOST_QUADTREE")) h->gpuQuadtree = atoi(hv) == 0;
   if (const char* pv = getenv("ORBFE_PROFILE_KERNELS")) h->profileKernels = atoi(pv) != 0;
   h->selPerFrame = 0;
