@@ -140,6 +140,12 @@ __global__ __launch_bounds__(256) void k_resize(PyramidParams P, int level) {
 // One wave per cell: ROI -> LDS, score tile -> LDS, NMS, then the iniTh/minTh decision by
 // wave-wide ballot and an ordered (row-major) write of the survivors into the cell's slots.
 // ------------------------------------------------------------------------------------------------
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 as_u16x2(unsigned v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ unsigned as_u32(u16x2 v) { return __builtin_bit_cast(unsigned, v); }
+__device__ __forceinline__ s16x2 as_s16x2(unsigned v) { return __builtin_bit_cast(s16x2, v); }
+
 __device__ __forceinline__ bool has_arc9(unsigned m) {  // 9 contiguous set bits in a circular 16-bit mask
   m |= m << 16;
   m &= m >> 1;
@@ -228,10 +234,11 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
     const float rcpNdw = 1.0f / (float)ndw;
     const int total = ndw * rh;
     const uint8_t* base = roi - a;
-    for (int i0 = lane; i0 < total; i0 += 64 * 8) {
-      uint32_t v[8];
+    // 9 dwords per lane cover the usual 43-row x 12-dword ROI (516 dwords) in a single batch
+    for (int i0 = lane; i0 < total; i0 += 64 * 9) {
+      uint32_t v[9];
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
+      for (int u = 0; u < 9; u++) {
         const int i = i0 + u * 64;
         v[u] = 0;
         if (i < total) {
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
         }
       }
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
+      for (int u = 0; u < 9; u++) {
         const int i = i0 + u * 64;
         if (i < total) {
           const int y = (int)(((float)i + 0.5f) * rcpNdw), c = i - m24(y, ndw);
@@ -313,18 +320,26 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
                                         : __builtin_amdgcn_alignbyte(uw[2], uw[1], (A + 3) & 3);
         const uint32_t D4 = (A + 3 < 4) ? __builtin_amdgcn_alignbyte(dw[1], dw[0], (A + 3) & 3)
                                         : __builtin_amdgcn_alignbyte(dw[2], dw[1], (A + 3) & 3);
+        // two pixels per instruction: bytes (0,1) and (2,3) of every window become two 16-bit lanes
+        // (v_perm_b32), the compass arithmetic runs on v_pk_add/sub_u16 and plain bitwise ops; the sign
+        // bits of the two lanes (bits 15 and 31) say "two adjacent compass points of one polarity"
+        const unsigned T2 = (unsigned)tlo * 0x10001u;
+        unsigned hit = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          const int v = (C4 >> (8 * j)) & 255;
-          const int r0 = (D4 >> (8 * j)) & 255, r4 = (R4 >> (8 * j)) & 255, r8 = (U4 >> (8 * j)) & 255,
-                    r12 = (L4 >> (8 * j)) & 255;
-          // sign bit of k* set <=> ring darker than centre by more than tlo; of b* <=> brighter
-          const int kd = tlo - v, kb = v + tlo;
-          const int k0 = r0 + kd, k4 = r4 + kd, k8 = r8 + kd, k12 = r12 + kd;
-          const int b0 = kb - r0, b4 = kb - r4, b8 = kb - r8, b12 = kb - r12;
-          const int e = (k0 & k4) | (k4 & k8) | (k8 & k12) | (k12 & k0) | (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0);
-          if (e < 0 && x + j < ew) passBits |= 1u << j;
+        for (int h = 0; h < 2; h++) {
+          const unsigned sel = h ? 0x0c030c02u : 0x0c010c00u;
+          const u16x2 v2 = as_u16x2(__builtin_amdgcn_perm(0u, C4, sel));
+          const u16x2 r0 = as_u16x2(__builtin_amdgcn_perm(0u, D4, sel)), r4 = as_u16x2(__builtin_amdgcn_perm(0u, R4, sel)),
+                      r8 = as_u16x2(__builtin_amdgcn_perm(0u, U4, sel)), r12 = as_u16x2(__builtin_amdgcn_perm(0u, L4, sel));
+          // sign of k* set <=> ring darker than centre by more than tlo; of b* <=> brighter
+          const u16x2 kd = as_u16x2(T2) - v2, kb = v2 + as_u16x2(T2);
+          const unsigned k0 = as_u32(r0 + kd), k4 = as_u32(r4 + kd), k8 = as_u32(r8 + kd), k12 = as_u32(r12 + kd);
+          const unsigned b0 = as_u32(kb - r0), b4 = as_u32(kb - r4), b8 = as_u32(kb - r8), b12 = as_u32(kb - r12);
+          const unsigned e = (k0 & k4) | (k4 & k8) | (k8 & k12) | (k12 & k0) | (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0);
+          hit |= (((e >> 15) & 1u) | ((e >> 30) & 2u)) << (2 * h);
         }
+        const int nvalid = min(4, ew - x);                    // pixels x+j < ew
+        passBits = hit & ((1u << nvalid) - 1u);
       }
       int off = 0, tot = 0;
 #pragma unroll
@@ -347,7 +362,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
     default: stage1(std::integral_constant<int, 3>{}); break;
   }
   __syncthreads();
-  // ---- stage 2: full arc test, compacted in place; bit 15 / 7 carry the polarity ----------------
+  // ---- stage 2: score of every stage-1 survivor; survivors of the arc test stay in the queue ---------
+  // S = max(max_arc min(v - ring), max_arc min(ring - v)) decides both "is a corner at tlo" (S > tlo) and the
+  // OpenCV score (S - 1).  Both polarities are evaluated at once: each register holds (v - r, r - v) as two
+  // signed 16-bit lanes and the sliding min-of-9 / max-over-arcs runs on v_pk_min_i16 / v_pk_max_i16.
   int nq2 = 0;
   for (int i0 = 0; i0 < nq; i0 += 64) {
     const int i = i0 + lane;
@@ -357,41 +375,33 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
       e = queue[i];
       const int y = e >> 8, x = e & 0xff;
       const uint8_t* c = tile + m24(y + 3, TP) + (x + 3);
-      int d[16];
-      ring_diffs(c, TP, c[0], d);
-      // one funnel shift per ring pixel and polarity: the sign of (tlo - d) / (d + tlo) is shifted into the
-      // mask (bit order is reversed, which does not matter for a circular run test)
-      unsigned mdark = 0, mbright = 0;
+      const unsigned vv = (unsigned)c[0] * 0x10001u;
+      s16x2 d[16];
+      const s16x2 flip = {1, -1};
+#define RING(k, off) d[k] = (as_s16x2(vv) - as_s16x2((unsigned)c[off] * 0x10001u)) * flip
+      RING(0, 3 * TP);       RING(1, 3 * TP + 1);   RING(2, 2 * TP + 2);    RING(3, TP + 3);
+      RING(4, 3);            RING(5, -TP + 3);      RING(6, -2 * TP + 2);   RING(7, -3 * TP + 1);
+      RING(8, -3 * TP);      RING(9, -3 * TP - 1);  RING(10, -2 * TP - 2);  RING(11, -TP - 3);
+      RING(12, -3);          RING(13, TP - 3);      RING(14, 2 * TP - 2);   RING(15, 3 * TP - 1);
+#undef RING
+      s16x2 m2[16], m4[16], m8[16];
 #pragma unroll
-      for (int k = 0; k < 16; k++) {
-        mdark = __builtin_amdgcn_alignbit(mdark, (unsigned)(tlo - d[k]), 31);
-        mbright = __builtin_amdgcn_alignbit(mbright, (unsigned)(d[k] + tlo), 31);
-      }
-      const bool pd = has_arc9(mdark), pb = has_arc9(mbright);
-      pass = pd | pb;
-      e |= (pd ? 0x8000u : 0u) | (pb ? 0x80u : 0u);  // y, x < 64: bits 15 and 7 are free
+      for (int k = 0; k < 16; k++) m2[k] = __builtin_elementwise_min(d[k], d[(k + 1) & 15]);
+#pragma unroll
+      for (int k = 0; k < 16; k++) m4[k] = __builtin_elementwise_min(m2[k], m2[(k + 2) & 15]);
+#pragma unroll
+      for (int k = 0; k < 16; k++) m8[k] = __builtin_elementwise_min(m4[k], m4[(k + 4) & 15]);
+      s16x2 best = {-256, -256};
+#pragma unroll
+      for (int k = 0; k < 16; k++) best = __builtin_elementwise_max(best, __builtin_elementwise_min(m8[k], d[(k + 8) & 15]));
+      const int S = max((int)best.x, (int)best.y);
+      pass = S > tlo;
+      if (pass) sc[m24(y + 1, SP) + (x + 1)] = (uint8_t)(S - 1);  // tlo <= S-1 <= 254
     }
     // the ballot consumes every lane's queue read, so the in-place writes below cannot overtake them
     const unsigned long long m = __ballot(pass);
     if (pass) queue[nq2 + __popcll(m & below)] = (uint16_t)e;
     nq2 += __popcll(m);
-  }
-  __syncthreads();
-  // ---- stage 3: scores -------------------------------------------------------------------------
-  for (int i = lane; i < nq2; i += 64) {
-    const unsigned e = queue[i];
-    const int y = (e >> 8) & 0x7f, x = e & 0x7f;
-    const uint8_t* c = tile + m24(y + 3, TP) + (x + 3);
-    int d[16];
-    ring_diffs(c, TP, c[0], d);
-    int S = 0;
-    if (e & 0x8000u) S = max_arc_min9(d);
-    if (e & 0x80u) {
-#pragma unroll
-      for (int k = 0; k < 16; k++) d[k] = -d[k];
-      S = max(S, max_arc_min9(d));
-    }
-    sc[m24(y + 1, SP) + (x + 1)] = (uint8_t)(S - 1);  // tlo <= S-1 <= 254
   }
   __syncthreads();
   // ---- stage 4: NMS inside the emit region, threshold decision, ordered emission ----------------
