@@ -20,6 +20,8 @@
 // Creation order (seq) = processing order, n1..n4 inside a parent.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "orbfe_internal.h"
 
 namespace orbfe {
@@ -445,8 +447,499 @@ __global__ __launch_bounds__(kQtThreads) void k_quadtree(QtParams Q) {
   if (tid == 0) *selCount = (uint32_t)m;
 }
 
+// =====================================================================================================
+// k_quadtree2 -- same algorithm, restructured for latency and footprint (the v1 kernel above stays as the
+// reference implementation for A/B tests, ORBFE_QT_V1=1):
+//   * 512 threads / block, ~60 VGPRs: a block leaves most of its CU to the other batch's kernels;
+//   * candidates carry their packed (x, y, score) word, so no index indirection;
+//   * element passes are tile loops (one element per thread, coalesced), quadrant ranks by wave ballots
+//     + one block barrier per tile; per-node lookups (split point, child positions, range deltas, scan
+//     bases) live in LDS;
+//   * node passes unchanged in substance (processing order, cut, list positions).
+// =====================================================================================================
+constexpr int kQt2Threads = 512;
+
+template <int CAP>
+struct Qt2Shared {
+  QtNode nodes[CAP <= 1024 ? 2 : 1][CAP <= 1024 ? CAP : 1];   // node tables in LDS when they fit (CAP = 1024)
+  unsigned short proc[CAP];   // node ids in processing order
+  uint32_t ninfo[CAP];        // midX | midY << 12 | divide << 24
+  uint16_t cpos[CAP][4];      // new list position of child q; kept nodes: [0] = new position
+  uint32_t baseS[CAP][4];     // exclusive quadrant scan at the node's first element -> later: child.begin - baseS
+  uint32_t endS[CAP][4];      // inclusive quadrant scan at the node's last element
+  short tproc[CAP];           // index in processing order, -1 = not divided
+  unsigned long long sortKeys[CAP];
+  uint32_t wcnt[2][4][kQt2Threads / 64][4];   // [parity][sub-tile][wave][class]
+  int wsumI[kQt2Threads / 64];
+  int s_int[4];
+};
+
+template <int CAP>
+__device__ int blockScanInt2(Qt2Shared<CAP>& sh, int v, int& total) {  // exclusive, 512 threads
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int iv = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(iv, o, 64);
+    if (lane >= o) iv += t;
+  }
+  __syncthreads();
+  if (lane == 63) sh.wsumI[wv] = iv;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kQt2Threads / 64; w++) {
+    if (w < wv) base += sh.wsumI[w];
+    tot += sh.wsumI[w];
+  }
+  total = tot;
+  return base + iv - v;
+}
+
+template <int CAP>
+__device__ void blockSortDesc2(Qt2Shared<CAP>& sh, int n) {
+  int m = 1;
+  while (m < n) m <<= 1;
+  for (int i = n + threadIdx.x; i < m; i += kQt2Threads) sh.sortKeys[i] = 0ull;
+  __syncthreads();
+  for (int k = 2; k <= m; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < m; i += kQt2Threads) {
+        const int p = i ^ j;
+        if (p > i) {
+          const unsigned long long a = sh.sortKeys[i], b = sh.sortKeys[p];
+          const bool desc = ((i & k) == 0);
+          if (desc ? (a < b) : (a > b)) { sh.sortKeys[i] = b; sh.sortKeys[p] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// One tile pass: class c(p) in 0..3 (4 = none) for every element; computes the exclusive count of equal-class
+// elements before p (stored with the class in rankq) and per-segment (= per node) base / end scan values.
+// Each step covers kEpt * 512 consecutive elements: a thread owns kEpt elements 512 apart (coalesced,
+// independent loads in flight together), ranks come from wave ballots, one block barrier per step.
+constexpr int kEpt = 4;
+
+template <int CAP, class ClassFn>
+__device__ void tileScan(Qt2Shared<CAP>& sh, int n, const uint16_t* own, const uint32_t* val, uint32_t* rankq,
+                         bool recordSegments, ClassFn cls, uint32_t total[4]) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  constexpr int NW = kQt2Threads / 64;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  uint32_t carry[4] = {0, 0, 0, 0};
+  int parity = 0;
+  for (int b = 0; b < n; b += kEpt * kQt2Threads, parity ^= 1) {
+    int o[kEpt], q[kEpt];
+    uint32_t v[kEpt];
+#pragma unroll
+    for (int j = 0; j < kEpt; j++) {
+      const int p = b + j * kQt2Threads + tid;
+      o[j] = -1;
+      v[j] = 0;
+      if (p < n) {
+        o[j] = own ? (int)own[p] : 0;
+        v[j] = val[p];
+      }
+    }
+    uint32_t lanePre[kEpt][4];
+#pragma unroll
+    for (int j = 0; j < kEpt; j++) {
+      const int p = b + j * kQt2Threads + tid;
+      q[j] = p < n ? cls(p, o[j], v[j]) : 4;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const unsigned long long m = __ballot(q[j] == k);
+        lanePre[j][k] = __popcll(m & below);
+        if (lane == 0) sh.wcnt[parity][j][wv][k] = __popcll(m);
+      }
+    }
+    __syncthreads();
+    // prefix over (sub-tile j, wave) in element order
+    uint32_t run[4] = {carry[0], carry[1], carry[2], carry[3]};
+#pragma unroll
+    for (int j = 0; j < kEpt; j++) {
+      uint32_t pre[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        uint32_t a = 0, t = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+          const uint32_t c = sh.wcnt[parity][j][w][k];
+          if (w < wv) a += c;
+          t += c;
+        }
+        pre[k] = run[k] + a + lanePre[j][k];   // exclusive scan value of class k at p
+        run[k] += t;
+      }
+      const int p = b + j * kQt2Threads + tid;
+      // segment boundaries = neighbours with a different owner (shuffles run with every lane active)
+      int oPrev = __shfl_up(o[j], 1, 64), oNext = __shfl_down(o[j], 1, 64);
+      if (p < n && q[j] < 4) {
+        rankq[p] = pre[q[j]] | ((uint32_t)q[j] << 30);
+        if (recordSegments) {
+          if (lane == 0) oPrev = p > 0 ? (int)own[p - 1] : -1;
+          if (lane == 63 || p == n - 1) oNext = p + 1 < n ? (int)own[p + 1] : -1;
+          if (oPrev != o[j]) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) sh.baseS[o[j]][k] = pre[k];
+          }
+          if (oNext != o[j]) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) sh.endS[o[j]][k] = pre[k] + (q[j] == k ? 1u : 0u);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) carry[k] = run[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) total[k] = carry[k];
+  __syncthreads();
+}
+
+template <int CAP>
+__global__ __launch_bounds__(kQt2Threads) void k_quadtree2(QtParams Q) {
+  __shared__ Qt2Shared<CAP> sh;
+  constexpr int IPT = CAP / kQt2Threads;   // node items per thread
+  const int level = blockIdx.x, f = Q.frameBase + blockIdx.y, tid = threadIdx.x;
+  const uint32_t* ls = Q.levelStart + (long long)f * (kMaxLevels + 1);
+  const uint32_t first = ls[level];
+  const int n = (int)(ls[level + 1] - first);
+  const int N = Q.nfeat[level];
+  uint32_t* selCount = Q.selCount + (long long)f * kMaxLevels + level;
+  SelKp* selOut = Q.sel + (long long)f * Q.selPerFrame + Q.selOff[level];
+  if (n <= 0) {
+    if (tid == 0) *selCount = 0;
+    return;
+  }
+  const long long eo = (long long)f * Q.candCap + first;
+  const uint32_t* cand = Q.cand + eo;
+  uint32_t* valCur = Q.idxA + eo;
+  uint32_t* valNxt = Q.idxB + eo;
+  uint16_t* ownCur = Q.ownA + eo;
+  uint16_t* ownNxt = Q.ownB + eo;
+  uint32_t* rankq = Q.rank + eo;
+  const long long no = ((long long)f * Q.nlevels + level) * kQtNodeCap;
+  constexpr bool kNodesInLds = CAP <= 1024;
+  QtNode* cur = kNodesInLds ? sh.nodes[0] : Q.nodesA + no;
+  QtNode* nxt = kNodesInLds ? sh.nodes[kNodesInLds ? 1 : 0] : Q.nodesB + no;
+  unsigned short* proc = sh.proc;
+  const int maxX = Q.levW[level] - kBorder, maxY = Q.levH[level] - kBorder;
+
+  // ---- roots (ORBextractor.cc:574-617) ---------------------------------------------------------------
+  const int nIni = (int)roundf(static_cast<float>(maxX - kBorder) / (maxY - kBorder));
+  const float hX = static_cast<float>(maxX - kBorder) / nIni;
+  int m = 0;
+  uint32_t seq = 0;
+  {
+    uint32_t cnt[4];
+    tileScan<CAP>(sh, n, nullptr, cand, rankq, false,
+                  [&](int, int, uint32_t v) {
+                    const int x = (int)(v & 0xfff) - kBorder;
+                    return min((int)((float)x / hX), nIni - 1);
+                  },
+                  cnt);
+    uint32_t start[4];
+    start[0] = 0; start[1] = cnt[0]; start[2] = cnt[0] + cnt[1]; start[3] = cnt[0] + cnt[1] + cnt[2];
+    int rootId[4], nr = 0;
+    for (int r = 0; r < 4; r++) rootId[r] = (r < nIni && cnt[r] > 0) ? nr++ : -1;
+    for (int p = tid; p < n; p += kQt2Threads) {
+      const uint32_t rq = rankq[p];
+      const int r = rq >> 30;
+      const uint32_t np = start[r] + (rq & 0x3fffffffu);
+      valCur[np] = cand[p];
+      ownCur[np] = (uint16_t)rootId[r];
+    }
+    if (tid < 4 && tid < nIni && cnt[tid] > 0) {
+      QtNode nd;
+      nd.x0 = (short)(int)(hX * static_cast<float>(tid));
+      nd.x1 = (short)(int)(hX * static_cast<float>(tid + 1));
+      nd.y0 = 0;
+      nd.y1 = (short)(maxY - kBorder);
+      nd.begin = start[tid];
+      nd.end = start[tid] + cnt[tid];
+      nd.seq = (uint32_t)tid;
+      cur[rootId[tid]] = nd;
+    }
+    m = nr;
+    seq = (uint32_t)nIni;
+    __syncthreads();
+  }
+
+  bool finalPhase = false;
+  int nRec = 0;
+  for (int iter = 0; iter < 64; iter++) {
+    const int prevSize = m;
+    int nproc = 0;
+    // ---- processing order + per-node split info ----------------------------------------------------
+    if (!finalPhase) {
+      int flag[IPT], loc = 0;
+#pragma unroll
+      for (int k = 0; k < IPT; k++) {
+        const int i = IPT * tid + k;
+        flag[k] = (i < m && cur[i].end - cur[i].begin > 1) ? 1 : 0;
+        loc += flag[k];
+      }
+      int tot;
+      int ex = blockScanInt2<CAP>(sh, loc, tot);
+#pragma unroll
+      for (int k = 0; k < IPT; k++) {
+        const int i = IPT * tid + k;
+        if (i < m) {
+          sh.tproc[i] = (short)(flag[k] ? ex : -1);
+          if (flag[k]) proc[ex++] = (unsigned short)i;
+        }
+      }
+      nproc = tot;
+    } else {
+      blockSortDesc2<CAP>(sh, nRec);
+      for (int i = tid; i < m; i += kQt2Threads) sh.tproc[i] = -1;
+      __syncthreads();
+      for (int t = tid; t < nRec; t += kQt2Threads) {
+        const int id = (int)(sh.sortKeys[t] & 0xffff);
+        proc[t] = (unsigned short)id;
+        sh.tproc[id] = (short)t;
+      }
+      nproc = nRec;
+    }
+    __syncthreads();
+    if (nproc == 0) break;
+    for (int i = tid; i < m; i += kQt2Threads) {
+      const QtNode nd = cur[i];
+      const int midX = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), midY = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+      sh.ninfo[i] = (uint32_t)midX | ((uint32_t)midY << 12) | (sh.tproc[i] >= 0 ? (1u << 24) : 0u);
+    }
+    __syncthreads();
+
+    // ---- element pass 1: quadrant + segmented scan -------------------------------------------------
+    {
+      uint32_t dummy[4];
+      tileScan<CAP>(sh, n, ownCur, valCur, rankq, true,
+                    [&](int, int o, uint32_t v) {
+                      const uint32_t info = sh.ninfo[o];
+                      if (!(info >> 24)) return 4;
+                      const int x = (int)(v & 0xfff) - kBorder, y = (int)((v >> 12) & 0xfff) - kBorder;
+                      return (x < (int)(info & 0xfff) ? 0 : 1) + (y < (int)((info >> 12) & 0xfff) ? 0 : 2);
+                    },
+                    dummy);
+    }
+
+    // ---- node pass: children counts, cut, new list positions -----------------------------------------
+    int C[IPT], locC = 0, locGrow = 0;
+#pragma unroll
+    for (int k = 0; k < IPT; k++) {
+      const int t = IPT * tid + k;
+      C[k] = 0;
+      if (t < nproc) {
+        const int id = proc[t];
+        for (int q = 0; q < 4; q++) C[k] += (sh.endS[id][q] - sh.baseS[id][q]) > 0;
+        locC += C[k];
+        locGrow += C[k] - 1;
+      }
+    }
+    int totC, totGrow;
+    int exC = blockScanInt2<CAP>(sh, locC, totC);
+    int exGrow = blockScanInt2<CAP>(sh, locGrow, totGrow);
+    int cutT = nproc - 1;
+    if (finalPhase) {
+      if (tid == 0) sh.s_int[0] = nproc - 1;
+      __syncthreads();
+      int g = exGrow;
+#pragma unroll
+      for (int k = 0; k < IPT; k++) {
+        const int t = IPT * tid + k;
+        if (t < nproc) {
+          g += C[k] - 1;
+          if (prevSize + g >= N) atomicMin(&sh.s_int[0], t);
+        }
+      }
+      __syncthreads();
+      cutT = sh.s_int[0];
+    }
+    if (tid == 0) sh.s_int[1] = 0;
+    __syncthreads();
+    {
+      int pc = exC;
+#pragma unroll
+      for (int k = 0; k < IPT; k++) {
+        const int t = IPT * tid + k;
+        if (t < nproc) {
+          if (t == cutT) sh.s_int[1] = pc + C[k];
+          pc += C[k];
+        }
+      }
+    }
+    __syncthreads();
+    const int T = sh.s_int[1];
+    int keptFlag[IPT], locK = 0;
+#pragma unroll
+    for (int k = 0; k < IPT; k++) {
+      const int i = IPT * tid + k;
+      keptFlag[k] = 0;
+      if (i < m) {
+        const int t = sh.tproc[i];
+        keptFlag[k] = (t < 0 || t > cutT) ? 1 : 0;
+      }
+      locK += keptFlag[k];
+    }
+    int totK;
+    int exK = blockScanInt2<CAP>(sh, locK, totK);
+    const int mNew = T + totK;
+    {
+      int pc = exC;
+#pragma unroll
+      for (int k = 0; k < IPT; k++) {
+        const int t = IPT * tid + k;
+        if (t < nproc) {
+          const int id = proc[t];
+          if (t <= cutT) {
+            const QtNode nd = cur[id];
+            const int midX = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), midY = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
+            uint32_t c[4];
+            int nonEmptyAfter = 0;
+            for (int q = 0; q < 4; q++) { c[q] = sh.endS[id][q] - sh.baseS[id][q]; nonEmptyAfter += c[q] > 0; }
+            const int groupBase = T - pc - C[k];
+            uint32_t b = nd.begin;
+            int before = 0;
+            for (int q = 0; q < 4; q++) {
+              if (c[q] == 0) { sh.cpos[id][q] = 0xffff; continue; }
+              nonEmptyAfter--;
+              const int pos = groupBase + nonEmptyAfter;
+              QtNode ch;
+              ch.x0 = (q & 1) ? (short)midX : nd.x0;
+              ch.x1 = (q & 1) ? nd.x1 : (short)midX;
+              ch.y0 = (q & 2) ? (short)midY : nd.y0;
+              ch.y1 = (q & 2) ? nd.y1 : (short)midY;
+              ch.begin = b;
+              ch.end = b + c[q];
+              ch.seq = seq + (uint32_t)(pc + before);
+              nxt[pos] = ch;
+              sh.cpos[id][q] = (uint16_t)pos;
+              sh.baseS[id][q] = b - sh.baseS[id][q];   // delta: new position = rank + delta
+              b += c[q];
+              before++;
+            }
+          } else {
+            sh.tproc[id] = -1;  // beyond the cut: not divided after all (keptFlag was computed before)
+          }
+          pc += C[k];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < IPT; k++) {
+        const int i = IPT * tid + k;
+        if (i < m && keptFlag[k]) {
+          const int pos = T + exK++;
+          nxt[pos] = cur[i];
+          sh.cpos[i][0] = (uint16_t)pos;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- element pass 2: move candidates into their children, re-own (4 independent elements in flight)
+    for (int b = 0; b < n; b += kEpt * kQt2Threads) {
+      int o[kEpt];
+      uint32_t v[kEpt], rq[kEpt];
+#pragma unroll
+      for (int j = 0; j < kEpt; j++) {
+        const int p = b + j * kQt2Threads + tid;
+        o[j] = 0; v[j] = 0; rq[j] = 0;
+        if (p < n) { o[j] = ownCur[p]; v[j] = valCur[p]; rq[j] = rankq[p]; }
+      }
+#pragma unroll
+      for (int j = 0; j < kEpt; j++) {
+        const int p = b + j * kQt2Threads + tid;
+        if (p < n) {
+          if (sh.tproc[o[j]] >= 0) {
+            const int q = rq[j] >> 30;
+            const uint32_t np = (rq[j] & 0x3fffffffu) + sh.baseS[o[j]][q];
+            valNxt[np] = v[j];
+            ownNxt[np] = sh.cpos[o[j]][q];
+          } else {
+            valNxt[p] = v[j];
+            ownNxt[p] = sh.cpos[o[j]][0];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    { uint32_t* t0 = valCur; valCur = valNxt; valNxt = t0; }
+    { uint16_t* t1 = ownCur; ownCur = ownNxt; ownNxt = t1; }
+    { QtNode* t2 = cur; cur = nxt; nxt = t2; }
+    m = mNew;
+    seq += (uint32_t)T;
+
+    // ---- record of nodes created in this pass with more than one candidate (positions [0,T)) --------
+    int recFlag[IPT], locR = 0;
+#pragma unroll
+    for (int k = 0; k < IPT; k++) {
+      const int i = IPT * tid + k;
+      recFlag[k] = (i < T && cur[i].end - cur[i].begin > 1) ? 1 : 0;
+      locR += recFlag[k];
+    }
+    int totR;
+    int exR = blockScanInt2<CAP>(sh, locR, totR);
+#pragma unroll
+    for (int k = 0; k < IPT; k++) {
+      const int i = IPT * tid + k;
+      if (recFlag[k]) {
+        const QtNode nd = cur[i];
+        sh.sortKeys[exR++] = ((unsigned long long)(nd.end - nd.begin) << 40) | ((unsigned long long)nd.seq << 16) |
+                             (unsigned long long)i;
+      }
+    }
+    nRec = totR;
+    __syncthreads();
+
+    if (m >= N || m == prevSize) break;
+    if (!finalPhase && m + 3 * totR > N) finalPhase = true;
+    if (finalPhase && nRec == 0) break;
+  }
+
+  // ---- one keypoint per node: highest response, first wins (ORBextractor.cc:774-792) ------------------
+  const int lane = tid & 63, wv = tid >> 6;
+  for (int i = wv; i < m; i += kQt2Threads / 64) {
+    const QtNode nd = cur[i];
+    int bestScore = -1;
+    uint32_t bestPos = 0xffffffffu;
+    for (uint32_t p = nd.begin + lane; p < nd.end; p += 64) {
+      const int s = (int)(valCur[p] >> 24);
+      if (s > bestScore) { bestScore = s; bestPos = p; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const int os = __shfl_xor(bestScore, o, 64);
+      const uint32_t op = __shfl_xor(bestPos, o, 64);
+      if (os > bestScore || (os == bestScore && op < bestPos)) { bestScore = os; bestPos = op; }
+    }
+    if (lane == 0) {
+      const uint32_t c = valCur[bestPos];
+      SelKp s;
+      s.xy = (c & 0xfff) | (((c >> 12) & 0xfff) << 16);
+      s.lf = (uint32_t)level | ((uint32_t)f << 8) | ((c >> 24) << 24);
+      selOut[i] = s;
+    }
+  }
+  if (tid == 0) *selCount = (uint32_t)m;
+}
+
 void launch_quadtree(const QtParams& Q, int nframes, hipStream_t st) {
-  hipLaunchKernelGGL(k_quadtree, dim3(Q.nlevels, nframes), dim3(kQtThreads), 0, st, Q);
+  static const bool v1 = getenv("ORBFE_QT_V1") && atoi(getenv("ORBFE_QT_V1")) != 0;
+  if (v1) {
+    hipLaunchKernelGGL(k_quadtree, dim3(Q.nlevels, nframes), dim3(kQtThreads), 0, st, Q);
+    return;
+  }
+  int maxN = 0;
+  for (int l = 0; l < Q.nlevels; l++) maxN = Q.nfeat[l] > maxN ? Q.nfeat[l] : maxN;
+  if (maxN + 4 <= 1024)
+    hipLaunchKernelGGL(k_quadtree2<1024>, dim3(Q.nlevels, nframes), dim3(kQt2Threads), 0, st, Q);
+  else
+    hipLaunchKernelGGL(k_quadtree2<2048>, dim3(Q.nlevels, nframes), dim3(kQt2Threads), 0, st, Q);
 }
 
 }  // namespace orbfe
