@@ -97,6 +97,7 @@ def main():
 
     run(args.warmup)
     st.kernel_ms(reset=True)
+    st.stats(reset=True)
     nmatch_total[0] = 0
     sync()
     if dist is not None:
@@ -108,6 +109,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     kms, kbatches, kframes = st.kernel_ms()
+    wstats = st.stats()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -149,6 +151,8 @@ def main():
                        'input': 'frames resident in HBM; keypoints/descriptors/matches returned to host'},
             'gpu_kernel_ms_per_frame': {k: round(v / max(kframes, 1), 5) for k, v in
                                         zip(('pyramid', 'fast_cells', 'compaction', 'describe', 'quadtree'), kms)},
+            'host_worker_ms_per_step': {'submit': round(wstats[0] / max(wstats[3], 1), 4), 'collect_incl_gpu_wait': round(wstats[1] / max(wstats[3], 1), 4),
+                                        'match': round(wstats[2] / max(wstats[3], 1), 4)},
             'roofline': {'kernel': 'k_fast_cells', 'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
                          'algorithmic_bytes_per_launch': fast_bytes_per_frame * B,

@@ -174,6 +174,9 @@ int orbfe_stream_push(orbfe_stream* s, const uint8_t* const* gray, int in_device
  *   nmatches [batch]: return values of the searches (0 for the very first frame of the stream). */
 int orbfe_stream_pop(orbfe_stream* s, const OrbfeKeyPoint** kps, const uint8_t** desc, const int** n_kps,
                      const int32_t** matches12, const int** nmatches);
+/* Host wall-clock ms the workers spent in submit / collect (incl. waiting for the GPU) / match calls, and the
+ * number of finished batches, since the last reset: out = {submit, collect, match, batches}. */
+int orbfe_stream_stats(orbfe_stream* s, double out[4], int reset);
 /* Sum of orbfe_debug_kernel_ms over the stream's extractor handles. */
 int orbfe_stream_kernel_ms(orbfe_stream* s, double out_ms[5], long long* batches, long long* frames, int reset);
 

@@ -93,6 +93,7 @@ def load_library():
     L.orbfe_stream_capacity.argtypes = [vp]
     L.orbfe_stream_push.argtypes = [vp, vp, ci, ci, ci, C.c_size_t]
     L.orbfe_stream_pop.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.orbfe_stream_stats.argtypes = [vp, vp, ci]
     L.orbfe_stream_kernel_ms.argtypes = [vp, vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), ci]
     L.orbfe_debug_quadtree.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, ci, C.POINTER(ci)]
     L.orbfe_debug_sincos_host_check.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_longlong)]
@@ -448,6 +449,12 @@ class Stream:
             return a.copy() if copy else a
         return (view(pk, KP_DTYPE, (B, cap)), view(pd, np.uint8, (B, cap, 32)), view(pn, np.int32, (B,)),
                 view(pm, np.int32, (B, cap)), view(pnm, np.int32, (B,)))
+
+    def stats(self, reset=False):
+        """{submit, collect, match} worker busy ms and batches done since the last reset."""
+        out = np.zeros(4, np.float64)
+        _check(self.L.orbfe_stream_stats(self.h, _p(out), int(reset)))
+        return out
 
     def kernel_ms(self, reset=False):
         ms = np.zeros(5, np.float64)

@@ -67,7 +67,7 @@ struct MatchParams {
   const int* soct;
   const int* sidx;        // original keypoint index inside its frame
   const int* cellStart;   // per pair [64*48+1], values relative to the pair's trainOff
-  const uint8_t* tdesc;   // descriptor rows, ORIGINAL order per frame
+  const uint8_t* tdesc;   // descriptor rows in the same grid-sorted order as sx/sy/soct/sidx
   const PairInfo* pairs;
   // queries (all pairs concatenated)
   const int* qpair;       // pair of each query
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(64) void k_window_match(MatchParams M) {
   for (int e = b; e < e1; e++) {
     if (!inWindow(e)) continue;
     const int idx = sidx[e];
-    const int d = hamming256(reinterpret_cast<const uint32_t*>(tdesc + (size_t)idx * 32), qd);
+    const int d = hamming256(reinterpret_cast<const uint32_t*>(tdesc + (size_t)e * 32), qd);  // descriptors are grid-sorted
     if (pos < M.poolCap) M.pool[pos] = (uint32_t)idx | ((uint32_t)d << 16);
     pos++;
   }
@@ -256,71 +256,119 @@ struct orbfe_matcher {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
   }
 
-  // Runs the window kernel for all jobs in ONE upload + ONE launch.
+  // Results of candidates(), indexed by ORIGINAL query number (all jobs concatenated)
+  std::vector<uint32_t> qcountFull, qoffFull;
+  std::vector<int> qmap;        // compact (launched) query -> original query
+  struct JobPlan { int lo, hi; size_t trainOff, q0c; int nTrain, nqc; };
+  std::vector<JobPlan> plan;
+
+  // Runs the window kernel for all jobs in ONE upload + ONE launch.  Only what can influence a result is
+  // uploaded: active queries (r >= 0) and the train keypoints whose octave some active query of the job
+  // accepts (e.g. SearchForInitialization touches level-0 keypoints only, ORBmatcher.cc:416-420).
+  // Dropping the others cannot change any candidate list: Frame::GetFeaturesInArea would skip them.
   int candidates(const Job* jobs, int njobs) {
     const double tA = nowMs();
     HIP_TRY(hipSetDevice(device));
     int rc;
     const int ncell = kGridCols * kGridRows;
     jobQ0.assign(njobs + 1, 0);
-    size_t nTrain = 0, nDesc = 0, nq = 0;
-    std::vector<size_t> trainOff(njobs), descOff(njobs);
+    plan.assign(njobs, JobPlan{});
+    size_t nTrain = 0, nqOrig = 0, nq = 0;
     for (int j = 0; j < njobs; j++) {
-      trainOff[j] = nTrain; descOff[j] = nDesc; jobQ0[j] = (int)nq;
-      nTrain += jobs[j].n; nDesc += jobs[j].n; nq += jobs[j].nq;
+      const Job& J = jobs[j];
+      jobQ0[j] = (int)nqOrig;
+      nqOrig += J.nq;
+      JobPlan& pl = plan[j];
+      pl.lo = INT_MAX; pl.hi = INT_MIN; pl.nqc = 0;
+      for (int q = 0; q < J.nq; q++) {
+        if (!(J.qr[q] >= 0.f)) continue;
+        pl.nqc++;
+        const bool check = (J.qminL[q] > 0) || (J.qmaxL[q] >= 0);
+        const int lo = check ? J.qminL[q] : INT_MIN, hi = (check && J.qmaxL[q] >= 0) ? J.qmaxL[q] : INT_MAX;
+        pl.lo = std::min(pl.lo, lo);
+        pl.hi = std::max(pl.hi, hi);
+      }
+      pl.trainOff = nTrain;
+      pl.q0c = nq;
+      nq += pl.nqc;
+      int cnt = 0;
+      if (pl.nqc)
+        for (int i = 0; i < J.n; i++) cnt += (J.kps[i].octave >= pl.lo && J.kps[i].octave <= pl.hi) ? 1 : 0;
+      pl.nTrain = cnt;   // upper bound (keypoints outside the grid are dropped below)
+      nTrain += cnt;
     }
-    jobQ0[njobs] = (int)nq;
-    // arena layout (one H2D copy)
+    jobQ0[njobs] = (int)nqOrig;
+    qcountFull.assign(nqOrig, 0);
+    qoffFull.assign(nqOrig, 0);
+    qmap.resize(nq);
+    if (nq == 0) {
+      qcount = qcountFull.data();
+      qoff = qoffFull.data();
+      stageMs[0] = nowMs() - tA;
+      stageMs[1] = 0;
+      return ORBFE_OK;
+    }
+    // arena layout (one H2D copy); train descriptors are stored in grid-sorted order
     const size_t oSx = 0, oSy = oSx + al(4 * nTrain), oOct = oSy + al(4 * nTrain), oIdx = oOct + al(4 * nTrain),
                  oCell = oIdx + al(4 * nTrain), oTd = oCell + al(4 * (size_t)(ncell + 1) * njobs),
-                 oPair = oTd + al(32 * nDesc), oQp = oPair + al(sizeof(PairInfo) * (size_t)njobs),
+                 oPair = oTd + al(32 * nTrain), oQp = oPair + al(sizeof(PairInfo) * (size_t)njobs),
                  oQx = oQp + al(4 * nq), oQy = oQx + al(4 * nq), oQr = oQy + al(4 * nq), oQa = oQr + al(4 * nq),
                  oQb = oQa + al(4 * nq), oQd = oQb + al(4 * nq), total = oQd + al(32 * nq);
     if ((rc = h_in.ensure(total))) return rc;
     if ((rc = d_in.ensure(total))) return rc;
     uint8_t* H = h_in.p;
-    // per job: AssignFeaturesToGrid / PosInGrid (Frame.cc:114-129, 264-274) as a stable counting sort by cell
     pool->parallelFor(njobs, [&](int j, int) {
       const Job& J = jobs[j];
+      const JobPlan& pl = plan[j];
       const float minX = J.bounds[0], maxX = J.bounds[1], minY = J.bounds[2], maxY = J.bounds[3];
       const float invW = static_cast<float>(kGridCols) / static_cast<float>(maxX - minX);   // Frame.cc:98
       const float invH = static_cast<float>(kGridRows) / static_cast<float>(maxY - minY);   // Frame.cc:99
       int* cellCnt = (int*)(H + oCell) + (size_t)(ncell + 1) * j;
-      std::vector<int> cellOf(J.n);
       for (int c = 0; c <= ncell; c++) cellCnt[c] = 0;
+      PairInfo pi;
+      pi.trainOff = (int)pl.trainOff; pi.cellOff = (ncell + 1) * j; pi.tdescOff = (int)pl.trainOff;
+      pi.minX = minX; pi.minY = minY; pi.invW = invW; pi.invH = invH;
+      ((PairInfo*)(H + oPair))[j] = pi;
+      if (pl.nqc == 0) return;
+      // AssignFeaturesToGrid / PosInGrid (Frame.cc:114-129, 264-274) as a stable counting sort by cell
+      std::vector<int> cellOf(J.n);
       for (int i = 0; i < J.n; i++) {
+        cellOf[i] = -1;
+        if (J.kps[i].octave < pl.lo || J.kps[i].octave > pl.hi) continue;
         const int px = (int)roundf((J.kps[i].x - minX) * invW);
         const int py = (int)roundf((J.kps[i].y - minY) * invH);
-        if (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) { cellOf[i] = -1; continue; }
+        if (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) continue;
         cellOf[i] = px * kGridRows + py;
         cellCnt[cellOf[i] + 1]++;
       }
       for (int c = 0; c < ncell; c++) cellCnt[c + 1] += cellCnt[c];
       std::vector<int> order(cellCnt, cellCnt + ncell);
-      float* sx = (float*)(H + oSx) + trainOff[j];
-      float* sy = (float*)(H + oSy) + trainOff[j];
-      int* so = (int*)(H + oOct) + trainOff[j];
-      int* si = (int*)(H + oIdx) + trainOff[j];
+      float* sx = (float*)(H + oSx) + pl.trainOff;
+      float* sy = (float*)(H + oSy) + pl.trainOff;
+      int* so = (int*)(H + oOct) + pl.trainOff;
+      int* si = (int*)(H + oIdx) + pl.trainOff;
+      uint8_t* td = H + oTd + 32 * pl.trainOff;
       for (int i = 0; i < J.n; i++) {
         if (cellOf[i] < 0) continue;
         const int p = order[cellOf[i]]++;
         sx[p] = J.kps[i].x; sy[p] = J.kps[i].y; so[p] = J.kps[i].octave; si[p] = i;
+        memcpy(td + 32 * (size_t)p, J.desc + 32 * (size_t)i, 32);
       }
-      if (J.n) memcpy(H + oTd + 32 * descOff[j], J.desc, 32 * (size_t)J.n);
-      PairInfo pi;
-      pi.trainOff = (int)trainOff[j]; pi.cellOff = (ncell + 1) * j; pi.tdescOff = (int)descOff[j];
-      pi.minX = minX; pi.minY = minY; pi.invW = invW; pi.invH = invH;
-      ((PairInfo*)(H + oPair))[j] = pi;
-      const size_t q0 = jobQ0[j];
-      int* qp = (int*)(H + oQp) + q0;
-      for (int q = 0; q < J.nq; q++) qp[q] = j;
-      if (J.nq) {
-        memcpy((float*)(H + oQx) + q0, J.qx, 4 * (size_t)J.nq);
-        memcpy((float*)(H + oQy) + q0, J.qy, 4 * (size_t)J.nq);
-        memcpy((float*)(H + oQr) + q0, J.qr, 4 * (size_t)J.nq);
-        memcpy((int*)(H + oQa) + q0, J.qminL, 4 * (size_t)J.nq);
-        memcpy((int*)(H + oQb) + q0, J.qmaxL, 4 * (size_t)J.nq);
-        memcpy(H + oQd + 32 * q0, J.qdesc, 32 * (size_t)J.nq);
+      // active queries, compacted
+      int* qp = (int*)(H + oQp) + pl.q0c;
+      float* qxo = (float*)(H + oQx) + pl.q0c;
+      float* qyo = (float*)(H + oQy) + pl.q0c;
+      float* qro = (float*)(H + oQr) + pl.q0c;
+      int* qao = (int*)(H + oQa) + pl.q0c;
+      int* qbo = (int*)(H + oQb) + pl.q0c;
+      uint8_t* qdo = H + oQd + 32 * pl.q0c;
+      int c = 0;
+      for (int q = 0; q < J.nq; q++) {
+        if (!(J.qr[q] >= 0.f)) continue;
+        qp[c] = j; qxo[c] = J.qx[q]; qyo[c] = J.qy[q]; qro[c] = J.qr[q]; qao[c] = J.qminL[q]; qbo[c] = J.qmaxL[q];
+        memcpy(qdo + 32 * (size_t)c, J.qdesc + 32 * (size_t)q, 32);
+        qmap[pl.q0c + c] = jobQ0[j] + q;
+        c++;
       }
     });
     const double tB = nowMs();
@@ -344,7 +392,7 @@ struct orbfe_matcher {
       M.nq = (int)nq;
       M.total = d_out.p; M.qcount = d_out.p + 64; M.qoff = d_out.p + 64 + nq;
       M.pool = d_pool.p; M.poolCap = (uint32_t)d_pool.n;
-      if (nq > 0) hipLaunchKernelGGL(k_window_match, dim3((unsigned)nq), dim3(64), 0, stream, M);
+      hipLaunchKernelGGL(k_window_match, dim3((unsigned)nq), dim3(64), 0, stream, M);
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipMemcpyAsync(h_out.p, d_out.p, outWords * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
       // optimistic: fetch a generous prefix of the pool in the same round trip
@@ -361,8 +409,14 @@ struct orbfe_matcher {
         }
         lastTotal = tot;
         stageMs[1] = nowMs() - tB;
-        qcount = h_out.p + 64;
-        qoff = h_out.p + 64 + nq;
+        const uint32_t* qc = h_out.p + 64;
+        const uint32_t* qo = h_out.p + 64 + nq;
+        for (size_t c = 0; c < nq; c++) {
+          qcountFull[qmap[c]] = qc[c];
+          qoffFull[qmap[c]] = qo[c];
+        }
+        qcount = qcountFull.data();
+        qoff = qoffFull.data();
         return ORBFE_OK;
       }
       poolCap = tot;  // pool too small: grow to the exact demand and rerun once

@@ -13,7 +13,9 @@
 // (orbfe_extract_batch_submit/_collect, orbfe_search_for_initialization_batch), so results are
 // identical to calling those one by one.
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <mutex>
@@ -40,6 +42,12 @@ struct Slot {
   std::vector<int32_t> m12;
   std::vector<int> nm;
   std::vector<float> prevxy;
+  // predecessor of frame 0 (last frame of the previous batch), copied at collect time
+  std::vector<OrbfeKeyPoint> prevKps;
+  std::vector<uint8_t> prevDesc;
+  int prevN = -1;
+  long long seq = 0;
+  bool done = false;
   int status = ORBFE_OK;
   std::string err;
 };
@@ -51,7 +59,7 @@ struct orbfe_stream {
   float nnratio = 0.9f;
   float bounds[4] = {0, 0, 0, 0};
   std::vector<orbfe_extractor*> ext;
-  orbfe_matcher* matcher = nullptr;
+  std::vector<orbfe_matcher*> matchers;   // one per match worker
   std::vector<Slot> slots;
 
   std::mutex mu;
@@ -59,12 +67,21 @@ struct orbfe_stream {
   std::deque<int> freeQ, extractQ, matchQ, doneQ;
   int popped = -1;  // slot handed to the caller by the last pop (returned to freeQ on the next pop)
   bool stop = false;
-  std::thread tExtract, tMatch;
+  std::thread tExtract;
+  std::vector<std::thread> tMatch;
+  long long pushSeq = 0, popSeq = 0;
 
   // last frame of the previous batch (the predecessor of frame 0 of the next one)
   std::vector<OrbfeKeyPoint> lastKps;
   std::vector<uint8_t> lastDesc;
   int lastN = -1;
+
+  // busy time of the two workers (ms) and batches done, for orbfe_stream_stats
+  double busySubmit = 0, busyCollect = 0, busyMatch = 0;
+  long long nBatches = 0;
+  static double nowMs() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  }
 
   void extractLoop() {
     std::deque<std::pair<int, int>> inflight;  // (slot, extractor)
@@ -83,7 +100,9 @@ struct orbfe_stream {
       if (job >= 0) {
         Slot& s = slots[job];
         orbfe_extractor* h = ext[nextExt];
+        const double ta = nowMs();
         s.status = orbfe_extract_batch_submit(h, batch, s.frames.data(), s.onDevice, s.rows, s.cols, s.stride);
+        busySubmit += nowMs() - ta;
         if (s.status != ORBFE_OK) s.err = orbfe_last_error();
         inflight.emplace_back(job, nextExt);
         nextExt = (nextExt + 1) % depth;
@@ -94,8 +113,17 @@ struct orbfe_stream {
       inflight.pop_front();
       Slot& s = slots[slot];
       if (s.status == ORBFE_OK) {
+        const double ta = nowMs();
         s.status = orbfe_extract_batch_collect(ext[e], s.kps.data(), s.desc.data(), cap, s.n.data());
+        busyCollect += nowMs() - ta;
         if (s.status != ORBFE_OK) s.err = orbfe_last_error();
+      }
+      if (s.status == ORBFE_OK) {
+        s.prevN = lastN;
+        if (lastN >= 0) { s.prevKps = lastKps; s.prevDesc = lastDesc; }
+        lastN = s.n[batch - 1];
+        lastKps.assign(s.kps.begin() + (size_t)(batch - 1) * cap, s.kps.begin() + (size_t)(batch - 1) * cap + lastN);
+        lastDesc.assign(s.desc.begin() + (size_t)(batch - 1) * cap * 32, s.desc.begin() + ((size_t)(batch - 1) * cap + lastN) * 32);
       }
       {
         std::lock_guard<std::mutex> lk(mu);
@@ -105,7 +133,8 @@ struct orbfe_stream {
     }
   }
 
-  void matchLoop() {
+  void matchLoop(int worker) {
+    orbfe_matcher* matcher = matchers[worker];
     std::vector<const OrbfeKeyPoint*> k1, k2;
     std::vector<const uint8_t*> d1, d2;
     std::vector<int> n1, n2;
@@ -125,6 +154,7 @@ struct orbfe_stream {
         matchQ.pop_front();
       }
       Slot& s = slots[slot];
+      const double tm0 = nowMs();
       if (s.status == ORBFE_OK && window > 0) {
         // pairs (predecessor, frame): Tracking::MonocularInitialization style, vbPrevMatched := F1 keypoints
         k1.clear(); k2.clear(); d1.clear(); d2.clear(); n1.clear(); n2.clear(); prev.clear(); m12.clear();
@@ -134,12 +164,12 @@ struct orbfe_stream {
           const uint8_t* pd;
           int pn;
           if (i == 0) {
-            if (lastN < 0) {  // very first frame of the stream: no predecessor
+            if (s.prevN < 0) {  // very first frame of the stream: no predecessor
               s.nm[0] = 0;
               std::fill(s.m12.begin(), s.m12.begin() + cap, -1);
               continue;
             }
-            pk = lastKps.data(); pd = lastDesc.data(); pn = lastN;
+            pk = s.prevKps.data(); pd = s.prevDesc.data(); pn = s.prevN;
           } else {
             pk = s.kps.data() + (size_t)(i - 1) * cap; pd = s.desc.data() + (size_t)(i - 1) * cap * 32; pn = s.n[i - 1];
           }
@@ -160,14 +190,12 @@ struct orbfe_stream {
           for (size_t p = 0; p < frameOfPair.size(); p++) s.nm[frameOfPair[p]] = nm[p];
         }
       }
-      if (s.status == ORBFE_OK) {
-        lastN = s.n[batch - 1];
-        lastKps.assign(s.kps.begin() + (size_t)(batch - 1) * cap, s.kps.begin() + (size_t)(batch - 1) * cap + lastN);
-        lastDesc.assign(s.desc.begin() + (size_t)(batch - 1) * cap * 32, s.desc.begin() + ((size_t)(batch - 1) * cap + lastN) * 32);
-      }
+      const double tmBusy = nowMs() - tm0;
       {
         std::lock_guard<std::mutex> lk(mu);
-        doneQ.push_back(slot);
+        busyMatch += tmBusy;
+        nBatches++;
+        s.done = true;
       }
       cv.notify_all();
     }
@@ -194,14 +222,21 @@ int orbfe_stream_create(int nfeatures, float scaleFactor, int nlevels, int iniTh
     }
     s->ext.push_back(h);
   }
-  int rc = orbfe_matcher_create(device_id, &s->matcher);
-  if (rc != ORBFE_OK) {
-    for (auto* e : s->ext) orbfe_extractor_destroy(e);
-    delete s;
-    return rc;
+  int nMatch = 2;   // SearchForInitialization workers (batches are independent once extracted)
+  if (const char* ev = getenv("ORBFE_MATCH_WORKERS")) nMatch = std::max(1, std::min(4, atoi(ev)));
+  for (int w = 0; w < nMatch; w++) {
+    orbfe_matcher* mm = nullptr;
+    int rc = orbfe_matcher_create(device_id, &mm);
+    if (rc != ORBFE_OK) {
+      for (auto* e : s->ext) orbfe_extractor_destroy(e);
+      for (auto* q : s->matchers) orbfe_matcher_destroy(q);
+      delete s;
+      return rc;
+    }
+    s->matchers.push_back(mm);
   }
   s->cap = orbfe_extractor_max_keypoints(s->ext[0]);
-  const int nslots = depth + 3;
+  const int nslots = depth + 4;
   s->slots.resize(nslots);
   for (int i = 0; i < nslots; i++) {
     Slot& sl = s->slots[i];
@@ -215,7 +250,7 @@ int orbfe_stream_create(int nfeatures, float scaleFactor, int nlevels, int iniTh
     s->freeQ.push_back(i);
   }
   s->tExtract = std::thread([s] { s->extractLoop(); });
-  s->tMatch = std::thread([s] { s->matchLoop(); });
+  for (int w = 0; w < nMatch; w++) s->tMatch.emplace_back([s, w] { s->matchLoop(w); });
   *out = s;
   return ORBFE_OK;
 }
@@ -228,9 +263,9 @@ void orbfe_stream_destroy(orbfe_stream* s) {
   }
   s->cv.notify_all();
   if (s->tExtract.joinable()) s->tExtract.join();
-  if (s->tMatch.joinable()) s->tMatch.join();
+  for (auto& t : s->tMatch) if (t.joinable()) t.join();
   for (auto* e : s->ext) orbfe_extractor_destroy(e);
-  orbfe_matcher_destroy(s->matcher);
+  for (auto* q : s->matchers) orbfe_matcher_destroy(q);
   delete s;
 }
 
@@ -261,8 +296,10 @@ int orbfe_stream_push(orbfe_stream* s, const uint8_t* const* gray, int in_device
   for (int i = 0; i < s->batch; i++) sl.frames[i] = gray[i];
   sl.rows = rows; sl.cols = cols; sl.stride = stride_bytes; sl.onDevice = in_device_memory;
   sl.status = ORBFE_OK;
+  sl.done = false;
   {
     std::lock_guard<std::mutex> lk(s->mu);
+    sl.seq = s->pushSeq++;
     s->extractQ.push_back(slot);
   }
   s->cv.notify_all();
@@ -280,9 +317,15 @@ int orbfe_stream_pop(orbfe_stream* s, const OrbfeKeyPoint** kps, const uint8_t**
       s->popped = -1;
       s->cv.notify_all();
     }
-    s->cv.wait(lk, [&] { return !s->doneQ.empty(); });
-    slot = s->doneQ.front();
-    s->doneQ.pop_front();
+    auto ready = [&]() -> int {
+      for (size_t i = 0; i < s->slots.size(); i++)
+        if (s->slots[i].done && s->slots[i].seq == s->popSeq) return (int)i;
+      return -1;
+    };
+    s->cv.wait(lk, [&] { return ready() >= 0; });
+    slot = ready();
+    s->slots[slot].done = false;
+    s->popSeq++;
     s->popped = slot;
   }
   Slot& sl = s->slots[slot];
@@ -293,6 +336,13 @@ int orbfe_stream_pop(orbfe_stream* s, const OrbfeKeyPoint** kps, const uint8_t**
   if (nmatches) *nmatches = sl.nm.data();
   if (sl.status != ORBFE_OK) set_err("%s", sl.err.c_str());
   return sl.status;
+}
+
+int orbfe_stream_stats(orbfe_stream* s, double out[4], int reset) {
+  if (!s || !out) { set_err("NULL argument"); return ORBFE_ERR_INVALID; }
+  out[0] = s->busySubmit; out[1] = s->busyCollect; out[2] = s->busyMatch; out[3] = (double)s->nBatches;
+  if (reset) { s->busySubmit = s->busyCollect = s->busyMatch = 0; s->nBatches = 0; }
+  return ORBFE_OK;
 }
 
 int orbfe_stream_kernel_ms(orbfe_stream* s, double out_ms[5], long long* batches, long long* frames, int reset) {
