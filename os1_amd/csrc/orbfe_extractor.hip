@@ -117,10 +117,7 @@ struct orbfe_extractor {
   int selPerFrame = 0;
   DevBuf<uint32_t> d_idxA, d_idxB, d_rank;
   DevBuf<uint16_t> d_ownA, d_ownB;
-  DevBuf<uint8_t> d_quad;
   DevBuf<QtNode> d_nodesA, d_nodesB;
-  DevBuf<QtTmp> d_qtmp;
-  DevBuf<int> d_proc;
   hipEvent_t evQt[2] = {};
   hipStream_t qtStream = nullptr;       // high-priority stream for the latency-bound quadtree kernel
   hipEvent_t evQtIn = nullptr, evQtOut = nullptr;
@@ -177,7 +174,7 @@ struct orbfe_extractor {
     if (evQtOut) (void)hipEventDestroy(evQtOut);
     if (qtStream) (void)hipStreamDestroy(qtStream);
     d_idxA.release(); d_idxB.release(); d_rank.release(); d_ownA.release(); d_ownB.release();
-    d_quad.release(); d_nodesA.release(); d_nodesB.release(); d_qtmp.release(); d_proc.release();
+    d_nodesA.release(); d_nodesB.release();
     if (evFrame0) (void)hipEventDestroy(evFrame0);
     for (auto& st : streams) if (st) (void)hipStreamDestroy(st);
   }
@@ -322,11 +319,8 @@ struct orbfe_extractor {
         if ((rc = d_rank.ensure(ce))) return rc;
         if ((rc = d_ownA.ensure(ce))) return rc;
         if ((rc = d_ownB.ensure(ce))) return rc;
-        if ((rc = d_quad.ensure(ce))) return rc;
         if ((rc = d_nodesA.ensure(nn))) return rc;
         if ((rc = d_nodesB.ensure(nn))) return rc;
-        if ((rc = d_qtmp.ensure(nn))) return rc;
-        if ((rc = d_proc.ensure(nn))) return rc;
       }
       batchCap = nframes;
       if (candHostCap == 0) candHostCap = 96 * 1024;
@@ -386,8 +380,8 @@ struct orbfe_extractor {
     launch_compact(P, nframes, st);
     if (prof) HIP_TRY(hipEventRecord(ev[0][3], st));
     QP.cand = d_cand.p; QP.levelStart = d_levelStart.p; QP.candCap = P.candCap; QP.nlevels = nlevels; QP.frameBase = 0;
-    QP.idxA = d_idxA.p; QP.idxB = d_idxB.p; QP.ownA = d_ownA.p; QP.ownB = d_ownB.p; QP.quad = d_quad.p; QP.rank = d_rank.p;
-    QP.nodesA = d_nodesA.p; QP.nodesB = d_nodesB.p; QP.tmp = d_qtmp.p; QP.proc = d_proc.p;
+    QP.idxA = d_idxA.p; QP.idxB = d_idxB.p; QP.ownA = d_ownA.p; QP.ownB = d_ownB.p; QP.rank = d_rank.p;
+    QP.nodesA = d_nodesA.p; QP.nodesB = d_nodesB.p;
     QP.sel = d_sel.p; QP.selCount = d_selCount.p; QP.selPerFrame = selPerFrame;
     for (int l = 0; l < nlevels; l++) {
       QP.levW[l] = P.lv[l].w; QP.levH[l] = P.lv[l].h; QP.nfeat[l] = nfeat[l]; QP.selOff[l] = selOff[l];

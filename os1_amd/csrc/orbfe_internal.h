@@ -56,21 +56,12 @@ struct SelKp {
 };
 
 // ---- GPU quadtree (orbfe_quadtree.hip) -------------------------------------------------------------
-constexpr int kQtThreads = 1024;
 constexpr int kQtNodeCap = 2048;  // live nodes <= N + 3  =>  N <= 2044 per level
 
 struct QtNode {
   short x0, x1, y0, y1;    // UL.x, UR.x, UL.y, BL.y
   uint32_t begin, end;     // candidate positions (relative to the level's first candidate)
   uint32_t seq;            // creation order
-};
-
-struct QtTmp {
-  uint32_t baseS[4];       // exclusive per-quadrant scan value at the node's first position
-  uint32_t endS[4];        // inclusive per-quadrant scan value at the node's last position
-  int childPos[4];         // new list position of child q (-1: empty)
-  int newPos;              // new list position if the node is kept
-  int t;                   // index in processing order (-1: not divided this pass)
 };
 
 struct QtParams {
@@ -81,16 +72,13 @@ struct QtParams {
   int levW[kMaxLevels], levH[kMaxLevels], nfeat[kMaxLevels];
   int selOff[kMaxLevels];      // first slot of the level inside a frame's selection region
   int selPerFrame;
-  uint32_t* idxA;              // [nframes][candCap] candidate index per position (ping)
-  uint32_t* idxB;              //                                               (pong)
+  uint32_t* idxA;              // [nframes][candCap] packed candidate word per position (ping)
+  uint32_t* idxB;              //                                                     (pong)
   uint16_t* ownA;              // [nframes][candCap] owning node (= list position) per position
   uint16_t* ownB;
-  uint8_t* quad;               // [nframes][candCap] quadrant of the element in its node
-  uint32_t* rank;              // [nframes][candCap] exclusive scan value of the element's quadrant
-  QtNode* nodesA;              // [nframes][nlevels][kQtNodeCap]
+  uint32_t* rank;              // [nframes][candCap] exclusive quadrant scan value | quadrant << 30
+  QtNode* nodesA;              // [nframes][nlevels][kQtNodeCap] (used when the tables do not fit in LDS)
   QtNode* nodesB;
-  QtTmp* tmp;                  // [nframes][nlevels][kQtNodeCap]
-  int* proc;                   // [nframes][nlevels][kQtNodeCap] node ids in processing order
   SelKp* sel;                  // [nframes][selPerFrame]
   uint32_t* selCount;          // [nframes][kMaxLevels]
 };

@@ -146,46 +146,15 @@ __device__ __forceinline__ u16x2 as_u16x2(unsigned v) { return __builtin_bit_cas
 __device__ __forceinline__ unsigned as_u32(u16x2 v) { return __builtin_bit_cast(unsigned, v); }
 __device__ __forceinline__ s16x2 as_s16x2(unsigned v) { return __builtin_bit_cast(s16x2, v); }
 
-__device__ __forceinline__ bool has_arc9(unsigned m) {  // 9 contiguous set bits in a circular 16-bit mask
-  m |= m << 16;
-  m &= m >> 1;
-  m &= m >> 2;
-  m &= m >> 4;
-  m &= m >> 1;
-  return m != 0;
-}
-
-// max over the 16 arcs of the minimum of 9 consecutive values (circular)
-__device__ __forceinline__ int max_arc_min9(const int d[16]) {
-  int m2[16], m4[16], m8[16];
-#pragma unroll
-  for (int k = 0; k < 16; k++) m2[k] = min(d[k], d[(k + 1) & 15]);
-#pragma unroll
-  for (int k = 0; k < 16; k++) m4[k] = min(m2[k], m2[(k + 2) & 15]);
-#pragma unroll
-  for (int k = 0; k < 16; k++) m8[k] = min(m4[k], m4[(k + 4) & 15]);
-  int best = -256;
-#pragma unroll
-  for (int k = 0; k < 16; k++) best = max(best, min(m8[k], d[(k + 8) & 15]));
-  return best;
-}
-
 // Work decomposition inside the wave (all stages keep row-major order, so the final list is already
 // in cv::FAST's emission order):
-//   stage 1  every emit pixel: 4-point compass pre-test (a 9-arc always contains two ADJACENT compass
-//            points of the same polarity) -> ballot-compacted queue of survivors
-//   stage 2  queue: full 16-point arc test at tlo = min(iniTh, minTh) -> compacted in place
-//   stage 3  queue: score S-1 (only the polarity that passed) -> score tile
-//   stage 4  queue: 3x3 NMS against the score tile, iniTh/minTh decision by ballot, ordered write
+//   stage 1  every emit pixel, 4 per lane: compass pre-test (a 9-arc always contains two ADJACENT
+//            compass points of one polarity) on packed 16-bit lanes -> ballot-compacted queue
+//   stage 2  queue: S = max over both polarities of max_arc min9, both polarities per packed op;
+//            S > tlo keeps the entry (compacted in place) and writes the score S-1 to the score tile
+//   stage 3  queue: 3x3 NMS against the score tile, iniTh/minTh decision by ballot, ordered write
 // Blocks are remapped so that the blocks an XCD receives (b, b+8, b+16, ...) are CONSECUTIVE cells:
 // neighbouring cells share ROI halos and cache lines in that XCD's L2.
-__device__ __forceinline__ void ring_diffs(const uint8_t* c, int TP, int v, int d[16]) {
-  d[0] = v - c[3 * TP];       d[1] = v - c[3 * TP + 1];   d[2] = v - c[2 * TP + 2];   d[3] = v - c[TP + 3];
-  d[4] = v - c[3];            d[5] = v - c[-TP + 3];      d[6] = v - c[-2 * TP + 2];  d[7] = v - c[-3 * TP + 1];
-  d[8] = v - c[-3 * TP];      d[9] = v - c[-3 * TP - 1];  d[10] = v - c[-2 * TP - 2]; d[11] = v - c[-TP - 3];
-  d[12] = v - c[-3];          d[13] = v - c[TP - 3];      d[14] = v - c[2 * TP - 2];  d[15] = v - c[3 * TP - 1];
-}
-
 __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
   extern __shared__ __align__(16) uint8_t lds[];
   const int chunk = (P.ncells + 7) >> 3;
@@ -220,7 +189,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
   uint8_t* tile = lds;
   uint8_t* sc = tile + TP * (L.hCell + 6);
   uint16_t* queue = reinterpret_cast<uint16_t*>(lds + ((TP * (L.hCell + 6) + SP * (L.hCell + 2) + 3) & ~3));
-  uint8_t* kept = lds;  // stage 4 only: aliases the ROI tile, which is dead after stage 3 (TP*(hCell+6) >= wCell*hCell)
+  uint8_t* kept = lds;  // stage 3 only: aliases the ROI tile, which is dead after stage 2 (TP*(hCell+6) >= wCell*hCell)
 
   const int rw = ew + 6, rh = eh + 6;
   const int istr = (int)stride;
@@ -404,7 +373,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
     nq2 += __popcll(m);
   }
   __syncthreads();
-  // ---- stage 4: NMS inside the emit region, threshold decision, ordered emission ----------------
+  // ---- stage 3: NMS inside the emit region, threshold decision, ordered emission ----------------
   bool anyIni = false;
   for (int i0 = 0; i0 < nq2; i0 += 64) {
     const int i = i0 + lane;
@@ -508,7 +477,6 @@ __global__ __launch_bounds__(64) void k_gather(PyramidParams P) {
 __constant__ int8_t c_pattern[1024] = {
 #include "brief_pattern.inc"
 };
-__constant__ int c_umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {  // cv::fastAtan2, SURVEY.md B.4
   const float scale = (float)(180 / 3.1415926535897932384626433832795);

@@ -2,8 +2,8 @@
 //
 // Behaviour contract: ORBextractor::DistributeOctTree + ExtractorNode::DivideNode of the reference
 // (src/ORBextractor.cc:513-569, 571-795), same tie-break convention as quadtree.h / the oracle
-// (equal-sized nodes: later-created first).  One 1024-thread workgroup per
-// (frame, level) problem; problems of a batch run concurrently on different CUs.
+// (equal-sized nodes: later-created first).  One workgroup per
+// (frame, level) problem (k_quadtree2, 512 threads); problems of a batch run concurrently on different CUs.
 //
 // The reference algorithm is a sequential walk over a std::list, but its result is a pure
 // function of three orderings, all of which can be produced with scans and one sort:
@@ -26,437 +26,14 @@
 
 namespace orbfe {
 
-// ---- block primitives (1024 threads = 16 waves) ---------------------------------------------------
-struct QtShared {
-  unsigned long long wsumA[16], wsumB[16];
-  int wsumI[16];
-  unsigned long long sortKeys[kQtNodeCap];
-  int s_int[8];
-};
-
-__device__ __forceinline__ unsigned long long shfl_up_u64(unsigned long long v, int o) {
-  const unsigned lo = __shfl_up((unsigned)v, o, 64), hi = __shfl_up((unsigned)(v >> 32), o, 64);
-  return ((unsigned long long)hi << 32) | lo;
-}
-
-// exclusive block scan of two packed u64 (each 2 x 32-bit counters); returns totals through tot*
-__device__ void blockScan2(QtShared& sh, unsigned long long a, unsigned long long b, unsigned long long& ea,
-                           unsigned long long& eb, unsigned long long& totA, unsigned long long& totB) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  unsigned long long ia = a, ib = b;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const unsigned long long ta = shfl_up_u64(ia, o), tb = shfl_up_u64(ib, o);
-    if (lane >= o) { ia += ta; ib += tb; }
-  }
-  __syncthreads();
-  if (lane == 63) { sh.wsumA[wv] = ia; sh.wsumB[wv] = ib; }
-  __syncthreads();
-  unsigned long long ba = 0, bb = 0, ta = 0, tb = 0;
-  for (int w = 0; w < 16; w++) {
-    if (w < wv) { ba += sh.wsumA[w]; bb += sh.wsumB[w]; }
-    ta += sh.wsumA[w];
-    tb += sh.wsumB[w];
-  }
-  ea = ba + ia - a;
-  eb = bb + ib - b;
-  totA = ta;
-  totB = tb;
-}
-
-__device__ int blockScanInt(QtShared& sh, int v, int& total) {  // exclusive
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int iv = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(iv, o, 64);
-    if (lane >= o) iv += t;
-  }
-  __syncthreads();
-  if (lane == 63) sh.wsumI[wv] = iv;
-  __syncthreads();
-  int base = 0, tot = 0;
-  for (int w = 0; w < 16; w++) {
-    if (w < wv) base += sh.wsumI[w];
-    tot += sh.wsumI[w];
-  }
-  total = tot;
-  return base + iv - v;
-}
-
-// bitonic sort, descending, of sh.sortKeys[0..n) (n <= kQtNodeCap); pads with 0
-__device__ void blockSortDesc(QtShared& sh, int n) {
-  int m = 1;
-  while (m < n) m <<= 1;
-  for (int i = n + threadIdx.x; i < m; i += kQtThreads) sh.sortKeys[i] = 0ull;
-  __syncthreads();
-  for (int k = 2; k <= m; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = threadIdx.x; i < m; i += kQtThreads) {
-        const int p = i ^ j;
-        if (p > i) {
-          const unsigned long long a = sh.sortKeys[i], b = sh.sortKeys[p];
-          const bool desc = ((i & k) == 0);
-          if (desc ? (a < b) : (a > b)) { sh.sortKeys[i] = b; sh.sortKeys[p] = a; }
-        }
-      }
-      __syncthreads();
-    }
-  }
-}
-
-__global__ __launch_bounds__(kQtThreads) void k_quadtree(QtParams Q) {
-  __shared__ QtShared sh;
-  const int level = blockIdx.x, f = Q.frameBase + blockIdx.y, tid = threadIdx.x;
-  const uint32_t* ls = Q.levelStart + (long long)f * (kMaxLevels + 1);
-  const uint32_t first = ls[level];
-  const int n = (int)(ls[level + 1] - first);
-  const int N = Q.nfeat[level];
-  uint32_t* selCount = Q.selCount + (long long)f * kMaxLevels + level;
-  SelKp* selOut = Q.sel + (long long)f * Q.selPerFrame + Q.selOff[level];
-  if (n <= 0) {
-    if (tid == 0) *selCount = 0;
-    return;
-  }
-  const long long eo = (long long)f * Q.candCap + first;  // element arrays of this problem
-  const uint32_t* cand = Q.cand + eo;
-  uint32_t* idxCur = Q.idxA + eo;
-  uint32_t* idxNxt = Q.idxB + eo;
-  uint16_t* ownCur = Q.ownA + eo;
-  uint16_t* ownNxt = Q.ownB + eo;
-  uint8_t* quad = Q.quad + eo;
-  uint32_t* rank = Q.rank + eo;
-  const long long no = ((long long)f * Q.nlevels + level) * kQtNodeCap;
-  QtNode* cur = Q.nodesA + no;
-  QtNode* nxt = Q.nodesB + no;
-  QtTmp* tmp = Q.tmp + no;
-  int* proc = Q.proc + no;
-
-  const int minX = kBorder, minY = kBorder, maxX = Q.levW[level] - kBorder, maxY = Q.levH[level] - kBorder;
-  const int chunk = (n + kQtThreads - 1) / kQtThreads;
-  const int p0 = min(tid * chunk, n), p1 = min(p0 + chunk, n);
-
-  // ---- roots (ORBextractor.cc:574-617): class = root index, stable; at most 4 roots ------------------
-  const int nIni = (int)roundf(static_cast<float>(maxX - minX) / (maxY - minY));
-  const float hX = static_cast<float>(maxX - minX) / nIni;
-  int m = 0;  // live nodes
-  uint32_t seq = 0;
-  {
-    unsigned long long a = 0, b = 0;
-    for (int p = p0; p < p1; p++) {
-      const int x = (int)(cand[p] & 0xfff) - kBorder;
-      int r = (int)((float)x / hX);
-      r = min(r, nIni - 1);
-      quad[p] = (uint8_t)r;
-      if (r == 0) a += 1ull; else if (r == 1) a += 1ull << 32; else if (r == 2) b += 1ull; else b += 1ull << 32;
-    }
-    unsigned long long ea, eb, ta, tb;
-    blockScan2(sh, a, b, ea, eb, ta, tb);
-    const uint32_t cnt[4] = {(uint32_t)ta, (uint32_t)(ta >> 32), (uint32_t)tb, (uint32_t)(tb >> 32)};
-    uint32_t start[4], run[4] = {(uint32_t)ea, (uint32_t)(ea >> 32), (uint32_t)eb, (uint32_t)(eb >> 32)};
-    start[0] = 0; start[1] = cnt[0]; start[2] = cnt[0] + cnt[1]; start[3] = cnt[0] + cnt[1] + cnt[2];
-    int rootId[4], nr = 0;
-    for (int r = 0; r < 4; r++) rootId[r] = (r < nIni && cnt[r] > 0) ? nr++ : -1;
-    for (int p = p0; p < p1; p++) {
-      const int r = quad[p];
-      const uint32_t np = start[r] + run[r]++;
-      idxCur[np] = (uint32_t)p;
-      ownCur[np] = (uint16_t)rootId[r];
-    }
-    if (tid < 4 && tid < nIni && cnt[tid] > 0) {
-      QtNode nd;
-      nd.x0 = (short)(int)(hX * static_cast<float>(tid));
-      nd.x1 = (short)(int)(hX * static_cast<float>(tid + 1));
-      nd.y0 = 0;
-      nd.y1 = (short)(maxY - minY);
-      nd.begin = start[tid];
-      nd.end = start[tid] + cnt[tid];
-      nd.seq = (uint32_t)tid;
-      cur[rootId[tid]] = nd;
-    }
-    m = nr;
-    seq = (uint32_t)nIni;
-    __syncthreads();
-  }
-
-  // ---- main loop ------------------------------------------------------------------------------------
-  bool finalPhase = false;
-  int nRec = 0;           // final phase: number of recorded nodes (sh.sortKeys holds them)
-  for (int iter = 0; iter < 64; iter++) {
-    const int prevSize = m;
-    // processing order
-    int nproc = 0;
-    if (!finalPhase) {
-      // every node with more than one candidate, in list order
-      int flag[2], loc = 0;
-      for (int k = 0; k < 2; k++) {
-        const int i = 2 * tid + k;
-        flag[k] = (i < m && cur[i].end - cur[i].begin > 1) ? 1 : 0;
-        loc += flag[k];
-      }
-      int tot;
-      int ex = blockScanInt(sh, loc, tot);
-      for (int k = 0; k < 2; k++) {
-        const int i = 2 * tid + k;
-        if (i < m) {
-          tmp[i].t = flag[k] ? ex : -1;
-          if (flag[k]) proc[ex++] = i;
-        }
-      }
-      nproc = tot;
-    } else {
-      // recorded nodes sorted by (size desc, creation desc): key = size<<40 | seq<<16 | id
-      blockSortDesc(sh, nRec);
-      for (int i = tid; i < m; i += kQtThreads) tmp[i].t = -1;
-      __syncthreads();
-      for (int t = tid; t < nRec; t += kQtThreads) {
-        const int id = (int)(sh.sortKeys[t] & 0xffff);
-        proc[t] = id;
-        tmp[id].t = t;
-      }
-      nproc = nRec;
-    }
-    __syncthreads();
-    if (nproc == 0) break;  // nothing can be divided: size unchanged => finish
-
-    // ---- element pass 1: quadrant + segmented scan ------------------------------------------------
-    {
-      unsigned long long a = 0, b = 0;
-      for (int p = p0; p < p1; p++) {
-        const int o = ownCur[p];
-        int q = 4;
-        if (tmp[o].t >= 0) {
-          const QtNode nd = cur[o];
-          const int midX = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), midY = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
-          const uint32_t c = cand[idxCur[p]];
-          const int x = (int)(c & 0xfff) - kBorder, y = (int)((c >> 12) & 0xfff) - kBorder;
-          q = (x < midX ? 0 : 1) + (y < midY ? 0 : 2);
-          if (q == 0) a += 1ull; else if (q == 1) a += 1ull << 32; else if (q == 2) b += 1ull; else b += 1ull << 32;
-        }
-        quad[p] = (uint8_t)q;
-      }
-      unsigned long long ea, eb, ta, tb;
-      blockScan2(sh, a, b, ea, eb, ta, tb);
-      uint32_t run[4] = {(uint32_t)ea, (uint32_t)(ea >> 32), (uint32_t)eb, (uint32_t)(eb >> 32)};
-      for (int p = p0; p < p1; p++) {
-        const int q = quad[p];
-        if (q == 4) continue;
-        const int o = ownCur[p];
-        const QtNode nd = cur[o];
-        if ((uint32_t)p == nd.begin) {
-          tmp[o].baseS[0] = run[0]; tmp[o].baseS[1] = run[1]; tmp[o].baseS[2] = run[2]; tmp[o].baseS[3] = run[3];
-        }
-        rank[p] = run[q]++;
-        if ((uint32_t)p == nd.end - 1) {
-          tmp[o].endS[0] = run[0]; tmp[o].endS[1] = run[1]; tmp[o].endS[2] = run[2]; tmp[o].endS[3] = run[3];
-        }
-      }
-    }
-    __syncthreads();
-
-    // ---- node pass: children counts, cut (final phase), new list positions -------------------------
-    int C[2] = {0, 0}, E[2] = {0, 0}, locC = 0, locGrow = 0;
-    for (int k = 0; k < 2; k++) {
-      const int t = 2 * tid + k;
-      if (t < nproc) {
-        const QtTmp& tm = tmp[proc[t]];
-        for (int q = 0; q < 4; q++) {
-          const uint32_t c = tm.endS[q] - tm.baseS[q];
-          C[k] += c > 0;
-          E[k] += c > 1;
-        }
-        locC += C[k];
-        locGrow += C[k] - 1;
-      }
-    }
-    int totC, totGrow;
-    int exC = blockScanInt(sh, locC, totC);
-    int exGrow = blockScanInt(sh, locGrow, totGrow);
-    // cut: smallest t with prevSize + sum_{t' <= t}(C-1) >= N (final phase only)
-    int cutT = nproc - 1;
-    if (finalPhase) {
-      if (tid == 0) sh.s_int[0] = nproc - 1;
-      __syncthreads();
-      int g = exGrow;
-      for (int k = 0; k < 2; k++) {
-        const int t = 2 * tid + k;
-        if (t < nproc) {
-          g += C[k] - 1;
-          if (prevSize + g >= N) atomicMin(&sh.s_int[0], t);
-        }
-      }
-      __syncthreads();
-      cutT = sh.s_int[0];
-    }
-    // T = children created = prefix of C up to the cut
-    if (tid == 0) sh.s_int[1] = 0;
-    __syncthreads();
-    {
-      int pc = exC;
-      for (int k = 0; k < 2; k++) {
-        const int t = 2 * tid + k;
-        if (t < nproc) {
-          if (t == cutT) sh.s_int[1] = pc + C[k];
-          pc += C[k];
-        }
-      }
-    }
-    __syncthreads();
-    const int T = sh.s_int[1];
-    // kept nodes: not processed (or beyond the cut), in list order, after the T children
-    int keptFlag[2], locK = 0;
-    for (int k = 0; k < 2; k++) {
-      const int i = 2 * tid + k;
-      keptFlag[k] = 0;
-      if (i < m) {
-        const int t = tmp[i].t;
-        keptFlag[k] = (t < 0 || t > cutT) ? 1 : 0;
-      }
-      locK += keptFlag[k];
-    }
-    int totK;
-    int exK = blockScanInt(sh, locK, totK);
-    const int mNew = T + totK;
-    // write children + kept nodes into nxt[] at their new list positions
-    {
-      int pc = exC;
-      for (int k = 0; k < 2; k++) {
-        const int t = 2 * tid + k;
-        if (t < nproc) {
-          const int id = proc[t];
-          if (t <= cutT) {
-            const QtNode nd = cur[id];
-            QtTmp& tm = tmp[id];
-            const int midX = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), midY = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
-            uint32_t c[4];
-            int nonEmptyAfter = 0;
-            for (int q = 0; q < 4; q++) c[q] = tm.endS[q] - tm.baseS[q];
-            // list position: children of later-processed parents come first; inside a parent n4..n1
-            const int groupBase = T - pc - C[k];
-            uint32_t b = nd.begin;
-            int before = 0;
-            for (int q = 0; q < 4; q++) nonEmptyAfter += c[q] > 0;
-            for (int q = 0; q < 4; q++) {
-              if (c[q] == 0) { tm.childPos[q] = -1; continue; }
-              nonEmptyAfter--;
-              const int pos = groupBase + nonEmptyAfter;
-              QtNode ch;
-              ch.x0 = (q & 1) ? (short)midX : nd.x0;
-              ch.x1 = (q & 1) ? nd.x1 : (short)midX;
-              ch.y0 = (q & 2) ? (short)midY : nd.y0;
-              ch.y1 = (q & 2) ? nd.y1 : (short)midY;
-              ch.begin = b;
-              ch.end = b + c[q];
-              ch.seq = seq + (uint32_t)(pc + before);
-              nxt[pos] = ch;
-              tm.childPos[q] = pos;
-              b += c[q];
-              before++;
-            }
-          } else {
-            tmp[id].t = -1;  // beyond the cut: not divided after all
-          }
-          pc += C[k];
-        }
-      }
-      for (int k = 0; k < 2; k++) {
-        const int i = 2 * tid + k;
-        if (i < m && keptFlag[k]) {
-          const int pos = T + exK++;
-          nxt[pos] = cur[i];
-          tmp[i].newPos = pos;
-        }
-      }
-    }
-    __syncthreads();
-
-    // ---- element pass 2: move candidates into their children, re-own -------------------------------
-    for (int p = p0; p < p1; p++) {
-      const int o = ownCur[p];
-      const QtTmp& tm = tmp[o];
-      if (tm.t >= 0) {
-        const int q = quad[p];
-        const int child = tm.childPos[q];
-        const uint32_t np = nxt[child].begin + (rank[p] - tm.baseS[q]);
-        idxNxt[np] = idxCur[p];
-        ownNxt[np] = (uint16_t)child;
-      } else {
-        idxNxt[p] = idxCur[p];
-        ownNxt[p] = (uint16_t)tm.newPos;
-      }
-    }
-    __syncthreads();
-    { uint32_t* t0 = idxCur; idxCur = idxNxt; idxNxt = t0; }
-    { uint16_t* t1 = ownCur; ownCur = ownNxt; ownNxt = t1; }
-    { QtNode* t2 = cur; cur = nxt; nxt = t2; }
-    m = mNew;
-    seq += (uint32_t)T;
-
-    // ---- record of nodes created in this pass with more than one candidate (positions [0,T)) --------
-    int recFlag[2], locR = 0;
-    for (int k = 0; k < 2; k++) {
-      const int i = 2 * tid + k;
-      recFlag[k] = (i < T && cur[i].end - cur[i].begin > 1) ? 1 : 0;
-      locR += recFlag[k];
-    }
-    int totR;
-    int exR = blockScanInt(sh, locR, totR);
-    for (int k = 0; k < 2; k++) {
-      const int i = 2 * tid + k;
-      if (recFlag[k]) {
-        const QtNode nd = cur[i];
-        sh.sortKeys[exR++] = ((unsigned long long)(nd.end - nd.begin) << 40) | ((unsigned long long)nd.seq << 16) |
-                             (unsigned long long)i;
-      }
-    }
-    nRec = totR;
-    __syncthreads();
-
-    // ---- stop rules (ORBextractor.cc:699-705, 766-767) ------------------------------------------------
-    if (m >= N || m == prevSize) break;
-    if (!finalPhase) {
-      if (m + 3 * totR > N) finalPhase = true;   // nToExpand == totR
-    }
-    if (finalPhase && nRec == 0) break;           // nothing left to divide: size would not change
-  }
-
-  // ---- one keypoint per node: highest response, first wins (ORBextractor.cc:774-792) ------------------
-  const int lane = tid & 63, wv = tid >> 6;
-  for (int i = wv; i < m; i += kQtThreads / 64) {
-    const QtNode nd = cur[i];
-    int bestScore = -1;
-    uint32_t bestPos = 0xffffffffu;
-    for (uint32_t p = nd.begin + lane; p < nd.end; p += 64) {
-      const int s = (int)(cand[idxCur[p]] >> 24);
-      if (s > bestScore) { bestScore = s; bestPos = p; }   // ascending p per lane: first max kept
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const int os = __shfl_xor(bestScore, o, 64);
-      const uint32_t op = __shfl_xor(bestPos, o, 64);
-      if (os > bestScore || (os == bestScore && op < bestPos)) { bestScore = os; bestPos = op; }
-    }
-    if (lane == 0) {
-      const uint32_t c = cand[idxCur[bestPos]];
-      SelKp s;
-      s.xy = (c & 0xfff) | (((c >> 12) & 0xfff) << 16);
-      s.lf = (uint32_t)level | ((uint32_t)f << 8) | ((c >> 24) << 24);   // score rides in the top byte
-      selOut[i] = s;
-    }
-  }
-  if (tid == 0) *selCount = (uint32_t)m;
-}
-
-// =====================================================================================================
-// k_quadtree2 -- same algorithm, restructured for latency and footprint (the v1 kernel above stays as the
-// reference implementation for A/B tests, ORBFE_QT_V1=1):
-//   * 512 threads / block, ~60 VGPRs: a block leaves most of its CU to the other batch's kernels;
-//   * candidates carry their packed (x, y, score) word, so no index indirection;
-//   * element passes are tile loops (one element per thread, coalesced), quadrant ranks by wave ballots
-//     + one block barrier per tile; per-node lookups (split point, child positions, range deltas, scan
-//     bases) live in LDS;
-//   * node passes unchanged in substance (processing order, cut, list positions).
-// =====================================================================================================
+// Implementation notes:
+//   * 512 threads / block: a block leaves most of its CU to the other in-flight batch's kernels;
+//   * candidates carry their packed (x, y, score) word, so there is no index indirection;
+//   * element passes are tile loops (4 elements per thread and step, coalesced, independent loads in
+//     flight together); quadrant ranks come from wave ballots + one block barrier per step;
+//   * per-node lookups (split point, child positions, range deltas, scan bases, the node tables
+//     themselves when CAP = 1024) live in LDS;
+//   * node passes: processing order (scan / bitonic sort), cut (prefix sum), list positions (scans).
 constexpr int kQt2Threads = 512;
 
 template <int CAP>
@@ -929,11 +506,6 @@ __global__ __launch_bounds__(kQt2Threads) void k_quadtree2(QtParams Q) {
 }
 
 void launch_quadtree(const QtParams& Q, int nframes, hipStream_t st) {
-  static const bool v1 = getenv("ORBFE_QT_V1") && atoi(getenv("ORBFE_QT_V1")) != 0;
-  if (v1) {
-    hipLaunchKernelGGL(k_quadtree, dim3(Q.nlevels, nframes), dim3(kQtThreads), 0, st, Q);
-    return;
-  }
   int maxN = 0;
   for (int l = 0; l < Q.nlevels; l++) maxN = Q.nfeat[l] > maxN ? Q.nfeat[l] : maxN;
   if (maxN + 4 <= 1024)

@@ -226,7 +226,7 @@ def test_host_and_gpu_quadtree_paths_agree(api, oracle, monkeypatch):
     rng = np.random.default_rng(17)
     imgs = [synth(40, 1280, 720), rng.integers(0, 256, (600, 800), dtype=np.uint8),
             (((np.mgrid[0:480, 0:640][0] // 9) + (np.mgrid[0:480, 0:640][1] // 7)) % 2 * 200 + 20).astype(np.uint8)]
-    for N in (2000, 137, 4000):
+    for N in (2000, 137, 6000):          # 6000 -> 1300 features on level 0: the 2048-node quadtree variant
         ox = OracleExtractor(N, 1.2, 8, 20, 7, oracle)
         monkeypatch.setenv('ORBFE_HOST_QUADTREE', '1')
         ex_host = api.Extractor(N, 1.2, 8, 20, 7)
