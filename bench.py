@@ -74,6 +74,7 @@ def main():
     bounds = (0.0, float(W), 0.0, float(H))
     st.set_matching(bounds, 0 if args.no_match else 100, 0.9, True)   # window 100, nnratio 0.9, checkOrientation
     nmatch_total = [0]
+    pop_times = []
 
     def run(nsteps):
         """nsteps passes of the hot path: push a batch (async extraction on the GPU, then SearchForInitialization
@@ -85,6 +86,7 @@ def main():
             pushed += 1
         for _ in range(nsteps):
             _, _, n, _, nm = st.pop()
+            pop_times.append(time.perf_counter())
             nmatch_total[0] += int(nm.sum())
             if pushed < nsteps:
                 st.push_ptrs(dev.ptrs, H, W, dev.stride, True)
@@ -96,6 +98,7 @@ def main():
             torch.cuda.synchronize()
 
     run(args.warmup)
+    del pop_times[:]
     st.kernel_ms(reset=True)
     st.stats(reset=True)
     nmatch_total[0] = 0
@@ -151,6 +154,8 @@ def main():
                        'input': 'frames resident in HBM; keypoints/descriptors/matches returned to host'},
             'gpu_kernel_ms_per_frame': {k: round(v / max(kframes, 1), 5) for k, v in
                                         zip(('pyramid', 'fast_cells', 'compaction', 'describe', 'quadtree'), kms)},
+            'ms_per_step_percentiles': (lambda d: {'p10': round(float(np.percentile(d, 10)), 4), 'p50': round(float(np.percentile(d, 50)), 4),
+                                                    'p90': round(float(np.percentile(d, 90)), 4), 'max': round(float(d.max()), 4)})(np.diff(np.array(pop_times)) * 1e3) if len(pop_times) > 2 else None,
             'host_worker_ms_per_step': {'submit': round(wstats[0] / max(wstats[3], 1), 4), 'collect_incl_gpu_wait': round(wstats[1] / max(wstats[3], 1), 4),
                                         'match': round(wstats[2] / max(wstats[3], 1), 4)},
             'roofline': {'kernel': 'k_fast_cells', 'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,

@@ -93,37 +93,42 @@ __device__ __forceinline__ int hamming256(const uint32_t* __restrict__ a, const 
   return d;
 }
 
-// One wave per query, one LANE per grid column of the window.  Window semantics:
-// Frame::GetFeaturesInArea, Frame.cc:209-262: columns ix ascending, rows iy ascending inside a column,
-// insertion order inside a cell -- i.e. for column ix the contiguous run
-// [cellStart[ix*48+cy0], cellStart[ix*48+cy1+1]) of the cell-sorted keypoint table.  Lane l walks the
-// run of column cx0+l (a handful of entries), a wave prefix sum over the per-lane hit counts gives
-// every lane its output offset, so the candidate list comes out in exactly the reference order in a
-// single pass with all columns in flight at once.
+// LPQ lanes per query (64/LPQ queries per wave), one LANE per grid column of the window.  Window
+// semantics: Frame::GetFeaturesInArea, Frame.cc:209-262: columns ix ascending, rows iy ascending inside a
+// column, insertion order inside a cell -- i.e. for column ix the contiguous run
+// [cellStart[ix*48+cy0], cellStart[ix*48+cy1+1]) of the cell-sorted keypoint table.  Lane l of a query's
+// group walks the run of column cx0+l (a handful of entries), a prefix sum over the group's hit counts
+// gives every lane its output offset, so the candidate list comes out in exactly the reference order in
+// a single pass with all columns in flight at once.  The host picks LPQ >= the widest window in columns.
+template <int LPQ>
 __global__ __launch_bounds__(64) void k_window_match(MatchParams M) {
-  const int q = blockIdx.x;
   const int lane = threadIdx.x;
-  const float r = M.qr[q];
-  if (!(r >= 0.f)) {  // inactive query
-    if (lane == 0) { M.qcount[q] = 0; M.qoff[q] = 0; }
-    return;
+  const int sub = lane & (LPQ - 1);
+  const int q = blockIdx.x * (64 / LPQ) + lane / LPQ;
+  const bool live = q < M.nq;
+  float r = -1.f, x = 0.f, y = 0.f;
+  int minL = 0, maxL = -1;
+  PairInfo pi = M.pairs[0];
+  if (live) {
+    r = M.qr[q]; x = M.qx[q]; y = M.qy[q]; minL = M.qminL[q]; maxL = M.qmaxL[q];
+    pi = M.pairs[M.qpair[q]];
   }
-  const PairInfo pi = M.pairs[M.qpair[q]];
   const float* sx = M.sx + pi.trainOff;
   const float* sy = M.sy + pi.trainOff;
   const int* soct = M.soct + pi.trainOff;
   const int* sidx = M.sidx + pi.trainOff;
   const int* cellStart = M.cellStart + pi.cellOff;
   const uint8_t* tdesc = M.tdesc + (size_t)pi.tdescOff * 32;
-  const float x = M.qx[q], y = M.qy[q];
-  int cx0 = max(0, (int)floorf((x - pi.minX - r) * pi.invW));
-  int cx1 = min(kGridCols - 1, (int)ceilf((x - pi.minX + r) * pi.invW));
-  const int cy0 = max(0, (int)floorf((y - pi.minY - r) * pi.invH));
-  const int cy1 = min(kGridRows - 1, (int)ceilf((y - pi.minY + r) * pi.invH));
-  if (cx0 >= kGridCols || cx1 < 0 || cy0 >= kGridRows || cy1 < 0) cx1 = cx0 - 1;  // empty window
-  const int minL = M.qminL[q], maxL = M.qmaxL[q];
+  int cx0 = 0, cx1 = -1, cy0 = 0, cy1 = -1;
+  if (live && r >= 0.f) {
+    cx0 = max(0, (int)floorf((x - pi.minX - r) * pi.invW));
+    cx1 = min(kGridCols - 1, (int)ceilf((x - pi.minX + r) * pi.invW));
+    cy0 = max(0, (int)floorf((y - pi.minY - r) * pi.invH));
+    cy1 = min(kGridRows - 1, (int)ceilf((y - pi.minY + r) * pi.invH));
+    if (cx0 >= kGridCols || cx1 < 0 || cy0 >= kGridRows || cy1 < 0) cx1 = cx0 - 1;  // empty window
+  }
   const bool checkLevels = (minL > 0) || (maxL >= 0);
-  const int ix = cx0 + lane;  // at most 64 columns exist, so one lane per column always suffices
+  const int ix = cx0 + sub;
   int b = 0, e1 = 0;
   if (ix <= cx1) {
     b = cellStart[ix * kGridRows + cy0];
@@ -138,24 +143,23 @@ __global__ __launch_bounds__(64) void k_window_match(MatchParams M) {
     const float dx = sx[e] - x, dy = sy[e] - y;
     return fabsf(dx) < r && fabsf(dy) < r;
   };
-  // pass 1: hits per column
+  // pass 1: hits per column, prefix sum inside the query's lane group
   int hits = 0;
   for (int e = b; e < e1; e++) hits += inWindow(e) ? 1 : 0;
   int incl = hits;
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += t;
+  for (int o = 1; o < LPQ; o <<= 1) {
+    const int t = __shfl_up(incl, o, LPQ);
+    if (sub >= o) incl += t;
   }
-  const uint32_t count = (uint32_t)__shfl(incl, 63, 64);
+  const uint32_t count = (uint32_t)__shfl(incl, LPQ - 1, LPQ);
   uint32_t off = 0;
-  if (lane == 0) {
+  if (live && sub == 0) {
     if (count) off = atomicAdd(M.total, count);
     M.qcount[q] = count;
     M.qoff[q] = off;
   }
-  if (count == 0) return;
-  off = __shfl(off, 0, 64);
+  off = __shfl(off, 0, LPQ);
   if (hits == 0) return;
   uint32_t qd[8];
   const uint32_t* qp = reinterpret_cast<const uint32_t*>(M.qdesc + (size_t)q * 32);
@@ -297,6 +301,15 @@ struct orbfe_matcher {
       pl.nTrain = cnt;   // upper bound (keypoints outside the grid are dropped below)
       nTrain += cnt;
     }
+    int maxCols = 1;
+    for (int j = 0; j < njobs; j++) {
+      const Job& J = jobs[j];
+      const float invW = static_cast<float>(kGridCols) / static_cast<float>(J.bounds[1] - J.bounds[0]);
+      float rmax = 0.f;
+      for (int q = 0; q < J.nq; q++) rmax = std::max(rmax, J.qr[q]);
+      const float cols = 2.f * rmax * invW + 3.f;
+      maxCols = std::max(maxCols, cols >= 64.f ? 64 : (int)std::ceil(cols));
+    }
     jobQ0[njobs] = (int)nqOrig;
     qcountFull.assign(nqOrig, 0);
     qoffFull.assign(nqOrig, 0);
@@ -392,7 +405,16 @@ struct orbfe_matcher {
       M.nq = (int)nq;
       M.total = d_out.p; M.qcount = d_out.p + 64; M.qoff = d_out.p + 64 + nq;
       M.pool = d_pool.p; M.poolCap = (uint32_t)d_pool.n;
-      hipLaunchKernelGGL(k_window_match, dim3((unsigned)nq), dim3(64), 0, stream, M);
+      {
+        // widest window in grid columns over all active queries (+3: floor/ceil slack of the cell range)
+        int lpq = 8;
+        while (lpq < 64 && lpq < maxCols) lpq <<= 1;
+        const unsigned nblk = (unsigned)((nq + (64 / lpq) - 1) / (64 / lpq));
+        if (lpq == 8) hipLaunchKernelGGL(k_window_match<8>, dim3(nblk), dim3(64), 0, stream, M);
+        else if (lpq == 16) hipLaunchKernelGGL(k_window_match<16>, dim3(nblk), dim3(64), 0, stream, M);
+        else if (lpq == 32) hipLaunchKernelGGL(k_window_match<32>, dim3(nblk), dim3(64), 0, stream, M);
+        else hipLaunchKernelGGL(k_window_match<64>, dim3(nblk), dim3(64), 0, stream, M);
+      }
       HIP_TRY(hipGetLastError());
       HIP_TRY(hipMemcpyAsync(h_out.p, d_out.p, outWords * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
       // optimistic: fetch a generous prefix of the pool in the same round trip
