@@ -42,6 +42,8 @@ def main():
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if 'ORBFE_BENCH_DEVICE' in os.environ:          # testing aid: run several ranks on one GPU
+        local_rank = int(os.environ['ORBFE_BENCH_DEVICE'])
     world = int(os.environ.get('WORLD_SIZE', '1'))
 
     # torch first (it carries its own HIP runtime; loading it after liborbfe has initialised HIP

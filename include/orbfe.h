@@ -260,6 +260,12 @@ int orbfe_search_by_projection_uv(orbfe_matcher* m, const OrbfeKeyPoint* kps_un,
  * [2] sequential bookkeeping (resolve). */
 int orbfe_debug_matcher_ms(const orbfe_matcher* m, double out[3]);
 
+/* void Frame::antidistorsionarProyeccionEquidistante(cv::Mat& puntos)  (src/Frame.cc:355-384): os1's
+ * equidistant-fisheye keypoint undistortion (camera `modo: 1`), used by Frame::UndistortKeyPoints (:286-320) and
+ * Frame::ComputeImageBounds (:322-353).  Host double-precision math on n (x, y) float pairs, in place; K is the
+ * float intrinsic matrix {fx, fy, cx, cy}.  (Microseconds of scalar work per frame: it stays on the host.) */
+int orbfe_undistort_equidistant(float* xy, int n, float fx, float fy, float cx, float cy);
+
 /* Frame::GetFeaturesInArea (src/Frame.cc:209-262) evaluated by the GPU candidate kernel, for the
  * parity tests: indices in reference order.  out[cap]. */
 int orbfe_debug_features_in_area(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, int n, const float bounds[4],

@@ -78,6 +78,7 @@ def load_library():
                                              C.POINTER(ci)]
     L.orbfe_search_by_projection_uv.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, ci,
                                                 ci, ci, vp, C.POINTER(ci)]
+    L.orbfe_undistort_equidistant.argtypes = [vp, ci, cf, cf, cf, cf]
     L.orbfe_debug_matcher_ms.argtypes = [vp, vp]
     L.orbfe_debug_features_in_area.argtypes = [vp, vp, ci, vp, cf, cf, cf, ci, ci, vp, ci, C.POINTER(ci)]
     L.orbfe_debug_kernel_ms.argtypes = [vp, vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), ci]
@@ -361,6 +362,13 @@ def quadtree(x, y, score, min_x, max_x, min_y, max_y, n_target):
     _check(load_library().orbfe_debug_quadtree(_p(x), _p(y), _p(score), len(x), min_x, max_x, min_y, max_y, n_target,
                                                _p(out), len(out), C.byref(n)))
     return out[:n.value].copy()
+
+
+def undistort_equidistant(xy, fx, fy, cx, cy):
+    """Frame::antidistorsionarProyeccionEquidistante (host helper of the C ABI)."""
+    xy = np.ascontiguousarray(xy, np.float32).copy()
+    _check(load_library().orbfe_undistort_equidistant(_p(xy), len(xy), fx, fy, cx, cy))
+    return xy
 
 
 def sincos_host_mismatches(lo_bits, hi_bits, step=1):

@@ -517,6 +517,25 @@ int orbfe_hamming(const uint8_t a[32], const uint8_t b[32]) {
   return d;
 }
 
+int orbfe_undistort_equidistant(float* xy, int n, float fx, float fy, float cx, float cy) {
+  if (n < 0 || (n && !xy)) { set_err("bad argument"); return ORBFE_ERR_INVALID; }
+  // Frame.cc:357-383: f, c as double copies of the float intrinsics; K (Matx33f) * Vec3d in double
+  const double f0 = fx, f1 = fy, c0 = cx, c1 = cy;
+  for (int i = 0; i < n; i++) {
+    const double pi0 = xy[2 * i], pi1 = xy[2 * i + 1];
+    const double pw0 = (pi0 - c0) / f0, pw1 = (pi1 - c1) / f1;
+    const double theta_d = std::sqrt(pw0 * pw0 + pw1 * pw1);
+    const double scale = theta_d > 1e-8 ? std::tan(theta_d) / theta_d : 1.0;
+    const double pu0 = pw0 * scale, pu1 = pw1 * scale;
+    const double pr0 = (double)fx * pu0 + 0.0 * pu1 + (double)cx * 1.0;
+    const double pr1 = 0.0 * pu0 + (double)fy * pu1 + (double)cy * 1.0;
+    const double pr2 = 0.0 * pu0 + 0.0 * pu1 + 1.0 * 1.0;
+    xy[2 * i] = (float)(pr0 / pr2);
+    xy[2 * i + 1] = (float)(pr1 / pr2);
+  }
+  return ORBFE_OK;
+}
+
 int orbfe_matcher_create(int device_id, orbfe_matcher** out) {
   if (!out) { set_err("out is NULL"); return ORBFE_ERR_INVALID; }
   *out = nullptr;

@@ -68,3 +68,19 @@ def test_sincos_restatement_matches_libm_exhaustively():
     # every float in [0, 6.3] (the rBRIEF argument is angle*pi/180 in [0, 2*pi)): bitwise equal to libm
     hi = int(np.float32(6.3).view(np.uint32))
     assert api.sincos_host_mismatches(0, hi, 1) == 0
+
+
+def test_fisheye_undistortion_matches_oracle(oracle):
+    # Sony AS-20 720p fisheye calibration scaled x3
+    fx = fy = 2196.0
+    cx, cy = 1839.0, 1155.0
+    rng = np.random.default_rng(0)
+    pts = np.stack([rng.uniform(0, 3840, 5000), rng.uniform(0, 2160, 5000)], 1).astype(np.float32)
+    pts[0] = (cx, cy)                                   # theta = 0 branch
+    got = api.undistort_equidistant(pts, fx, fy, cx, cy)
+    want = oracle.undistort_equidistant(pts, fx, fy, cx, cy)
+    assert got.tobytes() == want.tobytes()
+    assert got[0].tolist() == [cx, cy]
+    r_in = np.hypot(pts[:, 0] - cx, pts[:, 1] - cy)
+    r_out = np.hypot(got[:, 0] - cx, got[:, 1] - cy)
+    assert (r_out >= r_in - 1e-2).all()                 # tan(theta)/theta >= 1: points move outwards
