@@ -260,6 +260,22 @@ int orbfe_search_by_projection_uv(orbfe_matcher* m, const OrbfeKeyPoint* kps_un,
  * [2] sequential bookkeeping (resolve). */
 int orbfe_debug_matcher_ms(const orbfe_matcher* m, double out[3]);
 
+/* Generic GPU primitive under every windowed search of the reference (Fuse x2
+ * ORBmatcher.cc:806-1064, SearchBySim3 :1066-1290, SearchByProjection(KeyFrame*, Scw, ...) :285-398,
+ * SearchForTriangulation's window variant): for nq queries (x, y, r, minLevel, maxLevel, 32-byte descriptor)
+ * against one frame's keypoints, the candidate lists Frame/KeyFrame::GetFeaturesInArea would return, in
+ * reference order, each with its Hamming distance to the query descriptor.  r < 0 marks an inactive query.
+ *   counts[nq], offsets[nq] : candidate count and first entry of each query in `pool`
+ *   pool[pool_cap]          : entries  index | distance << 16
+ *   *pool_used              : entries needed; if > pool_cap the call returns ORBFE_ERR_OVERFLOW (nothing lost:
+ *                             call again with a larger pool)
+ * The per-function bookkeeping (chi-square gates, best/second-best, occupancy) stays with the caller, exactly
+ * like orb_shim.hpp does for the searches above. */
+int orbfe_window_candidates(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, const uint8_t* desc, int n,
+                            const float bounds[4], int nq, const float* qx, const float* qy, const float* qr,
+                            const int32_t* qmin_level, const int32_t* qmax_level, const uint8_t* qdesc,
+                            uint32_t* counts, uint32_t* offsets, uint32_t* pool, size_t pool_cap, size_t* pool_used);
+
 /* void Frame::antidistorsionarProyeccionEquidistante(cv::Mat& puntos)  (src/Frame.cc:355-384): os1's
  * equidistant-fisheye keypoint undistortion (camera `modo: 1`), used by Frame::UndistortKeyPoints (:286-320) and
  * Frame::ComputeImageBounds (:322-353).  Host double-precision math on n (x, y) float pairs, in place; K is the

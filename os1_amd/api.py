@@ -78,6 +78,8 @@ def load_library():
                                              C.POINTER(ci)]
     L.orbfe_search_by_projection_uv.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, ci,
                                                 ci, ci, vp, C.POINTER(ci)]
+    L.orbfe_window_candidates.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t,
+                                          C.POINTER(C.c_size_t)]
     L.orbfe_undistort_equidistant.argtypes = [vp, ci, cf, cf, cf, cf]
     L.orbfe_debug_matcher_ms.argtypes = [vp, vp]
     L.orbfe_debug_features_in_area.argtypes = [vp, vp, ci, vp, cf, cf, cf, ci, ci, vp, ci, C.POINTER(ci)]
@@ -336,6 +338,32 @@ class Matcher:
                                                     int(skip_any_occupied), int(check_ori), _p(assigned),
                                                     C.byref(n)))
         return n.value, assigned[:len(kps)]
+
+    def window_candidates(self, kps, desc, bounds, qx, qy, qr, qmin, qmax, qdesc):
+        """Ordered candidate lists (index, Hamming distance) per query -- the GPU part of every windowed search."""
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        b = np.asarray(bounds, np.float32)
+        qx, qy, qr = (np.ascontiguousarray(a, np.float32) for a in (qx, qy, qr))
+        qmin, qmax = (np.ascontiguousarray(a, np.int32) for a in (qmin, qmax))
+        qdesc = np.ascontiguousarray(qdesc, np.uint8)
+        nq = len(qx)
+        counts = np.zeros(max(nq, 1), np.uint32)
+        offsets = np.zeros(max(nq, 1), np.uint32)
+        cap = 1 << 16
+        while True:
+            pool = np.zeros(cap, np.uint32)
+            used = C.c_size_t(0)
+            rc = self.L.orbfe_window_candidates(self.h, _p(kps), _p(desc), len(kps), _p(b), nq, _p(qx), _p(qy), _p(qr),
+                                                _p(qmin), _p(qmax), _p(qdesc), _p(counts), _p(offsets), _p(pool), cap,
+                                                C.byref(used))
+            if rc == -5:
+                cap = int(used.value)
+                continue
+            _check(rc)
+            break
+        return [(pool[offsets[q]:offsets[q] + counts[q]] & 0xffff, pool[offsets[q]:offsets[q] + counts[q]] >> 16)
+                for q in range(nq)]
 
     def stage_ms(self):
         out = np.zeros(3, np.float64)

@@ -517,6 +517,36 @@ int orbfe_hamming(const uint8_t a[32], const uint8_t b[32]) {
   return d;
 }
 
+int orbfe_window_candidates(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, const uint8_t* desc, int n,
+                            const float bounds[4], int nq, const float* qx, const float* qy, const float* qr,
+                            const int32_t* qmin_level, const int32_t* qmax_level, const uint8_t* qdesc,
+                            uint32_t* counts, uint32_t* offsets, uint32_t* pool, size_t pool_cap, size_t* pool_used) {
+  if (!m || !bounds || n < 0 || n > 65535 || nq < 0 || !pool_used || (n && (!kps_un || !desc)) ||
+      (nq && (!qx || !qy || !qr || !qmin_level || !qmax_level || !qdesc || !counts || !offsets))) {
+    set_err("bad argument (note: at most 65535 keypoints per frame)");
+    return ORBFE_ERR_INVALID;
+  }
+  *pool_used = 0;
+  if (nq == 0) return ORBFE_OK;
+  int rc = m->candidates(kps_un, desc, n, bounds, qx, qy, qr, qmin_level, qmax_level, qdesc, nq);
+  if (rc) return rc;
+  // repack per query so the caller's pool is dense and in query order
+  size_t used = 0;
+  for (int q = 0; q < nq; q++) {
+    counts[q] = m->qcount[q];
+    offsets[q] = (uint32_t)used;
+    used += m->qcount[q];
+  }
+  *pool_used = used;
+  if (used > pool_cap || (used && !pool)) {
+    set_err("candidate pool too small: %zu entries needed, %zu given", used, pool_cap);
+    return ORBFE_ERR_OVERFLOW;
+  }
+  for (int q = 0; q < nq; q++)
+    if (counts[q]) memcpy(pool + offsets[q], m->h_pool.p + m->qoff[q], sizeof(uint32_t) * counts[q]);
+  return ORBFE_OK;
+}
+
 int orbfe_undistort_equidistant(float* xy, int n, float fx, float fy, float cx, float cy) {
   if (n < 0 || (n && !xy)) { set_err("bad argument"); return ORBFE_ERR_INVALID; }
   // Frame.cc:357-383: f, c as double copies of the float intrinsics; K (Matx33f) * Vec3d in double

@@ -321,3 +321,31 @@ def test_config5_4k_fisheye_search_by_projection(api, oracle):
         on, oa = oracle.search_by_projection(kun, d, bounds, sf, occ, mxy, level, viewcos, flags, mdesc, th, 0.8)
         assert n == on and (a == oa).all()
         assert n > 1000
+
+
+def test_window_candidates_primitive(api, oracle):
+    """orbfe_window_candidates: per query the GetFeaturesInArea list in reference order with Hamming distances
+    (the GPU half of Fuse / SearchBySim3 / SearchByProjection(KeyFrame*, Scw, ...))."""
+    ex, (k, d), _, bounds = _frames(api, oracle, 1280, 720, 1500, 33)
+    m = api.Matcher()
+    rng = np.random.default_rng(9)
+    nq = 300
+    qx = rng.uniform(-20, 1300, nq).astype(np.float32)
+    qy = rng.uniform(-20, 740, nq).astype(np.float32)
+    qr = rng.choice([-1.0, 3.0, 7.5, 25.0, 90.0, 400.0], nq).astype(np.float32)
+    lv = rng.integers(0, 8, nq)
+    qmin = np.where(rng.random(nq) < 0.2, -1, lv - 1).astype(np.int32)
+    qmax = np.where(qmin < 0, -1, lv + rng.integers(0, 2, nq)).astype(np.int32)
+    qdesc = d[rng.integers(0, len(k), nq)].copy()
+    res = m.window_candidates(k, d, bounds, qx, qy, qr, qmin, qmax, qdesc)
+    total = 0
+    for q in range(nq):
+        idx, dist = res[q]
+        if qr[q] < 0:
+            assert len(idx) == 0
+            continue
+        want = oracle.get_features_in_area(k, bounds, float(qx[q]), float(qy[q]), float(qr[q]), int(qmin[q]), int(qmax[q]))
+        assert idx.tolist() == want.tolist()
+        assert dist.tolist() == [oracle.hamming(qdesc[q], d[i]) for i in want]
+        total += len(want)
+    assert total > 2000
