@@ -157,6 +157,7 @@ struct orbfe_extractor {
     std::vector<int> qsel;
   };
   std::unique_ptr<HostPool> pool;
+  int hostThreads = 1;
   std::vector<Worker> workers;
   std::vector<std::vector<Meta>> taskOut;  // [frame*nlevels + level]
   std::vector<Meta> meta;
@@ -491,6 +492,10 @@ struct orbfe_extractor {
     if ((rc = setGeometry(r, c))) return rc;
     if ((rc = setBatch(nframes, !onDevice))) return rc;
     const double t0 = now_ms();
+    if (!pool) {
+      pool.reset(new HostPool(hostThreads));
+      workers.resize(hostThreads);
+    }
     const int nsub = std::min(nframes, std::min(kMaxSub, std::max(1, subBatches)));
     const int maxKp = nfeatures + 2 * nlevels;
     int subF0[kMaxSub + 1];
@@ -792,8 +797,7 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
   if (nthreads > 16) nthreads = 16;
   if (const char* ev = getenv("ORBFE_HOST_THREADS")) nthreads = atoi(ev);
   if (nthreads < 1) nthreads = 1;
-  h->pool.reset(new HostPool(nthreads));
-  h->workers.resize(nthreads);
+  h->hostThreads = nthreads;   // the pool itself is created on first use (host-quadtree path only)
   *out = h;
   return ORBFE_OK;
 }

@@ -584,7 +584,7 @@ int orbfe_matcher_create(int device_id, orbfe_matcher** out) {
     return ORBFE_ERR_HIP;
   }
   int nthreads = (int)std::thread::hardware_concurrency();
-  if (nthreads > 16) nthreads = 16;
+  if (nthreads > 8) nthreads = 8;
   if (const char* ev = getenv("ORBFE_HOST_THREADS")) nthreads = atoi(ev);
   if (nthreads < 1) nthreads = 1;
   m->pool.reset(new orbfe::HostPool(nthreads));
