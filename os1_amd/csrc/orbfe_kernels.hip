@@ -60,28 +60,21 @@ __global__ __launch_bounds__(256) void k_resize(PyramidParams P, int level) {
   const int a = (int)(reinterpret_cast<uintptr_t>(rbase) & 3);
   const int tid = threadIdx.x;
   if ((sstride & 3) == 0) {
-    const int ndw = (a + rw + 3) >> 2;
-    const float rcp = 1.0f / (float)ndw;
-    const int total = ndw * rh;
-    const uint8_t* base = rbase - a;
-    for (int i0 = tid; i0 < total; i0 += 256 * 4) {
-      uint32_t v[4];
+    // thread (c, r0) = (tid % 32, tid / 32) copies dword column c of rows r0, r0+8, ...: plain adds, no
+    // per-element index arithmetic; 4 loads are issued before the first LDS write
+    const int ndw = (a + rw + 3) >> 2;            // ~21 at scale 1.2; wider footprints take a second column pass
+    const int r0 = tid >> 5;
+    for (int c = tid & 31; c < ndw; c += 32) {
+      const uint8_t* g = rbase - a + 4 * c + m24(r0, istr);
+      uint8_t* l = rz + 4 * c + m24(r0, LP);
+      const int gstep = 8 * istr, lstep = 8 * LP;
+      for (int r = r0; r < rh; r += 32, g += 4 * gstep, l += 4 * lstep) {
+        uint32_t v[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int i = i0 + u * 256;
-        v[u] = 0;
-        if (i < total) {
-          const int y = (int)(((float)i + 0.5f) * rcp), c = i - m24(y, ndw);
-          v[u] = *reinterpret_cast<const uint32_t*>(base + m24(y, istr) + 4 * c);
-        }
-      }
+        for (int u = 0; u < 4; u++) v[u] = (r + 8 * u < rh) ? *reinterpret_cast<const uint32_t*>(g + u * gstep) : 0u;
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int i = i0 + u * 256;
-        if (i < total) {
-          const int y = (int)(((float)i + 0.5f) * rcp), c = i - m24(y, ndw);
-          *reinterpret_cast<uint32_t*>(rz + m24(y, LP) + 4 * c) = v[u];
-        }
+        for (int u = 0; u < 4; u++)
+          if (r + 8 * u < rh) *reinterpret_cast<uint32_t*>(l + u * lstep) = v[u];
       }
     }
   } else {
@@ -199,29 +192,22 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
   // the row pitch allows it; `a` is the byte offset of the ROI inside its first dword.
   const int a = (int)(reinterpret_cast<uintptr_t>(roi) & 3);
   if ((stride & 3) == 0) {
+    // lane (c, r0) = (lane % 16, lane / 16) copies dword column c of rows r0, r0+4, ... with plain adds;
+    // columns 16.. of very wide cells are covered by a second column pass
     const int ndw = (a + rw + 3) >> 2;
-    const float rcpNdw = 1.0f / (float)ndw;
-    const int total = ndw * rh;
     const uint8_t* base = roi - a;
-    // 9 dwords per lane cover the usual 43-row x 12-dword ROI (516 dwords) in a single batch
-    for (int i0 = lane; i0 < total; i0 += 64 * 9) {
-      uint32_t v[9];
+    const int r0 = lane >> 4;
+    for (int c = lane & 15; c < ndw; c += 16) {
+      const uint8_t* g = base + 4 * c + m24(r0, istr);
+      uint8_t* l = tile + 4 * c + m24(r0, TP);
+      const int gstep = 4 * istr, lstep = 4 * TP;
+      for (int r = r0; r < rh; r += 48, g += 12 * gstep, l += 12 * lstep) {
+        uint32_t v[12];
 #pragma unroll
-      for (int u = 0; u < 9; u++) {
-        const int i = i0 + u * 64;
-        v[u] = 0;
-        if (i < total) {
-          const int y = (int)(((float)i + 0.5f) * rcpNdw), c = i - m24(y, ndw);
-          v[u] = *reinterpret_cast<const uint32_t*>(base + m24(y, istr) + 4 * c);
-        }
-      }
+        for (int u = 0; u < 12; u++) v[u] = (r + 4 * u < rh) ? *reinterpret_cast<const uint32_t*>(g + u * gstep) : 0u;
 #pragma unroll
-      for (int u = 0; u < 9; u++) {
-        const int i = i0 + u * 64;
-        if (i < total) {
-          const int y = (int)(((float)i + 0.5f) * rcpNdw), c = i - m24(y, ndw);
-          *reinterpret_cast<uint32_t*>(tile + m24(y, TP) + 4 * c) = v[u];
-        }
+        for (int u = 0; u < 12; u++)
+          if (r + 4 * u < rh) *reinterpret_cast<uint32_t*>(l + u * lstep) = v[u];
       }
     }
   } else {
@@ -580,26 +566,18 @@ __global__ __launch_bounds__(64) void k_describe(PyramidParams P, const SelKp* _
     const uint8_t* rbase = img + m24(cy - kRawRad, istr) + (cx - kRawRad);
     pa = (int)(reinterpret_cast<uintptr_t>(rbase) & 3);
     const int ndw = (pa + kRawW + 3) >> 2;  // 11 or 12
-    const float rcp = 1.0f / (float)ndw;
-    const int total = ndw * kRawW;            // <= 516
-    const uint8_t* base = rbase - pa;
-    uint32_t v[9];
+    // lane (c, r0) = (lane % 16, lane / 16) copies dword column c of rows r0, r0+4, ..., r0+40: 11 loads in flight
+    const int c = lane & 15, r0 = lane >> 4;
+    if (c < ndw) {
+      const uint8_t* g = rbase - pa + 4 * c + m24(r0, istr);
+      uint8_t* l = raw + 4 * c + m24(r0, kRawP);
+      const int gstep = 4 * istr;
+      uint32_t v[11];
 #pragma unroll
-    for (int u = 0; u < 9; u++) {
-      const int i = lane + u * 64;
-      v[u] = 0;
-      if (i < total) {
-        const int y = (int)(((float)i + 0.5f) * rcp), c = i - m24(y, ndw);
-        v[u] = *reinterpret_cast<const uint32_t*>(base + m24(y, istr) + 4 * c);
-      }
-    }
+      for (int u = 0; u < 11; u++) v[u] = (r0 + 4 * u < kRawW) ? *reinterpret_cast<const uint32_t*>(g + u * gstep) : 0u;
 #pragma unroll
-    for (int u = 0; u < 9; u++) {
-      const int i = lane + u * 64;
-      if (i < total) {
-        const int y = (int)(((float)i + 0.5f) * rcp), c = i - m24(y, ndw);
-        *reinterpret_cast<uint32_t*>(raw + m24(y, kRawP) + 4 * c) = v[u];
-      }
+      for (int u = 0; u < 11; u++)
+        if (r0 + 4 * u < kRawW) *reinterpret_cast<uint32_t*>(l + u * 4 * kRawP) = v[u];
     }
   } else {
     for (int i0 = lane; i0 < kRawW * kRawW; i0 += 64 * 8) {
