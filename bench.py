@@ -37,6 +37,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='frames per step and GPU')
     ap.add_argument('--cpu-frames', type=int, default=24, help='frames of the CPU-oracle baseline sample (0 = skip)')
     ap.add_argument('--no-match', action='store_true', help='extract only (configs[1])')
+    ap.add_argument('--host-input', action='store_true', help='frames start in pageable HOST memory (PCIe-inclusive rate; never the headline value)')
     ap.add_argument('--depth', type=int, default=2, help='extraction batches in flight inside the stream runner')
     args = ap.parse_args()
 
@@ -71,6 +72,13 @@ def main():
     # by (2,1) px"; derived from the base frame so that noise does not accumulate along the stream)
     frames = [base] + [shifted(base, 2 * i, i, seed * 1000 + i) for i in range(1, B)]
     dev = api.DeviceFrames(frames, local_rank)
+    host_ptrs = [f.ctypes.data for f in frames]
+
+    def push():
+        if args.host_input:
+            st.push_ptrs(host_ptrs, H, W, W, False)
+        else:
+            st.push_ptrs(dev.ptrs, H, W, dev.stride, True)
     # native stream runner: `depth` extractor handles + one matcher + two worker threads, all C++
     st = api.Stream(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, local_rank, B, max(1, args.depth))
     bounds = (0.0, float(W), 0.0, float(H))
@@ -84,14 +92,14 @@ def main():
         Up to depth+2 batches are in the pipeline; every push and pop of the nsteps batches is inside this call."""
         pushed = 0
         while pushed < min(args.depth + 2, nsteps):
-            st.push_ptrs(dev.ptrs, H, W, dev.stride, True)
+            push()
             pushed += 1
         for _ in range(nsteps):
             _, _, n, _, nm = st.pop()
             pop_times.append(time.perf_counter())
             nmatch_total[0] += int(nm.sum())
             if pushed < nsteps:
-                st.push_ptrs(dev.ptrs, H, W, dev.stride, True)
+                push()
                 pushed += 1
 
     def sync():
@@ -153,7 +161,7 @@ def main():
                        'frames_per_step_per_gpu': B, 'image': '%dx%d' % (W, H), 'nfeatures': NFEAT, 'nlevels': NLEVELS,
                        'parallelism': 'independent streams, 1 per GPU' if world > 1 else 'single GPU',
                        'matches_per_frame': round(nmatch_total[0] / max(B * args.steps, 1), 1),
-                       'input': 'frames resident in HBM; keypoints/descriptors/matches returned to host'},
+                       'input': ('frames in pageable host memory (PCIe-inclusive)' if args.host_input else 'frames resident in HBM') + '; keypoints/descriptors/matches returned to host'},
             'gpu_kernel_ms_per_frame': {k: round(v / max(kframes, 1), 5) for k, v in
                                         zip(('pyramid', 'fast_cells', 'compaction', 'describe', 'quadtree'), kms)},
             'ms_per_step_percentiles': (lambda d: {'p10': round(float(np.percentile(d, 10)), 4), 'p50': round(float(np.percentile(d, 50)), 4),
@@ -167,6 +175,7 @@ def main():
         }
         if world == 1 and args.cpu_frames > 0:
             out['cpu_baseline'] = cpu_baseline(frames, args.cpu_frames, not args.no_match)
+            out['cpu_baseline_all_cores'] = cpu_baseline_all_cores(frames)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
@@ -194,6 +203,31 @@ def cpu_baseline(frames, nframes, do_match):
             'host_cores_available': os.cpu_count(),
             'sample': '%d frames of the same 1920x1080 stream, extract%s, oracle/liborb_oracle.so (scalar C++ '
                       'restatement, g++ -O3 -ffp-contract=off), %.1f s' % (nframes, '+SearchForInitialization' if do_match else '', dt)}
+
+
+def cpu_baseline_all_cores(frames):
+    """The same oracle with one extractor instance per host thread over independent frames (SURVEY.md s8(d)(ii));
+    extraction only, 4 frames per thread, at most 64 threads so the run stays bounded."""
+    import threading
+    from oracle.pyoracle import Oracle, OracleExtractor
+    nthreads = max(1, min(os.cpu_count() or 1, 64))
+    o = Oracle()
+    exs = [OracleExtractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, o) for _ in range(nthreads)]
+    per = 4
+
+    def work(i):
+        for k in range(per):
+            exs[i].extract(frames[(i * per + k) % len(frames)])
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    dt = time.perf_counter() - t0
+    return {'value': round(nthreads * per / dt, 2), 'unit': 'frames/s', 'cores': nthreads, 'kind': 'port',
+            'sample': '%d threads x %d frames, extract only, %.1f s' % (nthreads, per, dt)}
 
 
 if __name__ == '__main__':
