@@ -276,6 +276,14 @@ int orbfe_window_candidates(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, const
                             const int32_t* qmin_level, const int32_t* qmax_level, const uint8_t* qdesc,
                             uint32_t* counts, uint32_t* offsets, uint32_t* pool, size_t pool_cap, size_t* pool_used);
 
+/* void MapPoint::ComputeDistinctiveDescriptors()  (src/MapPoint.cc:227-292), from the gathered descriptor list
+ * onwards, batched over MapPoints: MapPoint p owns descriptor rows [offsets[p], offsets[p+1]) of `descs`
+ * (32-byte rows, the non-bad observations in std::map order); best_idx[p] = index inside its own list of the
+ * descriptor with the least median distance to the rest (median = sorted[ (size_t)(0.5*(N-1)) ], first minimum
+ * wins), -1 for an empty list.  All-pairs 256-bit Hamming + per-row median on the GPU, one wave per MapPoint. */
+int orbfe_distinctive_descriptors(orbfe_matcher* m, int n_mp, const int32_t* offsets, const uint8_t* descs,
+                                  int32_t* best_idx);
+
 /* void Frame::antidistorsionarProyeccionEquidistante(cv::Mat& puntos)  (src/Frame.cc:355-384): os1's
  * equidistant-fisheye keypoint undistortion (camera `modo: 1`), used by Frame::UndistortKeyPoints (:286-320) and
  * Frame::ComputeImageBounds (:322-353).  Host double-precision math on n (x, y) float pairs, in place; K is the

@@ -1007,6 +1007,30 @@ int orc_search_by_projection_uv(const OrcKeyPoint* kpsUn, const uint8_t* desc, i
   return nmatches;
 }
 
+// MapPoint::ComputeDistinctiveDescriptors -- MapPoint.cc:227-292, from the descriptor list onwards:
+// index of the descriptor with the least median Hamming distance to the rest (first minimum wins).
+int orc_distinctive_descriptor(const uint8_t* descs, int N) {
+  if (N <= 0) return -1;
+  std::vector<float> Distances((size_t)N * N);
+  for (int i = 0; i < N; i++) {
+    Distances[(size_t)i * N + i] = 0;
+    for (int j = i + 1; j < N; j++) {
+      int distij = descriptor_distance(descs + 32 * (size_t)i, descs + 32 * (size_t)j);
+      Distances[(size_t)i * N + j] = distij;
+      Distances[(size_t)j * N + i] = distij;
+    }
+  }
+  int BestMedian = INT_MAX;
+  int BestIdx = 0;
+  for (int i = 0; i < N; i++) {
+    std::vector<int> vDists(Distances.begin() + (size_t)i * N, Distances.begin() + (size_t)(i + 1) * N);
+    std::sort(vDists.begin(), vDists.end());
+    int median = vDists[0.5 * (N - 1)];
+    if (median < BestMedian) { BestMedian = median; BestIdx = i; }
+  }
+  return BestIdx;
+}
+
 // Frame::antidistorsionarProyeccionEquidistante -- Frame.cc:355-384 (os1's equidistant fisheye, modo 1).
 // K = [fx 0 cx; 0 fy cy; 0 0 1] as floats; points in/out as float pairs.
 void orc_undistort_equidistant(float* xy, int n, float fx, float fy, float cx, float cy) {

@@ -57,6 +57,7 @@ class Oracle:
                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                   C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
                                                   C.c_void_p]
+        L.orc_distinctive_descriptor.argtypes = [C.c_void_p, C.c_int]
         L.orc_undistort_equidistant.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
 
     # ---- primitives -------------------------------------------------------------------------
@@ -164,6 +165,10 @@ class Oracle:
                                                _p(src_desc), len(src_level), th, max_dist, int(skip_any_occupied),
                                                int(check_ori), _p(assigned))
         return n, assigned[:len(kps)]
+
+    def distinctive_descriptor(self, descs):
+        descs = np.ascontiguousarray(descs, np.uint8)
+        return self.L.orc_distinctive_descriptor(_p(descs), len(descs))
 
     def undistort_equidistant(self, xy, fx, fy, cx, cy):
         xy = np.ascontiguousarray(xy, np.float32).copy()

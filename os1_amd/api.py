@@ -78,6 +78,7 @@ def load_library():
                                              C.POINTER(ci)]
     L.orbfe_search_by_projection_uv.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, ci,
                                                 ci, ci, vp, C.POINTER(ci)]
+    L.orbfe_distinctive_descriptors.argtypes = [vp, ci, vp, vp, vp]
     L.orbfe_window_candidates.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t,
                                           C.POINTER(C.c_size_t)]
     L.orbfe_undistort_equidistant.argtypes = [vp, ci, cf, cf, cf, cf]
@@ -364,6 +365,16 @@ class Matcher:
             break
         return [(pool[offsets[q]:offsets[q] + counts[q]] & 0xffff, pool[offsets[q]:offsets[q] + counts[q]] >> 16)
                 for q in range(nq)]
+
+    def distinctive_descriptors(self, desc_lists):
+        """Batched MapPoint::ComputeDistinctiveDescriptors: list of (N_i, 32) arrays -> best index per list."""
+        offs = np.zeros(len(desc_lists) + 1, np.int32)
+        offs[1:] = np.cumsum([len(d) for d in desc_lists])
+        allv = np.ascontiguousarray(np.concatenate([np.asarray(d, np.uint8).reshape(-1, 32) for d in desc_lists])
+                                     if len(desc_lists) and offs[-1] else np.zeros((1, 32), np.uint8))
+        out = np.zeros(max(len(desc_lists), 1), np.int32)
+        _check(self.L.orbfe_distinctive_descriptors(self.h, len(desc_lists), _p(offs), _p(allv), _p(out)))
+        return out[:len(desc_lists)]
 
     def stage_ms(self):
         out = np.zeros(3, np.float64)

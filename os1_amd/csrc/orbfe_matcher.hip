@@ -176,6 +176,50 @@ __global__ __launch_bounds__(64) void k_window_match(MatchParams M) {
   }
 }
 
+// MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:258-286): one wave per MapPoint.  Lane i owns row i of
+// the N x N distance matrix (rows beyond 64 in further passes); the row median (element of rank (N-1)/2) is the
+// smallest v with #{d_ij <= v} >= rank+1, found by bisection over the 257 possible distances with the row's
+// distances recomputed from LDS each step; the best (median, index) pair is a wave min-reduction.
+__global__ __launch_bounds__(64) void k_distinctive(const int* __restrict__ offsets, const uint8_t* __restrict__ descs,
+                                                    int* __restrict__ best, int maxN) {
+  extern __shared__ __align__(16) uint32_t dd[];   // [N][8]
+  const int p = blockIdx.x, lane = threadIdx.x;
+  const int o0 = offsets[p], N = offsets[p + 1] - o0;
+  if (N <= 0) {
+    if (lane == 0) best[p] = -1;
+    return;
+  }
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(descs + (size_t)o0 * 32);
+  for (int i = lane; i < N * 8; i += 64) dd[i] = src[i];
+  __syncthreads();
+  const int rank = (N - 1) >> 1;   // (size_t)(0.5 * (N - 1))
+  int bestMed = 0x7fffffff, bestIdx = 0x7fffffff;
+  for (int i = lane; i < N; i += 64) {
+    uint32_t qi[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++) qi[w] = dd[i * 8 + w];
+    int lo = 0, hi = 256;   // median in [lo, hi]
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      int cnt = 0;
+      for (int j = 0; j < N; j++) {
+        int d = 0;
+#pragma unroll
+        for (int w = 0; w < 8; w++) d += __popc(qi[w] ^ dd[j * 8 + w]);
+        cnt += d <= mid;
+      }
+      if (cnt >= rank + 1) hi = mid; else lo = mid + 1;
+    }
+    if (lo < bestMed) { bestMed = lo; bestIdx = i; }   // ascending i per lane: first minimum kept
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int om = __shfl_xor(bestMed, o, 64), oi = __shfl_xor(bestIdx, o, 64);
+    if (om < bestMed || (om == bestMed && oi < bestIdx)) { bestMed = om; bestIdx = oi; }
+  }
+  if (lane == 0) best[p] = bestIdx;
+}
+
 template <class T>
 struct DevBuf {
   T* p = nullptr;
@@ -544,6 +588,42 @@ int orbfe_window_candidates(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, const
   }
   for (int q = 0; q < nq; q++)
     if (counts[q]) memcpy(pool + offsets[q], m->h_pool.p + m->qoff[q], sizeof(uint32_t) * counts[q]);
+  return ORBFE_OK;
+}
+
+int orbfe_distinctive_descriptors(orbfe_matcher* m, int n_mp, const int32_t* offsets, const uint8_t* descs,
+                                  int32_t* best_idx) {
+  if (!m || n_mp < 0 || (n_mp && (!offsets || !best_idx))) { set_err("bad argument"); return ORBFE_ERR_INVALID; }
+  if (n_mp == 0) return ORBFE_OK;
+  int maxN = 0;
+  for (int p = 0; p < n_mp; p++) {
+    const int N = offsets[p + 1] - offsets[p];
+    if (N < 0) { set_err("offsets must be non-decreasing"); return ORBFE_ERR_INVALID; }
+    maxN = std::max(maxN, N);
+  }
+  const size_t total = (size_t)offsets[n_mp] - (size_t)offsets[0];
+  if (total && !descs) { set_err("descs is NULL"); return ORBFE_ERR_INVALID; }
+  if ((size_t)maxN * 32 > 150 * 1024) { set_err("a MapPoint with %d observations exceeds the LDS budget", maxN); return ORBFE_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(m->device));
+  int rc;
+  const size_t oOff = 0, oDesc = al(4 * (size_t)(n_mp + 1)), bytes = oDesc + al(32 * total + 32);
+  if ((rc = m->h_in.ensure(bytes))) return rc;
+  if ((rc = m->d_in.ensure(bytes))) return rc;
+  if ((rc = m->d_out.ensure((size_t)n_mp + 64))) return rc;
+  if ((rc = m->h_out.ensure((size_t)n_mp + 64))) return rc;
+  int* ho = (int*)(m->h_in.p + oOff);
+  for (int p = 0; p <= n_mp; p++) ho[p] = offsets[p] - offsets[0];
+  if (total) memcpy(m->h_in.p + oDesc, descs + (size_t)offsets[0] * 32, 32 * total);
+  HIP_TRY(hipMemcpyAsync(m->d_in.p, m->h_in.p, bytes, hipMemcpyHostToDevice, m->stream));
+  const size_t lds = std::max<size_t>((size_t)maxN * 32, 32);
+  if (lds > 64 * 1024)
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_distinctive), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_distinctive, dim3(n_mp), dim3(64), lds, m->stream, (const int*)(m->d_in.p + oOff),
+                     (const uint8_t*)(m->d_in.p + oDesc), (int*)m->d_out.p, maxN);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(m->h_out.p, m->d_out.p, sizeof(int) * n_mp, hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  memcpy(best_idx, m->h_out.p, sizeof(int) * n_mp);
   return ORBFE_OK;
 }
 

@@ -349,3 +349,23 @@ def test_window_candidates_primitive(api, oracle):
         assert dist.tolist() == [oracle.hamming(qdesc[q], d[i]) for i in want]
         total += len(want)
     assert total > 2000
+
+
+def test_distinctive_descriptors_parity(api, oracle):
+    """MapPoint::ComputeDistinctiveDescriptors, batched: all-pairs Hamming + row medians on the GPU."""
+    rng = np.random.default_rng(77)
+    base = rng.integers(0, 256, (64, 32), dtype=np.uint8)
+    lists = []
+    for N in [1, 2, 3, 4, 5, 7, 8, 20, 33, 64, 65, 100, 257] + rng.integers(1, 60, 200).tolist():
+        proto = base[rng.integers(0, 64)]
+        d = np.repeat(proto[None], N, 0).copy()
+        for i in range(N):                                    # noisy copies of one descriptor: realistic and tie-rich
+            for b in rng.integers(0, 256, rng.integers(0, 60)):
+                d[i, b >> 3] ^= np.uint8(1 << (b & 7))
+        if N > 3 and rng.random() < 0.3:
+            d[rng.integers(0, N)] = d[rng.integers(0, N)]      # exact duplicates
+        lists.append(d)
+    lists.append(np.zeros((0, 32), np.uint8))                  # MapPoint without usable observations
+    got = api.Matcher().distinctive_descriptors(lists)
+    for d, g in zip(lists, got):
+        assert g == oracle.distinctive_descriptor(d), len(d)

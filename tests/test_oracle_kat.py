@@ -293,3 +293,13 @@ def test_extract_invariants(oracle):
     # empty image => no output
     k0, d0 = ex.extract(np.zeros((0, 0), np.uint8))
     assert len(k0) == 0
+
+
+def test_distinctive_descriptor_definition(oracle):
+    # independent numpy restatement of MapPoint.cc:258-286
+    rng = np.random.default_rng(4)
+    for N in (1, 2, 3, 6, 11, 40):
+        d = rng.integers(0, 256, (N, 32), dtype=np.uint8)
+        D = np.array([[int(np.unpackbits(d[i] ^ d[j]).sum()) for j in range(N)] for i in range(N)])
+        med = [sorted(D[i])[int(0.5 * (N - 1))] for i in range(N)]
+        assert oracle.distinctive_descriptor(d) == int(np.argmin(med))
