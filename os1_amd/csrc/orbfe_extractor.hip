@@ -127,6 +127,7 @@ struct orbfe_extractor {
   int rows = 0, cols = 0, batchCap = 0;
   PyramidParams P{};
   DevBuf<uint8_t> d_tables, d_slab, d_in;
+  DevBuf<CellInfo> d_cells;
   DevBuf<uint32_t> d_cellCount, d_cellOff, d_slots, d_cand;
   DevBuf<const uint8_t*> d_frame0;
   // results leave the GPU in ONE copy: [levelStart][selCount][sel][angle][desc] carved from one arena
@@ -165,7 +166,7 @@ struct orbfe_extractor {
   ~orbfe_extractor() {
     (void)hipSetDevice(device);
     d_tables.release(); d_slab.release(); d_in.release(); d_cellCount.release(); d_cellOff.release();
-    d_slots.release(); d_cand.release(); d_frame0.release(); d_outArena.release(); h_outArena.release();
+    d_cells.release(); d_slots.release(); d_cand.release(); d_frame0.release(); d_outArena.release(); h_outArena.release();
     d_f32tmp.release();
     h_frame0.release(); h_cand.release();
     for (auto& es : ev) for (auto& e : es) if (e) (void)hipEventDestroy(e);
@@ -279,7 +280,29 @@ struct orbfe_extractor {
       L.rzRows = maxH;
     }
     HIP_TRY(hipMemcpyAsync(d_tables.p, tab.data(), tableBytes, hipMemcpyHostToDevice, stream));
+    // per-cell geometry (emit regions of ComputeKeyPointsOctTree's cell grid, ORBextractor.cc:826-844)
+    std::vector<CellInfo> cells(Q.ncells);
+    for (int l = 0; l < nlevels; l++) {
+      const LevelGeom& L = Q.lv[l];
+      for (int i = 0; i < L.nRows; i++)
+        for (int j = 0; j < L.nCols; j++) {
+          CellInfo ci{};
+          const int ex0 = kEdge + j * L.wCell, ey0 = kEdge + i * L.hCell;
+          const int ew = std::min(L.wCell, L.w - kEdge - ex0), eh = std::min(L.hCell, L.h - kEdge - ey0);
+          ci.ex0 = (uint16_t)ex0;
+          ci.ey0 = (uint16_t)ey0;
+          ci.ew = (int8_t)std::max(-1, std::min(ew, 127));
+          ci.eh = (int8_t)std::max(-1, std::min(eh, 127));
+          ci.level = (uint8_t)l;
+          ci.local = (uint32_t)(i * L.nCols + j);
+          ci.slotOff = (uint32_t)(L.slotBase + (long long)ci.local * L.slotCap);
+          cells[L.cellBase + ci.local] = ci;
+        }
+    }
+    if ((rc = d_cells.ensure(cells.size()))) return rc;
+    HIP_TRY(hipMemcpyAsync(d_cells.p, cells.data(), sizeof(CellInfo) * cells.size(), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    Q.cells = d_cells.p;
     P = Q;
     rows = r;
     cols = c;

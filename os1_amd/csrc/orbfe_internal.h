@@ -30,6 +30,16 @@ struct LevelGeom {
   int rzPitch, rzRows;     // LDS pitch / rows of the largest 64x64-tile source footprint (k_resize)
 };
 
+// Per-cell geometry, precomputed on the host so a cell's wave needs one 16-byte load instead of a scalar
+// search over the level table.
+struct CellInfo {
+  uint16_t ex0, ey0;     // first emit pixel (level coordinates)
+  int8_t ew, eh;         // emit size (<= 0: the cell emits nothing)
+  uint8_t level, pad;
+  uint32_t slotOff;      // first slot of the cell inside a frame's slot array (u32 units)
+  uint32_t local;        // cell index inside its level
+};
+
 struct PyramidParams {
   LevelGeom lv[kMaxLevels];
   int nlevels;
@@ -45,6 +55,7 @@ struct PyramidParams {
   uint32_t* slots;                  // [nframes][slotsPerFrame]
   uint32_t* cand;                   // [nframes][candCap]  packed x | y<<12 | score<<24 (level coords)
   uint32_t* levelStart;             // [nframes][kMaxLevels+1]
+  const CellInfo* cells;            // [ncells]
   int iniTh, minTh;
   int frameBase;                    // first frame of this launch (sub-batch pipelining)
 };

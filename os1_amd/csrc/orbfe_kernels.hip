@@ -155,13 +155,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
   if (cell >= P.ncells) return;
   const int f = P.frameBase + blockIdx.y;
   const int lane = threadIdx.x;
-  int level = 0;
-  while (level + 1 < P.nlevels && cell >= P.lv[level + 1].cellBase) level++;
+  const CellInfo ci = P.cells[cell];
+  const int level = ci.level;
   const LevelGeom& L = P.lv[level];
-  const int local = cell - L.cellBase;
-  const int ci = local / L.nCols, cj = local - ci * L.nCols;
-  const int ex0 = kEdge + cj * L.wCell, ey0 = kEdge + ci * L.hCell;
-  const int ew = min(L.wCell, L.w - kEdge - ex0), eh = min(L.hCell, L.h - kEdge - ey0);
+  const int ex0 = ci.ex0, ey0 = ci.ey0, ew = ci.ew, eh = ci.eh;
   uint32_t* cnt = P.cellCount + (long long)f * P.ncells + cell;
   if (ew <= 0 || eh <= 0) {
     if (lane == 0) *cnt = 0;
@@ -378,7 +375,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
   }
   __syncthreads();
   const int th = anyIni ? P.iniTh : P.minTh;
-  uint32_t* slot = P.slots + (long long)f * P.slotsPerFrame + L.slotBase + (long long)local * L.slotCap;
+  uint32_t* slot = P.slots + (long long)f * P.slotsPerFrame + ci.slotOff;
   int base = 0;
   for (int i0 = 0; i0 < nq2; i0 += 64) {
     const int i = i0 + lane;
@@ -436,15 +433,12 @@ __global__ __launch_bounds__(1024) void k_scan_cells(PyramidParams P) {
   if (tid == 0) ls[P.nlevels] = carry;
 }
 
-__global__ __launch_bounds__(64) void k_gather(PyramidParams P) {
-  const int cell = blockIdx.x, f = P.frameBase + blockIdx.y, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void k_gather(PyramidParams P) {   // one wave per cell, 4 cells per block
+  const int cell = blockIdx.x * 4 + (threadIdx.x >> 6), f = P.frameBase + blockIdx.y, lane = threadIdx.x & 63;
+  if (cell >= P.ncells) return;
   const uint32_t n = P.cellCount[(long long)f * P.ncells + cell];
   if (n == 0) return;
-  int level = 0;
-  while (level + 1 < P.nlevels && cell >= P.lv[level + 1].cellBase) level++;
-  const LevelGeom& L = P.lv[level];
-  const uint32_t* slot =
-      P.slots + (long long)f * P.slotsPerFrame + L.slotBase + (long long)(cell - L.cellBase) * L.slotCap;
+  const uint32_t* slot = P.slots + (long long)f * P.slotsPerFrame + P.cells[cell].slotOff;
   const uint32_t o = P.cellOff[(long long)f * P.ncells + cell];
   uint32_t* dst = P.cand + (long long)f * P.candCap;
   for (uint32_t i = lane; i < n; i += 64)
@@ -690,7 +684,7 @@ void launch_fast(const PyramidParams& P, int nframes, hipStream_t st) {
 
 void launch_compact(const PyramidParams& P, int nframes, hipStream_t st) {
   hipLaunchKernelGGL(k_scan_cells, dim3(nframes), dim3(1024), 0, st, P);
-  hipLaunchKernelGGL(k_gather, dim3(P.ncells, nframes), dim3(64), 0, st, P);
+  hipLaunchKernelGGL(k_gather, dim3((P.ncells + 3) / 4, nframes), dim3(256), 0, st, P);
 }
 
 void launch_describe(const PyramidParams& P, const SelKp* sel, int nsel, float* angle, uint8_t* desc,
