@@ -44,3 +44,31 @@ def test_gpu_reproduces_golden():
     prev = np.stack([k1['x'], k1['y']], 1)
     n, m12, p = api.Matcher().search_for_initialization(k1, d1, k2, d2, (0, 640, 0, 480), prev, 100, 0.9, True)
     assert n == int(g['nmatches']) and (m12 == g['matches12']).all() and p.tobytes() == g['prev_out'].tobytes()
+
+
+def _sha(*arrs):
+    h = hashlib.sha256()
+    for a in arrs:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_1080p_digests():
+    """BASELINE.json configs[1] and configs[2] at full size against committed digests (tools/gen_golden.py)."""
+    import json
+    from os1_amd import api
+    g = json.load(open(os.path.join(os.path.dirname(G), 'hd1080_digests.json')))
+    ex = api.Extractor(2000, 1.2, 8, 20, 7)
+    A = synth(2, 1920, 1080)
+    assert _sha(A) == g['config2']['frame_sha256']
+    k, d = ex(A)
+    assert len(k) == g['config2']['n'] and _sha(k, d) == g['config2']['kps_desc_sha256']
+    assert [len(ex.candidates(l)) for l in range(8)] == g['config2']['cand_counts']
+    A3 = synth(3, 1920, 1080)
+    B3 = shifted(A3, -24, 3, 3)
+    (k1, d1), (k2, d2) = ex(A3), ex(B3)
+    assert _sha(k1, d1, k2, d2) == g['config3']['extract_sha256']
+    prev = np.stack([k1['x'], k1['y']], 1)
+    n, m12, p = api.Matcher().search_for_initialization(k1, d1, k2, d2, (0, 1920, 0, 1080), prev, 100, 0.9, True)
+    assert n == g['config3']['nmatches'] and _sha(m12, p) == g['config3']['match_sha256']

@@ -34,3 +34,26 @@ np.savez_compressed(os.path.join(out, 'vga_seed1.npz'), kps1=k1, desc1=d1, kps2=
                     nmatches=np.int32(n), matches12=m12, prev_out=p,
                     frame_sha=np.frombuffer(__import__('hashlib').sha256(A.tobytes()).digest(), np.uint8))
 print('vga_seed1: %d/%d kps, %d matches' % (len(k1), len(k2), n))
+
+# configs 2 and 3 (BASELINE.json configs[1], configs[2]): 1080p, N=2000 -- digests only (the arrays are large)
+import hashlib, json
+def sha(*arrs):
+    h = hashlib.sha256()
+    for a in arrs:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+A = synth(2, 1920, 1080)
+ox = OracleExtractor(2000, 1.2, 8, 20, 7, o)
+k, d = ox.extract(A)
+g = {'config2': {'seed': 2, 'n': int(len(k)), 'kps_desc_sha256': sha(k, d), 'frame_sha256': sha(A),
+                 'cand_counts': [int(len(ox.candidates(l))) for l in range(8)]}}
+A3 = synth(3, 1920, 1080)
+B3 = shifted(A3, -24, 3, 3)
+k1, d1 = ox.extract(A3)
+k2, d2 = ox.extract(B3)
+prev = np.stack([k1['x'], k1['y']], 1)
+n, m12, p = o.search_for_initialization(k1, d1, k2, d2, (0, 1920, 0, 1080), prev, 100, 0.9, True)
+g['config3'] = {'seed': 3, 'shift': [-24, 3], 'n1': int(len(k1)), 'n2': int(len(k2)), 'nmatches': int(n),
+                'extract_sha256': sha(k1, d1, k2, d2), 'match_sha256': sha(m12, p)}
+json.dump(g, open(os.path.join(out, 'hd1080_digests.json'), 'w'), indent=1)
+print('hd1080 digests:', g['config2']['n'], g['config3']['nmatches'])
