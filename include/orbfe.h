@@ -112,6 +112,24 @@ int orbfe_extract_batch_submit(orbfe_extractor* h, int nframes, const uint8_t* c
                                int rows, int cols, size_t stride_bytes);
 int orbfe_extract_batch_collect(orbfe_extractor* h, OrbfeKeyPoint* kps, uint8_t* desc, int cap, int* n_out);
 
+/* Extraction + GPU-resident matching for consecutive frames of ONE stream.  A chain carries the predecessor
+ * (the previous batch's last frame, kept in HBM) across batches; the batches of a stream may alternate between
+ * extractor handles of identical configuration on the same device, but must be submitted in stream order.
+ * _submit_matched = orbfe_extract_batch_submit followed, on the GPU, by
+ *   ORBmatcher(nnratio, check_orientation).SearchForInitialization(F1 = predecessor, F2 = frame,
+ *       vbPrevMatched := F1's keypoints (Tracking.cc:355-357), vnMatches12, window_size)   (ORBmatcher.cc:400-515)
+ * for every frame of the batch, reading keypoints, angles and descriptors straight from the extractor's result
+ * arena.  _collect_matched additionally returns matches12 [nframes][cap] (row f = vnMatches12 of frame f, indexed
+ * by the predecessor's keypoints, -1 = none) and nmatches [nframes] (0 for a stream's very first frame). */
+typedef struct orbfe_sfi_chain orbfe_sfi_chain;
+int orbfe_sfi_chain_create(const orbfe_extractor* h, orbfe_sfi_chain** out);
+void orbfe_sfi_chain_destroy(orbfe_sfi_chain* c);
+int orbfe_extract_batch_submit_matched(orbfe_extractor* h, orbfe_sfi_chain* chain, int nframes, const uint8_t* const* gray,
+                                       int in_device_memory, int rows, int cols, size_t stride_bytes, const float bounds[4],
+                                       int window_size, float nnratio, int check_orientation);
+int orbfe_extract_batch_collect_matched(orbfe_extractor* h, OrbfeKeyPoint* kps, uint8_t* desc, int cap, int* n_out,
+                                        int32_t* matches12, int* nmatches);
+
 /* Stage accessors for the parity tests (state of the LAST extract call, frame index in batch). */
 int orbfe_debug_level_size(const orbfe_extractor* h, int level, int* w, int* hgt);
 int orbfe_debug_level_copy(orbfe_extractor* h, int frame, int level, uint8_t* out /* w*h, tight */);

@@ -34,6 +34,7 @@ void launch_sincos(const float* deg, int n, float* c, float* s, hipStream_t st);
 void launch_describe_slots(const PyramidParams& P, const SelKp* sel, int nslots, float* angle, uint8_t* desc,
                            const uint32_t* selCount, int selPerFrame, const int* selOff, hipStream_t st);
 void launch_quadtree(const QtParams& Q, int nframes, hipStream_t st);
+void launch_sfi(const SfiParams& S, int nframes, hipStream_t st);
 
 thread_local std::string g_err;
 void set_err(const char* fmt, ...) {
@@ -98,6 +99,23 @@ struct PinBuf {
 };
 }  // namespace
 
+// Predecessor hand-over between consecutive batches of one stream (the batches alternate between extractor
+// handles): level-0 data of a batch's last frame, double-buffered, with an event per buffer.
+struct orbfe_sfi_chain {
+  int device = 0, n0cap = 0;
+  DevBuf<SelKp> sel[2];
+  DevBuf<float> angle[2];
+  DevBuf<uint8_t> desc[2];
+  DevBuf<uint32_t> count;      // [0],[1]: level-0 count of the buffers; [2]: constant 0xffffffff ("none")
+  hipEvent_t ready[2] = {};
+  long long seq = 0;           // batches submitted so far
+  ~orbfe_sfi_chain() {
+    (void)hipSetDevice(device);
+    for (int i = 0; i < 2; i++) { sel[i].release(); angle[i].release(); desc[i].release(); if (ready[i]) (void)hipEventDestroy(ready[i]); }
+    count.release();
+  }
+};
+
 struct orbfe_extractor {
   int nfeatures, nlevels, iniTh, minTh, device;
   double scaleFactor;  // the reference keeps the float ctor argument in a double member (ORBextractor.h:313)
@@ -139,6 +157,11 @@ struct orbfe_extractor {
   View<SelKp> d_sel, h_sel;
   View<float> d_angle, h_angle;
   View<uint8_t> d_desc, h_desc;
+  View<int32_t> d_m12, h_m12, d_nm, h_nm;   // GPU SearchForInitialization outputs ([B][n0cap], [B])
+  DevBuf<uint16_t> d_sfiOrder;
+  DevBuf<int> d_sfiOrderCount;
+  DevBuf<uint32_t> d_sfiPool, d_sfiPcount;
+  bool pendingMatched = false;
   DevBuf<float> d_f32tmp;
   bool profileKernels = false;  // HIP events around every kernel group (adds ~5-10 us of gaps per event)
   PinBuf<const uint8_t*> h_frame0;
@@ -166,6 +189,7 @@ struct orbfe_extractor {
   ~orbfe_extractor() {
     (void)hipSetDevice(device);
     d_tables.release(); d_slab.release(); d_in.release(); d_cellCount.release(); d_cellOff.release();
+    d_sfiOrder.release(); d_sfiOrderCount.release(); d_sfiPool.release(); d_sfiPcount.release();
     d_cells.release(); d_slots.release(); d_cand.release(); d_frame0.release(); d_outArena.release(); h_outArena.release();
     d_f32tmp.release();
     h_frame0.release(); h_cand.release();
@@ -325,7 +349,8 @@ struct orbfe_extractor {
         auto al256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
         const size_t oLs = 0, oSc = oLs + al256(sizeof(uint32_t) * (kMaxLevels + 1) * nframes),
                      oSel = oSc + al256(sizeof(uint32_t) * kMaxLevels * nframes), oAng = oSel + al256(sizeof(SelKp) * maxKp),
-                     oDesc = oAng + al256(sizeof(float) * maxKp), total = oDesc + al256(32 * maxKp);
+                     oDesc = oAng + al256(sizeof(float) * maxKp), oM12 = oDesc + al256(32 * maxKp),
+                     oNm = oM12 + al256(sizeof(int32_t) * (size_t)(nfeat[0] + 4) * nframes), total = oNm + al256(sizeof(int32_t) * nframes);
         if ((rc = d_outArena.ensure(total))) return rc;
         if ((rc = h_outArena.ensure(total))) return rc;
         outArenaBytes = total;
@@ -335,6 +360,8 @@ struct orbfe_extractor {
         d_sel.p = (SelKp*)(D + oSel); h_sel.p = (SelKp*)(Hh + oSel);
         d_angle.p = (float*)(D + oAng); h_angle.p = (float*)(Hh + oAng);
         d_desc.p = D + oDesc; h_desc.p = Hh + oDesc;
+        d_m12.p = (int32_t*)(D + oM12); h_m12.p = (int32_t*)(Hh + oM12);
+        d_nm.p = (int32_t*)(D + oNm); h_nm.p = (int32_t*)(Hh + oNm);
       }
       if (gpuQuadtree) {
         const size_t ce = (size_t)P.candCap * nframes, nn = (size_t)nframes * nlevels * kQtNodeCap;
@@ -377,7 +404,10 @@ struct orbfe_extractor {
   int pendingFrames = 0;   // frames of the submitted, not yet collected batch (0 = none)
   double tSubmit0 = 0, tSubmit1 = 0;
 
-  int submitGpuQt(int nframes, const uint8_t* const* gray, bool onDevice, int r, int c, size_t stride) {
+  struct MatchSpec { orbfe_sfi_chain* chain; float bounds[4]; int window; float nnratio; int checkOri; };
+
+  int submitGpuQt(int nframes, const uint8_t* const* gray, bool onDevice, int r, int c, size_t stride,
+                  const MatchSpec* ms = nullptr) {
     if (pendingFrames) { set_err("a submitted batch has not been collected yet"); return ORBFE_ERR_INVALID; }
     HIP_TRY(hipSetDevice(device));
     int rc;
@@ -430,6 +460,42 @@ struct orbfe_extractor {
     launch_describe_slots(P, d_sel.p, nslots, d_angle.p, d_desc.p, d_selCount.p, selPerFrame, selOff, st);
     if (prof) HIP_TRY(hipEventRecord(ev[0][5], st));
     HIP_TRY(hipGetLastError());
+    pendingMatched = false;
+    if (ms && ms->chain) {
+      // SearchForInitialization of every frame against its predecessor, on the data that is already in HBM
+      orbfe_sfi_chain& ch = *ms->chain;
+      const int n0cap = selOff[1] - selOff[0];
+      if (ch.n0cap != n0cap || ch.device != device) { set_err("match chain belongs to a different extractor configuration"); return ORBFE_ERR_INVALID; }
+      if ((rc = d_sfiOrder.ensure((size_t)batchCap * n0cap))) return rc;
+      if ((rc = d_sfiOrderCount.ensure(batchCap))) return rc;
+      if ((rc = d_sfiPool.ensure((size_t)batchCap * n0cap * n0cap))) return rc;
+      if ((rc = d_sfiPcount.ensure((size_t)batchCap * n0cap))) return rc;
+      SfiParams SP{};
+      SP.sel = d_sel.p; SP.angle = d_angle.p; SP.desc = d_desc.p; SP.selCount = d_selCount.p;
+      SP.selPerFrame = selPerFrame; SP.n0cap = n0cap; SP.frameBase = 0;
+      const int prev = (int)((ch.seq + 1) & 1), cur = (int)(ch.seq & 1);   // buffer written by the previous / this batch
+      SP.carrySel = ch.sel[prev].p; SP.carryAngle = ch.angle[prev].p; SP.carryDesc = ch.desc[prev].p;
+      SP.carryCount = ch.count.p + (ch.seq == 0 ? 2 : prev);
+      SP.minX = ms->bounds[0]; SP.minY = ms->bounds[2];
+      SP.invW = static_cast<float>(64) / static_cast<float>(ms->bounds[1] - ms->bounds[0]);   // Frame.cc:98
+      SP.invH = static_cast<float>(48) / static_cast<float>(ms->bounds[3] - ms->bounds[2]);   // Frame.cc:99
+      SP.window = (float)ms->window; SP.nnratio = ms->nnratio; SP.checkOri = ms->checkOri;
+      SP.order = d_sfiOrder.p; SP.orderCount = d_sfiOrderCount.p; SP.pool = d_sfiPool.p; SP.pcount = d_sfiPcount.p;
+      SP.matches12 = d_m12.p; SP.nmatches = d_nm.p;
+      if (ch.seq > 0) HIP_TRY(hipStreamWaitEvent(st, ch.ready[prev], 0));
+      launch_sfi(SP, nframes, st);
+      HIP_TRY(hipGetLastError());
+      // hand the last frame's level-0 data to the next batch
+      const size_t lastBase = (size_t)(nframes - 1) * selPerFrame;
+      HIP_TRY(hipMemcpyAsync(ch.sel[cur].p, d_sel.p + lastBase, sizeof(SelKp) * n0cap, hipMemcpyDeviceToDevice, st));
+      HIP_TRY(hipMemcpyAsync(ch.angle[cur].p, d_angle.p + lastBase, sizeof(float) * n0cap, hipMemcpyDeviceToDevice, st));
+      HIP_TRY(hipMemcpyAsync(ch.desc[cur].p, d_desc.p + lastBase * 32, (size_t)32 * n0cap, hipMemcpyDeviceToDevice, st));
+      HIP_TRY(hipMemcpyAsync(ch.count.p + cur, d_selCount.p + (size_t)(nframes - 1) * kMaxLevels, sizeof(uint32_t),
+                             hipMemcpyDeviceToDevice, st));
+      HIP_TRY(hipEventRecord(ch.ready[cur], st));
+      ch.seq++;
+      pendingMatched = true;
+    }
     HIP_TRY(hipMemcpyAsync(h_outArena.p, d_outArena.p, outArenaBytes, hipMemcpyDeviceToHost, st));   // all results, one copy
     submitProfiled = prof;
     tSubmit0 = t0;
@@ -438,7 +504,8 @@ struct orbfe_extractor {
     return ORBFE_OK;
   }
 
-  int waitGpuQt(OrbfeKeyPoint* kps, uint8_t* desc, int cap, int* n_out) {
+  int waitGpuQt(OrbfeKeyPoint* kps, uint8_t* desc, int cap, int* n_out, int32_t* matches12 = nullptr,
+                int* nmatches = nullptr) {
     if (!pendingFrames) { set_err("no submitted batch to collect"); return ORBFE_ERR_INVALID; }
     HIP_TRY(hipSetDevice(device));
     const int nframes = pendingFrames;
@@ -491,6 +558,20 @@ struct orbfe_extractor {
       if (n > cap) {
         set_err("frame %d produced %d keypoints, cap is %d", f, n, cap);
         status = ORBFE_ERR_OVERFLOW;
+      }
+    }
+    if (matches12 && nmatches) {
+      const int n0cap = selOff[1] - selOff[0];
+      for (int f = 0; f < nframes; f++) {
+        int32_t* row = matches12 + (size_t)f * cap;
+        const int m = std::min(cap, n0cap);
+        if (pendingMatched) {
+          memcpy(row, h_m12.p + (size_t)f * n0cap, sizeof(int32_t) * m);
+          nmatches[f] = h_nm.p[f];
+        } else {
+          nmatches[f] = 0;
+        }
+        for (int i = pendingMatched ? m : 0; i < cap; i++) row[i] = -1;
       }
     }
     const double t3 = now_ms();
@@ -872,6 +953,55 @@ int orbfe_extract_batch_submit(orbfe_extractor* h, int nframes, const uint8_t* c
 int orbfe_extract_batch_collect(orbfe_extractor* h, OrbfeKeyPoint* kps, uint8_t* desc, int cap, int* n_out) {
   if (!h || !kps || !desc || !n_out || cap <= 0) { set_err("invalid arguments"); return ORBFE_ERR_INVALID; }
   return h->waitGpuQt(kps, desc, cap, n_out);
+}
+
+int orbfe_sfi_chain_create(const orbfe_extractor* h, orbfe_sfi_chain** out) {
+  if (!h || !out) { set_err("NULL argument"); return ORBFE_ERR_INVALID; }
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(h->device));
+  orbfe_sfi_chain* c = new orbfe_sfi_chain();
+  c->device = h->device;
+  c->n0cap = h->selOff[1] - h->selOff[0];
+  int rc = ORBFE_OK;
+  for (int i = 0; i < 2 && rc == ORBFE_OK; i++) {
+    if ((rc = c->sel[i].ensure(c->n0cap))) break;
+    if ((rc = c->angle[i].ensure(c->n0cap))) break;
+    if ((rc = c->desc[i].ensure((size_t)c->n0cap * 32))) break;
+    if (hipEventCreateWithFlags(&c->ready[i], hipEventDisableTiming) != hipSuccess) { set_err("hipEventCreate failed"); rc = ORBFE_ERR_HIP; }
+  }
+  if (rc == ORBFE_OK) rc = c->count.ensure(4);
+  if (rc == ORBFE_OK) {
+    const uint32_t init[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    if (hipMemcpy(c->count.p, init, sizeof init, hipMemcpyHostToDevice) != hipSuccess) { set_err("hipMemcpy failed"); rc = ORBFE_ERR_HIP; }
+  }
+  if (rc != ORBFE_OK) { delete c; return rc; }
+  *out = c;
+  return ORBFE_OK;
+}
+
+void orbfe_sfi_chain_destroy(orbfe_sfi_chain* c) { delete c; }
+
+int orbfe_extract_batch_submit_matched(orbfe_extractor* h, orbfe_sfi_chain* chain, int nframes, const uint8_t* const* gray,
+                                       int in_device_memory, int rows, int cols, size_t stride_bytes, const float bounds[4],
+                                       int window_size, float nnratio, int check_orientation) {
+  if (!h || !chain || !gray || !bounds || nframes <= 0 || rows <= 0 || cols <= 0 || stride_bytes < (size_t)cols || window_size <= 0) {
+    set_err("invalid arguments");
+    return ORBFE_ERR_INVALID;
+  }
+  if (!h->gpuQuadtree) { set_err("GPU matching needs the GPU quadtree path"); return ORBFE_ERR_INVALID; }
+  orbfe_extractor::MatchSpec ms;
+  ms.chain = chain;
+  memcpy(ms.bounds, bounds, sizeof ms.bounds);
+  ms.window = window_size;
+  ms.nnratio = nnratio;
+  ms.checkOri = check_orientation;
+  return h->submitGpuQt(nframes, gray, in_device_memory != 0, rows, cols, stride_bytes, &ms);
+}
+
+int orbfe_extract_batch_collect_matched(orbfe_extractor* h, OrbfeKeyPoint* kps, uint8_t* desc, int cap, int* n_out,
+                                        int32_t* matches12, int* nmatches) {
+  if (!h || !kps || !desc || !n_out || !matches12 || !nmatches || cap <= 0) { set_err("invalid arguments"); return ORBFE_ERR_INVALID; }
+  return h->waitGpuQt(kps, desc, cap, n_out, matches12, nmatches);
 }
 
 int orbfe_extract(orbfe_extractor* h, const uint8_t* gray, int rows, int cols, size_t stride_bytes, OrbfeKeyPoint* kps,

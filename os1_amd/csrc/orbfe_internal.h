@@ -66,6 +66,32 @@ struct SelKp {
   uint32_t lf;     // level | frame << 8
 };
 
+// ---- GPU-resident SearchForInitialization over consecutive frames (orbfe_sfi.hip) ------------------------
+struct SfiParams {
+  // result arena of the batch (device): level-0 slots are the first region of every frame
+  const SelKp* sel;
+  const float* angle;
+  const uint8_t* desc;
+  const uint32_t* selCount;     // [nframes][kMaxLevels]
+  int selPerFrame, n0cap, frameBase;
+  // predecessor of the batch's first frame (level-0 data of the previous batch's last frame)
+  const SelKp* carrySel;
+  const float* carryAngle;
+  const uint8_t* carryDesc;
+  const uint32_t* carryCount;   // device word; > n0cap (0xffffffff) = no predecessor
+  float minX, minY, invW, invH; // Frame grid (Frame.cc:98-99)
+  float window, nnratio;
+  int checkOri;
+  // scratch
+  uint16_t* order;              // [nframes][n0cap] level-0 keypoints of a frame in GetFeaturesInArea order
+  int* orderCount;              // [nframes]
+  uint32_t* pool;               // [nframes][n0cap][n0cap] candidate entries  index | distance << 16
+  uint32_t* pcount;             // [nframes][n0cap]
+  // outputs (inside the result arena)
+  int32_t* matches12;           // [nframes][n0cap] vnMatches12 restricted to level-0 queries
+  int32_t* nmatches;            // [nframes]
+};
+
 // ---- GPU quadtree (orbfe_quadtree.hip) -------------------------------------------------------------
 constexpr int kQtNodeCap = 2048;  // live nodes <= N + 3  =>  N <= 2044 per level
 

@@ -430,7 +430,9 @@ struct orbfe_matcher {
     });
     const double tB = nowMs();
     stageMs[0] = tB - tA;
-    HIP_TRY(hipMemcpyAsync(d_in.p, H, total, hipMemcpyHostToDevice, stream));
+    // ORBFE_MATCH_ZEROCOPY=1: the kernel reads the pinned host arena directly over PCIe instead of a DMA upload
+    static const bool zeroCopy = getenv("ORBFE_MATCH_ZEROCOPY") && atoi(getenv("ORBFE_MATCH_ZEROCOPY")) != 0;
+    if (!zeroCopy) HIP_TRY(hipMemcpyAsync(d_in.p, H, total, hipMemcpyHostToDevice, stream));
 
     const size_t outWords = 64 + 2 * nq;
     if ((rc = d_out.ensure(outWords))) return rc;
@@ -440,7 +442,7 @@ struct orbfe_matcher {
       if ((rc = d_pool.ensure(poolCap))) return rc;
       HIP_TRY(hipMemsetAsync(d_out.p, 0, 64 * sizeof(uint32_t), stream));
       MatchParams M;
-      uint8_t* D = d_in.p;
+      uint8_t* D = zeroCopy ? H : d_in.p;
       M.sx = (const float*)(D + oSx); M.sy = (const float*)(D + oSy); M.soct = (const int*)(D + oOct);
       M.sidx = (const int*)(D + oIdx); M.cellStart = (const int*)(D + oCell); M.tdesc = D + oTd;
       M.pairs = (const PairInfo*)(D + oPair); M.qpair = (const int*)(D + oQp);

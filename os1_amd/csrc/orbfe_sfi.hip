@@ -1,0 +1,259 @@
+// orbfe_sfi.hip -- GPU-resident ORBmatcher::SearchForInitialization for consecutive frames of a stream.
+//
+// Behaviour contract: ORBmatcher::SearchForInitialization (reference src/ORBmatcher.cc:400-515) with
+// vbPrevMatched initialised to F1's keypoints (Tracking.cc:355-357), F1 = the frame's predecessor in the
+// stream, F2 = the frame; Frame grid semantics of Frame.cc:98-99,114-129,209-274.  Everything it reads is
+// already in HBM (the extractor's result arena: level-0 selection slots, angles, descriptors), so a
+// streamed frame is matched without its descriptors ever being re-uploaded.
+//
+// Only level-0 keypoints take part (queries must have octave 0, ORBmatcher.cc:416-418; the window query
+// is restricted to levels [0,0], :420), and level 0 is the first region of the output order, so
+// "keypoint index" == "level-0 slot index" for every index this search produces.
+//
+// Three kernels per batch, all on the extractor's stream:
+//   k_sfi_sort        per frame (as F2): grid cell of every level-0 keypoint (PosInGrid, round()), stable rank
+//                     by (cell, index)  == the order GetFeaturesInArea enumerates candidates in
+//   k_sfi_candidates  one wave per (pair, query): scan F2 in that order, box test, Hamming -> ordered list
+//   k_sfi_resolve     one wave per pair: the reference's sequential bookkeeping (vMatchedDistance, vnMatches21,
+//                     steal-back, rotation histogram, ComputeThreeMaxima) replayed in order; each step's
+//                     best / second-best is a wave reduction over the query's candidate list
+#include <hip/hip_runtime.h>
+
+#include "orbfe_internal.h"
+
+namespace orbfe {
+
+constexpr int kSfiGridCols = 64, kSfiGridRows = 48;   // FRAME_GRID_COLS / ROWS (Frame.h:36-37)
+constexpr int kSfiThLow = 50, kSfiHisto = 30;        // TH_LOW, HISTO_LENGTH (ORBmatcher.cc:38-39)
+
+// level-0 keypoint data of frame f (or of the carried predecessor)
+struct SfiFrame {
+  const SelKp* sel;
+  const float* angle;
+  const uint8_t* desc;
+  int n;
+};
+
+__device__ __forceinline__ SfiFrame sfi_frame(const SfiParams& S, int f) {
+  SfiFrame F;
+  if (f < 0) {
+    F.sel = S.carrySel; F.angle = S.carryAngle; F.desc = S.carryDesc;
+    F.n = S.carryCount ? (int)*S.carryCount : -1;
+    if (F.n > S.n0cap) F.n = -1;   // 0xffffffff = no predecessor yet
+  } else {
+    const long long base = (long long)f * S.selPerFrame;   // level 0 is the first region of a frame's slots
+    F.sel = S.sel + base; F.angle = S.angle + base; F.desc = S.desc + base * 32;
+    F.n = (int)S.selCount[(long long)f * kMaxLevels];
+  }
+  return F;
+}
+
+// ---- per frame: candidate enumeration order -------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sfi_sort(SfiParams S) {
+  extern __shared__ int cellOf[];   // [n0cap]
+  const int f = S.frameBase + blockIdx.x, tid = threadIdx.x;
+  const SfiFrame F = sfi_frame(S, f);
+  for (int k = tid; k < F.n; k += 256) {
+    const uint32_t xy = F.sel[k].xy;
+    const float x = (float)(xy & 0xffff), y = (float)(xy >> 16);
+    const int px = (int)roundf((x - S.minX) * S.invW), py = (int)roundf((y - S.minY) * S.invH);   // Frame.cc:266-267
+    cellOf[k] = (px < 0 || px >= kSfiGridCols || py < 0 || py >= kSfiGridRows) ? -1 : px * kSfiGridRows + py;
+  }
+  __syncthreads();
+  uint16_t* order = S.order + (long long)f * S.n0cap;
+  int nin = 0;
+  for (int k = tid; k < F.n; k += 256) {
+    const int c = cellOf[k];
+    if (c < 0) continue;
+    int rank = 0;
+    for (int j = 0; j < F.n; j++) {
+      const int cj = cellOf[j];
+      rank += (cj >= 0 && (cj < c || (cj == c && j < k))) ? 1 : 0;
+    }
+    order[rank] = (uint16_t)k;
+  }
+  for (int k = tid; k < F.n; k += 256) nin += cellOf[k] >= 0;
+  // block sum of nin
+  __shared__ int tot;
+  if (tid == 0) tot = 0;
+  __syncthreads();
+  atomicAdd(&tot, nin);
+  __syncthreads();
+  if (tid == 0) S.orderCount[f] = tot;
+}
+
+// ---- per (pair, query): ordered candidate list with distances -------------------------------------------------
+__global__ __launch_bounds__(64) void k_sfi_candidates(SfiParams S) {
+  const int i1 = blockIdx.x, fr = blockIdx.y, lane = threadIdx.x;
+  const int f = S.frameBase + fr;
+  const SfiFrame F2 = sfi_frame(S, f);
+  const SfiFrame F1 = sfi_frame(S, fr == 0 ? -1 : f - 1);
+  uint32_t* cnt = S.pcount + (long long)f * S.n0cap + i1;
+  if (F1.n < 0 || i1 >= F1.n) {
+    if (lane == 0 && i1 < S.n0cap) *cnt = 0;
+    return;
+  }
+  const uint32_t qxy = F1.sel[i1].xy;
+  const float x = (float)(qxy & 0xffff), y = (float)(qxy >> 16), r = S.window;
+  uint32_t qd[8];
+  const uint32_t* qp = reinterpret_cast<const uint32_t*>(F1.desc + (long long)i1 * 32);
+#pragma unroll
+  for (int w = 0; w < 8; w++) qd[w] = qp[w];
+  const uint16_t* order = S.order + (long long)f * S.n0cap;
+  const int nin = S.orderCount[f];
+  uint32_t* pool = S.pool + ((long long)f * S.n0cap + i1) * S.n0cap;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int run = 0;
+  for (int e0 = 0; e0 < nin; e0 += 64) {
+    const int e = e0 + lane;
+    bool ok = false;
+    int i2 = 0;
+    if (e < nin) {
+      i2 = order[e];
+      const uint32_t xy = F2.sel[i2].xy;
+      const float dx = (float)(xy & 0xffff) - x, dy = (float)(xy >> 16) - y;
+      ok = fabsf(dx) < r && fabsf(dy) < r;   // Frame.cc:252-256 (levels are 0 by construction)
+    }
+    const unsigned long long m = __ballot(ok);
+    if (ok) {
+      const uint32_t* dp = reinterpret_cast<const uint32_t*>(F2.desc + (long long)i2 * 32);
+      int d = 0;
+#pragma unroll
+      for (int w = 0; w < 8; w++) d += __popc(dp[w] ^ qd[w]);
+      pool[run + __popcll(m & below)] = (uint32_t)i2 | ((uint32_t)d << 16);
+    }
+    run += __popcll(m);
+  }
+  if (lane == 0) *cnt = (uint32_t)run;
+}
+
+// ---- per pair: the sequential bookkeeping ---------------------------------------------------------------------
+__device__ __forceinline__ int sfi_rot_bin(float a1, float a2) {   // ORBmatcher.cc:470-475
+  const float factor = 1.0f / kSfiHisto;
+  float rot = a1 - a2;
+  if (rot < 0.0f) rot += 360.0f;
+  int bin = (int)roundf(rot * factor);
+  if (bin == kSfiHisto) bin = 0;
+  return bin;
+}
+
+__global__ __launch_bounds__(64) void k_sfi_resolve(SfiParams S) {
+  extern __shared__ int sm[];
+  const int fr = blockIdx.x, lane = threadIdx.x;
+  const int f = S.frameBase + fr;
+  const SfiFrame F2 = sfi_frame(S, f);
+  const SfiFrame F1 = sfi_frame(S, fr == 0 ? -1 : f - 1);
+  int32_t* out = S.matches12 + (long long)f * S.n0cap;
+  if (F1.n < 0) {   // no predecessor: first frame of the stream
+    for (int i = lane; i < S.n0cap; i += 64) out[i] = -1;
+    if (lane == 0) S.nmatches[f] = 0;
+    return;
+  }
+  const int n1 = F1.n, n2 = F2.n, cap = S.n0cap;
+  int* vMatchedDistance = sm;            // [cap]
+  int* vnMatches21 = sm + cap;           // [cap]
+  int* vnMatches12 = sm + 2 * cap;       // [cap]
+  int* binOf = sm + 3 * cap;             // [cap] rotation bin of a pushed query, -1 = never pushed
+  int* pcnt = sm + 4 * cap;              // [cap] candidate counts of the queries
+  int* hist = sm + 5 * cap;              // [32]
+  for (int i = lane; i < cap; i += 64) {
+    vMatchedDistance[i] = 0x7fffffff;
+    vnMatches21[i] = -1;
+    vnMatches12[i] = -1;
+    binOf[i] = -1;
+    pcnt[i] = i < n1 ? (int)S.pcount[(long long)f * cap + i] : 0;
+  }
+  if (lane < 32) hist[lane] = 0;
+  __syncthreads();
+  const uint32_t* pool = S.pool + (long long)f * cap * cap;
+  int nm = 0;
+  // software pipeline: the first chunk of query i1+1 is fetched while query i1 is resolved
+  uint32_t nextEntry = 0;
+  if (n1 > 0 && lane < pcnt[0]) nextEntry = pool[lane];
+  for (int i1 = 0; i1 < n1; i1++) {
+    const int cnt = pcnt[i1];
+    uint32_t entry = nextEntry;
+    if (i1 + 1 < n1 && lane < pcnt[i1 + 1]) nextEntry = pool[(long long)(i1 + 1) * cap + lane];
+    if (cnt == 0) continue;
+    int bestDist = 0x7fffffff, bestDist2 = 0x7fffffff, bestIdx2 = -1;
+    for (int c0 = 0; c0 < cnt; c0 += 64) {
+      if (c0 > 0) entry = (c0 + lane < cnt) ? pool[(long long)i1 * cap + c0 + lane] : 0u;
+      int d = 0x7fffffff, i2 = -1;
+      if (c0 + lane < cnt) {
+        i2 = (int)(entry & 0xffff);
+        const int dist = (int)(entry >> 16);
+        if (!(vMatchedDistance[i2] <= dist)) d = dist;   // :439 candidate owned by an equal-or-better match
+      }
+      // chunk minimum, first position wins
+      int md = d, ml = (d == 0x7fffffff) ? 64 : lane;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const int od = __shfl_xor(md, o, 64), ol = __shfl_xor(ml, o, 64);
+        if (od < md || (od == md && ol < ml)) { md = od; ml = ol; }
+      }
+      // second smallest of the chunk (with multiplicity): minimum over the other lanes
+      int sd = (lane == ml) ? 0x7fffffff : d;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sd = min(sd, __shfl_xor(sd, o, 64));
+      const int mi2 = __shfl(i2, ml & 63, 64);
+      // merge with the running (best, second) -- sequential semantics of :441-450, earlier chunk wins ties
+      if (md < bestDist) {
+        bestDist2 = min(bestDist, sd);
+        bestDist = md;
+        bestIdx2 = mi2;
+      } else {
+        bestDist2 = min(bestDist2, md);
+      }
+    }
+    if (bestDist <= kSfiThLow && (float)bestDist < (float)bestDist2 * S.nnratio) {
+      if (lane == 0) {
+        const int old = vnMatches21[bestIdx2];
+        if (old >= 0) vnMatches12[old] = -1;
+        vnMatches12[i1] = bestIdx2;
+        vnMatches21[bestIdx2] = i1;
+        vMatchedDistance[bestIdx2] = bestDist;
+        if (S.checkOri) {
+          const int bin = sfi_rot_bin(F1.angle[i1], F2.angle[bestIdx2]);
+          binOf[i1] = bin;
+          hist[bin]++;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  if (S.checkOri) {
+    // ComputeThreeMaxima, ORBmatcher.cc:1554-1595 (every lane evaluates it identically)
+    int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+    for (int i = 0; i < kSfiHisto; i++) {
+      const int s = hist[i];
+      if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+      else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+      else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+    for (int i = lane; i < n1; i += 64) {
+      const int b = binOf[i];
+      if (b >= 0 && b != ind1 && b != ind2 && b != ind3 && vnMatches12[i] >= 0) vnMatches12[i] = -1;
+    }
+    __syncthreads();
+  }
+  for (int i = lane; i < cap; i += 64) {
+    const int v = i < n1 ? vnMatches12[i] : -1;
+    out[i] = v;
+    nm += v >= 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nm += __shfl_xor(nm, o, 64);
+  if (lane == 0) S.nmatches[f] = nm;
+  (void)n2;
+}
+
+void launch_sfi(const SfiParams& S, int nframes, hipStream_t st) {
+  hipLaunchKernelGGL(k_sfi_sort, dim3(nframes), dim3(256), sizeof(int) * S.n0cap, st, S);
+  hipLaunchKernelGGL(k_sfi_candidates, dim3(S.n0cap, nframes), dim3(64), 0, st, S);
+  hipLaunchKernelGGL(k_sfi_resolve, dim3(nframes), dim3(64), sizeof(int) * (5 * S.n0cap + 32), st, S);
+}
+
+}  // namespace orbfe

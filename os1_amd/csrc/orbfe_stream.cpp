@@ -59,7 +59,9 @@ struct orbfe_stream {
   float nnratio = 0.9f;
   float bounds[4] = {0, 0, 0, 0};
   std::vector<orbfe_extractor*> ext;
-  std::vector<orbfe_matcher*> matchers;   // one per match worker
+  std::vector<orbfe_matcher*> matchers;   // one per match worker (host-side matching path)
+  orbfe_sfi_chain* chain = nullptr;       // GPU-resident matching path (default)
+  bool gpuMatch = true;
   std::vector<Slot> slots;
 
   std::mutex mu;
@@ -101,7 +103,11 @@ struct orbfe_stream {
         Slot& s = slots[job];
         orbfe_extractor* h = ext[nextExt];
         const double ta = nowMs();
-        s.status = orbfe_extract_batch_submit(h, batch, s.frames.data(), s.onDevice, s.rows, s.cols, s.stride);
+        if (gpuMatch && window > 0)
+          s.status = orbfe_extract_batch_submit_matched(h, chain, batch, s.frames.data(), s.onDevice, s.rows, s.cols, s.stride,
+                                                        bounds, window, nnratio, checkOri);
+        else
+          s.status = orbfe_extract_batch_submit(h, batch, s.frames.data(), s.onDevice, s.rows, s.cols, s.stride);
         busySubmit += nowMs() - ta;
         if (s.status != ORBFE_OK) s.err = orbfe_last_error();
         inflight.emplace_back(job, nextExt);
@@ -114,7 +120,11 @@ struct orbfe_stream {
       Slot& s = slots[slot];
       if (s.status == ORBFE_OK) {
         const double ta = nowMs();
-        s.status = orbfe_extract_batch_collect(ext[e], s.kps.data(), s.desc.data(), cap, s.n.data());
+        if (gpuMatch && window > 0)
+          s.status = orbfe_extract_batch_collect_matched(ext[e], s.kps.data(), s.desc.data(), cap, s.n.data(), s.m12.data(),
+                                                         s.nm.data());
+        else
+          s.status = orbfe_extract_batch_collect(ext[e], s.kps.data(), s.desc.data(), cap, s.n.data());
         busyCollect += nowMs() - ta;
         if (s.status != ORBFE_OK) s.err = orbfe_last_error();
       }
@@ -127,7 +137,12 @@ struct orbfe_stream {
       }
       {
         std::lock_guard<std::mutex> lk(mu);
-        matchQ.push_back(slot);
+        if (gpuMatch || window <= 0) {   // matches (if any) came back with the batch: done
+          nBatches++;
+          s.done = true;
+        } else {
+          matchQ.push_back(slot);
+        }
       }
       cv.notify_all();
     }
@@ -155,7 +170,7 @@ struct orbfe_stream {
       }
       Slot& s = slots[slot];
       const double tm0 = nowMs();
-      if (s.status == ORBFE_OK && window > 0) {
+      if (s.status == ORBFE_OK && window > 0 && !gpuMatch) {
         // pairs (predecessor, frame): Tracking::MonocularInitialization style, vbPrevMatched := F1 keypoints
         k1.clear(); k2.clear(); d1.clear(); d2.clear(); n1.clear(); n2.clear(); prev.clear(); m12.clear();
         std::vector<int> frameOfPair;
@@ -235,6 +250,16 @@ int orbfe_stream_create(int nfeatures, float scaleFactor, int nlevels, int iniTh
     }
     s->matchers.push_back(mm);
   }
+  if (const char* hv = getenv("ORBFE_STREAM_HOST_MATCH")) s->gpuMatch = atoi(hv) == 0;
+  {
+    int rc = orbfe_sfi_chain_create(s->ext[0], &s->chain);
+    if (rc != ORBFE_OK) {
+      for (auto* e : s->ext) orbfe_extractor_destroy(e);
+      for (auto* q : s->matchers) orbfe_matcher_destroy(q);
+      delete s;
+      return rc;
+    }
+  }
   s->cap = orbfe_extractor_max_keypoints(s->ext[0]);
   const int nslots = depth + 4;
   s->slots.resize(nslots);
@@ -266,6 +291,7 @@ void orbfe_stream_destroy(orbfe_stream* s) {
   for (auto& t : s->tMatch) if (t.joinable()) t.join();
   for (auto* e : s->ext) orbfe_extractor_destroy(e);
   for (auto* q : s->matchers) orbfe_matcher_destroy(q);
+  orbfe_sfi_chain_destroy(s->chain);
   delete s;
 }
 
