@@ -184,18 +184,29 @@ __global__ __launch_bounds__(64) void k_sfi_resolve(SfiParams S) {
         const int dist = (int)(entry >> 16);
         if (!(vMatchedDistance[i2] <= dist)) d = dist;   // :439 candidate owned by an equal-or-better match
       }
-      // chunk minimum, first position wins
-      int md = d, ml = (d == 0x7fffffff) ? 64 : lane;
+      // Chunk minimum / second minimum by bitwise bisection with ballots (distances fit 9 bits; 511 = skipped):
+      // after the loop `c1` holds exactly the lanes with the smallest distance; its lowest lane is the first
+      // position (candidate order = lane order).  Scalar mask arithmetic instead of 19 dependent cross-lane
+      // permutes per query.
+      const unsigned dd = (d == 0x7fffffff) ? 511u : (unsigned)d;
+      unsigned long long c1 = ~0ull;
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const int od = __shfl_xor(md, o, 64), ol = __shfl_xor(ml, o, 64);
-        if (od < md || (od == md && ol < ml)) { md = od; ml = ol; }
+      for (int b = 8; b >= 0; b--) {
+        const unsigned long long z = __ballot(((dd >> b) & 1u) == 0u) & c1;
+        if (z) c1 = z;
       }
-      // second smallest of the chunk (with multiplicity): minimum over the other lanes
-      int sd = (lane == ml) ? 0x7fffffff : d;
+      const int ml = (int)__builtin_ctzll(c1);
+      const unsigned d1 = (unsigned)__shfl((int)dd, ml, 64);
+      unsigned long long c2 = ~(1ull << ml);   // everyone but the winner
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) sd = min(sd, __shfl_xor(sd, o, 64));
-      const int mi2 = __shfl(i2, ml & 63, 64);
+      for (int b = 8; b >= 0; b--) {
+        const unsigned long long z = __ballot(((dd >> b) & 1u) == 0u) & c2;
+        if (z) c2 = z;
+      }
+      const unsigned d2 = (unsigned)__shfl((int)dd, (int)__builtin_ctzll(c2), 64);
+      const int md = d1 >= 511u ? 0x7fffffff : (int)d1;
+      const int sd = d2 >= 511u ? 0x7fffffff : (int)d2;
+      const int mi2 = __shfl(i2, ml, 64);
       // merge with the running (best, second) -- sequential semantics of :441-450, earlier chunk wins ties
       if (md < bestDist) {
         bestDist2 = min(bestDist, sd);
