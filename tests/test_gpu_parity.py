@@ -346,3 +346,35 @@ def test_distinctive_descriptors_parity(api, oracle):
     got = api.Matcher().distinctive_descriptors(lists)
     for d, g in zip(lists, got):
         assert g == oracle.distinctive_descriptor(d), len(d)
+
+
+def test_config5_4k_fisheye_search_by_projection(api, oracle):
+    """BASELINE.json configs[4]: 3840x2160, nFeatures=4000, camera modo 1 (equidistant fisheye: keypoints are
+    undistorted on the host, the image is not warped), SearchByProjection against 10 000 MapPoints, th 1 and 5."""
+    W, H, N = 3840, 2160, 4000
+    fx = fy = 2196.0
+    cx, cy = 1839.0, 1155.0
+    img = synth(5, W, H)
+    ex = api.Extractor(N, 1.2, 8, 20, 7)
+    ox = OracleExtractor(N, 1.2, 8, 20, 7, oracle)
+    k, d = ex(img)
+    _cmp_extract((k, d), ox.extract(img))
+    assert len(k) >= 3900
+    # Frame::UndistortKeyPoints (modo 1) and ComputeImageBounds: product helper == oracle
+    kun = k.copy()
+    xy = api.undistort_equidistant(np.stack([k['x'], k['y']], 1), fx, fy, cx, cy)
+    assert xy.tobytes() == oracle.undistort_equidistant(np.stack([k['x'], k['y']], 1), fx, fy, cx, cy).tobytes()
+    kun['x'], kun['y'] = xy[:, 0], xy[:, 1]
+    corners = api.undistort_equidistant(np.array([[0, 0], [W, 0], [0, H], [W, H]], np.float32), fx, fy, cx, cy)
+    bounds = (float(min(corners[0, 0], corners[2, 0])), float(max(corners[1, 0], corners[3, 0])),
+              float(min(corners[0, 1], corners[1, 1])), float(max(corners[2, 1], corners[3, 1])))
+    sf = ex.tables()['sf']
+    rng = np.random.default_rng(55)
+    mxy, level, viewcos, flags, mdesc = _mappoints(kun, d, 10000, rng)
+    occ = np.zeros(len(k), np.uint8)
+    m = api.Matcher()
+    for th in (1.0, 5.0):
+        n, a = m.search_by_projection(kun, d, bounds, sf, occ, mxy, level, viewcos, flags, mdesc, th, 0.8)
+        on, oa = oracle.search_by_projection(kun, d, bounds, sf, occ, mxy, level, viewcos, flags, mdesc, th, 0.8)
+        assert n == on and (a == oa).all()
+        assert n > 1000
