@@ -35,6 +35,8 @@ void launch_describe_slots(const PyramidParams& P, const SelKp* sel, int nslots,
                            const uint32_t* selCount, int selPerFrame, const int* selOff, hipStream_t st);
 void launch_quadtree(const QtParams& Q, int nframes, hipStream_t st);
 void launch_sfi(const SfiParams& S, int nframes, hipStream_t st);
+void launch_sfi_carry(const SfiParams& S, int lastFrame, SelKp* cSel, float* cAngle, uint8_t* cDesc, uint32_t* cCount,
+                      hipStream_t st);
 
 thread_local std::string g_err;
 void set_err(const char* fmt, ...) {
@@ -486,12 +488,8 @@ struct orbfe_extractor {
       launch_sfi(SP, nframes, st);
       HIP_TRY(hipGetLastError());
       // hand the last frame's level-0 data to the next batch
-      const size_t lastBase = (size_t)(nframes - 1) * selPerFrame;
-      HIP_TRY(hipMemcpyAsync(ch.sel[cur].p, d_sel.p + lastBase, sizeof(SelKp) * n0cap, hipMemcpyDeviceToDevice, st));
-      HIP_TRY(hipMemcpyAsync(ch.angle[cur].p, d_angle.p + lastBase, sizeof(float) * n0cap, hipMemcpyDeviceToDevice, st));
-      HIP_TRY(hipMemcpyAsync(ch.desc[cur].p, d_desc.p + lastBase * 32, (size_t)32 * n0cap, hipMemcpyDeviceToDevice, st));
-      HIP_TRY(hipMemcpyAsync(ch.count.p + cur, d_selCount.p + (size_t)(nframes - 1) * kMaxLevels, sizeof(uint32_t),
-                             hipMemcpyDeviceToDevice, st));
+      launch_sfi_carry(SP, nframes - 1, ch.sel[cur].p, ch.angle[cur].p, ch.desc[cur].p, ch.count.p + cur, st);
+      HIP_TRY(hipGetLastError());
       HIP_TRY(hipEventRecord(ch.ready[cur], st));
       ch.seq++;
       pendingMatched = true;

@@ -261,6 +261,25 @@ __global__ __launch_bounds__(64) void k_sfi_resolve(SfiParams S) {
   (void)n2;
 }
 
+// Hand the level-0 data of the batch's last frame to the next batch (one small kernel instead of four D2D copies).
+__global__ __launch_bounds__(256) void k_sfi_carry(SfiParams S, int lastFrame, SelKp* cSel, float* cAngle, uint8_t* cDesc,
+                                                   uint32_t* cCount) {
+  const long long base = (long long)lastFrame * S.selPerFrame;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < S.n0cap) {
+    cSel[i] = S.sel[base + i];
+    cAngle[i] = S.angle[base + i];
+  }
+  if (i < S.n0cap * 8)
+    reinterpret_cast<uint32_t*>(cDesc)[i] = reinterpret_cast<const uint32_t*>(S.desc + base * 32)[i];
+  if (i == 0) *cCount = S.selCount[(long long)lastFrame * kMaxLevels];
+}
+
+void launch_sfi_carry(const SfiParams& S, int lastFrame, SelKp* cSel, float* cAngle, uint8_t* cDesc, uint32_t* cCount,
+                      hipStream_t st) {
+  hipLaunchKernelGGL(k_sfi_carry, dim3((S.n0cap * 8 + 255) / 256), dim3(256), 0, st, S, lastFrame, cSel, cAngle, cDesc, cCount);
+}
+
 void launch_sfi(const SfiParams& S, int nframes, hipStream_t st) {
   hipLaunchKernelGGL(k_sfi_sort, dim3(nframes), dim3(256), sizeof(int) * S.n0cap, st, S);
   hipLaunchKernelGGL(k_sfi_candidates, dim3(S.n0cap, nframes), dim3(64), 0, st, S);
