@@ -37,7 +37,8 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='frames per step and GPU')
     ap.add_argument('--cpu-frames', type=int, default=24, help='frames of the CPU-oracle baseline sample (0 = skip)')
     ap.add_argument('--no-match', action='store_true', help='extract only (configs[1])')
-    ap.add_argument('--host-input', action='store_true', help='frames start in pageable HOST memory (PCIe-inclusive rate; never the headline value)')
+    ap.add_argument('--host-input', nargs='?', const='pageable', default=None, choices=['pageable', 'pinned'],
+                    help='frames start in HOST memory, pageable or page-locked (PCIe-inclusive rate; never the headline value)')
     ap.add_argument('--depth', type=int, default=2, help='extraction batches in flight inside the stream runner')
     args = ap.parse_args()
 
@@ -72,7 +73,8 @@ def main():
     # by (2,1) px"; derived from the base frame so that noise does not accumulate along the stream)
     frames = [base] + [shifted(base, 2 * i, i, seed * 1000 + i) for i in range(1, B)]
     dev = api.DeviceFrames(frames, local_rank)
-    host_ptrs = [f.ctypes.data for f in frames]
+    pinned = api.PinnedFrames(frames) if args.host_input == 'pinned' else None
+    host_ptrs = pinned.ptrs if pinned else [f.ctypes.data for f in frames]
 
     def push():
         if args.host_input:
@@ -161,7 +163,7 @@ def main():
                        'frames_per_step_per_gpu': B, 'image': '%dx%d' % (W, H), 'nfeatures': NFEAT, 'nlevels': NLEVELS,
                        'parallelism': 'independent streams, 1 per GPU' if world > 1 else 'single GPU',
                        'matches_per_frame': round(nmatch_total[0] / max(B * args.steps, 1), 1),
-                       'input': ('frames in pageable host memory (PCIe-inclusive)' if args.host_input else 'frames resident in HBM') + '; keypoints/descriptors/matches returned to host'},
+                       'input': ('frames in %s host memory (PCIe-inclusive)' % args.host_input if args.host_input else 'frames resident in HBM') + '; keypoints/descriptors/matches returned to host'},
             'gpu_kernel_ms_per_frame': {k: round(v / max(kframes, 1), 5) for k, v in
                                         zip(('pyramid', 'fast_cells', 'compaction', 'describe', 'quadtree'), kms)},
             'ms_per_step_percentiles': (lambda d: {'p10': round(float(np.percentile(d, 10)), 4), 'p50': round(float(np.percentile(d, 50)), 4),

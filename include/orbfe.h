@@ -58,6 +58,13 @@ int orbfe_device_malloc(int device_id, size_t bytes, void** out);
 int orbfe_device_free(int device_id, void* ptr);
 int orbfe_device_upload(int device_id, void* dst_device, const void* src_host, size_t bytes);
 int orbfe_device_synchronize(int device_id);
+/* Page-locked host memory for frames handed over in HOST memory (in_device_memory == 0): a frame that
+ * lives in such a buffer is copied by DMA straight from it while earlier batches compute; a frame in
+ * ordinary pageable memory is staged by the HIP runtime first (several times slower).  hipHostMalloc /
+ * hipHostFree.  A cv::Mat can wrap the buffer (Mat(rows, cols, CV_8UC1, ptr, step)) so the camera/decoder
+ * writes into it directly. */
+int orbfe_host_alloc(size_t bytes, void** out);
+int orbfe_host_free(void* ptr);
 
 /* ---------------------------------------------------------------------------------------------
  * Extractor.  Replaces ORB_SLAM2::ORBextractor (include/ORBextractor.h:155-373).

@@ -89,6 +89,8 @@ def load_library():
     L.orbfe_device_malloc.argtypes = [ci, C.c_size_t, C.POINTER(vp)]
     L.orbfe_device_free.argtypes = [ci, vp]
     L.orbfe_device_upload.argtypes = [ci, vp, vp, C.c_size_t]
+    L.orbfe_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.orbfe_host_free.argtypes = [vp]
     L.orbfe_device_synchronize.argtypes = [ci]
     L.orbfe_stream_create.argtypes = [ci, cf, ci, ci, ci, ci, ci, ci, C.POINTER(vp)]
     L.orbfe_stream_destroy.argtypes = [vp]
@@ -414,6 +416,36 @@ def sincos_host_mismatches(lo_bits, hi_bits, step=1):
     bad = C.c_longlong(0)
     _check(load_library().orbfe_debug_sincos_host_check(lo_bits, hi_bits, step, C.byref(bad)))
     return bad.value
+
+
+class PinnedFrames:
+    """A stack of equally sized u8 frames in page-locked HOST memory (orbfe_host_alloc): the fast way to hand
+    host frames to the extractor (in_device_memory == 0)."""
+
+    def __init__(self, frames):
+        L = load_library()
+        self.rows, self.cols = frames[0].shape
+        self.stride = self.cols
+        self.n = len(frames)
+        self.frame_bytes = self.rows * self.stride
+        p = C.c_void_p()
+        _check(L.orbfe_host_alloc(self.frame_bytes * self.n, C.byref(p)))
+        self.base = p.value
+        view = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(self.n, self.rows, self.cols))
+        for i, f in enumerate(frames):
+            view[i] = f
+        self.ptrs = [self.base + i * self.frame_bytes for i in range(self.n)]
+
+    def free(self):
+        if getattr(self, 'base', None):
+            load_library().orbfe_host_free(C.c_void_p(self.base))
+            self.base = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class DeviceFrames:

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -118,6 +119,26 @@ struct orbfe_sfi_chain {
   }
 };
 
+// One upload lane (HIP stream) per device, shared by every extractor handle: host frames of successive
+// batches cross PCIe one after the other at full link rate while the previous batch computes.  With each handle
+// copying on its own stream, two handles settle into lock-step (both copy at half rate, then both compute).
+struct UploadLane {
+  std::mutex mu;
+  hipStream_t stream = nullptr;
+};
+static UploadLane* upload_lane(int device) {
+  static std::mutex mu;
+  static UploadLane* lanes[64] = {};
+  if (device < 0 || device >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!lanes[device]) {
+    UploadLane* l = new UploadLane;
+    if (hipStreamCreateWithFlags(&l->stream, hipStreamNonBlocking) != hipSuccess) { delete l; return nullptr; }
+    lanes[device] = l;   // lives for the process
+  }
+  return lanes[device];
+}
+
 struct orbfe_extractor {
   int nfeatures, nlevels, iniTh, minTh, device;
   double scaleFactor;  // the reference keeps the float ctor argument in a double member (ORBextractor.h:313)
@@ -127,6 +148,7 @@ struct orbfe_extractor {
   hipStream_t stream = nullptr;          // == streams[0]
   hipStream_t streams[kMaxSub] = {};
   int subBatches = 4;
+  hipEvent_t evUpload = nullptr;
   hipEvent_t evFrame0 = nullptr, evS1[kMaxSub] = {};
   int subSel[kMaxSub] = {};
   size_t candHostCap = 0;
@@ -169,6 +191,7 @@ struct orbfe_extractor {
   PinBuf<const uint8_t*> h_frame0;
   PinBuf<uint32_t> h_cand;
   long long inPitch = 0;
+  bool inLinear = false;   // host frames are uploaded with linear copies (inPitch == host stride)
   int lastFrames = 0;
   float stageMs[5] = {0, 0, 0, 0, 0};
   hipEvent_t ev[kMaxSub][6] = {};
@@ -204,6 +227,7 @@ struct orbfe_extractor {
     d_idxA.release(); d_idxB.release(); d_rank.release(); d_ownA.release(); d_ownB.release();
     d_nodesA.release(); d_nodesB.release();
     if (evFrame0) (void)hipEventDestroy(evFrame0);
+    if (evUpload) (void)hipEventDestroy(evUpload);
     for (auto& st : streams) if (st) (void)hipStreamDestroy(st);
   }
 
@@ -336,7 +360,7 @@ struct orbfe_extractor {
     return ORBFE_OK;
   }
 
-  int setBatch(int nframes, bool hostInput) {
+  int setBatch(int nframes, bool hostInput, size_t hostStride = 0) {
     int rc;
     if (nframes > batchCap) {
       if ((rc = d_slab.ensure((size_t)P.slabBytes * nframes))) return rc;
@@ -380,7 +404,10 @@ struct orbfe_extractor {
       if ((rc = h_cand.ensure(candHostCap * (size_t)batchCap))) return rc;
     }
     if (hostInput) {
-      inPitch = align_up(cols, 256);
+      // rows that are (nearly) contiguous on the host travel as ONE linear DMA per run of frames; a narrow view
+      // of a much wider image is copied row by row into a compact device frame
+      inLinear = hostStride >= (size_t)cols && hostStride - cols <= (size_t)cols / 8;
+      inPitch = inLinear ? (long long)hostStride : align_up(cols, 256);
       if ((rc = d_in.ensure((size_t)inPitch * rows * nframes))) return rc;
     }
     P.slab = d_slab.p;
@@ -395,6 +422,24 @@ struct orbfe_extractor {
 
   // GPU-quadtree path: frame -> pyramid -> FAST -> compaction -> quadtree -> orientation/blur/rBRIEF in ONE
   // stream submission, one synchronisation, fixed-size D2H of the selection slots.
+  // H2D of host frames [f0, f0+nf) into d_in on `st`
+  int uploadFrames(int f0, int nf, const uint8_t* const* gray, size_t stride, int r, int c, hipStream_t st) {
+    if (!inLinear) {
+      for (int f = f0; f < f0 + nf; f++)
+        HIP_TRY(hipMemcpy2DAsync(d_in.p + (size_t)inPitch * rows * f, inPitch, gray[f], stride, c, r, hipMemcpyHostToDevice, st));
+      return ORBFE_OK;
+    }
+    const size_t frameBytes = stride * (size_t)r;
+    for (int f = f0; f < f0 + nf;) {
+      int g = f + 1;
+      while (g < f0 + nf && gray[g] == gray[g - 1] + frameBytes) g++;   // frames contiguous in host memory
+      const size_t bytes = frameBytes * (size_t)(g - f - 1) + stride * (size_t)(r - 1) + c;
+      HIP_TRY(hipMemcpyAsync(d_in.p + frameBytes * f, gray[f], bytes, hipMemcpyHostToDevice, st));
+      f = g;
+    }
+    return ORBFE_OK;
+  }
+
   int runGpuQt(int nframes, const uint8_t* const* gray, bool onDevice, int r, int c, size_t stride, OrbfeKeyPoint* kps,
                uint8_t* desc, int cap, int* n_out) {
     int rc = submitGpuQt(nframes, gray, onDevice, r, c, stride);
@@ -414,15 +459,25 @@ struct orbfe_extractor {
     HIP_TRY(hipSetDevice(device));
     int rc;
     if ((rc = setGeometry(r, c))) return rc;
-    if ((rc = setBatch(nframes, !onDevice))) return rc;
+    if ((rc = setBatch(nframes, !onDevice, stride))) return rc;
     const double t0 = now_ms();
     hipStream_t st = streams[0];
     for (int f = 0; f < nframes; f++) {
       if (!gray[f]) { set_err("frame %d is NULL", f); return ORBFE_ERR_INVALID; }
       h_frame0.p[f] = onDevice ? gray[f] : d_in.p + (size_t)inPitch * rows * f;
-      if (!onDevice)
-        HIP_TRY(hipMemcpy2DAsync(const_cast<uint8_t*>(h_frame0.p[f]), inPitch, gray[f], stride, c, r,
-                                 hipMemcpyHostToDevice, st));
+    }
+    hipPointerAttribute_t attr;
+    const bool pinned = !onDevice && hipPointerGetAttributes(&attr, gray[0]) == hipSuccess && attr.type == hipMemoryTypeHost;
+    if (!onDevice && !pinned) {
+      (void)hipGetLastError();   // pageable memory: the runtime stages the copy synchronously; keep it on this handle's stream
+      if ((rc = uploadFrames(0, nframes, gray, stride, r, c, st))) return rc;
+    } else if (!onDevice) {
+      UploadLane* lane = upload_lane(device);
+      if (!lane) { set_err("cannot create the upload stream"); return ORBFE_ERR_HIP; }
+      std::lock_guard<std::mutex> lk(lane->mu);
+      if ((rc = uploadFrames(0, nframes, gray, stride, r, c, lane->stream))) return rc;
+      HIP_TRY(hipEventRecord(evUpload, lane->stream));
+      HIP_TRY(hipStreamWaitEvent(st, evUpload, 0));
     }
     P.stride0 = onDevice ? (long long)stride : inPitch;
     P.frameBase = 0;
@@ -592,7 +647,7 @@ struct orbfe_extractor {
     HIP_TRY(hipSetDevice(device));
     int rc;
     if ((rc = setGeometry(r, c))) return rc;
-    if ((rc = setBatch(nframes, !onDevice))) return rc;
+    if ((rc = setBatch(nframes, !onDevice, stride))) return rc;
     const double t0 = now_ms();
     if (!pool) {
       pool.reset(new HostPool(hostThreads));
@@ -615,10 +670,7 @@ struct orbfe_extractor {
       hipStream_t st = streams[s];
       const int f0 = subF0[s], nf = subF0[s + 1] - f0;
       if (s) HIP_TRY(hipStreamWaitEvent(st, evFrame0, 0));
-      if (!onDevice)
-        for (int f = f0; f < f0 + nf; f++)
-          HIP_TRY(hipMemcpy2DAsync(const_cast<uint8_t*>(h_frame0.p[f]), inPitch, gray[f], stride, c, r,
-                                   hipMemcpyHostToDevice, st));
+      if (!onDevice && (rc = uploadFrames(f0, nf, gray, stride, r, c, st))) return rc;
       PyramidParams Q = P;
       Q.frameBase = f0;
       HIP_TRY(hipEventRecord(ev[s][0], st));
@@ -801,6 +853,15 @@ int orbfe_device_upload(int device_id, void* dst_device, const void* src_host, s
   HIP_TRY(hipMemcpy(dst_device, src_host, bytes, hipMemcpyHostToDevice));
   return ORBFE_OK;
 }
+int orbfe_host_alloc(size_t bytes, void** out) {
+  if (!out || bytes == 0) { set_err("bad argument"); return ORBFE_ERR_INVALID; }
+  HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocPortable));
+  return ORBFE_OK;
+}
+int orbfe_host_free(void* ptr) {
+  HIP_TRY(hipHostFree(ptr));
+  return ORBFE_OK;
+}
 int orbfe_device_synchronize(int device_id) {
   HIP_TRY(hipSetDevice(device_id));
   HIP_TRY(hipDeviceSynchronize());
@@ -864,7 +925,8 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
     }
   }
   h->stream = h->streams[0];
-  bool evOk = hipEventCreate(&h->evFrame0) == hipSuccess;
+  bool evOk = hipEventCreate(&h->evFrame0) == hipSuccess &&
+              hipEventCreateWithFlags(&h->evUpload, hipEventDisableTiming) == hipSuccess;
   for (auto& e : h->evS1) evOk = evOk && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
   for (auto& es : h->ev) for (auto& e : es) evOk = evOk && hipEventCreate(&e) == hipSuccess;
   if (!evOk) { set_err("hipEventCreate failed"); delete h; return ORBFE_ERR_HIP; }

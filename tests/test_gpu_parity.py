@@ -59,6 +59,12 @@ def test_batch_device_input_and_strides(api, oracle):
     kps, desc, n = ex.extract_batch_ptrs(dev.ptrs, 600, 800, 832, True)
     for i in range(3):
         _cmp_extract((kps[i, :n[i]], desc[i, :n[i]]), want[i])
+    # frames in page-locked host memory (orbfe_host_alloc)
+    pin = api.PinnedFrames(imgs)
+    kps, desc, n = ex.extract_batch_ptrs(pin.ptrs, 600, 800, 800, False)
+    for i in range(3):
+        _cmp_extract((kps[i, :n[i]], desc[i, :n[i]]), want[i])
+    pin.free()
     # host image with a padded stride (a ROI view)
     big = np.zeros((600, 900), np.uint8)
     big[:, 50:850] = imgs[0]
