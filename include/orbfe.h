@@ -309,6 +309,53 @@ int orbfe_window_candidates(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, const
 int orbfe_distinctive_descriptors(orbfe_matcher* m, int n_mp, const int32_t* offsets, const uint8_t* descs,
                                   int32_t* best_idx);
 
+/* ---------------------------------------------------------------------------------------------
+ * Bag of words.  Replaces the DBoW2 calls on the path: Frame::ComputeBoW (src/Frame.cc:277-284) ->
+ * TemplatedVocabulary<FORB>::transform(features, BowVector&, FeatureVector&, levelsup)
+ * (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1136-1204, descent :1306-1347), and the two
+ * ORBmatcher::SearchByBoW overloads (src/ORBmatcher.cc:154-283, 517-650).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct orbfe_vocabulary orbfe_vocabulary;
+
+/* Vocabulary from the fork's binary file (loadFromBinaryFile, TemplatedVocabulary.h:1563-1640): 4 header bytes
+ * {k, L, scoring, weighting} followed by 45-byte node records {int32 parent, u8 isLeaf, u8 descriptor[32],
+ * f64 weight} (packed, little endian).  Node ids count from 1 in record order (0 = root), children keep record
+ * order, word ids count the isLeaf records.  orbfe_vocabulary_create takes the header fields and the records
+ * separately (a loader of the text / yml formats fills the same records); _from_image takes the file contents.
+ * scoring: 0 L1_NORM .. 5 DOT_PRODUCT, weighting: 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY (BowVector.h:36-53).
+ * The tree lives in HBM (k=10, L=6: 1.1 M nodes, about 45 MB). */
+int orbfe_vocabulary_create(int device_id, int k, int L, int scoring, int weighting, const void* records, int n_records,
+                            orbfe_vocabulary** out);
+int orbfe_vocabulary_create_from_image(int device_id, const void* image, size_t bytes, orbfe_vocabulary** out);
+void orbfe_vocabulary_destroy(orbfe_vocabulary* v);
+int orbfe_vocabulary_info(const orbfe_vocabulary* v, int* k, int* L, int* scoring, int* weighting, int* n_nodes,
+                          int* n_words);
+
+/* transform(features, v, fv, levelsup) for n descriptors (32-byte rows; host memory, or device memory when
+ * in_device_memory != 0).  BowVector: n_words (word id ascending, value) pairs in bow_ids / bow_values (capacity
+ * n).  FeatureVector: n_fv_nodes node ids ascending in fv_nodes (capacity n), fv_offsets[i]..fv_offsets[i+1]
+ * (capacity n+1) delimit the node's feature indices in fv_features (capacity n), in push_back order.
+ * word_of_feature / node_of_feature (optional, n each): the word id and the node id `levelsup` levels above the
+ * leaf that each descriptor reached (stopped words, weight 0, are reported here but left out of both vectors).
+ * Values are bit-identical to DBoW2's doubles: weights are summed in feature order, normalised in word order. */
+int orbfe_bow_transform(orbfe_vocabulary* v, const uint8_t* desc, int n, int in_device_memory, int levelsup,
+                        uint32_t* bow_ids, double* bow_values, int* n_words, uint32_t* fv_nodes, uint32_t* fv_offsets,
+                        uint32_t* fv_features, int* n_fv_nodes, uint32_t* word_of_feature, uint32_t* node_of_feature);
+
+/* int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches)  (ORBmatcher.cc:154-283;
+ * strict_threshold = 0, valid2 = NULL) and int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2,
+ * vector<MapPoint*>& vpMatches12)  (:517-650; strict_threshold = 1: `bestDist1 < TH_LOW`).
+ * Side 1 is the keyframe whose MapPoints are searched for: valid1[i] != 0 iff keypoint i has a MapPoint that is
+ * not bad; valid2 likewise for side 2 (NULL = every keypoint is a candidate, as for a Frame).  angle1 / angle2: the
+ * keypoints' angles (needed when check_orientation).  fvX_*: the FeatureVectors in the layout
+ * orbfe_bow_transform writes.  matches12[i1] = matched index on side 2 or -1 (capacity n1); for the Frame overload
+ * vpMapPointMatches[matches12[i1]] = vpMapPointsKF[i1].  *nmatches = the function's return value. */
+int orbfe_search_by_bow(orbfe_matcher* m, const uint8_t* desc1, const float* angle1, const uint8_t* valid1, int n1,
+                        const uint32_t* fv1_nodes, const uint32_t* fv1_offsets, const uint32_t* fv1_features, int n_fv1,
+                        const uint8_t* desc2, const float* angle2, const uint8_t* valid2, int n2,
+                        const uint32_t* fv2_nodes, const uint32_t* fv2_offsets, const uint32_t* fv2_features, int n_fv2,
+                        float nnratio, int check_orientation, int strict_threshold, int32_t* matches12, int* nmatches);
+
 /* void Frame::antidistorsionarProyeccionEquidistante(cv::Mat& puntos)  (src/Frame.cc:355-384): os1's
  * equidistant-fisheye keypoint undistortion (camera `modo: 1`), used by Frame::UndistortKeyPoints (:286-320) and
  * Frame::ComputeImageBounds (:322-353).  Host double-precision math on n (x, y) float pairs, in place; K is the

@@ -39,6 +39,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <list>
+#include <map>
 #include <utility>
 #include <vector>
 
@@ -1048,6 +1049,238 @@ void orc_undistort_equidistant(float* xy, int n, float fx, float fy, float cx, f
     xy[2 * i] = (float)(pr0 / pr2);
     xy[2 * i + 1] = (float)(pr1 / pr2);
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bag of words: Frame::ComputeBoW (Frame.cc:277-284) = DBoW2 TemplatedVocabulary<FORB>::transform
+// (features, BowVector&, FeatureVector&, levelsup) -- Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1136-1204,
+// single-feature descent :1306-1347, BowVector::addWeight/addIfNotExist/normalize (BowVector.cpp:30-82),
+// FeatureVector::addFeature (FeatureVector.cpp:27-41), FORB::distance (FORB.cpp:81-101).
+// The vocabulary is the fork's binary file format (TemplatedVocabulary.h:1563-1640): header bytes k, L, scoring,
+// weighting, then 45-byte records {int32 parent, u8 isLeaf, u8 descriptor[32], double weight}; node ids count
+// from 1 in record order, children are appended in record order, word ids count leaves in record order.
+// (The reference's `while(!eof)` loop appends one stale copy of the last record; a copy can never win the strict
+// `d < best_d` descent, so it is not reproduced.)
+// ---------------------------------------------------------------------------------------------
+struct BowNode {
+  int parent = 0;
+  std::vector<int> children;
+  uint8_t descriptor[32] = {};
+  double weight = 0;
+  int word_id = 0;
+  bool isLeaf() const { return children.empty(); }
+};
+struct BowVocabulary {
+  int k, L, scoring, weighting;
+  std::vector<BowNode> nodes;
+};
+
+void* orc_vocab_create(int k, int L, int scoring, int weighting, const uint8_t* records, int nrecords) {
+  BowVocabulary* v = new BowVocabulary{k, L, scoring, weighting, {}};
+  v->nodes.resize(1);
+  int nwords = 0;
+  for (int r = 0; r < nrecords; r++) {
+    const uint8_t* buffer = records + 45 * (size_t)r;
+    int nid = (int)v->nodes.size();
+    v->nodes.resize(v->nodes.size() + 1);
+    int pid;
+    memcpy(&pid, buffer, 4);
+    v->nodes[nid].parent = pid;
+    v->nodes[pid].children.push_back(nid);
+    memcpy(v->nodes[nid].descriptor, buffer + 5, 32);
+    memcpy(&v->nodes[nid].weight, buffer + 37, 8);
+    if (buffer[4] > 0) v->nodes[nid].word_id = nwords++;
+  }
+  return v;
+}
+void orc_vocab_destroy(void* h) { delete (BowVocabulary*)h; }
+
+// transform(features, v, fv, levelsup).  Outputs: BowVector as (ascending word id, value) pairs; FeatureVector as
+// ascending node ids with CSR offsets into the feature-index list; per-feature word / node / weight for debugging.
+int orc_bow_transform(void* h, const uint8_t* desc, int n, int levelsup, uint32_t* bow_ids, double* bow_vals,
+                      int* n_words, uint32_t* fv_nodes, uint32_t* fv_off, uint32_t* fv_feat, int* n_fv,
+                      uint32_t* word_of_feature, uint32_t* node_of_feature) {
+  const BowVocabulary& V = *(BowVocabulary*)h;
+  std::map<uint32_t, double> v;
+  std::map<uint32_t, std::vector<unsigned>> fv;
+  const bool must = V.scoring != 5;                 // DotProductScoring does not normalise (ScoringObject.h:74-89)
+  const bool normL2 = V.scoring == 1;
+  if (V.nodes.size() > 1) {
+    for (int i = 0; i < n; i++) {
+      const uint8_t* feature = desc + 32 * (size_t)i;
+      // TemplatedVocabulary.h:1306-1347
+      const int nid_level = V.L - levelsup;
+      uint32_t nid = 0;
+      int final_id = 0, current_level = 0;
+      do {
+        ++current_level;
+        const std::vector<int>& nodes = V.nodes[final_id].children;
+        final_id = nodes[0];
+        double best_d = descriptor_distance(feature, V.nodes[final_id].descriptor);
+        for (size_t c = 1; c < nodes.size(); c++) {
+          double d = descriptor_distance(feature, V.nodes[nodes[c]].descriptor);
+          if (d < best_d) { best_d = d; final_id = nodes[c]; }
+        }
+        if (current_level == nid_level) nid = final_id;
+      } while (!V.nodes[final_id].isLeaf());
+      const uint32_t id = V.nodes[final_id].word_id;
+      const double w = V.nodes[final_id].weight;
+      if (word_of_feature) word_of_feature[i] = id;
+      if (node_of_feature) node_of_feature[i] = nid;
+      if (w > 0) {
+        if (V.weighting == 0 || V.weighting == 1) v[id] += w;   // addWeight
+        else v.insert({id, w});                                 // addIfNotExist
+        fv[nid].push_back(i);
+      }
+    }
+    if ((V.weighting == 0 || V.weighting == 1) && !v.empty() && !must) {
+      const double nd = v.size();
+      for (auto& e : v) e.second /= nd;
+    }
+    if (must) {
+      double norm = 0.0;
+      if (!normL2) { for (auto& e : v) norm += fabs(e.second); }
+      else { for (auto& e : v) norm += e.second * e.second; norm = sqrt(norm); }
+      if (norm > 0.0) for (auto& e : v) e.second /= norm;
+    }
+  }
+  int nw = 0;
+  for (auto& e : v) { bow_ids[nw] = e.first; bow_vals[nw] = e.second; nw++; }
+  *n_words = nw;
+  int nn = 0, pos = 0;
+  for (auto& e : fv) {
+    fv_nodes[nn] = e.first;
+    fv_off[nn] = pos;
+    for (unsigned f : e.second) fv_feat[pos++] = f;
+    nn++;
+  }
+  fv_off[nn] = pos;
+  *n_fv = nn;
+  return 0;
+}
+
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) -- ORBmatcher.cc:154-283.
+// FeatureVectors as ascending node ids + CSR offsets + feature indices; valid1[i] != 0 <=> the keyframe keypoint has a
+// MapPoint that is not bad; angles from pKF->mvKeysUn / F.mvKeys.  matches21[i2] = keyframe index whose MapPoint
+// is assigned to frame keypoint i2, or -1.  Returns nmatches.
+int orc_search_by_bow(const uint8_t* desc1, const float* angle1, const uint8_t* valid1, int n1,
+                      const uint32_t* fv1_nodes, const uint32_t* fv1_off, const uint32_t* fv1_feat, int nfv1,
+                      const uint8_t* desc2, const float* angle2, int n2, const uint32_t* fv2_nodes,
+                      const uint32_t* fv2_off, const uint32_t* fv2_feat, int nfv2, float nnratio, int checkOri,
+                      int32_t* matches21) {
+  (void)n1;
+  const int TH_LOW = 50, HISTO_LENGTH = 30;
+  for (int i = 0; i < n2; i++) matches21[i] = -1;
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  int a = 0, b = 0;
+  while (a < nfv1 && b < nfv2) {
+    if (fv1_nodes[a] == fv2_nodes[b]) {
+      for (uint32_t iKF = fv1_off[a]; iKF < fv1_off[a + 1]; iKF++) {
+        const unsigned realIdxKF = fv1_feat[iKF];
+        if (!valid1[realIdxKF]) continue;
+        const uint8_t* dKF = desc1 + 32 * (size_t)realIdxKF;
+        int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+        for (uint32_t iF = fv2_off[b]; iF < fv2_off[b + 1]; iF++) {
+          const unsigned realIdxF = fv2_feat[iF];
+          if (matches21[realIdxF] >= 0) continue;
+          const int dist = descriptor_distance(dKF, desc2 + 32 * (size_t)realIdxF);
+          if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+          else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist1 <= TH_LOW) {
+          if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+            matches21[bestIdxF] = realIdxKF;
+            if (checkOri) {
+              float rot = angle1[realIdxKF] - angle2[bestIdxF];
+              if (rot < 0.0) rot += 360.0f;
+              int bin = round(rot * factor);
+              if (bin == HISTO_LENGTH) bin = 0;
+              rotHist[bin].push_back(bestIdxF);
+            }
+            nmatches++;
+          }
+        }
+      }
+      a++; b++;
+    } else if (fv1_nodes[a] < fv2_nodes[b]) {
+      a = (int)(std::lower_bound(fv1_nodes, fv1_nodes + nfv1, fv2_nodes[b]) - fv1_nodes);
+    } else {
+      b = (int)(std::lower_bound(fv2_nodes, fv2_nodes + nfv2, fv1_nodes[a]) - fv2_nodes);
+    }
+  }
+  if (checkOri) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    compute_three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0; j < rotHist[i].size(); j++) { matches21[rotHist[i][j]] = -1; nmatches--; }
+    }
+  }
+  return nmatches;
+}
+
+
+// ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) -- ORBmatcher.cc:517-650.  valid1/valid2: the keypoint
+// has a MapPoint that is not bad.  matches12[i1] = index in keyframe 2 or -1.  Returns nmatches.
+int orc_search_by_bow_kf(const uint8_t* desc1, const float* angle1, const uint8_t* valid1, int n1,
+                         const uint32_t* fv1_nodes, const uint32_t* fv1_off, const uint32_t* fv1_feat, int nfv1,
+                         const uint8_t* desc2, const float* angle2, const uint8_t* valid2, int n2,
+                         const uint32_t* fv2_nodes, const uint32_t* fv2_off, const uint32_t* fv2_feat, int nfv2,
+                         float nnratio, int checkOri, int32_t* matches12) {
+  const int TH_LOW = 50, HISTO_LENGTH = 30;
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  std::vector<bool> vbMatched2(n2, false);
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  int nmatches = 0;
+  int a = 0, b = 0;
+  while (a < nfv1 && b < nfv2) {
+    if (fv1_nodes[a] == fv2_nodes[b]) {
+      for (uint32_t i1 = fv1_off[a]; i1 < fv1_off[a + 1]; i1++) {
+        const size_t idx1 = fv1_feat[i1];
+        if (!valid1[idx1]) continue;
+        const uint8_t* d1 = desc1 + 32 * idx1;
+        int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+        for (uint32_t i2 = fv2_off[b]; i2 < fv2_off[b + 1]; i2++) {
+          const size_t idx2 = fv2_feat[i2];
+          if (vbMatched2[idx2] || !valid2[idx2]) continue;
+          int dist = descriptor_distance(d1, desc2 + 32 * idx2);
+          if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = (int)idx2; }
+          else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist1 < TH_LOW) {
+          if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+            matches12[idx1] = bestIdx2;
+            vbMatched2[bestIdx2] = true;
+            if (checkOri) {
+              float rot = angle1[idx1] - angle2[bestIdx2];
+              if (rot < 0.0) rot += 360.0f;
+              int bin = round(rot * factor);
+              if (bin == HISTO_LENGTH) bin = 0;
+              rotHist[bin].push_back((int)idx1);
+            }
+            nmatches++;
+          }
+        }
+      }
+      a++; b++;
+    } else if (fv1_nodes[a] < fv2_nodes[b]) {
+      a = (int)(std::lower_bound(fv1_nodes, fv1_nodes + nfv1, fv2_nodes[b]) - fv1_nodes);
+    } else {
+      b = (int)(std::lower_bound(fv2_nodes, fv2_nodes + nfv2, fv1_nodes[a]) - fv2_nodes);
+    }
+  }
+  if (checkOri) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    compute_three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0; j < rotHist[i].size(); j++) { matches12[rotHist[i][j]] = -1; nmatches--; }
+    }
+  }
+  return nmatches;
 }
 
 }  // extern "C"

@@ -58,6 +58,15 @@ class Oracle:
                                                   C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
                                                   C.c_void_p]
         L.orc_distinctive_descriptor.argtypes = [C.c_void_p, C.c_int]
+        L.orc_vocab_create.restype = C.c_void_p
+        L.orc_vocab_create.argtypes = [C.c_int] * 4 + [C.c_void_p, C.c_int]
+        L.orc_vocab_destroy.argtypes = [C.c_void_p]
+        L.orc_bow_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 2 + \
+            [C.POINTER(C.c_int)] + [C.c_void_p] * 3 + [C.POINTER(C.c_int)] + [C.c_void_p] * 2
+        L.orc_search_by_bow.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] + \
+            [C.c_void_p] * 2 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_float, C.c_int, C.c_void_p]
+        L.orc_search_by_bow_kf.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] + \
+            [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_float, C.c_int, C.c_void_p]
         L.orc_undistort_equidistant.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
 
     # ---- primitives -------------------------------------------------------------------------
@@ -170,10 +179,73 @@ class Oracle:
         descs = np.ascontiguousarray(descs, np.uint8)
         return self.L.orc_distinctive_descriptor(_p(descs), len(descs))
 
+    def vocabulary(self, image):
+        return OracleVocabulary(self, image)
+
+    def search_by_bow(self, desc1, angle1, valid1, fv1, desc2, angle2, valid2, fv2, nnratio=0.7, check_ori=True):
+        """valid2 None: (KeyFrame, Frame) overload, result converted to matches12; else (KeyFrame, KeyFrame)."""
+        desc1 = np.ascontiguousarray(desc1, np.uint8)
+        desc2 = np.ascontiguousarray(desc2, np.uint8)
+        angle1 = np.ascontiguousarray(angle1, np.float32)
+        angle2 = np.ascontiguousarray(angle2, np.float32)
+        valid1 = np.ascontiguousarray(valid1, np.uint8)
+        f1 = [np.ascontiguousarray(a, np.uint32) for a in fv1]
+        f2 = [np.ascontiguousarray(a, np.uint32) for a in fv2]
+        n1, n2 = len(desc1), len(desc2)
+        if valid2 is None:
+            m21 = np.full(max(n2, 1), -1, np.int32)
+            nm = self.L.orc_search_by_bow(_p(desc1), _p(angle1), _p(valid1), n1, _p(f1[0]), _p(f1[1]), _p(f1[2]),
+                                          len(f1[0]), _p(desc2), _p(angle2), n2, _p(f2[0]), _p(f2[1]), _p(f2[2]),
+                                          len(f2[0]), nnratio, int(check_ori), _p(m21))
+            m12 = np.full(n1, -1, np.int32)
+            for i2 in range(n2):
+                if m21[i2] >= 0:
+                    assert m12[m21[i2]] == -1
+                    m12[m21[i2]] = i2
+            return nm, m12
+        valid2 = np.ascontiguousarray(valid2, np.uint8)
+        m12 = np.full(max(n1, 1), -1, np.int32)
+        nm = self.L.orc_search_by_bow_kf(_p(desc1), _p(angle1), _p(valid1), n1, _p(f1[0]), _p(f1[1]), _p(f1[2]),
+                                         len(f1[0]), _p(desc2), _p(angle2), _p(valid2), n2, _p(f2[0]), _p(f2[1]),
+                                         _p(f2[2]), len(f2[0]), nnratio, int(check_ori), _p(m12))
+        return nm, m12[:n1]
+
     def undistort_equidistant(self, xy, fx, fy, cx, cy):
         xy = np.ascontiguousarray(xy, np.float32).copy()
         self.L.orc_undistort_equidistant(_p(xy), len(xy), fx, fy, cx, cy)
         return xy
+
+
+class OracleVocabulary:
+    """DBoW2 vocabulary + transform(features, v, fv, levelsup) restated on the CPU."""
+
+    def __init__(self, oracle, image):
+        self.o = oracle
+        buf = np.frombuffer(image, np.uint8)
+        self.h = oracle.L.orc_vocab_create(int(buf[0]), int(buf[1]), int(buf[2]), int(buf[3]), _p(buf[4:].copy()),
+                                           (buf.size - 4) // 45)
+
+    def transform(self, desc, levelsup=4):
+        desc = np.ascontiguousarray(desc, np.uint8)
+        n = len(desc)
+        ids = np.zeros(max(n, 1), np.uint32)
+        vals = np.zeros(max(n, 1), np.float64)
+        fvn = np.zeros(max(n, 1), np.uint32)
+        fvo = np.zeros(n + 1, np.uint32)
+        fvf = np.zeros(max(n, 1), np.uint32)
+        wof = np.zeros(max(n, 1), np.uint32)
+        nof = np.zeros(max(n, 1), np.uint32)
+        nw, nn = C.c_int(0), C.c_int(0)
+        self.o.L.orc_bow_transform(self.h, _p(desc), n, levelsup, _p(ids), _p(vals), C.byref(nw), _p(fvn), _p(fvo),
+                                   _p(fvf), C.byref(nn), _p(wof), _p(nof))
+        nw, nn = nw.value, nn.value
+        return ids[:nw], vals[:nw], (fvn[:nn], fvo[:nn + 1], fvf[:int(fvo[nn])]), wof[:n], nof[:n]
+
+    def __del__(self):
+        try:
+            self.o.L.orc_vocab_destroy(self.h)
+        except Exception:
+            pass
 
 
 class OracleExtractor:

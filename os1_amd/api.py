@@ -82,6 +82,14 @@ def load_library():
     L.orbfe_window_candidates.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t,
                                           C.POINTER(C.c_size_t)]
     L.orbfe_undistort_equidistant.argtypes = [vp, ci, cf, cf, cf, cf]
+    L.orbfe_vocabulary_create.argtypes = [ci, ci, ci, ci, ci, vp, ci, C.POINTER(vp)]
+    L.orbfe_vocabulary_create_from_image.argtypes = [ci, vp, C.c_size_t, C.POINTER(vp)]
+    L.orbfe_vocabulary_destroy.argtypes = [vp]
+    L.orbfe_vocabulary_destroy.restype = None
+    L.orbfe_vocabulary_info.argtypes = [vp] + [C.POINTER(ci)] * 6
+    L.orbfe_bow_transform.argtypes = [vp, vp, ci, ci, ci, vp, vp, C.POINTER(ci), vp, vp, vp, C.POINTER(ci), vp, vp]
+    L.orbfe_search_by_bow.argtypes = [vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, cf, ci, ci, vp,
+                                      C.POINTER(ci)]
     L.orbfe_debug_matcher_ms.argtypes = [vp, vp]
     L.orbfe_debug_features_in_area.argtypes = [vp, vp, ci, vp, cf, cf, cf, ci, ci, vp, ci, C.POINTER(ci)]
     L.orbfe_debug_kernel_ms.argtypes = [vp, vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), ci]
@@ -378,6 +386,27 @@ class Matcher:
         _check(self.L.orbfe_distinctive_descriptors(self.h, len(desc_lists), _p(offs), _p(allv), _p(out)))
         return out[:len(desc_lists)]
 
+    def search_by_bow(self, desc1, angle1, valid1, fv1, desc2, angle2, valid2, fv2, nnratio=0.7, check_ori=True,
+                      strict=False):
+        """ORBmatcher::SearchByBoW; fvX = (nodes, offsets, features) as returned by Vocabulary.transform.
+        valid2=None is the (KeyFrame, Frame) overload, strict=True + valid2 the (KeyFrame, KeyFrame) one.
+        Returns (nmatches, matches12)."""
+        desc1 = np.ascontiguousarray(desc1, np.uint8)
+        desc2 = np.ascontiguousarray(desc2, np.uint8)
+        angle1 = np.ascontiguousarray(angle1, np.float32)
+        angle2 = np.ascontiguousarray(angle2, np.float32)
+        valid1 = np.ascontiguousarray(valid1, np.uint8)
+        v2 = None if valid2 is None else np.ascontiguousarray(valid2, np.uint8)
+        f1 = [np.ascontiguousarray(a, np.uint32) for a in fv1]
+        f2 = [np.ascontiguousarray(a, np.uint32) for a in fv2]
+        m12 = np.full(max(len(desc1), 1), -1, np.int32)
+        nm = C.c_int(0)
+        _check(self.L.orbfe_search_by_bow(self.h, _p(desc1), _p(angle1), _p(valid1), len(desc1), _p(f1[0]), _p(f1[1]),
+                                          _p(f1[2]), len(f1[0]), _p(desc2), _p(angle2), None if v2 is None else _p(v2),
+                                          len(desc2), _p(f2[0]), _p(f2[1]), _p(f2[2]), len(f2[0]), nnratio,
+                                          int(check_ori), int(strict), _p(m12), C.byref(nm)))
+        return nm.value, m12[:len(desc1)]
+
     def stage_ms(self):
         out = np.zeros(3, np.float64)
         _check(self.L.orbfe_debug_matcher_ms(self.h, _p(out)))
@@ -416,6 +445,50 @@ def sincos_host_mismatches(lo_bits, hi_bits, step=1):
     bad = C.c_longlong(0)
     _check(load_library().orbfe_debug_sincos_host_check(lo_bits, hi_bits, step, C.byref(bad)))
     return bad.value
+
+
+class Vocabulary:
+    """DBoW2 ORB vocabulary resident in HBM; transform() = Frame::ComputeBoW."""
+
+    def __init__(self, image, device=0):
+        self.L = load_library()
+        h = C.c_void_p()
+        buf = np.frombuffer(image, np.uint8)
+        _check(self.L.orbfe_vocabulary_create_from_image(device, _p(buf), buf.size, C.byref(h)))
+        self.h = h
+
+    def info(self):
+        v = [C.c_int(0) for _ in range(6)]
+        _check(self.L.orbfe_vocabulary_info(self.h, *[C.byref(x) for x in v]))
+        return dict(zip(('k', 'L', 'scoring', 'weighting', 'n_nodes', 'n_words'), [x.value for x in v]))
+
+    def transform(self, desc, levelsup=4):
+        """-> (bow_ids, bow_values, (fv_nodes, fv_offsets, fv_features), word_of_feature, node_of_feature)"""
+        desc = np.ascontiguousarray(desc, np.uint8)
+        n = len(desc)
+        ids = np.zeros(max(n, 1), np.uint32)
+        vals = np.zeros(max(n, 1), np.float64)
+        fvn = np.zeros(max(n, 1), np.uint32)
+        fvo = np.zeros(n + 1, np.uint32)
+        fvf = np.zeros(max(n, 1), np.uint32)
+        wof = np.zeros(max(n, 1), np.uint32)
+        nof = np.zeros(max(n, 1), np.uint32)
+        nw, nn = C.c_int(0), C.c_int(0)
+        _check(self.L.orbfe_bow_transform(self.h, _p(desc), n, 0, levelsup, _p(ids), _p(vals), C.byref(nw), _p(fvn),
+                                          _p(fvo), _p(fvf), C.byref(nn), _p(wof), _p(nof)))
+        nw, nn = nw.value, nn.value
+        return ids[:nw], vals[:nw], (fvn[:nn], fvo[:nn + 1], fvf[:int(fvo[nn])]), wof[:n], nof[:n]
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.L.orbfe_vocabulary_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class PinnedFrames:

@@ -1,0 +1,489 @@
+// orbfe_bow.hip -- bag-of-words side of the path:
+//   * Frame::ComputeBoW (Frame.cc:277-284) = DBoW2 TemplatedVocabulary<FORB>::transform(features, BowVector&,
+//     FeatureVector&, levelsup) -- Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1136-1204, descent :1306-1347,
+//     BowVector.cpp:30-82, FeatureVector.cpp:27-41, FORB::distance FORB.cpp:81-101;
+//   * ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) ORBmatcher.cc:154-283 and (KeyFrame*, KeyFrame*, ...) :517-650.
+// C ABI: include/orbfe.h (bag-of-words section).
+//
+// Split of work.  The data-parallel part runs on the GPU: the k-ary tree descent of every descriptor (16 lanes per
+// descriptor, one lane per child, 256-bit Hamming per lane, DPP row minimum with "first minimum wins"), and the
+// per-node best / second-best Hamming search of SearchByBoW (one wave per common vocabulary node; the sequential
+// "already matched" dependency lives inside one node group, so groups are independent).  What is left is
+// bookkeeping in the order the reference does it, on a few thousand scalars: summing word weights in feature order
+// (double, so the order is part of the result), the L1/L2 normalisation in ascending word order, grouping feature
+// indices by node, and the rotation-histogram pruning.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "../../include/orbfe.h"
+
+namespace orbfe {
+void set_err(const char* fmt, ...);
+int matcher_device(const orbfe_matcher* m);
+hipStream_t matcher_stream(const orbfe_matcher* m);
+std::shared_ptr<void>& matcher_bow_slot(orbfe_matcher* m);
+}
+using orbfe::set_err;
+
+#define HIP_TRY(expr)                                                                        \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);    \
+      return ORBFE_ERR_HIP;                                                                  \
+    }                                                                                        \
+  } while (0)
+
+namespace {
+
+constexpr int TH_LOW = 50, HISTO_LENGTH = 30;   // ORBmatcher.cc:37-39
+constexpr int kRecord = 45;                     // bytes per node record of the binary vocabulary file
+constexpr int kMaxGroup = 65535;                // SearchByBoW: features of one frame under one vocabulary node
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  int ensure(size_t count) {
+    if (count <= n) return ORBFE_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+    HIP_TRY(hipMalloc((void**)&p, count * sizeof(T)));
+    n = count;
+    return ORBFE_OK;
+  }
+  ~DevBuf() { if (p) (void)hipFree(p); }
+};
+template <class T>
+struct PinBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  int ensure(size_t count) {
+    if (count <= n) return ORBFE_OK;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    n = 0;
+    HIP_TRY(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault));
+    n = count;
+    return ORBFE_OK;
+  }
+  ~PinBuf() { if (p) (void)hipHostFree(p); }
+};
+
+// row_ror:n -- rotate right by n lanes inside each row of 16 lanes
+template <int N>
+__device__ inline unsigned row_ror(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x120 + N, 0xf, 0xf, false);
+}
+// minimum over the 16 lanes of a DPP row, in every lane of the row
+__device__ inline unsigned row_min16(unsigned v) {
+  v = min(v, row_ror<8>(v));
+  v = min(v, row_ror<4>(v));
+  v = min(v, row_ror<2>(v));
+  v = min(v, row_ror<1>(v));
+  return v;
+}
+// minimum over the 64 lanes of the wave (wave-uniform result)
+__device__ inline unsigned wave_min(unsigned v) {
+  v = row_min16(v);
+  const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+  const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+  return min(min(a, b), min(c, d));
+}
+
+__device__ inline int hamming256(const uint4& a0, const uint4& a1, const uint4& b0, const uint4& b1) {
+  return __popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+         __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w);
+}
+
+// Tree descent (TemplatedVocabulary.h:1306-1347).  16 lanes per descriptor; lane c compares child c, c+16, ... of the
+// current node; key = distance << 8 | child position, so the row minimum is the first child with the least distance
+// (`d < best_d` strict).  Children of a node are contiguous "slots" (descriptor + node id) in the order the reference
+// appends them.  out[f] = (leaf node id, node id at level nidLevel or 0).
+__global__ void __launch_bounds__(256) k_bow_descend(const uint4* __restrict__ desc, int n, const int* __restrict__ childBegin,
+                                                     const int* __restrict__ childCount, const int* __restrict__ slotNode,
+                                                     const uint4* __restrict__ slotDesc, int nidLevel, int maxDepth,
+                                                     uint2* __restrict__ out) {
+  const int lane16 = threadIdx.x & 15;
+  const int f = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+  const bool live = f < n;
+  uint4 f0 = make_uint4(0, 0, 0, 0), f1 = f0;
+  if (live) { f0 = desc[2 * (size_t)f]; f1 = desc[2 * (size_t)f + 1]; }
+  int cur = 0;
+  unsigned nid = 0;
+  bool done = !live;
+  for (int level = 1; level <= maxDepth; level++) {   // uniform trip count: the DPP reduction needs every lane
+    unsigned key = 0xffffffffu;
+    int cb = 0;
+    if (!done) {
+      cb = childBegin[cur];
+      const int cc = childCount[cur];
+      for (int c = lane16; c < cc; c += 16) {
+        const uint4 d0 = slotDesc[2 * (size_t)(cb + c)], d1 = slotDesc[2 * (size_t)(cb + c) + 1];
+        key = min(key, ((unsigned)hamming256(f0, f1, d0, d1) << 8) | (unsigned)c);
+      }
+    }
+    key = row_min16(key);
+    if (!done) {
+      cur = slotNode[cb + (int)(key & 255u)];
+      if (level == nidLevel) nid = (unsigned)cur;
+      done = childCount[cur] == 0;
+    }
+  }
+  if (live && lane16 == 0) out[f] = make_uint2((unsigned)cur, nid);
+}
+
+// SearchByBoW inner search: one wave per vocabulary node common to both FeatureVectors.  Frame-1 features of the node
+// are visited in order; for each, lanes scan the node's frame-2 features (skipping matched / invalid ones), the wave
+// takes best (first minimum) and second-best distance, applies the reference's acceptance test and marks the winner
+// matched (LDS bitmap) before the next frame-1 feature.
+struct BowPair { int b1, e1, b2, e2; };   // [b,e) ranges into fv1_feat / fv2_feat
+
+__global__ void __launch_bounds__(64) k_bow_match(const uint4* __restrict__ desc1, const uint8_t* __restrict__ valid1,
+                                                  const uint32_t* __restrict__ feat1, const uint4* __restrict__ desc2,
+                                                  const uint8_t* __restrict__ valid2, const uint32_t* __restrict__ feat2,
+                                                  const BowPair* __restrict__ pairs, int maxDist, float nnratio,
+                                                  int32_t* __restrict__ matches12) {
+  __shared__ unsigned matched[(kMaxGroup + 1) / 32];
+  const BowPair P = pairs[blockIdx.x];
+  const int lane = threadIdx.x;
+  const int n2g = P.e2 - P.b2;
+  for (int i = lane; i < (n2g + 31) / 32; i += 64) matched[i] = 0;
+  __syncthreads();
+  for (int i1 = P.b1; i1 < P.e1; i1++) {
+    const unsigned idx1 = feat1[i1];
+    if (!valid1[idx1]) continue;   // wave-uniform
+    const uint4 a0 = desc1[2 * (size_t)idx1], a1 = desc1[2 * (size_t)idx1 + 1];
+    unsigned k1 = (256u << 16) | 0xffffu, k2 = k1;   // lane-local least and second-least key (distance << 16 | position)
+    for (int p = lane; p < n2g; p += 64) {
+      const unsigned idx2 = feat2[P.b2 + p];
+      const bool skip = ((matched[p >> 5] >> (p & 31)) & 1u) || (valid2 && !valid2[idx2]);
+      if (skip) continue;
+      const unsigned key = ((unsigned)hamming256(a0, a1, desc2[2 * (size_t)idx2], desc2[2 * (size_t)idx2 + 1]) << 16) | (unsigned)p;
+      if (key < k1) { k2 = k1; k1 = key; }
+      else if (key < k2) k2 = key;
+    }
+    const unsigned best = wave_min(k1);
+    const unsigned second = wave_min(k1 == best ? k2 : k1) >> 16;   // least distance among everything but the winner
+    const int bestDist = (int)(best >> 16);
+    if (bestDist <= maxDist && static_cast<float>(bestDist) < nnratio * static_cast<float>((int)second)) {
+      const int p = (int)(best & 0xffffu);
+      if (lane == 0) {
+        matches12[idx1] = (int32_t)feat2[P.b2 + p];
+        matched[p >> 5] |= 1u << (p & 31);
+      }
+      __syncthreads();   // one wave per block: orders the LDS update before the next scan
+    }
+  }
+}
+
+}  // namespace
+
+struct orbfe_vocabulary {
+  int device = 0, k = 0, L = 0, scoring = 0, weighting = 0;
+  int nNodes = 0, maxDepth = 0;
+  std::vector<double> weight;     // per node
+  std::vector<uint32_t> word;     // per node (leaves flagged in the file count up from 0)
+  DevBuf<int> d_childBegin, d_childCount, d_slotNode;
+  DevBuf<uint4> d_slotDesc;
+  DevBuf<uint4> d_desc;
+  DevBuf<uint2> d_out;
+  PinBuf<uint2> h_out;
+  hipStream_t stream = nullptr;
+  std::vector<std::pair<uint32_t, uint32_t>> tmp;
+};
+
+extern "C" {
+
+int orbfe_vocabulary_create(int device_id, int k, int L, int scoring, int weighting, const void* records, int n_records,
+                            orbfe_vocabulary** out) {
+  if (!out || !records || n_records < 1 || k < 1 || k > 255 || L < 1 || scoring < 0 || scoring > 5 || weighting < 0 ||
+      weighting > 3) {
+    set_err("bad vocabulary arguments");
+    return ORBFE_ERR_INVALID;
+  }
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) {
+    set_err("no HIP device %d (the bag-of-words path has no CPU fallback)", device_id);
+    return ORBFE_ERR_NO_DEVICE;
+  }
+  HIP_TRY(hipSetDevice(device_id));
+  const uint8_t* rec = (const uint8_t*)records;
+  const int nNodes = n_records + 1;
+  std::vector<int> parent(nNodes, 0), childCount(nNodes, 0), childBegin(nNodes + 1, 0), depth(nNodes, 0);
+  std::unique_ptr<orbfe_vocabulary> v(new orbfe_vocabulary);
+  v->weight.assign(nNodes, 0.0);
+  v->word.assign(nNodes, 0);
+  uint32_t nwords = 0;
+  int maxDepth = 0;
+  for (int nid = 1; nid < nNodes; nid++) {
+    const uint8_t* b = rec + (size_t)kRecord * (nid - 1);
+    int pid;
+    memcpy(&pid, b, 4);
+    if (pid < 0 || pid >= nid) { set_err("vocabulary record %d: parent %d is not an earlier node", nid - 1, pid); return ORBFE_ERR_INVALID; }
+    parent[nid] = pid;
+    childCount[pid]++;
+    depth[nid] = depth[pid] + 1;
+    maxDepth = std::max(maxDepth, depth[nid]);
+    memcpy(&v->weight[nid], b + 37, 8);
+    if (b[4] > 0) v->word[nid] = nwords++;
+  }
+  for (int i = 0; i < nNodes; i++) {
+    if (childCount[i] > 255) { set_err("vocabulary node %d has %d children (max 255)", i, childCount[i]); return ORBFE_ERR_OVERFLOW; }
+    childBegin[i + 1] = childBegin[i] + childCount[i];
+  }
+  std::vector<int> fill(childBegin.begin(), childBegin.end() - 1), slotNode(n_records);
+  std::vector<uint8_t> slotDesc((size_t)n_records * 32);
+  for (int nid = 1; nid < nNodes; nid++) {   // children in the order the reference appends them (record order)
+    const int s = fill[parent[nid]]++;
+    slotNode[s] = nid;
+    memcpy(&slotDesc[(size_t)s * 32], rec + (size_t)kRecord * (nid - 1) + 5, 32);
+  }
+  v->device = device_id; v->k = k; v->L = L; v->scoring = scoring; v->weighting = weighting;
+  v->nNodes = nNodes; v->maxDepth = maxDepth;
+  int rc;
+  if ((rc = v->d_childBegin.ensure(nNodes)) || (rc = v->d_childCount.ensure(nNodes)) || (rc = v->d_slotNode.ensure(n_records)) ||
+      (rc = v->d_slotDesc.ensure((size_t)n_records * 2)))
+    return rc;
+  HIP_TRY(hipMemcpy(v->d_childBegin.p, childBegin.data(), sizeof(int) * nNodes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(v->d_childCount.p, childCount.data(), sizeof(int) * nNodes, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(v->d_slotNode.p, slotNode.data(), sizeof(int) * n_records, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(v->d_slotDesc.p, slotDesc.data(), slotDesc.size(), hipMemcpyHostToDevice));
+  HIP_TRY(hipStreamCreateWithFlags(&v->stream, hipStreamNonBlocking));
+  *out = v.release();
+  return ORBFE_OK;
+}
+
+int orbfe_vocabulary_create_from_image(int device_id, const void* image, size_t bytes, orbfe_vocabulary** out) {
+  if (!image || bytes < 4 + kRecord) { set_err("vocabulary image too short"); return ORBFE_ERR_INVALID; }
+  const uint8_t* b = (const uint8_t*)image;
+  // header checks of the reference's loader (TemplatedVocabulary.h:1574-1586)
+  if (b[0] > 20 || b[1] < 1 || b[1] > 10 || b[2] > 5 || b[3] > 3) { set_err("not a binary ORB vocabulary"); return ORBFE_ERR_INVALID; }
+  return orbfe_vocabulary_create(device_id, b[0], b[1], b[2], b[3], b + 4, (int)((bytes - 4) / kRecord), out);
+}
+
+void orbfe_vocabulary_destroy(orbfe_vocabulary* v) {
+  if (!v) return;
+  (void)hipSetDevice(v->device);
+  if (v->stream) { (void)hipStreamSynchronize(v->stream); (void)hipStreamDestroy(v->stream); }
+  delete v;
+}
+
+int orbfe_vocabulary_info(const orbfe_vocabulary* v, int* k, int* L, int* scoring, int* weighting, int* n_nodes, int* n_words) {
+  if (!v) { set_err("vocabulary is NULL"); return ORBFE_ERR_INVALID; }
+  if (k) *k = v->k;
+  if (L) *L = v->L;
+  if (scoring) *scoring = v->scoring;
+  if (weighting) *weighting = v->weighting;
+  if (n_nodes) *n_nodes = v->nNodes;
+  if (n_words) {
+    uint32_t m = 0;
+    bool any = false;
+    for (int i = 1; i < v->nNodes; i++) if (v->word[i] >= m) { m = v->word[i]; any = true; }
+    *n_words = any ? (int)m + 1 : 0;
+  }
+  return ORBFE_OK;
+}
+
+int orbfe_bow_transform(orbfe_vocabulary* v, const uint8_t* desc, int n, int in_device_memory, int levelsup,
+                        uint32_t* bow_ids, double* bow_values, int* n_words, uint32_t* fv_nodes, uint32_t* fv_offsets,
+                        uint32_t* fv_features, int* n_fv_nodes, uint32_t* word_of_feature, uint32_t* node_of_feature) {
+  if (!v || n < 0 || (n > 0 && !desc) || !bow_ids || !bow_values || !n_words || !fv_nodes || !fv_offsets || !fv_features ||
+      !n_fv_nodes) {
+    set_err("bad argument");
+    return ORBFE_ERR_INVALID;
+  }
+  *n_words = 0;
+  *n_fv_nodes = 0;
+  fv_offsets[0] = 0;
+  if (n == 0) return ORBFE_OK;
+  HIP_TRY(hipSetDevice(v->device));
+  int rc;
+  if ((rc = v->d_out.ensure(n)) || (rc = v->h_out.ensure(n))) return rc;
+  const uint4* d = (const uint4*)desc;
+  if (!in_device_memory) {
+    if ((rc = v->d_desc.ensure((size_t)n * 2))) return rc;
+    HIP_TRY(hipMemcpyAsync(v->d_desc.p, desc, (size_t)n * 32, hipMemcpyHostToDevice, v->stream));
+    d = v->d_desc.p;
+  }
+  const int nidLevel = v->L - levelsup;   // <= 0: the node is the root (0), TemplatedVocabulary.h:1315-1316
+  const int blocks = (int)(((size_t)n * 16 + 255) / 256);
+  hipLaunchKernelGGL(k_bow_descend, dim3(blocks), dim3(256), 0, v->stream, d, n, v->d_childBegin.p, v->d_childCount.p,
+                     v->d_slotNode.p, v->d_slotDesc.p, nidLevel, v->maxDepth, v->d_out.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(v->h_out.p, v->d_out.p, sizeof(uint2) * n, hipMemcpyDeviceToHost, v->stream));
+  HIP_TRY(hipStreamSynchronize(v->stream));
+
+  // ---- BowVector / FeatureVector in the reference's order (TemplatedVocabulary.h:1155-1203) ----
+  const bool tf = v->weighting == 0 || v->weighting == 1;   // TF_IDF, TF: weights add up; IDF, BINARY: first one stays
+  auto& key = v->tmp;
+  key.clear();
+  for (int i = 0; i < n; i++) {
+    const uint32_t leaf = v->h_out.p[i].x;
+    if (word_of_feature) word_of_feature[i] = v->word[leaf];
+    if (node_of_feature) node_of_feature[i] = v->h_out.p[i].y;
+    if (v->weight[leaf] > 0) key.emplace_back(v->word[leaf], (uint32_t)i);   // "not stopped"
+  }
+  std::sort(key.begin(), key.end());   // by word, then feature index: the order std::map accumulation sees
+  int nw = 0;
+  for (size_t a = 0; a < key.size();) {
+    size_t b = a;
+    double w = 0;
+    for (; b < key.size() && key[b].first == key[a].first; b++) {
+      const double wi = v->weight[v->h_out.p[key[b].second].x];
+      if (b == a) w = wi;
+      else if (tf) w += wi;
+    }
+    bow_ids[nw] = key[a].first;
+    bow_values[nw] = w;
+    nw++;
+    a = b;
+  }
+  const bool must = v->scoring != 5;   // every scoring but DOT_PRODUCT normalises (ScoringObject.h:73-90)
+  if (tf && nw > 0 && !must) {
+    const double nd = nw;
+    for (int i = 0; i < nw; i++) bow_values[i] /= nd;
+  }
+  if (must) {   // BowVector::normalize, BowVector.cpp:60-82
+    double norm = 0.0;
+    if (v->scoring != 1) { for (int i = 0; i < nw; i++) norm += fabs(bow_values[i]); }
+    else { for (int i = 0; i < nw; i++) norm += bow_values[i] * bow_values[i]; norm = sqrt(norm); }
+    if (norm > 0.0) for (int i = 0; i < nw; i++) bow_values[i] /= norm;
+  }
+  *n_words = nw;
+  for (auto& e : key) e.first = v->h_out.p[e.second].y;
+  std::sort(key.begin(), key.end());   // by node, then feature index (push_back order)
+  int nn = 0;
+  for (size_t a = 0; a < key.size(); a++) {
+    if (a == 0 || key[a].first != key[a - 1].first) { fv_nodes[nn] = key[a].first; fv_offsets[nn] = (uint32_t)a; nn++; }
+    fv_features[a] = key[a].second;
+  }
+  fv_offsets[nn] = (uint32_t)key.size();
+  *n_fv_nodes = nn;
+  return ORBFE_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// SearchByBoW
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+// ComputeThreeMaxima on bin counts (ORBmatcher.cc:1554-1595)
+void three_maxima(const int* count, int L, int& ind1, int& ind2, int& ind3) {
+  int max1 = 0, max2 = 0, max3 = 0;
+  for (int i = 0; i < L; i++) {
+    const int s = count[i];
+    if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+    else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+    else if (s > max3) { max3 = s; ind3 = i; }
+  }
+  if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+  else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+}
+
+struct BowScratch {
+  DevBuf<uint4> d_desc1, d_desc2;
+  DevBuf<uint8_t> d_valid1, d_valid2;
+  DevBuf<uint32_t> d_feat1, d_feat2;
+  DevBuf<BowPair> d_pairs;
+  DevBuf<int32_t> d_m12;
+  PinBuf<int32_t> h_m12;
+};
+
+}  // namespace
+
+extern "C" int orbfe_search_by_bow(orbfe_matcher* m, const uint8_t* desc1, const float* angle1, const uint8_t* valid1, int n1,
+                                   const uint32_t* fv1_nodes, const uint32_t* fv1_offsets, const uint32_t* fv1_features,
+                                   int n_fv1, const uint8_t* desc2, const float* angle2, const uint8_t* valid2, int n2,
+                                   const uint32_t* fv2_nodes, const uint32_t* fv2_offsets, const uint32_t* fv2_features,
+                                   int n_fv2, float nnratio, int check_orientation, int strict_threshold,
+                                   int32_t* matches12, int* nmatches) {
+  if (!m || n1 < 0 || n2 < 0 || n_fv1 < 0 || n_fv2 < 0 || !matches12 || !nmatches || (n1 > 0 && (!desc1 || !valid1)) ||
+      (n2 > 0 && !desc2) || (n_fv1 > 0 && (!fv1_nodes || !fv1_offsets || !fv1_features)) ||
+      (n_fv2 > 0 && (!fv2_nodes || !fv2_offsets || !fv2_features)) || (check_orientation && (!angle1 || !angle2))) {
+    set_err("bad argument");
+    return ORBFE_ERR_INVALID;
+  }
+  *nmatches = 0;
+  for (int i = 0; i < n1; i++) matches12[i] = -1;
+  // common nodes (the lower_bound zig-zag of ORBmatcher.cc:175-258 visits exactly the intersection, in ascending order)
+  std::vector<BowPair> pairs;
+  for (int a = 0, b = 0; a < n_fv1 && b < n_fv2;) {
+    if (fv1_nodes[a] == fv2_nodes[b]) {
+      BowPair p = {(int)fv1_offsets[a], (int)fv1_offsets[a + 1], (int)fv2_offsets[b], (int)fv2_offsets[b + 1]};
+      if (p.e2 - p.b2 > kMaxGroup) { set_err("a vocabulary node holds %d features (max %d)", p.e2 - p.b2, kMaxGroup); return ORBFE_ERR_OVERFLOW; }
+      if (p.e1 > p.b1 && p.e2 > p.b2) pairs.push_back(p);
+      a++; b++;
+    } else if (fv1_nodes[a] < fv2_nodes[b]) a++;
+    else b++;
+  }
+  const int nf1 = n_fv1 ? (int)fv1_offsets[n_fv1] : 0, nf2 = n_fv2 ? (int)fv2_offsets[n_fv2] : 0;
+  for (int i = 0; i < nf1; i++) if (fv1_features[i] >= (uint32_t)n1) { set_err("fv1 feature index out of range"); return ORBFE_ERR_INVALID; }
+  for (int i = 0; i < nf2; i++) if (fv2_features[i] >= (uint32_t)n2) { set_err("fv2 feature index out of range"); return ORBFE_ERR_INVALID; }
+  if (pairs.empty()) return ORBFE_OK;
+  HIP_TRY(hipSetDevice(orbfe::matcher_device(m)));
+  std::shared_ptr<void>& slot = orbfe::matcher_bow_slot(m);
+  if (!slot) slot = std::make_shared<BowScratch>();
+  BowScratch* S = static_cast<BowScratch*>(slot.get());
+  int rc;
+  if ((rc = S->d_desc1.ensure((size_t)n1 * 2)) || (rc = S->d_desc2.ensure((size_t)n2 * 2)) || (rc = S->d_valid1.ensure(n1)) ||
+      (rc = S->d_valid2.ensure(std::max(n2, 1))) || (rc = S->d_feat1.ensure(nf1)) || (rc = S->d_feat2.ensure(nf2)) ||
+      (rc = S->d_pairs.ensure(pairs.size())) || (rc = S->d_m12.ensure(n1)) || (rc = S->h_m12.ensure(n1)))
+    return rc;
+  hipStream_t st = orbfe::matcher_stream(m);
+  HIP_TRY(hipMemcpyAsync(S->d_desc1.p, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(S->d_desc2.p, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(S->d_valid1.p, valid1, n1, hipMemcpyHostToDevice, st));
+  if (valid2) HIP_TRY(hipMemcpyAsync(S->d_valid2.p, valid2, n2, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(S->d_feat1.p, fv1_features, sizeof(uint32_t) * nf1, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(S->d_feat2.p, fv2_features, sizeof(uint32_t) * nf2, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(S->d_pairs.p, pairs.data(), sizeof(BowPair) * pairs.size(), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(S->d_m12.p, 0xff, sizeof(int32_t) * n1, st));
+  hipLaunchKernelGGL(k_bow_match, dim3((unsigned)pairs.size()), dim3(64), 0, st, S->d_desc1.p, S->d_valid1.p, S->d_feat1.p,
+                     S->d_desc2.p, valid2 ? S->d_valid2.p : (const uint8_t*)nullptr, S->d_feat2.p, S->d_pairs.p,
+                     strict_threshold ? TH_LOW - 1 : TH_LOW, nnratio, S->d_m12.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(S->h_m12.p, S->d_m12.p, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  int nm = 0;
+  int count[HISTO_LENGTH] = {};
+  std::vector<int8_t> bin(check_orientation ? n1 : 0, -1);
+  const float factor = 1.0f / HISTO_LENGTH;
+  for (int i = 0; i < n1; i++) {
+    const int j = S->h_m12.p[i];
+    matches12[i] = j;
+    if (j < 0) continue;
+    nm++;
+    if (check_orientation) {   // ORBmatcher.cc:226-236 / 596-606
+      float rot = angle1[i] - angle2[j];
+      if (rot < 0.0) rot += 360.0f;
+      int b = (int)round(rot * factor);
+      if (b == HISTO_LENGTH) b = 0;
+      if (b < 0 || b >= HISTO_LENGTH) continue;   // the reference asserts; cannot happen for angles in [0,360)
+      bin[i] = (int8_t)b;
+      count[b]++;
+    }
+  }
+  if (check_orientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    three_maxima(count, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < n1; i++) {
+      const int b = bin[i];
+      if (b < 0 || b == ind1 || b == ind2 || b == ind3) continue;
+      matches12[i] = -1;
+      nm--;
+    }
+  }
+  *nmatches = nm;
+  return ORBFE_OK;
+}

@@ -277,6 +277,7 @@ inline int rotBin(float a1, float a2) {  // ORBmatcher.cc:470-475 (factor = 1/HI
 struct orbfe_matcher {
   int device = 0;
   hipStream_t stream = nullptr;
+  std::shared_ptr<void> bow;   // scratch of orbfe_search_by_bow (orbfe_bow.hip)
   DevBuf<uint8_t> d_in;    // packed upload arena
   PinBuf<uint8_t> h_in;
   DevBuf<uint32_t> d_out;  // [total(1) pad][qcount nq][qoff nq]
@@ -675,6 +676,15 @@ int orbfe_matcher_create(int device_id, orbfe_matcher** out) {
 }
 
 void orbfe_matcher_destroy(orbfe_matcher* m) { delete m; }
+
+extern "C++" {
+namespace orbfe {
+// for orbfe_bow.hip, which keeps its device scratch on the matcher handle
+int matcher_device(const orbfe_matcher* m) { return m->device; }
+hipStream_t matcher_stream(const orbfe_matcher* m) { return m->stream; }
+std::shared_ptr<void>& matcher_bow_slot(orbfe_matcher* m) { return m->bow; }
+}  // namespace orbfe
+}  // extern "C++"
 
 int orbfe_debug_matcher_ms(const orbfe_matcher* m, double out[3]) {
   if (!m || !out) { set_err("NULL argument"); return ORBFE_ERR_INVALID; }

@@ -77,3 +77,41 @@ def shifted(frame, dx, dy, seed):
     out = p[pad - dy:pad - dy + H, pad - dx:pad - dx + W].astype(np.int64)
     noise = (splitmix64(seed, W * H, 7) % np.uint64(9)).astype(np.int64).reshape(H, W) - 4
     return np.ascontiguousarray(np.clip(out + noise, 0, 255).astype(np.uint8))
+
+
+def synth_vocabulary(seed, k=10, L=6, scoring=0, weighting=0, stop_fraction=0.02):
+    """A synthetic ORB vocabulary in the fork's binary file layout (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:
+    1563-1640): 4 header bytes (k, L, scoring, weighting) followed by one 45-byte record per node in id order
+    {int32 parent, u8 isLeaf, u8 descriptor[32], f64 weight}.  The tree is complete (k^l nodes at level l, written
+    level by level); a child's descriptor is its parent's with a level-dependent number of random bit flips, so a
+    descent is meaningful; leaf weights look like idf values (log(N/Ni)) and a few are 0 ("stopped" words)."""
+    rng = np.random.default_rng(seed)
+    level_desc = [rng.integers(0, 256, (k, 32), dtype=np.uint8)]
+    parents = [np.zeros(k, np.int32)]
+    first_id = 1
+    for lvl in range(2, L + 1):
+        prev = level_desc[-1]
+        n = prev.shape[0] * k
+        flips = max(4, 128 >> (lvl - 1))
+        bits = np.unpackbits(np.repeat(prev, k, axis=0), axis=1)
+        pos = rng.integers(0, 256, (n, flips))
+        np.put_along_axis(bits, pos, 1 - np.take_along_axis(bits, pos, axis=1), axis=1)
+        level_desc.append(np.packbits(bits, axis=1))
+        parents.append(first_id + np.repeat(np.arange(prev.shape[0], dtype=np.int32), k))
+        first_id += prev.shape[0]
+    desc = np.concatenate(level_desc)
+    parent = np.concatenate(parents)
+    n_nodes = desc.shape[0]
+    n_leaves = level_desc[-1].shape[0]
+    leaf = np.zeros(n_nodes, np.uint8)
+    leaf[n_nodes - n_leaves:] = 1
+    weight = np.zeros(n_nodes, np.float64)
+    w = np.log(1000.0 / rng.integers(1, 900, n_leaves))
+    w[rng.random(n_leaves) < stop_fraction] = 0.0
+    weight[n_nodes - n_leaves:] = w
+    rec = np.zeros((n_nodes, 45), np.uint8)
+    rec[:, 0:4] = parent.astype('<i4').view(np.uint8).reshape(-1, 4)
+    rec[:, 4] = leaf
+    rec[:, 5:37] = desc
+    rec[:, 37:45] = weight.astype('<f8').view(np.uint8).reshape(-1, 8)
+    return bytes([k, L, scoring, weighting]) + rec.tobytes()

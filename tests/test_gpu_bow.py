@@ -1,0 +1,94 @@
+"""-m gpu: bag-of-words on the GPU (orbfe_bow_transform, orbfe_search_by_bow) against the CPU oracle -- bit-exact,
+including the double-precision BowVector values."""
+import numpy as np
+import pytest
+
+from bow_util import ragged_vocabulary, with_header
+from os1_amd.synth import shifted, synth, synth_vocabulary
+from test_bow_oracle import _descs, make_bow_pair
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def api():
+    from os1_amd import api as a
+    assert a.device_count() >= 1, 'no GPU visible: the product has no CPU fallback'
+    return a
+
+
+def _same_transform(got, want):
+    gi, gv, gfv, gw, gn = got
+    wi, wv, wfv, ww, wn = want
+    assert gi.tobytes() == wi.tobytes()
+    assert gv.tobytes() == wv.tobytes()            # doubles, bit for bit
+    for a, b in zip(gfv, wfv):
+        assert a.tobytes() == b.tobytes()
+    assert gw.tobytes() == ww.tobytes() and gn.tobytes() == wn.tobytes()
+
+
+@pytest.mark.parametrize('scoring,weighting', [(0, 0), (1, 1), (5, 0), (3, 2), (0, 3)])
+def test_bow_transform_parity(api, oracle, scoring, weighting):
+    for image, levelsups in [(synth_vocabulary(3, 10, 4), (0, 2, 4, 6)), (ragged_vocabulary(4), (0, 1, 2, 4)),
+                             (synth_vocabulary(8, 19, 2), (0, 1))]:
+        image = with_header(image, scoring, weighting)
+        v = api.Vocabulary(image)
+        ov = oracle.vocabulary(image)
+        assert v.info()['n_nodes'] == (len(image) - 4) // 45 + 1
+        for n in (1, 17, 1500):
+            d = _descs(n, image, n)
+            for lu in levelsups:
+                _same_transform(v.transform(d, lu), ov.transform(d, lu))
+        got = v.transform(np.zeros((0, 32), np.uint8), 2)
+        assert len(got[0]) == 0 and len(got[2][0]) == 0
+        v.close()
+
+
+def test_compute_bow_of_extracted_frames_full_size_vocabulary(api, oracle):
+    """Frame::ComputeBoW on real descriptors with a k=10, L=6 vocabulary (1.1 M nodes, the size of ORBvoc), levelsup 4;
+    then both SearchByBoW overloads between a frame and its shifted successor."""
+    image = synth_vocabulary(1, 10, 6)
+    v = api.Vocabulary(image)
+    ov = oracle.vocabulary(image)
+    ex = api.Extractor(2000, 1.2, 8, 20, 7)
+    A = synth(3, 1920, 1080)
+    B = shifted(A, -24, 3, 33)
+    (k1, d1), (k2, d2) = ex(A), ex(B)
+    t1, t2 = v.transform(d1, 4), v.transform(d2, 4)
+    _same_transform(t1, ov.transform(d1, 4))
+    _same_transform(t2, ov.transform(d2, 4))
+    assert len(t1[0]) > 1000 and abs(t1[1].sum() - 1.0) < 1e-9
+    m = api.Matcher()
+    rng = np.random.default_rng(0)
+    v1 = (rng.random(len(k1)) < 0.85).astype(np.uint8)
+    v2 = (rng.random(len(k2)) < 0.85).astype(np.uint8)
+    for ratio, ori in [(0.7, True), (0.75, False)]:
+        for valid2, strict in [(None, False), (v2, True)]:
+            nm, m12 = m.search_by_bow(d1, k1['angle'], v1, t1[2], d2, k2['angle'], valid2, t2[2], ratio, ori, strict)
+            wn, w12 = oracle.search_by_bow(d1, k1['angle'], v1, t1[2], d2, k2['angle'], valid2, t2[2], ratio, ori)
+            assert nm == wn and m12.tobytes() == w12.tobytes()
+    v.close()
+
+
+@pytest.mark.parametrize('levelsup', [0, 1, 3])
+def test_search_by_bow_parity(api, oracle, levelsup):
+    """Synthetic descriptor sets with many true correspondences; levelsup 3 on an L=3 tree puts every feature under
+    the root (one group of several hundred features per side)."""
+    image = synth_vocabulary(6, 10, 3)
+    ov = oracle.vocabulary(image)
+    m = api.Matcher()
+    for seed, n1, n2 in [(7, 400, 450), (9, 1, 300), (10, 900, 70)]:
+        d1, a1, v1, d2, a2, v2 = make_bow_pair(seed, image, n1, n2)
+        fv1, fv2 = ov.transform(d1, levelsup)[2], ov.transform(d2, levelsup)[2]
+        total = 0
+        for ratio, ori in [(0.7, True), (0.9, False), (0.6, True)]:
+            for valid2, strict in [(None, False), (v2, True)]:
+                nm, m12 = m.search_by_bow(d1, a1, v1, fv1, d2, a2, valid2, fv2, ratio, ori, strict)
+                wn, w12 = oracle.search_by_bow(d1, a1, v1, fv1, d2, a2, valid2, fv2, ratio, ori)
+                assert nm == wn and m12.tobytes() == w12.tobytes()
+                total += nm
+        assert total > 0 or n1 == 1
+    # empty sides
+    e = (np.zeros(0, np.uint32), np.zeros(1, np.uint32), np.zeros(0, np.uint32))
+    nm, m12 = m.search_by_bow(d1, a1, v1, fv1, np.zeros((0, 32), np.uint8), np.zeros(0, np.float32), None, e)
+    assert nm == 0 and (m12 == -1).all()
