@@ -12,6 +12,7 @@
 // silently corrupt tracking.
 #pragma once
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -163,6 +164,147 @@ inline int SearchByProjection(MatcherContext& ctx, float mfNNratio, FrameT& F,
                                    flags.data(), mdesc.data(), nmp, th, mfNNratio, assigned.data(), &nmatches));
   for (int i = 0; i < n; i++)
     if (assigned[i] >= 0) F.mvpMapPoints[i] = vpMapPoints[assigned[i]];
+  return nmatches;
+}
+
+// ORBVocabulary (DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>) as far as the path uses it: loaded from the
+// fork's binary vocabulary file (TemplatedVocabulary.h:1563-1640), resident in HBM.
+class Vocabulary {
+ public:
+  explicit Vocabulary(int device = 0) : device_(device) {}
+  ~Vocabulary() { orbfe_vocabulary_destroy(v_); }
+  Vocabulary(const Vocabulary&) = delete;
+  Vocabulary& operator=(const Vocabulary&) = delete;
+  // bool loadFromBinaryFile(const std::string& filename)
+  bool loadFromBinaryFile(const std::string& filename) {
+    FILE* f = std::fopen(filename.c_str(), "rb");
+    if (!f) return false;
+    std::vector<uint8_t> image;
+    uint8_t buf[1 << 16];
+    size_t got;
+    while ((got = std::fread(buf, 1, sizeof buf, f)) > 0) image.insert(image.end(), buf, buf + got);
+    std::fclose(f);
+    orbfe_vocabulary* nv = nullptr;
+    if (orbfe_vocabulary_create_from_image(device_, image.data(), image.size(), &nv) != ORBFE_OK) return false;
+    orbfe_vocabulary_destroy(v_);
+    v_ = nv;
+    return true;
+  }
+  bool empty() const { return v_ == nullptr; }
+  orbfe_vocabulary* get() const { return v_; }
+
+  // void transform(const std::vector<TDescriptor>& features, BowVector& v, FeatureVector& fv, int levelsup) const
+  // (TemplatedVocabulary.h:1136-1204) on the rows of a CV_8U N x 32 matrix.  BowVectorT / FeatureVectorT are the
+  // DBoW2 map types (std::map<WordId, WordValue>, std::map<NodeId, std::vector<unsigned int>>).
+  template <class MatT, class BowVectorT, class FeatureVectorT>
+  void transform(const MatT& descriptors, int n, BowVectorT& v, FeatureVectorT& fv, int levelsup) {
+    v.clear();
+    fv.clear();
+    if (!v_ || n == 0) return;
+    std::vector<uint8_t> tmp;
+    ids_.resize(n); vals_.resize(n); nodes_.resize(n); offs_.resize(n + 1); feats_.resize(n);
+    int nw = 0, nn = 0;
+    check(orbfe_bow_transform(v_, detail::packedDescriptors(descriptors, n, tmp), n, 0, levelsup, ids_.data(),
+                              vals_.data(), &nw, nodes_.data(), offs_.data(), feats_.data(), &nn, nullptr, nullptr));
+    for (int i = 0; i < nw; i++) v.insert(v.end(), typename BowVectorT::value_type(ids_[i], vals_[i]));
+    for (int i = 0; i < nn; i++) {
+      auto it = fv.insert(fv.end(), typename FeatureVectorT::value_type(nodes_[i], typename FeatureVectorT::mapped_type()));
+      it->second.assign(feats_.begin() + offs_[i], feats_.begin() + offs_[i + 1]);
+    }
+  }
+
+ private:
+  int device_;
+  orbfe_vocabulary* v_ = nullptr;
+  std::vector<uint32_t> ids_, nodes_, offs_, feats_;
+  std::vector<double> vals_;
+};
+
+// void Frame::ComputeBoW()   (Frame.cc:277-284); KeyFrame::ComputeBoW (KeyFrame.cc) is the same call.
+template <class FrameT>
+inline void ComputeBoW(Vocabulary& voc, FrameT& F) {
+  if (F.mBowVec.empty()) voc.transform(F.mDescriptors, (int)F.mDescriptors.rows, F.mBowVec, F.mFeatVec, 4);
+}
+
+namespace detail {
+template <class FeatureVectorT>
+inline void flattenFeatureVector(const FeatureVectorT& fv, std::vector<uint32_t>& nodes, std::vector<uint32_t>& offs,
+                                 std::vector<uint32_t>& feats) {
+  nodes.clear(); offs.clear(); feats.clear();
+  for (const auto& e : fv) {
+    nodes.push_back((uint32_t)e.first);
+    offs.push_back((uint32_t)feats.size());
+    feats.insert(feats.end(), e.second.begin(), e.second.end());
+  }
+  offs.push_back((uint32_t)feats.size());
+}
+template <class KeyPointT>
+inline void angles(const std::vector<KeyPointT>& k, std::vector<float>& a) {
+  a.resize(k.size());
+  for (size_t i = 0; i < k.size(); i++) a[i] = k[i].angle;
+}
+template <class MapPointT>
+inline void validFlags(const std::vector<MapPointT*>& mps, std::vector<uint8_t>& valid) {
+  valid.assign(mps.size(), 0);
+  for (size_t i = 0; i < mps.size(); i++)
+    if (mps[i] && !mps[i]->isBad()) valid[i] = 1;   // ORBmatcher.cc:191-196 / 553-557
+}
+}  // namespace detail
+
+// int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches)  (ORBmatcher.cc:154-283)
+template <class KeyFrameT, class FrameT, class MapPointT>
+inline int SearchByBoW(MatcherContext& ctx, float mfNNratio, bool mbCheckOrientation, KeyFrameT* pKF, FrameT& F,
+                       std::vector<MapPointT*>& vpMapPointMatches) {
+  const std::vector<MapPointT*> vpMapPointsKF = pKF->GetMapPointMatches();
+  const int n1 = (int)vpMapPointsKF.size(), n2 = (int)F.N;
+  vpMapPointMatches.assign(n2, static_cast<MapPointT*>(nullptr));
+  std::vector<uint8_t> valid1, t1, t2;
+  std::vector<float> a1, a2;
+  std::vector<uint32_t> n1v, o1v, f1v, n2v, o2v, f2v;
+  detail::validFlags(vpMapPointsKF, valid1);
+  detail::angles(pKF->mvKeysUn, a1);
+  detail::angles(F.mvKeys, a2);
+  detail::flattenFeatureVector(pKF->mFeatVec, n1v, o1v, f1v);
+  detail::flattenFeatureVector(F.mFeatVec, n2v, o2v, f2v);
+  std::vector<int32_t> m12(n1 > 0 ? n1 : 1, -1);
+  int nmatches = 0;
+  check(orbfe_search_by_bow(ctx.get(), detail::packedDescriptors(pKF->mDescriptors, n1, t1), a1.data(), valid1.data(), n1,
+                            n1v.data(), o1v.data(), f1v.data(), (int)n1v.size(),
+                            detail::packedDescriptors(F.mDescriptors, n2, t2), a2.data(), nullptr, n2, n2v.data(),
+                            o2v.data(), f2v.data(), (int)n2v.size(), mfNNratio, mbCheckOrientation ? 1 : 0, 0, m12.data(),
+                            &nmatches));
+  for (int i = 0; i < n1; i++)
+    if (m12[i] >= 0) vpMapPointMatches[m12[i]] = vpMapPointsKF[i];
+  return nmatches;
+}
+
+// int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12)  (ORBmatcher.cc:517-650)
+template <class KeyFrameT, class MapPointT>
+inline int SearchByBoW(MatcherContext& ctx, float mfNNratio, bool mbCheckOrientation, KeyFrameT* pKF1, KeyFrameT* pKF2,
+                       std::vector<MapPointT*>& vpMatches12) {
+  const std::vector<MapPointT*> vpMapPoints1 = pKF1->GetMapPointMatches();
+  const std::vector<MapPointT*> vpMapPoints2 = pKF2->GetMapPointMatches();
+  const int n1 = (int)vpMapPoints1.size(), n2 = (int)vpMapPoints2.size();
+  vpMatches12.assign(n1, static_cast<MapPointT*>(nullptr));
+  std::vector<uint8_t> valid1, valid2, t1, t2;
+  std::vector<float> a1, a2;
+  std::vector<uint32_t> n1v, o1v, f1v, n2v, o2v, f2v;
+  detail::validFlags(vpMapPoints1, valid1);
+  detail::validFlags(vpMapPoints2, valid2);
+  detail::angles(pKF1->mvKeysUn, a1);
+  detail::angles(pKF2->mvKeysUn, a2);
+  detail::flattenFeatureVector(pKF1->mFeatVec, n1v, o1v, f1v);
+  detail::flattenFeatureVector(pKF2->mFeatVec, n2v, o2v, f2v);
+  std::vector<int32_t> m12(n1 > 0 ? n1 : 1, -1);
+  if (valid2.empty()) valid2.push_back(0);
+  int nmatches = 0;
+  check(orbfe_search_by_bow(ctx.get(), detail::packedDescriptors(pKF1->mDescriptors, n1, t1), a1.data(), valid1.data(), n1,
+                            n1v.data(), o1v.data(), f1v.data(), (int)n1v.size(),
+                            detail::packedDescriptors(pKF2->mDescriptors, n2, t2), a2.data(), valid2.data(), n2,
+                            n2v.data(), o2v.data(), f2v.data(), (int)n2v.size(), mfNNratio, mbCheckOrientation ? 1 : 0, 1,
+                            m12.data(), &nmatches));
+  for (int i = 0; i < n1; i++)
+    if (m12[i] >= 0) vpMatches12[i] = vpMapPoints2[m12[i]];
   return nmatches;
 }
 

@@ -5,6 +5,8 @@
 //   usage: facade_test <dir>      reads <dir>/A.gray, <dir>/B.gray (W,H from <dir>/meta.txt)
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -26,7 +28,12 @@ struct MapPoint {
   int Observations() { return nObs; }
   Mat GetDescriptor() { Mat m; m.data = desc; m.step = 32; m.rows = 1; return m; }
 };
+typedef std::map<unsigned, double> BowVector;                         // DBoW2::BowVector
+typedef std::map<unsigned, std::vector<unsigned> > FeatureVector;     // DBoW2::FeatureVector
 struct Frame {
+  int N = 0;
+  BowVector mBowVec;
+  FeatureVector mFeatVec;
   std::vector<KeyPoint> mvKeys, mvKeysUn;
   std::vector<unsigned char> descStore;
   Mat mDescriptors;
@@ -35,6 +42,9 @@ struct Frame {
   static float mnMinX, mnMaxX, mnMinY, mnMaxY;
 };
 float Frame::mnMinX, Frame::mnMaxX, Frame::mnMinY, Frame::mnMaxY;
+struct KeyFrame : Frame {   // the members SearchByBoW reads (KeyFrame.h)
+  std::vector<MapPoint*> GetMapPointMatches() { return mvpMapPoints; }
+};
 
 static std::vector<unsigned char> readFile(const std::string& p) {
   FILE* f = fopen(p.c_str(), "rb");
@@ -65,7 +75,7 @@ int main(int argc, char** argv) {
   orbfe::Extractor extractor(N, 1.2f, 8, 20, 7);           // Tracking.cc:65
   orbfe::MatcherContext ctx;
   Frame::mnMinX = 0; Frame::mnMaxX = (float)W; Frame::mnMinY = 0; Frame::mnMaxY = (float)H;  // Frame.cc:347-352
-  Frame F[2];
+  KeyFrame F[2];
   const char* names[2] = {"A", "B"};
   for (int i = 0; i < 2; i++) {
     std::vector<unsigned char> img = readFile(dir + "/" + names[i] + ".gray");
@@ -74,6 +84,7 @@ int main(int argc, char** argv) {
     F[i].mDescriptors.data = F[i].descStore.data();
     F[i].mDescriptors.step = 32;
     F[i].mDescriptors.rows = (int)F[i].mvKeys.size();
+    F[i].N = (int)F[i].mvKeys.size();
     F[i].mvpMapPoints.assign(F[i].mvKeys.size(), nullptr);
     F[i].mvScaleFactors = extractor.GetScaleFactors();
     writeFile(dir + "/" + names[i] + ".kps", F[i].mvKeys.data(), F[i].mvKeys.size() * sizeof(KeyPoint));
@@ -107,6 +118,42 @@ int main(int argc, char** argv) {
   for (size_t i = 0; i < assigned.size(); i++)
     if (F[1].mvpMapPoints[i]) assigned[i] = (int)(F[1].mvpMapPoints[i] - mps.data());
   writeFile(dir + "/sbp.assigned", assigned.data(), assigned.size() * sizeof(int));
-  printf("%zu %zu %d %d\n", F[0].mvKeys.size(), F[1].mvKeys.size(), nm, nsbp);
+  // Relocalisation / TrackReferenceKeyFrame (Tracking.cc:543-548): ComputeBoW of both, SearchByBoW(KF, F) and the
+  // keyframe-keyframe overload (LoopClosing.cc:242).  A and B carry "MapPoints" flagged in <dir>/bow.valid.
+  int nbow1 = -1, nbow2 = -1;
+  FILE* vf = fopen((dir + "/voc.bin").c_str(), "rb");
+  if (vf) {
+    fclose(vf);
+    orbfe::Vocabulary voc;
+    if (!voc.loadFromBinaryFile(dir + "/voc.bin")) return 3;
+    std::vector<unsigned char> valid = readFile(dir + "/bow.valid");   // n1 + n2 bytes: 0 none, 1 MapPoint, 2 bad MapPoint
+    std::vector<MapPoint> own[2];
+    for (int i = 0; i < 2; i++) {
+      orbfe::ComputeBoW(voc, F[i]);
+      std::vector<double> bv;
+      for (auto& e : F[i].mBowVec) { bv.push_back((double)e.first); bv.push_back(e.second); }
+      writeFile(dir + "/" + names[i] + ".bow", bv.data(), bv.size() * sizeof(double));
+      std::vector<unsigned> fvv;
+      for (auto& e : F[i].mFeatVec) { fvv.push_back(e.first); fvv.push_back((unsigned)e.second.size()); fvv.insert(fvv.end(), e.second.begin(), e.second.end()); }
+      writeFile(dir + "/" + names[i] + ".fv", fvv.data(), fvv.size() * sizeof(unsigned));
+      const size_t n = F[i].mvKeys.size(), base = i ? F[0].mvKeys.size() : 0;
+      own[i].resize(n);
+      F[i].mvpMapPoints.assign(n, nullptr);
+      for (size_t j = 0; j < n; j++)
+        if (valid[base + j]) { own[i][j].bad = valid[base + j] == 2; F[i].mvpMapPoints[j] = &own[i][j]; }
+    }
+    std::vector<MapPoint*> vpMapPointMatches, vpMatches12;
+    nbow1 = orbfe::SearchByBoW(ctx, 0.7f, true, &F[0], static_cast<Frame&>(F[1]), vpMapPointMatches);
+    std::vector<int> r1(vpMapPointMatches.size(), -1), r2;
+    for (size_t i = 0; i < r1.size(); i++)
+      if (vpMapPointMatches[i]) r1[i] = (int)(vpMapPointMatches[i] - own[0].data());
+    writeFile(dir + "/bow1.matches", r1.data(), r1.size() * sizeof(int));
+    nbow2 = orbfe::SearchByBoW(ctx, 0.75f, true, &F[0], &F[1], vpMatches12);
+    r2.assign(vpMatches12.size(), -1);
+    for (size_t i = 0; i < r2.size(); i++)
+      if (vpMatches12[i]) r2[i] = (int)(vpMatches12[i] - own[1].data());
+    writeFile(dir + "/bow2.matches", r2.data(), r2.size() * sizeof(int));
+  }
+  printf("%zu %zu %d %d %d %d\n", F[0].mvKeys.size(), F[1].mvKeys.size(), nm, nsbp, nbow1, nbow2);
   return 0;
 }

@@ -74,9 +74,14 @@ def test_facade_matches_oracle(tmp_path, oracle):
     assert rec.dtype.itemsize == 49
     rec.tofile(tmp_path / 'mp.bin')
     open(tmp_path / 'meta.txt', 'w').write('%d %d %d %d\n' % (W, H, N, NMP))
+    from os1_amd.synth import synth_vocabulary
+    voc = synth_vocabulary(2, 10, 4)
+    open(tmp_path / 'voc.bin', 'wb').write(voc)
+    valid = rng.choice(np.array([0, 1, 2], np.uint8), len(k1) + len(k2), p=[0.15, 0.8, 0.05])
+    valid.tofile(tmp_path / 'bow.valid')
     out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
-    n1, n2, nm, nsbp = (int(v) for v in out.stdout.split())
+    n1, n2, nm, nsbp, nbow1, nbow2 = (int(v) for v in out.stdout.split())
     gk1 = np.fromfile(tmp_path / 'A.kps', KP_DTYPE)
     gk2 = np.fromfile(tmp_path / 'B.kps', KP_DTYPE)
     assert gk1.tobytes() == k1.tobytes() and gk2.tobytes() == k2.tobytes()
@@ -93,3 +98,23 @@ def test_facade_matches_oracle(tmp_path, oracle):
                                           mdesc, 1.0, 0.8)
     assert nsbp == osn and nsbp > 100
     assert (np.fromfile(tmp_path / 'sbp.assigned', np.int32) == oa).all()
+    # bag of words through the shim: BowVector / FeatureVector maps and both SearchByBoW overloads
+    ov = oracle.vocabulary(voc)
+    t1, t2 = ov.transform(d1, 4), ov.transform(d2, 4)
+    for name, t in (('A', t1), ('B', t2)):
+        bow = np.fromfile(tmp_path / (name + '.bow'), np.float64).reshape(-1, 2)
+        assert bow[:, 0].astype(np.uint32).tobytes() == t[0].tobytes() and bow[:, 1].tobytes() == t[1].tobytes()
+        fv = np.fromfile(tmp_path / (name + '.fv'), np.uint32)
+        nodes, off, feat = t[2]
+        want = []
+        for i in range(len(nodes)):
+            want += [nodes[i], off[i + 1] - off[i]] + list(feat[off[i]:off[i + 1]])
+        assert fv.tolist() == [int(x) for x in want]
+    v1, v2 = (valid[:len(k1)] == 1).astype(np.uint8), (valid[len(k1):] == 1).astype(np.uint8)
+    wn, w12 = oracle.search_by_bow(d1, k1['angle'], v1, t1[2], d2, k2['angle'], None, t2[2], 0.7, True)
+    r1 = np.fromfile(tmp_path / 'bow1.matches', np.int32)
+    w21 = np.full(len(k2), -1, np.int32)
+    w21[w12[w12 >= 0]] = np.nonzero(w12 >= 0)[0]
+    assert nbow1 == wn and nbow1 > 20 and (r1 == w21).all()
+    wn, w12 = oracle.search_by_bow(d1, k1['angle'], v1, t1[2], d2, k2['angle'], v2, t2[2], 0.75, True)
+    assert nbow2 == wn and nbow2 > 20 and (np.fromfile(tmp_path / 'bow2.matches', np.int32) == w12).all()
