@@ -90,6 +90,16 @@ int orbfe_extractor_features_per_level(const orbfe_extractor* h, int32_t* out);
  * its quota by <= 2). Size `cap` with it. */
 int orbfe_extractor_max_keypoints(const orbfe_extractor* h);
 
+/* Colour input (Tracking::GrabImageMonocular, src/Tracking.cc:96-109: cvtColor(RGB2GRAY / BGR2GRAY) on 3- and
+ * 4-channel images before the Frame is built).  After this call `gray` in the extract calls points to interleaved
+ * 8-bit pixels of the given format (stride in bytes, cols in pixels); the conversion runs on the GPU in front of the
+ * pyramid: gray = (R*cr + G*cg + B*cb + half) >> shift, alpha ignored -- OpenCV's 8-bit RGB2Gray with 15-bit
+ * coefficients {9798, 19235, 3735} (ORBFE_GRAY_Q15, OpenCV >= 4.1.1) or 14-bit {4899, 9617, 1868}
+ * (ORBFE_GRAY_Q14, earlier releases). */
+enum { ORBFE_INPUT_GRAY8 = 0, ORBFE_INPUT_RGB8 = 1, ORBFE_INPUT_BGR8 = 2, ORBFE_INPUT_RGBA8 = 3, ORBFE_INPUT_BGRA8 = 4 };
+enum { ORBFE_GRAY_Q15 = 0, ORBFE_GRAY_Q14 = 1 };
+int orbfe_extractor_set_input_format(orbfe_extractor* h, int format, int gray_variant);
+
 /* void ORBextractor::operator()(InputArray image, InputArray mask, vector<KeyPoint>& keypoints,
  *                               OutputArray descriptors)
  * (include/ORBextractor.h:185-187, src/ORBextractor.cc:907-969).
@@ -186,6 +196,8 @@ void orbfe_stream_destroy(orbfe_stream* s);
 /* bounds = {mnMinX, mnMaxX, mnMinY, mnMaxY}; window_size <= 0 disables matching (extract only). */
 int orbfe_stream_set_matching(orbfe_stream* s, const float bounds[4], int window_size, float nnratio,
                               int check_orientation);
+/* orbfe_extractor_set_input_format for every extractor of the runner (only while no batch is in flight). */
+int orbfe_stream_set_input_format(orbfe_stream* s, int format, int gray_variant);
 /* Per-frame output capacity (keypoints) of the arrays returned by orbfe_stream_pop. */
 int orbfe_stream_capacity(const orbfe_stream* s);
 /* Enqueue one batch (`batch` frame pointers; device pointers if in_device_memory != 0).  Returns at once

@@ -1283,4 +1283,21 @@ int orc_search_by_bow_kf(const uint8_t* desc1, const float* angle1, const uint8_
   return nmatches;
 }
 
+// cv::cvtColor(COLOR_RGB2GRAY / COLOR_BGR2GRAY) for 8-bit 3- or 4-channel images, as called from
+// Tracking::GrabImageMonocular (Tracking.cc:96-109).  OpenCV's RGB2Gray<uchar> (imgproc color_rgb): fixed-point
+// gray = (R*cr + G*cg + B*cb + (1 << (shift-1))) >> shift; variant 0: shift 15, {9798, 19235, 3735}
+// (OpenCV >= 4.1.1); variant 1: shift 14, {4899, 9617, 1868} (earlier releases).  Alpha is ignored.  UNPINNED like the
+// other OpenCV-side primitives (recalled from upstream; pinned by known-answer tests only).
+void orc_cvt_gray(const uint8_t* src, int rows, int cols, int stride, int channels, int rgb_order, int variant,
+                  uint8_t* dst, int dstride) {
+  const int shift = variant == 0 ? 15 : 14;
+  const int cr = variant == 0 ? 9798 : 4899, cg = variant == 0 ? 19235 : 9617, cb = variant == 0 ? 3735 : 1868;
+  for (int y = 0; y < rows; y++)
+    for (int x = 0; x < cols; x++) {
+      const uint8_t* p = src + (size_t)y * stride + (size_t)x * channels;
+      const int r = rgb_order ? p[0] : p[2], g = p[1], b = rgb_order ? p[2] : p[0];
+      dst[(size_t)y * dstride + x] = (uint8_t)((r * cr + g * cg + b * cb + (1 << (shift - 1))) >> shift);
+    }
+}
+
 }  // extern "C"

@@ -58,6 +58,7 @@ class Oracle:
                                                   C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int,
                                                   C.c_void_p]
         L.orc_distinctive_descriptor.argtypes = [C.c_void_p, C.c_int]
+        L.orc_cvt_gray.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_int]
         L.orc_vocab_create.restype = C.c_void_p
         L.orc_vocab_create.argtypes = [C.c_int] * 4 + [C.c_void_p, C.c_int]
         L.orc_vocab_destroy.argtypes = [C.c_void_p]
@@ -178,6 +179,14 @@ class Oracle:
     def distinctive_descriptor(self, descs):
         descs = np.ascontiguousarray(descs, np.uint8)
         return self.L.orc_distinctive_descriptor(_p(descs), len(descs))
+
+    def cvt_gray(self, img, rgb_order=True, variant=0):
+        """(H, W, 3|4) uint8 -> (H, W) uint8 like cv::cvtColor(RGB2GRAY / BGR2GRAY)."""
+        img = np.ascontiguousarray(img, np.uint8)
+        H, W, ch = img.shape
+        out = np.zeros((H, W), np.uint8)
+        self.L.orc_cvt_gray(_p(img), H, W, W * ch, ch, int(rgb_order), variant, _p(out), W)
+        return out
 
     def vocabulary(self, image):
         return OracleVocabulary(self, image)

@@ -82,6 +82,8 @@ def load_library():
     L.orbfe_window_candidates.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t,
                                           C.POINTER(C.c_size_t)]
     L.orbfe_undistort_equidistant.argtypes = [vp, ci, cf, cf, cf, cf]
+    L.orbfe_extractor_set_input_format.argtypes = [vp, ci, ci]
+    L.orbfe_stream_set_input_format.argtypes = [vp, ci, ci]
     L.orbfe_vocabulary_create.argtypes = [ci, ci, ci, ci, ci, vp, ci, C.POINTER(vp)]
     L.orbfe_vocabulary_create_from_image.argtypes = [ci, vp, C.c_size_t, C.POINTER(vp)]
     L.orbfe_vocabulary_destroy.argtypes = [vp]
@@ -172,6 +174,22 @@ class Extractor:
             _check(self.L.orbfe_extract(self.h, None, 0, 0, 0, None, None, 0, C.byref(n)))
             return np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
         assert image.dtype == np.uint8 and image.ndim == 2 and image.strides[1] == 1
+        kps = np.zeros(self.cap, KP_DTYPE)
+        desc = np.zeros((self.cap, 32), np.uint8)
+        n = C.c_int(0)
+        _check(self.L.orbfe_extract(self.h, _p(image), image.shape[0], image.shape[1], image.strides[0], _p(kps),
+                                    _p(desc), self.cap, C.byref(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+    FORMATS = {'gray': 0, 'rgb': 1, 'bgr': 2, 'rgba': 3, 'bgra': 4}
+
+    def set_input_format(self, fmt='gray', variant=0):
+        """Frames of later calls are interleaved 8-bit `fmt` pixels; variant 0 = 15-bit, 1 = 14-bit coefficients."""
+        _check(self.L.orbfe_extractor_set_input_format(self.h, self.FORMATS[fmt], variant))
+
+    def extract_color(self, image):
+        """image: (H, W, 3|4) uint8 host array in the format given to set_input_format."""
+        image = np.ascontiguousarray(image, np.uint8)
         kps = np.zeros(self.cap, KP_DTYPE)
         desc = np.zeros((self.cap, 32), np.uint8)
         n = C.c_int(0)

@@ -27,6 +27,8 @@
 
 namespace orbfe {
 void launch_pyramid(const PyramidParams& P, int nframes, hipStream_t st);
+void launch_to_gray(const uint8_t* const* raw, long long rawStride, const uint8_t* const* gray, long long grayPitch, int rows,
+                    int cols, int channels, const int coef[3], int shift, bool aligned, int nframes, hipStream_t st);
 void launch_fast(const PyramidParams& P, int nframes, hipStream_t st);
 void launch_compact(const PyramidParams& P, int nframes, hipStream_t st);
 void launch_describe(const PyramidParams& P, const SelKp* sel, int nsel, float* angle, uint8_t* desc,
@@ -191,6 +193,9 @@ struct orbfe_extractor {
   PinBuf<const uint8_t*> h_frame0;
   PinBuf<uint32_t> h_cand;
   long long inPitch = 0;
+  int inFormat = ORBFE_INPUT_GRAY8, grayVariant = ORBFE_GRAY_Q15;   // orbfe_extractor_set_input_format
+  long long grayPitch = 0;
+  DevBuf<uint8_t> d_gray;   // level 0 of colour input
   bool inLinear = false;   // host frames are uploaded with linear copies (inPitch == host stride)
   int lastFrames = 0;
   float stageMs[5] = {0, 0, 0, 0, 0};
@@ -215,7 +220,7 @@ struct orbfe_extractor {
     (void)hipSetDevice(device);
     d_tables.release(); d_slab.release(); d_in.release(); d_cellCount.release(); d_cellOff.release();
     d_sfiOrder.release(); d_sfiOrderCount.release(); d_sfiPool.release(); d_sfiPcount.release();
-    d_cells.release(); d_slots.release(); d_cand.release(); d_frame0.release(); d_outArena.release(); h_outArena.release();
+    d_cells.release(); d_slots.release(); d_cand.release(); d_frame0.release(); d_gray.release(); d_outArena.release(); h_outArena.release();
     d_f32tmp.release();
     h_frame0.release(); h_cand.release();
     for (auto& es : ev) for (auto& e : es) if (e) (void)hipEventDestroy(e);
@@ -360,6 +365,8 @@ struct orbfe_extractor {
     return ORBFE_OK;
   }
 
+  int inChannels() const { return inFormat == ORBFE_INPUT_GRAY8 ? 1 : (inFormat == ORBFE_INPUT_RGB8 || inFormat == ORBFE_INPUT_BGR8) ? 3 : 4; }
+
   int setBatch(int nframes, bool hostInput, size_t hostStride = 0) {
     int rc;
     if (nframes > batchCap) {
@@ -368,8 +375,8 @@ struct orbfe_extractor {
       if ((rc = d_cellOff.ensure((size_t)P.ncells * nframes))) return rc;
       if ((rc = d_slots.ensure((size_t)P.slotsPerFrame * nframes))) return rc;
       if ((rc = d_cand.ensure((size_t)P.candCap * nframes))) return rc;
-      if ((rc = d_frame0.ensure(nframes))) return rc;
-      if ((rc = h_frame0.ensure(nframes))) return rc;
+      if ((rc = d_frame0.ensure(2 * (size_t)nframes))) return rc;   // [gray level-0 pointers][raw colour pointers]
+      if ((rc = h_frame0.ensure(2 * (size_t)nframes))) return rc;
       const size_t maxKp = (size_t)(nfeatures + 4 * nlevels + 8) * nframes;  // >= selPerFrame * nframes
       {
         auto al256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -403,11 +410,16 @@ struct orbfe_extractor {
       if (candHostCap == 0) candHostCap = 96 * 1024;
       if ((rc = h_cand.ensure(candHostCap * (size_t)batchCap))) return rc;
     }
+    if (inChannels() > 1) {
+      grayPitch = align_up(cols, 256);
+      if ((rc = d_gray.ensure((size_t)grayPitch * rows * nframes))) return rc;
+    }
     if (hostInput) {
       // rows that are (nearly) contiguous on the host travel as ONE linear DMA per run of frames; a narrow view
       // of a much wider image is copied row by row into a compact device frame
-      inLinear = hostStride >= (size_t)cols && hostStride - cols <= (size_t)cols / 8;
-      inPitch = inLinear ? (long long)hostStride : align_up(cols, 256);
+      const size_t rowBytes = (size_t)cols * inChannels();
+      inLinear = hostStride >= rowBytes && hostStride - rowBytes <= rowBytes / 8;
+      inPitch = inLinear ? (long long)hostStride : align_up((long long)rowBytes, 256);
       if ((rc = d_in.ensure((size_t)inPitch * rows * nframes))) return rc;
     }
     P.slab = d_slab.p;
@@ -462,26 +474,41 @@ struct orbfe_extractor {
     if ((rc = setBatch(nframes, !onDevice, stride))) return rc;
     const double t0 = now_ms();
     hipStream_t st = streams[0];
+    const int ch = inChannels();
+    const int rowBytes = c * ch;
+    bool rawAligned = ((onDevice ? (long long)stride : inPitch) & 3) == 0;
     for (int f = 0; f < nframes; f++) {
       if (!gray[f]) { set_err("frame %d is NULL", f); return ORBFE_ERR_INVALID; }
-      h_frame0.p[f] = onDevice ? gray[f] : d_in.p + (size_t)inPitch * rows * f;
+      const uint8_t* raw = onDevice ? gray[f] : d_in.p + (size_t)inPitch * rows * f;
+      rawAligned = rawAligned && ((uintptr_t)raw & (ch == 4 ? 15 : 3)) == 0;
+      h_frame0.p[f] = ch == 1 ? raw : d_gray.p + (size_t)grayPitch * rows * f;
+      h_frame0.p[nframes + f] = raw;
     }
     hipPointerAttribute_t attr;
     const bool pinned = !onDevice && hipPointerGetAttributes(&attr, gray[0]) == hipSuccess && attr.type == hipMemoryTypeHost;
     if (!onDevice && !pinned) {
       (void)hipGetLastError();   // pageable memory: the runtime stages the copy synchronously; keep it on this handle's stream
-      if ((rc = uploadFrames(0, nframes, gray, stride, r, c, st))) return rc;
+      if ((rc = uploadFrames(0, nframes, gray, stride, r, rowBytes, st))) return rc;
     } else if (!onDevice) {
       UploadLane* lane = upload_lane(device);
       if (!lane) { set_err("cannot create the upload stream"); return ORBFE_ERR_HIP; }
       std::lock_guard<std::mutex> lk(lane->mu);
-      if ((rc = uploadFrames(0, nframes, gray, stride, r, c, lane->stream))) return rc;
+      if ((rc = uploadFrames(0, nframes, gray, stride, r, rowBytes, lane->stream))) return rc;
       HIP_TRY(hipEventRecord(evUpload, lane->stream));
       HIP_TRY(hipStreamWaitEvent(st, evUpload, 0));
     }
-    P.stride0 = onDevice ? (long long)stride : inPitch;
+    const long long rawStride = onDevice ? (long long)stride : inPitch;
+    P.stride0 = ch == 1 ? rawStride : grayPitch;
     P.frameBase = 0;
-    HIP_TRY(hipMemcpyAsync(d_frame0.p, h_frame0.p, sizeof(void*) * nframes, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_frame0.p, h_frame0.p, sizeof(void*) * nframes * (ch == 1 ? 1 : 2), hipMemcpyHostToDevice, st));
+    if (ch > 1) {
+      // OpenCV RGB2Gray<uchar>: 15-bit coefficients {R 9798, G 19235, B 3735} (>= 4.1.1) or 14-bit {4899, 9617, 1868}
+      const bool q15 = grayVariant == ORBFE_GRAY_Q15;
+      const int cr = q15 ? 9798 : 4899, cg = q15 ? 19235 : 9617, cb = q15 ? 3735 : 1868;
+      const bool rgb = inFormat == ORBFE_INPUT_RGB8 || inFormat == ORBFE_INPUT_RGBA8;
+      const int coef[3] = {rgb ? cr : cb, cg, rgb ? cb : cr};
+      launch_to_gray(d_frame0.p + nframes, rawStride, d_frame0.p, grayPitch, r, c, ch, coef, q15 ? 15 : 14, rawAligned, nframes, st);
+    }
     const bool prof = profileKernels;
     if (prof) HIP_TRY(hipEventRecord(ev[0][0], st));
     launch_pyramid(P, nframes, st);
@@ -653,6 +680,7 @@ struct orbfe_extractor {
       pool.reset(new HostPool(hostThreads));
       workers.resize(hostThreads);
     }
+    if (inChannels() != 1) { set_err("colour input needs the GPU quadtree path (unset ORBFE_HOST_QUADTREE)"); return ORBFE_ERR_INVALID; }
     const int nsub = std::min(nframes, std::min(kMaxSub, std::max(1, subBatches)));
     const int maxKp = nfeatures + 2 * nlevels;
     int subF0[kMaxSub + 1];
@@ -868,6 +896,18 @@ int orbfe_device_synchronize(int device_id) {
   return ORBFE_OK;
 }
 
+int orbfe_extractor_set_input_format(orbfe_extractor* h, int format, int gray_variant) {
+  if (!h || format < ORBFE_INPUT_GRAY8 || format > ORBFE_INPUT_BGRA8 || (gray_variant != ORBFE_GRAY_Q15 && gray_variant != ORBFE_GRAY_Q14)) {
+    set_err("bad input format");
+    return ORBFE_ERR_INVALID;
+  }
+  if (h->pendingFrames) { set_err("a submitted batch has not been collected yet"); return ORBFE_ERR_INVALID; }
+  h->inFormat = format;
+  h->grayVariant = gray_variant;
+  h->batchCap = 0;   // buffers are re-sized on the next call
+  return ORBFE_OK;
+}
+
 int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device_id,
                            orbfe_extractor** out) {
   if (!out) { set_err("out is NULL"); return ORBFE_ERR_INVALID; }
@@ -992,7 +1032,7 @@ int orbfe_extract_batch(orbfe_extractor* h, int nframes, const uint8_t* const* g
   if (nframes <= 0) return ORBFE_OK;
   for (int f = 0; f < nframes; f++) n_out[f] = 0;
   if (rows == 0 || cols == 0 || !gray) return ORBFE_OK;  // empty image: silent return (ORBextractor.cc:910-911)
-  if (rows < 0 || cols < 0 || stride_bytes < (size_t)cols || !kps || !desc || cap <= 0) {
+  if (rows < 0 || cols < 0 || stride_bytes < (size_t)cols * h->inChannels() || !kps || !desc || cap <= 0) {
     set_err("invalid image / output arguments");
     return ORBFE_ERR_INVALID;
   }
@@ -1002,7 +1042,7 @@ int orbfe_extract_batch(orbfe_extractor* h, int nframes, const uint8_t* const* g
 
 int orbfe_extract_batch_submit(orbfe_extractor* h, int nframes, const uint8_t* const* gray, int in_device_memory,
                                int rows, int cols, size_t stride_bytes) {
-  if (!h || !gray || nframes <= 0 || rows <= 0 || cols <= 0 || stride_bytes < (size_t)cols) {
+  if (!h || !gray || nframes <= 0 || rows <= 0 || cols <= 0 || stride_bytes < (size_t)cols * h->inChannels()) {
     set_err("invalid arguments");
     return ORBFE_ERR_INVALID;
   }
@@ -1044,7 +1084,7 @@ void orbfe_sfi_chain_destroy(orbfe_sfi_chain* c) { delete c; }
 int orbfe_extract_batch_submit_matched(orbfe_extractor* h, orbfe_sfi_chain* chain, int nframes, const uint8_t* const* gray,
                                        int in_device_memory, int rows, int cols, size_t stride_bytes, const float bounds[4],
                                        int window_size, float nnratio, int check_orientation) {
-  if (!h || !chain || !gray || !bounds || nframes <= 0 || rows <= 0 || cols <= 0 || stride_bytes < (size_t)cols || window_size <= 0) {
+  if (!h || !chain || !gray || !bounds || nframes <= 0 || rows <= 0 || cols <= 0 || stride_bytes < (size_t)cols * h->inChannels() || window_size <= 0) {
     set_err("invalid arguments");
     return ORBFE_ERR_INVALID;
   }

@@ -657,6 +657,62 @@ __global__ void k_sincos(const float* deg, int n, float* c, float* s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Colour -> gray for frames handed over as interleaved RGB / BGR / RGBA / BGRA (Tracking::GrabImageMonocular,
+// Tracking.cc:96-109: cvtColor(RGB2GRAY / BGR2GRAY) before the Frame is built).  OpenCV's 8-bit path:
+// gray = (src[0]*c0 + src[1]*c1 + src[2]*c2 + (1 << (shift-1))) >> shift, alpha ignored.  Four pixels per thread
+// (3 dwords or one dwordx4 in, one dword out); unaligned sources and row tails take the byte path.
+// ------------------------------------------------------------------------------------------------
+template <int CH>
+__global__ void __launch_bounds__(256) k_to_gray(const uint8_t* const* __restrict__ raw, long long rawStride,
+                                                 const uint8_t* const* __restrict__ gray, long long grayPitch, int cols,
+                                                 int c0, int c1, int c2, int shift, int aligned) {
+  const int x = (int)(blockIdx.x * 256 + threadIdx.x) * 4;
+  if (x >= cols) return;
+  const int y = blockIdx.y, f = blockIdx.z;
+  const uint8_t* src = raw[f] + (long long)y * rawStride + (long long)x * CH;
+  uint8_t* dst = const_cast<uint8_t*>(gray[f]) + (long long)y * grayPitch + x;
+  const int rnd = 1 << (shift - 1);
+  if (aligned && x + 4 <= cols) {
+    uint32_t w[CH];
+    if (CH == 3) {
+      const uint32_t* s32 = (const uint32_t*)src;
+      w[0] = s32[0]; w[1] = s32[1]; w[2] = s32[2];
+    } else {
+      const uint4 q = *(const uint4*)src;
+      w[0] = q.x; w[1] = q.y; w[2] = q.z; w[CH - 1] = q.w;
+    }
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      uint32_t a, b, c;
+      if (CH == 3) {   // bytes 3i, 3i+1, 3i+2 of the 12-byte group
+        a = (w[(3 * i) >> 2] >> (((3 * i) & 3) * 8)) & 255u;
+        b = (w[(3 * i + 1) >> 2] >> (((3 * i + 1) & 3) * 8)) & 255u;
+        c = (w[(3 * i + 2) >> 2] >> (((3 * i + 2) & 3) * 8)) & 255u;
+      } else {
+        a = w[i] & 255u; b = (w[i] >> 8) & 255u; c = (w[i] >> 16) & 255u;
+      }
+      out |= ((uint32_t)(m24((int)a, c0) + m24((int)b, c1) + m24((int)c, c2) + rnd) >> shift) << (8 * i);
+    }
+    *(uint32_t*)dst = out;
+  } else {
+    for (int i = 0; i < 4 && x + i < cols; i++)
+      dst[i] = (uint8_t)((m24(src[CH * i], c0) + m24(src[CH * i + 1], c1) + m24(src[CH * i + 2], c2) + rnd) >> shift);
+  }
+}
+
+void launch_to_gray(const uint8_t* const* raw, long long rawStride, const uint8_t* const* gray, long long grayPitch, int rows,
+                    int cols, int channels, const int coef[3], int shift, bool aligned, int nframes, hipStream_t st) {
+  dim3 grid((cols + 1023) / 1024, rows, nframes);
+  if (channels == 3)
+    hipLaunchKernelGGL(k_to_gray<3>, grid, dim3(256), 0, st, raw, rawStride, gray, grayPitch, cols, coef[0], coef[1], coef[2],
+                       shift, aligned ? 1 : 0);
+  else
+    hipLaunchKernelGGL(k_to_gray<4>, grid, dim3(256), 0, st, raw, rawStride, gray, grayPitch, cols, coef[0], coef[1], coef[2],
+                       shift, aligned ? 1 : 0);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Launchers (called by the host engine).
 // ------------------------------------------------------------------------------------------------
 void launch_pyramid(const PyramidParams& P, int nframes, hipStream_t st) {

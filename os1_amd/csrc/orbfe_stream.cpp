@@ -72,6 +72,7 @@ struct orbfe_stream {
   std::thread tExtract;
   std::vector<std::thread> tMatch;
   long long pushSeq = 0, popSeq = 0;
+  int channels = 1;   // bytes per pixel of the pushed frames (orbfe_stream_set_input_format)
 
   // last frame of the previous batch (the predecessor of frame 0 of the next one)
   std::vector<OrbfeKeyPoint> lastKps;
@@ -306,11 +307,23 @@ int orbfe_stream_set_matching(orbfe_stream* s, const float bounds[4], int window
   return ORBFE_OK;
 }
 
+int orbfe_stream_set_input_format(orbfe_stream* s, int format, int gray_variant) {
+  if (!s) { set_err("invalid arguments"); return ORBFE_ERR_INVALID; }
+  std::lock_guard<std::mutex> lk(s->mu);
+  if (s->pushSeq != s->popSeq) { set_err("batches are still in flight"); return ORBFE_ERR_INVALID; }
+  for (orbfe_extractor* e : s->ext) {
+    const int rc = orbfe_extractor_set_input_format(e, format, gray_variant);
+    if (rc) return rc;
+  }
+  s->channels = format == ORBFE_INPUT_GRAY8 ? 1 : (format == ORBFE_INPUT_RGB8 || format == ORBFE_INPUT_BGR8) ? 3 : 4;
+  return ORBFE_OK;
+}
+
 int orbfe_stream_capacity(const orbfe_stream* s) { return s ? s->cap : 0; }
 
 int orbfe_stream_push(orbfe_stream* s, const uint8_t* const* gray, int in_device_memory, int rows, int cols,
                       size_t stride_bytes) {
-  if (!s || !gray || rows <= 0 || cols <= 0 || stride_bytes < (size_t)cols) { set_err("invalid arguments"); return ORBFE_ERR_INVALID; }
+  if (!s || !gray || rows <= 0 || cols <= 0 || stride_bytes < (size_t)cols * s->channels) { set_err("invalid arguments"); return ORBFE_ERR_INVALID; }
   int slot;
   {
     std::unique_lock<std::mutex> lk(s->mu);

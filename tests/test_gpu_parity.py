@@ -74,6 +74,34 @@ def test_batch_device_input_and_strides(api, oracle):
     _cmp_extract(ex(img2), ox.extract(img2))
 
 
+def test_colour_input_parity(api, oracle):
+    """RGB / BGR / RGBA / BGRA frames (Tracking.cc:96-109): GPU colour->gray in front of the pyramid == oracle cvtColor
+    restatement followed by the gray extractor; host and device input, odd widths (row tails, unaligned rows)."""
+    rng = np.random.default_rng(3)
+    for W, H in [(640, 480), (611, 403)]:
+        g = synth(40 + W, W, H).astype(np.int32)
+        col = np.stack([np.clip(g + rng.integers(-30, 31, g.shape), 0, 255),
+                        np.clip(g + rng.integers(-10, 11, g.shape), 0, 255),
+                        np.clip(g + rng.integers(-40, 41, g.shape), 0, 255),
+                        rng.integers(0, 256, g.shape)], axis=-1).astype(np.uint8)
+        ex = api.Extractor(700, 1.2, 8, 20, 7)
+        ox = OracleExtractor(700, 1.2, 8, 20, 7, oracle)
+        for fmt, ch, rgb in [('rgb', 3, True), ('bgr', 3, False), ('rgba', 4, True), ('bgra', 4, False)]:
+            for variant in (0, 1):
+                img = np.ascontiguousarray(col[..., :ch])
+                gray = oracle.cvt_gray(img, rgb, variant)
+                ex.set_input_format(fmt, variant)
+                want = ox.extract(gray)
+                _cmp_extract(ex.extract_color(img), want)
+                assert (ex.level(0) == gray).all()
+                if variant == 0:
+                    dev = api.DeviceFrames([img.reshape(H, W * ch)], 0)
+                    kps, desc, n = ex.extract_batch_ptrs(dev.ptrs, H, W, W * ch, True)
+                    _cmp_extract((kps[0, :n[0]], desc[0, :n[0]]), want)
+        ex.set_input_format('gray')
+        _cmp_extract(ex(gray), ox.extract(gray))
+
+
 def test_other_parameters(api, oracle):
     img = synth(7, 960, 540)
     for (N, sf, nl, ini, mn) in [(1500, 1.2, 8, 20, 7), (300, 1.5, 4, 30, 10), (1000, 1.1, 6, 12, 5), (50, 1.2, 3, 40, 40)]:

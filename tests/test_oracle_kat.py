@@ -303,3 +303,23 @@ def test_distinctive_descriptor_definition(oracle):
         D = np.array([[int(np.unpackbits(d[i] ^ d[j]).sum()) for j in range(N)] for i in range(N)])
         med = [sorted(D[i])[int(0.5 * (N - 1))] for i in range(N)]
         assert oracle.distinctive_descriptor(d) == int(np.argmin(med))
+
+
+def test_cvt_gray_known_answers(oracle):
+    """cv::cvtColor RGB2GRAY 8u: primaries, white, and an independent numpy restatement of both fixed-point variants."""
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0], [1, 1, 1], [128, 64, 32]]], np.uint8)
+    # 0.299 / 0.587 / 0.114 of 255, rounded by the fixed-point formula
+    assert oracle.cvt_gray(px, True, 0)[0].tolist() == [76, 150, 29, 255, 0, 1, 79]
+    assert oracle.cvt_gray(px, False, 0)[0].tolist() == [29, 150, 76, 255, 0, 1, 62]
+    assert oracle.cvt_gray(px, True, 1)[0].tolist() == [76, 150, 29, 255, 0, 1, 79]
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (37, 53, 4), dtype=np.uint8)
+    for variant, (cr, cg, cb, sh) in enumerate([(9798, 19235, 3735, 15), (4899, 9617, 1868, 14)]):
+        assert cr + cg + cb == 1 << sh
+        i = img.astype(np.int64)
+        want = ((i[..., 0] * cr + i[..., 1] * cg + i[..., 2] * cb + (1 << (sh - 1))) >> sh).astype(np.uint8)
+        assert (oracle.cvt_gray(img, True, variant) == want).all()
+        assert (oracle.cvt_gray(img[..., :3], True, variant) == want).all()
+        assert (oracle.cvt_gray(img[..., [2, 1, 0, 3]], False, variant) == want).all()
+    # the two variants do differ somewhere (so the choice is observable)
+    assert (oracle.cvt_gray(img, True, 0) != oracle.cvt_gray(img, True, 1)).any()
