@@ -368,6 +368,20 @@ int orbfe_search_by_bow(orbfe_matcher* m, const uint8_t* desc1, const float* ang
                         const uint32_t* fv2_nodes, const uint32_t* fv2_offsets, const uint32_t* fv2_features, int n_fv2,
                         float nnratio, int check_orientation, int strict_threshold, int32_t* matches12, int* nmatches);
 
+/* int ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, vector<pair<size_t,size_t>>&
+ * vMatchedPairs)  (ORBmatcher.cc:652-804, with CheckDistEpipolarLine :135-152), from the epipole onwards: the caller
+ * computes (ex, ey) (:657-666) and passes F12 row-major.  has_mpX[i] != 0: the keypoint already has a MapPoint and is
+ * skipped (:708, :726).  kpsX_un = mvKeysUn; scale_factors2 / level_sigma2_2 = pKF2->mvScaleFactors / mvLevelSigma2
+ * (nlevels2 <= 16).  pairs_out: (idx1, idx2) int32 pairs in ascending idx1, capacity n1 pairs; *nmatches = return
+ * value = number of pairs.  (The reference never sets vbMatched2, so a keypoint of pKF2 may appear in several pairs.) */
+int orbfe_search_for_triangulation(orbfe_matcher* m, const OrbfeKeyPoint* kps1_un, const uint8_t* desc1,
+                                   const uint8_t* has_mp1, int n1, const uint32_t* fv1_nodes, const uint32_t* fv1_offsets,
+                                   const uint32_t* fv1_features, int n_fv1, const OrbfeKeyPoint* kps2_un,
+                                   const uint8_t* desc2, const uint8_t* has_mp2, int n2, const uint32_t* fv2_nodes,
+                                   const uint32_t* fv2_offsets, const uint32_t* fv2_features, int n_fv2, const float F12[9],
+                                   float ex, float ey, const float* scale_factors2, const float* level_sigma2_2,
+                                   int nlevels2, int check_orientation, int32_t* pairs_out, int* nmatches);
+
 /* void Frame::antidistorsionarProyeccionEquidistante(cv::Mat& puntos)  (src/Frame.cc:355-384): os1's
  * equidistant-fisheye keypoint undistortion (camera `modo: 1`), used by Frame::UndistortKeyPoints (:286-320) and
  * Frame::ComputeImageBounds (:322-353).  Host double-precision math on n (x, y) float pairs, in place; K is the

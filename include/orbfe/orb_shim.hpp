@@ -16,6 +16,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../orbfe.h"
@@ -305,6 +306,37 @@ inline int SearchByBoW(MatcherContext& ctx, float mfNNratio, bool mbCheckOrienta
                             m12.data(), &nmatches));
   for (int i = 0; i < n1; i++)
     if (m12[i] >= 0) vpMatches12[i] = vpMapPoints2[m12[i]];
+  return nmatches;
+}
+
+// int ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12,
+//                                        vector<pair<size_t,size_t>>& vMatchedPairs)   (ORBmatcher.cc:652-804).
+// The body keeps the reference's epipole lines (:657-666) and passes (ex, ey); F12 is read through .at<float>(r,c).
+template <class KeyFrameT, class MatT>
+inline int SearchForTriangulation(MatcherContext& ctx, bool mbCheckOrientation, KeyFrameT* pKF1, KeyFrameT* pKF2,
+                                  const MatT& F12, float ex, float ey,
+                                  std::vector<std::pair<size_t, size_t> >& vMatchedPairs) {
+  const int n1 = (int)pKF1->N, n2 = (int)pKF2->N;
+  std::vector<uint8_t> has1(n1 > 0 ? n1 : 1, 0), has2(n2 > 0 ? n2 : 1, 0), t1, t2;
+  for (int i = 0; i < n1; i++) has1[i] = pKF1->GetMapPoint(i) ? 1 : 0;   // ORBmatcher.cc:704-709
+  for (int i = 0; i < n2; i++) has2[i] = pKF2->GetMapPoint(i) ? 1 : 0;   // :723-727
+  std::vector<uint32_t> n1v, o1v, f1v, n2v, o2v, f2v;
+  detail::flattenFeatureVector(pKF1->mFeatVec, n1v, o1v, f1v);
+  detail::flattenFeatureVector(pKF2->mFeatVec, n2v, o2v, f2v);
+  float F[9];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) F[3 * r + c] = F12.template at<float>(r, c);
+  std::vector<int32_t> pairs((size_t)(n1 > 0 ? n1 : 1) * 2, -1);
+  int nmatches = 0;
+  check(orbfe_search_for_triangulation(
+      ctx.get(), reinterpret_cast<const OrbfeKeyPoint*>(pKF1->mvKeysUn.data()), detail::packedDescriptors(pKF1->mDescriptors, n1, t1),
+      has1.data(), n1, n1v.data(), o1v.data(), f1v.data(), (int)n1v.size(),
+      reinterpret_cast<const OrbfeKeyPoint*>(pKF2->mvKeysUn.data()), detail::packedDescriptors(pKF2->mDescriptors, n2, t2),
+      has2.data(), n2, n2v.data(), o2v.data(), f2v.data(), (int)n2v.size(), F, ex, ey, pKF2->mvScaleFactors.data(),
+      pKF2->mvLevelSigma2.data(), (int)pKF2->mvScaleFactors.size(), mbCheckOrientation ? 1 : 0, pairs.data(), &nmatches));
+  vMatchedPairs.clear();
+  vMatchedPairs.reserve(nmatches);
+  for (int i = 0; i < nmatches; i++) vMatchedPairs.push_back(std::make_pair((size_t)pairs[2 * i], (size_t)pairs[2 * i + 1]));
   return nmatches;
 }
 

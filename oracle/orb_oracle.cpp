@@ -1300,4 +1300,87 @@ void orc_cvt_gray(const uint8_t* src, int rows, int cols, int stride, int channe
     }
 }
 
+// ORBmatcher::SearchForTriangulation (ORBmatcher.cc:652-804) from the epipole onwards, with
+// ORBmatcher::CheckDistEpipolarLine (:135-152).  hasMP1/hasMP2: the keypoint already has a MapPoint (skipped);
+// F12 row-major float[9]; (ex, ey) the epipole in image 2 (:660-666); scale2 / sigma2: pKF2->mvScaleFactors /
+// mvLevelSigma2.  NOTE vbMatched2 is never set by the reference (:676, :718), so it is not modelled.
+// pairs = (idx1, idx2) in ascending idx1 (:792-800).  Returns nmatches.
+int orc_search_for_triangulation(const OrcKeyPoint* kps1, const uint8_t* desc1, const uint8_t* hasMP1, int n1,
+                                 const uint32_t* fv1_nodes, const uint32_t* fv1_off, const uint32_t* fv1_feat, int nfv1,
+                                 const OrcKeyPoint* kps2, const uint8_t* desc2, const uint8_t* hasMP2, int n2,
+                                 const uint32_t* fv2_nodes, const uint32_t* fv2_off, const uint32_t* fv2_feat, int nfv2,
+                                 const float* F12, float ex, float ey, const float* scale2, const float* sigma2,
+                                 int checkOri, int32_t* pairs) {
+  (void)n2;
+  const int TH_LOW = 50, HISTO_LENGTH = 30;
+  int nmatches = 0;
+  std::vector<int> vMatches12(n1, -1);
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const float factor = 1.0f / HISTO_LENGTH;
+  int a = 0, b = 0;
+  while (a < nfv1 && b < nfv2) {
+    if (fv1_nodes[a] == fv2_nodes[b]) {
+      for (uint32_t i1 = fv1_off[a]; i1 < fv1_off[a + 1]; i1++) {
+        const size_t idx1 = fv1_feat[i1];
+        if (hasMP1[idx1]) continue;
+        const OrcKeyPoint& kp1 = kps1[idx1];
+        const uint8_t* d1 = desc1 + 32 * idx1;
+        int bestDist = TH_LOW;
+        int bestIdx2 = -1;
+        for (uint32_t i2 = fv2_off[b]; i2 < fv2_off[b + 1]; i2++) {
+          size_t idx2 = fv2_feat[i2];
+          if (hasMP2[idx2]) continue;
+          const int dist = descriptor_distance(d1, desc2 + 32 * idx2);
+          if (dist > TH_LOW || dist > bestDist) continue;
+          const OrcKeyPoint& kp2 = kps2[idx2];
+          const float distex = ex - kp2.x;
+          const float distey = ey - kp2.y;
+          if (distex * distex + distey * distey < 100 * scale2[kp2.octave]) continue;
+          // CheckDistEpipolarLine
+          const float la = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+          const float lb = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+          const float lc = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+          const float num = la * kp2.x + lb * kp2.y + lc;
+          const float den = la * la + lb * lb;
+          if (den == 0) continue;
+          const float dsqr = num * num / den;
+          if (dsqr < 3.84 * sigma2[kp2.octave]) { bestIdx2 = (int)idx2; bestDist = dist; }
+        }
+        if (bestIdx2 >= 0) {
+          vMatches12[idx1] = bestIdx2;
+          nmatches++;
+          if (checkOri) {
+            float rot = kp1.angle - kps2[bestIdx2].angle;
+            if (rot < 0.0) rot += 360.0f;
+            int bin = round(rot * factor);
+            if (bin == HISTO_LENGTH) bin = 0;
+            rotHist[bin].push_back((int)idx1);
+          }
+        }
+      }
+      a++; b++;
+    } else if (fv1_nodes[a] < fv2_nodes[b]) {
+      a = (int)(std::lower_bound(fv1_nodes, fv1_nodes + nfv1, fv2_nodes[b]) - fv1_nodes);
+    } else {
+      b = (int)(std::lower_bound(fv2_nodes, fv2_nodes + nfv2, fv1_nodes[a]) - fv2_nodes);
+    }
+  }
+  if (checkOri) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    compute_three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      if (i == ind1 || i == ind2 || i == ind3) continue;
+      for (size_t j = 0; j < rotHist[i].size(); j++) { vMatches12[rotHist[i][j]] = -1; nmatches--; }
+    }
+  }
+  int np = 0;
+  for (int i = 0; i < n1; i++) {
+    if (vMatches12[i] < 0) continue;
+    pairs[2 * np] = i;
+    pairs[2 * np + 1] = vMatches12[i];
+    np++;
+  }
+  return nmatches;
+}
+
 }  // extern "C"

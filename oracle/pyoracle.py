@@ -59,6 +59,9 @@ class Oracle:
                                                   C.c_void_p]
         L.orc_distinctive_descriptor.argtypes = [C.c_void_p, C.c_int]
         L.orc_cvt_gray.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.c_void_p, C.c_int]
+        L.orc_search_for_triangulation.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] + \
+            [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p,
+                                                                  C.c_void_p, C.c_int, C.c_void_p]
         L.orc_vocab_create.restype = C.c_void_p
         L.orc_vocab_create.argtypes = [C.c_int] * 4 + [C.c_void_p, C.c_int]
         L.orc_vocab_destroy.argtypes = [C.c_void_p]
@@ -187,6 +190,26 @@ class Oracle:
         out = np.zeros((H, W), np.uint8)
         self.L.orc_cvt_gray(_p(img), H, W, W * ch, ch, int(rgb_order), variant, _p(out), W)
         return out
+
+    def search_for_triangulation(self, kps1, desc1, has_mp1, fv1, kps2, desc2, has_mp2, fv2, F12, ex, ey, scale2, sigma2,
+                                 check_ori=True):
+        kps1 = np.ascontiguousarray(kps1)
+        kps2 = np.ascontiguousarray(kps2)
+        desc1 = np.ascontiguousarray(desc1, np.uint8)
+        desc2 = np.ascontiguousarray(desc2, np.uint8)
+        h1 = np.ascontiguousarray(has_mp1, np.uint8)
+        h2 = np.ascontiguousarray(has_mp2, np.uint8)
+        f1 = [np.ascontiguousarray(a, np.uint32) for a in fv1]
+        f2 = [np.ascontiguousarray(a, np.uint32) for a in fv2]
+        F = np.ascontiguousarray(F12, np.float32).reshape(9)
+        sc = np.ascontiguousarray(scale2, np.float32)
+        sg = np.ascontiguousarray(sigma2, np.float32)
+        pairs = np.full((max(len(kps1), 1), 2), -1, np.int32)
+        nm = self.L.orc_search_for_triangulation(_p(kps1), _p(desc1), _p(h1), len(kps1), _p(f1[0]), _p(f1[1]), _p(f1[2]),
+                                                 len(f1[0]), _p(kps2), _p(desc2), _p(h2), len(kps2), _p(f2[0]), _p(f2[1]),
+                                                 _p(f2[2]), len(f2[0]), _p(F), C.c_float(ex), C.c_float(ey), _p(sc), _p(sg),
+                                                 int(check_ori), _p(pairs))
+        return nm, pairs[:nm]
 
     def vocabulary(self, image):
         return OracleVocabulary(self, image)

@@ -82,6 +82,8 @@ def load_library():
     L.orbfe_window_candidates.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t,
                                           C.POINTER(C.c_size_t)]
     L.orbfe_undistort_equidistant.argtypes = [vp, ci, cf, cf, cf, cf]
+    L.orbfe_search_for_triangulation.argtypes = [vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, cf, cf,
+                                                 vp, vp, ci, ci, vp, C.POINTER(ci)]
     L.orbfe_extractor_set_input_format.argtypes = [vp, ci, ci]
     L.orbfe_stream_set_input_format.argtypes = [vp, ci, ci]
     L.orbfe_vocabulary_create.argtypes = [ci, ci, ci, ci, ci, vp, ci, C.POINTER(vp)]
@@ -403,6 +405,28 @@ class Matcher:
         out = np.zeros(max(len(desc_lists), 1), np.int32)
         _check(self.L.orbfe_distinctive_descriptors(self.h, len(desc_lists), _p(offs), _p(allv), _p(out)))
         return out[:len(desc_lists)]
+
+    def search_for_triangulation(self, kps1, desc1, has_mp1, fv1, kps2, desc2, has_mp2, fv2, F12, ex, ey, scale2, sigma2,
+                                 check_ori=True):
+        """ORBmatcher::SearchForTriangulation from the epipole onwards -> (nmatches, pairs[n,2])."""
+        kps1 = np.ascontiguousarray(kps1)
+        kps2 = np.ascontiguousarray(kps2)
+        desc1 = np.ascontiguousarray(desc1, np.uint8)
+        desc2 = np.ascontiguousarray(desc2, np.uint8)
+        h1 = np.ascontiguousarray(has_mp1, np.uint8)
+        h2 = np.ascontiguousarray(has_mp2, np.uint8)
+        f1 = [np.ascontiguousarray(a, np.uint32) for a in fv1]
+        f2 = [np.ascontiguousarray(a, np.uint32) for a in fv2]
+        F = np.ascontiguousarray(F12, np.float32).reshape(9)
+        sc = np.ascontiguousarray(scale2, np.float32)
+        sg = np.ascontiguousarray(sigma2, np.float32)
+        pairs = np.full((max(len(kps1), 1), 2), -1, np.int32)
+        nm = C.c_int(0)
+        _check(self.L.orbfe_search_for_triangulation(self.h, _p(kps1), _p(desc1), _p(h1), len(kps1), _p(f1[0]), _p(f1[1]),
+                                                     _p(f1[2]), len(f1[0]), _p(kps2), _p(desc2), _p(h2), len(kps2),
+                                                     _p(f2[0]), _p(f2[1]), _p(f2[2]), len(f2[0]), _p(F), ex, ey, _p(sc),
+                                                     _p(sg), len(sc), int(check_ori), _p(pairs), C.byref(nm)))
+        return nm.value, pairs[:nm.value]
 
     def search_by_bow(self, desc1, angle1, valid1, fv1, desc2, angle2, valid2, fv2, nnratio=0.7, check_ori=True,
                       strict=False):

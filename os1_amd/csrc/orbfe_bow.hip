@@ -184,6 +184,56 @@ __global__ void __launch_bounds__(64) k_bow_match(const uint4* __restrict__ desc
   }
 }
 
+// SearchForTriangulation inner search (ORBmatcher.cc:695-747): the reference never sets vbMatched2, so every
+// frame-1 feature is independent: among the node's frame-2 features without a MapPoint, with distance <= TH_LOW, far
+// enough from the epipole and close enough to the epipolar line, take the least distance -- the LAST one on ties
+// (`dist > bestDist` is the skip test).  key = distance << 16 | (0xffff - position).
+struct TriParams {
+  float F12[9];
+  float ex, ey;
+  float scale2[16], sigma2[16];
+};
+
+__global__ void __launch_bounds__(64) k_bow_triangulate(const OrbfeKeyPoint* __restrict__ kps1, const uint4* __restrict__ desc1,
+                                                        const uint8_t* __restrict__ hasMP1, const uint32_t* __restrict__ feat1,
+                                                        const OrbfeKeyPoint* __restrict__ kps2, const uint4* __restrict__ desc2,
+                                                        const uint8_t* __restrict__ hasMP2, const uint32_t* __restrict__ feat2,
+                                                        const BowPair* __restrict__ pairs, TriParams T,
+                                                        int32_t* __restrict__ matches12) {
+  const BowPair P = pairs[blockIdx.x];
+  const int lane = threadIdx.x;
+  const int n2g = P.e2 - P.b2;
+  for (int i1 = P.b1; i1 < P.e1; i1++) {
+    const unsigned idx1 = feat1[i1];
+    if (hasMP1[idx1]) continue;   // wave-uniform
+    const uint4 a0 = desc1[2 * (size_t)idx1], a1 = desc1[2 * (size_t)idx1 + 1];
+    const float x1 = kps1[idx1].x, y1 = kps1[idx1].y;
+    // epipolar line in image 2, l = x1' F12 (ORBmatcher.cc:138-140)
+    const float la = x1 * T.F12[0] + y1 * T.F12[3] + T.F12[6];
+    const float lb = x1 * T.F12[1] + y1 * T.F12[4] + T.F12[7];
+    const float lc = x1 * T.F12[2] + y1 * T.F12[5] + T.F12[8];
+    const float den = la * la + lb * lb;
+    unsigned key = 0xffffffffu;
+    for (int p = lane; p < n2g; p += 64) {
+      const unsigned idx2 = feat2[P.b2 + p];
+      if (hasMP2[idx2]) continue;
+      const int dist = hamming256(a0, a1, desc2[2 * (size_t)idx2], desc2[2 * (size_t)idx2 + 1]);
+      if (dist > TH_LOW) continue;
+      const float x2 = kps2[idx2].x, y2 = kps2[idx2].y;
+      const int oct = kps2[idx2].octave;
+      const float distex = T.ex - x2, distey = T.ey - y2;
+      if (distex * distex + distey * distey < 100 * T.scale2[oct]) continue;
+      const float num = la * x2 + lb * y2 + lc;
+      if (den == 0) continue;
+      const float dsqr = num * num / den;
+      if (!((double)dsqr < 3.84 * (double)T.sigma2[oct])) continue;
+      key = min(key, ((unsigned)dist << 16) | (0xffffu - (unsigned)p));
+    }
+    key = wave_min(key);
+    if (key != 0xffffffffu && lane == 0) matches12[idx1] = (int32_t)feat2[P.b2 + (int)(0xffffu - (key & 0xffffu))];
+  }
+}
+
 }  // namespace
 
 struct orbfe_vocabulary {
@@ -398,7 +448,53 @@ struct BowScratch {
   DevBuf<BowPair> d_pairs;
   DevBuf<int32_t> d_m12;
   PinBuf<int32_t> h_m12;
+  DevBuf<OrbfeKeyPoint> d_kps1, d_kps2;
 };
+
+// common vocabulary nodes of two FeatureVectors (the lower_bound zig-zag of ORBmatcher.cc:175-258 visits exactly the
+// intersection, in ascending order) as feature ranges
+int common_nodes(const uint32_t* fv1_nodes, const uint32_t* fv1_offsets, int n_fv1, const uint32_t* fv2_nodes,
+                 const uint32_t* fv2_offsets, int n_fv2, std::vector<BowPair>& pairs) {
+  pairs.clear();
+  for (int a = 0, b = 0; a < n_fv1 && b < n_fv2;) {
+    if (fv1_nodes[a] == fv2_nodes[b]) {
+      BowPair p = {(int)fv1_offsets[a], (int)fv1_offsets[a + 1], (int)fv2_offsets[b], (int)fv2_offsets[b + 1]};
+      if (p.e2 - p.b2 > kMaxGroup) { set_err("a vocabulary node holds %d features (max %d)", p.e2 - p.b2, kMaxGroup); return ORBFE_ERR_OVERFLOW; }
+      if (p.e1 > p.b1 && p.e2 > p.b2) pairs.push_back(p);
+      a++; b++;
+    } else if (fv1_nodes[a] < fv2_nodes[b]) a++;
+    else b++;
+  }
+  return ORBFE_OK;
+}
+
+// rotation-histogram pruning shared by the BoW searches (ORBmatcher.cc:226-236,261-280)
+int prune_by_orientation(const float* angle1, size_t stride1, const float* angle2, size_t stride2, int n1, int32_t* matches12) {
+  int count[HISTO_LENGTH] = {};
+  std::vector<int8_t> bin(n1, -1);
+  const float factor = 1.0f / HISTO_LENGTH;
+  for (int i = 0; i < n1; i++) {
+    const int j = matches12[i];
+    if (j < 0) continue;
+    float rot = *(const float*)((const char*)angle1 + stride1 * i) - *(const float*)((const char*)angle2 + stride2 * j);
+    if (rot < 0.0) rot += 360.0f;
+    int b = (int)round(rot * factor);
+    if (b == HISTO_LENGTH) b = 0;
+    if (b < 0 || b >= HISTO_LENGTH) continue;   // the reference asserts; cannot happen for angles in [0,360)
+    bin[i] = (int8_t)b;
+    count[b]++;
+  }
+  int ind1 = -1, ind2 = -1, ind3 = -1, removed = 0;
+  three_maxima(count, HISTO_LENGTH, ind1, ind2, ind3);
+  for (int i = 0; i < n1; i++) {
+    const int b = bin[i];
+    if (b < 0 || b == ind1 || b == ind2 || b == ind3) continue;
+    matches12[i] = -1;
+    removed++;
+  }
+  return removed;
+}
+
 
 }  // namespace
 
@@ -416,17 +512,9 @@ extern "C" int orbfe_search_by_bow(orbfe_matcher* m, const uint8_t* desc1, const
   }
   *nmatches = 0;
   for (int i = 0; i < n1; i++) matches12[i] = -1;
-  // common nodes (the lower_bound zig-zag of ORBmatcher.cc:175-258 visits exactly the intersection, in ascending order)
   std::vector<BowPair> pairs;
-  for (int a = 0, b = 0; a < n_fv1 && b < n_fv2;) {
-    if (fv1_nodes[a] == fv2_nodes[b]) {
-      BowPair p = {(int)fv1_offsets[a], (int)fv1_offsets[a + 1], (int)fv2_offsets[b], (int)fv2_offsets[b + 1]};
-      if (p.e2 - p.b2 > kMaxGroup) { set_err("a vocabulary node holds %d features (max %d)", p.e2 - p.b2, kMaxGroup); return ORBFE_ERR_OVERFLOW; }
-      if (p.e1 > p.b1 && p.e2 > p.b2) pairs.push_back(p);
-      a++; b++;
-    } else if (fv1_nodes[a] < fv2_nodes[b]) a++;
-    else b++;
-  }
+  int rc = common_nodes(fv1_nodes, fv1_offsets, n_fv1, fv2_nodes, fv2_offsets, n_fv2, pairs);
+  if (rc) return rc;
   const int nf1 = n_fv1 ? (int)fv1_offsets[n_fv1] : 0, nf2 = n_fv2 ? (int)fv2_offsets[n_fv2] : 0;
   for (int i = 0; i < nf1; i++) if (fv1_features[i] >= (uint32_t)n1) { set_err("fv1 feature index out of range"); return ORBFE_ERR_INVALID; }
   for (int i = 0; i < nf2; i++) if (fv2_features[i] >= (uint32_t)n2) { set_err("fv2 feature index out of range"); return ORBFE_ERR_INVALID; }
@@ -435,7 +523,6 @@ extern "C" int orbfe_search_by_bow(orbfe_matcher* m, const uint8_t* desc1, const
   std::shared_ptr<void>& slot = orbfe::matcher_bow_slot(m);
   if (!slot) slot = std::make_shared<BowScratch>();
   BowScratch* S = static_cast<BowScratch*>(slot.get());
-  int rc;
   if ((rc = S->d_desc1.ensure((size_t)n1 * 2)) || (rc = S->d_desc2.ensure((size_t)n2 * 2)) || (rc = S->d_valid1.ensure(n1)) ||
       (rc = S->d_valid2.ensure(std::max(n2, 1))) || (rc = S->d_feat1.ensure(nf1)) || (rc = S->d_feat2.ensure(nf2)) ||
       (rc = S->d_pairs.ensure(pairs.size())) || (rc = S->d_m12.ensure(n1)) || (rc = S->h_m12.ensure(n1)))
@@ -456,33 +543,77 @@ extern "C" int orbfe_search_by_bow(orbfe_matcher* m, const uint8_t* desc1, const
   HIP_TRY(hipMemcpyAsync(S->h_m12.p, S->d_m12.p, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   int nm = 0;
-  int count[HISTO_LENGTH] = {};
-  std::vector<int8_t> bin(check_orientation ? n1 : 0, -1);
-  const float factor = 1.0f / HISTO_LENGTH;
   for (int i = 0; i < n1; i++) {
-    const int j = S->h_m12.p[i];
-    matches12[i] = j;
-    if (j < 0) continue;
-    nm++;
-    if (check_orientation) {   // ORBmatcher.cc:226-236 / 596-606
-      float rot = angle1[i] - angle2[j];
-      if (rot < 0.0) rot += 360.0f;
-      int b = (int)round(rot * factor);
-      if (b == HISTO_LENGTH) b = 0;
-      if (b < 0 || b >= HISTO_LENGTH) continue;   // the reference asserts; cannot happen for angles in [0,360)
-      bin[i] = (int8_t)b;
-      count[b]++;
-    }
+    matches12[i] = S->h_m12.p[i];
+    if (matches12[i] >= 0) nm++;
   }
-  if (check_orientation) {
-    int ind1 = -1, ind2 = -1, ind3 = -1;
-    three_maxima(count, HISTO_LENGTH, ind1, ind2, ind3);
-    for (int i = 0; i < n1; i++) {
-      const int b = bin[i];
-      if (b < 0 || b == ind1 || b == ind2 || b == ind3) continue;
-      matches12[i] = -1;
-      nm--;
-    }
+  if (check_orientation) nm -= prune_by_orientation(angle1, sizeof(float), angle2, sizeof(float), n1, matches12);
+  *nmatches = nm;
+  return ORBFE_OK;
+}
+
+extern "C" int orbfe_search_for_triangulation(orbfe_matcher* m, const OrbfeKeyPoint* kps1_un, const uint8_t* desc1,
+                                              const uint8_t* has_mp1, int n1, const uint32_t* fv1_nodes,
+                                              const uint32_t* fv1_offsets, const uint32_t* fv1_features, int n_fv1,
+                                              const OrbfeKeyPoint* kps2_un, const uint8_t* desc2, const uint8_t* has_mp2,
+                                              int n2, const uint32_t* fv2_nodes, const uint32_t* fv2_offsets,
+                                              const uint32_t* fv2_features, int n_fv2, const float F12[9], float ex, float ey,
+                                              const float* scale_factors2, const float* level_sigma2_2, int nlevels2,
+                                              int check_orientation, int32_t* pairs_out, int* nmatches) {
+  if (!m || n1 < 0 || n2 < 0 || n_fv1 < 0 || n_fv2 < 0 || !pairs_out || !nmatches || !F12 || !scale_factors2 || !level_sigma2_2 ||
+      nlevels2 < 1 || nlevels2 > 16 || (n1 > 0 && (!kps1_un || !desc1 || !has_mp1)) || (n2 > 0 && (!kps2_un || !desc2 || !has_mp2)) ||
+      (n_fv1 > 0 && (!fv1_nodes || !fv1_offsets || !fv1_features)) || (n_fv2 > 0 && (!fv2_nodes || !fv2_offsets || !fv2_features))) {
+    set_err("bad argument");
+    return ORBFE_ERR_INVALID;
+  }
+  *nmatches = 0;
+  std::vector<BowPair> pairs;
+  int rc = common_nodes(fv1_nodes, fv1_offsets, n_fv1, fv2_nodes, fv2_offsets, n_fv2, pairs);
+  if (rc) return rc;
+  const int nf1 = n_fv1 ? (int)fv1_offsets[n_fv1] : 0, nf2 = n_fv2 ? (int)fv2_offsets[n_fv2] : 0;
+  for (int i = 0; i < nf1; i++) if (fv1_features[i] >= (uint32_t)n1) { set_err("fv1 feature index out of range"); return ORBFE_ERR_INVALID; }
+  for (int i = 0; i < nf2; i++) if (fv2_features[i] >= (uint32_t)n2) { set_err("fv2 feature index out of range"); return ORBFE_ERR_INVALID; }
+  for (int i = 0; i < n2; i++) if (kps2_un[i].octave < 0 || kps2_un[i].octave >= nlevels2) { set_err("keypoint octave out of range"); return ORBFE_ERR_INVALID; }
+  if (pairs.empty()) return ORBFE_OK;
+  HIP_TRY(hipSetDevice(orbfe::matcher_device(m)));
+  std::shared_ptr<void>& slot = orbfe::matcher_bow_slot(m);
+  if (!slot) slot = std::make_shared<BowScratch>();
+  BowScratch* S = static_cast<BowScratch*>(slot.get());
+  if ((rc = S->d_desc1.ensure((size_t)n1 * 2)) || (rc = S->d_desc2.ensure((size_t)n2 * 2)) || (rc = S->d_valid1.ensure(n1)) ||
+      (rc = S->d_valid2.ensure(n2)) || (rc = S->d_feat1.ensure(nf1)) || (rc = S->d_feat2.ensure(nf2)) ||
+      (rc = S->d_pairs.ensure(pairs.size())) || (rc = S->d_m12.ensure(n1)) || (rc = S->h_m12.ensure(n1)) ||
+      (rc = S->d_kps1.ensure(n1)) || (rc = S->d_kps2.ensure(n2)))
+    return rc;
+  hipStream_t st = orbfe::matcher_stream(m);
+  HIP_TRY(hipMemcpyAsync(S->d_kps1.p, kps1_un, sizeof(OrbfeKeyPoint) * n1, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(S->d_kps2.p, kps2_un, sizeof(OrbfeKeyPoint) * n2, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(S->d_desc1.p, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(S->d_desc2.p, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(S->d_valid1.p, has_mp1, n1, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(S->d_valid2.p, has_mp2, n2, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(S->d_feat1.p, fv1_features, sizeof(uint32_t) * nf1, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(S->d_feat2.p, fv2_features, sizeof(uint32_t) * nf2, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(S->d_pairs.p, pairs.data(), sizeof(BowPair) * pairs.size(), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(S->d_m12.p, 0xff, sizeof(int32_t) * n1, st));
+  TriParams T;
+  memcpy(T.F12, F12, sizeof T.F12);
+  T.ex = ex; T.ey = ey;
+  for (int i = 0; i < 16; i++) { T.scale2[i] = scale_factors2[std::min(i, nlevels2 - 1)]; T.sigma2[i] = level_sigma2_2[std::min(i, nlevels2 - 1)]; }
+  hipLaunchKernelGGL(k_bow_triangulate, dim3((unsigned)pairs.size()), dim3(64), 0, st, S->d_kps1.p, S->d_desc1.p, S->d_valid1.p,
+                     S->d_feat1.p, S->d_kps2.p, S->d_desc2.p, S->d_valid2.p, S->d_feat2.p, S->d_pairs.p, T, S->d_m12.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(S->h_m12.p, S->d_m12.p, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  int nm = 0;
+  for (int i = 0; i < n1; i++) if (S->h_m12.p[i] >= 0) nm++;
+  if (check_orientation)
+    nm -= prune_by_orientation(&kps1_un[0].angle, sizeof(OrbfeKeyPoint), &kps2_un[0].angle, sizeof(OrbfeKeyPoint), n1, S->h_m12.p);
+  int np = 0;
+  for (int i = 0; i < n1; i++) {   // vMatchedPairs in ascending idx1 (ORBmatcher.cc:792-800)
+    if (S->h_m12.p[i] < 0) continue;
+    pairs_out[2 * np] = i;
+    pairs_out[2 * np + 1] = S->h_m12.p[i];
+    np++;
   }
   *nmatches = nm;
   return ORBFE_OK;

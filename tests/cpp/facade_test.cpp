@@ -42,8 +42,14 @@ struct Frame {
   static float mnMinX, mnMaxX, mnMinY, mnMaxY;
 };
 float Frame::mnMinX, Frame::mnMaxX, Frame::mnMinY, Frame::mnMaxY;
-struct KeyFrame : Frame {   // the members SearchByBoW reads (KeyFrame.h)
+struct KeyFrame : Frame {   // the members SearchByBoW / SearchForTriangulation read (KeyFrame.h)
+  std::vector<float> mvLevelSigma2;
   std::vector<MapPoint*> GetMapPointMatches() { return mvpMapPoints; }
+  MapPoint* GetMapPoint(size_t i) { return mvpMapPoints[i]; }
+};
+struct Mat33f {   // cv::Mat F12 as far as the shim reads it
+  float v[9];
+  template <class T> T at(int r, int c) const { return v[3 * r + c]; }
 };
 
 static std::vector<unsigned char> readFile(const std::string& p) {
@@ -87,6 +93,7 @@ int main(int argc, char** argv) {
     F[i].N = (int)F[i].mvKeys.size();
     F[i].mvpMapPoints.assign(F[i].mvKeys.size(), nullptr);
     F[i].mvScaleFactors = extractor.GetScaleFactors();
+    F[i].mvLevelSigma2 = extractor.GetScaleSigmaSquares();
     writeFile(dir + "/" + names[i] + ".kps", F[i].mvKeys.data(), F[i].mvKeys.size() * sizeof(KeyPoint));
     writeFile(dir + "/" + names[i] + ".desc", F[i].descStore.data(), F[i].descStore.size());
   }
@@ -120,7 +127,7 @@ int main(int argc, char** argv) {
   writeFile(dir + "/sbp.assigned", assigned.data(), assigned.size() * sizeof(int));
   // Relocalisation / TrackReferenceKeyFrame (Tracking.cc:543-548): ComputeBoW of both, SearchByBoW(KF, F) and the
   // keyframe-keyframe overload (LoopClosing.cc:242).  A and B carry "MapPoints" flagged in <dir>/bow.valid.
-  int nbow1 = -1, nbow2 = -1;
+  int nbow1 = -1, nbow2 = -1, ntri = -1;
   FILE* vf = fopen((dir + "/voc.bin").c_str(), "rb");
   if (vf) {
     fclose(vf);
@@ -153,7 +160,14 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < r2.size(); i++)
       if (vpMatches12[i]) r2[i] = (int)(vpMatches12[i] - own[1].data());
     writeFile(dir + "/bow2.matches", r2.data(), r2.size() * sizeof(int));
+    // LocalMapping::CreateNewMapPoints (LocalMapping.cc:396): F12 = [t]x for the image translation A -> B
+    Mat33f F12 = {{0.f, 0.f, 4e-3f, 0.f, 0.f, 10e-3f, -4e-3f, -10e-3f, 0.f}};
+    std::vector<std::pair<size_t, size_t> > vMatchedPairs;
+    ntri = orbfe::SearchForTriangulation(ctx, true, &F[0], &F[1], F12, 480.f, 270.f, vMatchedPairs);
+    std::vector<int> tp;
+    for (auto& pr : vMatchedPairs) { tp.push_back((int)pr.first); tp.push_back((int)pr.second); }
+    writeFile(dir + "/tri.pairs", tp.data(), tp.size() * sizeof(int));
   }
-  printf("%zu %zu %d %d %d %d\n", F[0].mvKeys.size(), F[1].mvKeys.size(), nm, nsbp, nbow1, nbow2);
+  printf("%zu %zu %d %d %d %d %d\n", F[0].mvKeys.size(), F[1].mvKeys.size(), nm, nsbp, nbow1, nbow2, ntri);
   return 0;
 }

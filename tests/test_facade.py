@@ -81,7 +81,7 @@ def test_facade_matches_oracle(tmp_path, oracle):
     valid.tofile(tmp_path / 'bow.valid')
     out = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
-    n1, n2, nm, nsbp, nbow1, nbow2 = (int(v) for v in out.stdout.split())
+    n1, n2, nm, nsbp, nbow1, nbow2, ntri = (int(v) for v in out.stdout.split())
     gk1 = np.fromfile(tmp_path / 'A.kps', KP_DTYPE)
     gk2 = np.fromfile(tmp_path / 'B.kps', KP_DTYPE)
     assert gk1.tobytes() == k1.tobytes() and gk2.tobytes() == k2.tobytes()
@@ -118,3 +118,8 @@ def test_facade_matches_oracle(tmp_path, oracle):
     assert nbow1 == wn and nbow1 > 20 and (r1 == w21).all()
     wn, w12 = oracle.search_by_bow(d1, k1['angle'], v1, t1[2], d2, k2['angle'], v2, t2[2], 0.75, True)
     assert nbow2 == wn and nbow2 > 20 and (np.fromfile(tmp_path / 'bow2.matches', np.int32) == w12).all()
+    F12 = np.array([0, 0, 4e-3, 0, 0, 10e-3, -4e-3, -10e-3, 0], np.float32)
+    tab = ox.tables()
+    wn, wp = oracle.search_for_triangulation(k1, d1, valid[:len(k1)] != 0, t1[2], k2, d2, valid[len(k1):] != 0, t2[2], F12,
+                                             480.0, 270.0, tab['sf'], tab['s2'], True)
+    assert ntri == wn and ntri > 5 and np.fromfile(tmp_path / 'tri.pairs', np.int32).tobytes() == wp.tobytes()

@@ -92,3 +92,36 @@ def test_search_by_bow_parity(api, oracle, levelsup):
     e = (np.zeros(0, np.uint32), np.zeros(1, np.uint32), np.zeros(0, np.uint32))
     nm, m12 = m.search_by_bow(d1, a1, v1, fv1, np.zeros((0, 32), np.uint8), np.zeros(0, np.float32), None, e)
     assert nm == 0 and (m12 == -1).all()
+
+
+def test_search_for_triangulation_parity(api, oracle):
+    """LocalMapping::CreateNewMapPoints' matcher: two extracted frames related by an image translation t, F12 = [t]x
+    (true correspondences lie on their epipolar lines), an epipole placed inside the image so the epipole-distance
+    test rejects some, random 'already has a MapPoint' flags."""
+    image = synth_vocabulary(2, 10, 4)
+    ov = oracle.vocabulary(image)
+    ex = api.Extractor(1500, 1.2, 8, 20, 7)
+    A = synth(12, 1280, 720)
+    B = shifted(A, -18, 5, 77)
+    (k1, d1), (k2, d2) = ex(A), ex(B)
+    tab = ex.tables()
+    m = api.Matcher()
+    rng = np.random.default_rng(4)
+    total = 0
+    for levelsup, t, epi in [(2, (18.0, -5.0), (600.0, 300.0)), (3, (-18.0, 5.0), (-1e4, 50.0)), (2, (3.0, 40.0), (640.0, 360.0))]:
+        fv1, fv2 = ov.transform(d1, levelsup)[2], ov.transform(d2, levelsup)[2]
+        tx, ty = t
+        F12 = np.array([[0, 0, ty], [0, 0, -tx], [-ty, tx, 0]], np.float32) * np.float32(1e-3)
+        h1 = (rng.random(len(k1)) < 0.3).astype(np.uint8)
+        h2 = (rng.random(len(k2)) < 0.3).astype(np.uint8)
+        for ori in (True, False):
+            nm, pairs = m.search_for_triangulation(k1, d1, h1, fv1, k2, d2, h2, fv2, F12, epi[0], epi[1], tab['sf'],
+                                                   tab['s2'], ori)
+            wn, wp = oracle.search_for_triangulation(k1, d1, h1, fv1, k2, d2, h2, fv2, F12, epi[0], epi[1], tab['sf'],
+                                                     tab['s2'], ori)
+            assert nm == wn and pairs.tobytes() == wp.tobytes()
+            total += nm
+    assert total > 200
+    # zero fundamental matrix: den == 0 everywhere -> nothing matches
+    nm, _ = m.search_for_triangulation(k1, d1, h1, fv1, k2, d2, h2, fv2, np.zeros(9, np.float32), 0.0, 0.0, tab['sf'], tab['s2'])
+    assert nm == 0
