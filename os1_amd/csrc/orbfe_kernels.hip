@@ -247,21 +247,30 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
   // is uniform for the cell, so it is a template constant of the loop body).
   int nq = 0;
   const int G = (ew + 3) >> 2, nItems = G * eh;
-  const float rcpG = 1.0f / (float)G;
+  const int stepY = 64 / G, stepG = 64 - stepY * G;   // item i+64 = (y + stepY, g + stepG) with one carry
   auto stage1 = [&](auto aTag) {
     constexpr int A = decltype(aTag)::value;
+    // The test is CONSERVATIVE (a superset of "two adjacent compass points of one polarity", stage 2 decides
+    // exactly) and runs on the packed bytes as they come out of LDS: a 16-bit lane holds pixels (2j, 2j+1) as
+    // (low byte, high byte).  min/max of such lanes is exact in the high byte, so for the odd pixels
+    //   bright: min(max(r0,r8), max(r4,r12)) > v+t     dark: max(min(r0,r8), min(r4,r12)) < v-t
+    // are evaluated with v_pk_min/max_u16 and saturating add/sub against (v +- t) << 8; the junk low byte can
+    // only turn an exact tie into a pass.  The even pixels take the same path after a packed shift left by 8
+    // (exact).  Pixels beyond the emit width are dropped in stage 2.
+    const u16x2 T2 = as_u16x2((unsigned)tlo * 0x01000100u);
+    int y = (int)(((float)lane + 0.5f) / (float)G), g = lane - m24(y, G);
+    int ro = m24(y, TP) + (g << 2);               // byte offset of (row y, column 4g) in the tile
+    const int roStep = m24(stepY, TP) + (stepG << 2), roCarry = TP - (G << 2);
+    const uint8_t* t0 = tile - A;
     for (int i0 = 0; i0 < nItems; i0 += 64) {
-      const int i = i0 + lane;
       unsigned passBits = 0;
-      int y = 0, x = 0;
-      if (i < nItems) {
-        y = (int)(((float)i + 0.5f) * rcpG);
-        x = (i - m24(y, G)) << 2;
+      const int x = g << 2;
+      if (i0 + lane < nItems) {
         // aligned dword pointer of (row y+3, tile column x): tile already includes the +A shift
-        const uint32_t* cw = reinterpret_cast<const uint32_t*>(tile - A + m24(y + 3, TP) + x);
+        const uint32_t* cw = reinterpret_cast<const uint32_t*>(t0 + 3 * TP + ro);
         const uint32_t w0 = cw[0], w1 = cw[1], w2 = cw[2], w3 = cw[3];
-        const uint32_t* uw = reinterpret_cast<const uint32_t*>(tile - A + m24(y, TP) + x);         // row y-3 (+3 halo)
-        const uint32_t* dw = reinterpret_cast<const uint32_t*>(tile - A + m24(y + 6, TP) + x);   // row y+3
+        const uint32_t* uw = reinterpret_cast<const uint32_t*>(t0 + ro);                    // row y-3 (+3 halo)
+        const uint32_t* dw = reinterpret_cast<const uint32_t*>(t0 + 6 * TP + ro);           // row y+3
         // byte windows: left = bytes [A, A+4), centre/up/down = [A+3, A+7), right = [A+6, A+10) of the row
         const uint32_t L4 = __builtin_amdgcn_alignbyte(w1, w0, A);
         const uint32_t C4 = (A + 3 < 4) ? __builtin_amdgcn_alignbyte(w1, w0, (A + 3) & 3)
@@ -272,39 +281,40 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
                                         : __builtin_amdgcn_alignbyte(uw[2], uw[1], (A + 3) & 3);
         const uint32_t D4 = (A + 3 < 4) ? __builtin_amdgcn_alignbyte(dw[1], dw[0], (A + 3) & 3)
                                         : __builtin_amdgcn_alignbyte(dw[2], dw[1], (A + 3) & 3);
-        // two pixels per instruction: bytes (0,1) and (2,3) of every window become two 16-bit lanes
-        // (v_perm_b32), the compass arithmetic runs on v_pk_add/sub_u16 and plain bitwise ops; the sign
-        // bits of the two lanes (bits 15 and 31) say "two adjacent compass points of one polarity"
-        const unsigned T2 = (unsigned)tlo * 0x10001u;
-        unsigned hit = 0;
+        unsigned flag[2];
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-          const unsigned sel = h ? 0x0c030c02u : 0x0c010c00u;
-          const u16x2 v2 = as_u16x2(__builtin_amdgcn_perm(0u, C4, sel));
-          const u16x2 r0 = as_u16x2(__builtin_amdgcn_perm(0u, D4, sel)), r4 = as_u16x2(__builtin_amdgcn_perm(0u, R4, sel)),
-                      r8 = as_u16x2(__builtin_amdgcn_perm(0u, U4, sel)), r12 = as_u16x2(__builtin_amdgcn_perm(0u, L4, sel));
-          // sign of k* set <=> ring darker than centre by more than tlo; of b* <=> brighter
-          const u16x2 kd = as_u16x2(T2) - v2, kb = v2 + as_u16x2(T2);
-          const unsigned k0 = as_u32(r0 + kd), k4 = as_u32(r4 + kd), k8 = as_u32(r8 + kd), k12 = as_u32(r12 + kd);
-          const unsigned b0 = as_u32(kb - r0), b4 = as_u32(kb - r4), b8 = as_u32(kb - r8), b12 = as_u32(kb - r12);
-          const unsigned e = (k0 & k4) | (k4 & k8) | (k8 & k12) | (k12 & k0) | (b0 & b4) | (b4 & b8) | (b8 & b12) | (b12 & b0);
-          hit |= (((e >> 15) & 1u) | ((e >> 30) & 2u)) << (2 * h);
+        for (int h = 0; h < 2; h++) {   // h = 0: odd pixels (high bytes), h = 1: even pixels (shifted up)
+          const u16x2 v2 = h ? as_u16x2(C4) << 8 : as_u16x2(C4);
+          const u16x2 r0 = h ? as_u16x2(D4) << 8 : as_u16x2(D4), r4 = h ? as_u16x2(R4) << 8 : as_u16x2(R4);
+          const u16x2 r8 = h ? as_u16x2(U4) << 8 : as_u16x2(U4), r12 = h ? as_u16x2(L4) << 8 : as_u16x2(L4);
+          const u16x2 mx = __builtin_elementwise_min(__builtin_elementwise_max(r0, r8), __builtin_elementwise_max(r4, r12));
+          const u16x2 mn = __builtin_elementwise_max(__builtin_elementwise_min(r0, r8), __builtin_elementwise_min(r4, r12));
+          const u16x2 hi = __builtin_elementwise_add_sat(v2, T2), lo = __builtin_elementwise_sub_sat(v2, T2);
+          const unsigned e = as_u32(__builtin_elementwise_sub_sat(mx, hi)) | as_u32(__builtin_elementwise_sub_sat(lo, mn));
+          asm("v_pk_min_u16 %0, %1, %2" : "=v"(flag[h]) : "v"(e), "v"(0x00010001u));   // 1 per passing 16-bit lane
         }
-        const int nvalid = min(4, ew - x);                    // pixels x+j < ew
-        passBits = hit & ((1u << nvalid) - 1u);
+        passBits = flag[1] | (flag[0] << 1);   // bit 0: pixel 0, bit 1: pixel 1, bit 16: pixel 2, bit 17: pixel 3
       }
-      int off = 0, tot = 0;
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const unsigned long long m = __ballot((passBits >> j) & 1u);
-        off += __popcll(m & below);
-        tot += __popcll(m);
-      }
-      int pos = nq + off;
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-        if ((passBits >> j) & 1u) queue[pos++] = (uint16_t)((y << 8) | (x + j));
-      nq += tot;
+      // ordered compaction: inclusive wave scan of the per-lane counts (DPP, 6 adds)
+      const int c = __popc(passBits);
+      int incl = c;
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);   // row_shr:1
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);   // row_shr:2
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);   // row_shr:4
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);   // row_shr:8
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+      int pos = nq + incl - c;
+      const unsigned e = (unsigned)((y << 8) | x);
+      if (passBits & 1u) queue[pos++] = (uint16_t)e;
+      if (passBits & 2u) queue[pos++] = (uint16_t)(e + 1);
+      if (passBits & 0x10000u) queue[pos++] = (uint16_t)(e + 2);
+      if (passBits & 0x20000u) queue[pos++] = (uint16_t)(e + 3);
+      nq += __builtin_amdgcn_readlane(incl, 63);
+      y += stepY;
+      g += stepG;
+      ro += roStep;
+      if (g >= G) { g -= G; y++; ro += roCarry; }
     }
   };
   switch (a) {
@@ -327,10 +337,11 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
       e = queue[i];
       const int y = e >> 8, x = e & 0xff;
       const uint8_t* c = tile + m24(y + 3, TP) + (x + 3);
-      const unsigned vv = (unsigned)c[0] * 0x10001u;
+      const unsigned vv = c[0];
       s16x2 d[16];
-      const s16x2 flip = {1, -1};
-#define RING(k, off) d[k] = (as_s16x2(vv) - as_s16x2((unsigned)c[off] * 0x10001u)) * flip
+      // P = (v, r) in the two 16-bit lanes; one v_pk_sub_i16 with swapped operand halves gives (v - r, r - v)
+#define RING(k, off) { const unsigned P = ((unsigned)c[off] << 16) | vv; unsigned dd; \
+        asm("v_pk_sub_i16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(dd) : "v"(P)); d[k] = as_s16x2(dd); }
       RING(0, 3 * TP);       RING(1, 3 * TP + 1);   RING(2, 2 * TP + 2);    RING(3, TP + 3);
       RING(4, 3);            RING(5, -TP + 3);      RING(6, -2 * TP + 2);   RING(7, -3 * TP + 1);
       RING(8, -3 * TP);      RING(9, -3 * TP - 1);  RING(10, -2 * TP - 2);  RING(11, -TP - 3);
@@ -347,7 +358,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
 #pragma unroll
       for (int k = 0; k < 16; k++) best = __builtin_elementwise_max(best, __builtin_elementwise_min(m8[k], d[(k + 8) & 15]));
       const int S = max((int)best.x, (int)best.y);
-      pass = S > tlo;
+      pass = S > tlo && x < ew;   // stage 1 tests whole 4-pixel groups
       if (pass) sc[m24(y + 1, SP) + (x + 1)] = (uint8_t)(S - 1);  // tlo <= S-1 <= 254
     }
     // the ballot consumes every lane's queue read, so the in-place writes below cannot overtake them
@@ -728,7 +739,7 @@ size_t fast_lds_bytes(const PyramidParams& P) {
     const LevelGeom& L = P.lv[l];
     const size_t TP = (L.wCell + 6 + 3 + 3) & ~3;
     const size_t b = ((TP * (L.hCell + 6) + (size_t)(L.wCell + 2) * (L.hCell + 2) + 3) & ~(size_t)3) +
-                     2 * (size_t)L.wCell * L.hCell;  // tile (+ kept alias) + score tile + u16 queue
+                     2 * (size_t)(L.wCell + 3) * L.hCell;  // tile (+ kept alias) + score tile + u16 queue (whole 4-pixel groups)
     mx = b > mx ? b : mx;
   }
   return (mx + 15) & ~(size_t)15;
