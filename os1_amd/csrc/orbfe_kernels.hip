@@ -22,6 +22,13 @@ namespace orbfe {
 // Index arithmetic of these kernels stays far below 2^23, so every product is a full-rate 24-bit
 // multiply (v_mul_i32_i24 / v_mad_i32_i24) instead of the quarter-rate v_mul_lo_u32 / 64-bit mads.
 __device__ __forceinline__ int m24(int a, int b) { return __mul24(a, b); }
+// v_mul_u32_u24 spelled out: the compiler rewrites __mul24 into a full 32-bit multiply (quarter rate) when it cannot
+// prove the 24-bit range itself; callers guarantee 0 <= a, b < 2^24 and a*b < 2^32
+__device__ __forceinline__ unsigned mulu24(unsigned a, unsigned b) {
+  unsigned r;
+  asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 
 // ------------------------------------------------------------------------------------------------
 // Pyramid: level l <- bilinear(level l-1).  Reference: ComputePyramid, src/ORBextractor.cc:971-996
@@ -50,6 +57,20 @@ __global__ __launch_bounds__(256) void k_resize(PyramidParams P, int level) {
     src = P.slab + (long long)f * P.slabBytes + S.off;
     sstride = S.pitch;
   }
+  const int tid = threadIdx.x;
+  // this thread's 4x4 patch: its 4 column and 4 row coefficient sets are requested first, so that their latency
+  // overlaps the staging of the source tile
+  const int cx = tx0 + (tid & 15) * 4, cy = ty0 + (tid >> 4) * 4;
+  int sx[4], syv[4];
+  int al[4], be[4];   // (a0, a1) / (b0, b1) as two shorts
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int x = min(cx + i, D.w - 1), y = min(cy + i, D.h - 1);
+    sx[i] = D.xofs[x];
+    al[i] = reinterpret_cast<const int*>(D.xalpha)[x];
+    syv[i] = D.yofs[y];
+    be[i] = reinterpret_cast<const int*>(D.ybeta)[y];
+  }
   // source footprint of the tile
   const int rx0 = D.xofs[tx0], rx1 = min(D.xofs[tx1] + 1, S.w - 1);
   const int ry0 = min(max(D.yofs[ty0], 0), S.h - 1), ry1 = min(max(D.yofs[ty1] + 1, 0), S.h - 1);
@@ -58,7 +79,6 @@ __global__ __launch_bounds__(256) void k_resize(PyramidParams P, int level) {
   const int istr = (int)sstride;
   const uint8_t* rbase = src + (long long)ry0 * sstride + rx0;
   const int a = (int)(reinterpret_cast<uintptr_t>(rbase) & 3);
-  const int tid = threadIdx.x;
   if ((sstride & 3) == 0) {
     // thread (c, r0) = (tid % 32, tid / 32) copies dword column c of rows r0, r0+8, ...: plain adds, no
     // per-element index arithmetic; 4 loads are issued before the first LDS write
@@ -88,33 +108,28 @@ __global__ __launch_bounds__(256) void k_resize(PyramidParams P, int level) {
   __syncthreads();
   const uint8_t* tile = rz + a - rx0;  // tile[(sy - ry0) * LP + sx] is source pixel (sx, sy)
 
-  const int cx = tx0 + (tid & 15) * 4, cy = ty0 + (tid >> 4) * 4;   // this thread's 4x4 patch
   if (cx > tx1 || cy > ty1) return;
-  int sx[4], sx1[4], a0[4], a1[4];
+  int sx1[4];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int x = min(cx + i, D.w - 1);
-    sx[i] = D.xofs[x];
-    sx1[i] = min(sx[i] + 1, S.w - 1);  // a1 == 0 whenever sx+1 is out of range
-    a0[i] = D.xalpha[2 * x];
-    a1[i] = D.xalpha[2 * x + 1];
-  }
+  for (int i = 0; i < 4; i++) sx1[i] = min(sx[i] + 1, S.w - 1);  // a1 == 0 whenever sx+1 is out of range
   uint8_t* dst = P.slab + (long long)f * P.slabBytes + D.off;
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int y = cy + j;
     if (y > ty1) break;
-    const int sy = D.yofs[y];
+    const int sy = syv[j];
     const int sy0 = min(max(sy, 0), S.h - 1) - ry0, sy1 = min(max(sy + 1, 0), S.h - 1) - ry0;
-    const int b0 = D.ybeta[2 * y], b1 = D.ybeta[2 * y + 1];
+    const int b0 = (short)be[j], b1 = be[j] >> 16;
     const uint8_t* r0 = tile + m24(sy0, LP);
     const uint8_t* r1 = tile + m24(sy1, LP);
     uint32_t packed = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const int h0 = m24(r0[sx[i]], a0[i]) + m24(r0[sx1[i]], a1[i]);
-      const int h1 = m24(r1[sx[i]], a0[i]) + m24(r1[sx1[i]], a1[i]);
-      const int v = (((m24(b0, h0 >> 4)) >> 16) + ((m24(b1, h1 >> 4)) >> 16) + 2) >> 2;
+      const int a0 = (short)al[i], a1 = al[i] >> 16;
+      const int h0 = m24(r0[sx[i]], a0) + m24(r0[sx1[i]], a1);
+      const int h1 = m24(r1[sx[i]], a0) + m24(r1[sx1[i]], a1);
+      // b <= 2048, h >> 4 <= 32640: the products fit 27 bits
+      const int v = (int)((mulu24((unsigned)b0, (unsigned)h0 >> 4) >> 16) + (mulu24((unsigned)b1, (unsigned)h1 >> 4) >> 16) + 2) >> 2;
       packed |= (uint32_t)(v & 255) << (8 * i);
     }
     *reinterpret_cast<uint32_t*>(dst + m24(y, D.pitch) + cx) = packed;  // pitch % 64 == 0: in bounds
