@@ -513,30 +513,59 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 
 constexpr int kRawW = 2 * kRawRad + 1;   // 43
 constexpr int kBlurW = 2 * kBlurRad + 1; // 37
-constexpr int kRawP = 48, kHP = 38, kBP = 40;   // raw pitch holds alignment offset (<=3) + 43 bytes
+constexpr int kRawP = 48;    // raw pitch (bytes): alignment offset (<= 3) + 43 pixels
+constexpr int kHPT = 50;     // pitch (u16) of the TRANSPOSED horizontal-pass image hbT[x][y]: y <= 45 is read, even, and
+                             // 4 rows apart (the 4 outputs of one lane) land in different LDS banks
+constexpr int kBPT = 40;     // pitch (bytes) of the TRANSPOSED blurred patch blT[x][y]
 
-// (u, v) offsets of the circular IC-angle patch, rows v = -15..15, |u| <= umax[|v|] (749 entries;
-// umax from ORBextractor.cc:486-501 equals floor(sqrt(240 - v*v)), checked by static_assert below)
+// IC-angle over the circular patch of radius 15 (rows v = -15..15, |u| <= umax[|v|], 749 pixels; umax from
+// ORBextractor.cc:486-501 equals floor(sqrt(240 - v*v)), checked by the static_assert below).  The patch is
+// walked as 31 rows x 8 dwords (u + 15 = 4k + j); per dword three byte-weight words feed v_dot4_u32_u8:
+//   w1 = inside ? 1 : 0,   w2 = inside ? u + 15 : 0,   w3 = inside ? v + 15 : 0
+// so that m10 = sum(w2 . I) - 15 sum(w1 . I) and m01 = sum(w3 . I) - 15 sum(w1 . I).
 constexpr int kIcCount = 749;
-struct IcTab { uint16_t e[kIcCount + 3]; };
+constexpr int kIcItems = 31 * 8;
+struct IcW { uint32_t w1, w2, w3, pad; };
+struct IcTab { IcW e[kIcItems]; };
 constexpr IcTab make_ic_tab() {
   IcTab t{};
   const int um[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
-  int n = 0;
-  for (int v = -15; v <= 15; v++) {
-    const int d = um[v < 0 ? -v : v];
-    for (int u = -d; u <= d; u++) t.e[n++] = (uint16_t)(((unsigned)(uint8_t)(int8_t)u) | (((unsigned)(uint8_t)(int8_t)v) << 8));
+  for (int r = 0; r < 31; r++) {
+    const int v = r - 15, d = um[v < 0 ? -v : v];
+    for (int k = 0; k < 8; k++) {
+      uint32_t w1 = 0, w2 = 0, w3 = 0;
+      for (int j = 0; j < 4; j++) {
+        const int u = 4 * k + j - 15;
+        if (u >= -d && u <= d) {
+          w1 |= 1u << (8 * j);
+          w2 |= (uint32_t)(u + 15) << (8 * j);
+          w3 |= (uint32_t)(v + 15) << (8 * j);
+        }
+      }
+      t.e[r * 8 + k] = IcW{w1, w2, w3, 0};
+    }
   }
   return t;
 }
 constexpr int ic_count() {
-  const int um[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
-  int n = 2 * um[0] + 1;
-  for (int v = 1; v <= 15; v++) n += 2 * (2 * um[v] + 1);
+  const IcTab t = make_ic_tab();
+  int n = 0;
+  for (int i = 0; i < kIcItems; i++)
+    for (int j = 0; j < 4; j++) n += (t.e[i].w1 >> (8 * j)) & 1;
   return n;
 }
 static_assert(ic_count() == kIcCount, "circular patch must have 749 pixels");
 __constant__ IcTab c_icTab = make_ic_tab();
+
+// sum over the wave (wave-uniform result): DPP row rotations, then one value per row of 16 lanes
+__device__ __forceinline__ int wave_sum_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false);   // row_ror:8
+  v += __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xf, false);   // row_ror:4
+  v += __builtin_amdgcn_update_dpp(v, v, 0x122, 0xf, 0xf, false);   // row_ror:2
+  v += __builtin_amdgcn_update_dpp(v, v, 0x121, 0xf, 0xf, false);   // row_ror:1
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+         __builtin_amdgcn_readlane(v, 48);
+}
 
 // Slot mode (GPU quadtree): `sel` is laid out [frame][selPerFrame] with per-level sub-regions; slot k is
 // live iff its index inside its level region is below selCount[frame][level].  Dense mode (host
@@ -551,9 +580,9 @@ struct SlotInfo {
 __global__ __launch_bounds__(64) void k_describe(PyramidParams P, const SelKp* __restrict__ sel, int nsel,
                                                   float* __restrict__ angleOut, uint8_t* __restrict__ descOut,
                                                   SlotInfo SI) {
-  __shared__ __align__(16) uint8_t raw[kRawW * kRawP];
-  __shared__ __align__(16) uint16_t hb[kRawW * kHP];
-  __shared__ __align__(16) uint8_t bl[kBlurW * kBP];
+  __shared__ __align__(16) uint8_t raw[kRawW * kRawP + 16];   // + 16: the last row's 4-dword reads
+  __shared__ __align__(16) uint16_t hbT[40 * kHPT];            // horizontal pass, transposed: hbT[x][y]
+  __shared__ __align__(16) uint8_t blT[kBlurW * kBPT];         // blurred 37x37 patch, transposed: blT[x][y]
   const int k = blockIdx.x;
   if (k >= nsel) return;
   if (SI.selCount) {
@@ -623,52 +652,89 @@ __global__ __launch_bounds__(64) void k_describe(PyramidParams P, const SelKp* _
     }
   }
   __syncthreads();
-  const uint8_t* rawp = raw + pa;  // raw pixel (x, y) of the 43x43 patch lives at rawp[y * kRawP + x]
+  // raw pixel (x, y) of the 43x43 patch lives at raw[y * kRawP + pa + x]
 
-  // IC-angle moments over the circular patch of radius 15: the 749 (u, v) offsets come from a table
-  int m10 = 0, m01 = 0;
-  for (int i = lane; i < kIcCount; i += 64) {
-    const int uv = c_icTab.e[i];
-    const int u = (int)(int8_t)(uv & 0xff), v = (int)(int8_t)(uv >> 8);
-    const int I = rawp[m24(kRawRad + v, kRawP) + kRawRad + u];
-    m10 += m24(u, I);
-    m01 += m24(v, I);
-  }
+  // IC-angle moments (ORBextractor.cc:86-113) of the UNBLURRED patch: 31 rows x 8 dwords, three v_dot4_u32_u8 each
+  const int sIc = (pa + 6) & 3, qIc = (pa + 6) & ~3;   // patch column u = -15 is raw byte pa + 6 of a row
+  int S1 = 0, S2 = 0, S3 = 0;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    m10 += __shfl_xor(m10, o, 64);
-    m01 += __shfl_xor(m01, o, 64);
+  for (int it = 0; it < kIcItems / 64 + 1; it++) {
+    const int i = it * 64 + lane;
+    if (i < kIcItems) {
+      const int r = i >> 3, kk = i & 7;
+      const uint32_t* rp = reinterpret_cast<const uint32_t*>(raw + m24(r + (kRawRad - 15), kRawP) + qIc + 4 * kk);
+      const uint32_t e = __builtin_amdgcn_alignbyte(rp[1], rp[0], sIc);
+      const IcW w = c_icTab.e[i];
+      S1 = (int)__builtin_amdgcn_udot4(e, w.w1, (unsigned)S1, false);
+      S2 = (int)__builtin_amdgcn_udot4(e, w.w2, (unsigned)S2, false);
+      S3 = (int)__builtin_amdgcn_udot4(e, w.w3, (unsigned)S3, false);
+    }
   }
+  S1 = wave_sum_i32(S1);
+  S2 = wave_sum_i32(S2);
+  S3 = wave_sum_i32(S3);
+  const int m10 = S2 - 15 * S1, m01 = S3 - 15 * S1;
   const float angle = fast_atan2_deg((float)m01, (float)m10);
 
-  // horizontal 7-tap on the 43 rows x 37 columns that feed the 37x37 output
-  for (int i = lane; i < kRawW * kBlurW; i += 64) {
-    const int y = i / kBlurW, x = i - y * kBlurW;
-    const uint8_t* r = rawp + y * kRawP + x;
-    hb[y * kHP + x] = (uint16_t)(18 * (r[0] + r[6]) + 34 * (r[1] + r[5]) + 48 * (r[2] + r[4]) + 56 * r[3]);
+  // GaussianBlur 7x7, sigma 2 (ORBextractor.cc:950) in OpenCV's 8.8 fixed point, kernel [18,34,48,56,48,34,18]/256:
+  // exact integer sums with one rounding at the end, so the two passes commute.  Horizontal pass on the raw bytes with
+  // v_dot4_u32_u8, 4 outputs per lane, written TRANSPOSED as u16 so that the vertical pass finds vertically adjacent
+  // taps in one dword and runs on v_dot2_u32_u16 (4 outputs per lane, one dword store into the transposed patch).
+  {
+    const unsigned K0 = 0x38302212u, K1 = 0x00122230u;   // taps 0..3 and 4..6 as bytes
+    for (int i = lane; i < kRawW * 10; i += 64) {
+      const int y = (int)(mulu24((unsigned)i, 205u) >> 11), g = i - y * 10;   // i / 10 for i < 1029
+      const uint32_t* rp = reinterpret_cast<const uint32_t*>(raw + m24(y, kRawP) + 4 * g);
+      const uint32_t d0 = rp[0], d1 = rp[1], d2 = rp[2], d3 = rp[3];
+      const uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, pa), a1 = __builtin_amdgcn_alignbyte(d2, d1, pa),
+                     a2 = __builtin_amdgcn_alignbyte(d3, d2, pa);   // raw pixels 4g .. 4g+11 of row y
+      uint16_t* o = hbT + m24(4 * g, kHPT) + y;
+      o[0] = (uint16_t)__builtin_amdgcn_udot4(a1, K1, __builtin_amdgcn_udot4(a0, K0, 0u, false), false);
+#pragma unroll
+      for (int j = 1; j < 4; j++) {
+        const uint32_t lo = __builtin_amdgcn_alignbyte(a1, a0, j), hi = __builtin_amdgcn_alignbyte(a2, a1, j);
+        o[j * kHPT] = (uint16_t)__builtin_amdgcn_udot4(hi, K1, __builtin_amdgcn_udot4(lo, K0, 0u, false), false);
+      }
+    }
   }
   __syncthreads();
-  for (int i = lane; i < kBlurW * kBlurW; i += 64) {
-    const int y = i / kBlurW, x = i - y * kBlurW;
-    const uint16_t* c = hb + y * kHP + x;
-    const uint32_t acc = 18u * (c[0] + c[6 * kHP]) + 34u * (c[kHP] + c[5 * kHP]) + 48u * (c[2 * kHP] + c[4 * kHP]) +
-                         56u * c[3 * kHP];
-    bl[y * kBP + x] = (uint8_t)((acc + 32768u) >> 16);
+  {
+    // (lo, hi) tap pairs for an output whose first tap is the LOW half of p0 (even) or the HIGH half (odd)
+    const u16x2 E0 = {18, 34}, E1 = {48, 56}, E2 = {48, 34}, E3 = {18, 0};
+    const u16x2 O0 = {0, 18}, O1 = {34, 48}, O2 = {56, 48}, O3 = {34, 18};
+    for (int i = lane; i < kBlurW * 10; i += 64) {
+      const int x = (int)(mulu24((unsigned)i, 205u) >> 11), yq = i - x * 10;
+      const uint32_t* cp = reinterpret_cast<const uint32_t*>(hbT + m24(x, kHPT) + 4 * yq);
+      u16x2 p[5];
+#pragma unroll
+      for (int t = 0; t < 5; t++) p[t] = as_u16x2(cp[t]);   // rows 4yq .. 4yq+9 of column x
+      uint32_t packed = 0;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        unsigned e = 32768u, o = 32768u;
+        e = __builtin_amdgcn_udot2(p[h], E0, e, false);     o = __builtin_amdgcn_udot2(p[h], O0, o, false);
+        e = __builtin_amdgcn_udot2(p[h + 1], E1, e, false); o = __builtin_amdgcn_udot2(p[h + 1], O1, o, false);
+        e = __builtin_amdgcn_udot2(p[h + 2], E2, e, false); o = __builtin_amdgcn_udot2(p[h + 2], O2, o, false);
+        e = __builtin_amdgcn_udot2(p[h + 3], E3, e, false); o = __builtin_amdgcn_udot2(p[h + 3], O3, o, false);
+        packed |= ((e >> 16) | ((o >> 16) << 8)) << (16 * h);
+      }
+      *reinterpret_cast<uint32_t*>(blT + m24(x, kBPT) + 4 * yq) = packed;   // rows 37..39 are padding
+    }
   }
   __syncthreads();
 
   const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
   float a, b;
   sincosf_glibc(angle * factorPI, &b, &a);  // a = cos, b = sin
-  const uint8_t* center = bl + kBlurRad * kBP + kBlurRad;
+  const uint8_t* center = blT + kBlurRad * kBPT + kBlurRad;   // center[x * kBPT + y]
   unsigned long long words[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int bit = j * 64 + lane;
     const int8_t* p = &c_pattern[4 * bit];
     const float x1 = (float)p[0], y1 = (float)p[1], x2 = (float)p[2], y2 = (float)p[3];
-    const int t0 = center[__float2int_rn(x1 * b + y1 * a) * kBP + __float2int_rn(x1 * a - y1 * b)];
-    const int t1 = center[__float2int_rn(x2 * b + y2 * a) * kBP + __float2int_rn(x2 * a - y2 * b)];
+    const int t0 = center[__float2int_rn(x1 * a - y1 * b) * kBPT + __float2int_rn(x1 * b + y1 * a)];
+    const int t1 = center[__float2int_rn(x2 * a - y2 * b) * kBPT + __float2int_rn(x2 * b + y2 * a)];
     words[j] = __ballot(t0 < t1);
   }
   if (lane < 4) reinterpret_cast<unsigned long long*>(descOut + (long long)k * 32)[lane] = words[lane];
