@@ -39,7 +39,7 @@ def main():
     ap.add_argument('--no-match', action='store_true', help='extract only (configs[1])')
     ap.add_argument('--host-input', nargs='?', const='pageable', default=None, choices=['pageable', 'pinned'],
                     help='frames start in HOST memory, pageable or page-locked (PCIe-inclusive rate; never the headline value)')
-    ap.add_argument('--depth', type=int, default=2, help='extraction batches in flight inside the stream runner')
+    ap.add_argument('--depth', type=int, default=3, help='extraction batches in flight inside the stream runner')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))

@@ -141,6 +141,23 @@ static UploadLane* upload_lane(int device) {
   return lanes[device];
 }
 
+// Per device, the VALU-bound front of every batch (colour conversion, pyramid, FAST, candidate compaction) is chained
+// across extractor handles in submission order: batch k+1's front starts when batch k's front is done, so it runs
+// beside batch k's latency-bound tail (quadtree, descriptors, matching, D2H) instead of beside another front.  Without
+// the chain two handles drift into lock-step: both fronts share the CUs, then both tails leave them idle.
+struct FrontLane {
+  std::mutex mu;
+  hipEvent_t last = nullptr;   // recorded after the most recently submitted front (owned by that handle)
+};
+static FrontLane* front_lane(int device) {
+  static std::mutex mu;
+  static FrontLane* lanes[64] = {};
+  if (device < 0 || device >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!lanes[device]) lanes[device] = new FrontLane;   // lives for the process
+  return lanes[device];
+}
+
 struct orbfe_extractor {
   int nfeatures, nlevels, iniTh, minTh, device;
   double scaleFactor;  // the reference keeps the float ctor argument in a double member (ORBextractor.h:313)
@@ -151,6 +168,8 @@ struct orbfe_extractor {
   hipStream_t streams[kMaxSub] = {};
   int subBatches = 4;
   hipEvent_t evUpload = nullptr;
+  hipEvent_t evFront = nullptr;   // end of this handle's last front (FrontLane)
+  bool frontLane = true;          // ORBFE_FRONT_LANE=0 disables the chaining
   hipEvent_t evFrame0 = nullptr, evS1[kMaxSub] = {};
   int subSel[kMaxSub] = {};
   size_t candHostCap = 0;
@@ -233,6 +252,13 @@ struct orbfe_extractor {
     d_nodesA.release(); d_nodesB.release();
     if (evFrame0) (void)hipEventDestroy(evFrame0);
     if (evUpload) (void)hipEventDestroy(evUpload);
+    if (evFront) {
+      if (FrontLane* fl = front_lane(device)) {
+        std::lock_guard<std::mutex> lk(fl->mu);
+        if (fl->last == evFront) fl->last = nullptr;
+      }
+      (void)hipEventDestroy(evFront);
+    }
     for (auto& st : streams) if (st) (void)hipStreamDestroy(st);
   }
 
@@ -362,6 +388,12 @@ struct orbfe_extractor {
     rows = r;
     cols = c;
     batchCap = 0;
+    return ORBFE_OK;
+  }
+
+  int ensureSubStreams(int nsub) {
+    for (int s = 1; s < nsub; s++)
+      if (!streams[s]) HIP_TRY(hipStreamCreateWithFlags(&streams[s], hipStreamNonBlocking));
     return ORBFE_OK;
   }
 
@@ -510,13 +542,25 @@ struct orbfe_extractor {
       launch_to_gray(d_frame0.p + nframes, rawStride, d_frame0.p, grayPitch, r, c, ch, coef, q15 ? 15 : 14, rawAligned, nframes, st);
     }
     const bool prof = profileKernels;
-    if (prof) HIP_TRY(hipEventRecord(ev[0][0], st));
-    launch_pyramid(P, nframes, st);
-    HIP_TRY(hipEventRecord(ev[0][1], st));   // the dominant kernel is always timed (bench.py roofline)
-    launch_fast(P, nframes, st);
-    HIP_TRY(hipEventRecord(ev[0][2], st));
-    launch_compact(P, nframes, st);
-    if (prof) HIP_TRY(hipEventRecord(ev[0][3], st));
+    {
+      FrontLane* fl = frontLane ? front_lane(device) : nullptr;
+      std::unique_lock<std::mutex> lk;
+      if (fl) {
+        lk = std::unique_lock<std::mutex>(fl->mu);
+        if (fl->last && fl->last != evFront) HIP_TRY(hipStreamWaitEvent(st, fl->last, 0));
+      }
+      if (prof) HIP_TRY(hipEventRecord(ev[0][0], st));
+      launch_pyramid(P, nframes, st);
+      HIP_TRY(hipEventRecord(ev[0][1], st));   // the dominant kernel is always timed (bench.py roofline)
+      launch_fast(P, nframes, st);
+      HIP_TRY(hipEventRecord(ev[0][2], st));
+      launch_compact(P, nframes, st);
+      if (prof) HIP_TRY(hipEventRecord(ev[0][3], st));
+      if (fl) {
+        HIP_TRY(hipEventRecord(evFront, st));
+        fl->last = evFront;
+      }
+    }
     QP.cand = d_cand.p; QP.levelStart = d_levelStart.p; QP.candCap = P.candCap; QP.nlevels = nlevels; QP.frameBase = 0;
     QP.idxA = d_idxA.p; QP.idxB = d_idxB.p; QP.ownA = d_ownA.p; QP.ownB = d_ownB.p; QP.rank = d_rank.p;
     QP.nodesA = d_nodesA.p; QP.nodesB = d_nodesB.p;
@@ -683,6 +727,7 @@ struct orbfe_extractor {
     if (inChannels() != 1) { set_err("colour input needs the GPU quadtree path (unset ORBFE_HOST_QUADTREE)"); return ORBFE_ERR_INVALID; }
     const int nsub = std::min(nframes, std::min(kMaxSub, std::max(1, subBatches)));
     const int maxKp = nfeatures + 2 * nlevels;
+    if ((rc = ensureSubStreams(nsub))) return rc;
     int subF0[kMaxSub + 1];
     for (int s = 0; s <= nsub; s++) subF0[s] = (int)((long long)nframes * s / nsub);
 
@@ -956,8 +1001,11 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
     nDesired *= factor;
   }
   h->nfeat[nlevels - 1] = nfeatures - sum > 0 ? nfeatures - sum : 0;
-  for (auto& st : h->streams) {
-    hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+  // One HIP stream per handle.  The runtime multiplexes streams onto a few hardware queues (4 by default) and two
+  // streams on one queue serialise, so nothing is created that the chosen path does not use: the extra streams of the
+  // host-quadtree path appear on its first call (ensureSubStreams), the quadtree stream only with ORBFE_QT_STREAM=1.
+  {
+    hipError_t e = hipStreamCreateWithFlags(&h->streams[0], hipStreamNonBlocking);
     if (e != hipSuccess) {
       set_err("hipStreamCreate failed: %s", hipGetErrorString(e));
       delete h;
@@ -966,7 +1014,8 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
   }
   h->stream = h->streams[0];
   bool evOk = hipEventCreate(&h->evFrame0) == hipSuccess &&
-              hipEventCreateWithFlags(&h->evUpload, hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&h->evUpload, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&h->evFront, hipEventDisableTiming) == hipSuccess;
   for (auto& e : h->evS1) evOk = evOk && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
   for (auto& es : h->ev) for (auto& e : es) evOk = evOk && hipEventCreate(&e) == hipSuccess;
   if (!evOk) { set_err("hipEventCreate failed"); delete h; return ORBFE_ERR_HIP; }
@@ -977,7 +1026,8 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     if (const char* qv = getenv("ORBFE_QT_STREAM")) h->qtOwnStream = atoi(qv) != 0;
-    evOk = hipStreamCreateWithPriority(&h->qtStream, hipStreamNonBlocking, greatest) == hipSuccess &&
+    if (const char* fv = getenv("ORBFE_FRONT_LANE")) h->frontLane = atoi(fv) != 0;
+    evOk = (!h->qtOwnStream || hipStreamCreateWithPriority(&h->qtStream, hipStreamNonBlocking, greatest) == hipSuccess) &&
            hipEventCreateWithFlags(&h->evQtIn, hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&h->evQtOut, hipEventDisableTiming) == hipSuccess;
     if (!evOk) { set_err("creating the quadtree stream failed"); delete h; return ORBFE_ERR_HIP; }

@@ -238,8 +238,14 @@ int orbfe_stream_create(int nfeatures, float scaleFactor, int nlevels, int iniTh
     }
     s->ext.push_back(h);
   }
-  int nMatch = 2;   // SearchForInitialization workers (batches are independent once extracted)
-  if (const char* ev = getenv("ORBFE_MATCH_WORKERS")) nMatch = std::max(1, std::min(4, atoi(ev)));
+  if (const char* hv = getenv("ORBFE_STREAM_HOST_MATCH")) s->gpuMatch = atoi(hv) == 0;
+  // host-side matching path only: SearchForInitialization workers, each with its own matcher (and HIP stream; streams
+  // are not created unless used, because the runtime folds them onto a handful of hardware queues)
+  int nMatch = 0;
+  if (!s->gpuMatch) {
+    nMatch = 2;
+    if (const char* ev = getenv("ORBFE_MATCH_WORKERS")) nMatch = std::max(1, std::min(4, atoi(ev)));
+  }
   for (int w = 0; w < nMatch; w++) {
     orbfe_matcher* mm = nullptr;
     int rc = orbfe_matcher_create(device_id, &mm);
@@ -251,7 +257,6 @@ int orbfe_stream_create(int nfeatures, float scaleFactor, int nlevels, int iniTh
     }
     s->matchers.push_back(mm);
   }
-  if (const char* hv = getenv("ORBFE_STREAM_HOST_MATCH")) s->gpuMatch = atoi(hv) == 0;
   {
     int rc = orbfe_sfi_chain_create(s->ext[0], &s->chain);
     if (rc != ORBFE_OK) {
