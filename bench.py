@@ -35,7 +35,7 @@ def main():
     ap.add_argument('--steps', type=int, default=60)
     ap.add_argument('--warmup', type=int, default=6)
     ap.add_argument('--batch', type=int, default=32, help='frames per step and GPU')
-    ap.add_argument('--cpu-frames', type=int, default=24, help='frames of the CPU-oracle baseline sample (0 = skip)')
+    ap.add_argument('--cpu-frames', type=int, default=64, help='frames of the CPU-oracle baseline sample (0 = skip)')
     ap.add_argument('--no-match', action='store_true', help='extract only (configs[1])')
     ap.add_argument('--host-input', nargs='?', const='pageable', default=None, choices=['pageable', 'pinned'],
                     help='frames start in HOST memory, pageable or page-locked (PCIe-inclusive rate; never the headline value)')
