@@ -188,13 +188,12 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
     img = P.slab + (long long)f * P.slabBytes + L.off;
     stride = L.pitch;
   }
-  // LDS carve: ROI tile, score tile with a zero ring, queue (y<<8|x), kept score per queue entry
+  // LDS carve: ROI tile, score tile with a zero ring, queue (y<<8|x)
   const int TP = (L.wCell + 6 + 3 + 3) & ~3;
   const int SP = L.wCell + 2;
   uint8_t* tile = lds;
   uint8_t* sc = tile + TP * (L.hCell + 6);
   uint16_t* queue = reinterpret_cast<uint16_t*>(lds + ((TP * (L.hCell + 6) + SP * (L.hCell + 2) + 3) & ~3));
-  uint8_t* kept = lds;  // stage 3 only: aliases the ROI tile, which is dead after stage 2 (TP*(hCell+6) >= wCell*hCell)
 
   const int rw = ew + 6, rh = eh + 6;
   const int istr = (int)stride;
@@ -254,14 +253,20 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
   }
   __syncthreads();
 
-  const int tlo = min(P.iniTh, P.minTh);
   const unsigned long long below = (1ull << lane) - 1ull;
+  uint32_t* slot = P.slots + (long long)f * P.slotsPerFrame + ci.slotOff;
+  int base = 0;
+  // Two passes at most, like the reference (ORBextractor.cc:846-856): cv::FAST at iniThFAST; only if that leaves the
+  // cell without a keypoint (after NMS), cv::FAST again at minThFAST.  The threshold decides how many pixels survive
+  // the pre-test, so the common first pass touches a fraction of what a combined low-threshold pass would.
+  for (int pass = 0; pass < 2; pass++) {
+  const int tlo = pass ? P.minTh : P.iniTh;
   // ---- stage 1: compass pre-test, 4 horizontally adjacent pixels per lane -------------------------
   // Lane item i = (row y, group g): pixels x = 4g..4g+3.  The 10 centre-row bytes and the 4 bytes of rows
   // y-3 / y+3 come from aligned LDS dwords and one funnel shift each (the byte alignment `a` of the ROI
   // is uniform for the cell, so it is a template constant of the loop body).
   int nq = 0;
-  const int G = (ew + 3) >> 2, nItems = G * eh;
+  const int G = (ew + 7) >> 3, nItems = G * eh;      // lane item = (row y, group g): pixels x = 8g .. 8g+7
   const int stepY = 64 / G, stepG = 64 - stepY * G;   // item i+64 = (y + stepY, g + stepG) with one carry
   auto stage1 = [&](auto aTag) {
     constexpr int A = decltype(aTag)::value;
@@ -273,45 +278,49 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
     // only turn an exact tie into a pass.  The even pixels take the same path after a packed shift left by 8
     // (exact).  Pixels beyond the emit width are dropped in stage 2.
     const u16x2 T2 = as_u16x2((unsigned)tlo * 0x01000100u);
+    // bits 0, 1, 16, 17 of the result = pixels 0, 1, 2, 3 of the 4-pixel windows (L = left, C = centre, ...)
+    auto test4 = [&](uint32_t L4, uint32_t C4, uint32_t R4, uint32_t U4, uint32_t D4) -> unsigned {
+      unsigned flag[2];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {   // h = 0: odd pixels (high bytes), h = 1: even pixels (shifted up)
+        const u16x2 v2 = h ? as_u16x2(C4) << 8 : as_u16x2(C4);
+        const u16x2 r0 = h ? as_u16x2(D4) << 8 : as_u16x2(D4), r4 = h ? as_u16x2(R4) << 8 : as_u16x2(R4);
+        const u16x2 r8 = h ? as_u16x2(U4) << 8 : as_u16x2(U4), r12 = h ? as_u16x2(L4) << 8 : as_u16x2(L4);
+        const u16x2 mx = __builtin_elementwise_min(__builtin_elementwise_max(r0, r8), __builtin_elementwise_max(r4, r12));
+        const u16x2 mn = __builtin_elementwise_max(__builtin_elementwise_min(r0, r8), __builtin_elementwise_min(r4, r12));
+        const u16x2 hi = __builtin_elementwise_add_sat(v2, T2), lo = __builtin_elementwise_sub_sat(v2, T2);
+        const unsigned e = as_u32(__builtin_elementwise_sub_sat(mx, hi)) | as_u32(__builtin_elementwise_sub_sat(lo, mn));
+        asm("v_pk_min_u16 %0, %1, %2" : "=v"(flag[h]) : "v"(e), "v"(0x00010001u));   // 1 per passing 16-bit lane
+      }
+      return flag[1] | (flag[0] << 1);
+    };
     int y = (int)(((float)lane + 0.5f) / (float)G), g = lane - m24(y, G);
-    int ro = m24(y, TP) + (g << 2);               // byte offset of (row y, column 4g) in the tile
-    const int roStep = m24(stepY, TP) + (stepG << 2), roCarry = TP - (G << 2);
+    int ro = m24(y, TP) + (g << 3);               // byte offset of (row y, column 8g) in the tile
+    const int roStep = m24(stepY, TP) + (stepG << 3), roCarry = TP - (G << 3);
     const uint8_t* t0 = tile - A;
     for (int i0 = 0; i0 < nItems; i0 += 64) {
-      unsigned passBits = 0;
-      const int x = g << 2;
+      unsigned pb0 = 0, pb1 = 0;   // pixels 0..3 and 4..7
+      const int x = g << 3;
       if (i0 + lane < nItems) {
-        // aligned dword pointer of (row y+3, tile column x): tile already includes the +A shift
+        // aligned dwords of (row y+3, tile column x): tile already includes the +A shift.  Byte windows of a row:
+        // left = bytes [A, A+8), centre / up / down = [A+3, A+11), right = [A+6, A+14)
+        constexpr int c0 = (A + 3) >> 2, cs = (A + 3) & 3, q0 = (A + 6) >> 2, qs = (A + 6) & 3;
         const uint32_t* cw = reinterpret_cast<const uint32_t*>(t0 + 3 * TP + ro);
-        const uint32_t w0 = cw[0], w1 = cw[1], w2 = cw[2], w3 = cw[3];
-        const uint32_t* uw = reinterpret_cast<const uint32_t*>(t0 + ro);                    // row y-3 (+3 halo)
-        const uint32_t* dw = reinterpret_cast<const uint32_t*>(t0 + 6 * TP + ro);           // row y+3
-        // byte windows: left = bytes [A, A+4), centre/up/down = [A+3, A+7), right = [A+6, A+10) of the row
-        const uint32_t L4 = __builtin_amdgcn_alignbyte(w1, w0, A);
-        const uint32_t C4 = (A + 3 < 4) ? __builtin_amdgcn_alignbyte(w1, w0, (A + 3) & 3)
-                                        : __builtin_amdgcn_alignbyte(w2, w1, (A + 3) & 3);
-        const uint32_t R4 = (A + 6 < 8) ? __builtin_amdgcn_alignbyte(w2, w1, (A + 6) & 3)
-                                        : __builtin_amdgcn_alignbyte(w3, w2, (A + 6) & 3);
-        const uint32_t U4 = (A + 3 < 4) ? __builtin_amdgcn_alignbyte(uw[1], uw[0], (A + 3) & 3)
-                                        : __builtin_amdgcn_alignbyte(uw[2], uw[1], (A + 3) & 3);
-        const uint32_t D4 = (A + 3 < 4) ? __builtin_amdgcn_alignbyte(dw[1], dw[0], (A + 3) & 3)
-                                        : __builtin_amdgcn_alignbyte(dw[2], dw[1], (A + 3) & 3);
-        unsigned flag[2];
-#pragma unroll
-        for (int h = 0; h < 2; h++) {   // h = 0: odd pixels (high bytes), h = 1: even pixels (shifted up)
-          const u16x2 v2 = h ? as_u16x2(C4) << 8 : as_u16x2(C4);
-          const u16x2 r0 = h ? as_u16x2(D4) << 8 : as_u16x2(D4), r4 = h ? as_u16x2(R4) << 8 : as_u16x2(R4);
-          const u16x2 r8 = h ? as_u16x2(U4) << 8 : as_u16x2(U4), r12 = h ? as_u16x2(L4) << 8 : as_u16x2(L4);
-          const u16x2 mx = __builtin_elementwise_min(__builtin_elementwise_max(r0, r8), __builtin_elementwise_max(r4, r12));
-          const u16x2 mn = __builtin_elementwise_max(__builtin_elementwise_min(r0, r8), __builtin_elementwise_min(r4, r12));
-          const u16x2 hi = __builtin_elementwise_add_sat(v2, T2), lo = __builtin_elementwise_sub_sat(v2, T2);
-          const unsigned e = as_u32(__builtin_elementwise_sub_sat(mx, hi)) | as_u32(__builtin_elementwise_sub_sat(lo, mn));
-          asm("v_pk_min_u16 %0, %1, %2" : "=v"(flag[h]) : "v"(e), "v"(0x00010001u));   // 1 per passing 16-bit lane
-        }
-        passBits = flag[1] | (flag[0] << 1);   // bit 0: pixel 0, bit 1: pixel 1, bit 16: pixel 2, bit 17: pixel 3
+        const uint32_t w0 = cw[0], w1 = cw[1], w2 = cw[2], w3 = cw[3], w4 = cw[4];
+        const uint32_t w[5] = {w0, w1, w2, w3, w4};
+        const uint32_t* uw = reinterpret_cast<const uint32_t*>(t0 + ro) + c0;               // row y-3 (+3 halo)
+        const uint32_t* dw = reinterpret_cast<const uint32_t*>(t0 + 6 * TP + ro) + c0;      // row y+3
+        const uint32_t u0 = uw[0], u1 = uw[1], u2 = uw[2], d0 = dw[0], d1 = dw[1], d2 = dw[2];
+        const uint32_t La = __builtin_amdgcn_alignbyte(w1, w0, A), Lb = __builtin_amdgcn_alignbyte(w2, w1, A);
+        const uint32_t Ca = __builtin_amdgcn_alignbyte(w[c0 + 1], w[c0], cs), Cb = __builtin_amdgcn_alignbyte(w[c0 + 2], w[c0 + 1], cs);
+        const uint32_t Ra = __builtin_amdgcn_alignbyte(w[q0 + 1], w[q0], qs), Rb = __builtin_amdgcn_alignbyte(w[q0 + 2], w[q0 + 1], qs);
+        const uint32_t Ua = __builtin_amdgcn_alignbyte(u1, u0, cs), Ub = __builtin_amdgcn_alignbyte(u2, u1, cs);
+        const uint32_t Da = __builtin_amdgcn_alignbyte(d1, d0, cs), Db = __builtin_amdgcn_alignbyte(d2, d1, cs);
+        pb0 = test4(La, Ca, Ra, Ua, Da);
+        pb1 = test4(Lb, Cb, Rb, Ub, Db);
       }
       // ordered compaction: inclusive wave scan of the per-lane counts (DPP, 6 adds)
-      const int c = __popc(passBits);
+      const int c = __popc(pb0) + __popc(pb1);
       int incl = c;
       incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);   // row_shr:1
       incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);   // row_shr:2
@@ -321,10 +330,14 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
       incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
       int pos = nq + incl - c;
       const unsigned e = (unsigned)((y << 8) | x);
-      if (passBits & 1u) queue[pos++] = (uint16_t)e;
-      if (passBits & 2u) queue[pos++] = (uint16_t)(e + 1);
-      if (passBits & 0x10000u) queue[pos++] = (uint16_t)(e + 2);
-      if (passBits & 0x20000u) queue[pos++] = (uint16_t)(e + 3);
+      if (pb0 & 1u) queue[pos++] = (uint16_t)e;
+      if (pb0 & 2u) queue[pos++] = (uint16_t)(e + 1);
+      if (pb0 & 0x10000u) queue[pos++] = (uint16_t)(e + 2);
+      if (pb0 & 0x20000u) queue[pos++] = (uint16_t)(e + 3);
+      if (pb1 & 1u) queue[pos++] = (uint16_t)(e + 4);
+      if (pb1 & 2u) queue[pos++] = (uint16_t)(e + 5);
+      if (pb1 & 0x10000u) queue[pos++] = (uint16_t)(e + 6);
+      if (pb1 & 0x20000u) queue[pos++] = (uint16_t)(e + 7);
       nq += __builtin_amdgcn_readlane(incl, 63);
       y += stepY;
       g += stepG;
@@ -373,7 +386,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
 #pragma unroll
       for (int k = 0; k < 16; k++) best = __builtin_elementwise_max(best, __builtin_elementwise_min(m8[k], d[(k + 8) & 15]));
       const int S = max((int)best.x, (int)best.y);
-      pass = S > tlo && x < ew;   // stage 1 tests whole 4-pixel groups
+      pass = S > tlo && x < ew;   // stage 1 tests whole 8-pixel groups
       if (pass) sc[m24(y + 1, SP) + (x + 1)] = (uint8_t)(S - 1);  // tlo <= S-1 <= 254
     }
     // the ballot consumes every lane's queue read, so the in-place writes below cannot overtake them
@@ -382,42 +395,27 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
     nq2 += __popcll(m);
   }
   __syncthreads();
-  // ---- stage 3: NMS inside the emit region, threshold decision, ordered emission ----------------
-  bool anyIni = false;
+  // ---- stage 3: NMS inside the emit region and ordered emission (every survivor has score >= tlo) ---------
   for (int i0 = 0; i0 < nq2; i0 += 64) {
     const int i = i0 + lane;
-    int keep = 0;
+    int keep = 0, y = 0, x = 0;
     if (i < nq2) {
       const unsigned e = queue[i];
-      const int y = (e >> 8) & 0x7f, x = e & 0x7f;
+      y = (e >> 8) & 0x7f;
+      x = e & 0x7f;
       const uint8_t* q = sc + m24(y + 1, SP) + (x + 1);
-      const int s = q[0];
-      if (s > 0 && s > q[-1] && s > q[1] && s > q[-SP - 1] && s > q[-SP] && s > q[-SP + 1] && s > q[SP - 1] &&
-          s > q[SP] && s > q[SP + 1])
-        keep = s;
-      kept[i] = (uint8_t)keep;
+      const int sv = q[0];
+      if (sv > 0 && sv > q[-1] && sv > q[1] && sv > q[-SP - 1] && sv > q[-SP] && sv > q[-SP + 1] && sv > q[SP - 1] &&
+          sv > q[SP] && sv > q[SP + 1])
+        keep = sv;
     }
-    anyIni |= (__ballot(keep > 0 && keep >= P.iniTh) != 0ull);
-  }
-  __syncthreads();
-  const int th = anyIni ? P.iniTh : P.minTh;
-  uint32_t* slot = P.slots + (long long)f * P.slotsPerFrame + ci.slotOff;
-  int base = 0;
-  for (int i0 = 0; i0 < nq2; i0 += 64) {
-    const int i = i0 + lane;
-    int s = 0;
-    unsigned e = 0;
-    if (i < nq2) {
-      s = kept[i];
-      e = queue[i];
-    }
-    const bool emit = s > 0 && s >= th;
-    const unsigned long long m = __ballot(emit);
-    if (emit) {
-      const int y = (e >> 8) & 0x7f, x = e & 0x7f;
-      slot[base + __popcll(m & below)] = (uint32_t)(ex0 + x) | ((uint32_t)(ey0 + y) << 12) | ((uint32_t)s << 24);
-    }
+    const unsigned long long m = __ballot(keep > 0);
+    if (keep > 0)
+      slot[base + __popcll(m & below)] = (uint32_t)(ex0 + x) | ((uint32_t)(ey0 + y) << 12) | ((uint32_t)keep << 24);
     base += __popcll(m);
+  }
+  if (base > 0 || P.minTh == P.iniTh) break;
+  __syncthreads();   // the queue is rebuilt by the second pass
   }
   if (lane == 0) *cnt = (uint32_t)base;
 }
@@ -820,7 +818,7 @@ size_t fast_lds_bytes(const PyramidParams& P) {
     const LevelGeom& L = P.lv[l];
     const size_t TP = (L.wCell + 6 + 3 + 3) & ~3;
     const size_t b = ((TP * (L.hCell + 6) + (size_t)(L.wCell + 2) * (L.hCell + 2) + 3) & ~(size_t)3) +
-                     2 * (size_t)(L.wCell + 3) * L.hCell;  // tile (+ kept alias) + score tile + u16 queue (whole 4-pixel groups)
+                     2 * (size_t)(L.wCell + 7) * L.hCell;  // tile + score tile + u16 queue (whole 8-pixel groups)
     mx = b > mx ? b : mx;
   }
   return (mx + 15) & ~(size_t)15;
