@@ -147,7 +147,8 @@ static UploadLane* upload_lane(int device) {
 // the chain two handles drift into lock-step: both fronts share the CUs, then both tails leave them idle.
 struct FrontLane {
   std::mutex mu;
-  hipEvent_t last = nullptr;   // recorded after the most recently submitted front (owned by that handle)
+  hipEvent_t last = nullptr;    // recorded after the most recently submitted front (owned by that handle)
+  hipEvent_t lastPyr = nullptr; // recorded after its pyramid (two-link mode)
 };
 static FrontLane* front_lane(int device) {
   static std::mutex mu;
@@ -169,6 +170,8 @@ struct orbfe_extractor {
   int subBatches = 4;
   hipEvent_t evUpload = nullptr;
   hipEvent_t evFront = nullptr;   // end of this handle's last front (FrontLane)
+  hipEvent_t evPyr = nullptr;     // end of this handle's last pyramid (FrontLane, two-link mode)
+  bool frontSplit = true;         // pyramid and FAST are separate links of the chain (ORBFE_FRONT_SPLIT=0: one link)
   bool frontLane = true;          // ORBFE_FRONT_LANE=0 disables the chaining
   hipEvent_t evFrame0 = nullptr, evS1[kMaxSub] = {};
   int subSel[kMaxSub] = {};
@@ -256,8 +259,10 @@ struct orbfe_extractor {
       if (FrontLane* fl = front_lane(device)) {
         std::lock_guard<std::mutex> lk(fl->mu);
         if (fl->last == evFront) fl->last = nullptr;
+        if (fl->lastPyr == evPyr) fl->lastPyr = nullptr;
       }
       (void)hipEventDestroy(evFront);
+      if (evPyr) (void)hipEventDestroy(evPyr);
     }
     for (auto& st : streams) if (st) (void)hipStreamDestroy(st);
   }
@@ -547,10 +552,16 @@ struct orbfe_extractor {
       std::unique_lock<std::mutex> lk;
       if (fl) {
         lk = std::unique_lock<std::mutex>(fl->mu);
-        if (fl->last && fl->last != evFront) HIP_TRY(hipStreamWaitEvent(st, fl->last, 0));
+        hipEvent_t w = frontSplit ? fl->lastPyr : fl->last;
+        if (w && w != evFront && w != evPyr) HIP_TRY(hipStreamWaitEvent(st, w, 0));
       }
       if (prof) HIP_TRY(hipEventRecord(ev[0][0], st));
       launch_pyramid(P, nframes, st);
+      if (fl && frontSplit) {
+        HIP_TRY(hipEventRecord(evPyr, st));
+        fl->lastPyr = evPyr;
+        if (fl->last && fl->last != evFront) HIP_TRY(hipStreamWaitEvent(st, fl->last, 0));
+      }
       HIP_TRY(hipEventRecord(ev[0][1], st));   // the dominant kernel is always timed (bench.py roofline)
       launch_fast(P, nframes, st);
       HIP_TRY(hipEventRecord(ev[0][2], st));
@@ -1015,7 +1026,8 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
   h->stream = h->streams[0];
   bool evOk = hipEventCreate(&h->evFrame0) == hipSuccess &&
               hipEventCreateWithFlags(&h->evUpload, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&h->evFront, hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&h->evFront, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&h->evPyr, hipEventDisableTiming) == hipSuccess;
   for (auto& e : h->evS1) evOk = evOk && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
   for (auto& es : h->ev) for (auto& e : es) evOk = evOk && hipEventCreate(&e) == hipSuccess;
   if (!evOk) { set_err("hipEventCreate failed"); delete h; return ORBFE_ERR_HIP; }
@@ -1027,6 +1039,7 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     if (const char* qv = getenv("ORBFE_QT_STREAM")) h->qtOwnStream = atoi(qv) != 0;
     if (const char* fv = getenv("ORBFE_FRONT_LANE")) h->frontLane = atoi(fv) != 0;
+    if (const char* fv = getenv("ORBFE_FRONT_SPLIT")) h->frontSplit = atoi(fv) != 0;
     evOk = (!h->qtOwnStream || hipStreamCreateWithPriority(&h->qtStream, hipStreamNonBlocking, greatest) == hipSuccess) &&
            hipEventCreateWithFlags(&h->evQtIn, hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&h->evQtOut, hipEventDisableTiming) == hipSuccess;
