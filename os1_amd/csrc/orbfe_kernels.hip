@@ -457,16 +457,28 @@ __global__ __launch_bounds__(1024) void k_scan_cells(PyramidParams P) {
   if (tid == 0) ls[P.nlevels] = carry;
 }
 
-__global__ __launch_bounds__(256) void k_gather(PyramidParams P) {   // one wave per cell, 4 cells per block
-  const int cell = blockIdx.x * 4 + (threadIdx.x >> 6), f = P.frameBase + blockIdx.y, lane = threadIdx.x & 63;
-  if (cell >= P.ncells) return;
-  const uint32_t n = P.cellCount[(long long)f * P.ncells + cell];
-  if (n == 0) return;
-  const uint32_t* slot = P.slots + (long long)f * P.slotsPerFrame + P.cells[cell].slotOff;
-  const uint32_t o = P.cellOff[(long long)f * P.ncells + cell];
-  uint32_t* dst = P.cand + (long long)f * P.candCap;
-  for (uint32_t i = lane; i < n; i += 64)
-    if (o + i < (uint32_t)P.candCap) dst[o + i] = slot[i];
+// One LANE per cell (cells hold a handful of candidates each; a wave per cell spent its time being launched):
+// every lane copies its cell's slots to the cell's offset in the frame's candidate list, 4 entries in flight.
+__global__ __launch_bounds__(64) void k_gather(PyramidParams P) {
+  const int cell = blockIdx.x * 64 + threadIdx.x, f = P.frameBase + blockIdx.y;
+  uint32_t n = 0, o = 0;
+  const uint32_t* slot = nullptr;
+  if (cell < P.ncells) {
+    n = P.cellCount[(long long)f * P.ncells + cell];
+    o = P.cellOff[(long long)f * P.ncells + cell];
+    slot = P.slots + (long long)f * P.slotsPerFrame + P.cells[cell].slotOff;
+    if (o >= (uint32_t)P.candCap) n = 0;
+    else n = min(n, (uint32_t)P.candCap - o);
+  }
+  uint32_t* dst = P.cand + (long long)f * P.candCap + o;
+  for (uint32_t i = 0; __any(i < n); i += 4) {
+    uint32_t v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) v[u] = (i + u < n) ? slot[i + u] : 0u;
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (i + u < n) dst[i + u] = v[u];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -830,7 +842,7 @@ void launch_fast(const PyramidParams& P, int nframes, hipStream_t st) {
 
 void launch_compact(const PyramidParams& P, int nframes, hipStream_t st) {
   hipLaunchKernelGGL(k_scan_cells, dim3(nframes), dim3(1024), 0, st, P);
-  hipLaunchKernelGGL(k_gather, dim3((P.ncells + 3) / 4, nframes), dim3(256), 0, st, P);
+  hipLaunchKernelGGL(k_gather, dim3((P.ncells + 63) / 64, nframes), dim3(64), 0, st, P);
 }
 
 void launch_describe(const PyramidParams& P, const SelKp* sel, int nsel, float* angle, uint8_t* desc,
