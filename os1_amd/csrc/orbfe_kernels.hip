@@ -34,10 +34,13 @@ __device__ __forceinline__ unsigned mulu24(unsigned a, unsigned b) {
 // Pyramid: level l <- bilinear(level l-1).  Reference: ComputePyramid, src/ORBextractor.cc:971-996
 // (cv::resize call at :984); fixed-point semantics: SURVEY.md Appendix B.2.
 //
-// One 256-thread block produces a 64x64 output tile: the source footprint of the tile (about
-// 79x79 bytes at scale 1.2) is staged in LDS with aligned dword loads, every thread owns a 4x4 patch
-// of outputs (its 4 column and 4 row coefficient sets live in registers, so the tables are read
-// 1.5 times per output instead of 8), and each output row of the patch leaves as one dword store.
+// One 256-thread block produces a 64x64 output tile in two separable passes through LDS:
+//   stage  the source footprint of the tile (about 79x79 bytes at scale 1.2), aligned dword loads;
+//   rows   H[r][c] = (p[sx_c] * a0_c + p[sx_c + 1] * a1_c) >> 4 for every footprint row r and output column c
+//          (u16, <= 32640): thread = one output column, its coefficient set in registers, 20 rows each;
+//   cols   out = ((b0 * H[sy][c] >> 16) + (b1 * H[sy+1][c] >> 16) + 2) >> 2: thread = 4 columns x 4 rows, 64-bit LDS
+//          reads of 4 columns, one dword store per row.
+// The horizontal interpolation is done once per footprint row (79 per tile) instead of twice per output row (128).
 // ------------------------------------------------------------------------------------------------
 constexpr int kRzTile = 64;
 
@@ -58,16 +61,17 @@ __global__ __launch_bounds__(256) void k_resize(PyramidParams P, int level) {
     sstride = S.pitch;
   }
   const int tid = threadIdx.x;
-  // this thread's 4x4 patch: its 4 column and 4 row coefficient sets are requested first, so that their latency
-  // overlaps the staging of the source tile
+  // coefficient sets are requested first, so that their latency overlaps the staging of the source tile:
+  // the column set of the row pass (column tx0 + tid % 64) and the 4 row sets of the column pass
+  const int hc = tid & 63;
+  const int hx = min(tx0 + hc, D.w - 1);
+  const int hsx = D.xofs[hx];
+  const int hal = reinterpret_cast<const int*>(D.xalpha)[hx];   // (a0, a1) as two shorts
   const int cx = tx0 + (tid & 15) * 4, cy = ty0 + (tid >> 4) * 4;
-  int sx[4], syv[4];
-  int al[4], be[4];   // (a0, a1) / (b0, b1) as two shorts
+  int syv[4], be[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const int x = min(cx + i, D.w - 1), y = min(cy + i, D.h - 1);
-    sx[i] = D.xofs[x];
-    al[i] = reinterpret_cast<const int*>(D.xalpha)[x];
+    const int y = min(cy + i, D.h - 1);
     syv[i] = D.yofs[y];
     be[i] = reinterpret_cast<const int*>(D.ybeta)[y];
   }
@@ -79,6 +83,7 @@ __global__ __launch_bounds__(256) void k_resize(PyramidParams P, int level) {
   const int istr = (int)sstride;
   const uint8_t* rbase = src + (long long)ry0 * sstride + rx0;
   const int a = (int)(reinterpret_cast<uintptr_t>(rbase) & 3);
+  uint16_t* H = reinterpret_cast<uint16_t*>(rz + ((m24(LP, D.rzRows) + 15) & ~15));   // [rh][64]
   if ((sstride & 3) == 0) {
     // thread (c, r0) = (tid % 32, tid / 32) copies dword column c of rows r0, r0+8, ...: plain adds, no
     // per-element index arithmetic; 4 loads are issued before the first LDS write
@@ -106,31 +111,36 @@ __global__ __launch_bounds__(256) void k_resize(PyramidParams P, int level) {
     }
   }
   __syncthreads();
-  const uint8_t* tile = rz + a - rx0;  // tile[(sy - ry0) * LP + sx] is source pixel (sx, sy)
-
+  // ---- row pass ----
+  {
+    const int a0 = (short)hal, a1 = hal >> 16;
+    const int o0 = a + hsx - rx0, o1 = a + min(hsx + 1, S.w - 1) - rx0;   // a1 == 0 whenever sx + 1 is out of range
+    const uint8_t* p = rz + m24(tid >> 6, LP);
+    uint16_t* h = H + (tid >> 6) * 64 + hc;
+    for (int r = tid >> 6; r < rh; r += 4, p += 4 * LP, h += 4 * 64)
+      *h = (uint16_t)((m24(p[o0], a0) + m24(p[o1], a1)) >> 4);
+  }
+  __syncthreads();
+  // ---- column pass ----
   if (cx > tx1 || cy > ty1) return;
-  int sx1[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) sx1[i] = min(sx[i] + 1, S.w - 1);  // a1 == 0 whenever sx+1 is out of range
   uint8_t* dst = P.slab + (long long)f * P.slabBytes + D.off;
+  const uint16_t* hcol = H + (cx - tx0);
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int y = cy + j;
     if (y > ty1) break;
     const int sy = syv[j];
     const int sy0 = min(max(sy, 0), S.h - 1) - ry0, sy1 = min(max(sy + 1, 0), S.h - 1) - ry0;
-    const int b0 = (short)be[j], b1 = be[j] >> 16;
-    const uint8_t* r0 = tile + m24(sy0, LP);
-    const uint8_t* r1 = tile + m24(sy1, LP);
+    const unsigned b0 = (unsigned)(int)(short)be[j], b1 = (unsigned)(be[j] >> 16);
+    const uint2 q0 = *reinterpret_cast<const uint2*>(hcol + sy0 * 64), q1 = *reinterpret_cast<const uint2*>(hcol + sy1 * 64);
+    const unsigned h0[4] = {q0.x & 0xffffu, q0.x >> 16, q0.y & 0xffffu, q0.y >> 16};
+    const unsigned h1[4] = {q1.x & 0xffffu, q1.x >> 16, q1.y & 0xffffu, q1.y >> 16};
     uint32_t packed = 0;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      const int a0 = (short)al[i], a1 = al[i] >> 16;
-      const int h0 = m24(r0[sx[i]], a0) + m24(r0[sx1[i]], a1);
-      const int h1 = m24(r1[sx[i]], a0) + m24(r1[sx1[i]], a1);
-      // b <= 2048, h >> 4 <= 32640: the products fit 27 bits
-      const int v = (int)((mulu24((unsigned)b0, (unsigned)h0 >> 4) >> 16) + (mulu24((unsigned)b1, (unsigned)h1 >> 4) >> 16) + 2) >> 2;
-      packed |= (uint32_t)(v & 255) << (8 * i);
+      // b <= 2048, h <= 32640: the products fit 27 bits
+      const unsigned v = ((mulu24(b0, h0[i]) >> 16) + (mulu24(b1, h1[i]) >> 16) + 2) >> 2;
+      packed |= v << (8 * i);
     }
     *reinterpret_cast<uint32_t*>(dst + m24(y, D.pitch) + cx) = packed;  // pitch % 64 == 0: in bounds
   }
@@ -820,7 +830,8 @@ void launch_to_gray(const uint8_t* const* raw, long long rawStride, const uint8_
 void launch_pyramid(const PyramidParams& P, int nframes, hipStream_t st) {
   for (int l = 1; l < P.nlevels; l++) {
     dim3 grid((P.lv[l].w + kRzTile - 1) / kRzTile, (P.lv[l].h + kRzTile - 1) / kRzTile, nframes);
-    hipLaunchKernelGGL(k_resize, grid, dim3(256), (size_t)P.lv[l].rzPitch * P.lv[l].rzRows, st, P, l);
+    hipLaunchKernelGGL(k_resize, grid, dim3(256), (((size_t)P.lv[l].rzPitch * P.lv[l].rzRows + 15) & ~(size_t)15) + (size_t)P.lv[l].rzRows * 64 * 2, st,
+                       P, l);
   }
 }
 
