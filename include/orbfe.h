@@ -313,6 +313,27 @@ int orbfe_window_candidates(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, const
                             const int32_t* qmin_level, const int32_t* qmax_level, const uint8_t* qdesc,
                             uint32_t* counts, uint32_t* offsets, uint32_t* pool, size_t pool_cap, size_t* pool_used);
 
+/* The projected best-match loop shared by int ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const
+ * vector<MapPoint*>& vpPoints, vector<MapPoint*>& vpMatched, int th) (src/ORBmatcher.cc:285-398, loop :357-392),
+ * int ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, float th) (:806-939, loop :872-936),
+ * int ORBmatcher::Fuse(KeyFrame*, cv::Mat Scw, ...) (:941-1064, loop :1014-1050) and both directions of
+ * int ORBmatcher::SearchBySim3(...) (:1066-1290), from KeyFrame::GetFeaturesInArea (src/KeyFrame.cc:637-676) onwards.
+ * The caller keeps the reference's projection code (cv::Mat float arithmetic, depth / viewing-angle / PredictScale
+ * checks) and passes, per surviving MapPoint: src_uv, src_radius (= th * mvScaleFactors[nPredictedLevel]), src_level
+ * (= nPredictedLevel; keypoints of octave [level-1, level] qualify), src_desc, src_valid (0 = rejected earlier).
+ *   kp_skip (n, optional) / claim: vpMatched semantics of SearchByProjection -- a keypoint with kp_skip != 0 is never
+ *     taken, and with claim != 0 an accepted keypoint is skipped by later sources (vpMatched[bestIdx] = pMP);
+ *   inv_level_sigma2 (nlevels, optional) + chi2: Fuse's reprojection gate e2 * mvInvLevelSigma2[kpLevel] > 5.99;
+ *   max_dist: TH_LOW (50) for SearchByProjection / Fuse, TH_HIGH (100) for SearchBySim3.
+ * best_idx[i] = accepted keypoint index or -1 (the first minimum in GetFeaturesInArea order), best_dist[i] (optional)
+ * its distance; *nmatches = number accepted.  The MapPoint bookkeeping (Replace / AddObservation / vnMatch agreement)
+ * stays with the caller. */
+int orbfe_search_projected(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, const uint8_t* desc, int n, const float bounds[4],
+                           int n_src, const float* src_uv, const float* src_radius, const int32_t* src_level,
+                           const uint8_t* src_valid, const uint8_t* src_desc, const uint8_t* kp_skip, int claim,
+                           const float* inv_level_sigma2, int nlevels, double chi2, int max_dist, int32_t* best_idx,
+                           int32_t* best_dist, int* nmatches);
+
 /* void MapPoint::ComputeDistinctiveDescriptors()  (src/MapPoint.cc:227-292), from the gathered descriptor list
  * onwards, batched over MapPoints: MapPoint p owns descriptor rows [offsets[p], offsets[p+1]) of `descs`
  * (32-byte rows, the non-bad observations in std::map order); best_idx[p] = index inside its own list of the

@@ -1383,4 +1383,56 @@ int orc_search_for_triangulation(const OrcKeyPoint* kps1, const uint8_t* desc1, 
   return nmatches;
 }
 
+// The projected best-match loop shared by ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched, th)
+// (ORBmatcher.cc:285-398, loop :357-392), ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th) (:806-939, loop :872-936),
+// ORBmatcher::Fuse(KeyFrame*, Scw, ...) (:941-1064, loop :1014-1050) and both directions of SearchBySim3 (:1066-1290),
+// from KeyFrame::GetFeaturesInArea (KeyFrame.cc:637-676) onwards.  Per source (a projected MapPoint): window
+// (u, v, radius), predicted level p => keypoint levels [p-1, p], descriptor.  Variants:
+//   kp_skip / claim : vpMatched[idx] skips a keypoint and an accepted one is claimed (SearchByProjection, :366-367,:388);
+//   inv_sigma2 + chi2: Fuse's reprojection gate, `e2*mvInvLevelSigma2[kpLevel] > 5.99` => skip (:896-903);
+//   max_dist         : TH_LOW (50) or TH_HIGH (100).
+// best_idx[i] = accepted keypoint or -1, best_dist[i] = its distance.  Returns the number accepted.
+int orc_search_projected(const OrcKeyPoint* kpsUn, const uint8_t* desc, int n, const float bounds[4], int n_src,
+                         const float* src_uv, const float* src_radius, const int32_t* src_level,
+                         const uint8_t* src_valid, const uint8_t* src_desc, const uint8_t* kp_skip, int claim,
+                         const float* inv_sigma2, double chi2, int max_dist, int32_t* best_idx, int32_t* best_dist) {
+  std::vector<uint8_t> vpMatched(n, 0);
+  if (kp_skip) vpMatched.assign(kp_skip, kp_skip + n);
+  FrameGrid grid(kpsUn, n, bounds);
+  int nmatches = 0;
+  for (int i = 0; i < n_src; i++) {
+    best_idx[i] = -1;
+    best_dist[i] = -1;
+    if (!src_valid[i]) continue;
+    const float u = src_uv[2 * i], v = src_uv[2 * i + 1];
+    const int nPredictedLevel = src_level[i];
+    const std::vector<size_t> vIndices = grid.getFeaturesInArea(u, v, src_radius[i], -1, -1);
+    if (vIndices.empty()) continue;
+    const uint8_t* dMP = src_desc + 32 * (size_t)i;
+    int bestDist = INT_MAX;
+    int bestIdx = -1;
+    for (size_t idx : vIndices) {
+      if ((kp_skip || claim) && vpMatched[idx]) continue;
+      const OrcKeyPoint& kp = kpsUn[idx];
+      const int kpLevel = kp.octave;
+      if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+      if (inv_sigma2) {
+        const float ex = u - kp.x;
+        const float ey = v - kp.y;
+        const float e2 = ex * ex + ey * ey;
+        if (e2 * inv_sigma2[kpLevel] > chi2) continue;
+      }
+      const int dist = descriptor_distance(dMP, desc + 32 * idx);
+      if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx; }
+    }
+    if (bestDist <= max_dist) {
+      best_idx[i] = bestIdx;
+      best_dist[i] = bestDist;
+      if (claim) vpMatched[bestIdx] = 1;
+      nmatches++;
+    }
+  }
+  return nmatches;
+}
+
 }  // extern "C"

@@ -62,6 +62,8 @@ class Oracle:
         L.orc_search_for_triangulation.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] + \
             [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_void_p,
                                                                   C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_search_projected.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 6 + \
+            [C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_vocab_create.restype = C.c_void_p
         L.orc_vocab_create.argtypes = [C.c_int] * 4 + [C.c_void_p, C.c_int]
         L.orc_vocab_destroy.argtypes = [C.c_void_p]
@@ -210,6 +212,26 @@ class Oracle:
                                                  _p(f2[2]), len(f2[0]), _p(F), C.c_float(ex), C.c_float(ey), _p(sc), _p(sg),
                                                  int(check_ori), _p(pairs))
         return nm, pairs[:nm]
+
+    def search_projected(self, kps, desc, bounds, uv, radius, level, valid, sdesc, kp_skip=None, claim=False,
+                         inv_sigma2=None, chi2=5.99, max_dist=50):
+        kps = np.ascontiguousarray(kps)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        b = np.asarray(bounds, np.float32)
+        uv = np.ascontiguousarray(uv, np.float32)
+        radius = np.ascontiguousarray(radius, np.float32)
+        level = np.ascontiguousarray(level, np.int32)
+        valid = np.ascontiguousarray(valid, np.uint8)
+        sdesc = np.ascontiguousarray(sdesc, np.uint8)
+        ns = len(radius)
+        skip = None if kp_skip is None else np.ascontiguousarray(kp_skip, np.uint8)
+        inv = None if inv_sigma2 is None else np.ascontiguousarray(inv_sigma2, np.float32)
+        bi = np.full(max(ns, 1), -1, np.int32)
+        bd = np.full(max(ns, 1), -1, np.int32)
+        nm = self.L.orc_search_projected(_p(kps), _p(desc), len(kps), _p(b), ns, _p(uv), _p(radius), _p(level), _p(valid),
+                                         _p(sdesc), None if skip is None else _p(skip), int(claim),
+                                         None if inv is None else _p(inv), C.c_double(chi2), max_dist, _p(bi), _p(bd))
+        return nm, bi[:ns], bd[:ns]
 
     def vocabulary(self, image):
         return OracleVocabulary(self, image)

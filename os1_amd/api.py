@@ -82,6 +82,8 @@ def load_library():
     L.orbfe_window_candidates.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t,
                                           C.POINTER(C.c_size_t)]
     L.orbfe_undistort_equidistant.argtypes = [vp, ci, cf, cf, cf, cf]
+    L.orbfe_search_projected.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp, ci, C.c_double, ci, vp, vp,
+                                         C.POINTER(ci)]
     L.orbfe_search_for_triangulation.argtypes = [vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, cf, cf,
                                                  vp, vp, ci, ci, vp, C.POINTER(ci)]
     L.orbfe_extractor_set_input_format.argtypes = [vp, ci, ci]
@@ -405,6 +407,29 @@ class Matcher:
         out = np.zeros(max(len(desc_lists), 1), np.int32)
         _check(self.L.orbfe_distinctive_descriptors(self.h, len(desc_lists), _p(offs), _p(allv), _p(out)))
         return out[:len(desc_lists)]
+
+    def search_projected(self, kps, desc, bounds, uv, radius, level, valid, sdesc, kp_skip=None, claim=False,
+                         inv_sigma2=None, chi2=5.99, max_dist=50):
+        """Projected best-match loop of SearchByProjection(KF, Scw) / Fuse / SearchBySim3 -> (n, best_idx, best_dist)."""
+        kps = np.ascontiguousarray(kps)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        b = np.asarray(bounds, np.float32)
+        uv = np.ascontiguousarray(uv, np.float32)
+        radius = np.ascontiguousarray(radius, np.float32)
+        level = np.ascontiguousarray(level, np.int32)
+        valid = np.ascontiguousarray(valid, np.uint8)
+        sdesc = np.ascontiguousarray(sdesc, np.uint8)
+        ns = len(radius)
+        skip = None if kp_skip is None else np.ascontiguousarray(kp_skip, np.uint8)
+        inv = None if inv_sigma2 is None else np.ascontiguousarray(inv_sigma2, np.float32)
+        bi = np.full(max(ns, 1), -1, np.int32)
+        bd = np.full(max(ns, 1), -1, np.int32)
+        nm = C.c_int(0)
+        _check(self.L.orbfe_search_projected(self.h, _p(kps), _p(desc), len(kps), _p(b), ns, _p(uv), _p(radius), _p(level),
+                                             _p(valid), _p(sdesc), None if skip is None else _p(skip), int(claim),
+                                             None if inv is None else _p(inv), 0 if inv is None else len(inv), chi2,
+                                             max_dist, _p(bi), _p(bd), C.byref(nm)))
+        return nm.value, bi[:ns], bd[:ns]
 
     def search_for_triangulation(self, kps1, desc1, has_mp1, fv1, kps2, desc2, has_mp2, fv2, F12, ex, ey, scale2, sigma2,
                                  check_ori=True):

@@ -895,4 +895,69 @@ int orbfe_search_by_projection_uv(orbfe_matcher* m, const OrbfeKeyPoint* kps_un,
   return ORBFE_OK;
 }
 
+// The projected best-match loop of SearchByProjection(KeyFrame*, Scw, ...) (ORBmatcher.cc:357-392), Fuse x2
+// (:872-936, :1014-1050) and SearchBySim3 (:1066-1290): see include/orbfe.h.
+int orbfe_search_projected(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, const uint8_t* desc, int n, const float bounds[4],
+                           int n_src, const float* src_uv, const float* src_radius, const int32_t* src_level,
+                           const uint8_t* src_valid, const uint8_t* src_desc, const uint8_t* kp_skip, int claim,
+                           const float* inv_level_sigma2, int nlevels, double chi2, int max_dist, int32_t* best_idx,
+                           int32_t* best_dist, int* nmatches) {
+  if (!m || !bounds || !nmatches || n < 0 || n_src < 0 || (n && (!kps_un || !desc)) ||
+      (n_src && (!src_uv || !src_radius || !src_level || !src_valid || !src_desc || !best_idx))) {
+    set_err("bad argument");
+    return ORBFE_ERR_INVALID;
+  }
+  *nmatches = 0;
+  for (int i = 0; i < n_src; i++) {
+    best_idx[i] = -1;
+    if (best_dist) best_dist[i] = -1;
+  }
+  if (n_src == 0 || n == 0) return ORBFE_OK;
+  if (inv_level_sigma2)
+    for (int i = 0; i < n; i++)
+      if (kps_un[i].octave < 0 || kps_un[i].octave >= nlevels) { set_err("keypoint octave out of range"); return ORBFE_ERR_INVALID; }
+  std::vector<float> qx(n_src), qy(n_src), qr(n_src);
+  std::vector<int> qa(n_src), qb(n_src);
+  for (int i = 0; i < n_src; i++) {
+    qx[i] = src_uv[2 * i];
+    qy[i] = src_uv[2 * i + 1];
+    qa[i] = src_level[i] - 1;                      // kpLevel < nPredictedLevel-1 || kpLevel > nPredictedLevel => skip
+    qb[i] = src_level[i];
+    qr[i] = (src_valid[i] && src_level[i] >= 0) ? src_radius[i] : -1.f;   // no octave lies in [level-1, level] for level < 0
+  }
+  int rc = m->candidates(kps_un, desc, n, bounds, qx.data(), qy.data(), qr.data(), qa.data(), qb.data(), src_desc, n_src);
+  if (rc) return rc;
+  const uint32_t* pool = m->h_pool.p;
+  std::vector<uint8_t> occ(n, 0);
+  if (kp_skip) occ.assign(kp_skip, kp_skip + n);
+  const bool useOcc = kp_skip || claim;
+  int nm = 0;
+  for (int i = 0; i < n_src; i++) {
+    if (qr[i] < 0.f) continue;
+    const uint32_t cnt = m->qcount[i];
+    const uint32_t* cl = pool + m->qoff[i];
+    const float u = qx[i], v = qy[i];
+    int bestDist = INT_MAX, bestIdx = -1;
+    for (uint32_t c = 0; c < cnt; c++) {
+      const int idx = (int)(cl[c] & 0xffff), dist = (int)(cl[c] >> 16);
+      if (useOcc && occ[idx]) continue;
+      if (inv_level_sigma2) {   // ORBmatcher.cc:896-903
+        const float ex = u - kps_un[idx].x;
+        const float ey = v - kps_un[idx].y;
+        const float e2 = ex * ex + ey * ey;
+        if (e2 * inv_level_sigma2[kps_un[idx].octave] > chi2) continue;
+      }
+      if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+    }
+    if (bestDist <= max_dist) {
+      best_idx[i] = bestIdx;
+      if (best_dist) best_dist[i] = bestDist;
+      if (claim) occ[bestIdx] = 1;
+      nm++;
+    }
+  }
+  *nmatches = nm;
+  return ORBFE_OK;
+}
+
 }  // extern "C"

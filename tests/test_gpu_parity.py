@@ -412,3 +412,43 @@ def test_config5_4k_fisheye_search_by_projection(api, oracle):
         on, oa = oracle.search_by_projection(kun, d, bounds, sf, occ, mxy, level, viewcos, flags, mdesc, th, 0.8)
         assert n == on and (a == oa).all()
         assert n > 1000
+
+
+def test_search_projected_parity(api, oracle):
+    """The projected best-match loop of SearchByProjection(KeyFrame*, Scw, ...), Fuse x2 and SearchBySim3:
+    claim / skip semantics, Fuse's chi-square gate, TH_LOW / TH_HIGH."""
+    W, H, N = 1280, 720, 1500
+    img = synth(21, W, H)
+    ex = api.Extractor(N, 1.2, 8, 20, 7)
+    kps, desc = ex(img)
+    tab = ex.tables()
+    m = api.Matcher()
+    rng = np.random.default_rng(8)
+    NS = 4000
+    src = rng.integers(0, len(kps), NS)
+    sdesc = desc[src].copy()
+    for i in range(NS):
+        for b in rng.integers(0, 256, rng.integers(0, 45)):
+            sdesc[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    uv = (np.stack([kps['x'][src], kps['y'][src]], 1) + rng.normal(0, 2.5, (NS, 2))).astype(np.float32)
+    level = np.clip(kps['octave'][src] + rng.integers(-1, 2, NS), -1, 7).astype(np.int32)
+    valid = (rng.random(NS) < 0.93).astype(np.uint8)
+    bounds = (0.0, float(W), 0.0, float(H))
+    total = 0
+    for th, claim, skip, gate, maxd in [(4.0, True, True, False, 50), (3.0, False, False, True, 50), (2.5, False, False, False, 50),
+                                        (7.5, False, False, False, 100), (10.0, True, False, True, 100)]:
+        radius = (th * tab['sf'][np.clip(level, 0, 7)]).astype(np.float32)
+        kp_skip = (rng.random(len(kps)) < 0.2).astype(np.uint8) if skip else None
+        inv = tab['is2'] if gate else None
+        got = m.search_projected(kps, desc, bounds, uv, radius, level, valid, sdesc, kp_skip, claim, inv, 5.99, maxd)
+        want = oracle.search_projected(kps, desc, bounds, uv, radius, level, valid, sdesc, kp_skip, claim, inv, 5.99, maxd)
+        assert got[0] == want[0] and got[1].tobytes() == want[1].tobytes() and got[2].tobytes() == want[2].tobytes()
+        if claim:
+            acc = got[1][got[1] >= 0]
+            assert len(np.unique(acc)) == len(acc)          # a claimed keypoint is taken once
+        if kp_skip is not None:
+            assert not kp_skip[got[1][got[1] >= 0]].any()
+        total += got[0]
+    assert total > 3000
+    n, bi, bd = m.search_projected(kps, desc, bounds, uv[:0], uv[:0, 0], level[:0], valid[:0], sdesc[:0])
+    assert n == 0 and len(bi) == 0
