@@ -86,9 +86,15 @@ int orbfe_extractor_scale_tables(const orbfe_extractor* h, float* scale, float* 
                                  float* inv_sigma2);
 /* mnFeaturesPerLevel (src/ORBextractor.cc:467-478); nlevels ints. */
 int orbfe_extractor_features_per_level(const orbfe_extractor* h, int32_t* out);
-/* Upper bound on keypoints one frame can return: nfeatures + 2*nlevels (each level may overshoot
- * its quota by <= 2). Size `cap` with it. */
+/* Upper bound on keypoints one frame can return: sum over levels of max(N_l + 2, 16) -- a level overshoots its quota
+ * N_l by at most 2, but DistributeOctTree divides every root node once before it looks at N_l (src/ORBextractor.cc:
+ * 620-700), so a level with a tiny quota still returns up to 4 * roots keypoints (roots = round(width/height) <= 4
+ * for aspect ratios below 4.5; wider strips are reported with ORBFE_ERR_OVERFLOW if they exceed `cap`).  Equals
+ * nfeatures + 2*nlevels whenever every N_l >= 14.  Size `cap` with it. */
 int orbfe_extractor_max_keypoints(const orbfe_extractor* h);
+/* The same bound for a given image size (exact number of quadtree roots per level): needed only for strips wider
+ * than 4.5 : 1 or to size buffers tightly. */
+int orbfe_extractor_max_keypoints_for_size(const orbfe_extractor* h, int rows, int cols);
 
 /* Colour input (Tracking::GrabImageMonocular, src/Tracking.cc:96-109: cvtColor(RGB2GRAY / BGR2GRAY) on 3- and
  * 4-channel images before the Frame is built).  After this call `gray` in the extract calls points to interleaved

@@ -11,6 +11,7 @@
 // orbfe_last_error() because the reference has no channel to report it and continuing would
 // silently corrupt tracking.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -47,6 +48,7 @@ class Extractor {
                std::vector<uint8_t>& descriptors) {
     static_assert(sizeof(KeyPointT) == sizeof(OrbfeKeyPoint), "KeyPointT must match cv::KeyPoint's layout");
     if (!gray || rows == 0 || cols == 0) return;  // reference: silent return, outputs untouched
+    cap_ = std::max(cap_, orbfe_extractor_max_keypoints_for_size(h_, rows, cols));   // strips wider than 4.5 : 1
     kp_.resize(cap_);
     desc_.resize((size_t)cap_ * 32);
     int n = 0;

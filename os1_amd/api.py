@@ -86,6 +86,7 @@ def load_library():
                                          C.POINTER(ci)]
     L.orbfe_search_for_triangulation.argtypes = [vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, cf, cf,
                                                  vp, vp, ci, ci, vp, C.POINTER(ci)]
+    L.orbfe_extractor_max_keypoints_for_size.argtypes = [vp, ci, ci]
     L.orbfe_extractor_set_input_format.argtypes = [vp, ci, ci]
     L.orbfe_stream_set_input_format.argtypes = [vp, ci, ci]
     L.orbfe_vocabulary_create.argtypes = [ci, ci, ci, ci, ci, vp, ci, C.POINTER(vp)]
@@ -178,11 +179,12 @@ class Extractor:
             _check(self.L.orbfe_extract(self.h, None, 0, 0, 0, None, None, 0, C.byref(n)))
             return np.zeros(0, KP_DTYPE), np.zeros((0, 32), np.uint8)
         assert image.dtype == np.uint8 and image.ndim == 2 and image.strides[1] == 1
-        kps = np.zeros(self.cap, KP_DTYPE)
-        desc = np.zeros((self.cap, 32), np.uint8)
+        cap = max(self.cap, self.L.orbfe_extractor_max_keypoints_for_size(self.h, image.shape[0], image.shape[1]))
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
         n = C.c_int(0)
         _check(self.L.orbfe_extract(self.h, _p(image), image.shape[0], image.shape[1], image.strides[0], _p(kps),
-                                    _p(desc), self.cap, C.byref(n)))
+                                    _p(desc), cap, C.byref(n)))
         return kps[:n.value].copy(), desc[:n.value].copy()
 
     FORMATS = {'gray': 0, 'rgb': 1, 'bgr': 2, 'rgba': 3, 'bgra': 4}

@@ -178,6 +178,8 @@ struct orbfe_extractor {
   size_t candHostCap = 0;
   // GPU quadtree path (default): everything from the frame to descriptors in one stream submission
   bool gpuQuadtree = true;
+  int kpPerFrameCap = 0;     // internal per-frame keypoint capacity of the result arena (set by setGeometry)
+  bool geomGpuQtOk = true;   // every level of the current image size has 1..4 quadtree roots (aspect ratio < 4.5)
   QtParams QP{};
   int selOff[kMaxLevels + 1] = {};
   int selPerFrame = 0;
@@ -274,6 +276,8 @@ struct orbfe_extractor {
       set_err("image %dx%d exceeds the 4095-pixel coordinate packing limit", c, r);
       return ORBFE_ERR_INVALID;
     }
+    bool qtOk = true;
+    int kpSum = 8;
     PyramidParams Q{};
     Q.nlevels = nlevels;
     Q.iniTh = iniTh;
@@ -295,6 +299,11 @@ struct orbfe_extractor {
       }
       L.wCell = (int)std::ceil(width / L.nCols);
       L.hCell = (int)std::ceil(height / L.nRows);
+      {   // root nodes of DistributeOctTree (ORBextractor.cc:574-578); k_quadtree2 holds up to 4 of them
+        const int nIni = (int)roundf(static_cast<float>(L.w - 2 * kBorder) / (L.h - 2 * kBorder));
+        if (nIni < 1 || nIni > 4) qtOk = false;
+        kpSum += std::max(nfeat[l] + 4, 4 * std::max(nIni, 4));
+      }
       L.cellBase = cellBase;
       cellBase += L.nCols * L.nRows;
       L.slotCap = ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2);
@@ -391,6 +400,13 @@ struct orbfe_extractor {
     Q.cells = d_cells.p;
     P = Q;
     rows = r;
+    geomGpuQtOk = qtOk;
+    // keypoints one frame can yield: a level returns at most max(N_l + 2, 4 * roots) (ORBextractor.cc:620-773)
+    const int kpCap = std::max(kpSum, selPerFrame);
+    if (kpCap > kpPerFrameCap) {
+      kpPerFrameCap = kpCap;
+      batchCap = 0;   // the result arena is carved again
+    }
     cols = c;
     batchCap = 0;
     return ORBFE_OK;
@@ -414,13 +430,13 @@ struct orbfe_extractor {
       if ((rc = d_cand.ensure((size_t)P.candCap * nframes))) return rc;
       if ((rc = d_frame0.ensure(2 * (size_t)nframes))) return rc;   // [gray level-0 pointers][raw colour pointers]
       if ((rc = h_frame0.ensure(2 * (size_t)nframes))) return rc;
-      const size_t maxKp = (size_t)(nfeatures + 4 * nlevels + 8) * nframes;  // >= selPerFrame * nframes
+      const size_t maxKp = (size_t)kpPerFrameCap * nframes;  // >= selPerFrame * nframes
       {
         auto al256 = [](size_t v) { return (v + 255) & ~(size_t)255; };
         const size_t oLs = 0, oSc = oLs + al256(sizeof(uint32_t) * (kMaxLevels + 1) * nframes),
                      oSel = oSc + al256(sizeof(uint32_t) * kMaxLevels * nframes), oAng = oSel + al256(sizeof(SelKp) * maxKp),
                      oDesc = oAng + al256(sizeof(float) * maxKp), oM12 = oDesc + al256(32 * maxKp),
-                     oNm = oM12 + al256(sizeof(int32_t) * (size_t)(nfeat[0] + 4) * nframes), total = oNm + al256(sizeof(int32_t) * nframes);
+                     oNm = oM12 + al256(sizeof(int32_t) * (size_t)(selOff[1] - selOff[0]) * nframes), total = oNm + al256(sizeof(int32_t) * nframes);
         if ((rc = d_outArena.ensure(total))) return rc;
         if ((rc = h_outArena.ensure(total))) return rc;
         outArenaBytes = total;
@@ -508,6 +524,11 @@ struct orbfe_extractor {
     HIP_TRY(hipSetDevice(device));
     int rc;
     if ((rc = setGeometry(r, c))) return rc;
+    if (!geomGpuQtOk) {
+      set_err("image %dx%d: a pyramid level has more than 4 (or no) quadtree root nodes; only the blocking "
+              "orbfe_extract / orbfe_extract_batch calls (host quadtree path) handle such aspect ratios", c, r);
+      return ORBFE_ERR_INVALID;
+    }
     if ((rc = setBatch(nframes, !onDevice, stride))) return rc;
     const double t0 = now_ms();
     hipStream_t st = streams[0];
@@ -737,7 +758,7 @@ struct orbfe_extractor {
     }
     if (inChannels() != 1) { set_err("colour input needs the GPU quadtree path (unset ORBFE_HOST_QUADTREE)"); return ORBFE_ERR_INVALID; }
     const int nsub = std::min(nframes, std::min(kMaxSub, std::max(1, subBatches)));
-    const int maxKp = nfeatures + 2 * nlevels;
+    const int maxKp = kpPerFrameCap;
     if ((rc = ensureSubStreams(nsub))) return rc;
     int subF0[kMaxSub + 1];
     for (int s = 0; s <= nsub; s++) subF0[s] = (int)((long long)nframes * s / nsub);
@@ -1050,13 +1071,12 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
   h->selPerFrame = 0;
   for (int l = 0; l < nlevels; l++) {
     h->selOff[l] = h->selPerFrame;
-    h->selPerFrame += h->nfeat[l] + 4;
-    if (h->gpuQuadtree && h->nfeat[l] + 4 > kQtNodeCap) {
-      set_err("nfeatures=%d puts %d features on level %d; the GPU quadtree handles at most %d per level "
-              "(set ORBFE_HOST_QUADTREE=1 for the host quadtree)", nfeatures, h->nfeat[l], l, kQtNodeCap - 4);
-      delete h;
-      return ORBFE_ERR_INVALID;
-    }
+    // a level returns at most max(N_l + 2, 4 * roots) keypoints: the first sweep of DistributeOctTree divides every root
+    // before any size check (ORBextractor.cc:620-700), later ones overshoot N_l by at most 2; roots <= 4 on this path
+    h->selPerFrame += std::max(h->nfeat[l] + 4, 16);
+    // k_quadtree2 holds at most kQtNodeCap - 4 features per level; beyond that the handle uses the host quadtree
+    // (blocking orbfe_extract / orbfe_extract_batch only, like ORBFE_HOST_QUADTREE=1)
+    if (h->nfeat[l] + 4 > kQtNodeCap) h->gpuQuadtree = false;
   }
   h->selOff[nlevels] = h->selPerFrame;
   // host workers for the per-(frame, level) quadtrees: ORBFE_HOST_THREADS, default min(cores, 16)
@@ -1087,7 +1107,24 @@ int orbfe_extractor_features_per_level(const orbfe_extractor* h, int32_t* out) {
   for (int i = 0; i < h->nlevels; i++) out[i] = h->nfeat[i];
   return ORBFE_OK;
 }
-int orbfe_extractor_max_keypoints(const orbfe_extractor* h) { return h ? h->nfeatures + 2 * h->nlevels : 0; }
+int orbfe_extractor_max_keypoints(const orbfe_extractor* h) {
+  if (!h) return 0;
+  int n = 0;   // per level max(N_l + 2, 4 * roots) with up to 4 roots (aspect ratio < 4.5); == nfeatures + 2 * nlevels when N_l >= 14
+  for (int l = 0; l < h->nlevels; l++) n += std::max(h->nfeat[l] + 2, 16);
+  return n;
+}
+
+int orbfe_extractor_max_keypoints_for_size(const orbfe_extractor* h, int rows, int cols) {
+  if (!h || rows <= 0 || cols <= 0) return 0;
+  int n = 0;
+  for (int l = 0; l < h->nlevels; l++) {
+    const int w = cv_round_f((float)cols * h->isf[l]), hh = cv_round_f((float)rows * h->isf[l]);
+    int roots = hh > 2 * kBorder ? (int)roundf(static_cast<float>(w - 2 * kBorder) / (hh - 2 * kBorder)) : 0;
+    if (roots < 0) roots = 0;
+    n += std::max(h->nfeat[l] + 2, 4 * roots);
+  }
+  return n;
+}
 
 int orbfe_extract_batch(orbfe_extractor* h, int nframes, const uint8_t* const* gray, int in_device_memory, int rows,
                         int cols, size_t stride_bytes, OrbfeKeyPoint* kps, uint8_t* desc, int cap, int* n_out) {
@@ -1099,7 +1136,13 @@ int orbfe_extract_batch(orbfe_extractor* h, int nframes, const uint8_t* const* g
     set_err("invalid image / output arguments");
     return ORBFE_ERR_INVALID;
   }
-  if (h->gpuQuadtree) return h->runGpuQt(nframes, gray, in_device_memory != 0, rows, cols, stride_bytes, kps, desc, cap, n_out);
+  {
+    HIP_TRY(hipSetDevice(h->device));
+    const int rc = h->setGeometry(rows, cols);
+    if (rc) return rc;
+  }
+  if (h->gpuQuadtree && h->geomGpuQtOk)
+    return h->runGpuQt(nframes, gray, in_device_memory != 0, rows, cols, stride_bytes, kps, desc, cap, n_out);
   return h->run(nframes, gray, in_device_memory != 0, rows, cols, stride_bytes, kps, desc, cap, n_out);
 }
 

@@ -108,6 +108,20 @@ def test_other_parameters(api, oracle):
         _cmp_extract(api.Extractor(N, sf, nl, ini, mn)(img), OracleExtractor(N, sf, nl, ini, mn, oracle).extract(img))
 
 
+def test_tiny_quotas_and_wide_strips(api, oracle):
+    """DistributeOctTree divides every root once before it looks at N (ORBextractor.cc:620-700): with a quota of 1-3
+    features a level still returns up to 4 * roots keypoints -- more than nfeatures in total; strips wider than 4.5 : 1
+    (more than 4 roots) take the host-quadtree path, also with a tiny quota."""
+    for (W, H, N, nl) in [(1920, 1080, 20, 8), (640, 480, 9, 8), (1600, 500, 16, 8), (1167, 252, 72, 5), (900, 120, 500, 2)]:
+        img = synth(5, W, H)
+        ex = api.Extractor(N, 1.2, nl, 20, 7)
+        want = OracleExtractor(N, 1.2, nl, 20, 7, oracle).extract(img)
+        got = ex(img)
+        _cmp_extract(got, want)
+        assert len(want[0]) <= ex.L.orbfe_extractor_max_keypoints_for_size(ex.h, H, W)
+    assert len(want[0]) > 0
+
+
 def test_edge_cases(api, oracle):
     ex = api.Extractor(500, 1.2, 8, 20, 7)
     k, d = ex(np.zeros((0, 0), np.uint8))                       # empty image: silent, no output
@@ -452,3 +466,35 @@ def test_search_projected_parity(api, oracle):
     assert total > 3000
     n, bi, bd = m.search_projected(kps, desc, bounds, uv[:0], uv[:0, 0], level[:0], valid[:0], sdesc[:0])
     assert n == 0 and len(bi) == 0
+
+
+def test_randomised_sizes_and_parameters(api, oracle):
+    """Seeded sweep over image sizes (odd widths, narrow strips, level-0 strides that are not multiples of 4), pyramid
+    shapes (wide strips with more than 4 quadtree roots take the host-quadtree path) and thresholds -- including
+    iniThFAST < minThFAST, where the reference's second cv::FAST call sees FEWER
+    corners than the first (ORBextractor.cc:846-856) -- and low-texture images where most cells need the second pass."""
+    rng = np.random.default_rng(2024)
+    for it in range(14):
+        W = int(rng.integers(97, 900))
+        H = min(int(rng.integers(97, 700)), int(1.7 * W))     # taller than 2:1 has no quadtree root (reference: division by zero)
+        N = int(rng.integers(30, 1500))
+        sf = float(rng.choice([1.1, 1.2, 1.3, 1.5]))
+        nl = int(rng.integers(1, 9))
+        ini, mn = [(20, 7), (7, 20), (12, 12), (40, 5), (9, 3)][it % 5]
+        while min(W, H) / sf ** (nl - 1) < 66:           # every level must hold at least one 30-px FAST cell inside the border
+            nl -= 1
+        img = synth(500 + it, W, H)
+        if it % 3 == 1:                                    # low texture: flatten contrast so iniTh finds little
+            img = (128 + (img.astype(np.int32) - 128) // 6).astype(np.uint8)
+        if it % 4 == 2:                                    # a constant block: cells with no corner at any threshold
+            img[: H // 2, : W // 2] = 90
+        ex = api.Extractor(N, sf, nl, ini, mn)
+        ox = OracleExtractor(N, sf, nl, ini, mn, oracle)
+        want = ox.extract(img)
+        _cmp_extract(ex(img), want)
+        # the same frame through the batch path with a padded device stride
+        stride = W + int(rng.integers(0, 3))
+        dev = api.DeviceFrames([img, img[::-1].copy()], 0, stride=stride)
+        kps, desc, n = ex.extract_batch_ptrs(dev.ptrs, H, W, stride, True)
+        _cmp_extract((kps[0, :n[0]], desc[0, :n[0]]), want)
+        _cmp_extract((kps[1, :n[1]], desc[1, :n[1]]), ox.extract(img[::-1].copy()))

@@ -1,0 +1,46 @@
+"""Exploratory parity sweep (GPU box): random sizes / parameters, product vs oracle.  usage: sweep_debug.py seed count"""
+import sys
+sys.path.insert(0, '.')
+import numpy as np
+from os1_amd import api
+from os1_amd.synth import synth
+from oracle.pyoracle import Oracle, OracleExtractor
+
+seed, count = int(sys.argv[1]), int(sys.argv[2])
+oracle = Oracle()
+rng = np.random.default_rng(seed)
+bad = 0
+for it in range(count):
+    W = int(rng.integers(97, 1400))
+    H = min(int(rng.integers(97, 1000)), int(1.7 * W))
+    N = int(rng.integers(30, 3000))
+    sf = float(rng.choice([1.1, 1.2, 1.25, 1.3, 1.5, 2.0]))
+    nl = int(rng.integers(1, 9))
+    ini, mn = [(20, 7), (7, 20), (12, 12), (40, 5), (9, 3), (100, 60), (1, 1)][it % 7]
+    while min(W, H) / sf ** (nl - 1) < 66:
+        nl -= 1
+    if any(round((W / sf ** l - 32) / (H / sf ** l - 32)) < 1 for l in range(nl)):
+        print(it, 'skipped: a level has no quadtree root (the reference divides by zero)')
+        continue
+    img = synth(seed * 1000 + it, W, H)
+    mode = int(rng.integers(0, 5))
+    if mode == 1:
+        img = (128 + (img.astype(np.int32) - 128) // 6).astype(np.uint8)
+    if mode == 2:
+        img[: H // 2, : W // 2] = 90
+    if mode == 3:
+        img = rng.integers(0, 256, img.shape, dtype=np.uint8)          # pure noise: a corner almost everywhere
+    if mode == 4:
+        img = np.clip(img.astype(np.int32) * 3 - 200, 0, 255).astype(np.uint8)   # saturated
+    try:
+        ex = api.Extractor(N, sf, nl, ini, mn)
+    except api.OrbfeError as e:
+        print(it, 'create refused:', e)
+        continue
+    ox = OracleExtractor(N, sf, nl, ini, mn, oracle)
+    wk, wd = ox.extract(img)
+    gk, gd = ex(img)
+    ok = gk.tobytes() == wk.tobytes() and gd.tobytes() == wd.tobytes()
+    print(it, W, H, N, sf, nl, ini, mn, mode, len(wk), 'OK' if ok else 'MISMATCH', flush=True)
+    bad += not ok
+print('mismatches', bad)
