@@ -348,6 +348,37 @@ def test_stream_runner_parity(api, oracle, mode, monkeypatch):
     st.close()
 
 
+@pytest.mark.parametrize('cfg', [(640, 480, 25, 8, 2), (1000, 300, 60, 4, 3), (333, 251, 300, 3, 2)])
+def test_stream_runner_small_quotas_and_odd_sizes(api, oracle, cfg):
+    """The streamed path (GPU quadtree, slot-mode descriptors, GPU SearchForInitialization chain) with tiny per-level
+    quotas (a level returns 4 x roots keypoints, more than its quota), 3-4 quadtree roots and odd image sizes."""
+    W, H, N, nl, B = cfg
+    base = synth(70 + W, W, H)
+    frames = [base] + [shifted(base, 2 * i, i, 700 + i) for i in range(1, 3 * B)]
+    dev = api.DeviceFrames(frames, 0)
+    st = api.Stream(N, 1.2, nl, 20, 7, 0, B, 2)
+    bounds = (0.0, float(W), 0.0, float(H))
+    st.set_matching(bounds, 60, 0.9, True)
+    ox = OracleExtractor(N, 1.2, nl, 20, 7, oracle)
+    want = [ox.extract(f) for f in frames]
+    for b in range(3):
+        st.push_ptrs(dev.ptrs[b * B:(b + 1) * B], H, W, dev.stride, True)
+    for b in range(3):
+        kps, desc, n, m12, nm = st.pop(copy=True)
+        for i in range(B):
+            g = b * B + i
+            wk, wd = want[g]
+            assert n[i] == len(wk)
+            assert kps[i, :n[i]].tobytes() == wk.tobytes() and desc[i, :n[i]].tobytes() == wd.tobytes()
+            if g == 0:
+                continue
+            pk, pd = want[g - 1]
+            on, om12, _ = oracle.search_for_initialization(pk, pd, wk, wd, bounds, np.stack([pk['x'], pk['y']], 1).reshape(-1, 2),
+                                                           60, 0.9, True)
+            assert nm[i] == on and (m12[i, :len(pk)] == om12).all()
+    st.close()
+
+
 def test_window_candidates_primitive(api, oracle):
     """orbfe_window_candidates: per query the GetFeaturesInArea list in reference order with Hamming distances
     (the GPU half of Fuse / SearchBySim3 / SearchByProjection(KeyFrame*, Scw, ...))."""
