@@ -2,8 +2,10 @@
 //
 // Behaviour contract: ORB_SLAM2::ORBextractor of the reference (src/ORBextractor.cc:442-502 ctor,
 // :907-969 operator(), :971-996 ComputePyramid, :797-895 ComputeKeyPointsOctTree).  The pixel work
-// runs in the kernels of orbfe_kernels.hip; the serial, order-defining quadtree runs on the host
-// (quadtree.h).  There is no CPU fallback for the kernels.
+// runs in the kernels of orbfe_kernels.hip, the order-defining quadtree in orbfe_quadtree.hip (one
+// stream submission per batch, submitGpuQt); a second, host-side quadtree (quadtree.h, run()) serves
+// geometries the kernel does not hold (more than 4 roots or 2044 features per level) and
+// ORBFE_HOST_QUADTREE=1.  There is no CPU fallback for the kernels.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

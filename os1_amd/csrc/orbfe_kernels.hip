@@ -3,12 +3,14 @@
 // All arithmetic that decides an output bit is integer, or float32 with contraction OFF
 // (build flag -ffp-contract=off) so it rounds like the reference's separate mul/add on x86-64.
 //
-//   k_resize        cv::resize INTER_LINEAR 8u (level l <- level l-1), 11-bit fixed point
-//   k_fast_cells    per reference FAST cell: score map + 3x3 NMS + iniTh/minTh fallback (1 wave/cell)
+//   k_to_gray       cv::cvtColor RGB/BGR(A) -> gray, 8u fixed point (colour input only)
+//   k_resize        cv::resize INTER_LINEAR 8u (level l <- level l-1), 11-bit fixed point, separable through LDS
+//   k_fast_cells    per reference FAST cell (1 wave/cell): iniTh pass, minTh pass only for cells left empty;
+//                   packed pre-test, exact score of the survivors, 3x3 NMS, ordered emission
 //   k_scan_cells    exclusive scan of per-cell counts -> reference candidate order
-//   k_gather        ordered compaction of the per-cell slots
-//   k_describe      per keypoint: IC-angle, 7x7 fixed-point Gaussian of the 37x37 neighbourhood,
-//                   steered BRIEF with __ballot packing (1 wave/keypoint)
+//   k_gather        ordered compaction of the per-cell slots (1 lane/cell)
+//   k_describe      per keypoint (1 wave): IC-angle (dot4), 7x7 fixed-point Gaussian of the 37x37 neighbourhood
+//                   (dot4 rows, dot2 columns), steered BRIEF with __ballot packing
 //   k_sincos        test hook for the device (cosf,sinf)
 #include <hip/hip_runtime.h>
 
