@@ -164,8 +164,10 @@ def main():
                        'parallelism': 'independent streams, 1 per GPU' if world > 1 else 'single GPU',
                        'matches_per_frame': round(nmatch_total[0] / max(B * args.steps, 1), 1),
                        'input': ('frames in %s host memory (PCIe-inclusive)' % args.host_input if args.host_input else 'frames resident in HBM') + '; keypoints/descriptors/matches returned to host'},
+            # HIP-event time of the kernels in the pipeline (they overlap other batches' kernels); only k_fast_cells is
+            # always timed (roofline), the others appear with ORBFE_PROFILE_KERNELS=1 (costs about 1 % of the rate)
             'gpu_kernel_ms_per_frame': {k: round(v / max(kframes, 1), 5) for k, v in
-                                        zip(('pyramid', 'fast_cells', 'compaction', 'describe', 'quadtree'), kms)},
+                                        zip(('pyramid', 'fast_cells', 'compaction', 'describe', 'quadtree'), kms) if v > 0},
             'ms_per_step_percentiles': (lambda d: {'p10': round(float(np.percentile(d, 10)), 4), 'p50': round(float(np.percentile(d, 50)), 4),
                                                     'p90': round(float(np.percentile(d, 90)), 4), 'max': round(float(d.max()), 4)})(np.diff(np.array(pop_times)) * 1e3) if len(pop_times) > 2 else None,
             'host_worker_ms_per_step': {'submit': round(wstats[0] / max(wstats[3], 1), 4), 'collect_incl_gpu_wait': round(wstats[1] / max(wstats[3], 1), 4),
