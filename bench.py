@@ -36,6 +36,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=32, help='frames per step and GPU')
     ap.add_argument('--cpu-frames', type=int, default=64, help='frames of the CPU-oracle baseline sample (0 = skip)')
+    ap.add_argument('--bow', action='store_true', help='also run Frame::ComputeBoW (k=10, L=6 synthetic vocabulary) behind the descriptor kernel (not the headline value)')
     ap.add_argument('--no-match', action='store_true', help='extract only (configs[1])')
     ap.add_argument('--host-input', nargs='?', const='pageable', default=None, choices=['pageable', 'pinned'],
                     help='frames start in HOST memory, pageable or page-locked (PCIe-inclusive rate; never the headline value)')
@@ -85,6 +86,10 @@ def main():
     st = api.Stream(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, local_rank, B, max(1, args.depth))
     bounds = (0.0, float(W), 0.0, float(H))
     st.set_matching(bounds, 0 if args.no_match else 100, 0.9, True)   # window 100, nnratio 0.9, checkOrientation
+    if args.bow:
+        from os1_amd.synth import synth_vocabulary
+        voc = api.Vocabulary(synth_vocabulary(1, 10, 6), local_rank)
+        st.set_vocabulary(voc, 4)
     nmatch_total = [0]
     pop_times = []
 
@@ -159,7 +164,7 @@ def main():
             'value': round(fps, 2), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
-            'config': {'workload': '1080p_2000feat_8lv_1.2_extract%s_stream' % ('' if args.no_match else '+SearchForInitialization'),
+            'config': {'workload': '1080p_2000feat_8lv_1.2_extract%s%s_stream' % ('' if args.no_match else '+SearchForInitialization', '+ComputeBoW' if args.bow else ''),
                        'frames_per_step_per_gpu': B, 'image': '%dx%d' % (W, H), 'nfeatures': NFEAT, 'nlevels': NLEVELS,
                        'parallelism': 'independent streams, 1 per GPU' if world > 1 else 'single GPU',
                        'matches_per_frame': round(nmatch_total[0] / max(B * args.steps, 1), 1),

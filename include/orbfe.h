@@ -46,6 +46,7 @@ typedef struct OrbfeKeyPoint {
 
 typedef struct orbfe_extractor orbfe_extractor;
 typedef struct orbfe_matcher orbfe_matcher;
+typedef struct orbfe_vocabulary orbfe_vocabulary;   /* bag-of-words section below */
 
 const char* orbfe_last_error(void);
 /* Number of visible HIP devices (0 if none / runtime unusable). Does not create a context. */
@@ -204,6 +205,11 @@ int orbfe_stream_set_matching(orbfe_stream* s, const float bounds[4], int window
                               int check_orientation);
 /* orbfe_extractor_set_input_format for every extractor of the runner (only while no batch is in flight). */
 int orbfe_stream_set_input_format(orbfe_stream* s, int format, int gray_variant);
+/* orbfe_extractor_set_vocabulary for every extractor of the runner (only while no batch is in flight); afterwards
+ * orbfe_stream_bow_raw returns, for frame `frame` of the LAST POPPED batch, the per-keypoint (leaf node, level node)
+ * pairs (pointers into the runner's buffers, valid until the next pop; feed them to orbfe_bow_assemble). */
+int orbfe_stream_set_vocabulary(orbfe_stream* s, orbfe_vocabulary* v, int levelsup);
+int orbfe_stream_bow_raw(orbfe_stream* s, int frame, const uint32_t** leaf_node, const uint32_t** level_node, int* n);
 /* Per-frame output capacity (keypoints) of the arrays returned by orbfe_stream_pop. */
 int orbfe_stream_capacity(const orbfe_stream* s);
 /* Enqueue one batch (`batch` frame pointers; device pointers if in_device_memory != 0).  Returns at once
@@ -354,8 +360,6 @@ int orbfe_distinctive_descriptors(orbfe_matcher* m, int n_mp, const int32_t* off
  * (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:1136-1204, descent :1306-1347), and the two
  * ORBmatcher::SearchByBoW overloads (src/ORBmatcher.cc:154-283, 517-650).
  * ------------------------------------------------------------------------------------------- */
-typedef struct orbfe_vocabulary orbfe_vocabulary;
-
 /* Vocabulary from the fork's binary file (loadFromBinaryFile, TemplatedVocabulary.h:1563-1640): 4 header bytes
  * {k, L, scoring, weighting} followed by 45-byte node records {int32 parent, u8 isLeaf, u8 descriptor[32],
  * f64 weight} (packed, little endian).  Node ids count from 1 in record order (0 = root), children keep record
@@ -380,6 +384,25 @@ int orbfe_vocabulary_info(const orbfe_vocabulary* v, int* k, int* L, int* scorin
 int orbfe_bow_transform(orbfe_vocabulary* v, const uint8_t* desc, int n, int in_device_memory, int levelsup,
                         uint32_t* bow_ids, double* bow_values, int* n_words, uint32_t* fv_nodes, uint32_t* fv_offsets,
                         uint32_t* fv_features, int* n_fv_nodes, uint32_t* word_of_feature, uint32_t* node_of_feature);
+
+/* Frame::ComputeBoW fused into the extractor: with a vocabulary set, every extract call also runs the tree descent on
+ * the descriptors while they are still in HBM (right behind the descriptor kernel, same stream) and keeps the per-
+ * keypoint (word, node) pairs of the last collected batch.  orbfe_extract_bow then returns frame `frame` of that batch
+ * in the layout of orbfe_bow_transform -- identical results, no descriptor round trip.  v = NULL switches it off.
+ * The vocabulary must outlive the extractor's use of it and live on the same device. */
+int orbfe_extractor_set_vocabulary(orbfe_extractor* h, orbfe_vocabulary* v, int levelsup);
+int orbfe_extract_bow(orbfe_extractor* h, int frame, uint32_t* bow_ids, double* bow_values, int* n_words, uint32_t* fv_nodes,
+                      uint32_t* fv_offsets, uint32_t* fv_features, int* n_fv_nodes, uint32_t* word_of_feature,
+                      uint32_t* node_of_feature);
+
+/* The two halves of orbfe_extract_bow, for callers that keep many frames and build the vectors later (the stream runner
+ * hands out the raw pairs): per keypoint the leaf node its descriptor reached and the node `levelsup` levels above it
+ * (cap entries are written, *n_out = the frame's keypoint count); orbfe_bow_assemble turns such pairs into the BowVector /
+ * FeatureVector (host bookkeeping only, no GPU work). */
+int orbfe_extract_bow_raw(orbfe_extractor* h, int frame, uint32_t* leaf_node, uint32_t* level_node, int cap, int* n_out);
+int orbfe_bow_assemble(orbfe_vocabulary* v, const uint32_t* leaf_node, const uint32_t* level_node, int n, uint32_t* bow_ids,
+                       double* bow_values, int* n_words, uint32_t* fv_nodes, uint32_t* fv_offsets, uint32_t* fv_features,
+                       int* n_fv_nodes, uint32_t* word_of_feature);
 
 /* int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, vector<MapPoint*>& vpMapPointMatches)  (ORBmatcher.cc:154-283;
  * strict_threshold = 0, valid2 = NULL) and int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2,

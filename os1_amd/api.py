@@ -87,6 +87,12 @@ def load_library():
     L.orbfe_search_for_triangulation.argtypes = [vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, cf, cf,
                                                  vp, vp, ci, ci, vp, C.POINTER(ci)]
     L.orbfe_extractor_max_keypoints_for_size.argtypes = [vp, ci, ci]
+    L.orbfe_extractor_set_vocabulary.argtypes = [vp, vp, ci]
+    L.orbfe_extract_bow_raw.argtypes = [vp, ci, vp, vp, ci, C.POINTER(ci)]
+    L.orbfe_bow_assemble.argtypes = [vp, vp, vp, ci, vp, vp, C.POINTER(ci), vp, vp, vp, C.POINTER(ci), vp]
+    L.orbfe_stream_set_vocabulary.argtypes = [vp, vp, ci]
+    L.orbfe_stream_bow_raw.argtypes = [vp, ci, C.POINTER(vp), C.POINTER(vp), C.POINTER(ci)]
+    L.orbfe_extract_bow.argtypes = [vp, ci, vp, vp, C.POINTER(ci), vp, vp, vp, C.POINTER(ci), vp, vp]
     L.orbfe_extractor_set_input_format.argtypes = [vp, ci, ci]
     L.orbfe_stream_set_input_format.argtypes = [vp, ci, ci]
     L.orbfe_vocabulary_create.argtypes = [ci, ci, ci, ci, ci, vp, ci, C.POINTER(vp)]
@@ -202,6 +208,26 @@ class Extractor:
         _check(self.L.orbfe_extract(self.h, _p(image), image.shape[0], image.shape[1], image.strides[0], _p(kps),
                                     _p(desc), self.cap, C.byref(n)))
         return kps[:n.value].copy(), desc[:n.value].copy()
+
+    def set_vocabulary(self, voc, levelsup=4):
+        """Fuse Frame::ComputeBoW behind the descriptor kernel (voc: api.Vocabulary or None)."""
+        self._voc = voc                                  # keep it alive
+        _check(self.L.orbfe_extractor_set_vocabulary(self.h, voc.h if voc is not None else None, levelsup))
+
+    def bow(self, frame, n):
+        """BoW of frame `frame` of the last collected batch (n = its keypoint count), layout of Vocabulary.transform."""
+        ids = np.zeros(max(n, 1), np.uint32)
+        vals = np.zeros(max(n, 1), np.float64)
+        fvn = np.zeros(max(n, 1), np.uint32)
+        fvo = np.zeros(n + 1, np.uint32)
+        fvf = np.zeros(max(n, 1), np.uint32)
+        wof = np.zeros(max(n, 1), np.uint32)
+        nof = np.zeros(max(n, 1), np.uint32)
+        nw, nn = C.c_int(0), C.c_int(0)
+        _check(self.L.orbfe_extract_bow(self.h, frame, _p(ids), _p(vals), C.byref(nw), _p(fvn), _p(fvo), _p(fvf), C.byref(nn),
+                                        _p(wof), _p(nof)))
+        nw, nn = nw.value, nn.value
+        return ids[:nw], vals[:nw], (fvn[:nn], fvo[:nn + 1], fvf[:int(fvo[nn])]), wof[:n], nof[:n]
 
     def extract_batch_ptrs(self, ptrs, rows, cols, stride, on_device, kps=None, desc=None):
         """ptrs: sequence of raw addresses (host or device).  Returns (kps[B,cap], desc[B,cap,32], n[B])."""
@@ -531,6 +557,23 @@ class Vocabulary:
         _check(self.L.orbfe_vocabulary_info(self.h, *[C.byref(x) for x in v]))
         return dict(zip(('k', 'L', 'scoring', 'weighting', 'n_nodes', 'n_words'), [x.value for x in v]))
 
+    def assemble(self, leaf, node):
+        """BowVector / FeatureVector from per-keypoint (leaf node, level node) pairs (Stream.bow_raw / orbfe_extract_bow_raw)."""
+        leaf = np.ascontiguousarray(leaf, np.uint32)
+        node = np.ascontiguousarray(node, np.uint32)
+        n = len(leaf)
+        ids = np.zeros(max(n, 1), np.uint32)
+        vals = np.zeros(max(n, 1), np.float64)
+        fvn = np.zeros(max(n, 1), np.uint32)
+        fvo = np.zeros(n + 1, np.uint32)
+        fvf = np.zeros(max(n, 1), np.uint32)
+        wof = np.zeros(max(n, 1), np.uint32)
+        nw, nn = C.c_int(0), C.c_int(0)
+        _check(self.L.orbfe_bow_assemble(self.h, _p(leaf), _p(node), n, _p(ids), _p(vals), C.byref(nw), _p(fvn), _p(fvo), _p(fvf),
+                                         C.byref(nn), _p(wof)))
+        nw, nn = nw.value, nn.value
+        return ids[:nw], vals[:nw], (fvn[:nn], fvo[:nn + 1], fvf[:int(fvo[nn])]), wof[:n], node[:n]
+
     def transform(self, desc, levelsup=4):
         """-> (bow_ids, bow_values, (fv_nodes, fv_offsets, fv_features), word_of_feature, node_of_feature)"""
         desc = np.ascontiguousarray(desc, np.uint8)
@@ -651,6 +694,20 @@ class Stream:
     def set_matching(self, bounds, window=100, nnratio=0.9, check_ori=True):
         b = np.asarray(bounds, np.float32)
         _check(self.L.orbfe_stream_set_matching(self.h, _p(b), window, nnratio, int(check_ori)))
+
+    def set_vocabulary(self, voc, levelsup=4):
+        self._voc = voc
+        _check(self.L.orbfe_stream_set_vocabulary(self.h, voc.h if voc is not None else None, levelsup))
+
+    def bow_raw(self, frame):
+        """(leaf, node) arrays of frame `frame` of the last popped batch (copies)."""
+        pl, pn, n = C.c_void_p(), C.c_void_p(), C.c_int(0)
+        _check(self.L.orbfe_stream_bow_raw(self.h, frame, C.byref(pl), C.byref(pn), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, np.uint32), np.zeros(0, np.uint32)
+        leaf = np.ctypeslib.as_array(C.cast(pl, C.POINTER(C.c_uint32)), shape=(n.value,)).copy()
+        node = np.ctypeslib.as_array(C.cast(pn, C.POINTER(C.c_uint32)), shape=(n.value,)).copy()
+        return leaf, node
 
     def push_ptrs(self, ptrs, rows, cols, stride, on_device=True):
         assert len(ptrs) == self.batch

@@ -247,8 +247,78 @@ struct orbfe_vocabulary {
   DevBuf<uint2> d_out;
   PinBuf<uint2> h_out;
   hipStream_t stream = nullptr;
-  std::vector<std::pair<uint32_t, uint32_t>> tmp;
 };
+
+namespace orbfe {
+// BowVector / FeatureVector of n descriptors from their (leaf node, node at the FeatureVector level) pairs, in the
+// reference's order (TemplatedVocabulary.h:1155-1203).  Host bookkeeping shared by orbfe_bow_transform and the
+// extractor's fused path.
+int bow_assemble(orbfe_vocabulary* v, const uint2* ln, int n, uint32_t* bow_ids, double* bow_values, int* n_words,
+                 uint32_t* fv_nodes, uint32_t* fv_offsets, uint32_t* fv_features, int* n_fv_nodes,
+                 uint32_t* word_of_feature, uint32_t* node_of_feature) {
+  *n_words = 0;
+  *n_fv_nodes = 0;
+  fv_offsets[0] = 0;
+  // ---- BowVector / FeatureVector in the reference's order (TemplatedVocabulary.h:1155-1203) ----
+  const bool tf = v->weighting == 0 || v->weighting == 1;   // TF_IDF, TF: weights add up; IDF, BINARY: first one stays
+  std::vector<std::pair<uint32_t, uint32_t>> key;   // local: several extractor handles may share one vocabulary
+  key.reserve(n);
+  for (int i = 0; i < n; i++) {
+    const uint32_t leaf = ln[i].x;
+    if (word_of_feature) word_of_feature[i] = v->word[leaf];
+    if (node_of_feature) node_of_feature[i] = ln[i].y;
+    if (v->weight[leaf] > 0) key.emplace_back(v->word[leaf], (uint32_t)i);   // "not stopped"
+  }
+  std::sort(key.begin(), key.end());   // by word, then feature index: the order std::map accumulation sees
+  int nw = 0;
+  for (size_t a = 0; a < key.size();) {
+    size_t b = a;
+    double w = 0;
+    for (; b < key.size() && key[b].first == key[a].first; b++) {
+      const double wi = v->weight[ln[key[b].second].x];
+      if (b == a) w = wi;
+      else if (tf) w += wi;
+    }
+    bow_ids[nw] = key[a].first;
+    bow_values[nw] = w;
+    nw++;
+    a = b;
+  }
+  const bool must = v->scoring != 5;   // every scoring but DOT_PRODUCT normalises (ScoringObject.h:73-90)
+  if (tf && nw > 0 && !must) {
+    const double nd = nw;
+    for (int i = 0; i < nw; i++) bow_values[i] /= nd;
+  }
+  if (must) {   // BowVector::normalize, BowVector.cpp:60-82
+    double norm = 0.0;
+    if (v->scoring != 1) { for (int i = 0; i < nw; i++) norm += fabs(bow_values[i]); }
+    else { for (int i = 0; i < nw; i++) norm += bow_values[i] * bow_values[i]; norm = sqrt(norm); }
+    if (norm > 0.0) for (int i = 0; i < nw; i++) bow_values[i] /= norm;
+  }
+  *n_words = nw;
+  for (auto& e : key) e.first = ln[e.second].y;
+  std::sort(key.begin(), key.end());   // by node, then feature index (push_back order)
+  int nn = 0;
+  for (size_t a = 0; a < key.size(); a++) {
+    if (a == 0 || key[a].first != key[a - 1].first) { fv_nodes[nn] = key[a].first; fv_offsets[nn] = (uint32_t)a; nn++; }
+    fv_features[a] = key[a].second;
+  }
+  fv_offsets[nn] = (uint32_t)key.size();
+  *n_fv_nodes = nn;
+  return ORBFE_OK;
+}
+
+// Enqueue the tree descent of n descriptors that already live in device memory (32-byte rows) on `st`.
+int bow_launch_descend(orbfe_vocabulary* v, const uint8_t* d_desc, int n, int levelsup, uint2* d_out, hipStream_t st) {
+  if (n <= 0) return ORBFE_OK;
+  const int blocks = (int)(((size_t)n * 16 + 255) / 256);
+  hipLaunchKernelGGL(k_bow_descend, dim3(blocks), dim3(256), 0, st, (const uint4*)d_desc, n, v->d_childBegin.p,
+                     v->d_childCount.p, v->d_slotNode.p, v->d_slotDesc.p, v->L - levelsup, v->maxDepth, d_out);
+  HIP_TRY(hipGetLastError());
+  return ORBFE_OK;
+}
+int bow_device(const orbfe_vocabulary* v) { return v->device; }
+}  // namespace orbfe
 
 extern "C" {
 
@@ -320,6 +390,23 @@ int orbfe_vocabulary_create_from_image(int device_id, const void* image, size_t 
   return orbfe_vocabulary_create(device_id, b[0], b[1], b[2], b[3], b + 4, (int)((bytes - 4) / kRecord), out);
 }
 
+int orbfe_bow_assemble(orbfe_vocabulary* v, const uint32_t* leaf_node, const uint32_t* level_node, int n, uint32_t* bow_ids,
+                       double* bow_values, int* n_words, uint32_t* fv_nodes, uint32_t* fv_offsets, uint32_t* fv_features,
+                       int* n_fv_nodes, uint32_t* word_of_feature) {
+  if (!v || n < 0 || (n > 0 && (!leaf_node || !level_node)) || !bow_ids || !bow_values || !n_words || !fv_nodes || !fv_offsets ||
+      !fv_features || !n_fv_nodes) {
+    set_err("bad argument");
+    return ORBFE_ERR_INVALID;
+  }
+  std::vector<uint2> ln(n);
+  for (int i = 0; i < n; i++) {
+    if (leaf_node[i] >= (uint32_t)v->nNodes) { set_err("feature %d: node id out of range", i); return ORBFE_ERR_INVALID; }
+    ln[i] = make_uint2(leaf_node[i], level_node[i]);
+  }
+  return orbfe::bow_assemble(v, ln.data(), n, bow_ids, bow_values, n_words, fv_nodes, fv_offsets, fv_features, n_fv_nodes,
+                             word_of_feature, nullptr);
+}
+
 void orbfe_vocabulary_destroy(orbfe_vocabulary* v) {
   if (!v) return;
   (void)hipSetDevice(v->device);
@@ -372,53 +459,8 @@ int orbfe_bow_transform(orbfe_vocabulary* v, const uint8_t* desc, int n, int in_
   HIP_TRY(hipMemcpyAsync(v->h_out.p, v->d_out.p, sizeof(uint2) * n, hipMemcpyDeviceToHost, v->stream));
   HIP_TRY(hipStreamSynchronize(v->stream));
 
-  // ---- BowVector / FeatureVector in the reference's order (TemplatedVocabulary.h:1155-1203) ----
-  const bool tf = v->weighting == 0 || v->weighting == 1;   // TF_IDF, TF: weights add up; IDF, BINARY: first one stays
-  auto& key = v->tmp;
-  key.clear();
-  for (int i = 0; i < n; i++) {
-    const uint32_t leaf = v->h_out.p[i].x;
-    if (word_of_feature) word_of_feature[i] = v->word[leaf];
-    if (node_of_feature) node_of_feature[i] = v->h_out.p[i].y;
-    if (v->weight[leaf] > 0) key.emplace_back(v->word[leaf], (uint32_t)i);   // "not stopped"
-  }
-  std::sort(key.begin(), key.end());   // by word, then feature index: the order std::map accumulation sees
-  int nw = 0;
-  for (size_t a = 0; a < key.size();) {
-    size_t b = a;
-    double w = 0;
-    for (; b < key.size() && key[b].first == key[a].first; b++) {
-      const double wi = v->weight[v->h_out.p[key[b].second].x];
-      if (b == a) w = wi;
-      else if (tf) w += wi;
-    }
-    bow_ids[nw] = key[a].first;
-    bow_values[nw] = w;
-    nw++;
-    a = b;
-  }
-  const bool must = v->scoring != 5;   // every scoring but DOT_PRODUCT normalises (ScoringObject.h:73-90)
-  if (tf && nw > 0 && !must) {
-    const double nd = nw;
-    for (int i = 0; i < nw; i++) bow_values[i] /= nd;
-  }
-  if (must) {   // BowVector::normalize, BowVector.cpp:60-82
-    double norm = 0.0;
-    if (v->scoring != 1) { for (int i = 0; i < nw; i++) norm += fabs(bow_values[i]); }
-    else { for (int i = 0; i < nw; i++) norm += bow_values[i] * bow_values[i]; norm = sqrt(norm); }
-    if (norm > 0.0) for (int i = 0; i < nw; i++) bow_values[i] /= norm;
-  }
-  *n_words = nw;
-  for (auto& e : key) e.first = v->h_out.p[e.second].y;
-  std::sort(key.begin(), key.end());   // by node, then feature index (push_back order)
-  int nn = 0;
-  for (size_t a = 0; a < key.size(); a++) {
-    if (a == 0 || key[a].first != key[a - 1].first) { fv_nodes[nn] = key[a].first; fv_offsets[nn] = (uint32_t)a; nn++; }
-    fv_features[a] = key[a].second;
-  }
-  fv_offsets[nn] = (uint32_t)key.size();
-  *n_fv_nodes = nn;
-  return ORBFE_OK;
+  return orbfe::bow_assemble(v, v->h_out.p, n, bow_ids, bow_values, n_words, fv_nodes, fv_offsets, fv_features, n_fv_nodes,
+                             word_of_feature, node_of_feature);
 }
 
 }  // extern "C"

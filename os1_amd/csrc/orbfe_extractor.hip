@@ -39,6 +39,12 @@ void launch_sincos(const float* deg, int n, float* c, float* s, hipStream_t st);
 void launch_describe_slots(const PyramidParams& P, const SelKp* sel, int nslots, float* angle, uint8_t* desc,
                            const uint32_t* selCount, int selPerFrame, const int* selOff, hipStream_t st);
 void launch_quadtree(const QtParams& Q, int nframes, hipStream_t st);
+// orbfe_bow.hip
+int bow_launch_descend(orbfe_vocabulary* v, const uint8_t* d_desc, int n, int levelsup, uint2* d_out, hipStream_t st);
+int bow_assemble(orbfe_vocabulary* v, const uint2* ln, int n, uint32_t* bow_ids, double* bow_values, int* n_words,
+                 uint32_t* fv_nodes, uint32_t* fv_offsets, uint32_t* fv_features, int* n_fv_nodes,
+                 uint32_t* word_of_feature, uint32_t* node_of_feature);
+int bow_device(const orbfe_vocabulary* v);
 void launch_sfi(const SfiParams& S, int nframes, hipStream_t st);
 void launch_sfi_carry(const SfiParams& S, int lastFrame, SelKp* cSel, float* cAngle, uint8_t* cDesc, uint32_t* cCount,
                       hipStream_t st);
@@ -180,6 +186,14 @@ struct orbfe_extractor {
   size_t candHostCap = 0;
   // GPU quadtree path (default): everything from the frame to descriptors in one stream submission
   bool gpuQuadtree = true;
+  // Frame::ComputeBoW fused behind k_describe (orbfe_extractor_set_vocabulary): the descent runs on the descriptors
+  // while they are still in HBM; (leaf, node) pairs of the last collected batch in keypoint order, per frame
+  orbfe_vocabulary* voc = nullptr;
+  int vocLevelsup = 4;
+  bool pendingBow = false;
+  DevBuf<uint2> d_bow;
+  PinBuf<uint2> h_bow;
+  std::vector<std::vector<uint2>> bowKp;
   int kpPerFrameCap = 0;     // internal per-frame keypoint capacity of the result arena (set by setGeometry)
   bool geomGpuQtOk = true;   // every level of the current image size has 1..4 quadtree roots (aspect ratio < 4.5)
   QtParams QP{};
@@ -622,6 +636,13 @@ struct orbfe_extractor {
     launch_describe_slots(P, d_sel.p, nslots, d_angle.p, d_desc.p, d_selCount.p, selPerFrame, selOff, st);
     if (prof) HIP_TRY(hipEventRecord(ev[0][5], st));
     HIP_TRY(hipGetLastError());
+    pendingBow = false;
+    if (voc) {
+      if ((rc = d_bow.ensure(nslots)) || (rc = h_bow.ensure(nslots))) return rc;
+      if ((rc = bow_launch_descend(voc, d_desc.p, nslots, vocLevelsup, d_bow.p, st))) return rc;   // dead slots descend too
+      HIP_TRY(hipMemcpyAsync(h_bow.p, d_bow.p, sizeof(uint2) * nslots, hipMemcpyDeviceToHost, st));
+      pendingBow = true;
+    }
     pendingMatched = false;
     if (ms && ms->chain) {
       // SearchForInitialization of every frame against its predecessor, on the data that is already in HBM
@@ -686,9 +707,12 @@ struct orbfe_extractor {
       kernFrames += nframes;
     }
     int status = ORBFE_OK;
+    if (pendingBow) bowKp.resize(nframes);
+    else bowKp.clear();
     for (int f = 0; f < nframes; f++) {
       OrbfeKeyPoint* ko = kps + (size_t)f * cap;
       uint8_t* dout = desc + (size_t)f * cap * 32;
+      if (pendingBow) bowKp[f].clear();
       int n = 0;
       for (int l = 0; l < nlevels; l++) {
         const int cnt = (int)h_selCount.p[(size_t)f * kMaxLevels + l];
@@ -709,6 +733,7 @@ struct orbfe_extractor {
           kp.class_id = -1;
           ko[n] = kp;
           memcpy(dout + (size_t)n * 32, h_desc.p + (base + i) * 32, 32);
+          if (pendingBow) bowKp[f].push_back(h_bow.p[base + i]);
           n++;
         }
       }
@@ -1114,6 +1139,45 @@ int orbfe_extractor_max_keypoints(const orbfe_extractor* h) {
   int n = 0;   // per level max(N_l + 2, 4 * roots) with up to 4 roots (aspect ratio < 4.5); == nfeatures + 2 * nlevels when N_l >= 14
   for (int l = 0; l < h->nlevels; l++) n += std::max(h->nfeat[l] + 2, 16);
   return n;
+}
+
+int orbfe_extractor_set_vocabulary(orbfe_extractor* h, orbfe_vocabulary* v, int levelsup) {
+  if (!h) { set_err("extractor is NULL"); return ORBFE_ERR_INVALID; }
+  if (h->pendingFrames) { set_err("a submitted batch has not been collected yet"); return ORBFE_ERR_INVALID; }
+  if (v && bow_device(v) != h->device) { set_err("vocabulary lives on device %d, extractor on %d", bow_device(v), h->device); return ORBFE_ERR_INVALID; }
+  if (v && !h->gpuQuadtree) { set_err("the fused bag-of-words path needs the GPU quadtree path"); return ORBFE_ERR_INVALID; }
+  h->voc = v;
+  h->vocLevelsup = levelsup;
+  return ORBFE_OK;
+}
+
+int orbfe_extract_bow(orbfe_extractor* h, int frame, uint32_t* bow_ids, double* bow_values, int* n_words, uint32_t* fv_nodes,
+                      uint32_t* fv_offsets, uint32_t* fv_features, int* n_fv_nodes, uint32_t* word_of_feature,
+                      uint32_t* node_of_feature) {
+  if (!h || !bow_ids || !bow_values || !n_words || !fv_nodes || !fv_offsets || !fv_features || !n_fv_nodes) {
+    set_err("bad argument");
+    return ORBFE_ERR_INVALID;
+  }
+  if (!h->voc || frame < 0 || frame >= (int)h->bowKp.size()) {
+    set_err("no bag-of-words result for frame %d (set a vocabulary before extracting)", frame);
+    return ORBFE_ERR_INVALID;
+  }
+  const std::vector<uint2>& ln = h->bowKp[frame];
+  return bow_assemble(h->voc, ln.data(), (int)ln.size(), bow_ids, bow_values, n_words, fv_nodes, fv_offsets, fv_features,
+                      n_fv_nodes, word_of_feature, node_of_feature);
+}
+
+int orbfe_extract_bow_raw(orbfe_extractor* h, int frame, uint32_t* leaf_node, uint32_t* level_node, int cap, int* n_out) {
+  if (!h || !leaf_node || !level_node || !n_out || cap < 0) { set_err("bad argument"); return ORBFE_ERR_INVALID; }
+  if (!h->voc || frame < 0 || frame >= (int)h->bowKp.size()) {
+    set_err("no bag-of-words result for frame %d (set a vocabulary before extracting)", frame);
+    return ORBFE_ERR_INVALID;
+  }
+  const std::vector<uint2>& ln = h->bowKp[frame];
+  *n_out = (int)ln.size();
+  const int m = std::min(cap, (int)ln.size());
+  for (int i = 0; i < m; i++) { leaf_node[i] = ln[i].x; level_node[i] = ln[i].y; }
+  return ORBFE_OK;
 }
 
 int orbfe_extractor_max_keypoints_for_size(const orbfe_extractor* h, int rows, int cols) {

@@ -42,6 +42,7 @@ struct Slot {
   std::vector<int32_t> m12;
   std::vector<int> nm;
   std::vector<float> prevxy;
+  std::vector<uint32_t> bowLeaf, bowNode;   // [batch][cap], with a vocabulary set
   // predecessor of frame 0 (last frame of the previous batch), copied at collect time
   std::vector<OrbfeKeyPoint> prevKps;
   std::vector<uint8_t> prevDesc;
@@ -73,6 +74,7 @@ struct orbfe_stream {
   std::vector<std::thread> tMatch;
   long long pushSeq = 0, popSeq = 0;
   int channels = 1;   // bytes per pixel of the pushed frames (orbfe_stream_set_input_format)
+  bool bow = false;   // orbfe_stream_set_vocabulary
 
   // last frame of the previous batch (the predecessor of frame 0 of the next one)
   std::vector<OrbfeKeyPoint> lastKps;
@@ -126,6 +128,14 @@ struct orbfe_stream {
                                                          s.nm.data());
         else
           s.status = orbfe_extract_batch_collect(ext[e], s.kps.data(), s.desc.data(), cap, s.n.data());
+        if (s.status == ORBFE_OK && bow) {   // raw (leaf, node) pairs of the batch; vectors are assembled on demand
+          s.bowLeaf.resize((size_t)batch * cap);
+          s.bowNode.resize((size_t)batch * cap);
+          for (int f = 0; f < batch && s.status == ORBFE_OK; f++) {
+            int nb = 0;
+            s.status = orbfe_extract_bow_raw(ext[e], f, s.bowLeaf.data() + (size_t)f * cap, s.bowNode.data() + (size_t)f * cap, cap, &nb);
+          }
+        }
         busyCollect += nowMs() - ta;
         if (s.status != ORBFE_OK) s.err = orbfe_last_error();
       }
@@ -321,6 +331,31 @@ int orbfe_stream_set_input_format(orbfe_stream* s, int format, int gray_variant)
     if (rc) return rc;
   }
   s->channels = format == ORBFE_INPUT_GRAY8 ? 1 : (format == ORBFE_INPUT_RGB8 || format == ORBFE_INPUT_BGR8) ? 3 : 4;
+  return ORBFE_OK;
+}
+
+int orbfe_stream_set_vocabulary(orbfe_stream* s, orbfe_vocabulary* v, int levelsup) {
+  if (!s) { set_err("invalid arguments"); return ORBFE_ERR_INVALID; }
+  std::lock_guard<std::mutex> lk(s->mu);
+  if (s->pushSeq != s->popSeq) { set_err("batches are still in flight"); return ORBFE_ERR_INVALID; }
+  for (orbfe_extractor* e : s->ext) {
+    const int rc = orbfe_extractor_set_vocabulary(e, v, levelsup);
+    if (rc) return rc;
+  }
+  s->bow = v != nullptr;
+  return ORBFE_OK;
+}
+
+int orbfe_stream_bow_raw(orbfe_stream* s, int frame, const uint32_t** leaf_node, const uint32_t** level_node, int* n) {
+  if (!s || !leaf_node || !level_node || !n || frame < 0 || frame >= s->batch) { set_err("invalid arguments"); return ORBFE_ERR_INVALID; }
+  if (s->popped < 0 || !s->bow || s->slots[s->popped].bowLeaf.empty()) {
+    set_err("no popped batch with bag-of-words results");
+    return ORBFE_ERR_INVALID;
+  }
+  const Slot& sl = s->slots[s->popped];
+  *leaf_node = sl.bowLeaf.data() + (size_t)frame * s->cap;
+  *level_node = sl.bowNode.data() + (size_t)frame * s->cap;
+  *n = sl.n[frame];
   return ORBFE_OK;
 }
 

@@ -125,3 +125,57 @@ def test_search_for_triangulation_parity(api, oracle):
     # zero fundamental matrix: den == 0 everywhere -> nothing matches
     nm, _ = m.search_for_triangulation(k1, d1, h1, fv1, k2, d2, h2, fv2, np.zeros(9, np.float32), 0.0, 0.0, tab['sf'], tab['s2'])
     assert nm == 0
+
+
+def test_compute_bow_fused_into_the_extractor(api, oracle):
+    """orbfe_extractor_set_vocabulary: the descent runs behind the descriptor kernel on descriptors still in HBM; every
+    frame of a batch gets the same BowVector / FeatureVector as the stand-alone transform and the oracle."""
+    image = synth_vocabulary(4, 10, 5)
+    v = api.Vocabulary(image)
+    ov = oracle.vocabulary(image)
+    ex = api.Extractor(900, 1.2, 8, 20, 7)
+    ex.set_vocabulary(v, 3)
+    frames = [synth(30 + i, 800, 600) for i in range(3)] + [np.full((600, 800), 77, np.uint8)]   # the last has no keypoint
+    dev = api.DeviceFrames(frames, 0)
+    kps, desc, n = ex.extract_batch_ptrs(dev.ptrs, 600, 800, dev.stride, True)
+    for f in range(4):
+        got = ex.bow(f, int(n[f]))
+        want = ov.transform(desc[f, :n[f]], 3)
+        _same_transform(got, want)
+        if n[f]:
+            _same_transform(got, v.transform(desc[f, :n[f]], 3))
+    assert n[3] == 0 and n[0] > 500
+    # single-frame call, other levelsup, then switched off again
+    ex.set_vocabulary(v, 1)
+    k, d = ex(frames[1])
+    _same_transform(ex.bow(0, len(k)), ov.transform(d, 1))
+    ex.set_vocabulary(None)
+    ex(frames[1])
+    with pytest.raises(api.OrbfeError):
+        ex.bow(0, len(k))
+    v.close()
+
+
+def test_stream_runner_with_vocabulary(api, oracle):
+    """orbfe_stream_set_vocabulary: every popped frame carries its (leaf, node) pairs; assembling them gives the oracle's
+    BowVector / FeatureVector of that frame's descriptors."""
+    image = synth_vocabulary(9, 10, 4)
+    v = api.Vocabulary(image)
+    ov = oracle.vocabulary(image)
+    W, H, N, B = 800, 600, 700, 3
+    base = synth(61, W, H)
+    frames = [base] + [shifted(base, 3 * i, -2 * i, 900 + i) for i in range(1, 2 * B)]
+    dev = api.DeviceFrames(frames, 0)
+    st = api.Stream(N, 1.2, 8, 20, 7, 0, B, 2)
+    st.set_matching((0.0, float(W), 0.0, float(H)), 100, 0.9, True)
+    st.set_vocabulary(v, 2)
+    for b in range(2):
+        st.push_ptrs(dev.ptrs[b * B:(b + 1) * B], H, W, dev.stride, True)
+    for b in range(2):
+        kps, desc, n, m12, nm = st.pop(copy=True)
+        for i in range(B):
+            leaf, node = st.bow_raw(i)
+            assert len(leaf) == n[i]
+            _same_transform(v.assemble(leaf, node), ov.transform(desc[i, :n[i]], 2))
+    st.close()
+    v.close()
