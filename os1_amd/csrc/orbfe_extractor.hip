@@ -258,6 +258,8 @@ struct orbfe_extractor {
 
   ~orbfe_extractor() {
     (void)hipSetDevice(device);
+    for (auto& st : streams) if (st) (void)hipStreamSynchronize(st);   // a batch may still be in flight
+    d_bow.release(); h_bow.release();
     d_tables.release(); d_slab.release(); d_in.release(); d_cellCount.release(); d_cellOff.release();
     d_sfiOrder.release(); d_sfiOrderCount.release(); d_sfiPool.release(); d_sfiPcount.release();
     d_cells.release(); d_slots.release(); d_cand.release(); d_frame0.release(); d_gray.release(); d_outArena.release(); h_outArena.release();
