@@ -508,7 +508,11 @@ __global__ __launch_bounds__(kQt2Threads) void k_quadtree2(QtParams Q) {
 void launch_quadtree(const QtParams& Q, int nframes, hipStream_t st) {
   int maxN = 0;
   for (int l = 0; l < Q.nlevels; l++) maxN = Q.nfeat[l] > maxN ? Q.nfeat[l] : maxN;
-  if (maxN + 4 <= 1024)
+  // the node-table capacity sets the block's LDS footprint (50 / 99 / 116 KB), and with it how many waves of the
+  // kernels that run beside the quadtree still fit on the CU
+  if (maxN + 4 <= 512)
+    hipLaunchKernelGGL(k_quadtree2<512>, dim3(Q.nlevels, nframes), dim3(kQt2Threads), 0, st, Q);
+  else if (maxN + 4 <= 1024)
     hipLaunchKernelGGL(k_quadtree2<1024>, dim3(Q.nlevels, nframes), dim3(kQt2Threads), 0, st, Q);
   else
     hipLaunchKernelGGL(k_quadtree2<2048>, dim3(Q.nlevels, nframes), dim3(kQt2Threads), 0, st, Q);
