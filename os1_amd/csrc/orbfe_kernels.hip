@@ -604,7 +604,11 @@ __global__ __launch_bounds__(64) void k_describe(PyramidParams P, const SelKp* _
                                                   SlotInfo SI) {
   __shared__ __align__(16) uint8_t raw[kRawW * kRawP + 16];   // + 16: the last row's 4-dword reads
   __shared__ __align__(16) uint16_t hbT[40 * kHPT];            // horizontal pass, transposed: hbT[x][y]
-  __shared__ __align__(16) uint8_t blT[kBlurW * kBPT];         // blurred 37x37 patch, transposed: blT[x][y]
+  // blurred 37x37 patch, transposed: blT[x][y].  It reuses the raw patch, which is dead once the horizontal pass
+  // (and the barrier behind it) is through: LDS per wave decides how many waves of the kernels that run beside this
+  // one (the next batches' FAST) fit on the CU.
+  static_assert(kBlurW * kBPT <= kRawW * kRawP, "the blurred patch must fit into the raw patch");
+  uint8_t* blT = raw;
   const int k = blockIdx.x;
   if (k >= nsel) return;
   if (SI.selCount) {
