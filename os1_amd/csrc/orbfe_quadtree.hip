@@ -43,9 +43,11 @@ struct Qt2Shared {
   uint32_t ninfo[CAP];        // midX | midY << 12 | divide << 24
   uint16_t cpos[CAP][4];      // new list position of child q; kept nodes: [0] = new position
   uint32_t baseS[CAP][4];     // exclusive quadrant scan at the node's first element -> later: child.begin - baseS
-  uint32_t endS[CAP][4];      // inclusive quadrant scan at the node's last element
+  union {                     // lifetimes do not overlap: endS lives from element pass 1 to the node pass of an iteration,
+    uint32_t endS[CAP][4];    //   inclusive quadrant scan at the node's last element
+    unsigned long long sortKeys[CAP];   // sortKeys from the record step of one iteration to the ordering step of the next
+  };
   short tproc[CAP];           // index in processing order, -1 = not divided
-  unsigned long long sortKeys[CAP];
   uint32_t wcnt[2][4][kQt2Threads / 64][4];   // [parity][sub-tile][wave][class]
   int wsumI[kQt2Threads / 64];
   int s_int[4];
