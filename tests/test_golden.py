@@ -72,3 +72,59 @@ def test_gpu_reproduces_1080p_digests():
     prev = np.stack([k1['x'], k1['y']], 1)
     n, m12, p = api.Matcher().search_for_initialization(k1, d1, k2, d2, (0, 1920, 0, 1080), prev, 100, 0.9, True)
     assert n == g['config3']['nmatches'] and _sha(m12, p) == g['config3']['match_sha256']
+
+
+GB = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'vga_seed1_bow.npz')
+
+
+def _bow_case(g):
+    from os1_amd.synth import synth_vocabulary
+    voc = synth_vocabulary(3, 10, 4)
+    assert hashlib.sha256(voc).digest() == g['voc_sha'].tobytes()                  # vocabulary generator unchanged
+    v = np.load(G)
+    return voc, v['kps1'], v['desc1'], v['kps2'], v['desc2']
+
+
+def _check_bow(g, tr1, tr2, sbb, tri, proj):
+    assert tr1[0].tobytes() == g['bow1_ids'].tobytes() and tr1[1].tobytes() == g['bow1_vals'].tobytes()
+    assert tr1[2][0].tobytes() == g['fv1_nodes'].tobytes() and tr1[2][1].tobytes() == g['fv1_off'].tobytes()
+    assert tr1[2][2].tobytes() == g['fv1_feat'].tobytes()
+    assert tr2[0].tobytes() == g['bow2_ids'].tobytes() and tr2[1].tobytes() == g['bow2_vals'].tobytes()
+    (n1, m1), (n2, m2) = sbb
+    assert n1 == int(g['sbb_kf_f_n']) and (m1 == g['sbb_kf_f']).all()
+    assert n2 == int(g['sbb_kf_kf_n']) and (m2 == g['sbb_kf_kf']).all()
+    assert tri[0] == int(g['tri_n']) and tri[1].tobytes() == g['tri_pairs'].tobytes()
+    assert proj[0] == int(g['proj_n']) and (proj[1] == g['proj_best']).all() and (proj[2] == g['proj_dist']).all()
+
+
+def test_oracle_reproduces_bow_golden(oracle):
+    g = np.load(GB)
+    voc, k1, d1, k2, d2 = _bow_case(g)
+    ov = oracle.vocabulary(voc)
+    t1, t2 = ov.transform(d1, 2), ov.transform(d2, 2)
+    v1, v2 = g['valid1'], g['valid2']
+    tab = OracleExtractor(1000, 1.2, 8, 20, 7, oracle).tables()
+    sbb = (oracle.search_by_bow(d1, k1['angle'], v1, t1[2], d2, k2['angle'], None, t2[2], 0.7, True),
+           oracle.search_by_bow(d1, k1['angle'], v1, t1[2], d2, k2['angle'], v2, t2[2], 0.75, True))
+    tri = oracle.search_for_triangulation(k1, d1, v1, t1[2], k2, d2, v2, t2[2], g['F12'], 320.0, 240.0, tab['sf'], tab['s2'], True)
+    proj = oracle.search_projected(k2, d2, (0, 640, 0, 480), g['proj_uv'], g['proj_radius'], g['proj_level'],
+                                   np.ones(len(g['proj_level']), np.uint8), g['proj_desc'], None, True, tab['is2'], 5.99, 50)
+    _check_bow(g, t1, t2, sbb, tri, proj)
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_bow_golden():
+    from os1_amd import api
+    g = np.load(GB)
+    voc, k1, d1, k2, d2 = _bow_case(g)
+    v = api.Vocabulary(voc)
+    m = api.Matcher()
+    t1, t2 = v.transform(d1, 2), v.transform(d2, 2)
+    v1, v2 = g['valid1'], g['valid2']
+    tab = api.Extractor(1000, 1.2, 8, 20, 7).tables()
+    sbb = (m.search_by_bow(d1, k1['angle'], v1, t1[2], d2, k2['angle'], None, t2[2], 0.7, True, False),
+           m.search_by_bow(d1, k1['angle'], v1, t1[2], d2, k2['angle'], v2, t2[2], 0.75, True, True))
+    tri = m.search_for_triangulation(k1, d1, v1, t1[2], k2, d2, v2, t2[2], g['F12'], 320.0, 240.0, tab['sf'], tab['s2'], True)
+    proj = m.search_projected(k2, d2, (0, 640, 0, 480), g['proj_uv'], g['proj_radius'], g['proj_level'],
+                              np.ones(len(g['proj_level']), np.uint8), g['proj_desc'], None, True, tab['is2'], 5.99, 50)
+    _check_bow(g, t1, t2, sbb, tri, proj)
