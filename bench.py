@@ -2,22 +2,38 @@
 """bench.py -- frames/sec of the ORB front end (extract + match) on N MI355X GPUs of one node.
 
 Metric (BASELINE.json): frames/sec extract+match, 1920x1080 @ 2000 ORB features, 8 levels, 1.2.
-A "step" is one pass of the hot path over one batch of B synthetic frames of a seeded stream:
-ORBextractor::operator() on every frame (orbfe_extract_batch, frames already resident in HBM) and
-ORBmatcher::SearchForInitialization of every frame against its predecessor in the stream
-(window 100, nnratio 0.9, checkOrientation) -- BASELINE.json configs[1]+[2] on the stream of
-configs[3].  Keypoints / descriptors / match indices come back to host memory inside the timed
-region (they are the path's outputs).  Independent streams shard across GPUs (one process and one
-stream per GPU, no data-path collective; the only cross-rank traffic is the barrier and the
-max-over-ranks of the elapsed time, done over gloo).
+Workload = BASELINE.json configs[3] per GPU (SURVEY.md s8(d) "Config 4", os1_amd/stream_workload.py): camera stream
+g (seed 100+g) -> GPU g, a pool of 256 DISTINCT 1080p frames (530 MB, larger than the 256 MB Infinity Cache), each
+frame = its predecessor shifted by (2,1) px; the stream walks the pool forwards and backwards.
+A "step" is one pass of the hot path over one batch of 256 frames of the stream (8 submissions of 32 frames to the
+native stream runner): ORBextractor::operator() on every frame and ORBmatcher::SearchForInitialization of every
+frame against its predecessor (window 100, nnratio 0.9, checkOrientation).  Keypoints / descriptors / match indices
+come back to host memory inside the timed region (they are the path's outputs).
 
-One JSON line on rank 0 (see the task's bench contract) with two extra objects:
-  roofline     -- dominant kernel (k_fast_cells): algorithmic bytes per launch / HIP-event duration
-  cpu_baseline -- the CPU oracle (scalar port, 1 core) on a bounded sample of the same frames
+`value`: frames resident in HBM when the timed region starts (the task's bench contract).  The same run also times
+the stream with the frames starting in page-locked HOST memory (`pcie_inclusive`: H2D of every frame inside the timed
+region, the figure SURVEY.md s8(d) defines) and prints it next to the measured link rate.
+
+Before anything is timed, the first 4 x 32 frames are pushed through the same runner and their outputs are hashed and
+compared with the oracle-generated digests in tests/golden/stream1080_digests.json: "verified": true means every
+keypoint, descriptor and vnMatches12 entry of those frames is bit-identical to the CPU oracle's.
+
+Multi-GPU: independent streams, one process + one stream runner per GPU, no data-path collective; the only cross-rank
+traffic is the barrier and the max-over-ranks of the elapsed time (gloo, CPU tensors).  Started either by the driver
+(`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`) or, when WORLD_SIZE is unset, by
+bench.py itself: `python bench.py --gpus N` spawns the N ranks as fresh child processes before it touches any GPU.
+
+One JSON line on rank 0 (see the task's bench contract) with extra objects:
+  roofline       -- dominant kernel (k_fast_cells): algorithmic bytes per launch / HIP-event duration vs HBM peak,
+                    plus its vector-instruction-issue roof (the bound that actually explains its time)
+  cpu_baseline   -- the CPU oracle (scalar port, 1 core) on a bounded sample of the same frames
+  pcie_inclusive -- the same stream from page-locked host frames
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,24 +41,62 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-W, H, NFEAT, NLEVELS, SCALE, INI_TH, MIN_TH = 1920, 1080, 2000, 8, 1.2, 20, 7
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak (MI355X_MICROARCH.md)
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4   # 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz = 6.1e11 /s
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--batch', type=int, default=32, help='frames per step and GPU')
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=32, help='frames per submission to the stream runner')
+    ap.add_argument('--pool', type=int, default=256, help='distinct frames per stream (= frames per step)')
     ap.add_argument('--cpu-frames', type=int, default=64, help='frames of the CPU-oracle baseline sample (0 = skip)')
     ap.add_argument('--bow', action='store_true', help='also run Frame::ComputeBoW (k=10, L=6 synthetic vocabulary) behind the descriptor kernel (not the headline value)')
     ap.add_argument('--no-match', action='store_true', help='extract only (configs[1])')
+    ap.add_argument('--no-pcie', action='store_true', help='skip the PCIe-inclusive leg')
+    ap.add_argument('--no-verify', action='store_true', help='skip the digest check of the first steps')
     ap.add_argument('--host-input', nargs='?', const='pageable', default=None, choices=['pageable', 'pinned'],
-                    help='frames start in HOST memory, pageable or page-locked (PCIe-inclusive rate; never the headline value)')
+                    help='headline leg from HOST frames instead (developer aid; never the contract value)')
     ap.add_argument('--depth', type=int, default=3, help='extraction batches in flight inside the stream runner')
-    args = ap.parse_args()
+    ap.add_argument('--plumbing-only', action='store_true',
+                    help='CPU test aid for the N>1 control plane: rendezvous, barrier, max-over-ranks and the JSON line with NO '
+                         'hot-path work and no value (tests/test_multiproc.py); never a measurement')
+    return ap.parse_args()
 
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes.  Nothing in this
+    (parent) process has touched a GPU -- no HIP call, no torch.cuda call -- and the children are new interpreters,
+    not exec()s of an initialised one."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = max(rc, abs(p.wait()))
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    return rc
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args))
+    run_rank(args)
+
+
+def run_rank(args):
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if 'ORBFE_BENCH_DEVICE' in os.environ:          # testing aid: run several ranks on one GPU
@@ -62,51 +116,83 @@ def main():
         # control plane only (barrier + max of a scalar): gloo; the data path has no exchange step
         dist.init_process_group(backend='gloo', rank=rank, world_size=world)
 
+    from os1_amd import stream_workload as wl
+    if args.plumbing_only:
+        # control plane only: what N>1 adds to the data path is stream sharding (seed 100+rank), the barrier and the
+        # max-over-ranks of the elapsed time -- exercised here without a GPU, with a rank-dependent fake duration
+        if dist is not None:
+            dist.barrier()
+        el = 0.01 * (rank + 1)
+        seeds = [wl.stream_seed(rank)]
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t[0])
+            seeds = [None] * world
+            dist.all_gather_object(seeds, wl.stream_seed(rank))
+        if rank == 0:
+            print(json.dumps({'plumbing_only': True, 'value': None, 'n_gpus': world, 'max_elapsed': el, 'seeds': seeds,
+                              'steps': args.steps, 'warmup': args.warmup}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     from os1_amd import api
-    from os1_amd.synth import shifted, synth
     if api.device_count() <= local_rank:
         raise SystemExit('bench.py needs GPU %d (found %d): the product has no CPU fallback' % (local_rank, api.device_count()))
+    # this rank's threads (stream-runner workers are created below) and page-locked buffers next to its GPU
+    numa_node = api.device_numa_node(local_rank)
+    numa_cpus = api.bind_thread_to_device(local_rank)
 
-    B = args.batch
-    seed = 100 + rank                       # config 4: stream g -> GPU g, seeds 100+g
-    base = synth(seed, W, H)
-    # frame i = the scene translated by (2i, i) px with fresh +-4 sensor noise ("each frame = previous shifted
-    # by (2,1) px"; derived from the base frame so that noise does not accumulate along the stream)
-    frames = [base] + [shifted(base, 2 * i, i, seed * 1000 + i) for i in range(1, B)]
+    W, H, B = wl.W, wl.H, args.batch
+    assert args.pool % B == 0, '--pool must be a multiple of --batch'
+    subs = args.pool // B                       # submissions per step
+    seed = wl.stream_seed(rank)                 # config 4: stream g -> GPU g, seeds 100+g
+    sf = wl.StreamFrames(seed, W, H, args.pool)
+    frames = sf.frames()
     dev = api.DeviceFrames(frames, local_rank)
-    pinned = api.PinnedFrames(frames) if args.host_input == 'pinned' else None
-    host_ptrs = pinned.ptrs if pinned else [f.ctypes.data for f in frames]
+    want_pinned = (not args.no_pcie) or args.host_input == 'pinned'
+    pinned = api.PinnedFrames(frames) if want_pinned else None
 
-    def push():
-        if args.host_input:
-            st.push_ptrs(host_ptrs, H, W, W, False)
-        else:
-            st.push_ptrs(dev.ptrs, H, W, dev.stride, True)
-    # native stream runner: `depth` extractor handles + one matcher + two worker threads, all C++
-    st = api.Stream(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, local_rank, B, max(1, args.depth))
-    bounds = (0.0, float(W), 0.0, float(H))
-    st.set_matching(bounds, 0 if args.no_match else 100, 0.9, True)   # window 100, nnratio 0.9, checkOrientation
+    # native stream runner: `depth` extractor handles, GPU-resident matching, C++ worker thread
+    st = api.Stream(wl.NFEAT, wl.SCALE, wl.NLEVELS, wl.INI_TH, wl.MIN_TH, local_rank, B, max(1, args.depth))
+    st.set_matching(wl.BOUNDS, 0 if args.no_match else wl.WINDOW, wl.NNRATIO, wl.CHECK_ORI)
     if args.bow:
         from os1_amd.synth import synth_vocabulary
         voc = api.Vocabulary(synth_vocabulary(1, 10, 6), local_rank)
         st.set_vocabulary(voc, 4)
+
+    pos = [0]                                   # stream position of the next pushed frame
+
+    def push(source):
+        idx = [wl.pool_index(pos[0] + i, args.pool) for i in range(B)]
+        pos[0] += B
+        if source == 'hbm':
+            st.push_ptrs([dev.ptrs[i] for i in idx], H, W, dev.stride, True)
+        elif source == 'pinned':
+            st.push_ptrs([pinned.ptrs[i] for i in idx], H, W, W, False)
+        else:
+            st.push_ptrs([frames[i].ctypes.data for i in idx], H, W, W, False)
+
     nmatch_total = [0]
     pop_times = []
 
-    def run(nsteps):
-        """nsteps passes of the hot path: push a batch (async extraction on the GPU, then SearchForInitialization
-        of every frame against its predecessor), pop its keypoints / descriptors / matches in host memory.
-        Up to depth+2 batches are in the pipeline; every push and pop of the nsteps batches is inside this call."""
+    def run(nbatches, source, on_pop=None):
+        """nbatches submissions through the runner: push (async extraction + SearchForInitialization of every frame
+        against its predecessor on the GPU), pop keypoints / descriptors / matches in host memory.  Up to depth+2
+        batches are in the pipeline; every push and pop of the nbatches batches is inside this call."""
         pushed = 0
-        while pushed < min(args.depth + 2, nsteps):
-            push()
+        while pushed < min(args.depth + 2, nbatches):
+            push(source)
             pushed += 1
-        for _ in range(nsteps):
-            _, _, n, _, nm = st.pop()
+        for _ in range(nbatches):
+            res = st.pop()
             pop_times.append(time.perf_counter())
-            nmatch_total[0] += int(nm.sum())
-            if pushed < nsteps:
-                push()
+            if on_pop:
+                on_pop(res)
+            nmatch_total[0] += int(res[4].sum())
+            if pushed < nbatches:
+                push(source)
                 pushed += 1
 
     def sync():
@@ -114,90 +200,162 @@ def main():
         if have_torch_gpu:
             torch.cuda.synchronize()
 
-    run(args.warmup)
-    del pop_times[:]
-    st.kernel_ms(reset=True)
-    st.stats(reset=True)
-    nmatch_total[0] = 0
-    sync()
-    if dist is not None:
-        dist.barrier()
-    t0 = time.perf_counter()
-    run(args.steps)
-    sync()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    def timed(nsteps, nwarm, source):
+        run(nwarm * subs, source)
+        del pop_times[:]
+        st.kernel_ms(reset=True)
+        st.stats(reset=True)
+        nmatch_total[0] = 0
+        sync()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        run(nsteps * subs, source)
+        sync()
+        if dist is not None:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t[0])
+        return el
+
+    # ---- self-check: the first steps of the stream against the committed oracle digests (outside the timed region)
+    verify = {'verified': None, 'outputs_sha256': None}
+    if not args.no_verify and not args.no_match and not args.bow and args.pool == wl.POOL and B == wl.BATCH:
+        verify = verify_first_steps(wl, seed, lambda n, cb: run(n, 'hbm', cb))
+    if dist is not None:                        # every rank checks its own stream; rank 0 reports the conjunction
+        flag = torch.tensor([1 if verify['verified'] else 0, 1 if verify['verified'] is None else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+        verify['ranks_verified'] = int(flag[0])
+        if verify['verified'] is not None:
+            verify['verified'] = int(flag[0]) == world
+
+    head_source = {'pinned': 'pinned', 'pageable': 'pageable', None: 'hbm'}[args.host_input]
+    elapsed = timed(args.steps, args.warmup, head_source)
     kms, kbatches, kframes = st.kernel_ms()
     wstats = st.stats()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    head_pops = np.array(pop_times)
+    head_matches = nmatch_total[0]
+
+    pcie = None
+    if not args.no_pcie and head_source == 'hbm':
+        psteps, pwarm = max(2, min(args.steps, 40)), max(1, min(args.warmup, 3))
+        link = api.h2d_rate_gbs(local_rank, pinned.base, pinned.frame_bytes * B)
+        pel = timed(psteps, pwarm, 'pinned')
+        pfps = world * args.pool * psteps / pel
+        pcie = {'value': round(pfps, 2), 'unit': 'frames/s', 'steps': psteps, 'warmup': pwarm,
+                'ms_per_step': round(pel / psteps * 1e3, 4),
+                'input': 'the same %d-frame pool in page-locked host memory (orbfe_host_alloc); H2D of every frame inside the timed region' % args.pool,
+                'h2d_link_gbs_rank0': round(link, 2), 'h2d_link_frames_per_s_rank0': round(link * 1e9 / (W * H), 1),
+                'frac_of_link_rank0': round(pfps / world * W * H / (link * 1e9), 4) if link > 0 else None}
 
     if rank == 0:
-        frames_done = world * B * args.steps
+        frames_done = world * args.pool * args.steps
         fps = frames_done / elapsed
-        # roofline of the dominant kernel (DESIGN.md "Roofline"): k_fast_cells reads every pyramid pixel once
-        # (sum of level sizes) and writes 4 B per surviving candidate; algorithmic bytes per launch = that x B.
-        ex = api.Extractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, device=local_rank)   # geometry + candidate count only
+        # roofline of the dominant kernel: k_fast_cells reads every pyramid pixel once (sum of level
+        # sizes) and writes 4 B per surviving candidate; algorithmic bytes per launch = that x B.
+        ex = api.Extractor(wl.NFEAT, wl.SCALE, wl.NLEVELS, wl.INI_TH, wl.MIN_TH, device=local_rank)   # geometry + candidate count only
         t = ex.tables()
         px = 0
-        for l in range(NLEVELS):
+        for l in range(wl.NLEVELS):
             lw = int(np.rint(np.float32(W) * t['isf'][l]))
             lh = int(np.rint(np.float32(H) * t['isf'][l]))
             px += lw * lh
         ex.extract_batch_ptrs(dev.ptrs[:1], H, W, dev.stride, True)
-        ncand = sum(len(ex.candidates(l, 0)) for l in range(NLEVELS))
+        ncand = sum(len(ex.candidates(l, 0)) for l in range(wl.NLEVELS))
         fast_bytes_per_frame = px + 4 * ncand
         fast_ms_per_launch = kms[1] / max(kbatches, 1)
         achieved = fast_bytes_per_frame * B / (fast_ms_per_launch * 1e-3) / 1e9 if fast_ms_per_launch > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')     # written from rocprofv3 --pmc passes (offline)
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get('k_fast_cells_bytes_per_launch_b%d' % B)
-            except Exception:
-                traffic = None
+        prof = load_profile_counters(B)
+        traffic = prof.get('traffic_bytes_per_launch')
+        valu = None
+        if prof.get('valu_insts_per_launch') and fast_ms_per_launch > 0:
+            rate = prof['valu_insts_per_launch'] / (fast_ms_per_launch * 1e-3)
+            valu = {'insts_per_launch': prof['valu_insts_per_launch'], 'insts_per_cell_wave': prof.get('valu_insts_per_cell_wave'),
+                    'issue_peak_per_s': VALU_ISSUE_PEAK, 'achieved_per_s': round(rate, 1), 'frac': round(rate / VALU_ISSUE_PEAK, 4),
+                    'note': 'wave64 VALU instructions (SQ_INSTS_VALU, separate rocprofv3 --pmc pass); peak = 1024 SIMDs x 2.4 GHz / 4 cycles'}
+        step_ms = np.diff(head_pops[subs - 1::subs]) * 1e3 if len(head_pops) >= 3 * subs else None
         out = {
             'metric': 'frames/sec extract+match, 1920x1080 @ 2000 ORB feats',
             'value': round(fps, 2), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
             'config': {'workload': '1080p_2000feat_8lv_1.2_extract%s%s_stream' % ('' if args.no_match else '+SearchForInitialization', '+ComputeBoW' if args.bow else ''),
-                       'frames_per_step_per_gpu': B, 'image': '%dx%d' % (W, H), 'nfeatures': NFEAT, 'nlevels': NLEVELS,
-                       'parallelism': 'independent streams, 1 per GPU' if world > 1 else 'single GPU',
-                       'matches_per_frame': round(nmatch_total[0] / max(B * args.steps, 1), 1),
-                       'input': ('frames in %s host memory (PCIe-inclusive)' % args.host_input if args.host_input else 'frames resident in HBM') + '; keypoints/descriptors/matches returned to host'},
+                       'frames_per_step_per_gpu': args.pool, 'frames_per_submission': B, 'distinct_frames_per_gpu': args.pool,
+                       'image': '%dx%d' % (W, H), 'nfeatures': wl.NFEAT, 'nlevels': wl.NLEVELS,
+                       'parallelism': 'independent streams, 1 per GPU (no collective)' if world > 1 else 'single GPU',
+                       'matches_per_frame': round(head_matches / max(args.pool * args.steps, 1), 1),
+                       'input': {'hbm': 'frames resident in HBM (pool of %d distinct frames, %d MB, walked forwards and backwards)' % (args.pool, args.pool * W * H >> 20),
+                                 'pinned': 'frames in page-locked host memory (PCIe-inclusive)',
+                                 'pageable': 'frames in pageable host memory (PCIe-inclusive)'}[head_source] + '; keypoints/descriptors/matches returned to host',
+                       'numa': {'node_of_gpu': numa_node, 'cpus_bound': numa_cpus}},
+            'verified': verify['verified'], 'outputs_sha256': verify['outputs_sha256'], 'verify': verify,
+            'pcie_inclusive': pcie,
             # HIP-event time of the kernels in the pipeline (they overlap other batches' kernels); only k_fast_cells is
             # always timed (roofline), the others appear with ORBFE_PROFILE_KERNELS=1 (costs about 1 % of the rate)
             'gpu_kernel_ms_per_frame': {k: round(v / max(kframes, 1), 5) for k, v in
                                         zip(('pyramid', 'fast_cells', 'compaction', 'describe', 'quadtree'), kms) if v > 0},
             'ms_per_step_percentiles': (lambda d: {'p10': round(float(np.percentile(d, 10)), 4), 'p50': round(float(np.percentile(d, 50)), 4),
-                                                    'p90': round(float(np.percentile(d, 90)), 4), 'max': round(float(d.max()), 4)})(np.diff(np.array(pop_times)) * 1e3) if len(pop_times) > 2 else None,
-            'host_worker_ms_per_step': {'submit': round(wstats[0] / max(wstats[3], 1), 4), 'collect_incl_gpu_wait': round(wstats[1] / max(wstats[3], 1), 4),
-                                        'match': round(wstats[2] / max(wstats[3], 1), 4)},
+                                                    'p90': round(float(np.percentile(d, 90)), 4), 'max': round(float(d.max()), 4)})(step_ms) if step_ms is not None and len(step_ms) > 1 else None,
+            'host_worker_ms_per_submission': {'submit': round(wstats[0] / max(wstats[3], 1), 4), 'collect_incl_gpu_wait': round(wstats[1] / max(wstats[3], 1), 4)},
             'roofline': {'kernel': 'k_fast_cells', 'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
+                         'traffic_source': prof.get('source'),
                          'algorithmic_bytes_per_launch': fast_bytes_per_frame * B,
-                         'launch_ms': round(fast_ms_per_launch, 4)},
+                         'launch_ms': round(fast_ms_per_launch, 4), 'valu': valu},
         }
         if world == 1 and args.cpu_frames > 0:
             out['cpu_baseline'] = cpu_baseline(frames, args.cpu_frames, not args.no_match)
-            out['cpu_baseline_all_cores'] = cpu_baseline_all_cores(frames)
+            out['cpu_baseline_all_cores'] = cpu_baseline_all_cores(frames, not args.no_match)
         print(json.dumps(out), flush=True)
+    st.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def verify_first_steps(wl, seed, run):
+    """Push the first steps of the stream through the runner, hash every frame's outputs and compare with the
+    oracle's digests (tests/golden/stream1080_digests.json <- tools/gen_stream_digests.py)."""
+    path = os.path.join(ROOT, 'tests', 'golden', 'stream1080_digests.json')
+    try:
+        ref = json.load(open(path))['streams'].get(str(seed))
+    except Exception:
+        ref = None
+    if not ref:
+        return {'verified': None, 'outputs_sha256': None, 'note': 'no committed digest for seed %d' % seed}
+    hasher = wl.StepHasher()
+    run(len(ref['steps']), lambda res: hasher.add(*res))
+    ok = hasher.steps == ref['steps']
+    import hashlib
+    return {'verified': bool(ok), 'outputs_sha256': hashlib.sha256(''.join(hasher.steps).encode()).hexdigest(),
+            'submissions_checked': len(ref['steps']), 'frames_checked': len(ref['steps']) * wl.BATCH,
+            'matches_in_checked_frames': hasher.nmatches, 'oracle_matches': ref.get('nmatches'),
+            'digest_file': 'tests/golden/stream1080_digests.json', 'seed': seed}
+
+
+def load_profile_counters(B):
+    """Counters of k_fast_cells from the committed rocprofv3 --pmc passes (profiles/counters.json names the
+    profile tag and the commit they were taken at; they are offline measurements of the same command, not of this run)."""
+    path = os.path.join(ROOT, 'profiles', 'counters.json')
+    try:
+        c = json.load(open(path))
+    except Exception:
+        return {}
+    if c.get('batch') != B:
+        return {}
+    return c
 
 
 def cpu_baseline(frames, nframes, do_match):
     """The CPU oracle (scalar C++ port of the reference path, g++ -O3, ONE core) on the same frames."""
     import numpy as np
     from oracle.pyoracle import Oracle, OracleExtractor
+    from os1_amd import stream_workload as wl
     o = Oracle()
-    ox = OracleExtractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, o)
-    bounds = (0.0, float(W), 0.0, float(H))
+    ox = OracleExtractor(wl.NFEAT, wl.SCALE, wl.NLEVELS, wl.INI_TH, wl.MIN_TH, o)
     ox.extract(frames[0])                                           # warm-up
     prev = None
     t0 = time.perf_counter()
@@ -205,7 +363,7 @@ def cpu_baseline(frames, nframes, do_match):
         k, d = ox.extract(frames[i % len(frames)])
         if do_match and prev is not None:
             pxy = np.stack([prev[0]['x'], prev[0]['y']], 1)
-            o.search_for_initialization(prev[0], prev[1], k, d, bounds, pxy, 100, 0.9, True)
+            o.search_for_initialization(prev[0], prev[1], k, d, wl.BOUNDS, pxy, wl.WINDOW, wl.NNRATIO, wl.CHECK_ORI)
         prev = (k, d)
     dt = time.perf_counter() - t0
     return {'value': round(nframes / dt, 3), 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
@@ -214,19 +372,31 @@ def cpu_baseline(frames, nframes, do_match):
                       'restatement, g++ -O3 -ffp-contract=off), %.1f s' % (nframes, '+SearchForInitialization' if do_match else '', dt)}
 
 
-def cpu_baseline_all_cores(frames):
-    """The same oracle with one extractor instance per host thread over independent frames (SURVEY.md s8(d)(ii));
-    extraction only, 4 frames per thread, at most 64 threads so the run stays bounded."""
+def cpu_baseline_all_cores(frames, do_match):
+    """The same oracle with one extractor instance per host thread over independent pieces of the stream
+    (SURVEY.md s8(d)(ii)): every host core, 4 consecutive frames per thread, each matched against its predecessor."""
     import threading
+    import numpy as np
     from oracle.pyoracle import Oracle, OracleExtractor
-    nthreads = max(1, min(os.cpu_count() or 1, 64))
+    from os1_amd import stream_workload as wl
+    nthreads = max(1, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
+    try:
+        os.sched_setaffinity(0, range(os.cpu_count() or 1))          # undo the NUMA binding for this leg
+        nthreads = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
     o = Oracle()
-    exs = [OracleExtractor(NFEAT, SCALE, NLEVELS, INI_TH, MIN_TH, o) for _ in range(nthreads)]
+    exs = [OracleExtractor(wl.NFEAT, wl.SCALE, wl.NLEVELS, wl.INI_TH, wl.MIN_TH, o) for _ in range(nthreads)]
     per = 4
 
     def work(i):
+        prev = None
         for k in range(per):
-            exs[i].extract(frames[(i * per + k) % len(frames)])
+            kp, d = exs[i].extract(frames[(i * per + k) % len(frames)])
+            if do_match and prev is not None:
+                o.search_for_initialization(prev[0], prev[1], kp, d, wl.BOUNDS, np.stack([prev[0]['x'], prev[0]['y']], 1),
+                                            wl.WINDOW, wl.NNRATIO, wl.CHECK_ORI)
+            prev = (kp, d)
 
     ths = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
     t0 = time.perf_counter()
@@ -236,7 +406,7 @@ def cpu_baseline_all_cores(frames):
         t.join()
     dt = time.perf_counter() - t0
     return {'value': round(nthreads * per / dt, 2), 'unit': 'frames/s', 'cores': nthreads, 'kind': 'port',
-            'sample': '%d threads x %d frames, extract only, %.1f s' % (nthreads, per, dt)}
+            'sample': '%d threads x %d consecutive frames, extract%s, %.1f s' % (nthreads, per, '+SearchForInitialization (3 of 4 frames have a predecessor)' if do_match else '', dt)}
 
 
 if __name__ == '__main__':

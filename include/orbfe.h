@@ -67,6 +67,16 @@ int orbfe_device_synchronize(int device_id);
  * writes into it directly. */
 int orbfe_host_alloc(size_t bytes, void** out);
 int orbfe_host_free(void* ptr);
+/* NUMA placement for multi-GPU hosts (one process or thread group per GPU): the NUMA node the
+ * device hangs off (sysfs numa_node of its PCI function; -1 = unknown), and a helper that restricts the CALLING
+ * thread to that node's CPUs (intersected with its current mask).  Threads created and page-locked buffers first
+ * touched afterwards -- the stream runner's workers, orbfe_host_alloc memory -- then live next to the GPU.
+ * Returns the number of CPUs in the new mask, 0 if nothing was changed (node unknown). */
+int orbfe_device_numa_node(int device_id);
+int orbfe_bind_thread_to_device(int device_id);
+/* Host-to-device link rate seen by `reps` back-to-back copies of `bytes` from `host` (page-locked for a DMA figure),
+ * in GB/s: the bound of any caller that hands over host frames (bench.py's pcie_inclusive leg). */
+int orbfe_debug_h2d_rate(int device_id, const void* host, size_t bytes, int reps, double* gb_per_s);
 
 /* ---------------------------------------------------------------------------------------------
  * Extractor.  Replaces ORB_SLAM2::ORBextractor (include/ORBextractor.h:155-373).
@@ -200,8 +210,11 @@ typedef struct orbfe_stream orbfe_stream;
 /* batch = frames per push; depth = extraction batches in flight (1..8). */
 int orbfe_stream_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device_id,
                         int batch, int depth, orbfe_stream** out);
+/* Batches the GPU is working on are waited for; batches still queued are dropped without being submitted.  Frames of
+ * submitted batches must stay valid until destroy returns (or pop every batch first). */
 void orbfe_stream_destroy(orbfe_stream* s);
-/* bounds = {mnMinX, mnMaxX, mnMinY, mnMaxY}; window_size <= 0 disables matching (extract only). */
+/* bounds = {mnMinX, mnMaxX, mnMinY, mnMaxY}; window_size <= 0 disables matching (extract only).  Only while no
+ * batch is in flight (every pushed batch popped); each batch carries the parameters in force at its push. */
 int orbfe_stream_set_matching(orbfe_stream* s, const float bounds[4], int window_size, float nnratio,
                               int check_orientation);
 /* orbfe_extractor_set_input_format for every extractor of the runner (only while no batch is in flight). */
@@ -217,7 +230,8 @@ int orbfe_stream_capacity(const orbfe_stream* s);
  * unless depth+3 batches are already queued.  The frames must stay valid until their batch is popped. */
 int orbfe_stream_push(orbfe_stream* s, const uint8_t* const* gray, int in_device_memory, int rows, int cols,
                       size_t stride_bytes);
-/* Wait for the oldest batch.  Output pointers stay valid until the next pop:
+/* Wait for the oldest batch; ORBFE_ERR_INVALID if no pushed batch is outstanding.  Output pointers stay valid until
+ * the next pop:
  *   kps [batch][cap], desc [batch][cap][32], n_kps [batch];
  *   matches12 [batch][cap]: row i = vnMatches12 of (F1 = frame i-1 of the stream, F2 = frame i), indexed by
  *   F1's keypoints (first n_kps[i-1] entries valid; row 0 uses the last frame of the previous batch);

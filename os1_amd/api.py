@@ -113,6 +113,9 @@ def load_library():
     L.orbfe_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.orbfe_host_free.argtypes = [vp]
     L.orbfe_device_synchronize.argtypes = [ci]
+    L.orbfe_device_numa_node.argtypes = [ci]
+    L.orbfe_bind_thread_to_device.argtypes = [ci]
+    L.orbfe_debug_h2d_rate.argtypes = [ci, vp, C.c_size_t, ci, C.POINTER(C.c_double)]
     L.orbfe_stream_create.argtypes = [ci, cf, ci, ci, ci, ci, ci, ci, C.POINTER(vp)]
     L.orbfe_stream_destroy.argtypes = [vp]
     L.orbfe_stream_destroy.restype = None
@@ -666,6 +669,21 @@ class DeviceFrames:
 
 def device_synchronize(device=0):
     _check(load_library().orbfe_device_synchronize(device))
+
+
+def device_numa_node(device=0):
+    return load_library().orbfe_device_numa_node(device)
+
+
+def bind_thread_to_device(device=0):
+    """Restrict the calling thread (and threads it creates later) to the CPUs of the GPU's NUMA node; 0 = unchanged."""
+    return load_library().orbfe_bind_thread_to_device(device)
+
+
+def h2d_rate_gbs(device, host_ptr, nbytes, reps=8):
+    g = C.c_double(0)
+    _check(load_library().orbfe_debug_h2d_rate(device, C.c_void_p(host_ptr), nbytes, reps, C.byref(g)))
+    return g.value
 
 
 class Stream:

@@ -7,8 +7,10 @@
 // geometries the kernel does not hold (more than 4 roots or 2044 features per level) and
 // ORBFE_HOST_QUADTREE=1.  There is no CPU fallback for the kernels.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <algorithm>
+#include <cctype>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -776,6 +778,7 @@ struct orbfe_extractor {
   //   all s : wait, assemble cv::KeyPoint-compatible outputs.
   int run(int nframes, const uint8_t* const* gray, bool onDevice, int r, int c, size_t stride, OrbfeKeyPoint* kps,
           uint8_t* desc, int cap, int* n_out) {
+    if (pendingFrames) { set_err("a submitted batch has not been collected yet"); return ORBFE_ERR_INVALID; }
     HIP_TRY(hipSetDevice(device));
     int rc;
     if ((rc = setGeometry(r, c))) return rc;
@@ -1002,6 +1005,83 @@ int orbfe_device_synchronize(int device_id) {
   return ORBFE_OK;
 }
 
+// NUMA placement (with one stream runner per GPU the expected limiter is the host side -- worker
+// threads and page-locked buffers on the wrong socket halve the PCIe rate).  The node comes from sysfs via the
+// device's PCI address; -1 when the platform does not say (single-socket boxes, containers without sysfs).
+int orbfe_device_numa_node(int device_id) {
+  char bdf[64] = {0};
+  if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf - 1, device_id) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  for (char* c = bdf; *c; c++) *c = (char)tolower(*c);
+  char path[160];
+  snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+  FILE* f = fopen(path, "r");
+  if (!f) return -1;
+  int node = -1;
+  if (fscanf(f, "%d", &node) != 1) node = -1;
+  fclose(f);
+  return node;
+}
+
+int orbfe_bind_thread_to_device(int device_id) {
+  const int node = orbfe_device_numa_node(device_id);
+  if (node < 0) return 0;
+  char path[96];
+  snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+  FILE* f = fopen(path, "r");
+  if (!f) return 0;
+  char list[4096] = {0};
+  const bool ok = fgets(list, sizeof list, f) != nullptr;
+  fclose(f);
+  if (!ok) return 0;
+  cpu_set_t cur, want;
+  CPU_ZERO(&want);
+  if (sched_getaffinity(0, sizeof cur, &cur) != 0) return 0;
+  int ncpu = 0;
+  for (char* p = list; *p;) {   // "0-31,64-95"
+    char* e;
+    long a = strtol(p, &e, 10);
+    if (e == p) break;
+    long b = a;
+    if (*e == '-') { p = e + 1; b = strtol(p, &e, 10); }
+    for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+      if (CPU_ISSET(c, &cur)) { CPU_SET(c, &want); ncpu++; }   // never widen the mask the process was given
+    p = (*e == ',') ? e + 1 : e;
+    if (*e != ',' ) break;
+  }
+  if (ncpu == 0) return 0;
+  if (sched_setaffinity(0, sizeof want, &want) != 0) return 0;
+  return ncpu;
+}
+
+// Link-rate probe for the bench's PCIe-inclusive leg: `reps` back-to-back host-to-device copies of `bytes` from the
+// caller's (page-locked) buffer on a private stream, timed with HIP events.
+int orbfe_debug_h2d_rate(int device_id, const void* host, size_t bytes, int reps, double* gb_per_s) {
+  if (!host || !bytes || reps < 1 || !gb_per_s) { set_err("bad argument"); return ORBFE_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(device_id));
+  void* d = nullptr;
+  HIP_TRY(hipMalloc(&d, bytes));
+  hipStream_t st = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = ORBFE_OK;
+  float ms = 0;
+  if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&e0) != hipSuccess ||
+      hipEventCreate(&e1) != hipSuccess) { set_err("stream/event creation failed"); rc = ORBFE_ERR_HIP; }
+  if (rc == ORBFE_OK) {
+    bool ok = hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    ok = ok && hipEventRecord(e0, st) == hipSuccess;
+    for (int i = 0; i < reps && ok; i++) ok = hipMemcpyAsync(d, host, bytes, hipMemcpyHostToDevice, st) == hipSuccess;
+    ok = ok && hipEventRecord(e1, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess &&
+         hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+    if (!ok) { set_err("h2d probe failed: %s", hipGetErrorString(hipGetLastError())); rc = ORBFE_ERR_HIP; }
+  }
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (st) (void)hipStreamDestroy(st);
+  (void)hipFree(d);
+  if (rc == ORBFE_OK) *gb_per_s = ms > 0 ? (double)bytes * reps / (ms * 1e-3) / 1e9 : 0.0;
+  return rc;
+}
+
 int orbfe_extractor_set_input_format(orbfe_extractor* h, int format, int gray_variant) {
   if (!h || format < ORBFE_INPUT_GRAY8 || format > ORBFE_INPUT_BGRA8 || (gray_variant != ORBFE_GRAY_Q15 && gray_variant != ORBFE_GRAY_Q14)) {
     set_err("bad input format");
@@ -1204,6 +1284,8 @@ int orbfe_extract_batch(orbfe_extractor* h, int nframes, const uint8_t* const* g
     set_err("invalid image / output arguments");
     return ORBFE_ERR_INVALID;
   }
+  // a blocking call between _submit and _collect would re-carve the arenas the pending batch still writes
+  if (h->pendingFrames) { set_err("a submitted batch has not been collected yet"); return ORBFE_ERR_INVALID; }
   {
     HIP_TRY(hipSetDevice(h->device));
     const int rc = h->setGeometry(rows, cols);

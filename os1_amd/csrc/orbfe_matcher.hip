@@ -902,9 +902,9 @@ int orbfe_search_projected(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, const 
                            const uint8_t* src_valid, const uint8_t* src_desc, const uint8_t* kp_skip, int claim,
                            const float* inv_level_sigma2, int nlevels, double chi2, int max_dist, int32_t* best_idx,
                            int32_t* best_dist, int* nmatches) {
-  if (!m || !bounds || !nmatches || n < 0 || n_src < 0 || (n && (!kps_un || !desc)) ||
+  if (!m || !bounds || !nmatches || n < 0 || n > 65535 || n_src < 0 || (n && (!kps_un || !desc)) ||
       (n_src && (!src_uv || !src_radius || !src_level || !src_valid || !src_desc || !best_idx))) {
-    set_err("bad argument");
+    set_err("bad argument (note: at most 65535 keypoints per frame)");
     return ORBFE_ERR_INVALID;
   }
   *nmatches = 0;

@@ -51,6 +51,11 @@ struct Slot {
   bool done = false;
   int status = ORBFE_OK;
   std::string err;
+  // match parameters of the stream at push time (orbfe_stream_set_matching only works on an idle stream, but the
+  // snapshot keeps submit and collect of one batch on the same variant by construction)
+  int window = 0, checkOri = 1;
+  float nnratio = 0.9f;
+  float bounds[4] = {0, 0, 0, 0};
 };
 }  // namespace
 
@@ -96,7 +101,10 @@ struct orbfe_stream {
       {
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&] { return stop || !inflight.empty() || !extractQ.empty(); });
-        if (stop && inflight.empty() && extractQ.empty()) return;
+        // on stop, batches that were queued but never submitted are dropped (their frames may already be gone);
+        // only batches the GPU is working on are waited for
+        if (stop) extractQ.clear();
+        if (stop && inflight.empty()) return;
         if (!extractQ.empty() && (int)inflight.size() < depth) {
           job = extractQ.front();
           extractQ.pop_front();
@@ -106,12 +114,15 @@ struct orbfe_stream {
         Slot& s = slots[job];
         orbfe_extractor* h = ext[nextExt];
         const double ta = nowMs();
-        if (gpuMatch && window > 0)
+        if (gpuMatch && s.window > 0)
           s.status = orbfe_extract_batch_submit_matched(h, chain, batch, s.frames.data(), s.onDevice, s.rows, s.cols, s.stride,
-                                                        bounds, window, nnratio, checkOri);
+                                                        s.bounds, s.window, s.nnratio, s.checkOri);
         else
           s.status = orbfe_extract_batch_submit(h, batch, s.frames.data(), s.onDevice, s.rows, s.cols, s.stride);
-        busySubmit += nowMs() - ta;
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          busySubmit += nowMs() - ta;
+        }
         if (s.status != ORBFE_OK) s.err = orbfe_last_error();
         inflight.emplace_back(job, nextExt);
         nextExt = (nextExt + 1) % depth;
@@ -123,7 +134,7 @@ struct orbfe_stream {
       Slot& s = slots[slot];
       if (s.status == ORBFE_OK) {
         const double ta = nowMs();
-        if (gpuMatch && window > 0)
+        if (gpuMatch && s.window > 0)
           s.status = orbfe_extract_batch_collect_matched(ext[e], s.kps.data(), s.desc.data(), cap, s.n.data(), s.m12.data(),
                                                          s.nm.data());
         else
@@ -136,7 +147,10 @@ struct orbfe_stream {
             s.status = orbfe_extract_bow_raw(ext[e], f, s.bowLeaf.data() + (size_t)f * cap, s.bowNode.data() + (size_t)f * cap, cap, &nb);
           }
         }
-        busyCollect += nowMs() - ta;
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          busyCollect += nowMs() - ta;
+        }
         if (s.status != ORBFE_OK) s.err = orbfe_last_error();
       }
       if (s.status == ORBFE_OK) {
@@ -148,7 +162,7 @@ struct orbfe_stream {
       }
       {
         std::lock_guard<std::mutex> lk(mu);
-        if (gpuMatch || window <= 0) {   // matches (if any) came back with the batch: done
+        if (gpuMatch || s.window <= 0) {   // matches (if any) came back with the batch: done
           nBatches++;
           s.done = true;
         } else {
@@ -181,7 +195,10 @@ struct orbfe_stream {
       }
       Slot& s = slots[slot];
       const double tm0 = nowMs();
-      if (s.status == ORBFE_OK && window > 0 && !gpuMatch) {
+      if (s.status == ORBFE_OK && s.window > 0 && !gpuMatch) {
+        const int window = s.window, checkOri = s.checkOri;
+        const float nnratio = s.nnratio;
+        const float* bounds = s.bounds;
         // pairs (predecessor, frame): Tracking::MonocularInitialization style, vbPrevMatched := F1 keypoints
         k1.clear(); k2.clear(); d1.clear(); d2.clear(); n1.clear(); n2.clear(); prev.clear(); m12.clear();
         std::vector<int> frameOfPair;
@@ -315,6 +332,7 @@ int orbfe_stream_set_matching(orbfe_stream* s, const float bounds[4], int window
                               int check_orientation) {
   if (!s || (window_size > 0 && !bounds)) { set_err("invalid arguments"); return ORBFE_ERR_INVALID; }
   std::lock_guard<std::mutex> lk(s->mu);
+  if (s->pushSeq != s->popSeq) { set_err("batches are still in flight"); return ORBFE_ERR_INVALID; }
   if (bounds) memcpy(s->bounds, bounds, sizeof s->bounds);
   s->window = window_size;
   s->nnratio = nnratio;
@@ -378,6 +396,8 @@ int orbfe_stream_push(orbfe_stream* s, const uint8_t* const* gray, int in_device
   sl.done = false;
   {
     std::lock_guard<std::mutex> lk(s->mu);
+    sl.window = s->window; sl.checkOri = s->checkOri; sl.nnratio = s->nnratio;
+    memcpy(sl.bounds, s->bounds, sizeof sl.bounds);
     sl.seq = s->pushSeq++;
     s->extractQ.push_back(slot);
   }
@@ -396,6 +416,7 @@ int orbfe_stream_pop(orbfe_stream* s, const OrbfeKeyPoint** kps, const uint8_t**
       s->popped = -1;
       s->cv.notify_all();
     }
+    if (s->popSeq == s->pushSeq) { set_err("no batch outstanding (every pushed batch has been popped)"); return ORBFE_ERR_INVALID; }
     auto ready = [&]() -> int {
       for (size_t i = 0; i < s->slots.size(); i++)
         if (s->slots[i].done && s->slots[i].seq == s->popSeq) return (int)i;
@@ -419,6 +440,7 @@ int orbfe_stream_pop(orbfe_stream* s, const OrbfeKeyPoint** kps, const uint8_t**
 
 int orbfe_stream_stats(orbfe_stream* s, double out[4], int reset) {
   if (!s || !out) { set_err("NULL argument"); return ORBFE_ERR_INVALID; }
+  std::lock_guard<std::mutex> lk(s->mu);
   out[0] = s->busySubmit; out[1] = s->busyCollect; out[2] = s->busyMatch; out[3] = (double)s->nBatches;
   if (reset) { s->busySubmit = s->busyCollect = s->busyMatch = 0; s->nBatches = 0; }
   return ORBFE_OK;

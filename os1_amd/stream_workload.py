@@ -1,0 +1,103 @@
+"""The synthetic camera stream of BASELINE.json configs[3] (SURVEY.md s8(d) "Config 4"): stream g has seed 100+g and
+256 frames, each frame = the previous one shifted by (2,1) px.  Shared by bench.py, tools/gen_golden.py and the tests
+so that the workload the bench measures is exactly the workload the parity tests and the committed digests cover.
+
+Frame i of stream `seed` = os1_amd.synth.shifted(base, 2*i, i, seed*1000 + i) with base = synth(seed, W, H) (frame 0 is
+the base itself): the scene translated by (2i, i) px with reflect fill and fresh +-4 sensor noise -- derived from the
+base frame so that noise does not accumulate along the stream.  An endless stream walks the 256 frames forwards and
+backwards (0,1,...,255,254,...,1,0,1,...), so that consecutive frames always differ by one (+-2,+-1) px step and the
+pool (530 MB at 1080p) is larger than the 256 MB Infinity Cache.
+"""
+import hashlib
+
+import numpy as np
+
+from .synth import splitmix64, synth
+
+W, H, NFEAT, NLEVELS, SCALE, INI_TH, MIN_TH = 1920, 1080, 2000, 8, 1.2, 20, 7
+WINDOW, NNRATIO, CHECK_ORI = 100, 0.9, True          # Tracking.cc:383-384
+POOL = 256
+BATCH = 32
+BOUNDS = (0.0, float(W), 0.0, float(H))
+
+
+def stream_seed(rank):
+    return 100 + rank
+
+
+def pool_index(pos, pool=POOL):
+    """Frame of the pool shown at stream position `pos` (forwards, then backwards, ...)."""
+    if pool <= 1:
+        return 0
+    period = 2 * pool - 2
+    r = pos % period
+    return r if r < pool else period - r
+
+
+class StreamFrames:
+    """Generates frames of one stream; bit-identical to synth.shifted(base, 2i, i, seed*1000+i) but pads the base once."""
+
+    def __init__(self, seed, w=W, h=H, pool=POOL):
+        self.seed, self.w, self.h, self.pool = seed, w, h, pool
+        self.base = synth(seed, w, h)
+        self.pad = 2 * (pool - 1) + 1
+        self._padded = None
+
+    def frame(self, i):
+        if i == 0:
+            return self.base
+        if self._padded is None:
+            self._padded = np.pad(self.base, self.pad, mode='reflect')
+        dx, dy, pad = 2 * i, i, self.pad
+        out = self._padded[pad - dy:pad - dy + self.h, pad - dx:pad - dx + self.w].astype(np.int16)
+        noise = (splitmix64(self.seed * 1000 + i, self.w * self.h, 7) % np.uint64(9)).astype(np.int16).reshape(self.h, self.w) - 4
+        return np.ascontiguousarray(np.clip(out + noise, 0, 255).astype(np.uint8))
+
+    def frames(self, n=None):
+        return [self.frame(i) for i in range(self.pool if n is None else n)]
+
+
+def frame_digest(kps, desc, n):
+    """sha256 over one frame's outputs: count, cv::KeyPoint-layout records, descriptor rows."""
+    h = hashlib.sha256()
+    h.update(np.int32(n).tobytes())
+    h.update(np.ascontiguousarray(kps[:n]).tobytes())
+    h.update(np.ascontiguousarray(desc[:n]).tobytes())
+    return h.hexdigest()
+
+
+def match_digest(nmatches, m12, n_prev):
+    """sha256 over one SearchForInitialization result: return value and vnMatches12 (size = predecessor's keypoints)."""
+    h = hashlib.sha256()
+    h.update(np.int32(nmatches).tobytes())
+    h.update(np.ascontiguousarray(m12[:max(n_prev, 0)], dtype=np.int32).tobytes())
+    return h.hexdigest()
+
+
+def step_digest(frame_hex, match_hex):
+    """One digest per step (= batch): the per-frame digests in stream order."""
+    h = hashlib.sha256()
+    for a, b in zip(frame_hex, match_hex):
+        h.update(bytes.fromhex(a))
+        h.update(bytes.fromhex(b))
+    return h.hexdigest()
+
+
+class StepHasher:
+    """Folds popped batches (Stream.pop() tuples) into per-step digests; carries the predecessor's keypoint count
+    across batches (vnMatches12 of frame i has as many entries as frame i-1 has keypoints)."""
+
+    def __init__(self):
+        self.prev_n = 0
+        self.steps = []
+        self.nmatches = 0
+
+    def add(self, kps, desc, n, m12, nm):
+        fh, mh = [], []
+        for i in range(len(n)):
+            fh.append(frame_digest(kps[i], desc[i], int(n[i])))
+            mh.append(match_digest(int(nm[i]), m12[i], self.prev_n))
+            self.prev_n = int(n[i])
+            self.nmatches += int(nm[i])
+        self.steps.append(step_digest(fh, mh))
+        return self.steps[-1]

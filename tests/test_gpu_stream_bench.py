@@ -1,0 +1,122 @@
+"""-m gpu: the workload bench.py measures (BASELINE.json configs[3]: stream seed 100+g, 1920x1080, 2000 features,
+32-frame submissions, depth 3, SearchForInitialization chained frame to frame and across submissions) against the
+CPU oracle -- live, frame by frame, and through the committed digests bench.py itself checks."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from os1_amd import stream_workload as wl
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DIGESTS = json.load(open(os.path.join(ROOT, 'tests', 'golden', 'stream1080_digests.json')))
+
+
+@pytest.fixture(scope='module')
+def api():
+    from os1_amd import api as a
+    assert a.device_count() >= 1, 'no GPU visible: the product has no CPU fallback'
+    return a
+
+
+def _run_stream(api, seed, nsub, depth=3, source='hbm'):
+    sf = wl.StreamFrames(seed)
+    idx = [wl.pool_index(p) for p in range(nsub * wl.BATCH)]
+    frames = {i: sf.frame(i) for i in sorted(set(idx))}
+    order = sorted(frames)
+    stack = [frames[i] for i in order]
+    dev = api.DeviceFrames(stack, 0) if source == 'hbm' else api.PinnedFrames(stack)
+    at = {i: dev.ptrs[k] for k, i in enumerate(order)}
+    st = api.Stream(wl.NFEAT, wl.SCALE, wl.NLEVELS, wl.INI_TH, wl.MIN_TH, 0, wl.BATCH, depth)
+    st.set_matching(wl.BOUNDS, wl.WINDOW, wl.NNRATIO, wl.CHECK_ORI)
+    pushed = 0
+
+    def push():
+        nonlocal pushed
+        ptrs = [at[i] for i in idx[pushed * wl.BATCH:(pushed + 1) * wl.BATCH]]
+        st.push_ptrs(ptrs, wl.H, wl.W, wl.W, source == 'hbm')
+        pushed += 1
+    while pushed < min(depth + 2, nsub):
+        push()
+    out = []
+    for _ in range(nsub):
+        out.append(st.pop(copy=True))
+        if pushed < nsub:
+            push()
+    st.close()
+    return out
+
+
+def test_bench_stream_matches_oracle_frame_by_frame(api, oracle):
+    """4 submissions of stream 100 at the bench's exact configuration (all 3 handles used, the SearchForInitialization
+    chain crosses 3 submission boundaries): every keypoint field, descriptor byte and vnMatches12 entry of the first 64
+    frames against the live oracle, and all 128 frames against the committed digests."""
+    from oracle.stream_ref import oracle_stream_steps
+    nlive = 2
+    steps, total, kept = oracle_stream_steps(100, nlive, keep=True)
+    assert steps == DIGESTS['streams']['100']['steps'][:nlive], 'committed digests are stale: run tools/gen_stream_digests.py'
+    got = _run_stream(api, 100, 4)
+    hasher = wl.StepHasher()
+    prev_n = 0
+    for s, (kps, desc, n, m12, nm) in enumerate(got):
+        if s < nlive:
+            for i in range(wl.BATCH):
+                wk, wd, wnm, wm12 = kept[s * wl.BATCH + i]
+                assert n[i] == len(wk), (s, i)
+                for f in wk.dtype.names:
+                    assert (kps[i, :n[i]][f] == wk[f]).all(), (s, i, f)
+                assert desc[i, :n[i]].tobytes() == wd.tobytes(), (s, i)
+                assert nm[i] == wnm, (s, i)
+                assert (m12[i, :prev_n] == wm12).all(), (s, i)
+                prev_n = int(n[i])
+        hasher.add(kps, desc, n, m12, nm)
+    assert hasher.steps == DIGESTS['streams']['100']['steps']
+    assert hasher.nmatches == DIGESTS['streams']['100']['nmatches'] and hasher.nmatches > 20000
+
+
+@pytest.mark.parametrize('seed', [101, 107])
+def test_other_ranks_streams_against_digests(api, seed):
+    got = _run_stream(api, seed, 4)
+    hasher = wl.StepHasher()
+    for res in got:
+        hasher.add(*res)
+    assert hasher.steps == DIGESTS['streams'][str(seed)]['steps']
+
+
+def test_host_input_stream_against_digests(api):
+    """The PCIe-inclusive leg (page-locked host frames, shared upload lane) returns the same bytes."""
+    got = _run_stream(api, 100, 4, source='pinned')
+    hasher = wl.StepHasher()
+    for res in got:
+        hasher.add(*res)
+    assert hasher.steps == DIGESTS['streams']['100']['steps']
+
+
+def _bench(args, extra_env=None):
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(extra_env or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, capture_output=True, text=True, timeout=1500, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+
+
+def test_bench_line_is_self_verified(api):
+    res = _bench(['--steps', '2', '--warmup', '1', '--cpu-frames', '0'])
+    assert res['n_gpus'] == 1 and res['verified'] is True and len(res['outputs_sha256']) == 64
+    assert res['verify']['frames_checked'] == 128
+    assert res['config']['distinct_frames_per_gpu'] == 256 and res['config']['frames_per_step_per_gpu'] == 256
+    assert res['value'] > 1000 and res['pcie_inclusive']['value'] > 1000
+    assert res['roofline']['frac'] > 0 and res['roofline']['launch_ms'] > 0
+
+
+def test_bench_two_ranks_on_one_gpu(api):
+    """bench.py --gpus 2 launches its two ranks itself; ORBFE_BENCH_DEVICE=0 puts both on the one GPU of this box.
+    Each rank runs its own stream (seeds 100, 101) through the product and checks it against that seed's digests."""
+    res = _bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--no-pcie'], {'ORBFE_BENCH_DEVICE': '0'})
+    assert res['n_gpus'] == 2
+    assert res['verified'] is True and res['verify']['ranks_verified'] == 2
+    assert res['value'] > 1000 and res['config']['parallelism'].startswith('independent streams')

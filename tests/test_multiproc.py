@@ -66,11 +66,45 @@ def test_two_rank_gloo_sharding(tmp_path):
     assert res['frames'] == 4
 
 
+def _json_line(out):
+    import json
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+
+
+def test_bench_self_launch_two_ranks_control_plane():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset starts the two ranks itself (fresh child processes, gloo on
+    127.0.0.1): rank g gets stream seed 100+g, the line reports n_gpus = 2 and the MAX over ranks of the elapsed
+    time.  --plumbing-only keeps the GPU hot path out so this runs on the CPU box; the product run of the same
+    launcher is tests/test_gpu_stream_bench.py::test_bench_two_ranks_on_one_gpu."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['OMP_NUM_THREADS'] = '1'
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                          '--plumbing-only'], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = _json_line(out)
+    assert res['n_gpus'] == 2 and res['seeds'] == [100, 101] and res['plumbing_only'] is True and res['value'] is None
+    assert abs(res['max_elapsed'] - 0.02) < 1e-12          # rank 1's (larger) time wins
+
+
+def test_bench_under_torchrun_two_ranks_control_plane():
+    """The driver's launch line (python -m torch.distributed.run ... bench.py --gpus 2) takes the same path."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--plumbing-only']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS='1'))
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = _json_line(out)
+    assert res['n_gpus'] == 2 and res['seeds'] == [100, 101]
+
+
 def test_bench_refuses_to_run_without_gpu():
     from os1_amd import api
     if api.device_count() > 0:
         return
-    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '0', '--batch', '2'],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '1', '--warmup', '0'],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode != 0
     assert 'no CPU fallback' in (out.stderr + out.stdout)
