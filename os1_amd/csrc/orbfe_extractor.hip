@@ -508,19 +508,56 @@ struct orbfe_extractor {
   // GPU-quadtree path: frame -> pyramid -> FAST -> compaction -> quadtree -> orientation/blur/rBRIEF in ONE
   // stream submission, one synchronisation, fixed-size D2H of the selection slots.
   // H2D of host frames [f0, f0+nf) into d_in on `st`
-  int uploadFrames(int f0, int nf, const uint8_t* const* gray, size_t stride, int r, int c, hipStream_t st) {
+  // H2D of host frames [f0, f0+nf) on `st`.  devAt[f] receives the device address frame f lands at.  Frames that tile
+  // one contiguous host block -- in ANY order: a ring buffer read forwards, backwards or rotated -- travel as ONE DMA
+  // (a 66 MB copy runs at 56.8 GB/s on this link, 32 separate 2 MB copies at 28 GB/s); otherwise ascending runs are
+  // coalesced and the rest goes frame by frame.
+  int uploadFrames(int f0, int nf, const uint8_t* const* gray, size_t stride, int r, int c, hipStream_t st,
+                   const uint8_t** devAt) {
     if (!inLinear) {
-      for (int f = f0; f < f0 + nf; f++)
+      for (int f = f0; f < f0 + nf; f++) {
         HIP_TRY(hipMemcpy2DAsync(d_in.p + (size_t)inPitch * rows * f, inPitch, gray[f], stride, c, r, hipMemcpyHostToDevice, st));
+        devAt[f] = d_in.p + (size_t)inPitch * rows * f;
+      }
       return ORBFE_OK;
     }
     const size_t frameBytes = stride * (size_t)r;
+    const size_t lastBytes = stride * (size_t)(r - 1) + c;   // the last frame of a block may end with its last pixel
+    if (nf > 1 && nf <= 64) {
+      const uint8_t* lo = gray[f0];
+      for (int f = f0 + 1; f < f0 + nf; f++) lo = std::min(lo, gray[f]);
+      uint64_t seen = 0;
+      bool tile = true;
+      for (int f = f0; f < f0 + nf && tile; f++) {
+        const size_t d = (size_t)(gray[f] - lo);
+        const size_t k = d / frameBytes;
+        tile = d % frameBytes == 0 && k < (size_t)nf && !(seen >> k & 1);
+        seen |= (uint64_t)1 << k;
+      }
+      if (tile) {
+        uint8_t* base = d_in.p + frameBytes * f0;
+        HIP_TRY(hipMemcpyAsync(base, lo, frameBytes * (size_t)(nf - 1) + lastBytes, hipMemcpyHostToDevice, st));
+        for (int f = f0; f < f0 + nf; f++) devAt[f] = base + (size_t)(gray[f] - lo);
+        return ORBFE_OK;
+      }
+    }
     for (int f = f0; f < f0 + nf;) {
       int g = f + 1;
       while (g < f0 + nf && gray[g] == gray[g - 1] + frameBytes) g++;   // frames contiguous in host memory
-      const size_t bytes = frameBytes * (size_t)(g - f - 1) + stride * (size_t)(r - 1) + c;
-      HIP_TRY(hipMemcpyAsync(d_in.p + frameBytes * f, gray[f], bytes, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(d_in.p + frameBytes * f, gray[f], frameBytes * (size_t)(g - f - 1) + lastBytes, hipMemcpyHostToDevice, st));
+      for (int k = f; k < g; k++) devAt[k] = d_in.p + frameBytes * k;
       f = g;
+    }
+    return ORBFE_OK;
+  }
+
+  // host-quadtree path: frame f always lands in slot f of d_in (the pointer table is uploaded before the frames)
+  int uploadSlots(int f0, int nf, const uint8_t* const* gray, size_t stride, int r, int c, hipStream_t st) {
+    for (int f = f0; f < f0 + nf; f++) {
+      if (inLinear)
+        HIP_TRY(hipMemcpyAsync(d_in.p + (size_t)inPitch * rows * f, gray[f], stride * (size_t)(r - 1) + c, hipMemcpyHostToDevice, st));
+      else
+        HIP_TRY(hipMemcpy2DAsync(d_in.p + (size_t)inPitch * rows * f, inPitch, gray[f], stride, c, r, hipMemcpyHostToDevice, st));
     }
     return ORBFE_OK;
   }
@@ -533,6 +570,7 @@ struct orbfe_extractor {
   }
 
   bool submitProfiled = false;
+  std::vector<const uint8_t*> devAt;   // device address of every uploaded host frame (uploadFrames)
   int pendingFrames = 0;   // frames of the submitted, not yet collected batch (0 = none)
   double tSubmit0 = 0, tSubmit1 = 0;
 
@@ -554,26 +592,28 @@ struct orbfe_extractor {
     hipStream_t st = streams[0];
     const int ch = inChannels();
     const int rowBytes = c * ch;
-    bool rawAligned = ((onDevice ? (long long)stride : inPitch) & 3) == 0;
-    for (int f = 0; f < nframes; f++) {
+    for (int f = 0; f < nframes; f++)
       if (!gray[f]) { set_err("frame %d is NULL", f); return ORBFE_ERR_INVALID; }
-      const uint8_t* raw = onDevice ? gray[f] : d_in.p + (size_t)inPitch * rows * f;
-      rawAligned = rawAligned && ((uintptr_t)raw & (ch == 4 ? 15 : 3)) == 0;
-      h_frame0.p[f] = ch == 1 ? raw : d_gray.p + (size_t)grayPitch * rows * f;
-      h_frame0.p[nframes + f] = raw;
-    }
+    devAt.resize(nframes);
     hipPointerAttribute_t attr;
     const bool pinned = !onDevice && hipPointerGetAttributes(&attr, gray[0]) == hipSuccess && attr.type == hipMemoryTypeHost;
     if (!onDevice && !pinned) {
       (void)hipGetLastError();   // pageable memory: the runtime stages the copy synchronously; keep it on this handle's stream
-      if ((rc = uploadFrames(0, nframes, gray, stride, r, rowBytes, st))) return rc;
+      if ((rc = uploadFrames(0, nframes, gray, stride, r, rowBytes, st, devAt.data()))) return rc;
     } else if (!onDevice) {
       UploadLane* lane = upload_lane(device);
       if (!lane) { set_err("cannot create the upload stream"); return ORBFE_ERR_HIP; }
       std::lock_guard<std::mutex> lk(lane->mu);
-      if ((rc = uploadFrames(0, nframes, gray, stride, r, rowBytes, lane->stream))) return rc;
+      if ((rc = uploadFrames(0, nframes, gray, stride, r, rowBytes, lane->stream, devAt.data()))) return rc;
       HIP_TRY(hipEventRecord(evUpload, lane->stream));
       HIP_TRY(hipStreamWaitEvent(st, evUpload, 0));
+    }
+    bool rawAligned = ((onDevice ? (long long)stride : inPitch) & 3) == 0;
+    for (int f = 0; f < nframes; f++) {
+      const uint8_t* raw = onDevice ? gray[f] : devAt[f];
+      rawAligned = rawAligned && ((uintptr_t)raw & (ch == 4 ? 15 : 3)) == 0;
+      h_frame0.p[f] = ch == 1 ? raw : d_gray.p + (size_t)grayPitch * rows * f;
+      h_frame0.p[nframes + f] = raw;
     }
     const long long rawStride = onDevice ? (long long)stride : inPitch;
     P.stride0 = ch == 1 ? rawStride : grayPitch;
@@ -795,8 +835,10 @@ struct orbfe_extractor {
     int subF0[kMaxSub + 1];
     for (int s = 0; s <= nsub; s++) subF0[s] = (int)((long long)nframes * s / nsub);
 
+    devAt.resize(nframes);
     for (int f = 0; f < nframes; f++) {
       if (!gray[f]) { set_err("frame %d is NULL", f); return ORBFE_ERR_INVALID; }
+      // per-frame copies on this path (sub-batches upload on their own streams): frame f lands in slot f
       h_frame0.p[f] = onDevice ? gray[f] : d_in.p + (size_t)inPitch * rows * f;
     }
     P.stride0 = onDevice ? (long long)stride : inPitch;
@@ -807,7 +849,7 @@ struct orbfe_extractor {
       hipStream_t st = streams[s];
       const int f0 = subF0[s], nf = subF0[s + 1] - f0;
       if (s) HIP_TRY(hipStreamWaitEvent(st, evFrame0, 0));
-      if (!onDevice && (rc = uploadFrames(f0, nf, gray, stride, r, c, st))) return rc;
+      if (!onDevice && (rc = uploadSlots(f0, nf, gray, stride, r, c, st))) return rc;
       PyramidParams Q = P;
       Q.frameBase = f0;
       HIP_TRY(hipEventRecord(ev[s][0], st));

@@ -379,24 +379,33 @@ __global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
       const uint8_t* c = tile + m24(y + 3, TP) + (x + 3);
       const unsigned vv = c[0];
       s16x2 d[16];
-      // P = (v, r) in the two 16-bit lanes; one v_pk_sub_i16 with swapped operand halves gives (v - r, r - v)
-#define RING(k, off) { const unsigned P = ((unsigned)c[off] << 16) | vv; unsigned dd; \
-        asm("v_pk_sub_i16 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(dd) : "v"(P)); d[k] = as_s16x2(dd); }
+      // d[k] = (v - r_k, r_k - v) in the two 16-bit lanes by ONE packed multiply-add per ring pixel:
+      // r_k (low half, used by both lanes) * (-1, +1) + (v, -v)
+      const unsigned VV = vv | ((0u - vv) << 16);
+#define RING(k, off) { unsigned dd; asm("v_pk_mad_i16 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(dd) : "v"((unsigned)c[off]), "v"(0x0001ffffu), "v"(VV)); \
+        d[k] = as_s16x2(dd); }
       RING(0, 3 * TP);       RING(1, 3 * TP + 1);   RING(2, 2 * TP + 2);    RING(3, TP + 3);
       RING(4, 3);            RING(5, -TP + 3);      RING(6, -2 * TP + 2);   RING(7, -3 * TP + 1);
       RING(8, -3 * TP);      RING(9, -3 * TP - 1);  RING(10, -2 * TP - 2);  RING(11, -TP - 3);
       RING(12, -3);          RING(13, TP - 3);      RING(14, 2 * TP - 2);   RING(15, 3 * TP - 1);
 #undef RING
-      s16x2 m2[16], m4[16], m8[16];
+      // min over every arc of 9 consecutive ring pixels: the ring is cut into two blocks of 8; an arc starting at k is
+      // a suffix of its block plus a prefix of the next one (van Herk / Gil-Werman), 28 + 16 packed minima instead of
+      // the 64 of the log-step sliding minimum
+      s16x2 sA[8], pA[8], sB[8], pB[8];
+      sA[7] = d[7]; sB[7] = d[15]; pA[0] = d[0]; pB[0] = d[8];
 #pragma unroll
-      for (int k = 0; k < 16; k++) m2[k] = __builtin_elementwise_min(d[k], d[(k + 1) & 15]);
+      for (int k = 6; k >= 0; k--) { sA[k] = __builtin_elementwise_min(d[k], sA[k + 1]); sB[k] = __builtin_elementwise_min(d[8 + k], sB[k + 1]); }
 #pragma unroll
-      for (int k = 0; k < 16; k++) m4[k] = __builtin_elementwise_min(m2[k], m2[(k + 2) & 15]);
+      for (int k = 1; k < 8; k++) { pA[k] = __builtin_elementwise_min(pA[k - 1], d[k]); pB[k] = __builtin_elementwise_min(pB[k - 1], d[8 + k]); }
+      s16x2 w[16];
 #pragma unroll
-      for (int k = 0; k < 16; k++) m8[k] = __builtin_elementwise_min(m4[k], m4[(k + 4) & 15]);
-      s16x2 best = {-256, -256};
+      for (int k = 0; k < 8; k++) { w[k] = __builtin_elementwise_min(sA[k], pB[k]); w[8 + k] = __builtin_elementwise_min(sB[k], pA[k]); }
 #pragma unroll
-      for (int k = 0; k < 16; k++) best = __builtin_elementwise_max(best, __builtin_elementwise_min(m8[k], d[(k + 8) & 15]));
+      for (int k = 0; k < 8; k++) w[k] = __builtin_elementwise_max(w[k], w[k + 8]);
+#pragma unroll
+      for (int k = 0; k < 4; k++) w[k] = __builtin_elementwise_max(w[k], w[k + 4]);
+      const s16x2 best = __builtin_elementwise_max(__builtin_elementwise_max(w[0], w[2]), __builtin_elementwise_max(w[1], w[3]));
       const int S = max((int)best.x, (int)best.y);
       pass = S > tlo && x < ew;   // stage 1 tests whole 8-pixel groups
       if (pass) sc[m24(y + 1, SP) + (x + 1)] = (uint8_t)(S - 1);  // tlo <= S-1 <= 254
