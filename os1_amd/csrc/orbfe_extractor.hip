@@ -214,6 +214,8 @@ struct orbfe_extractor {
   PyramidParams P{};
   DevBuf<uint8_t> d_tables, d_slab, d_in;
   DevBuf<CellInfo> d_cells;
+  DevBuf<FastTask> d_tasks;
+  bool pairCells = false;  // ORBFE_FAST_PAIRS=1: two adjacent cells per wave (7 % fewer vector instructions, but 10 % slower: DESIGN.md s5)
   DevBuf<uint32_t> d_cellCount, d_cellOff, d_slots, d_cand;
   DevBuf<const uint8_t*> d_frame0;
   // results leave the GPU in ONE copy: [levelStart][selCount][sel][angle][desc] carved from one arena
@@ -264,7 +266,7 @@ struct orbfe_extractor {
     d_bow.release(); h_bow.release();
     d_tables.release(); d_slab.release(); d_in.release(); d_cellCount.release(); d_cellOff.release();
     d_sfiOrder.release(); d_sfiOrderCount.release(); d_sfiPool.release(); d_sfiPcount.release();
-    d_cells.release(); d_slots.release(); d_cand.release(); d_frame0.release(); d_gray.release(); d_outArena.release(); h_outArena.release();
+    d_cells.release(); d_tasks.release(); d_slots.release(); d_cand.release(); d_frame0.release(); d_gray.release(); d_outArena.release(); h_outArena.release();
     d_f32tmp.release();
     h_frame0.release(); h_cand.release();
     for (auto& es : ev) for (auto& e : es) if (e) (void)hipEventDestroy(e);
@@ -416,8 +418,39 @@ struct orbfe_extractor {
     }
     if ((rc = d_cells.ensure(cells.size()))) return rc;
     HIP_TRY(hipMemcpyAsync(d_cells.p, cells.data(), sizeof(CellInfo) * cells.size(), hipMemcpyHostToDevice, stream));
+    // FAST tasks (k_fast_tasks): two horizontally adjacent cells of a cell row per wave where the pair is at most 64
+    // pixels wide (queue entries hold x in 8 bits, the pre-test handles 4 groups of 16 pixels per row)
+    std::vector<FastTask> tasks;
+    tasks.reserve(Q.ncells);
+    for (int l = 0; l < nlevels; l++) {
+      LevelGeom& L = Q.lv[l];
+      const bool pairOk = pairCells && 2 * L.wCell <= 64 && L.nCols >= 2;
+      L.fastW = pairOk ? 2 * L.wCell : L.wCell;
+      for (int i = 0; i < L.nRows; i++)
+        for (int j = 0; j < L.nCols;) {
+          const CellInfo& c0 = cells[L.cellBase + i * L.nCols + j];
+          FastTask t{};
+          t.ex0 = c0.ex0; t.ey0 = c0.ey0; t.level = (uint8_t)l;
+          t.cell0 = (uint32_t)(L.cellBase + i * L.nCols + j);
+          t.slotOff0 = c0.slotOff;
+          const bool valid0 = c0.ew > 0 && c0.eh > 0;
+          t.ew0 = valid0 ? (uint8_t)c0.ew : 0;
+          t.eh = valid0 ? (uint8_t)c0.eh : 0;
+          int used = 1;
+          if (pairOk && valid0 && j + 1 < L.nCols && c0.ew == L.wCell) {
+            const CellInfo& c1 = cells[L.cellBase + i * L.nCols + j + 1];
+            if (c1.ew > 0 && c1.eh == c0.eh) { t.ew1 = (uint8_t)c1.ew; used = 2; }
+          }
+          tasks.push_back(t);
+          j += used;
+        }
+    }
+    if ((rc = d_tasks.ensure(tasks.size()))) return rc;
+    HIP_TRY(hipMemcpyAsync(d_tasks.p, tasks.data(), sizeof(FastTask) * tasks.size(), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     Q.cells = d_cells.p;
+    Q.tasks = d_tasks.p;
+    Q.ntasks = (int)tasks.size();
     P = Q;
     rows = r;
     geomGpuQtOk = qtOk;
@@ -1218,6 +1251,7 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
     if (!evOk) { set_err("creating the quadtree stream failed"); delete h; return ORBFE_ERR_HIP; }
   }
   if (const char* hv = getenv("ORBFE_HOST_QUADTREE")) h->gpuQuadtree = atoi(hv) == 0;
+  if (const char* pv = getenv("ORBFE_FAST_PAIRS")) h->pairCells = atoi(pv) != 0;
   if (const char* pv = getenv("ORBFE_PROFILE_KERNELS")) h->profileKernels = atoi(pv) != 0;
   h->selPerFrame = 0;
   for (int l = 0; l < nlevels; l++) {

@@ -1,0 +1,361 @@
+// orbfe_fast.hip -- FAST-9/16 per reference cell, the dominant kernel of the extractor (gfx950, wave64).
+//
+// Reference: ComputeKeyPointsOctTree, src/ORBextractor.cc:797-870 (cv::FAST calls at :848,:854); cv::FAST
+// semantics: SURVEY.md Appendix B.1.
+//
+// Formulation (DESIGN.md "FAST"): with S(p) = max(max_arc min(v-ring), max_arc min(ring-v)) a pixel is a corner at
+// threshold t iff S(p) > t and its OpenCV score is S(p)-1, independent of t.  A cell's cv::FAST(t, nms) output is
+// therefore {p in emit region : S(p) > t and s(p) > s(q) for the 8 neighbours q inside the SAME cell's emit region},
+// s = S-1 where S > t and 0 elsewhere.  The emit region of cell (i,j) is [19+j*wCell, min(19+(j+1)*wCell, w-19)) x
+// [19+i*hCell, ...); the regions tile the level exactly.
+//
+// Work decomposition: ONE WAVE PER TASK, a task being one cell or two horizontally adjacent cells of one cell row
+// (FastTask; the union's ROI is one contiguous tile of at most 70 x (hCell+6) bytes).  Two cells per wave fill the
+// 64 lanes of the score stage (a 31x31 cell leaves about 91 candidates = 1.4 wave iterations; two cells need 3 instead
+// of 4) and halve the per-wave fixed cost, at less LDS per cell than one cell per wave.  All stages keep row-major
+// order over the union, which restricted to either cell is that cell's row-major order = cv::FAST's emission order:
+//   stage 1  every emit pixel, 16 per lane (one row, 16 adjacent columns): compass pre-test (a 9-arc always contains
+//            two ADJACENT compass points of one polarity) on packed 16-bit lanes -> DPP-scan-compacted queue
+//   stage 2  queue: S = max over both polarities of max_arc min9, both polarities per packed op; S > t keeps the
+//            entry (compacted in place) and writes the score S-1 to the score tile
+//   stage 3  queue: 3x3 NMS against the score tile (neighbours across the boundary between the two cells count 0),
+//            ballot-ordered emission into each cell's slots
+// Two passes at most, like the reference (:846-856): cv::FAST at iniThFAST; only a cell left without a keypoint (after
+// NMS) is emitted again from a pass at minThFAST.
+// Blocks are remapped so that the blocks an XCD receives (b, b+8, b+16, ...) are CONSECUTIVE tasks: neighbouring cells
+// share ROI halos and cache lines in that XCD's L2.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <type_traits>
+
+#include "orbfe_internal.h"
+
+namespace orbfe {
+
+namespace {
+__device__ __forceinline__ int m24(int a, int b) { return __mul24(a, b); }
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u16x2 as_u16x2(unsigned v) { return __builtin_bit_cast(u16x2, v); }
+__device__ __forceinline__ unsigned as_u32(u16x2 v) { return __builtin_bit_cast(unsigned, v); }
+__device__ __forceinline__ s16x2 as_s16x2(unsigned v) { return __builtin_bit_cast(s16x2, v); }
+}  // namespace
+
+// LDS traffic of one wave needs no s_barrier (a block is one wave; LDS operations of a wave execute in order): a
+// compiler-level memory fence plus the LDS counter is enough.
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// NPX = pixels per lane in the pre-test (8 or 16); tpPad = extra bytes of tile pitch (LDS bank spreading)
+template <int NPX>
+__global__ __launch_bounds__(64) void k_fast_tasks(PyramidParams P, int tpPad) {
+  extern __shared__ __align__(16) uint8_t lds[];
+  const int chunk = (P.ntasks + 7) >> 3;
+  const int tix = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (tix >= P.ntasks) return;
+  const int f = P.frameBase + blockIdx.y;
+  const int lane = threadIdx.x;
+  const FastTask tk = P.tasks[tix];
+  const int level = tk.level;
+  const LevelGeom& L = P.lv[level];
+  const int ex0 = tk.ex0, ey0 = tk.ey0, ew0 = tk.ew0, ew1 = tk.ew1, eh = tk.eh;
+  uint32_t* cnt = P.cellCount + (long long)f * P.ncells + tk.cell0;
+  if (ew0 == 0) {
+    if (lane == 0) cnt[0] = 0;
+    return;
+  }
+  const int W2 = ew0 + ew1;   // emit width of the task
+  const uint8_t* img;
+  long long stride;
+  if (level == 0) {
+    img = P.frame0[f];
+    stride = P.stride0;
+  } else {
+    img = P.slab + (long long)f * P.slabBytes + L.off;
+    stride = L.pitch;
+  }
+  // LDS carve (level-uniform): ROI tile, score tile with a zero ring, queue (y<<8|x)
+  const int TP = ((L.fastW + 6 + 3 + 3) & ~3) + tpPad;
+  const int SP = L.fastW + 2;
+  uint8_t* tile = lds;
+  uint8_t* sc = tile + TP * (L.hCell + 6);
+  uint16_t* queue = reinterpret_cast<uint16_t*>(lds + ((TP * (L.hCell + 6) + SP * (L.hCell + 2) + 3) & ~3));
+
+  const int rw = W2 + 6, rh = eh + 6;
+  const int istr = (int)stride;
+  const uint8_t* roi = img + (long long)(ey0 - 3) * stride + (ex0 - 3);
+  // ROI -> LDS.  Loads are issued in batches of 12 per lane before the first LDS write so the wave waits for memory
+  // once per batch, not once per element.  Rows are fetched as aligned dwords when the row pitch allows it; `a` is the
+  // byte offset of the ROI inside its first dword.
+  const int a = (int)(reinterpret_cast<uintptr_t>(roi) & 3);
+  if ((stride & 3) == 0) {
+    // lane (c, r0) copies dword column c of rows r0, r0 + rstep, ...: 16 columns x 4 rows per sweep for a single cell,
+    // 32 columns x 2 rows for a pair (up to 19 dword columns)
+    const int ndw = (a + rw + 3) >> 2;
+    const uint8_t* base = roi - a;
+    const int cshift = ndw > 16 ? 5 : 4;
+    const int c = lane & ((1 << cshift) - 1), r0 = lane >> cshift, rstep = 64 >> cshift;
+    if (c < ndw) {
+      const uint8_t* g = base + 4 * c + m24(r0, istr);
+      uint8_t* l = tile + 4 * c + m24(r0, TP);
+      const int gstep = m24(rstep, istr), lstep = m24(rstep, TP);
+      for (int r = r0; r < rh; r += 12 * rstep, g += 12 * gstep, l += 12 * lstep) {
+        uint32_t v[12];
+#pragma unroll
+        for (int u = 0; u < 12; u++) v[u] = (r + u * rstep < rh) ? *reinterpret_cast<const uint32_t*>(g + u * gstep) : 0u;
+#pragma unroll
+        for (int u = 0; u < 12; u++)
+          if (r + u * rstep < rh) *reinterpret_cast<uint32_t*>(l + u * lstep) = v[u];
+      }
+    }
+  } else {
+    const float rcpRw = 1.0f / (float)rw;
+    const int total = rw * rh;
+    for (int i0 = lane; i0 < total; i0 += 64 * 8) {
+      uint8_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = i0 + u * 64;
+        v[u] = 0;
+        if (i < total) {
+          const int y = (int)(((float)i + 0.5f) * rcpRw), x = i - m24(y, rw);
+          v[u] = roi[m24(y, istr) + x];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = i0 + u * 64;
+        if (i < total) {
+          const int y = (int)(((float)i + 0.5f) * rcpRw), x = i - m24(y, rw);
+          tile[m24(y, TP) + a + x] = v[u];
+        }
+      }
+    }
+  }
+  tile += a;  // ROI pixel (x, y) lives at tile[y * TP + x]
+  {  // zero the score tile with dword stores (sc is 4-byte aligned: TP*(hCell+6) is a multiple of 4)
+    uint32_t* z = reinterpret_cast<uint32_t*>(sc);
+    const int nz = (SP * (eh + 2) + 3) >> 2;
+    for (int i = lane; i < nz; i += 64) z[i] = 0u;
+  }
+  wave_lds_fence();
+
+  const unsigned long long below = (1ull << lane) - 1ull;
+  uint32_t* slot0 = P.slots + (long long)f * P.slotsPerFrame + tk.slotOff0;
+  uint32_t* slot1 = slot0 + L.slotCap;
+  int base0 = 0, base1 = 0;
+  bool emit0 = true, emit1 = ew1 > 0;
+  for (int pass = 0; pass < 2; pass++) {
+    const int tlo = pass ? P.minTh : P.iniTh;
+    // ---- stage 1: compass pre-test, NPX horizontally adjacent pixels per lane --------------------------------------
+    // Lane item i = (row y, group g): pixels x = NPX*g .. NPX*g + NPX-1.  The centre-row bytes and the bytes of rows
+    // y-3 / y+3 come from aligned LDS dwords and one funnel shift per 4-pixel window (the byte alignment `a` of the ROI
+    // is uniform for the task, so it is a template constant of the loop body).
+    int nq = 0;
+    constexpr int GS = NPX == 16 ? 4 : 3, NS = NPX / 4;   // log2(NPX), 4-pixel windows per lane
+    const int G = (W2 + NPX - 1) >> GS, nItems = G * eh;
+    const int stepY = 64 / G, stepG = 64 - stepY * G;   // item i+64 = (y + stepY, g + stepG) with one carry
+    auto stage1 = [&](auto aTag) {
+      constexpr int A = decltype(aTag)::value;
+      // The test is CONSERVATIVE (a superset of "two adjacent compass points of one polarity", stage 2 decides
+      // exactly) and runs on the packed bytes as they come out of LDS: a 16-bit lane holds pixels (2j, 2j+1) as
+      // (low byte, high byte).  min/max of such lanes is exact in the high byte, so for the odd pixels
+      //   bright: min(max(r0,r8), max(r4,r12)) > v+t     dark: max(min(r0,r8), min(r4,r12)) < v-t
+      // are evaluated with v_pk_min/max_u16 and saturating add/sub against (v +- t) << 8; the junk low byte can only
+      // turn an exact tie into a pass.  The even pixels take the same path after a packed shift left by 8 (exact).
+      const u16x2 T2 = as_u16x2((unsigned)tlo * 0x01000100u);
+      // fo / fe: bit 0 and bit 16 = odd pixels (1, 3) / even pixels (0, 2) of the 4-pixel windows (L = left, C = centre, ...)
+      auto test4 = [&](uint32_t L4, uint32_t C4, uint32_t R4, uint32_t U4, uint32_t D4, unsigned& fe, unsigned& fo) {
+        unsigned flag[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {   // h = 0: odd pixels (high bytes), h = 1: even pixels (shifted up)
+          const u16x2 v2 = h ? as_u16x2(C4) << 8 : as_u16x2(C4);
+          const u16x2 r0 = h ? as_u16x2(D4) << 8 : as_u16x2(D4), r4 = h ? as_u16x2(R4) << 8 : as_u16x2(R4);
+          const u16x2 r8 = h ? as_u16x2(U4) << 8 : as_u16x2(U4), r12 = h ? as_u16x2(L4) << 8 : as_u16x2(L4);
+          const u16x2 mx = __builtin_elementwise_min(__builtin_elementwise_max(r0, r8), __builtin_elementwise_max(r4, r12));
+          const u16x2 mn = __builtin_elementwise_max(__builtin_elementwise_min(r0, r8), __builtin_elementwise_min(r4, r12));
+          const u16x2 hi = __builtin_elementwise_add_sat(v2, T2), lo = __builtin_elementwise_sub_sat(v2, T2);
+          const unsigned e = as_u32(__builtin_elementwise_sub_sat(mx, hi)) | as_u32(__builtin_elementwise_sub_sat(lo, mn));
+          asm("v_pk_min_u16 %0, %1, %2" : "=v"(flag[h]) : "v"(e), "v"(0x00010001u));   // 1 per passing 16-bit lane
+        }
+        fo = flag[0];
+        fe = flag[1];
+      };
+      int y = (int)(((float)lane + 0.5f) / (float)G), g = lane - m24(y, G);
+      int ro = m24(y, TP) + (g << GS);               // byte offset of (row y, column NPX*g) in the tile
+      const int roStep = m24(stepY, TP) + (stepG << GS), roCarry = TP - (G << GS);
+      const uint8_t* t0 = tile - A;
+      for (int i0 = 0; i0 < nItems; i0 += 64) {
+        unsigned m = 0;   // bit k = pixel NPX*g + k passes
+        if (i0 + lane < nItems) {
+          // aligned dwords of (row y+3, tile column NPX*g): byte windows of a row: left = bytes [A, A+NPX),
+          // centre / up / down = [A+3, A+3+NPX), right = [A+6, A+6+NPX)
+          constexpr int c0 = (A + 3) >> 2, cs = (A + 3) & 3, q0 = (A + 6) >> 2, qs = (A + 6) & 3;
+          const uint32_t* cw = reinterpret_cast<const uint32_t*>(t0 + 3 * TP + ro);
+          uint32_t w[NS + 3];
+#pragma unroll
+          for (int k = 0; k < NS + 3; k++) w[k] = cw[k];
+          const uint32_t* uw = reinterpret_cast<const uint32_t*>(t0 + ro) + c0;               // row y-3 (+3 halo)
+          const uint32_t* dw = reinterpret_cast<const uint32_t*>(t0 + 6 * TP + ro) + c0;      // row y+3
+          uint32_t u[NS + 1], d[NS + 1];
+#pragma unroll
+          for (int k = 0; k < NS + 1; k++) { u[k] = uw[k]; d[k] = dw[k]; }
+          unsigned E = 0, O = 0;
+#pragma unroll
+          for (int j = 0; j < NS; j++) {
+            const uint32_t Lj = __builtin_amdgcn_alignbyte(w[j + 1], w[j], A);
+            const uint32_t Cj = __builtin_amdgcn_alignbyte(w[c0 + j + 1], w[c0 + j], cs);
+            const uint32_t Rj = __builtin_amdgcn_alignbyte(w[q0 + j + 1], w[q0 + j], qs);
+            const uint32_t Uj = __builtin_amdgcn_alignbyte(u[j + 1], u[j], cs);
+            const uint32_t Dj = __builtin_amdgcn_alignbyte(d[j + 1], d[j], cs);
+            unsigned fe, fo;
+            test4(Lj, Cj, Rj, Uj, Dj, fe, fo);
+            E |= fe << (4 * j);   // bit 4j = pixel 4j, bit 16+4j = pixel 4j+2
+            O |= fo << (4 * j);   // bit 4j = pixel 4j+1, bit 16+4j = pixel 4j+3
+          }
+          const unsigned T = E | (O << 1);
+          const int rem = W2 - (g << GS);   // pixels of this group inside the emit width (>= 1)
+          m = (T | (T >> 14)) & ((1u << min(rem, NPX)) - 1u);
+        }
+        // ordered compaction: inclusive wave scan of the per-lane counts (DPP, 6 adds)
+        const int c = __popc(m);
+        int incl = c;
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);   // row_shr:1
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);   // row_shr:2
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);   // row_shr:4
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);   // row_shr:8
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+        int pos = nq + incl - c;
+        const unsigned e = (unsigned)((y << 8) | (g << GS));
+#pragma unroll
+        for (int k = 0; k < NPX; k++)
+          if (m & (1u << k)) queue[pos++] = (uint16_t)(e + k);
+        nq += __builtin_amdgcn_readlane(incl, 63);
+        y += stepY;
+        g += stepG;
+        ro += roStep;
+        if (g >= G) { g -= G; y++; ro += roCarry; }
+      }
+    };
+    switch (a) {
+      case 0: stage1(std::integral_constant<int, 0>{}); break;
+      case 1: stage1(std::integral_constant<int, 1>{}); break;
+      case 2: stage1(std::integral_constant<int, 2>{}); break;
+      default: stage1(std::integral_constant<int, 3>{}); break;
+    }
+    wave_lds_fence();
+    // ---- stage 2: score of every stage-1 survivor; survivors of the arc test stay in the queue --------------------
+    // S = max(max_arc min(v - ring), max_arc min(ring - v)) decides both "is a corner at tlo" (S > tlo) and the
+    // OpenCV score (S - 1).  Both polarities are evaluated at once: each register holds (v - r, r - v) as two signed
+    // 16-bit lanes and the arc minima / their maximum run on v_pk_min_i16 / v_pk_max_i16.
+    int nq2 = 0;
+    for (int i0 = 0; i0 < nq; i0 += 64) {
+      const int i = i0 + lane;
+      bool ok = false;
+      unsigned e = 0;
+      if (i < nq) {
+        e = queue[i];
+        const int y = e >> 8, x = e & 0xff;
+        const uint8_t* c = tile + m24(y + 3, TP) + (x + 3);
+        const unsigned vv = c[0];
+        s16x2 d[16];
+        // d[k] = (v - r_k, r_k - v) in the two 16-bit lanes by ONE packed multiply-add per ring pixel:
+        // r_k (low half, used by both lanes) * (-1, +1) + (v, -v)
+        const unsigned VV = vv | ((0u - vv) << 16);
+#define RING(k, off) { unsigned dd; asm("v_pk_mad_i16 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(dd) : "v"((unsigned)c[off]), "v"(0x0001ffffu), "v"(VV)); \
+          d[k] = as_s16x2(dd); }
+        RING(0, 3 * TP);       RING(1, 3 * TP + 1);   RING(2, 2 * TP + 2);    RING(3, TP + 3);
+        RING(4, 3);            RING(5, -TP + 3);      RING(6, -2 * TP + 2);   RING(7, -3 * TP + 1);
+        RING(8, -3 * TP);      RING(9, -3 * TP - 1);  RING(10, -2 * TP - 2);  RING(11, -TP - 3);
+        RING(12, -3);          RING(13, TP - 3);      RING(14, 2 * TP - 2);   RING(15, 3 * TP - 1);
+#undef RING
+        // min over every arc of 9 consecutive ring pixels: the ring is cut into two blocks of 8; an arc starting at k
+        // is a suffix of its block plus a prefix of the next one (van Herk / Gil-Werman): 28 + 16 packed minima
+        s16x2 sA[8], pA[8], sB[8], pB[8];
+        sA[7] = d[7]; sB[7] = d[15]; pA[0] = d[0]; pB[0] = d[8];
+#pragma unroll
+        for (int k = 6; k >= 0; k--) { sA[k] = __builtin_elementwise_min(d[k], sA[k + 1]); sB[k] = __builtin_elementwise_min(d[8 + k], sB[k + 1]); }
+#pragma unroll
+        for (int k = 1; k < 8; k++) { pA[k] = __builtin_elementwise_min(pA[k - 1], d[k]); pB[k] = __builtin_elementwise_min(pB[k - 1], d[8 + k]); }
+        s16x2 w[16];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { w[k] = __builtin_elementwise_min(sA[k], pB[k]); w[8 + k] = __builtin_elementwise_min(sB[k], pA[k]); }
+#pragma unroll
+        for (int k = 0; k < 8; k++) w[k] = __builtin_elementwise_max(w[k], w[k + 8]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) w[k] = __builtin_elementwise_max(w[k], w[k + 4]);
+        const s16x2 best = __builtin_elementwise_max(__builtin_elementwise_max(w[0], w[2]), __builtin_elementwise_max(w[1], w[3]));
+        const int S = max((int)best.x, (int)best.y);
+        ok = S > tlo;
+        if (ok) sc[m24(y + 1, SP) + (x + 1)] = (uint8_t)(S - 1);  // tlo <= S-1 <= 254
+      }
+      // the ballot consumes every lane's queue read, so the in-place writes below cannot overtake them
+      const unsigned long long mk = __ballot(ok);
+      if (ok) queue[nq2 + __popcll(mk & below)] = (uint16_t)e;
+      nq2 += __popcll(mk);
+    }
+    wave_lds_fence();
+    // ---- stage 3: NMS inside each cell's emit region and ordered emission (every survivor has score >= tlo) --------
+    for (int i0 = 0; i0 < nq2; i0 += 64) {
+      const int i = i0 + lane;
+      int keep = 0, y = 0, x = 0;
+      if (i < nq2) {
+        const unsigned e = queue[i];
+        y = e >> 8;
+        x = e & 0xff;
+        const uint8_t* q = sc + m24(y + 1, SP) + (x + 1);
+        const int sv = q[0];
+        // neighbours on the other side of the boundary between the two cells count 0 (each cell is its own cv::FAST ROI)
+        const int lm = (ew1 && x == ew0) ? 0 : 0xff, rm = (ew1 && x == ew0 - 1) ? 0 : 0xff;
+        if (sv > 0 && sv > (q[-1] & lm) && sv > (q[1] & rm) && sv > (q[-SP - 1] & lm) && sv > q[-SP] && sv > (q[-SP + 1] & rm) &&
+            sv > (q[SP - 1] & lm) && sv > q[SP] && sv > (q[SP + 1] & rm))
+          keep = sv;
+      }
+      const bool in1 = x >= ew0;
+      const uint32_t rec = (uint32_t)(ex0 + x) | ((uint32_t)(ey0 + y) << 12) | ((uint32_t)keep << 24);
+      if (emit0) {
+        const unsigned long long mk = __ballot(keep > 0 && !in1);
+        if (keep > 0 && !in1) slot0[base0 + __popcll(mk & below)] = rec;
+        base0 += __popcll(mk);
+      }
+      if (emit1) {
+        const unsigned long long mk = __ballot(keep > 0 && in1);
+        if (keep > 0 && in1) slot1[base1 + __popcll(mk & below)] = rec;
+        base1 += __popcll(mk);
+      }
+    }
+    if (pass == 1 || P.minTh == P.iniTh) break;
+    // ORBextractor.cc:850-856: a cell whose first cv::FAST call returned nothing is detected again at minThFAST
+    emit0 = base0 == 0;
+    emit1 = ew1 > 0 && base1 == 0;
+    if (!emit0 && !emit1) break;
+    wave_lds_fence();   // the queue is rebuilt by the second pass
+  }
+  if (lane == 0) {
+    cnt[0] = (uint32_t)base0;
+    if (ew1) cnt[1] = (uint32_t)base1;
+  }
+}
+
+size_t fast_lds_bytes(const PyramidParams& P, int tpPad) {
+  size_t mx = 0;
+  for (int l = 0; l < P.nlevels; l++) {
+    const LevelGeom& L = P.lv[l];
+    const size_t TP = ((L.fastW + 6 + 3 + 3) & ~3) + tpPad;
+    const size_t b = ((TP * (L.hCell + 6) + (size_t)(L.fastW + 2) * (L.hCell + 2) + 3) & ~(size_t)3) +
+                     2 * (size_t)L.fastW * L.hCell + 64;  // tile + score tile + u16 queue + slack for the group over-read
+    mx = b > mx ? b : mx;
+  }
+  return (mx + 15) & ~(size_t)15;
+}
+
+void launch_fast(const PyramidParams& P, int nframes, hipStream_t st) {
+  static const int npx = getenv("ORBFE_FAST_NPX") ? atoi(getenv("ORBFE_FAST_NPX")) : 16;     // A/B aids
+  static const int tpPad = getenv("ORBFE_FAST_TPPAD") ? atoi(getenv("ORBFE_FAST_TPPAD")) & ~3 : 0;
+  const dim3 grid(8 * ((P.ntasks + 7) / 8), nframes);
+  if (npx == 8) hipLaunchKernelGGL(k_fast_tasks<8>, grid, dim3(64), fast_lds_bytes(P, tpPad), st, P, tpPad);
+  else hipLaunchKernelGGL(k_fast_tasks<16>, grid, dim3(64), fast_lds_bytes(P, tpPad), st, P, tpPad);
+}
+
+}  // namespace orbfe

@@ -28,6 +28,7 @@ struct LevelGeom {
   const int* yofs;         // [h]   source row (unclamped)
   const short* ybeta;      // [2*h] 11-bit weights (b0,b1)
   int rzPitch, rzRows;     // LDS pitch / rows of the largest 64x64-tile source footprint (k_resize)
+  int fastW;               // widest emit region of a FAST task on this level (2 * wCell when cells are paired, else wCell)
 };
 
 // Per-cell geometry, precomputed on the host so a cell's wave needs one 16-byte load instead of a scalar
@@ -38,6 +39,16 @@ struct CellInfo {
   uint8_t level, pad;
   uint32_t slotOff;      // first slot of the cell inside a frame's slot array (u32 units)
   uint32_t local;        // cell index inside its level
+};
+
+// One wave of k_fast_tasks: one FAST cell, or two horizontally adjacent cells of the same cell row whose union is at
+// most 64 pixels wide (the second cell starts where the first ends, so the union's ROI is one contiguous tile).
+struct FastTask {
+  uint16_t ex0, ey0;     // first emit pixel of cell 0 (level coordinates)
+  uint8_t ew0, ew1;      // emit widths of cell 0 / cell 1 (ew1 = 0: single cell; ew0 = 0: the cell emits nothing)
+  uint8_t eh, level;
+  uint32_t cell0;        // index of cell 0 in the per-frame cell arrays (cell 1 = cell0 + 1)
+  uint32_t slotOff0;     // first slot of cell 0 (cell 1: + the level's slotCap)
 };
 
 struct PyramidParams {
@@ -56,6 +67,8 @@ struct PyramidParams {
   uint32_t* cand;                   // [nframes][candCap]  packed x | y<<12 | score<<24 (level coords)
   uint32_t* levelStart;             // [nframes][kMaxLevels+1]
   const CellInfo* cells;            // [ncells]
+  const FastTask* tasks;            // [ntasks] work items of k_fast_tasks
+  int ntasks;
   int iniTh, minTh;
   int frameBase;                    // first frame of this launch (sub-batch pipelining)
 };

@@ -5,8 +5,7 @@
 //
 //   k_to_gray       cv::cvtColor RGB/BGR(A) -> gray, 8u fixed point (colour input only)
 //   k_resize        cv::resize INTER_LINEAR 8u (level l <- level l-1), 11-bit fixed point, separable through LDS
-//   k_fast_cells    per reference FAST cell (1 wave/cell): iniTh pass, minTh pass only for cells left empty;
-//                   packed pre-test, exact score of the survivors, 3x3 NMS, ordered emission
+//   (k_fast_tasks   per reference FAST cell, one wave per cell pair: orbfe_fast.hip)
 //   k_scan_cells    exclusive scan of per-cell counts -> reference candidate order
 //   k_gather        ordered compaction of the per-cell slots (1 lane/cell)
 //   k_describe      per keypoint (1 wave): IC-angle (dot4), 7x7 fixed-point Gaussian of the 37x37 neighbourhood
@@ -148,298 +147,10 @@ __global__ __launch_bounds__(256) void k_resize(PyramidParams P, int level) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// FAST-9/16 per reference cell.  Reference: ComputeKeyPointsOctTree, src/ORBextractor.cc:797-870
-// (cv::FAST calls at :848,:854); cv::FAST semantics: SURVEY.md Appendix B.1.
-//
-// Formulation (DESIGN.md "FAST"): with S(p) = max(max_arc min(v-ring), max_arc min(ring-v)) a pixel
-// is a corner at threshold t iff S(p) > t and its OpenCV score is S(p)-1, independent of t.  The
-// cell's FAST(t, nms) output is therefore {p in emit region : s(p) >= t and s(p) > s(q) for the 8
-// neighbours q inside the SAME cell's emit region}, s = S-1 (0 where S-1 < min(iniTh,minTh)).
-// The emit region of cell (i,j) is [19+j*wCell, min(19+(j+1)*wCell, w-19)) x [19+i*hCell, ...).
-// One wave per cell: ROI -> LDS, score tile -> LDS, NMS, then the iniTh/minTh decision by
-// wave-wide ballot and an ordered (row-major) write of the survivors into the cell's slots.
-// ------------------------------------------------------------------------------------------------
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2 as_u16x2(unsigned v) { return __builtin_bit_cast(u16x2, v); }
 __device__ __forceinline__ unsigned as_u32(u16x2 v) { return __builtin_bit_cast(unsigned, v); }
-__device__ __forceinline__ s16x2 as_s16x2(unsigned v) { return __builtin_bit_cast(s16x2, v); }
-
-// Work decomposition inside the wave (all stages keep row-major order, so the final list is already
-// in cv::FAST's emission order):
-//   stage 1  every emit pixel, 4 per lane: compass pre-test (a 9-arc always contains two ADJACENT
-//            compass points of one polarity) on packed 16-bit lanes -> ballot-compacted queue
-//   stage 2  queue: S = max over both polarities of max_arc min9, both polarities per packed op;
-//            S > tlo keeps the entry (compacted in place) and writes the score S-1 to the score tile
-//   stage 3  queue: 3x3 NMS against the score tile, iniTh/minTh decision by ballot, ordered write
-// Blocks are remapped so that the blocks an XCD receives (b, b+8, b+16, ...) are CONSECUTIVE cells:
-// neighbouring cells share ROI halos and cache lines in that XCD's L2.
-__global__ __launch_bounds__(64) void k_fast_cells(PyramidParams P) {
-  extern __shared__ __align__(16) uint8_t lds[];
-  const int chunk = (P.ncells + 7) >> 3;
-  const int cell = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-  if (cell >= P.ncells) return;
-  const int f = P.frameBase + blockIdx.y;
-  const int lane = threadIdx.x;
-  const CellInfo ci = P.cells[cell];
-  const int level = ci.level;
-  const LevelGeom& L = P.lv[level];
-  const int ex0 = ci.ex0, ey0 = ci.ey0, ew = ci.ew, eh = ci.eh;
-  uint32_t* cnt = P.cellCount + (long long)f * P.ncells + cell;
-  if (ew <= 0 || eh <= 0) {
-    if (lane == 0) *cnt = 0;
-    return;
-  }
-  const uint8_t* img;
-  long long stride;
-  if (level == 0) {
-    img = P.frame0[f];
-    stride = P.stride0;
-  } else {
-    img = P.slab + (long long)f * P.slabBytes + L.off;
-    stride = L.pitch;
-  }
-  // LDS carve: ROI tile, score tile with a zero ring, queue (y<<8|x)
-  const int TP = (L.wCell + 6 + 3 + 3) & ~3;
-  const int SP = L.wCell + 2;
-  uint8_t* tile = lds;
-  uint8_t* sc = tile + TP * (L.hCell + 6);
-  uint16_t* queue = reinterpret_cast<uint16_t*>(lds + ((TP * (L.hCell + 6) + SP * (L.hCell + 2) + 3) & ~3));
-
-  const int rw = ew + 6, rh = eh + 6;
-  const int istr = (int)stride;
-  const uint8_t* roi = img + (long long)(ey0 - 3) * stride + (ex0 - 3);
-  // ROI -> LDS.  Loads are issued in batches of 8 per lane before the first LDS write so the wave
-  // waits for memory once per batch, not once per element.  Rows are fetched as aligned dwords when
-  // the row pitch allows it; `a` is the byte offset of the ROI inside its first dword.
-  const int a = (int)(reinterpret_cast<uintptr_t>(roi) & 3);
-  if ((stride & 3) == 0) {
-    // lane (c, r0) = (lane % 16, lane / 16) copies dword column c of rows r0, r0+4, ... with plain adds;
-    // columns 16.. of very wide cells are covered by a second column pass
-    const int ndw = (a + rw + 3) >> 2;
-    const uint8_t* base = roi - a;
-    const int r0 = lane >> 4;
-    for (int c = lane & 15; c < ndw; c += 16) {
-      const uint8_t* g = base + 4 * c + m24(r0, istr);
-      uint8_t* l = tile + 4 * c + m24(r0, TP);
-      const int gstep = 4 * istr, lstep = 4 * TP;
-      for (int r = r0; r < rh; r += 48, g += 12 * gstep, l += 12 * lstep) {
-        uint32_t v[12];
-#pragma unroll
-        for (int u = 0; u < 12; u++) v[u] = (r + 4 * u < rh) ? *reinterpret_cast<const uint32_t*>(g + u * gstep) : 0u;
-#pragma unroll
-        for (int u = 0; u < 12; u++)
-          if (r + 4 * u < rh) *reinterpret_cast<uint32_t*>(l + u * lstep) = v[u];
-      }
-    }
-  } else {
-    const float rcpRw = 1.0f / (float)rw;
-    const int total = rw * rh;
-    for (int i0 = lane; i0 < total; i0 += 64 * 8) {
-      uint8_t v[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int i = i0 + u * 64;
-        v[u] = 0;
-        if (i < total) {
-          const int y = (int)(((float)i + 0.5f) * rcpRw), x = i - m24(y, rw);
-          v[u] = roi[m24(y, istr) + x];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int i = i0 + u * 64;
-        if (i < total) {
-          const int y = (int)(((float)i + 0.5f) * rcpRw), x = i - m24(y, rw);
-          tile[m24(y, TP) + a + x] = v[u];
-        }
-      }
-    }
-  }
-  tile += a;  // ROI pixel (x, y) lives at tile[y * TP + x]
-  {  // zero the score tile with dword stores (sc is 4-byte aligned: TP*(hCell+6) is a multiple of 4)
-    uint32_t* z = reinterpret_cast<uint32_t*>(sc);
-    const int nz = (SP * (eh + 2) + 3) >> 2;
-    for (int i = lane; i < nz; i += 64) z[i] = 0u;
-  }
-  __syncthreads();
-
-  const unsigned long long below = (1ull << lane) - 1ull;
-  uint32_t* slot = P.slots + (long long)f * P.slotsPerFrame + ci.slotOff;
-  int base = 0;
-  // Two passes at most, like the reference (ORBextractor.cc:846-856): cv::FAST at iniThFAST; only if that leaves the
-  // cell without a keypoint (after NMS), cv::FAST again at minThFAST.  The threshold decides how many pixels survive
-  // the pre-test, so the common first pass touches a fraction of what a combined low-threshold pass would.
-  for (int pass = 0; pass < 2; pass++) {
-  const int tlo = pass ? P.minTh : P.iniTh;
-  // ---- stage 1: compass pre-test, 4 horizontally adjacent pixels per lane -------------------------
-  // Lane item i = (row y, group g): pixels x = 4g..4g+3.  The 10 centre-row bytes and the 4 bytes of rows
-  // y-3 / y+3 come from aligned LDS dwords and one funnel shift each (the byte alignment `a` of the ROI
-  // is uniform for the cell, so it is a template constant of the loop body).
-  int nq = 0;
-  const int G = (ew + 7) >> 3, nItems = G * eh;      // lane item = (row y, group g): pixels x = 8g .. 8g+7
-  const int stepY = 64 / G, stepG = 64 - stepY * G;   // item i+64 = (y + stepY, g + stepG) with one carry
-  auto stage1 = [&](auto aTag) {
-    constexpr int A = decltype(aTag)::value;
-    // The test is CONSERVATIVE (a superset of "two adjacent compass points of one polarity", stage 2 decides
-    // exactly) and runs on the packed bytes as they come out of LDS: a 16-bit lane holds pixels (2j, 2j+1) as
-    // (low byte, high byte).  min/max of such lanes is exact in the high byte, so for the odd pixels
-    //   bright: min(max(r0,r8), max(r4,r12)) > v+t     dark: max(min(r0,r8), min(r4,r12)) < v-t
-    // are evaluated with v_pk_min/max_u16 and saturating add/sub against (v +- t) << 8; the junk low byte can
-    // only turn an exact tie into a pass.  The even pixels take the same path after a packed shift left by 8
-    // (exact).  Pixels beyond the emit width are dropped in stage 2.
-    const u16x2 T2 = as_u16x2((unsigned)tlo * 0x01000100u);
-    // bits 0, 1, 16, 17 of the result = pixels 0, 1, 2, 3 of the 4-pixel windows (L = left, C = centre, ...)
-    auto test4 = [&](uint32_t L4, uint32_t C4, uint32_t R4, uint32_t U4, uint32_t D4) -> unsigned {
-      unsigned flag[2];
-#pragma unroll
-      for (int h = 0; h < 2; h++) {   // h = 0: odd pixels (high bytes), h = 1: even pixels (shifted up)
-        const u16x2 v2 = h ? as_u16x2(C4) << 8 : as_u16x2(C4);
-        const u16x2 r0 = h ? as_u16x2(D4) << 8 : as_u16x2(D4), r4 = h ? as_u16x2(R4) << 8 : as_u16x2(R4);
-        const u16x2 r8 = h ? as_u16x2(U4) << 8 : as_u16x2(U4), r12 = h ? as_u16x2(L4) << 8 : as_u16x2(L4);
-        const u16x2 mx = __builtin_elementwise_min(__builtin_elementwise_max(r0, r8), __builtin_elementwise_max(r4, r12));
-        const u16x2 mn = __builtin_elementwise_max(__builtin_elementwise_min(r0, r8), __builtin_elementwise_min(r4, r12));
-        const u16x2 hi = __builtin_elementwise_add_sat(v2, T2), lo = __builtin_elementwise_sub_sat(v2, T2);
-        const unsigned e = as_u32(__builtin_elementwise_sub_sat(mx, hi)) | as_u32(__builtin_elementwise_sub_sat(lo, mn));
-        asm("v_pk_min_u16 %0, %1, %2" : "=v"(flag[h]) : "v"(e), "v"(0x00010001u));   // 1 per passing 16-bit lane
-      }
-      return flag[1] | (flag[0] << 1);
-    };
-    int y = (int)(((float)lane + 0.5f) / (float)G), g = lane - m24(y, G);
-    int ro = m24(y, TP) + (g << 3);               // byte offset of (row y, column 8g) in the tile
-    const int roStep = m24(stepY, TP) + (stepG << 3), roCarry = TP - (G << 3);
-    const uint8_t* t0 = tile - A;
-    for (int i0 = 0; i0 < nItems; i0 += 64) {
-      unsigned pb0 = 0, pb1 = 0;   // pixels 0..3 and 4..7
-      const int x = g << 3;
-      if (i0 + lane < nItems) {
-        // aligned dwords of (row y+3, tile column x): tile already includes the +A shift.  Byte windows of a row:
-        // left = bytes [A, A+8), centre / up / down = [A+3, A+11), right = [A+6, A+14)
-        constexpr int c0 = (A + 3) >> 2, cs = (A + 3) & 3, q0 = (A + 6) >> 2, qs = (A + 6) & 3;
-        const uint32_t* cw = reinterpret_cast<const uint32_t*>(t0 + 3 * TP + ro);
-        const uint32_t w0 = cw[0], w1 = cw[1], w2 = cw[2], w3 = cw[3], w4 = cw[4];
-        const uint32_t w[5] = {w0, w1, w2, w3, w4};
-        const uint32_t* uw = reinterpret_cast<const uint32_t*>(t0 + ro) + c0;               // row y-3 (+3 halo)
-        const uint32_t* dw = reinterpret_cast<const uint32_t*>(t0 + 6 * TP + ro) + c0;      // row y+3
-        const uint32_t u0 = uw[0], u1 = uw[1], u2 = uw[2], d0 = dw[0], d1 = dw[1], d2 = dw[2];
-        const uint32_t La = __builtin_amdgcn_alignbyte(w1, w0, A), Lb = __builtin_amdgcn_alignbyte(w2, w1, A);
-        const uint32_t Ca = __builtin_amdgcn_alignbyte(w[c0 + 1], w[c0], cs), Cb = __builtin_amdgcn_alignbyte(w[c0 + 2], w[c0 + 1], cs);
-        const uint32_t Ra = __builtin_amdgcn_alignbyte(w[q0 + 1], w[q0], qs), Rb = __builtin_amdgcn_alignbyte(w[q0 + 2], w[q0 + 1], qs);
-        const uint32_t Ua = __builtin_amdgcn_alignbyte(u1, u0, cs), Ub = __builtin_amdgcn_alignbyte(u2, u1, cs);
-        const uint32_t Da = __builtin_amdgcn_alignbyte(d1, d0, cs), Db = __builtin_amdgcn_alignbyte(d2, d1, cs);
-        pb0 = test4(La, Ca, Ra, Ua, Da);
-        pb1 = test4(Lb, Cb, Rb, Ub, Db);
-      }
-      // ordered compaction: inclusive wave scan of the per-lane counts (DPP, 6 adds)
-      const int c = __popc(pb0) + __popc(pb1);
-      int incl = c;
-      incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);   // row_shr:1
-      incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);   // row_shr:2
-      incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);   // row_shr:4
-      incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);   // row_shr:8
-      incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
-      incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
-      int pos = nq + incl - c;
-      const unsigned e = (unsigned)((y << 8) | x);
-      if (pb0 & 1u) queue[pos++] = (uint16_t)e;
-      if (pb0 & 2u) queue[pos++] = (uint16_t)(e + 1);
-      if (pb0 & 0x10000u) queue[pos++] = (uint16_t)(e + 2);
-      if (pb0 & 0x20000u) queue[pos++] = (uint16_t)(e + 3);
-      if (pb1 & 1u) queue[pos++] = (uint16_t)(e + 4);
-      if (pb1 & 2u) queue[pos++] = (uint16_t)(e + 5);
-      if (pb1 & 0x10000u) queue[pos++] = (uint16_t)(e + 6);
-      if (pb1 & 0x20000u) queue[pos++] = (uint16_t)(e + 7);
-      nq += __builtin_amdgcn_readlane(incl, 63);
-      y += stepY;
-      g += stepG;
-      ro += roStep;
-      if (g >= G) { g -= G; y++; ro += roCarry; }
-    }
-  };
-  switch (a) {
-    case 0: stage1(std::integral_constant<int, 0>{}); break;
-    case 1: stage1(std::integral_constant<int, 1>{}); break;
-    case 2: stage1(std::integral_constant<int, 2>{}); break;
-    default: stage1(std::integral_constant<int, 3>{}); break;
-  }
-  __syncthreads();
-  // ---- stage 2: score of every stage-1 survivor; survivors of the arc test stay in the queue ---------
-  // S = max(max_arc min(v - ring), max_arc min(ring - v)) decides both "is a corner at tlo" (S > tlo) and the
-  // OpenCV score (S - 1).  Both polarities are evaluated at once: each register holds (v - r, r - v) as two
-  // signed 16-bit lanes and the sliding min-of-9 / max-over-arcs runs on v_pk_min_i16 / v_pk_max_i16.
-  int nq2 = 0;
-  for (int i0 = 0; i0 < nq; i0 += 64) {
-    const int i = i0 + lane;
-    bool pass = false;
-    unsigned e = 0;
-    if (i < nq) {
-      e = queue[i];
-      const int y = e >> 8, x = e & 0xff;
-      const uint8_t* c = tile + m24(y + 3, TP) + (x + 3);
-      const unsigned vv = c[0];
-      s16x2 d[16];
-      // d[k] = (v - r_k, r_k - v) in the two 16-bit lanes by ONE packed multiply-add per ring pixel:
-      // r_k (low half, used by both lanes) * (-1, +1) + (v, -v)
-      const unsigned VV = vv | ((0u - vv) << 16);
-#define RING(k, off) { unsigned dd; asm("v_pk_mad_i16 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(dd) : "v"((unsigned)c[off]), "v"(0x0001ffffu), "v"(VV)); \
-        d[k] = as_s16x2(dd); }
-      RING(0, 3 * TP);       RING(1, 3 * TP + 1);   RING(2, 2 * TP + 2);    RING(3, TP + 3);
-      RING(4, 3);            RING(5, -TP + 3);      RING(6, -2 * TP + 2);   RING(7, -3 * TP + 1);
-      RING(8, -3 * TP);      RING(9, -3 * TP - 1);  RING(10, -2 * TP - 2);  RING(11, -TP - 3);
-      RING(12, -3);          RING(13, TP - 3);      RING(14, 2 * TP - 2);   RING(15, 3 * TP - 1);
-#undef RING
-      // min over every arc of 9 consecutive ring pixels: the ring is cut into two blocks of 8; an arc starting at k is
-      // a suffix of its block plus a prefix of the next one (van Herk / Gil-Werman), 28 + 16 packed minima instead of
-      // the 64 of the log-step sliding minimum
-      s16x2 sA[8], pA[8], sB[8], pB[8];
-      sA[7] = d[7]; sB[7] = d[15]; pA[0] = d[0]; pB[0] = d[8];
-#pragma unroll
-      for (int k = 6; k >= 0; k--) { sA[k] = __builtin_elementwise_min(d[k], sA[k + 1]); sB[k] = __builtin_elementwise_min(d[8 + k], sB[k + 1]); }
-#pragma unroll
-      for (int k = 1; k < 8; k++) { pA[k] = __builtin_elementwise_min(pA[k - 1], d[k]); pB[k] = __builtin_elementwise_min(pB[k - 1], d[8 + k]); }
-      s16x2 w[16];
-#pragma unroll
-      for (int k = 0; k < 8; k++) { w[k] = __builtin_elementwise_min(sA[k], pB[k]); w[8 + k] = __builtin_elementwise_min(sB[k], pA[k]); }
-#pragma unroll
-      for (int k = 0; k < 8; k++) w[k] = __builtin_elementwise_max(w[k], w[k + 8]);
-#pragma unroll
-      for (int k = 0; k < 4; k++) w[k] = __builtin_elementwise_max(w[k], w[k + 4]);
-      const s16x2 best = __builtin_elementwise_max(__builtin_elementwise_max(w[0], w[2]), __builtin_elementwise_max(w[1], w[3]));
-      const int S = max((int)best.x, (int)best.y);
-      pass = S > tlo && x < ew;   // stage 1 tests whole 8-pixel groups
-      if (pass) sc[m24(y + 1, SP) + (x + 1)] = (uint8_t)(S - 1);  // tlo <= S-1 <= 254
-    }
-    // the ballot consumes every lane's queue read, so the in-place writes below cannot overtake them
-    const unsigned long long m = __ballot(pass);
-    if (pass) queue[nq2 + __popcll(m & below)] = (uint16_t)e;
-    nq2 += __popcll(m);
-  }
-  __syncthreads();
-  // ---- stage 3: NMS inside the emit region and ordered emission (every survivor has score >= tlo) ---------
-  for (int i0 = 0; i0 < nq2; i0 += 64) {
-    const int i = i0 + lane;
-    int keep = 0, y = 0, x = 0;
-    if (i < nq2) {
-      const unsigned e = queue[i];
-      y = (e >> 8) & 0x7f;
-      x = e & 0x7f;
-      const uint8_t* q = sc + m24(y + 1, SP) + (x + 1);
-      const int sv = q[0];
-      if (sv > 0 && sv > q[-1] && sv > q[1] && sv > q[-SP - 1] && sv > q[-SP] && sv > q[-SP + 1] && sv > q[SP - 1] &&
-          sv > q[SP] && sv > q[SP + 1])
-        keep = sv;
-    }
-    const unsigned long long m = __ballot(keep > 0);
-    if (keep > 0)
-      slot[base + __popcll(m & below)] = (uint32_t)(ex0 + x) | ((uint32_t)(ey0 + y) << 12) | ((uint32_t)keep << 24);
-    base += __popcll(m);
-  }
-  if (base > 0 || P.minTh == P.iniTh) break;
-  __syncthreads();   // the queue is rebuilt by the second pass
-  }
-  if (lane == 0) *cnt = (uint32_t)base;
-}
 
 // ------------------------------------------------------------------------------------------------
 // Exclusive scan of the per-cell counts of one frame (cells are numbered level-major, cell-row-major:
@@ -848,22 +559,6 @@ void launch_pyramid(const PyramidParams& P, int nframes, hipStream_t st) {
     hipLaunchKernelGGL(k_resize, grid, dim3(256), (((size_t)P.lv[l].rzPitch * P.lv[l].rzRows + 15) & ~(size_t)15) + (size_t)P.lv[l].rzRows * 64 * 2, st,
                        P, l);
   }
-}
-
-size_t fast_lds_bytes(const PyramidParams& P) {
-  size_t mx = 0;
-  for (int l = 0; l < P.nlevels; l++) {
-    const LevelGeom& L = P.lv[l];
-    const size_t TP = (L.wCell + 6 + 3 + 3) & ~3;
-    const size_t b = ((TP * (L.hCell + 6) + (size_t)(L.wCell + 2) * (L.hCell + 2) + 3) & ~(size_t)3) +
-                     2 * (size_t)(L.wCell + 7) * L.hCell;  // tile + score tile + u16 queue (whole 8-pixel groups)
-    mx = b > mx ? b : mx;
-  }
-  return (mx + 15) & ~(size_t)15;
-}
-
-void launch_fast(const PyramidParams& P, int nframes, hipStream_t st) {
-  hipLaunchKernelGGL(k_fast_cells, dim3(8 * ((P.ncells + 7) / 8), nframes), dim3(64), fast_lds_bytes(P), st, P);
 }
 
 void launch_compact(const PyramidParams& P, int nframes, hipStream_t st) {

@@ -6,4 +6,4 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_W
   n=$(echo $set | md5sum | cut -c1-6)
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/$n -- python3 /root/repo/tools/quick_bench.py 32 > /dev/null 2>&1
 done
-python3 /root/repo/tools/pmc_summary.py $out
+python3 /root/repo/tools/pmc_summary.py $out ${@:2}

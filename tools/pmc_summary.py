@@ -9,7 +9,7 @@ only = sys.argv[2:]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + '/*/*/*_counter_collection.csv'):
     for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name'].split('(')[0].replace('orbfe::', '').replace('void ', '')
+        k = r['Kernel_Name'].split('(')[0].split('<')[0].replace('orbfe::', '').replace('void ', '')
         agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
 for k in sorted(agg):
     if not k.startswith('k_') or (only and k not in only):
