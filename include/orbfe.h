@@ -452,6 +452,15 @@ int orbfe_search_for_triangulation(orbfe_matcher* m, const OrbfeKeyPoint* kps1_u
  * Frame::ComputeImageBounds (:322-353).  Host double-precision math on n (x, y) float pairs, in place; K is the
  * float intrinsic matrix {fx, fy, cx, cy}.  (Microseconds of scalar work per frame: it stays on the host.) */
 int orbfe_undistort_equidistant(float* xy, int n, float fx, float fy, float cx, float cy);
+/* The pinhole branch of the same two callers: cv::undistortPoints(mat, mat, mK, mDistCoef, cv::Mat(), mK)
+ * (src/Frame.cc:307, 339; camera `modo: 0` with Camera.k1 != 0).  dist = mDistCoef: k1 k2 p1 p2 [k3 [k4 k5 k6]]
+ * (src/Tracking.cc:1221-1243), ndist 0..8.  Host double-precision math, in place. */
+int orbfe_undistort_pinhole(float* xy, int n, float fx, float fy, float cx, float cy, const float* dist, int ndist);
+/* void Frame::ComputeImageBounds(const cv::Mat& imLeft)  (src/Frame.cc:322-353): bounds = {mnMinX, mnMaxX, mnMinY,
+ * mnMaxY}; camera_mode 0 = pinhole (undistorted corners when dist[0] != 0, else the image rectangle), 1 = os1's
+ * equidistant fisheye. */
+int orbfe_compute_image_bounds(int cols, int rows, int camera_mode, float fx, float fy, float cx, float cy, const float* dist,
+                               int ndist, float bounds[4]);
 
 /* Frame::GetFeaturesInArea (src/Frame.cc:209-262) evaluated by the GPU candidate kernel, for the
  * parity tests: indices in reference order.  out[cap]. */

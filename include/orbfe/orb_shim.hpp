@@ -12,6 +12,7 @@
 // silently corrupt tracking.
 #pragma once
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -168,6 +169,425 @@ inline int SearchByProjection(MatcherContext& ctx, float mfNNratio, FrameT& F,
   for (int i = 0; i < n; i++)
     if (assigned[i] >= 0) F.mvpMapPoints[i] = vpMapPoints[assigned[i]];
   return nmatches;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Pose-driven searches.  The reference projects MapPoints with cv::Mat expressions; what those expressions compute
+// is OpenCV arithmetic.  RestatedOps restates it (OpenCV 4.x core/src/matmul.simd.hpp small-matrix gemm path,
+// matrix_expressions.cpp, norm.cpp; recalled) so that this header needs no OpenCV; a build that
+// has OpenCV passes CvOps (include/orbfe/ORBmatcher.h), whose members ARE the reference's expressions.
+// ---------------------------------------------------------------------------------------------------------------
+namespace detail {
+struct RestatedOps {
+  // alpha * A(3x3) * b(3x1) + beta * c   -- `Rcw*x3Dw+tcw`, `-sR21*t12` (gemm, flags 0, len 3: float dot, double epilogue)
+  static void gemm3(const float A[9], const float b[3], double alpha, const float* c, double beta, float d[3]) {
+    for (int i = 0; i < 3; i++) {
+      const float t = A[3 * i] * b[0] + A[3 * i + 1] * b[1] + A[3 * i + 2] * b[2];
+      d[i] = (float)((double)t * alpha + (double)(c ? c[i] : 0.f) * beta);
+    }
+  }
+  // alpha * A.t() * b   -- `-Rcw.t()*tcw` (gemm with GEMM_1_T: generic path, double accumulation)
+  static void gemmT3(const float A[9], const float b[3], double alpha, float d[3]) {
+    for (int i = 0; i < 3; i++) {
+      double s = 0;
+      for (int k = 0; k < 3; k++) s += (double)A[3 * k + i] * (double)b[k];
+      d[i] = (float)(s * alpha);
+    }
+  }
+  static double norm3(const float v[3]) {   // cv::norm(v)
+    double s = 0;
+    for (int k = 0; k < 3; k++) s += (double)v[k] * (double)v[k];
+    return std::sqrt(s);
+  }
+  static double dot3(const float a[3], const float b[3]) {   // a.dot(b)
+    double r = 0;
+    for (int k = 0; k < 3; k++) r += (double)a[k] * (double)b[k];
+    return r;
+  }
+  static void scale(const float* M, int n, double s, float* out) {   // `s*M` (MatExpr scale -> convertTo with a float factor)
+    const float f = (float)s;
+    for (int i = 0; i < n; i++) out[i] = M[i] * f;
+  }
+  static void divide(const float* M, int n, double s, float* out) { scale(M, n, 1.0 / s, out); }   // `M/s` = M * (1./s)
+};
+
+template <class MatT>
+inline void poseRt(const MatT& T, float R[9], float t[3]) {   // T.rowRange(0,3).colRange(0,3), T.rowRange(0,3).col(3)
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) R[3 * r + c] = T.template at<float>(r, c);
+    t[r] = T.template at<float>(r, 3);
+  }
+}
+template <class MatT>
+inline void vec3(const MatT& m, float v[3]) {
+  for (int r = 0; r < 3; r++) v[r] = m.template at<float>(r, 0);
+}
+template <class MatT>
+inline void mat33(const MatT& m, float v[9]) {
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) v[3 * r + c] = m.template at<float>(r, c);
+}
+// Scw -> Rcw, tcw, Ow   (ORBmatcher.cc:293-298, 949-954)
+template <class Ops, class MatT>
+inline void decomposeScw(const MatT& Scw, float Rcw[9], float tcw[3], float Ow[3]) {
+  float sR[9], st[3];
+  poseRt(Scw, sR, st);
+  const float scw = (float)std::sqrt(Ops::dot3(sR, sR));
+  Ops::divide(sR, 9, (double)scw, Rcw);   // sRcw/scw
+  Ops::divide(st, 3, (double)scw, tcw);   // Scw.rowRange(0,3).col(3)/scw
+  Ops::gemmT3(Rcw, tcw, -1.0, Ow);
+}
+
+// one windowed search of MapPoints projected into a KeyFrame (the loops of SearchByProjection(KF, Scw), Fuse x2, SearchBySim3)
+struct ProjectedSources {
+  std::vector<float> uv, radius;
+  std::vector<int32_t> level, bestIdx, bestDist;
+  std::vector<uint8_t> valid, desc;
+  explicit ProjectedSources(size_t n) : uv(2 * n, 0.f), radius(n, 0.f), level(n, 0), bestIdx(n, -1), bestDist(n, -1), valid(n, 0), desc(32 * n, 0) {}
+};
+template <class KeyFrameT>
+inline int searchProjected(MatcherContext& ctx, KeyFrameT* pKF, ProjectedSources& S, const uint8_t* kp_skip, int claim,
+                           bool chi2, int max_dist) {
+  const int n = (int)pKF->mvKeysUn.size(), ns = (int)S.valid.size();
+  std::vector<uint8_t> tmp;
+  float b[4];
+  frameBounds(*pKF, b);
+  int nm = 0;
+  check(orbfe_search_projected(ctx.get(), reinterpret_cast<const OrbfeKeyPoint*>(pKF->mvKeysUn.data()),
+                               packedDescriptors(pKF->mDescriptors, n, tmp), n, b, ns, S.uv.data(), S.radius.data(),
+                               S.level.data(), S.valid.data(), S.desc.data(), kp_skip, claim,
+                               chi2 ? pKF->mvInvLevelSigma2.data() : nullptr, chi2 ? (int)pKF->mvInvLevelSigma2.size() : 0, 5.99,
+                               max_dist, S.bestIdx.data(), S.bestDist.data(), &nm));
+  return nm;
+}
+// the part of the KeyFrame-side loops between GetWorldPos and GetFeaturesInArea (:322-355, 826-873, 972-1013): fills
+// source i and returns whether the point survives the depth / image / distance / viewing-angle tests
+template <class Ops, class KeyFrameT, class MapPointT>
+inline bool projectIntoKeyFrame(KeyFrameT* pKF, MapPointT* pMP, const float Rcw[9], const float tcw[3], const float Ow[3],
+                                float th, bool invzDouble, ProjectedSources& S, size_t i) {
+  float p3Dw[3], p3Dc[3];
+  vec3(pMP->GetWorldPos(), p3Dw);
+  Ops::gemm3(Rcw, p3Dw, 1.0, tcw, 1.0, p3Dc);
+  if (p3Dc[2] < 0.0f) return false;
+  const float invz = invzDouble ? (float)(1.0 / p3Dc[2]) : 1 / p3Dc[2];
+  const float x = p3Dc[0] * invz, y = p3Dc[1] * invz;
+  const float u = pKF->fx * x + pKF->cx, v = pKF->fy * y + pKF->cy;
+  if (!pKF->IsInImage(u, v)) return false;
+  const float maxDistance = pMP->GetMaxDistanceInvariance(), minDistance = pMP->GetMinDistanceInvariance();
+  const float PO[3] = {p3Dw[0] - Ow[0], p3Dw[1] - Ow[1], p3Dw[2] - Ow[2]};
+  const float dist3D = (float)Ops::norm3(PO);
+  if (dist3D < minDistance || dist3D > maxDistance) return false;
+  float Pn[3];
+  vec3(pMP->GetNormal(), Pn);
+  if (Ops::dot3(PO, Pn) < 0.5 * dist3D) return false;
+  const int nPredictedLevel = pMP->PredictScale(dist3D, pKF->mfLogScaleFactor);
+  S.uv[2 * i] = u; S.uv[2 * i + 1] = v;
+  S.level[i] = nPredictedLevel;
+  S.radius[i] = th * pKF->mvScaleFactors[nPredictedLevel];
+  const auto d = pMP->GetDescriptor();
+  std::memcpy(&S.desc[32 * i], d.data, 32);
+  S.valid[i] = 1;
+  return true;
+}
+}  // namespace detail
+
+// int ORBmatcher::SearchByProjection(Frame& CurrentFrame, const Frame& LastFrame, const float th)   (ORBmatcher.cc:1292-1423)
+template <class Ops = detail::RestatedOps, class FrameT>
+inline int SearchByProjection(MatcherContext& ctx, bool mbCheckOrientation, FrameT& CurrentFrame, const FrameT& LastFrame,
+                              const float th) {
+  float Rcw[9], tcw[3];
+  detail::poseRt(CurrentFrame.mTcw, Rcw, tcw);
+  const int n = (int)CurrentFrame.mvKeysUn.size(), ns = (int)LastFrame.N;
+  std::vector<float> uv((size_t)ns * 2, 0.f), ang(ns, 0.f);
+  std::vector<int32_t> lvl(ns, 0), assigned(n > 0 ? n : 1, -1);
+  std::vector<uint8_t> valid(ns, 0), flags(ns, 0), sdesc((size_t)ns * 32, 0), occ(n > 0 ? n : 1, 0), tmp;
+  for (int i = 0; i < n; i++)
+    if (CurrentFrame.mvpMapPoints[i] && CurrentFrame.mvpMapPoints[i]->Observations() > 0) occ[i] = 1;   // :1364-1366
+  for (int i = 0; i < ns; i++) {
+    auto* pMP = LastFrame.mvpMapPoints[i];
+    if (!pMP || LastFrame.mvbOutlier[i]) continue;
+    float x3Dw[3], x3Dc[3];
+    detail::vec3(pMP->GetWorldPos(), x3Dw);
+    Ops::gemm3(Rcw, x3Dw, 1.0, tcw, 1.0, x3Dc);                       // Rcw*x3Dw+tcw
+    const float xc = x3Dc[0], yc = x3Dc[1];
+    const float invzc = (float)(1.0 / x3Dc[2]);
+    if (invzc < 0) continue;
+    const float u = CurrentFrame.fx * xc * invzc + CurrentFrame.cx;
+    const float v = CurrentFrame.fy * yc * invzc + CurrentFrame.cy;
+    if (u < CurrentFrame.mnMinX || u > CurrentFrame.mnMaxX) continue;
+    if (v < CurrentFrame.mnMinY || v > CurrentFrame.mnMaxY) continue;
+    uv[2 * i] = u; uv[2 * i + 1] = v;
+    lvl[i] = LastFrame.mvKeys[i].octave;                              // nLastOctave
+    ang[i] = LastFrame.mvKeysUn[i].angle;
+    flags[i] = pMP->Observations() > 0 ? ORBFE_MP_OBSERVED : 0;
+    const auto d = pMP->GetDescriptor();
+    std::memcpy(&sdesc[(size_t)i * 32], d.data, 32);
+    valid[i] = 1;
+  }
+  float b[4];
+  detail::frameBounds(CurrentFrame, b);
+  int nmatches = 0;
+  check(orbfe_search_by_projection_uv(ctx.get(), reinterpret_cast<const OrbfeKeyPoint*>(CurrentFrame.mvKeysUn.data()),
+                                      detail::packedDescriptors(CurrentFrame.mDescriptors, n, tmp), n, b,
+                                      CurrentFrame.mvScaleFactors.data(), (int)CurrentFrame.mvScaleFactors.size(), occ.data(),
+                                      uv.data(), lvl.data(), ang.data(), flags.data(), valid.data(), sdesc.data(), ns, th,
+                                      /*TH_HIGH*/ 100, /*skip_any_occupied*/ 0, mbCheckOrientation ? 1 : 0, assigned.data(),
+                                      &nmatches));
+  for (int i = 0; i < n; i++) {
+    if (assigned[i] >= 0) CurrentFrame.mvpMapPoints[i] = LastFrame.mvpMapPoints[assigned[i]];
+    else if (assigned[i] == -2) CurrentFrame.mvpMapPoints[i] = nullptr;    // rotation check, :1409-1419
+  }
+  return nmatches;
+}
+
+// int ORBmatcher::SearchByProjection(Frame& CurrentFrame, KeyFrame* pKF, const set<MapPoint*>& sAlreadyFound,
+//                                    const float th, const int ORBdist)   (ORBmatcher.cc:1425-1552)
+template <class Ops = detail::RestatedOps, class FrameT, class KeyFrameT, class SetT>
+inline int SearchByProjection(MatcherContext& ctx, bool mbCheckOrientation, FrameT& CurrentFrame, KeyFrameT* pKF,
+                              const SetT& sAlreadyFound, const float th, const int ORBdist) {
+  float Rcw[9], tcw[3], Ow[3];
+  detail::poseRt(CurrentFrame.mTcw, Rcw, tcw);
+  Ops::gemmT3(Rcw, tcw, -1.0, Ow);                                       // -Rcw.t()*tcw
+  const auto vpMPs = pKF->GetMapPointMatches();
+  const int n = (int)CurrentFrame.mvKeysUn.size(), ns = (int)vpMPs.size();
+  std::vector<float> uv((size_t)ns * 2, 0.f), ang(ns, 0.f);
+  std::vector<int32_t> lvl(ns, 0), assigned(n > 0 ? n : 1, -1);
+  std::vector<uint8_t> valid(ns, 0), flags(ns, 0), sdesc((size_t)ns * 32, 0), occ(n > 0 ? n : 1, 0), tmp;
+  for (int i = 0; i < n; i++)
+    if (CurrentFrame.mvpMapPoints[i]) occ[i] = 1;                         // :1493-1494
+  for (int i = 0; i < ns; i++) {
+    auto* pMP = vpMPs[i];
+    if (!pMP) continue;
+    if (pMP->isBad() || sAlreadyFound.count(pMP)) continue;
+    float x3Dw[3], x3Dc[3];
+    detail::vec3(pMP->GetWorldPos(), x3Dw);
+    Ops::gemm3(Rcw, x3Dw, 1.0, tcw, 1.0, x3Dc);
+    const float xc = x3Dc[0], yc = x3Dc[1];
+    const float invzc = (float)(1.0 / x3Dc[2]);
+    const float u = CurrentFrame.fx * xc * invzc + CurrentFrame.cx;
+    const float v = CurrentFrame.fy * yc * invzc + CurrentFrame.cy;
+    if (u < CurrentFrame.mnMinX || u > CurrentFrame.mnMaxX) continue;
+    if (v < CurrentFrame.mnMinY || v > CurrentFrame.mnMaxY) continue;
+    const float PO[3] = {x3Dw[0] - Ow[0], x3Dw[1] - Ow[1], x3Dw[2] - Ow[2]};
+    const float dist3D = (float)Ops::norm3(PO);
+    const float maxDistance = pMP->GetMaxDistanceInvariance(), minDistance = pMP->GetMinDistanceInvariance();
+    if (dist3D < minDistance || dist3D > maxDistance) continue;
+    uv[2 * i] = u; uv[2 * i + 1] = v;
+    lvl[i] = pMP->PredictScale(dist3D, CurrentFrame.mfLogScaleFactor);
+    ang[i] = pKF->mvKeysUn[i].angle;
+    const auto d = pMP->GetDescriptor();
+    std::memcpy(&sdesc[(size_t)i * 32], d.data, 32);
+    valid[i] = 1;
+  }
+  float b[4];
+  detail::frameBounds(CurrentFrame, b);
+  int nmatches = 0;
+  check(orbfe_search_by_projection_uv(ctx.get(), reinterpret_cast<const OrbfeKeyPoint*>(CurrentFrame.mvKeysUn.data()),
+                                      detail::packedDescriptors(CurrentFrame.mDescriptors, n, tmp), n, b,
+                                      CurrentFrame.mvScaleFactors.data(), (int)CurrentFrame.mvScaleFactors.size(), occ.data(),
+                                      uv.data(), lvl.data(), ang.data(), flags.data(), valid.data(), sdesc.data(), ns, th, ORBdist,
+                                      /*skip_any_occupied*/ 1, mbCheckOrientation ? 1 : 0, assigned.data(), &nmatches));
+  for (int i = 0; i < n; i++) {
+    if (assigned[i] >= 0) CurrentFrame.mvpMapPoints[i] = vpMPs[assigned[i]];
+    else if (assigned[i] == -2) CurrentFrame.mvpMapPoints[i] = nullptr;
+  }
+  return nmatches;
+}
+
+// int ORBmatcher::SearchByProjection(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoints,
+//                                    vector<MapPoint*>& vpMatched, int th)   (ORBmatcher.cc:285-398)
+template <class Ops = detail::RestatedOps, class KeyFrameT, class MatT, class MapPointT>
+inline int SearchByProjection(MatcherContext& ctx, KeyFrameT* pKF, const MatT& Scw, const std::vector<MapPointT*>& vpPoints,
+                              std::vector<MapPointT*>& vpMatched, int th) {
+  float Rcw[9], tcw[3], Ow[3];
+  detail::decomposeScw<Ops>(Scw, Rcw, tcw, Ow);
+  std::vector<MapPointT*> found(vpMatched.begin(), vpMatched.end());     // spAlreadyFound (:301-302)
+  std::sort(found.begin(), found.end());
+  const size_t ns = vpPoints.size();
+  detail::ProjectedSources S(ns);
+  for (size_t i = 0; i < ns; i++) {
+    MapPointT* pMP = vpPoints[i];
+    if (pMP->isBad() || std::binary_search(found.begin(), found.end(), pMP)) continue;
+    detail::projectIntoKeyFrame<Ops>(pKF, pMP, Rcw, tcw, Ow, (float)th, /*invz = 1/z in float*/ false, S, i);
+  }
+  std::vector<uint8_t> skip(vpMatched.size() ? vpMatched.size() : 1, 0);
+  for (size_t i = 0; i < vpMatched.size(); i++) skip[i] = vpMatched[i] ? 1 : 0;   // :366-367
+  const int nmatches = detail::searchProjected(ctx, pKF, S, skip.data(), /*claim*/ 1, /*chi2*/ false, /*TH_LOW*/ 50);
+  for (size_t i = 0; i < ns; i++)
+    if (S.bestIdx[i] >= 0) vpMatched[S.bestIdx[i]] = vpPoints[i];
+  return nmatches;
+}
+
+// int ORBmatcher::Fuse(KeyFrame* pKF, const vector<MapPoint*>& vpMapPoints, const float th)   (ORBmatcher.cc:806-939).
+// Which keypoint a MapPoint selects depends only on the keyframe's keypoints and the point itself, so all windows are
+// searched in one GPU call; the reference's loop is then replayed IN ORDER with its live checks (isBad / IsInKeyFrame
+// change as earlier points are replaced or added).  vpMapPoints holds distinct points, as the reference's callers
+// guarantee (LocalMapping::SearchInNeighbors marks candidates with mnFuseCandidateForKF).
+template <class Ops = detail::RestatedOps, class KeyFrameT, class MapPointT>
+inline int Fuse(MatcherContext& ctx, KeyFrameT* pKF, const std::vector<MapPointT*>& vpMapPoints, const float th) {
+  float Rcw[9], tcw[3], Ow[3];
+  detail::mat33(pKF->GetRotation(), Rcw);
+  detail::vec3(pKF->GetTranslation(), tcw);
+  detail::vec3(pKF->GetCameraCenter(), Ow);
+  const size_t ns = vpMapPoints.size();
+  detail::ProjectedSources S(ns);
+  for (size_t i = 0; i < ns; i++)
+    if (vpMapPoints[i]) detail::projectIntoKeyFrame<Ops>(pKF, vpMapPoints[i], Rcw, tcw, Ow, th, false, S, i);
+  detail::searchProjected(ctx, pKF, S, nullptr, 0, /*chi2 gate :896-903*/ true, /*TH_LOW*/ 50);
+  int nFused = 0;
+  for (size_t i = 0; i < ns; i++) {
+    MapPointT* pMP = vpMapPoints[i];
+    if (!pMP) continue;
+    if (pMP->isBad() || pMP->IsInKeyFrame(pKF)) continue;
+    if (!S.valid[i] || S.bestIdx[i] < 0) continue;
+    const int bestIdx = S.bestIdx[i];
+    MapPointT* pMPinKF = pKF->GetMapPoint(bestIdx);
+    if (pMPinKF) {
+      if (!pMPinKF->isBad()) {
+        if (pMPinKF->Observations() > pMP->Observations()) pMP->Replace(pMPinKF);
+        else pMPinKF->Replace(pMP);
+      }
+    } else {
+      pMP->AddObservation(pKF, bestIdx);
+      pKF->AddMapPoint(pMP, bestIdx);
+    }
+    nFused++;
+  }
+  return nFused;
+}
+
+// int ORBmatcher::Fuse(KeyFrame* pKF, cv::Mat Scw, const vector<MapPoint*>& vpPoints, float th,
+//                      vector<MapPoint*>& vpReplacePoint)   (ORBmatcher.cc:941-1064)
+template <class Ops = detail::RestatedOps, class KeyFrameT, class MatT, class MapPointT>
+inline int Fuse(MatcherContext& ctx, KeyFrameT* pKF, const MatT& Scw, const std::vector<MapPointT*>& vpPoints, float th,
+                std::vector<MapPointT*>& vpReplacePoint) {
+  float Rcw[9], tcw[3], Ow[3];
+  detail::decomposeScw<Ops>(Scw, Rcw, tcw, Ow);
+  const auto spAlreadyFound = pKF->GetMapPoints();
+  const size_t ns = vpPoints.size();
+  detail::ProjectedSources S(ns);
+  for (size_t i = 0; i < ns; i++) {
+    MapPointT* pMP = vpPoints[i];
+    if (pMP->isBad() || spAlreadyFound.count(pMP)) continue;
+    detail::projectIntoKeyFrame<Ops>(pKF, pMP, Rcw, tcw, Ow, th, /*invz = 1.0/z*/ true, S, i);
+  }
+  detail::searchProjected(ctx, pKF, S, nullptr, 0, false, /*TH_LOW*/ 50);
+  int nFused = 0;
+  for (size_t i = 0; i < ns; i++) {
+    if (!S.valid[i] || S.bestIdx[i] < 0) continue;
+    MapPointT* pMP = vpPoints[i];
+    const int bestIdx = S.bestIdx[i];
+    MapPointT* pMPinKF = pKF->GetMapPoint(bestIdx);     // live: an earlier point of this call may have been added here
+    if (pMPinKF) {
+      if (!pMPinKF->isBad()) vpReplacePoint[i] = pMPinKF;
+    } else {
+      pMP->AddObservation(pKF, bestIdx);
+      pKF->AddMapPoint(pMP, bestIdx);
+    }
+    nFused++;
+  }
+  return nFused;
+}
+
+// int ORBmatcher::SearchBySim3(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12, const float& s12,
+//                              const cv::Mat& R12, const cv::Mat& t12, const float th)   (ORBmatcher.cc:1066-1290)
+template <class Ops = detail::RestatedOps, class KeyFrameT, class MatT, class MapPointT>
+inline int SearchBySim3(MatcherContext& ctx, KeyFrameT* pKF1, KeyFrameT* pKF2, std::vector<MapPointT*>& vpMatches12,
+                        const float& s12, const MatT& R12m, const MatT& t12m, const float th) {
+  const float fx = pKF1->fx, fy = pKF1->fy, cx = pKF1->cx, cy = pKF1->cy;
+  float R1w[9], t1w[3], R2w[9], t2w[3], R12[9], t12[3], sR12[9], sR21[9], R12t[9], t21[3];
+  detail::mat33(pKF1->GetRotation(), R1w); detail::vec3(pKF1->GetTranslation(), t1w);
+  detail::mat33(pKF2->GetRotation(), R2w); detail::vec3(pKF2->GetTranslation(), t2w);
+  detail::mat33(R12m, R12); detail::vec3(t12m, t12);
+  Ops::scale(R12, 9, (double)s12, sR12);                                  // s12*R12
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) R12t[3 * r + c] = R12[3 * c + r];
+  Ops::scale(R12t, 9, 1.0 / (double)s12, sR21);                           // (1.0/s12)*R12.t()
+  Ops::gemm3(sR21, t12, -1.0, nullptr, 0.0, t21);                         // -sR21*t12
+  const std::vector<MapPointT*> vpMapPoints1 = pKF1->GetMapPointMatches(), vpMapPoints2 = pKF2->GetMapPointMatches();
+  const int N1 = (int)vpMapPoints1.size(), N2 = (int)vpMapPoints2.size();
+  std::vector<bool> vbAlreadyMatched1(N1, false), vbAlreadyMatched2(N2, false);
+  for (int i = 0; i < N1; i++) {
+    MapPointT* pMP = vpMatches12[i];
+    if (pMP) {
+      vbAlreadyMatched1[i] = true;
+      const int idx2 = pMP->GetIndexInKeyFrame(pKF2);
+      if (idx2 >= 0 && idx2 < N2) vbAlreadyMatched2[idx2] = true;
+    }
+  }
+  // one direction: points of `from` (camera pose Rfw, tfw) through (sR, t) into `to`
+  auto direction = [&](const std::vector<MapPointT*>& pts, const std::vector<bool>& already, const float* Rfw, const float* tfw,
+                       const float* sR, const float* tt, KeyFrameT* to, std::vector<int>& vnMatch) {
+    detail::ProjectedSources S(pts.size());
+    for (size_t i = 0; i < pts.size(); i++) {
+      MapPointT* pMP = pts[i];
+      if (!pMP || already[i]) continue;
+      if (pMP->isBad()) continue;
+      float p3Dw[3], pa[3], pb[3];
+      detail::vec3(pMP->GetWorldPos(), p3Dw);
+      Ops::gemm3(Rfw, p3Dw, 1.0, tfw, 1.0, pa);
+      Ops::gemm3(sR, pa, 1.0, tt, 1.0, pb);
+      if (pb[2] < 0.0) continue;
+      const float invz = (float)(1.0 / pb[2]);
+      const float x = pb[0] * invz, y = pb[1] * invz;
+      const float u = fx * x + cx, v = fy * y + cy;                       // pKF1's intrinsics in both directions (:1069-1072)
+      if (!to->IsInImage(u, v)) continue;
+      const float maxDistance = pMP->GetMaxDistanceInvariance(), minDistance = pMP->GetMinDistanceInvariance();
+      const float dist3D = (float)Ops::norm3(pb);
+      if (dist3D < minDistance || dist3D > maxDistance) continue;
+      const int nPredictedLevel = pMP->PredictScale(dist3D, to->mfLogScaleFactor);
+      S.uv[2 * i] = u; S.uv[2 * i + 1] = v;
+      S.level[i] = nPredictedLevel;
+      S.radius[i] = th * to->mvScaleFactors[nPredictedLevel];
+      const auto d = pMP->GetDescriptor();
+      std::memcpy(&S.desc[32 * i], d.data, 32);
+      S.valid[i] = 1;
+    }
+    detail::searchProjected(ctx, to, S, nullptr, 0, false, /*TH_HIGH*/ 100);
+    vnMatch.assign(S.bestIdx.begin(), S.bestIdx.end());
+  };
+  std::vector<int> vnMatch1, vnMatch2;
+  direction(vpMapPoints1, vbAlreadyMatched1, R1w, t1w, sR21, t21, pKF2, vnMatch1);
+  direction(vpMapPoints2, vbAlreadyMatched2, R2w, t2w, sR12, t12, pKF1, vnMatch2);
+  int nFound = 0;
+  for (int i1 = 0; i1 < N1; i1++) {
+    const int idx2 = vnMatch1[i1];
+    if (idx2 >= 0) {
+      const int idx1 = vnMatch2[idx2];
+      if (idx1 == i1) { vpMatches12[i1] = vpMapPoints2[idx2]; nFound++; }
+    }
+  }
+  return nFound;
+}
+
+// void Frame::UndistortKeyPoints()   (Frame.cc:286-320) and void Frame::ComputeImageBounds(const cv::Mat& imLeft)
+// (:322-353), both camera models (camaraModo 0 = pinhole with mDistCoef through cv::undistortPoints, 1 = os1's
+// equidistant fisheye).  K = {fx, fy, cx, cy}; dist = mDistCoef (4, 5 or 8 floats; ignored for mode 1).
+template <class KeyPointT>
+inline void UndistortKeyPoints(const std::vector<KeyPointT>& mvKeys, std::vector<KeyPointT>& mvKeysUn, int camaraModo, float fx,
+                               float fy, float cx, float cy, const float* dist, int ndist) {
+  if (camaraModo == 0 && (ndist == 0 || dist[0] == 0.0)) { mvKeysUn = mvKeys; return; }
+  static_assert(sizeof(KeyPointT) == sizeof(OrbfeKeyPoint), "KeyPointT must match cv::KeyPoint's layout");
+  const int N = (int)mvKeys.size();
+  std::vector<float> mat((size_t)N * 2);
+  for (int i = 0; i < N; i++) {
+    OrbfeKeyPoint k;
+    std::memcpy(&k, &mvKeys[i], sizeof k);
+    mat[2 * i] = k.x; mat[2 * i + 1] = k.y;
+  }
+  if (camaraModo) check(orbfe_undistort_equidistant(mat.data(), N, fx, fy, cx, cy));
+  else check(orbfe_undistort_pinhole(mat.data(), N, fx, fy, cx, cy, dist, ndist));
+  mvKeysUn.resize(N);
+  for (int i = 0; i < N; i++) {
+    KeyPointT kp = mvKeys[i];
+    std::memcpy(static_cast<void*>(&kp), &mat[2 * i], 2 * sizeof(float));   // kp.pt = (x, y): the first two floats of cv::KeyPoint
+    mvKeysUn[i] = kp;
+  }
+}
+inline void ComputeImageBounds(int cols, int rows, int camaraModo, float fx, float fy, float cx, float cy, const float* dist,
+                               int ndist, float& mnMinX, float& mnMaxX, float& mnMinY, float& mnMaxY) {
+  float b[4];
+  check(orbfe_compute_image_bounds(cols, rows, camaraModo, fx, fy, cx, cy, dist, ndist, b));
+  mnMinX = b[0]; mnMaxX = b[1]; mnMinY = b[2]; mnMaxY = b[3];
 }
 
 // ORBVocabulary (DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB>) as far as the path uses it: loaded from the

@@ -1436,3 +1436,474 @@ int orc_search_projected(const OrcKeyPoint* kpsUn, const uint8_t* desc, int n, c
 }
 
 }  // extern "C"
+
+// =============================================================================================
+// Whole-function restatements of the pose-driven searches:
+// ORBmatcher::SearchByProjection(Frame&, const Frame&, th)            ORBmatcher.cc:1292-1423
+// ORBmatcher::SearchByProjection(Frame&, KeyFrame*, set, th, ORBdist) ORBmatcher.cc:1425-1552
+// ORBmatcher::SearchByProjection(KeyFrame*, Scw, vpPoints, vpMatched) ORBmatcher.cc:285-398
+// ORBmatcher::Fuse(KeyFrame*, vpMapPoints, th)                        ORBmatcher.cc:806-939
+// ORBmatcher::Fuse(KeyFrame*, Scw, vpPoints, th, vpReplacePoint)      ORBmatcher.cc:941-1064
+// ORBmatcher::SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12)    ORBmatcher.cc:1066-1290
+// Frame::UndistortKeyPoints (pinhole branch) / ComputeImageBounds     Frame.cc:286-353
+//
+// The reference does the projections with cv::Mat expressions; what those expressions compute is OpenCV arithmetic
+// (RECALLED from OpenCV 4.x core/src/matmul.simd.hpp, matrix_expressions.cpp, norm.cpp -- parity unpinned like the rest):
+//   A*b + c, A 3x3, b 3x1 (gemm, flags 0, len 3: small-matrix path): t = a0*b0 + a1*b1 + a2*b2 in FLOAT, left to
+//                          right; d = (float)((double)t*alpha + (double)c*beta)
+//   -A.t()*b              (gemm with GEMM_1_T: generic GEMMSingleMul<float,double>): double products and sums,
+//                          d = (float)(s*alpha)
+//   cv::norm(v)           sqrt of a double sum of double squares (returned as double)
+//   a.dot(b)              double sum of double products
+//   M / s, s * M          convertTo with a float scale: m * (float)(1.0/s) resp. m * (float)s
+// MapPoint / KeyFrame bookkeeping (Replace, AddObservation, AddMapPoint) follows the simplified model of
+// orb_oracle_pose.h; the search part (which keypoint each point selects) is exact reference logic.
+// =============================================================================================
+#include "orb_oracle_pose.h"
+
+namespace {
+static_assert(sizeof(OrcKp) == sizeof(OrcKeyPoint), "layout");
+
+void cvGemm3(const float A[9], const float b[3], double alpha, const float* c, double beta, float d[3]) {
+  for (int i = 0; i < 3; i++) {
+    const float t = A[3 * i] * b[0] + A[3 * i + 1] * b[1] + A[3 * i + 2] * b[2];
+    d[i] = (float)((double)t * alpha + (double)(c ? c[i] : 0.f) * beta);
+  }
+}
+void cvGemmT3(const float A[9], const float b[3], double alpha, float d[3]) {   // alpha * A^T * b
+  for (int i = 0; i < 3; i++) {
+    double s = 0;
+    for (int k = 0; k < 3; k++) s += (double)A[3 * k + i] * (double)b[k];
+    d[i] = (float)(s * alpha);
+  }
+}
+double cvNorm3(const float v[3]) {
+  double s = 0;
+  for (int k = 0; k < 3; k++) s += (double)v[k] * (double)v[k];
+  return std::sqrt(s);
+}
+double cvDot3(const float a[3], const float b[3]) {
+  double r = 0;
+  for (int k = 0; k < 3; k++) r += (double)a[k] * (double)b[k];
+  return r;
+}
+void poseRt(const float T[16], float R[9], float t[3]) {   // rowRange(0,3).colRange(0,3) / .col(3)
+  for (int r = 0; r < 3; r++) {
+    for (int c = 0; c < 3; c++) R[3 * r + c] = T[4 * r + c];
+    t[r] = T[4 * r + 3];
+  }
+}
+// Scw -> Rcw, tcw, Ow  (ORBmatcher.cc:293-298 / 949-954)
+void decomposeScw(const float S[16], float Rcw[9], float tcw[3], float Ow[3]) {
+  float sR[9], st[3];
+  poseRt(S, sR, st);
+  const float scw = (float)std::sqrt(cvDot3(sR, sR));          // sqrt(sRcw.row(0).dot(sRcw.row(0)))
+  const float inv = (float)(1.0 / (double)scw);
+  for (int i = 0; i < 9; i++) Rcw[i] = sR[i] * inv;           // sRcw/scw
+  for (int i = 0; i < 3; i++) tcw[i] = st[i] * inv;           // Scw...col(3)/scw
+  cvGemmT3(Rcw, tcw, -1.0, Ow);                                // -Rcw.t()*tcw
+}
+int predictScale(float maxDistance, float currentDist, float logScaleFactor) {   // MapPoint.cc:370-379
+  const float ratio = maxDistance / currentDist;
+  return (int)ceilf(logf(ratio) / logScaleFactor);
+}
+bool isInImage(const OrcView* v, float x, float y) {   // KeyFrame.cc:678-681
+  return x >= v->bounds[0] && x < v->bounds[1] && y >= v->bounds[2] && y < v->bounds[3];
+}
+// the simplified bookkeeping model (orb_oracle_pose.h)
+void addObservation(OrcPoints* P, int id, int idx) {
+  if (P->idxInKF[id] >= 0) return;
+  P->idxInKF[id] = idx;
+  P->nObs[id]++;
+}
+void replacePoint(OrcPoints* P, int32_t* slot, int a, int b) {   // a->Replace(b)
+  if (a == b) return;
+  P->bad[a] = 1;
+  const int ia = P->idxInKF[a];
+  P->nObs[b] += P->nObs[a] - (ia >= 0 ? 1 : 0);   // observations in other keyframes move to b
+  P->nObs[a] = 0;
+  P->idxInKF[a] = -1;
+  if (ia >= 0) {
+    if (P->idxInKF[b] < 0) { slot[ia] = b; addObservation(P, b, ia); }
+    else slot[ia] = -1;
+  }
+}
+// best keypoint of a KeyFrame window (the loops at :357-386, 888-916, 1026-1045, 1164-1185): levels [p-1, p]
+int bestInWindow(const FrameGrid& g, const OrcView* v, float u, float vv, float radius, int nPredictedLevel, const uint8_t* dMP,
+                 const int32_t* skipIfSet, bool chi2, int initBest, int& bestDist) {
+  const std::vector<size_t> vIndices = g.getFeaturesInArea(u, vv, radius, -1, -1);   // KeyFrame::GetFeaturesInArea: no level filter
+  bestDist = initBest;
+  int bestIdx = -1;
+  for (size_t idx : vIndices) {
+    if (skipIfSet && skipIfSet[idx] >= 0) continue;
+    const OrcKeyPoint& kp = reinterpret_cast<const OrcKeyPoint*>(v->kpsUn)[idx];
+    const int kpLevel = kp.octave;
+    if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+    if (chi2) {
+      const float ex = u - kp.x, ey = vv - kp.y;
+      const float e2 = ex * ex + ey * ey;
+      if (e2 * v->invLevelSigma2[kpLevel] > 5.99) continue;
+    }
+    const int dist = descriptor_distance(dMP, v->desc + 32 * idx);
+    if (dist < bestDist) { bestDist = dist; bestIdx = (int)idx; }
+  }
+  return bestIdx;
+}
+}  // namespace
+
+extern "C" {
+
+int orc_sbp_frame(const OrcView* cur, const float Tcw[16], const OrcKp* lastKeys, const OrcKp* lastKeysUn, int nLast,
+                  const int32_t* last_mp, const uint8_t* last_outlier, OrcPoints* P, int32_t* cur_mp, float th,
+                  int check_orientation) {
+  int nmatches = 0;
+  std::vector<int> rotHist[HISTO_LENGTH];
+  float Rcw[9], tcw[3];
+  poseRt(Tcw, Rcw, tcw);
+  const OrcKeyPoint* kpsUn = reinterpret_cast<const OrcKeyPoint*>(cur->kpsUn);
+  FrameGrid F(kpsUn, cur->n, cur->bounds);
+  for (int i = 0; i < nLast; i++) {
+    const int pMP = last_mp[i];
+    if (pMP < 0) continue;
+    if (last_outlier[i]) continue;
+    float x3Dc[3];
+    cvGemm3(Rcw, P->pos + 3 * pMP, 1.0, tcw, 1.0, x3Dc);
+    const float xc = x3Dc[0], yc = x3Dc[1];
+    const float invzc = (float)(1.0 / x3Dc[2]);
+    if (invzc < 0) continue;
+    float u = cur->fx * xc * invzc + cur->cx;
+    float v = cur->fy * yc * invzc + cur->cy;
+    if (u < cur->bounds[0] || u > cur->bounds[1]) continue;
+    if (v < cur->bounds[2] || v > cur->bounds[3]) continue;
+    const int nLastOctave = lastKeys[i].octave;
+    const float radius = th * cur->scaleFactors[nLastOctave];
+    std::vector<size_t> vIndices2 = F.getFeaturesInArea(u, v, radius, nLastOctave - 1, nLastOctave + 1);
+    if (vIndices2.empty()) continue;
+    const uint8_t* dMP = P->desc + 32 * (size_t)pMP;
+    int bestDist = 256, bestIdx2 = -1;
+    for (size_t i2 : vIndices2) {
+      if (cur_mp[i2] >= 0)
+        if (P->nObs[cur_mp[i2]] > 0) continue;
+      const int dist = descriptor_distance(dMP, cur->desc + 32 * i2);
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = (int)i2; }
+    }
+    if (bestDist <= TH_HIGH) {
+      cur_mp[bestIdx2] = pMP;
+      nmatches++;
+      if (check_orientation) rotHist[rot_bin(lastKeysUn[i].angle, kpsUn[bestIdx2].angle)].push_back(bestIdx2);
+    }
+  }
+  if (check_orientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    compute_three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++)
+      if (i != ind1 && i != ind2 && i != ind3)
+        for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) { cur_mp[rotHist[i][j]] = -1; nmatches--; }
+  }
+  return nmatches;
+}
+
+int orc_sbp_keyframe(const OrcView* cur, const float Tcw[16], const OrcKp* kfKeysUn, int nKF, const int32_t* kf_mp,
+                     const uint8_t* already, OrcPoints* P, int32_t* cur_mp, float th, int ORBdist, int check_orientation) {
+  int nmatches = 0;
+  float Rcw[9], tcw[3], Ow[3];
+  poseRt(Tcw, Rcw, tcw);
+  cvGemmT3(Rcw, tcw, -1.0, Ow);
+  std::vector<int> rotHist[HISTO_LENGTH];
+  const OrcKeyPoint* kpsUn = reinterpret_cast<const OrcKeyPoint*>(cur->kpsUn);
+  FrameGrid F(kpsUn, cur->n, cur->bounds);
+  for (int i = 0; i < nKF; i++) {
+    const int pMP = kf_mp[i];
+    if (pMP < 0) continue;
+    if (P->bad[pMP] || already[pMP]) continue;
+    const float* x3Dw = P->pos + 3 * pMP;
+    float x3Dc[3];
+    cvGemm3(Rcw, x3Dw, 1.0, tcw, 1.0, x3Dc);
+    const float xc = x3Dc[0], yc = x3Dc[1];
+    const float invzc = (float)(1.0 / x3Dc[2]);
+    const float u = cur->fx * xc * invzc + cur->cx;
+    const float v = cur->fy * yc * invzc + cur->cy;
+    if (u < cur->bounds[0] || u > cur->bounds[1]) continue;
+    if (v < cur->bounds[2] || v > cur->bounds[3]) continue;
+    const float PO[3] = {x3Dw[0] - Ow[0], x3Dw[1] - Ow[1], x3Dw[2] - Ow[2]};
+    float dist3D = (float)cvNorm3(PO);
+    const float maxDistance = P->maxDist[pMP], minDistance = P->minDist[pMP];
+    if (dist3D < minDistance || dist3D > maxDistance) continue;
+    int nPredictedLevel = predictScale(maxDistance, dist3D, cur->logScaleFactor);
+    const float radius = th * cur->scaleFactors[nPredictedLevel];
+    const std::vector<size_t> vIndices2 = F.getFeaturesInArea(u, v, radius, nPredictedLevel - 1, nPredictedLevel + 1);
+    if (vIndices2.empty()) continue;
+    const uint8_t* dMP = P->desc + 32 * (size_t)pMP;
+    int bestDist = 256, bestIdx2 = -1;
+    for (size_t i2 : vIndices2) {
+      if (cur_mp[i2] >= 0) continue;
+      const int dist = descriptor_distance(dMP, cur->desc + 32 * i2);
+      if (dist < bestDist) { bestDist = dist; bestIdx2 = (int)i2; }
+    }
+    if (bestDist <= ORBdist) {
+      cur_mp[bestIdx2] = pMP;
+      nmatches++;
+      if (check_orientation) rotHist[rot_bin(kfKeysUn[i].angle, kpsUn[bestIdx2].angle)].push_back(bestIdx2);
+    }
+  }
+  if (check_orientation) {
+    int ind1 = -1, ind2 = -1, ind3 = -1;
+    compute_three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+    for (int i = 0; i < HISTO_LENGTH; i++)
+      if (i != ind1 && i != ind2 && i != ind3)
+        for (size_t j = 0, jend = rotHist[i].size(); j < jend; j++) { cur_mp[rotHist[i][j]] = -1; nmatches--; }
+  }
+  return nmatches;
+}
+
+int orc_sbp_scw(const OrcView* kf, const float Scw[16], const int32_t* points, int npoints, OrcPoints* P,
+                int32_t* vpMatched, int th) {
+  float Rcw[9], tcw[3], Ow[3];
+  decomposeScw(Scw, Rcw, tcw, Ow);
+  std::vector<uint8_t> spAlreadyFound(P->M, 0);
+  for (int i = 0; i < kf->n; i++)
+    if (vpMatched[i] >= 0) spAlreadyFound[vpMatched[i]] = 1;
+  FrameGrid G(reinterpret_cast<const OrcKeyPoint*>(kf->kpsUn), kf->n, kf->bounds);
+  int nmatches = 0;
+  for (int iMP = 0; iMP < npoints; iMP++) {
+    const int pMP = points[iMP];
+    if (P->bad[pMP] || spAlreadyFound[pMP]) continue;
+    const float* p3Dw = P->pos + 3 * pMP;
+    float p3Dc[3];
+    cvGemm3(Rcw, p3Dw, 1.0, tcw, 1.0, p3Dc);
+    if (p3Dc[2] < 0.0) continue;
+    const float invz = 1 / p3Dc[2];
+    const float x = p3Dc[0] * invz, y = p3Dc[1] * invz;
+    const float u = kf->fx * x + kf->cx, v = kf->fy * y + kf->cy;
+    if (!isInImage(kf, u, v)) continue;
+    const float maxDistance = P->maxDist[pMP], minDistance = P->minDist[pMP];
+    const float PO[3] = {p3Dw[0] - Ow[0], p3Dw[1] - Ow[1], p3Dw[2] - Ow[2]};
+    const float dist = (float)cvNorm3(PO);
+    if (dist < minDistance || dist > maxDistance) continue;
+    if (cvDot3(PO, P->normal + 3 * pMP) < 0.5 * dist) continue;
+    int nPredictedLevel = predictScale(maxDistance, dist, kf->logScaleFactor);
+    const float radius = th * kf->scaleFactors[nPredictedLevel];
+    int bestDist;
+    const int bestIdx = bestInWindow(G, kf, u, v, radius, nPredictedLevel, P->desc + 32 * (size_t)pMP, vpMatched, false, 256, bestDist);
+    if (bestDist <= TH_LOW) { vpMatched[bestIdx] = pMP; nmatches++; }
+  }
+  return nmatches;
+}
+
+int orc_fuse(const OrcView* kf, const float Tcw[16], const int32_t* cand, int ncand, OrcPoints* P, int32_t* slot, float th) {
+  float Rcw[9], tcw[3], Ow[3];
+  poseRt(Tcw, Rcw, tcw);
+  {   // pKF->GetCameraCenter(): KeyFrame::SetPose computes Ow = -Rwc*tcw with Rwc = Rcw.t() already evaluated (KeyFrame.cc:93-97)
+    float Rwc[9];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Rwc[3 * r + c] = Rcw[3 * c + r];
+    cvGemm3(Rwc, tcw, -1.0, nullptr, 0.0, Ow);
+  }
+  FrameGrid G(reinterpret_cast<const OrcKeyPoint*>(kf->kpsUn), kf->n, kf->bounds);
+  int nFused = 0;
+  for (int i = 0; i < ncand; i++) {
+    const int pMP = cand[i];
+    if (pMP < 0) continue;
+    if (P->bad[pMP] || P->idxInKF[pMP] >= 0) continue;
+    const float* p3Dw = P->pos + 3 * pMP;
+    float p3Dc[3];
+    cvGemm3(Rcw, p3Dw, 1.0, tcw, 1.0, p3Dc);
+    if (p3Dc[2] < 0.0f) continue;
+    const float invz = 1 / p3Dc[2];
+    const float x = p3Dc[0] * invz, y = p3Dc[1] * invz;
+    const float u = kf->fx * x + kf->cx, v = kf->fy * y + kf->cy;
+    if (!isInImage(kf, u, v)) continue;
+    const float maxDistance = P->maxDist[pMP], minDistance = P->minDist[pMP];
+    const float PO[3] = {p3Dw[0] - Ow[0], p3Dw[1] - Ow[1], p3Dw[2] - Ow[2]};
+    const float dist3D = (float)cvNorm3(PO);
+    if (dist3D < minDistance || dist3D > maxDistance) continue;
+    if (cvDot3(PO, P->normal + 3 * pMP) < 0.5 * dist3D) continue;
+    int nPredictedLevel = predictScale(maxDistance, dist3D, kf->logScaleFactor);
+    const float radius = th * kf->scaleFactors[nPredictedLevel];
+    int bestDist;
+    const int bestIdx = bestInWindow(G, kf, u, v, radius, nPredictedLevel, P->desc + 32 * (size_t)pMP, nullptr, true, 256, bestDist);
+    if (bestDist <= TH_LOW) {
+      const int pMPinKF = slot[bestIdx];
+      if (pMPinKF >= 0) {
+        if (!P->bad[pMPinKF]) {
+          if (P->nObs[pMPinKF] > P->nObs[pMP]) replacePoint(P, slot, pMP, pMPinKF);
+          else replacePoint(P, slot, pMPinKF, pMP);
+        }
+      } else {
+        addObservation(P, pMP, bestIdx);
+        slot[bestIdx] = pMP;
+      }
+      nFused++;
+    }
+  }
+  return nFused;
+}
+
+int orc_fuse_scw(const OrcView* kf, const float Scw[16], const int32_t* points, int npoints, OrcPoints* P, int32_t* slot,
+                 float th, int32_t* replace_out) {
+  float Rcw[9], tcw[3], Ow[3];
+  decomposeScw(Scw, Rcw, tcw, Ow);
+  std::vector<uint8_t> spAlreadyFound(P->M, 0);   // pKF->GetMapPoints(): non-NULL, not bad
+  for (int i = 0; i < kf->n; i++)
+    if (slot[i] >= 0 && !P->bad[slot[i]]) spAlreadyFound[slot[i]] = 1;
+  FrameGrid G(reinterpret_cast<const OrcKeyPoint*>(kf->kpsUn), kf->n, kf->bounds);
+  int nFused = 0;
+  for (int iMP = 0; iMP < npoints; iMP++) {
+    const int pMP = points[iMP];
+    if (P->bad[pMP] || spAlreadyFound[pMP]) continue;
+    const float* p3Dw = P->pos + 3 * pMP;
+    float p3Dc[3];
+    cvGemm3(Rcw, p3Dw, 1.0, tcw, 1.0, p3Dc);
+    if (p3Dc[2] < 0.0f) continue;
+    const float invz = (float)(1.0 / p3Dc[2]);
+    const float x = p3Dc[0] * invz, y = p3Dc[1] * invz;
+    const float u = kf->fx * x + kf->cx, v = kf->fy * y + kf->cy;
+    if (!isInImage(kf, u, v)) continue;
+    const float maxDistance = P->maxDist[pMP], minDistance = P->minDist[pMP];
+    const float PO[3] = {p3Dw[0] - Ow[0], p3Dw[1] - Ow[1], p3Dw[2] - Ow[2]};
+    const float dist3D = (float)cvNorm3(PO);
+    if (dist3D < minDistance || dist3D > maxDistance) continue;
+    if (cvDot3(PO, P->normal + 3 * pMP) < 0.5 * dist3D) continue;
+    const int nPredictedLevel = predictScale(maxDistance, dist3D, kf->logScaleFactor);
+    const float radius = th * kf->scaleFactors[nPredictedLevel];
+    int bestDist;
+    const int bestIdx = bestInWindow(G, kf, u, v, radius, nPredictedLevel, P->desc + 32 * (size_t)pMP, nullptr, false, INT_MAX, bestDist);
+    if (bestDist <= TH_LOW) {
+      const int pMPinKF = slot[bestIdx];
+      if (pMPinKF >= 0) {
+        if (!P->bad[pMPinKF]) replace_out[iMP] = pMPinKF;
+      } else {
+        addObservation(P, pMP, bestIdx);
+        slot[bestIdx] = pMP;
+      }
+      nFused++;
+    }
+  }
+  return nFused;
+}
+
+int orc_search_by_sim3(const OrcView* kf1, const float T1w[16], const int32_t* mp1, const OrcView* kf2, const float T2w[16],
+                       const int32_t* mp2, OrcPoints* P, int32_t* matches12, float s12, const float R12[9],
+                       const float t12[3], float th) {
+  float R1w[9], t1w[3], R2w[9], t2w[3];
+  poseRt(T1w, R1w, t1w);
+  poseRt(T2w, R2w, t2w);
+  float sR12[9], sR21[9], t21[3];
+  for (int i = 0; i < 9; i++) sR12[i] = R12[i] * s12;                       // s12*R12
+  const float is = (float)(1.0 / (double)s12);
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) sR21[3 * r + c] = R12[3 * c + r] * is;   // (1.0/s12)*R12.t()
+  cvGemm3(sR21, t12, -1.0, nullptr, 0.0, t21);                               // -sR21*t12
+  const int N1 = kf1->n, N2 = kf2->n;
+  std::vector<bool> vbAlreadyMatched1(N1, false), vbAlreadyMatched2(N2, false);
+  for (int i = 0; i < N1; i++) {
+    const int pMP = matches12[i];
+    if (pMP >= 0) {
+      vbAlreadyMatched1[i] = true;
+      const int idx2 = P->idxInKF[pMP];
+      if (idx2 >= 0 && idx2 < N2) vbAlreadyMatched2[idx2] = true;
+    }
+  }
+  std::vector<int> vnMatch1(N1, -1), vnMatch2(N2, -1);
+  FrameGrid G1(reinterpret_cast<const OrcKeyPoint*>(kf1->kpsUn), N1, kf1->bounds), G2(reinterpret_cast<const OrcKeyPoint*>(kf2->kpsUn), N2, kf2->bounds);
+  for (int i1 = 0; i1 < N1; i1++) {
+    const int pMP = mp1[i1];
+    if (pMP < 0 || vbAlreadyMatched1[i1]) continue;
+    if (P->bad[pMP]) continue;
+    float p3Dc1[3], p3Dc2[3];
+    cvGemm3(R1w, P->pos + 3 * pMP, 1.0, t1w, 1.0, p3Dc1);
+    cvGemm3(sR21, p3Dc1, 1.0, t21, 1.0, p3Dc2);
+    if (p3Dc2[2] < 0.0) continue;
+    const float invz = (float)(1.0 / p3Dc2[2]);
+    const float x = p3Dc2[0] * invz, y = p3Dc2[1] * invz;
+    const float u = kf1->fx * x + kf1->cx, v = kf1->fy * y + kf1->cy;   // fx.. of pKF1 (:1069-1072)
+    if (!isInImage(kf2, u, v)) continue;
+    const float maxDistance = P->maxDist[pMP], minDistance = P->minDist[pMP];
+    const float dist3D = (float)cvNorm3(p3Dc2);
+    if (dist3D < minDistance || dist3D > maxDistance) continue;
+    const int nPredictedLevel = predictScale(maxDistance, dist3D, kf2->logScaleFactor);
+    const float radius = th * kf2->scaleFactors[nPredictedLevel];
+    int bestDist;
+    const int bestIdx = bestInWindow(G2, kf2, u, v, radius, nPredictedLevel, P->desc + 32 * (size_t)pMP, nullptr, false, INT_MAX, bestDist);
+    if (bestDist <= TH_HIGH) vnMatch1[i1] = bestIdx;
+  }
+  for (int i2 = 0; i2 < N2; i2++) {
+    const int pMP = mp2[i2];
+    if (pMP < 0 || vbAlreadyMatched2[i2]) continue;
+    if (P->bad[pMP]) continue;
+    float p3Dc2[3], p3Dc1[3];
+    cvGemm3(R2w, P->pos + 3 * pMP, 1.0, t2w, 1.0, p3Dc2);
+    cvGemm3(sR12, p3Dc2, 1.0, t12, 1.0, p3Dc1);
+    if (p3Dc1[2] < 0.0) continue;
+    const float invz = (float)(1.0 / p3Dc1[2]);
+    const float x = p3Dc1[0] * invz, y = p3Dc1[1] * invz;
+    const float u = kf1->fx * x + kf1->cx, v = kf1->fy * y + kf1->cy;
+    if (!isInImage(kf1, u, v)) continue;
+    const float maxDistance = P->maxDist[pMP], minDistance = P->minDist[pMP];
+    const float dist3D = (float)cvNorm3(p3Dc1);
+    if (dist3D < minDistance || dist3D > maxDistance) continue;
+    const int nPredictedLevel = predictScale(maxDistance, dist3D, kf1->logScaleFactor);
+    const float radius = th * kf1->scaleFactors[nPredictedLevel];
+    int bestDist;
+    const int bestIdx = bestInWindow(G1, kf1, u, v, radius, nPredictedLevel, P->desc + 32 * (size_t)pMP, nullptr, false, INT_MAX, bestDist);
+    if (bestDist <= TH_HIGH) vnMatch2[i2] = bestIdx;
+  }
+  int nFound = 0;
+  for (int i1 = 0; i1 < N1; i1++) {
+    const int idx2 = vnMatch1[i1];
+    if (idx2 >= 0) {
+      const int idx1 = vnMatch2[idx2];
+      if (idx1 == i1) { matches12[i1] = mp2[idx2]; nFound++; }
+    }
+  }
+  return nFound;
+}
+
+// cv::undistortPoints with R = empty, P = K (OpenCV 4.x calib3d/imgproc undistort.dispatch.cpp, cvUndistortPointsInternal;
+// RECALLED): x = (u-cx)/fx, y = (v-cy)/fy in double, 5 fixed-point iterations of the inverse distortion (default
+// TermCriteria(COUNT, 5, 0.01)), then u' = fx*x + cx.  k = {k1,k2,p1,p2,k3,k4,k5,k6}, missing ones 0.
+void orc_undistort_pinhole(float* xy, int n, float fxf, float fyf, float cxf, float cyf, const float* dist, int ndist) {
+  double k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < ndist && i < 8; i++) k[i] = dist[i];
+  const double fx = fxf, fy = fyf, cx = cxf, cy = cyf, ifx = 1. / fx, ify = 1. / fy;
+  for (int i = 0; i < n; i++) {
+    double x = xy[2 * i], y = xy[2 * i + 1];
+    const double u = x, v = y;
+    x = (x - cx) * ifx;
+    y = (y - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+      const double r2 = x * x + y * y;
+      const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+      if (icdist < 0) {   // test: undistortPoints.regression_14583
+        x = (u - cx) * ifx;
+        y = (v - cy) * ify;
+        break;
+      }
+      const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+      const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+      x = (x0 - deltaX) * icdist;
+      y = (y0 - deltaY) * icdist;
+    }
+    // RR = P (= K): xx = fx*x + 0*y + cx, yy = fy*y + cy, ww = 1./1
+    const double xx = fx * x + 0 * y + cx, yy = 0 * x + fy * y + cy, ww = 1. / (0 * x + 0 * y + 1);
+    xy[2 * i] = (float)(xx * ww);
+    xy[2 * i + 1] = (float)(yy * ww);
+  }
+}
+
+void orc_image_bounds(int cols, int rows, int mode, float fx, float fy, float cx, float cy, const float* dist, int ndist,
+                      float bounds[4]) {
+  if (mode != 0 || (ndist > 0 && dist[0] != 0.0)) {
+    float mat[8] = {0.0f, 0.0f, (float)cols, 0.0f, 0.0f, (float)rows, (float)cols, (float)rows};
+    if (mode) orc_undistort_equidistant(mat, 4, fx, fy, cx, cy);
+    else orc_undistort_pinhole(mat, 4, fx, fy, cx, cy, dist, ndist);
+    bounds[0] = std::min(mat[0], mat[4]);
+    bounds[1] = std::max(mat[2], mat[6]);
+    bounds[2] = std::min(mat[1], mat[3]);
+    bounds[3] = std::max(mat[5], mat[7]);
+  } else {
+    bounds[0] = 0.0f; bounds[1] = (float)cols; bounds[2] = 0.0f; bounds[3] = (float)rows;
+  }
+}
+
+}  // extern "C"
+

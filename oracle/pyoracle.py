@@ -74,6 +74,9 @@ class Oracle:
         L.orc_search_by_bow_kf.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] + \
             [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int, C.c_float, C.c_int, C.c_void_p]
         L.orc_undistort_equidistant.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float]
+        L.orc_undistort_pinhole.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int]
+        L.orc_image_bounds.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
+                                       C.c_int, C.c_void_p]
 
     # ---- primitives -------------------------------------------------------------------------
     def fast_atan2(self, y, x):
@@ -263,6 +266,18 @@ class Oracle:
                                          len(f1[0]), _p(desc2), _p(angle2), _p(valid2), n2, _p(f2[0]), _p(f2[1]),
                                          _p(f2[2]), len(f2[0]), nnratio, int(check_ori), _p(m12))
         return nm, m12[:n1]
+
+    def undistort_pinhole(self, xy, fx, fy, cx, cy, dist):
+        xy = np.ascontiguousarray(xy, np.float32).copy()
+        d = np.ascontiguousarray(dist, np.float32)
+        self.L.orc_undistort_pinhole(_p(xy), len(xy), fx, fy, cx, cy, _p(d) if len(d) else None, len(d))
+        return xy
+
+    def image_bounds(self, cols, rows, mode, fx, fy, cx, cy, dist=()):
+        d = np.ascontiguousarray(dist, np.float32)
+        b = np.zeros(4, np.float32)
+        self.L.orc_image_bounds(cols, rows, mode, fx, fy, cx, cy, _p(d) if len(d) else None, len(d), _p(b))
+        return b
 
     def undistort_equidistant(self, xy, fx, fy, cx, cy):
         xy = np.ascontiguousarray(xy, np.float32).copy()

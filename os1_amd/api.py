@@ -82,6 +82,8 @@ def load_library():
     L.orbfe_window_candidates.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_size_t,
                                           C.POINTER(C.c_size_t)]
     L.orbfe_undistort_equidistant.argtypes = [vp, ci, cf, cf, cf, cf]
+    L.orbfe_undistort_pinhole.argtypes = [vp, ci, cf, cf, cf, cf, vp, ci]
+    L.orbfe_compute_image_bounds.argtypes = [ci, ci, ci, cf, cf, cf, cf, vp, ci, vp]
     L.orbfe_search_projected.argtypes = [vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp, ci, C.c_double, ci, vp, vp,
                                          C.POINTER(ci)]
     L.orbfe_search_for_triangulation.argtypes = [vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, cf, cf,
@@ -537,6 +539,22 @@ def undistort_equidistant(xy, fx, fy, cx, cy):
     xy = np.ascontiguousarray(xy, np.float32).copy()
     _check(load_library().orbfe_undistort_equidistant(_p(xy), len(xy), fx, fy, cx, cy))
     return xy
+
+
+def undistort_pinhole(xy, fx, fy, cx, cy, dist):
+    """cv::undistortPoints(pts, pts, K, dist, Mat(), K) as Frame::UndistortKeyPoints calls it (host helper of the C ABI)."""
+    xy = np.ascontiguousarray(xy, np.float32).copy()
+    d = np.ascontiguousarray(dist, np.float32)
+    _check(load_library().orbfe_undistort_pinhole(_p(xy), len(xy), fx, fy, cx, cy, _p(d) if len(d) else None, len(d)))
+    return xy
+
+
+def compute_image_bounds(cols, rows, mode, fx, fy, cx, cy, dist=()):
+    """Frame::ComputeImageBounds -> (mnMinX, mnMaxX, mnMinY, mnMaxY)."""
+    d = np.ascontiguousarray(dist, np.float32)
+    b = np.zeros(4, np.float32)
+    _check(load_library().orbfe_compute_image_bounds(cols, rows, mode, fx, fy, cx, cy, _p(d) if len(d) else None, len(d), _p(b)))
+    return b
 
 
 def sincos_host_mismatches(lo_bits, hi_bits, step=1):

@@ -649,6 +649,58 @@ int orbfe_undistort_equidistant(float* xy, int n, float fx, float fy, float cx, 
   return ORBFE_OK;
 }
 
+// cv::undistortPoints(mat, mat, mK, mDistCoef, cv::Mat(), mK) as Frame::UndistortKeyPoints / ComputeImageBounds call it
+// (Frame.cc:307, 339): normalise with K, five fixed-point iterations of the inverse Brown / rational distortion (OpenCV's
+// default TermCriteria(COUNT, 5, 0.01)), project back with K -- all in double, one final rounding to float.  Host math:
+// a few thousand points per frame.
+int orbfe_undistort_pinhole(float* xy, int n, float fx, float fy, float cx, float cy, const float* dist, int ndist) {
+  if (n < 0 || (n && !xy) || ndist < 0 || ndist > 8 || (ndist && !dist)) { set_err("bad argument"); return ORBFE_ERR_INVALID; }
+  double k[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // k1 k2 p1 p2 k3 k4 k5 k6
+  for (int i = 0; i < ndist; i++) k[i] = dist[i];
+  const double dfx = fx, dfy = fy, dcx = cx, dcy = cy, ifx = 1. / dfx, ify = 1. / dfy;
+  for (int i = 0; i < n; i++) {
+    const double u = xy[2 * i], v = xy[2 * i + 1];
+    double x = (u - dcx) * ifx, y = (v - dcy) * ify;
+    const double x0 = x, y0 = y;
+    for (int it = 0; it < 5; it++) {
+      const double r2 = x * x + y * y;
+      const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+      if (icdist < 0) {   // the model folds back on itself here: OpenCV returns the undistorted guess
+        x = (u - dcx) * ifx;
+        y = (v - dcy) * ify;
+        break;
+      }
+      const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+      const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+      x = (x0 - deltaX) * icdist;
+      y = (y0 - deltaY) * icdist;
+    }
+    const double xx = dfx * x + 0 * y + dcx, yy = 0 * x + dfy * y + dcy, ww = 1. / (0 * x + 0 * y + 1);
+    xy[2 * i] = (float)(xx * ww);
+    xy[2 * i + 1] = (float)(yy * ww);
+  }
+  return ORBFE_OK;
+}
+
+// Frame::ComputeImageBounds (Frame.cc:322-353): the four image corners through the camera model's undistortion.
+int orbfe_compute_image_bounds(int cols, int rows, int camera_mode, float fx, float fy, float cx, float cy, const float* dist,
+                               int ndist, float bounds[4]) {
+  if (!bounds || cols <= 0 || rows <= 0 || ndist < 0 || ndist > 8 || (ndist && !dist)) { set_err("bad argument"); return ORBFE_ERR_INVALID; }
+  if (camera_mode != 0 || (ndist > 0 && dist[0] != 0.0)) {
+    float mat[8] = {0.0f, 0.0f, (float)cols, 0.0f, 0.0f, (float)rows, (float)cols, (float)rows};
+    const int rc = camera_mode ? orbfe_undistort_equidistant(mat, 4, fx, fy, cx, cy)
+                               : orbfe_undistort_pinhole(mat, 4, fx, fy, cx, cy, dist, ndist);
+    if (rc) return rc;
+    bounds[0] = std::min(mat[0], mat[4]);
+    bounds[1] = std::max(mat[2], mat[6]);
+    bounds[2] = std::min(mat[1], mat[3]);
+    bounds[3] = std::max(mat[5], mat[7]);
+  } else {
+    bounds[0] = 0.0f; bounds[1] = (float)cols; bounds[2] = 0.0f; bounds[3] = (float)rows;
+  }
+  return ORBFE_OK;
+}
+
 int orbfe_matcher_create(int device_id, orbfe_matcher** out) {
   if (!out) { set_err("out is NULL"); return ORBFE_ERR_INVALID; }
   *out = nullptr;

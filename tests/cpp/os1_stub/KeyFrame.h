@@ -1,0 +1,2 @@
+#pragma once
+#include "Frame.h"   // TEST INFRASTRUCTURE ONLY (see Frame.h)

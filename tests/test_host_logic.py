@@ -84,3 +84,22 @@ def test_fisheye_undistortion_matches_oracle(oracle):
     r_in = np.hypot(pts[:, 0] - cx, pts[:, 1] - cy)
     r_out = np.hypot(got[:, 0] - cx, got[:, 1] - cy)
     assert (r_out >= r_in - 1e-2).all()                 # tan(theta)/theta >= 1: points move outwards
+
+
+def test_pinhole_undistortion_and_image_bounds_match_oracle(oracle):
+    """Frame::UndistortKeyPoints (pinhole branch, cv::undistortPoints) and Frame::ComputeImageBounds (Frame.cc:286-353):
+    host double math of the C ABI against the oracle's restatement, all coefficient counts, both camera models."""
+    from os1_amd import api
+    rng = np.random.default_rng(3)
+    xy = rng.uniform(-20, 780, (4000, 2)).astype(np.float32)
+    K = (517.3, 516.5, 318.6, 255.3)
+    for dist in ([], [0.0, 0.0, 0.0, 0.0], [0.262383, -0.953104, -0.005358, 0.002628, 1.163314], [-0.28, 0.07, 0.0002, 0.00002],
+                 [-0.3, 0.1, 0.001, -0.002, 0.01, 0.02, -0.01, 0.001], [3.0, 9.0, 0.0, 0.0]):
+        got = api.undistort_pinhole(xy, *K, dist)
+        want = oracle.undistort_pinhole(xy, *K, dist)
+        assert got.tobytes() == want.tobytes(), dist
+        assert api.compute_image_bounds(752, 480, 0, *K, dist).tobytes() == oracle.image_bounds(752, 480, 0, *K, dist).tobytes()
+    assert (api.undistort_pinhole(xy, *K, []) == xy).all()                     # no coefficients: identity up to rounding of K math
+    assert list(api.compute_image_bounds(640, 480, 0, *K, [0.0, 0.1, 0, 0])) == [0.0, 640.0, 0.0, 480.0]   # k1 == 0: the image rectangle
+    fish = (2196.0, 2196.0, 1839.0, 1155.0)
+    assert api.compute_image_bounds(3840, 2160, 1, *fish).tobytes() == oracle.image_bounds(3840, 2160, 1, *fish).tobytes()
