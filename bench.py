@@ -373,40 +373,45 @@ def cpu_baseline(frames, nframes, do_match):
 
 
 def cpu_baseline_all_cores(frames, do_match):
-    """The same oracle with one extractor instance per host thread over independent pieces of the stream
-    (SURVEY.md s8(d)(ii)): every host core, 4 consecutive frames per thread, each matched against its predecessor."""
-    import threading
+    """The same oracle on EVERY host core: one extractor instance per core over independent
+    pieces of the stream, 4 consecutive frames each, every frame matched against its predecessor.  Worker processes
+    of 4 threads (tools/cpu_oracle_worker.py); they start together at a wall-clock instant and the rate is frames
+    over the time until the last one finishes."""
+    import tempfile
     import numpy as np
-    from oracle.pyoracle import Oracle, OracleExtractor
-    from os1_amd import stream_workload as wl
-    nthreads = max(1, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1))
     try:
-        os.sched_setaffinity(0, range(os.cpu_count() or 1))          # undo the NUMA binding for this leg
-        nthreads = len(os.sched_getaffinity(0))
+        os.sched_setaffinity(0, range(os.cpu_count() or 1))          # undo this rank's NUMA binding for this leg
     except Exception:
         pass
-    o = Oracle()
-    exs = [OracleExtractor(wl.NFEAT, wl.SCALE, wl.NLEVELS, wl.INI_TH, wl.MIN_TH, o) for _ in range(nthreads)]
-    per = 4
-
-    def work(i):
-        prev = None
-        for k in range(per):
-            kp, d = exs[i].extract(frames[(i * per + k) % len(frames)])
-            if do_match and prev is not None:
-                o.search_for_initialization(prev[0], prev[1], kp, d, wl.BOUNDS, np.stack([prev[0]['x'], prev[0]['y']], 1),
-                                            wl.WINDOW, wl.NNRATIO, wl.CHECK_ORI)
-            prev = (kp, d)
-
-    ths = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
-    t0 = time.perf_counter()
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
-    dt = time.perf_counter() - t0
-    return {'value': round(nthreads * per / dt, 2), 'unit': 'frames/s', 'cores': nthreads, 'kind': 'port',
-            'sample': '%d threads x %d consecutive frames, extract%s, %.1f s' % (nthreads, per, '+SearchForInitialization (3 of 4 frames have a predecessor)' if do_match else '', dt)}
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    tpp, per = 4, 4
+    nproc = max(1, cores // tpp)
+    shm = '/dev/shm' if os.path.isdir('/dev/shm') else tempfile.gettempdir()
+    path = os.path.join(shm, 'orbfe_cpu_frames_%d.npy' % os.getpid())
+    np.save(path, np.stack(frames[:64]))
+    try:
+        t0 = time.time() + (4.0 if nproc <= 16 else 10.0)            # interpreter + numpy start-up of every worker
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tools', 'cpu_oracle_worker.py'), path, str(p * tpp * per),
+                                   str(tpp), str(per), repr(t0), str(int(do_match))], stdout=subprocess.PIPE, text=True,
+                                  env=dict(os.environ, OMP_NUM_THREADS='1')) for p in range(nproc)]
+        ends, total = [], 0
+        for p in procs:
+            out, _ = p.communicate()
+            if p.returncode == 0 and out.strip():
+                te, nf = out.split()
+                ends.append(float(te))
+                total += int(nf)
+        if not ends:
+            return None
+        dt = max(ends) - t0
+    finally:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+    return {'value': round(total / dt, 2), 'unit': 'frames/s', 'cores': nproc * tpp, 'kind': 'port',
+            'sample': '%d processes x %d threads x %d consecutive frames, extract%s, %.1f s' % (
+                nproc, tpp, per, '+SearchForInitialization (3 of 4 frames have a predecessor)' if do_match else '', dt)}
 
 
 if __name__ == '__main__':

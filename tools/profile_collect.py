@@ -1,11 +1,13 @@
 """Turn gpurun_out/prof_<tag>/ (tools/profile_round.sh) into the committed summaries under profiles/:
-<tag>_bench.json, <tag>_kernel_stats.csv, <tag>_pmc_summary.csv, and refresh profiles/traffic.json."""
+<tag>_bench.json, <tag>_kernel_stats.csv, <tag>_pmc_summary.csv, <tag>_fetch_calibration.txt, and profiles/counters.json
+(what bench.py prints as roofline.traffic / roofline.valu, with the tag and commit they were measured at)."""
 import collections
 import csv
 import glob
 import json
 import os
 import shutil
+import subprocess
 import sys
 
 tag = sys.argv[1]
@@ -15,35 +17,55 @@ dst = os.path.join(root, 'profiles')
 line = [l for l in open(os.path.join(src, 'bench.json')).read().splitlines() if l.startswith('{')][-1]
 bench = json.loads(line)
 json.dump(bench, open(os.path.join(dst, tag + '_bench.json'), 'w'), indent=1)
-B = bench['config']['frames_per_step_per_gpu']
+B = bench['config']['frames_per_submission']
 stats = glob.glob(os.path.join(src, 'stats', '**', '*kernel_stats.csv'), recursive=True)
 shutil.copy(stats[0], os.path.join(dst, tag + '_kernel_stats.csv'))
+if os.path.exists(os.path.join(src, 'fetch_calibration.txt')):
+    shutil.copy(os.path.join(src, 'fetch_calibration.txt'), os.path.join(dst, tag + '_fetch_calibration.txt'))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for c in ('FETCH_SIZE', 'WRITE_SIZE'):
-    for f in glob.glob(os.path.join(src, 'pmc_' + c, '**', '*counter_collection.csv'), recursive=True):
+for d in ('pmc_FETCH_SIZE', 'pmc_WRITE_SIZE', 'pmc_SQ'):
+    for f in glob.glob(os.path.join(src, d, '**', '*counter_collection.csv'), recursive=True):
         for r in csv.DictReader(open(f)):
             k = r['Kernel_Name'].split('(')[0].replace('void ', '')
-            if int(r.get('Grid_Size_Y', r.get('Grid_Size_y', 0)) or 0) >= 0:
-                agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
+            agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
+names = ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_WAVES', 'SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_ACTIVE_INST_VALU', 'SQ_WAVE_CYCLES',
+         'SQ_BUSY_CYCLES', 'GRBM_GUI_ACTIVE')
+
+
+def steady(v):
+    v = sorted(v)                      # launches of B frames dominate; geometry / verification launches are smaller
+    v = v[len(v) // 2:]
+    return sum(v) / len(v)
+
+
 with open(os.path.join(dst, tag + '_pmc_summary.csv'), 'w') as f:
-    f.write('kernel,counter,dispatches,avg_value_KB_per_dispatch\n')
-    for c in ('FETCH_SIZE', 'WRITE_SIZE'):
+    f.write('kernel,counter,dispatches,avg_value_per_full_dispatch\n')
+    for c in names:
         for k in sorted(agg):
             v = agg[k].get(c)
             if v:
-                v = v[len(v) // 3:]          # steady state (skip warm-up / first-touch dispatches)
-                f.write('%s,%s,%d,%.3f\n' % (k, c, len(v), sum(v) / len(v)))
-fast = [k for k in agg if 'k_fast_cells' in k][0]
-fv = agg[fast]['FETCH_SIZE']; fv = fv[len(fv) // 3:]
-wv = agg[fast]['WRITE_SIZE']; wv = wv[len(wv) // 3:]
-fetch, write = sum(fv) / len(fv) * 1024, sum(wv) / len(wv) * 1024
-traffic = {
-    'k_fast_cells_bytes_per_launch_b%d' % B: int(2 * fetch + write),
-    'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes over `python3 bench.py`, %d-frame launches), KB units; '
-            'FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE reports half of wide coalesced reads); '
-            'raw FETCH_SIZE*1024 = %d, WRITE_SIZE*1024 = %d' % (B, fetch, write),
-    'source': 'profiles/%s_pmc_summary.csv' % tag,
+                f.write('%s,%s,%d,%.3f\n' % (k, c, len(v), steady(v)))
+fast = [k for k in agg if 'k_fast' in k][0]
+fetch, write = steady(agg[fast]['FETCH_SIZE']) * 1024, steady(agg[fast]['WRITE_SIZE']) * 1024
+valu, waves = steady(agg[fast]['SQ_INSTS_VALU']), steady(agg[fast]['SQ_WAVES'])
+factor, calib = 1.0, 'no calibration run'
+cal = os.path.join(src, 'fetch_calibration.txt')
+if os.path.exists(cal):
+    for l in open(cal):
+        if l.startswith('calib_tiles'):
+            ratio = float(l.split('ratio')[1])
+            factor = 1.0 / ratio if ratio > 0 else 1.0
+            calib = 'FETCH_SIZE*1024 / distinct bytes = %.3f for the same access pattern (dword per lane, 44-byte rows; tools/ubench/fetch_calib)' % ratio
+commit = subprocess.run(['git', '-C', root, 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip()
+out = {
+    'batch': B,
+    'kernel': fast,
+    'traffic_bytes_per_launch': int(fetch * factor + write),
+    'fetch_size_raw_bytes': int(fetch), 'write_size_raw_bytes': int(write), 'fetch_correction_factor': round(factor, 3),
+    'fetch_calibration': calib,
+    'valu_insts_per_launch': int(valu), 'valu_insts_per_cell_wave': round(valu / waves, 1), 'waves_per_launch': int(waves),
+    'source': 'profiles/%s_pmc_summary.csv (rocprofv3 --pmc, separate passes over `python3 bench.py`), measured at commit %s' % (tag, commit),
 }
-json.dump(traffic, open(os.path.join(dst, 'traffic.json'), 'w'), indent=1)
-print(json.dumps(bench)[:400])
-print(traffic)
+json.dump(out, open(os.path.join(dst, 'counters.json'), 'w'), indent=1)
+print(json.dumps(bench)[:300])
+print(out)
