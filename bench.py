@@ -384,6 +384,22 @@ def cpu_baseline_all_cores(frames, do_match):
     except Exception:
         pass
     cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    quota = None
+    try:                                                             # a container may see 256 CPUs and own 16 of them
+        q, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            quota = max(1, int(float(q) / float(period) + 0.5))
+    except Exception:
+        try:
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            period = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                quota = max(1, int(q / period + 0.5))
+        except Exception:
+            pass
+    visible = cores
+    if quota:
+        cores = min(cores, quota)
     tpp, per = 4, 4
     nproc = max(1, cores // tpp)
     shm = '/dev/shm' if os.path.isdir('/dev/shm') else tempfile.gettempdir()
@@ -410,6 +426,7 @@ def cpu_baseline_all_cores(frames, do_match):
         except OSError:
             pass
     return {'value': round(total / dt, 2), 'unit': 'frames/s', 'cores': nproc * tpp, 'kind': 'port',
+            'cpus_visible': visible, 'cgroup_cpu_quota': quota,
             'sample': '%d processes x %d threads x %d consecutive frames, extract%s, %.1f s' % (
                 nproc, tpp, per, '+SearchForInitialization (3 of 4 frames have a predecessor)' if do_match else '', dt)}
 

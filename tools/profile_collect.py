@@ -52,10 +52,11 @@ factor, calib = 1.0, 'no calibration run'
 cal = os.path.join(src, 'fetch_calibration.txt')
 if os.path.exists(cal):
     for l in open(cal):
-        if l.startswith('calib_tiles'):
+        if l.startswith('calib_b32'):      # the FAST kernel loads one dword per lane
             ratio = float(l.split('ratio')[1])
             factor = 1.0 / ratio if ratio > 0 else 1.0
-            calib = 'FETCH_SIZE*1024 / distinct bytes = %.3f for the same access pattern (dword per lane, 44-byte rows; tools/ubench/fetch_calib)' % ratio
+            calib = ('FETCH_SIZE*1024 / bytes streamed = %.3f for dword-per-lane loads of a 1 GiB buffer (tools/ubench/fetch_calib, '
+                     'same profile round): the counter tallies 128-B requests at 64 B for this width too' % ratio)
 commit = subprocess.run(['git', '-C', root, 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip()
 out = {
     'batch': B,
