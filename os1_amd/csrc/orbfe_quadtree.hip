@@ -48,7 +48,7 @@ struct Qt2Shared {
     unsigned long long sortKeys[CAP];   // sortKeys from the record step of one iteration to the ordering step of the next
   };
   short tproc[CAP];           // index in processing order, -1 = not divided
-  uint32_t wcnt[2][4][kQt2Threads / 64][4];   // [parity][sub-tile][wave][class]
+  alignas(16) uint32_t wcnt[2][4][kQt2Threads / 64][4];   // [parity][sub-tile][wave][class]
   int wsumI[kQt2Threads / 64];
   int s_int[4];
 };
@@ -110,19 +110,29 @@ __device__ void tileScan(Qt2Shared<CAP>& sh, int n, const uint16_t* own, const u
   const unsigned long long below = (1ull << lane) - 1ull;
   uint32_t carry[4] = {0, 0, 0, 0};
   int parity = 0;
+  // the next tile's loads are issued before the current tile is processed (the steps are serialised by the running
+  // class counts, so an unhidden L2 round trip per step is most of a step's time)
+  int oN[kEpt];
+  uint32_t vN[kEpt];
+  auto loadTile = [&](int b) {
+#pragma unroll
+    for (int j = 0; j < kEpt; j++) {
+      const int p = b + j * kQt2Threads + tid;
+      oN[j] = -1;
+      vN[j] = 0;
+      if (p < n) {
+        oN[j] = own ? (int)own[p] : 0;
+        vN[j] = val[p];
+      }
+    }
+  };
+  loadTile(0);
   for (int b = 0; b < n; b += kEpt * kQt2Threads, parity ^= 1) {
     int o[kEpt], q[kEpt];
     uint32_t v[kEpt];
 #pragma unroll
-    for (int j = 0; j < kEpt; j++) {
-      const int p = b + j * kQt2Threads + tid;
-      o[j] = -1;
-      v[j] = 0;
-      if (p < n) {
-        o[j] = own ? (int)own[p] : 0;
-        v[j] = val[p];
-      }
-    }
+    for (int j = 0; j < kEpt; j++) { o[j] = oN[j]; v[j] = vN[j]; }
+    if (b + kEpt * kQt2Threads < n) loadTile(b + kEpt * kQt2Threads);
     uint32_t lanePre[kEpt][4];
 #pragma unroll
     for (int j = 0; j < kEpt; j++) {
@@ -136,23 +146,36 @@ __device__ void tileScan(Qt2Shared<CAP>& sh, int n, const uint16_t* own, const u
       }
     }
     __syncthreads();
-    // prefix over (sub-tile j, wave) in element order
-    uint32_t run[4] = {carry[0], carry[1], carry[2], carry[3]};
+    // exclusive prefix over the (sub-tile j, wave w) pairs in element order, derived by every wave for itself: lane
+    // p = j * NW + w reads the pair's four class counts (one 16-byte LDS load), a DPP wave scan sums them, and the
+    // prefix of this thread's pair (j, wv) comes back through v_readlane -- 4 LDS loads and 24 DPP adds per wave and
+    // step instead of every thread adding up all 128 counts.
+    static_assert(kEpt * NW <= 64, "one lane per (sub-tile, wave) pair");
+    uint32_t inc[4];
+    {
+      const uint4 c4 = lane < kEpt * NW ? *reinterpret_cast<const uint4*>(&sh.wcnt[parity][0][0][0] + 4 * lane) : make_uint4(0, 0, 0, 0);
+      inc[0] = c4.x; inc[1] = c4.y; inc[2] = c4.z; inc[3] = c4.w;
+    }
+    uint32_t exc[4], tot[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      int v = (int)inc[k];
+      v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+      v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+      v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+      v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+      v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+      v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+      exc[k] = (uint32_t)v - inc[k];
+      tot[k] = (uint32_t)__builtin_amdgcn_readlane(v, 63);
+    }
+    const int wvU = __builtin_amdgcn_readfirstlane(wv);
 #pragma unroll
     for (int j = 0; j < kEpt; j++) {
       uint32_t pre[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        uint32_t a = 0, t = 0;
-#pragma unroll
-        for (int w = 0; w < NW; w++) {
-          const uint32_t c = sh.wcnt[parity][j][w][k];
-          if (w < wv) a += c;
-          t += c;
-        }
-        pre[k] = run[k] + a + lanePre[j][k];   // exclusive scan value of class k at p
-        run[k] += t;
-      }
+      for (int k = 0; k < 4; k++)
+        pre[k] = carry[k] + (uint32_t)__builtin_amdgcn_readlane((int)exc[k], j * NW + wvU) + lanePre[j][k];   // exclusive scan value of class k at p
       const int p = b + j * kQt2Threads + tid;
       // segment boundaries = neighbours with a different owner (shuffles run with every lane active)
       int oPrev = __shfl_up(o[j], 1, 64), oNext = __shfl_down(o[j], 1, 64);
@@ -173,7 +196,7 @@ __device__ void tileScan(Qt2Shared<CAP>& sh, int n, const uint16_t* own, const u
       }
     }
 #pragma unroll
-    for (int k = 0; k < 4; k++) carry[k] = run[k];
+    for (int k = 0; k < 4; k++) carry[k] += tot[k];
   }
 #pragma unroll
   for (int k = 0; k < 4; k++) total[k] = carry[k];
@@ -421,27 +444,37 @@ __global__ __launch_bounds__(kQt2Threads) void k_quadtree2(QtParams Q) {
     __syncthreads();
 
     // ---- element pass 2: move candidates into their children, re-own (4 independent elements in flight)
-    for (int b = 0; b < n; b += kEpt * kQt2Threads) {
-      int o[kEpt];
-      uint32_t v[kEpt], rq[kEpt];
+    {
+      int oN[kEpt];
+      uint32_t vN[kEpt], rN[kEpt];
+      auto loadTile2 = [&](int b) {
 #pragma unroll
-      for (int j = 0; j < kEpt; j++) {
-        const int p = b + j * kQt2Threads + tid;
-        o[j] = 0; v[j] = 0; rq[j] = 0;
-        if (p < n) { o[j] = ownCur[p]; v[j] = valCur[p]; rq[j] = rankq[p]; }
-      }
+        for (int j = 0; j < kEpt; j++) {
+          const int p = b + j * kQt2Threads + tid;
+          oN[j] = 0; vN[j] = 0; rN[j] = 0;
+          if (p < n) { oN[j] = ownCur[p]; vN[j] = valCur[p]; rN[j] = rankq[p]; }
+        }
+      };
+      loadTile2(0);
+      for (int b = 0; b < n; b += kEpt * kQt2Threads) {
+        int o[kEpt];
+        uint32_t v[kEpt], rq[kEpt];
 #pragma unroll
-      for (int j = 0; j < kEpt; j++) {
-        const int p = b + j * kQt2Threads + tid;
-        if (p < n) {
-          if (sh.tproc[o[j]] >= 0) {
-            const int q = rq[j] >> 30;
-            const uint32_t np = (rq[j] & 0x3fffffffu) + sh.baseS[o[j]][q];
-            valNxt[np] = v[j];
-            ownNxt[np] = sh.cpos[o[j]][q];
-          } else {
-            valNxt[p] = v[j];
-            ownNxt[p] = sh.cpos[o[j]][0];
+        for (int j = 0; j < kEpt; j++) { o[j] = oN[j]; v[j] = vN[j]; rq[j] = rN[j]; }
+        if (b + kEpt * kQt2Threads < n) loadTile2(b + kEpt * kQt2Threads);
+#pragma unroll
+        for (int j = 0; j < kEpt; j++) {
+          const int p = b + j * kQt2Threads + tid;
+          if (p < n) {
+            if (sh.tproc[o[j]] >= 0) {
+              const int q = rq[j] >> 30;
+              const uint32_t np = (rq[j] & 0x3fffffffu) + sh.baseS[o[j]][q];
+              valNxt[np] = v[j];
+              ownNxt[np] = sh.cpos[o[j]][q];
+            } else {
+              valNxt[p] = v[j];
+              ownNxt[p] = sh.cpos[o[j]][0];
+            }
           }
         }
       }
@@ -481,23 +514,27 @@ __global__ __launch_bounds__(kQt2Threads) void k_quadtree2(QtParams Q) {
   }
 
   // ---- one keypoint per node: highest response, first wins (ORBextractor.cc:774-792) ------------------
-  const int lane = tid & 63, wv = tid >> 6;
-  for (int i = wv; i < m; i += kQt2Threads / 64) {
-    const QtNode nd = cur[i];
-    int bestScore = -1;
-    uint32_t bestPos = 0xffffffffu;
-    for (uint32_t p = nd.begin + lane; p < nd.end; p += 64) {
-      const int s = (int)(valCur[p] >> 24);
-      if (s > bestScore) { bestScore = s; bestPos = p; }
+  // 16 lanes per node (a node holds about 20 candidates when the quota is reached), four nodes per wave at a time;
+  // key = score << 24 | (0xffffff - offset inside the node): the maximum is the highest score at the lowest position
+  const int lane = tid & 63, wv = tid >> 6, sub = lane >> 4, sl = lane & 15;
+  for (int i0 = wv * 4; i0 < m; i0 += (kQt2Threads / 64) * 4) {
+    const int i = i0 + sub;
+    uint32_t bestKey = 0, bestVal = 0;
+    if (i < m) {
+      const QtNode nd = cur[i];
+      for (uint32_t p = nd.begin + sl; p < nd.end; p += 16) {
+        const uint32_t c = valCur[p];
+        const uint32_t key = ((c >> 24) << 24) | (0xffffffu - (p - nd.begin));
+        if (key > bestKey) { bestKey = key; bestVal = c; }
+      }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const int os = __shfl_xor(bestScore, o, 64);
-      const uint32_t op = __shfl_xor(bestPos, o, 64);
-      if (os > bestScore || (os == bestScore && op < bestPos)) { bestScore = os; bestPos = op; }
+    for (int o = 8; o > 0; o >>= 1) {
+      const uint32_t ok = __shfl_xor(bestKey, o, 64), ov = __shfl_xor(bestVal, o, 64);
+      if (ok > bestKey) { bestKey = ok; bestVal = ov; }
     }
-    if (lane == 0) {
-      const uint32_t c = valCur[bestPos];
+    if (i < m && sl == 0) {
+      const uint32_t c = bestVal;
       SelKp s;
       s.xy = (c & 0xfff) | (((c >> 12) & 0xfff) << 16);
       s.lf = (uint32_t)level | ((uint32_t)f << 8) | ((c >> 24) << 24);
