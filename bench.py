@@ -24,7 +24,7 @@ traffic is the barrier and the max-over-ranks of the elapsed time (gloo, CPU ten
 bench.py itself: `python bench.py --gpus N` spawns the N ranks as fresh child processes before it touches any GPU.
 
 One JSON line on rank 0 (see the task's bench contract) with extra objects:
-  roofline       -- dominant kernel (k_fast_cells): algorithmic bytes per launch / HIP-event duration vs HBM peak,
+  roofline       -- dominant kernel (k_fast_tasks): algorithmic bytes per launch / HIP-event duration vs HBM peak,
                     plus its vector-instruction-issue roof (the bound that actually explains its time)
   cpu_baseline   -- the CPU oracle (scalar port, 1 core) on a bounded sample of the same frames
   pcie_inclusive -- the same stream from page-locked host frames
@@ -74,16 +74,33 @@ def launch_ranks(args):
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
+    if 'ORBFE_BENCH_DEVICE' not in os.environ and not args.plumbing_only:
+        import torch                                 # device_count() does not initialise the GPU on this image
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print('bench.py --gpus %d: only %d GPU(s) visible (the product has no CPU fallback)' % (args.gpus, have), file=sys.stderr)
+            return 2
     procs = []
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = max(rc, abs(p.wait()))
+    # a rank that dies would leave the others waiting in a gloo collective: watch all of them, stop the rest on the first failure
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = abs(code) or 1
+                for q in live:
+                    q.kill()                         # exact children of this process
+    out0 = procs[0].stdout.read() if procs[0].stdout else ''
     sys.stdout.write(out0)
     sys.stdout.flush()
     return rc
@@ -254,7 +271,7 @@ def run_rank(args):
     if rank == 0:
         frames_done = world * args.pool * args.steps
         fps = frames_done / elapsed
-        # roofline of the dominant kernel: k_fast_cells reads every pyramid pixel once (sum of level
+        # roofline of the dominant kernel: k_fast_tasks reads every pyramid pixel once (sum of level
         # sizes) and writes 4 B per surviving candidate; algorithmic bytes per launch = that x B.
         ex = api.Extractor(wl.NFEAT, wl.SCALE, wl.NLEVELS, wl.INI_TH, wl.MIN_TH, device=local_rank)   # geometry + candidate count only
         t = ex.tables()
@@ -293,14 +310,14 @@ def run_rank(args):
                        'numa': {'node_of_gpu': numa_node, 'cpus_bound': numa_cpus}},
             'verified': verify['verified'], 'outputs_sha256': verify['outputs_sha256'], 'verify': verify,
             'pcie_inclusive': pcie,
-            # HIP-event time of the kernels in the pipeline (they overlap other batches' kernels); only k_fast_cells is
+            # HIP-event time of the kernels in the pipeline (they overlap other batches' kernels); only k_fast_tasks is
             # always timed (roofline), the others appear with ORBFE_PROFILE_KERNELS=1 (costs about 1 % of the rate)
             'gpu_kernel_ms_per_frame': {k: round(v / max(kframes, 1), 5) for k, v in
                                         zip(('pyramid', 'fast_cells', 'compaction', 'describe', 'quadtree'), kms) if v > 0},
             'ms_per_step_percentiles': (lambda d: {'p10': round(float(np.percentile(d, 10)), 4), 'p50': round(float(np.percentile(d, 50)), 4),
                                                     'p90': round(float(np.percentile(d, 90)), 4), 'max': round(float(d.max()), 4)})(step_ms) if step_ms is not None and len(step_ms) > 1 else None,
             'host_worker_ms_per_submission': {'submit': round(wstats[0] / max(wstats[3], 1), 4), 'collect_incl_gpu_wait': round(wstats[1] / max(wstats[3], 1), 4)},
-            'roofline': {'kernel': 'k_fast_cells', 'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
+            'roofline': {'kernel': 'k_fast_tasks', 'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
                          'traffic_source': prof.get('source'),
                          'algorithmic_bytes_per_launch': fast_bytes_per_frame * B,
@@ -337,7 +354,7 @@ def verify_first_steps(wl, seed, run):
 
 
 def load_profile_counters(B):
-    """Counters of k_fast_cells from the committed rocprofv3 --pmc passes (profiles/counters.json names the
+    """Counters of k_fast_tasks from the committed rocprofv3 --pmc passes (profiles/counters.json names the
     profile tag and the commit they were taken at; they are offline measurements of the same command, not of this run)."""
     path = os.path.join(ROOT, 'profiles', 'counters.json')
     try:

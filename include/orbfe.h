@@ -177,7 +177,7 @@ int orbfe_debug_candidates(orbfe_extractor* h, int frame, int level, int32_t* xy
  * (orientation+blur+rBRIEF), [3]=output assembly, [4]=total. */
 int orbfe_debug_stage_ms(const orbfe_extractor* h, float out[5]);
 /* GPU time (HIP events recorded on the launch stream) accumulated per kernel group since the last
- * reset: out_ms[0]=pyramid (k_resize x (nlevels-1)), [1]=k_fast_cells, [2]=k_scan_cells+k_gather,
+ * reset: out_ms[0]=pyramid (k_resize x (nlevels-1)), [1]=k_fast_tasks, [2]=k_compact,
  * [3]=k_describe, [4]=k_quadtree; *batches = launches of each group, *frames = frames processed. */
 int orbfe_debug_kernel_ms(orbfe_extractor* h, double out_ms[5], long long* batches, long long* frames, int reset);
 /* k_fast_cells (the dominant kernel) is always timed; enable != 0 also times the other groups, at the

@@ -26,7 +26,6 @@
 // share ROI halos and cache lines in that XCD's L2.
 #include <hip/hip_runtime.h>
 
-#include <cstdlib>
 #include <type_traits>
 
 #include "orbfe_internal.h"
@@ -351,11 +350,10 @@ size_t fast_lds_bytes(const PyramidParams& P, int tpPad) {
 }
 
 void launch_fast(const PyramidParams& P, int nframes, hipStream_t st) {
-  static const int npx = getenv("ORBFE_FAST_NPX") ? atoi(getenv("ORBFE_FAST_NPX")) : 16;     // A/B aids
-  static const int tpPad = getenv("ORBFE_FAST_TPPAD") ? atoi(getenv("ORBFE_FAST_TPPAD")) & ~3 : 0;
+  // 16 pixels per lane in the pre-test: one wave iteration covers a 31 x 31 cell (8 pixels per lane take two and are
+  // equal in time, 9.9 us per 1080p frame, with more instructions)
   const dim3 grid(8 * ((P.ntasks + 7) / 8), nframes);
-  if (npx == 8) hipLaunchKernelGGL(k_fast_tasks<8>, grid, dim3(64), fast_lds_bytes(P, tpPad), st, P, tpPad);
-  else hipLaunchKernelGGL(k_fast_tasks<16>, grid, dim3(64), fast_lds_bytes(P, tpPad), st, P, tpPad);
+  hipLaunchKernelGGL(k_fast_tasks<16>, grid, dim3(64), fast_lds_bytes(P, 0), st, P, 0);
 }
 
 }  // namespace orbfe

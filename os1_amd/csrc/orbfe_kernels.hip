@@ -6,8 +6,7 @@
 //   k_to_gray       cv::cvtColor RGB/BGR(A) -> gray, 8u fixed point (colour input only)
 //   k_resize        cv::resize INTER_LINEAR 8u (level l <- level l-1), 11-bit fixed point, separable through LDS
 //   (k_fast_tasks   per reference FAST cell, one wave per cell pair: orbfe_fast.hip)
-//   k_scan_cells    exclusive scan of per-cell counts -> reference candidate order
-//   k_gather        ordered compaction of the per-cell slots (1 lane/cell)
+//   k_compact       ordered compaction of the per-cell slots into the reference's candidate order (1 lane/cell)
 //   k_describe      per keypoint (1 wave): IC-angle (dot4), 7x7 fixed-point Gaussian of the 37x37 neighbourhood
 //                   (dot4 rows, dot2 columns), steered BRIEF with __ballot packing
 //   k_sincos        test hook for the device (cosf,sinf)
@@ -153,51 +152,48 @@ __device__ __forceinline__ u16x2 as_u16x2(unsigned v) { return __builtin_bit_cas
 __device__ __forceinline__ unsigned as_u32(u16x2 v) { return __builtin_bit_cast(unsigned, v); }
 
 // ------------------------------------------------------------------------------------------------
-// Exclusive scan of the per-cell counts of one frame (cells are numbered level-major, cell-row-major:
-// exactly the order in which the reference appends to vToDistributeKeys, ORBextractor.cc:826-870).
-// One 1024-thread block per frame.
+// Ordered compaction of the per-cell candidate slots into the frame's candidate list (cells are numbered level-major,
+// cell-row-major: exactly the order in which the reference appends to vToDistributeKeys, ORBextractor.cc:826-870).
+// One wave per 64 consecutive cells, one LANE per cell.  A wave finds its first offset by itself -- the sum of the
+// counts of all earlier cells, at most 100 coalesced dwords per lane at 1080p -- so no separate scan kernel (and no
+// grid-wide dependency) is needed: one launch instead of two, 6 us instead of 25 on the single-frame path.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_scan_cells(PyramidParams P) {
-  __shared__ uint32_t wsum[16];
-  __shared__ uint32_t carry;
-  const int f = P.frameBase + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const uint32_t* cnt = P.cellCount + (long long)f * P.ncells;
-  uint32_t* off = P.cellOff + (long long)f * P.ncells;
-  if (tid == 0) carry = 0;
-  __syncthreads();
-  for (int base = 0; base < P.ncells; base += 1024) {
-    const int i = base + tid;
-    const uint32_t v = i < P.ncells ? cnt[i] : 0u;
-    uint32_t incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t t = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += t;
-    }
-    if (lane == 63) wsum[wv] = incl;
-    __syncthreads();
-    uint32_t wbase = 0;
-    for (int w = 0; w < wv; w++) wbase += wsum[w];
-    const uint32_t c = carry;
-    if (i < P.ncells) off[i] = c + wbase + incl - v;
-    __syncthreads();
-    if (tid == 1023) carry = c + wbase + incl;
-    __syncthreads();
-  }
-  uint32_t* ls = P.levelStart + (long long)f * (kMaxLevels + 1);
-  if (tid < P.nlevels) ls[tid] = off[P.lv[tid].cellBase];
-  if (tid == 0) ls[P.nlevels] = carry;
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);   // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);   // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);   // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);   // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+  return (uint32_t)x;
 }
 
-// One LANE per cell (cells hold a handful of candidates each; a wave per cell spent its time being launched):
-// every lane copies its cell's slots to the cell's offset in the frame's candidate list, 4 entries in flight.
-__global__ __launch_bounds__(64) void k_gather(PyramidParams P) {
-  const int cell = blockIdx.x * 64 + threadIdx.x, f = P.frameBase + blockIdx.y;
-  uint32_t n = 0, o = 0;
+__global__ __launch_bounds__(64) void k_compact(PyramidParams P) {
+  const int cell0 = blockIdx.x * 64, lane = threadIdx.x, f = P.frameBase + blockIdx.y;
+  const uint32_t* cnt = P.cellCount + (long long)f * P.ncells;
+  // offset of the wave's first cell
+  uint32_t s = 0;
+  for (int i = lane; i < cell0; i += 256) {
+    uint32_t v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) v[u] = (i + 64 * u < cell0) ? cnt[i + 64 * u] : 0u;
+    s += (v[0] + v[1]) + (v[2] + v[3]);
+  }
+  const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(s), 63);
+  const int cell = cell0 + lane;
+  uint32_t n = cell < P.ncells ? cnt[cell] : 0u;
+  const uint32_t incl = wave_incl_scan(n);
+  uint32_t o = base + incl - n;
+  uint32_t* ls = P.levelStart + (long long)f * (kMaxLevels + 1);
+  if (cell < P.ncells) {
+    P.cellOff[(long long)f * P.ncells + cell] = o;
+    for (int l = 0; l < P.nlevels; l++)
+      if (P.lv[l].cellBase == cell) ls[l] = o;
+    if (cell == P.ncells - 1) ls[P.nlevels] = o + n;
+  }
   const uint32_t* slot = nullptr;
   if (cell < P.ncells) {
-    n = P.cellCount[(long long)f * P.ncells + cell];
-    o = P.cellOff[(long long)f * P.ncells + cell];
     slot = P.slots + (long long)f * P.slotsPerFrame + P.cells[cell].slotOff;
     if (o >= (uint32_t)P.candCap) n = 0;
     else n = min(n, (uint32_t)P.candCap - o);
@@ -562,8 +558,7 @@ void launch_pyramid(const PyramidParams& P, int nframes, hipStream_t st) {
 }
 
 void launch_compact(const PyramidParams& P, int nframes, hipStream_t st) {
-  hipLaunchKernelGGL(k_scan_cells, dim3(nframes), dim3(1024), 0, st, P);
-  hipLaunchKernelGGL(k_gather, dim3((P.ncells + 63) / 64, nframes), dim3(64), 0, st, P);
+  hipLaunchKernelGGL(k_compact, dim3((P.ncells + 63) / 64, nframes), dim3(64), 0, st, P);
 }
 
 void launch_describe(const PyramidParams& P, const SelKp* sel, int nsel, float* angle, uint8_t* desc,

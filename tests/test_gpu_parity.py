@@ -529,3 +529,21 @@ def test_randomised_sizes_and_parameters(api, oracle):
         kps, desc, n = ex.extract_batch_ptrs(dev.ptrs, H, W, stride, True)
         _cmp_extract((kps[0, :n[0]], desc[0, :n[0]]), want)
         _cmp_extract((kps[1, :n[1]], desc[1, :n[1]]), ox.extract(img[::-1].copy()))
+
+
+def test_fast_cell_pairs_variant_bit_exact(api, oracle, monkeypatch):
+    """ORBFE_FAST_PAIRS=1: two horizontally adjacent FAST cells per wave (fewer instructions, kept as an option,
+    DESIGN.md s5) -- same keypoints and descriptors, including the per-cell minThFAST fallback and the NMS cut at the
+    boundary between the two cells of a wave."""
+    monkeypatch.setenv('ORBFE_FAST_PAIRS', '1')
+    for seed, W, H, N in ((2, 1920, 1080, 2000), (12, 752, 480, 900), (13, 801, 333, 600)):
+        img = synth(seed, W, H)
+        if seed == 13:
+            img[:, W // 2:] = (img[:, W // 2:] // 8 + 100).astype(np.uint8)     # low contrast half: cells that need the minTh pass
+        ex = api.Extractor(N, 1.2, 8, 20, 7)
+        ox = OracleExtractor(N, 1.2, 8, 20, 7, oracle)
+        _cmp_extract(ex(img), ox.extract(img))
+        for l in range(8):
+            c, oc = ex.candidates(l), ox.candidates(l)
+            assert len(c) == len(oc), (seed, l)
+            assert (c[:, 0] == oc['x']).all() and (c[:, 1] == oc['y']).all() and (c[:, 2] == oc['response']).all(), (seed, l)

@@ -103,3 +103,31 @@ def test_pinhole_undistortion_and_image_bounds_match_oracle(oracle):
     assert list(api.compute_image_bounds(640, 480, 0, *K, [0.0, 0.1, 0, 0])) == [0.0, 640.0, 0.0, 480.0]   # k1 == 0: the image rectangle
     fish = (2196.0, 2196.0, 1839.0, 1155.0)
     assert api.compute_image_bounds(3840, 2160, 1, *fish).tobytes() == oracle.image_bounds(3840, 2160, 1, *fish).tobytes()
+
+
+def test_bench_stream_definition():
+    """os1_amd/stream_workload.py: frame i of stream `seed` is synth.shifted(base, 2i, i, seed*1000+i) (config 4: each
+    frame = its predecessor shifted by (2,1) px), generated from one padded copy; the endless stream walks the pool
+    forwards and backwards so consecutive frames always differ by one step; the committed digests cover 8 ranks."""
+    import json
+    import os
+    from os1_amd import stream_workload as wl
+    from os1_amd.synth import shifted
+    sf = wl.StreamFrames(103, 320, 200, pool=40)
+    for i in (1, 2, 17, 39):
+        assert (sf.frame(i) == shifted(sf.base, 2 * i, i, 103 * 1000 + i)).all()
+    assert sf.frame(0) is sf.base
+    seq = [wl.pool_index(p, 5) for p in range(12)]
+    assert seq == [0, 1, 2, 3, 4, 3, 2, 1, 0, 1, 2, 3]
+    assert all(abs(a - b) == 1 for a, b in zip(seq, seq[1:]))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.load(open(os.path.join(root, 'tests', 'golden', 'stream1080_digests.json')))
+    assert sorted(d['streams']) == [str(wl.stream_seed(g)) for g in range(8)]
+    assert all(len(v['steps']) == 4 and v['nmatches'] > 20000 for v in d['streams'].values())
+    assert d['workload']['batch'] == wl.BATCH and d['workload']['image'] == [wl.W, wl.H]
+    # digest helpers: order and content sensitive
+    k = np.zeros(3, dtype=[('x', 'f4'), ('y', 'f4')])
+    a = wl.frame_digest(k, np.zeros((3, 32), np.uint8), 3)
+    k['x'][1] = 1
+    assert a != wl.frame_digest(k, np.zeros((3, 32), np.uint8), 3)
+    assert wl.match_digest(2, np.array([1, -1, 0]), 3) != wl.match_digest(2, np.array([1, 0, -1]), 3)
