@@ -156,7 +156,7 @@ __device__ __forceinline__ unsigned as_u32(u16x2 v) { return __builtin_bit_cast(
 // cell-row-major: exactly the order in which the reference appends to vToDistributeKeys, ORBextractor.cc:826-870).
 // One wave per 64 consecutive cells, one LANE per cell.  A wave finds its first offset by itself -- the sum of the
 // counts of all earlier cells, at most 100 coalesced dwords per lane at 1080p -- so no separate scan kernel (and no
-// grid-wide dependency) is needed: one launch instead of two, 6 us instead of 25 on the single-frame path.
+// grid-wide dependency) is needed: one launch instead of two.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
   int x = (int)v;
@@ -172,39 +172,49 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 __global__ __launch_bounds__(64) void k_compact(PyramidParams P) {
   const int cell0 = blockIdx.x * 64, lane = threadIdx.x, f = P.frameBase + blockIdx.y;
   const uint32_t* cnt = P.cellCount + (long long)f * P.ncells;
-  // offset of the wave's first cell
-  uint32_t s = 0;
-  for (int i = lane; i < cell0; i += 256) {
-    uint32_t v[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) v[u] = (i + 64 * u < cell0) ? cnt[i + 64 * u] : 0u;
-    s += (v[0] + v[1]) + (v[2] + v[3]);
-  }
-  const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(s), 63);
   const int cell = cell0 + lane;
-  uint32_t n = cell < P.ncells ? cnt[cell] : 0u;
+  const bool valid = cell < P.ncells;
+  // everything that does not depend on another load is requested up front (the data was written by another kernel,
+  // possibly through another XCD's L2: every dependent round trip costs 1-2 us): the cell's slot address, its own
+  // count, the counts of all earlier cells
+  const uint32_t slotOff = valid ? P.cells[cell].slotOff : 0u;
+  uint32_t n = valid ? cnt[cell] : 0u;
+  uint32_t s = 0;
+  for (int i = lane; i < cell0; i += 64 * 16) {   // 16 loads in flight per lane: the last wave of a 1080p frame needs 7 rounds
+    uint32_t v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) v[u] = (i + 64 * u < cell0) ? cnt[i + 64 * u] : 0u;
+#pragma unroll
+    for (int u = 0; u < 16; u += 4) s += (v[u] + v[u + 1]) + (v[u + 2] + v[u + 3]);
+  }
+  // the first 16 slots of the cell are fetched before its count is known (a cell owns at least 16 slots; surplus
+  // entries are never stored)
+  const uint32_t* slot = P.slots + (long long)f * P.slotsPerFrame + slotOff;
+  uint32_t first[16];
+#pragma unroll
+  for (int u = 0; u < 16; u++) first[u] = slot[u];
+  const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(s), 63);
   const uint32_t incl = wave_incl_scan(n);
-  uint32_t o = base + incl - n;
+  const uint32_t o = base + incl - n;
   uint32_t* ls = P.levelStart + (long long)f * (kMaxLevels + 1);
-  if (cell < P.ncells) {
+  if (valid) {
     P.cellOff[(long long)f * P.ncells + cell] = o;
     for (int l = 0; l < P.nlevels; l++)
       if (P.lv[l].cellBase == cell) ls[l] = o;
     if (cell == P.ncells - 1) ls[P.nlevels] = o + n;
   }
-  const uint32_t* slot = nullptr;
-  if (cell < P.ncells) {
-    slot = P.slots + (long long)f * P.slotsPerFrame + P.cells[cell].slotOff;
-    if (o >= (uint32_t)P.candCap) n = 0;
-    else n = min(n, (uint32_t)P.candCap - o);
-  }
+  if (o >= (uint32_t)P.candCap) n = 0;
+  else n = min(n, (uint32_t)P.candCap - o);
   uint32_t* dst = P.cand + (long long)f * P.candCap + o;
-  for (uint32_t i = 0; __any(i < n); i += 4) {
-    uint32_t v[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) v[u] = (i + u < n) ? slot[i + u] : 0u;
+  for (int u = 0; u < 16; u++)
+    if ((uint32_t)u < n) dst[u] = first[u];
+  for (uint32_t i = 16; __any(i < n); i += 16) {
+    uint32_t v[16];
 #pragma unroll
-    for (int u = 0; u < 4; u++)
+    for (int u = 0; u < 16; u++) v[u] = (i + u < n) ? slot[i + u] : 0u;
+#pragma unroll
+    for (int u = 0; u < 16; u++)
       if (i + u < n) dst[i + u] = v[u];
   }
 }
