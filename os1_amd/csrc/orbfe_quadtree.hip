@@ -42,8 +42,8 @@ struct Qt2Shared {
   unsigned short proc[CAP];   // node ids in processing order
   uint32_t ninfo[CAP];        // midX | midY << 12 | divide << 24
   uint16_t cpos[CAP][4];      // new list position of child q; kept nodes: [0] = new position
-  uint32_t baseS[CAP][4];     // exclusive quadrant scan at the node's first element -> later: child.begin - baseS
-  union {                     // lifetimes do not overlap: endS lives from element pass 1 to the node pass of an iteration,
+  alignas(16) uint32_t baseS[CAP][4];     // exclusive quadrant scan at the node's first element -> later: child.begin - baseS
+  union alignas(16) {         // lifetimes do not overlap: endS lives from element pass 1 to the node pass of an iteration,
     uint32_t endS[CAP][4];    //   inclusive quadrant scan at the node's last element
     unsigned long long sortKeys[CAP];   // sortKeys from the record step of one iteration to the ordering step of the next
   };
@@ -177,21 +177,17 @@ __device__ void tileScan(Qt2Shared<CAP>& sh, int n, const uint16_t* own, const u
       for (int k = 0; k < 4; k++)
         pre[k] = carry[k] + (uint32_t)__builtin_amdgcn_readlane((int)exc[k], j * NW + wvU) + lanePre[j][k];   // exclusive scan value of class k at p
       const int p = b + j * kQt2Threads + tid;
-      // segment boundaries = neighbours with a different owner (shuffles run with every lane active)
-      int oPrev = __shfl_up(o[j], 1, 64), oNext = __shfl_down(o[j], 1, 64);
+      // segment boundaries = neighbours with a different owner (DPP wave shifts; lanes 0 / 63 are patched below)
+      int oPrev = __builtin_amdgcn_update_dpp(-1, o[j], 0x138, 0xf, 0xf, false);   // wave_shr:1: lane i <- lane i-1
+      int oNext = __builtin_amdgcn_update_dpp(-1, o[j], 0x130, 0xf, 0xf, false);   // wave_shl:1: lane i <- lane i+1
       if (p < n && q[j] < 4) {
         rankq[p] = pre[q[j]] | ((uint32_t)q[j] << 30);
         if (recordSegments) {
           if (lane == 0) oPrev = p > 0 ? (int)own[p - 1] : -1;
           if (lane == 63 || p == n - 1) oNext = p + 1 < n ? (int)own[p + 1] : -1;
-          if (oPrev != o[j]) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) sh.baseS[o[j]][k] = pre[k];
-          }
-          if (oNext != o[j]) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) sh.endS[o[j]][k] = pre[k] + (q[j] == k ? 1u : 0u);
-          }
+          if (oPrev != o[j]) *reinterpret_cast<uint4*>(sh.baseS[o[j]]) = make_uint4(pre[0], pre[1], pre[2], pre[3]);
+          if (oNext != o[j])
+            *reinterpret_cast<uint4*>(sh.endS[o[j]]) = make_uint4(pre[0] + (q[j] == 0), pre[1] + (q[j] == 1), pre[2] + (q[j] == 2), pre[3] + (q[j] == 3));
         }
       }
     }
