@@ -282,6 +282,20 @@ def run_rank(args):
             px += lw * lh
         ex.extract_batch_ptrs(dev.ptrs[:1], H, W, dev.stride, True)
         ncand = sum(len(ex.candidates(l, 0)) for l in range(wl.NLEVELS))
+        # the call pattern of the reference's Tracking thread: one blocking ORBextractor::operator() per frame
+        # (Frame.cc:133), frame already in HBM; median wall time of 60 calls on distinct frames, outside the timed region
+        single = None
+        if world == 1:
+            kbuf = np.zeros((1, ex.cap), api.KP_DTYPE)
+            dbuf = np.zeros((1, ex.cap, 32), np.uint8)
+            lat = []
+            for i in range(70):
+                t_a = time.perf_counter()
+                ex.extract_batch_ptrs(dev.ptrs[i % args.pool:i % args.pool + 1], H, W, dev.stride, True, kbuf, dbuf)
+                lat.append(time.perf_counter() - t_a)
+            lat = np.array(lat[10:]) * 1e3
+            single = {'ms_median': round(float(np.median(lat)), 4), 'ms_p90': round(float(np.percentile(lat, 90)), 4),
+                      'call': 'blocking orbfe_extract_batch of ONE resident 1080p frame (extract only), 60 calls'}
         fast_bytes_per_frame = px + 4 * ncand
         fast_ms_per_launch = kms[1] / max(kbatches, 1)
         achieved = fast_bytes_per_frame * B / (fast_ms_per_launch * 1e-3) / 1e9 if fast_ms_per_launch > 0 else 0.0
@@ -310,6 +324,7 @@ def run_rank(args):
                        'numa': {'node_of_gpu': numa_node, 'cpus_bound': numa_cpus}},
             'verified': verify['verified'], 'outputs_sha256': verify['outputs_sha256'], 'verify': verify,
             'pcie_inclusive': pcie,
+            'single_frame_latency': single,
             # HIP-event time of the kernels in the pipeline (they overlap other batches' kernels); only k_fast_tasks is
             # always timed (roofline), the others appear with ORBFE_PROFILE_KERNELS=1 (costs about 1 % of the rate)
             'gpu_kernel_ms_per_frame': {k: round(v / max(kframes, 1), 5) for k, v in
