@@ -120,3 +120,37 @@ def test_bench_two_ranks_on_one_gpu(api):
     assert res['n_gpus'] == 2
     assert res['verified'] is True and res['verify']['ranks_verified'] == 2
     assert res['value'] > 1000 and res['config']['parallelism'].startswith('independent streams')
+
+
+def test_stream_runner_4k_4000_features(api, oracle):
+    """BASELINE configs[4] geometry through the streaming path: 3840x2160, 4000 features (the 1 024-node quadtree variant,
+    869 level-0 queries per SearchForInitialization), 2-frame submissions on 2 handles, against the live oracle."""
+    from oracle.pyoracle import OracleExtractor
+    from os1_amd.synth import shifted, synth
+    W, H, N, B = 3840, 2160, 4000, 2
+    base = synth(5, W, H)
+    frames = [base] + [shifted(base, 2 * i, i, 5000 + i) for i in range(1, 3 * B)]
+    dev = api.DeviceFrames(frames, 0)
+    st = api.Stream(N, 1.2, 8, 20, 7, 0, B, 2)
+    bounds = (0.0, float(W), 0.0, float(H))
+    st.set_matching(bounds, 100, 0.9, True)
+    ox = OracleExtractor(N, 1.2, 8, 20, 7, oracle)
+    want = [ox.extract(f) for f in frames]
+    for b in range(3):
+        st.push_ptrs(dev.ptrs[b * B:(b + 1) * B], H, W, dev.stride, True)
+    total = 0
+    for b in range(3):
+        kps, desc, n, m12, nm = st.pop(copy=True)
+        for i in range(B):
+            g = b * B + i
+            wk, wd = want[g]
+            assert n[i] == len(wk)
+            assert kps[i, :n[i]].tobytes() == wk.tobytes() and desc[i, :n[i]].tobytes() == wd.tobytes()
+            if g == 0:
+                continue
+            pk, pd = want[g - 1]
+            on, om12, _ = oracle.search_for_initialization(pk, pd, wk, wd, bounds, np.stack([pk['x'], pk['y']], 1).reshape(-1, 2), 100, 0.9, True)
+            assert nm[i] == on and (m12[i, :len(pk)] == om12).all()
+            total += on
+    assert total > 1000
+    st.close()
