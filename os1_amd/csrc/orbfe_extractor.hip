@@ -201,9 +201,7 @@ struct orbfe_extractor {
   QtParams QP{};
   int selOff[kMaxLevels + 1] = {};
   int selPerFrame = 0;
-  DevBuf<uint32_t> d_idxA, d_idxB, d_rank;
-  DevBuf<uint16_t> d_ownA, d_ownB;
-  DevBuf<QtNode> d_nodesA, d_nodesB;
+  DevBuf<uint16_t> d_own;   // node id per candidate (quadtree)
   hipEvent_t evQt[2] = {};
   hipStream_t qtStream = nullptr;       // high-priority stream for the latency-bound quadtree kernel
   hipEvent_t evQtIn = nullptr, evQtOut = nullptr;
@@ -275,8 +273,7 @@ struct orbfe_extractor {
     if (evQtIn) (void)hipEventDestroy(evQtIn);
     if (evQtOut) (void)hipEventDestroy(evQtOut);
     if (qtStream) (void)hipStreamDestroy(qtStream);
-    d_idxA.release(); d_idxB.release(); d_rank.release(); d_ownA.release(); d_ownB.release();
-    d_nodesA.release(); d_nodesB.release();
+    d_own.release();
     if (evFrame0) (void)hipEventDestroy(evFrame0);
     if (evUpload) (void)hipEventDestroy(evUpload);
     if (evFront) {
@@ -342,6 +339,7 @@ struct orbfe_extractor {
     Q.slabBytes = off;
     Q.slotsPerFrame = slot;
     Q.candCap = slot;
+    if (slot >= (1ll << 24)) qtOk = false;   // k_quadtree3 packs a candidate index into 24 bits (not reachable below 4096 x 4096)
 
     // bilinear tables, SURVEY.md Appendix B.2 (float/double arithmetic exactly as cv::resize)
     std::vector<uint8_t> tab(tableBytes);
@@ -503,14 +501,7 @@ struct orbfe_extractor {
         d_nm.p = (int32_t*)(D + oNm); h_nm.p = (int32_t*)(Hh + oNm);
       }
       if (gpuQuadtree) {
-        const size_t ce = (size_t)P.candCap * nframes, nn = (size_t)nframes * nlevels * kQtNodeCap;
-        if ((rc = d_idxA.ensure(ce))) return rc;
-        if ((rc = d_idxB.ensure(ce))) return rc;
-        if ((rc = d_rank.ensure(ce))) return rc;
-        if ((rc = d_ownA.ensure(ce))) return rc;
-        if ((rc = d_ownB.ensure(ce))) return rc;
-        if ((rc = d_nodesA.ensure(nn))) return rc;
-        if ((rc = d_nodesB.ensure(nn))) return rc;
+        if ((rc = d_own.ensure((size_t)P.candCap * nframes))) return rc;
       }
       batchCap = nframes;
       if (candHostCap == 0) candHostCap = 96 * 1024;
@@ -687,8 +678,7 @@ struct orbfe_extractor {
       }
     }
     QP.cand = d_cand.p; QP.levelStart = d_levelStart.p; QP.candCap = P.candCap; QP.nlevels = nlevels; QP.frameBase = 0;
-    QP.idxA = d_idxA.p; QP.idxB = d_idxB.p; QP.ownA = d_ownA.p; QP.ownB = d_ownB.p; QP.rank = d_rank.p;
-    QP.nodesA = d_nodesA.p; QP.nodesB = d_nodesB.p;
+    QP.own = d_own.p;
     QP.sel = d_sel.p; QP.selCount = d_selCount.p; QP.selPerFrame = selPerFrame;
     for (int l = 0; l < nlevels; l++) {
       QP.levW[l] = P.lv[l].w; QP.levH[l] = P.lv[l].h; QP.nfeat[l] = nfeat[l]; QP.selOff[l] = selOff[l];
@@ -1259,7 +1249,7 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
     // a level returns at most max(N_l + 2, 4 * roots) keypoints: the first sweep of DistributeOctTree divides every root
     // before any size check (ORBextractor.cc:620-700), later ones overshoot N_l by at most 2; roots <= 4 on this path
     h->selPerFrame += std::max(h->nfeat[l] + 4, 16);
-    // k_quadtree2 holds at most kQtNodeCap - 4 features per level; beyond that the handle uses the host quadtree
+    // k_quadtree3 holds at most kQtNodeCap - 4 features per level; beyond that the handle uses the host quadtree
     // (blocking orbfe_extract / orbfe_extract_batch only, like ORBFE_HOST_QUADTREE=1)
     if (h->nfeat[l] + 4 > kQtNodeCap) h->gpuQuadtree = false;
   }

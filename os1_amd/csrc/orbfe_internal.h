@@ -108,27 +108,15 @@ struct SfiParams {
 // ---- GPU quadtree (orbfe_quadtree.hip) -------------------------------------------------------------
 constexpr int kQtNodeCap = 2048;  // live nodes <= N + 3  =>  N <= 2044 per level
 
-struct QtNode {
-  short x0, x1, y0, y1;    // UL.x, UR.x, UL.y, BL.y
-  uint32_t begin, end;     // candidate positions (relative to the level's first candidate)
-  uint32_t seq;            // creation order
-};
-
 struct QtParams {
   const uint32_t* cand;        // [nframes][candCap] x | y<<12 | score<<24 (level coordinates)
   const uint32_t* levelStart;  // [nframes][kMaxLevels+1]
-  long long candCap;
+  long long candCap;           // < 2^24 (the final pick packs a candidate index into 24 bits)
   int nlevels, frameBase;
   int levW[kMaxLevels], levH[kMaxLevels], nfeat[kMaxLevels];
   int selOff[kMaxLevels];      // first slot of the level inside a frame's selection region
   int selPerFrame;
-  uint32_t* idxA;              // [nframes][candCap] packed candidate word per position (ping)
-  uint32_t* idxB;              //                                                     (pong)
-  uint16_t* ownA;              // [nframes][candCap] owning node (= list position) per position
-  uint16_t* ownB;
-  uint32_t* rank;              // [nframes][candCap] exclusive quadrant scan value | quadrant << 30
-  QtNode* nodesA;              // [nframes][nlevels][kQtNodeCap] (used when the tables do not fit in LDS)
-  QtNode* nodesB;
+  uint16_t* own;               // [nframes][candCap] node id | quadrant << 14 per candidate
   SelKp* sel;                  // [nframes][selPerFrame]
   uint32_t* selCount;          // [nframes][kMaxLevels]
 };
