@@ -32,7 +32,7 @@
 namespace orbfe {
 
 constexpr int kQt3Threads = 512;
-constexpr int kQtEpt = 4;   // candidates per thread and sweep step (independent loads in flight)
+constexpr int kQtEpt = 8;   // candidates per thread and sweep step (independent loads in flight)
 
 struct Qt3Node {
   short x0, x1, y0, y1;    // UL.x, UR.x, UL.y, BL.y
@@ -221,29 +221,38 @@ __global__ __launch_bounds__(kQt3Threads) void k_quadtree3(QtParams Q) {
 
     // ---- candidate sweep: node id in the current list (through the previous pass's child table), quadrant inside
     //      a node that is divided in this pass, one count per candidate ----------------------------------------
-    for (int b = 0; b < n; b += kQtEpt * kQt3Threads) {
-      uint32_t v[kQtEpt];
-      unsigned ow[kQtEpt];
+    {
+      uint32_t vN[kQtEpt];
+      unsigned owN[kQtEpt];
+      auto loadStep = [&](int b) {   // the next step's candidates travel while the current step is processed
 #pragma unroll
-      for (int j = 0; j < kQtEpt; j++) {
-        const int p = b + j * kQt3Threads + tid;
-        v[j] = 0u;
-        ow[j] = 0u;
-        if (p < n) { ow[j] = own[p]; v[j] = cand[p]; }
-      }
+        for (int j = 0; j < kQtEpt; j++) {
+          const int p = min(b + j * kQt3Threads + tid, n - 1);   // clamped, not predicated: all loads of a step issue back to back
+          owN[j] = own[p];
+          vN[j] = cand[p];
+        }
+      };
+      loadStep(0);
+      for (int b = 0; b < n; b += kQtEpt * kQt3Threads) {
+        uint32_t v[kQtEpt];
+        unsigned ow[kQtEpt];
 #pragma unroll
-      for (int j = 0; j < kQtEpt; j++) {
-        const int p = b + j * kQt3Threads + tid;
-        if (p < n) {
-          const unsigned id = sh.cpos[ow[j] & 0x3fffu][ow[j] >> 14];
-          const uint32_t info = sh.ninfo[id];
-          unsigned q = 0;
-          if (info >> 24) {
-            const int x = (int)(v[j] & 0xfff) - kBorder, y = (int)((v[j] >> 12) & 0xfff) - kBorder;
-            q = (x < (int)(info & 0xfff) ? 0u : 1u) + (y < (int)((info >> 12) & 0xfff) ? 0u : 2u);
-            atomicAdd(&sh.cnt[id][q], 1u);
+        for (int j = 0; j < kQtEpt; j++) { v[j] = vN[j]; ow[j] = owN[j]; }
+        if (b + kQtEpt * kQt3Threads < n) loadStep(b + kQtEpt * kQt3Threads);
+#pragma unroll
+        for (int j = 0; j < kQtEpt; j++) {
+          const int p = b + j * kQt3Threads + tid;
+          if (p < n) {
+            const unsigned id = sh.cpos[ow[j] & 0x3fffu][ow[j] >> 14];
+            const uint32_t info = sh.ninfo[id];
+            unsigned q = 0;
+            if (info >> 24) {   // the node is divided in this pass: one count for the child the candidate falls into
+              const int x = (int)(v[j] & 0xfff) - kBorder, y = (int)((v[j] >> 12) & 0xfff) - kBorder;
+              q = (x < (int)(info & 0xfff) ? 0u : 1u) + (y < (int)((info >> 12) & 0xfff) ? 0u : 2u);
+              atomicAdd(&sh.cnt[id][q], 1u);
+            }
+            own[p] = (uint16_t)(id | (q << 14));
           }
-          own[p] = (uint16_t)(id | (q << 14));
         }
       }
     }
