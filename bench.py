@@ -57,6 +57,7 @@ def parse_args():
     ap.add_argument('--no-match', action='store_true', help='extract only (configs[1])')
     ap.add_argument('--no-pcie', action='store_true', help='skip the PCIe-inclusive leg')
     ap.add_argument('--no-verify', action='store_true', help='skip the digest check of the first steps')
+    ap.add_argument('--no-latency', action='store_true', help='skip the blocking single-frame latency leg (profiling runs: keeps every launch a full batch)')
     ap.add_argument('--host-input', nargs='?', const='pageable', default=None, choices=['pageable', 'pinned'],
                     help='headline leg from HOST frames instead (developer aid; never the contract value)')
     ap.add_argument('--depth', type=int, default=3, help='extraction batches in flight inside the stream runner')
@@ -285,7 +286,7 @@ def run_rank(args):
         # the call pattern of the reference's Tracking thread: one blocking ORBextractor::operator() per frame
         # (Frame.cc:133), frame already in HBM; median wall time of 60 calls on distinct frames, outside the timed region
         single = None
-        if world == 1:
+        if world == 1 and not args.no_latency:
             kbuf = np.zeros((1, ex.cap), api.KP_DTYPE)
             dbuf = np.zeros((1, ex.cap, 32), np.uint8)
             lat = []

@@ -33,8 +33,8 @@ names = ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_WAVES', 'SQ_INSTS_VALU', 'SQ_INSTS_SALU
 
 
 def steady(v):
-    v = sorted(v)                      # launches of B frames dominate; geometry / verification launches are smaller
-    v = v[len(v) // 2:]
+    top = max(v)                       # full-batch launches; the one-frame geometry launch is far smaller
+    v = [x for x in v if x >= 0.8 * top]
     return sum(v) / len(v)
 
 
