@@ -30,7 +30,7 @@
 #include "quadtree.h"
 
 namespace orbfe {
-void launch_pyramid(const PyramidParams& P, int nframes, hipStream_t st);
+int launch_pyramid(const PyramidParams& P, int nframes, hipStream_t st, const ConeParams* cone);
 void launch_to_gray(const uint8_t* const* raw, long long rawStride, const uint8_t* const* gray, long long grayPitch, int rows,
                     int cols, int channels, const int coef[3], int shift, bool aligned, int nframes, hipStream_t st);
 void launch_fast(const PyramidParams& P, int nframes, hipStream_t st);
@@ -211,6 +211,11 @@ struct orbfe_extractor {
   int rows = 0, cols = 0, batchCap = 0;
   PyramidParams P{};
   DevBuf<uint8_t> d_tables, d_slab, d_in;
+  DevBuf<ConeRange> d_coneTab;
+  ConeParams cone{};
+  bool coneOk = false;
+  int coneTile = 0;        // tile edge on the top level (0 = chosen from the level's size)
+  int coneMaxFrames = 2;   // batches up to this size build the pyramid with k_pyramid_cone
   DevBuf<CellInfo> d_cells;
   DevBuf<FastTask> d_tasks;
   bool pairCells = false;  // ORBFE_FAST_PAIRS=1: two adjacent cells per wave (7 % fewer vector instructions, but 10 % slower: DESIGN.md s5)
@@ -262,7 +267,7 @@ struct orbfe_extractor {
     (void)hipSetDevice(device);
     for (auto& st : streams) if (st) (void)hipStreamSynchronize(st);   // a batch may still be in flight
     d_bow.release(); h_bow.release();
-    d_tables.release(); d_slab.release(); d_in.release(); d_cellCount.release(); d_cellOff.release();
+    d_tables.release(); d_coneTab.release(); d_slab.release(); d_in.release(); d_cellCount.release(); d_cellOff.release();
     d_sfiOrder.release(); d_sfiOrderCount.release(); d_sfiPool.release(); d_sfiPcount.release();
     d_cells.release(); d_tasks.release(); d_slots.release(); d_cand.release(); d_frame0.release(); d_gray.release(); d_outArena.release(); h_outArena.release();
     d_f32tmp.release();
@@ -346,17 +351,21 @@ struct orbfe_extractor {
     int rc = d_tables.ensure(tableBytes);
     if (rc) return rc;
     size_t cur = 0;
+    const int* xofsH[kMaxLevels] = {};
+    const int* yofsH[kMaxLevels] = {};
     for (int l = 1; l < nlevels; l++) {
       LevelGeom& L = Q.lv[l];
       const int sw = Q.lv[l - 1].w, sh = Q.lv[l - 1].h, dw = L.w, dh = L.h;
       const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
       int* xofs = (int*)(tab.data() + cur);
+      xofsH[l] = xofs;
       L.xofs = (const int*)(d_tables.p + cur);
       cur += align_up(dw * 4, 16);
       short* xa = (short*)(tab.data() + cur);
       L.xalpha = (const short*)(d_tables.p + cur);
       cur += align_up(dw * 4, 16);
       int* yofs = (int*)(tab.data() + cur);
+      yofsH[l] = yofs;
       L.yofs = (const int*)(d_tables.p + cur);
       cur += align_up(dh * 4, 16);
       short* yb = (short*)(tab.data() + cur);
@@ -395,6 +404,64 @@ struct orbfe_extractor {
       L.rzRows = maxH;
     }
     HIP_TRY(hipMemcpyAsync(d_tables.p, tab.data(), tableBytes, hipMemcpyHostToDevice, stream));
+    // one-launch pyramid for small batches (k_pyramid_cone): per tile column / row of the top level, the range of every
+    // lower level it depends on; the cone starts at the lowest level whose regions still fit the LDS budget
+    coneOk = false;
+    std::vector<ConeRange> coneTab;
+    if (nlevels >= 3 && scaleFactor <= 1.5f) {
+      const int top = nlevels - 1;
+      // a block is bound by its own CU's issue rate: the smallest tile that still gives every block a CU of its own
+      int tile = coneTile;
+      if (tile <= 0) {
+        tile = 32;
+        for (int t = 16; t < 32; t += 4)
+          if (((Q.lv[top].w + t - 1) / t) * ((Q.lv[top].h + t - 1) / t) <= 256) { tile = t; break; }
+      }
+      const int tx = (Q.lv[top].w + tile - 1) / tile, ty = (Q.lv[top].h + tile - 1) / tile;
+      coneTab.assign((size_t)(tx + ty) * kMaxLevels, ConeRange{0, 0});
+      int maxW[kMaxLevels] = {}, maxH[kMaxLevels] = {};
+      for (int b = 0; b < tx + ty; b++) {
+        const bool isX = b < tx;
+        int lo = (isX ? b : b - tx) * tile, hi = std::min(lo + tile, isX ? Q.lv[top].w : Q.lv[top].h) - 1;
+        ConeRange* R = coneTab.data() + (size_t)b * kMaxLevels;
+        for (int l = top;; l--) {
+          R[l] = ConeRange{lo, hi};
+          int& m = isX ? maxW[l] : maxH[l];
+          m = std::max(m, hi - lo + 1);
+          if (l == 0) break;
+          const int dn = isX ? Q.lv[l].w : Q.lv[l].h, sn = isX ? Q.lv[l - 1].w : Q.lv[l - 1].h;
+          const int* ofs = isX ? xofsH[l] : yofsH[l];
+          const int nlo = lo == 0 ? 0 : std::min(std::max(ofs[lo], 0), sn - 1);
+          const int nhi = hi == dn - 1 ? sn - 1 : std::min(std::max(ofs[hi] + 1, 0), sn - 1);
+          lo = nlo; hi = nhi;
+        }
+      }
+      for (int base = 0; base < top - 1; base++) {
+        // regions are padded to dword columns on both sides (k_pyramid_cone)
+        auto pitchOf = [&](int l) { return (maxW[l] + 3 + 3) & ~3; };
+        auto area = [&](int l) { return (size_t)align_up(pitchOf(l) * maxH[l], 16); };
+        size_t hBytes = 0;
+        int coefLen = 0;
+        for (int l = base + 1; l <= top; l++) {
+          hBytes = std::max(hBytes, (size_t)align_up(maxH[l - 1] * pitchOf(l) * 2, 16));
+          coefLen = std::max(coefLen, std::max(pitchOf(l), maxH[l]));
+        }
+        const size_t coefBytes = (size_t)kMaxLevels * 2 * coefLen * sizeof(int2);
+        const size_t total = area(base) + area(base + 1) + hBytes + coefBytes;
+        if (total > 128 * 1024 || coefLen > 512) continue;
+        cone.base = base; cone.top = top; cone.tile = tile; cone.tilesX = tx; cone.tilesY = ty;
+        cone.offB = (int)area(base); cone.offH = cone.offB + (int)area(base + 1); cone.offC = cone.offH + (int)hBytes;
+        cone.coefLen = coefLen; cone.ldsBytes = (int)total;
+        coneOk = true;
+        break;
+      }
+      if (coneOk) {
+        if ((rc = d_coneTab.ensure(coneTab.size()))) return rc;
+        HIP_TRY(hipMemcpyAsync(d_coneTab.p, coneTab.data(), sizeof(ConeRange) * coneTab.size(), hipMemcpyHostToDevice, stream));
+        cone.regX = d_coneTab.p;
+        cone.regY = d_coneTab.p + (size_t)tx * kMaxLevels;
+      }
+    }
     // per-cell geometry (emit regions of ComputeKeyPointsOctTree's cell grid, ORBextractor.cc:826-844)
     std::vector<CellInfo> cells(Q.ncells);
     for (int l = 0; l < nlevels; l++) {
@@ -593,7 +660,7 @@ struct orbfe_extractor {
     return waitGpuQt(kps, desc, cap, n_out);
   }
 
-  bool submitProfiled = false;
+  bool submitProfiled = false, fastTimed = false;
   std::vector<const uint8_t*> devAt;   // device address of every uploaded host frame (uploadFrames)
   int pendingFrames = 0;   // frames of the submitted, not yet collected batch (0 = none)
   double tSubmit0 = 0, tSubmit1 = 0;
@@ -661,15 +728,19 @@ struct orbfe_extractor {
         if (w && w != evFront && w != evPyr) HIP_TRY(hipStreamWaitEvent(st, w, 0));
       }
       if (prof) HIP_TRY(hipEventRecord(ev[0][0], st));
-      launch_pyramid(P, nframes, st);
+      if (launch_pyramid(P, nframes, st, coneOk && nframes <= coneMaxFrames ? &cone : nullptr)) { set_err("cannot configure the pyramid kernel"); return ORBFE_ERR_HIP; }
       if (fl && frontSplit) {
         HIP_TRY(hipEventRecord(evPyr, st));
         fl->lastPyr = evPyr;
         if (fl->last && fl->last != evFront) HIP_TRY(hipStreamWaitEvent(st, fl->last, 0));
       }
-      HIP_TRY(hipEventRecord(ev[0][1], st));   // the dominant kernel is always timed (bench.py roofline)
+      // the dominant kernel is timed in every batch (bench.py roofline); a latency-bound one- or two-frame call does
+      // without the two markers (each costs a few microseconds of dependent-launch gap) unless profiling is on
+      const bool timeFast = prof || nframes > coneMaxFrames;
+      fastTimed = timeFast;
+      if (timeFast) HIP_TRY(hipEventRecord(ev[0][1], st));
       launch_fast(P, nframes, st);
-      HIP_TRY(hipEventRecord(ev[0][2], st));
+      if (timeFast) HIP_TRY(hipEventRecord(ev[0][2], st));
       launch_compact(P, nframes, st);
       if (prof) HIP_TRY(hipEventRecord(ev[0][3], st));
       if (fl) {
@@ -686,15 +757,16 @@ struct orbfe_extractor {
     // k_quadtree is latency-bound (dependent scans, one block per (frame, level)) and leaves most issue
     // slots idle, so it runs on its own high-priority stream: with two batches in flight it overlaps the
     // other batch's VALU-bound kernels instead of queueing behind them.
-    hipStream_t qs = qtOwnStream ? qtStream : st;
-    if (qtOwnStream) {
+    const bool ownQs = qtOwnStream && nframes > coneMaxFrames;   // nothing to overlap with in a single-frame call
+    hipStream_t qs = ownQs ? qtStream : st;
+    if (ownQs) {
       HIP_TRY(hipEventRecord(evQtIn, st));
       HIP_TRY(hipStreamWaitEvent(qs, evQtIn, 0));
     }
     if (prof) HIP_TRY(hipEventRecord(evQt[0], qs));
     launch_quadtree(QP, nframes, qs);
     if (prof) HIP_TRY(hipEventRecord(evQt[1], qs));
-    if (qtOwnStream) {
+    if (ownQs) {
       HIP_TRY(hipEventRecord(evQtOut, qs));
       HIP_TRY(hipStreamWaitEvent(st, evQtOut, 0));
     }
@@ -763,15 +835,17 @@ struct orbfe_extractor {
     const double t2 = now_ms();
     {
       float ms = 0;
-      if (hipEventElapsedTime(&ms, ev[0][1], ev[0][2]) == hipSuccess) kernMs[1] += ms;
+      if (fastTimed && hipEventElapsedTime(&ms, ev[0][1], ev[0][2]) == hipSuccess) kernMs[1] += ms;
       if (submitProfiled) {
         if (hipEventElapsedTime(&ms, ev[0][0], ev[0][1]) == hipSuccess) kernMs[0] += ms;
         if (hipEventElapsedTime(&ms, ev[0][2], ev[0][3]) == hipSuccess) kernMs[2] += ms;
         if (hipEventElapsedTime(&ms, ev[0][4], ev[0][5]) == hipSuccess) kernMs[3] += ms;
         if (hipEventElapsedTime(&ms, evQt[0], evQt[1]) == hipSuccess) kernMs[4] += ms;
       }
-      kernBatches++;
-      kernFrames += nframes;
+      if (fastTimed) {
+        kernBatches++;
+        kernFrames += nframes;
+      }
     }
     int status = ORBFE_OK;
     if (pendingBow) bowKp.resize(nframes);
@@ -876,7 +950,7 @@ struct orbfe_extractor {
       PyramidParams Q = P;
       Q.frameBase = f0;
       HIP_TRY(hipEventRecord(ev[s][0], st));
-      launch_pyramid(Q, nf, st);
+      if (launch_pyramid(Q, nf, st, coneOk && nf <= coneMaxFrames ? &cone : nullptr)) { set_err("cannot configure the pyramid kernel"); return ORBFE_ERR_HIP; }
       HIP_TRY(hipEventRecord(ev[s][1], st));
       launch_fast(Q, nf, st);
       HIP_TRY(hipEventRecord(ev[s][2], st));
@@ -1242,6 +1316,8 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
   }
   if (const char* hv = getenv("ORBFE_HOST_QUADTREE")) h->gpuQuadtree = atoi(hv) == 0;
   if (const char* pv = getenv("ORBFE_FAST_PAIRS")) h->pairCells = atoi(pv) != 0;
+  if (const char* cv = getenv("ORBFE_CONE_MAX_FRAMES")) h->coneMaxFrames = atoi(cv);
+  if (const char* cv = getenv("ORBFE_CONE_TILE")) h->coneTile = atoi(cv) <= 0 ? 0 : std::max(8, atoi(cv)) & ~3;
   if (const char* pv = getenv("ORBFE_PROFILE_KERNELS")) h->profileKernels = atoi(pv) != 0;
   h->selPerFrame = 0;
   for (int l = 0; l < nlevels; l++) {

@@ -73,6 +73,18 @@ struct PyramidParams {
   int frameBase;                    // first frame of this launch (sub-batch pipelining)
 };
 
+// Small batches build the pyramid in ONE launch (k_pyramid_cone): a block owns a tile of the top level and computes
+// the part of every level below it that the tile depends on.  Host-computed per tile column / tile row.
+struct ConeRange { int lo, hi; };   // inclusive
+struct ConeParams {
+  int base, top;                    // the cone starts from level `base` (already in memory) and produces base+1 .. top
+  int tile, tilesX, tilesY;         // tile edge on level `top`, tiles per row / column
+  int offB, offH, offC, coefLen;    // LDS byte offsets: second region buffer, row-pass intermediate, coefficient slices
+  int ldsBytes;
+  const ConeRange* regX;            // [tilesX][kMaxLevels] columns of level l a tile column needs
+  const ConeRange* regY;            // [tilesY][kMaxLevels]
+};
+
 // One selected keypoint handed to the orientation + descriptor kernel.
 struct SelKp {
   uint32_t xy;     // x | y << 16 (level coordinates)

@@ -146,6 +146,205 @@ __global__ __launch_bounds__(256) void k_resize(PyramidParams P, int level) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pyramid for small batches: all levels in one launch.  Seven dependent k_resize launches cost 6-9 us each for a
+// single frame whatever the level's size; here one block owns a 32x32 tile of the TOP level and walks down the
+// dependency cone: the region of level l-1 that region [x0..x1]x[y0..y1] of level l reads is
+// [xofs[x0] .. xofs[x1]+1] x [yofs[y0] .. yofs[y1]+1] (extended to the level's edge at the image border, so that the
+// union of all blocks' regions is the whole level).  The block stages its region of the base level in LDS and
+// produces its region of every higher level from the previous one in LDS, writing each to the pyramid slab as it
+// goes.  Regions of neighbouring blocks overlap by the interpolation halo, so about 1.5x the pixels of a level are
+// computed (identical values, benign duplicate stores) -- irrelevant at batch size 1-2, where the chip is idle;
+// larger batches keep the per-level kernels.  Arithmetic identical to k_resize (same tables, same two passes).
+// ------------------------------------------------------------------------------------------------
+constexpr int kConeThreads = 1024;
+
+__global__ __launch_bounds__(kConeThreads) void k_pyramid_cone(PyramidParams P, ConeParams C) {
+  extern __shared__ __align__(16) uint8_t cone[];
+  const int tid = threadIdx.x, f = P.frameBase + blockIdx.z;
+  // the block's ranges on every level: two 64-byte scalar loads, then registers (the level loops are fully unrolled)
+  ConeRange rx[kMaxLevels], ry[kMaxLevels];
+#pragma unroll
+  for (int l = 0; l < kMaxLevels; l++) {
+    rx[l] = C.regX[blockIdx.x * kMaxLevels + l];
+    ry[l] = C.regY[blockIdx.y * kMaxLevels + l];
+  }
+  uint8_t* A = cone;
+  uint8_t* B = cone + C.offB;
+  uint16_t* H = reinterpret_cast<uint16_t*>(cone + C.offH);
+  int2* coef = reinterpret_cast<int2*>(cone + C.offC);   // [level][x: coefLen | y: coefLen]
+  // A region in LDS starts `pad` columns left of the region's first column, so that LDS column j and the global
+  // byte it mirrors have the same alignment: rows are moved as whole dwords in both directions.
+  ConeRange bx = rx[0], by = ry[0];
+#pragma unroll
+  for (int l = 1; l < kMaxLevels; l++)
+    if (l == C.base) { bx = rx[l]; by = ry[l]; }
+  const uint8_t* src;
+  int sstride;
+  if (C.base == 0) {
+    src = P.frame0[f];
+    sstride = (int)P.stride0;
+  } else {
+    src = P.slab + (long long)f * P.slabBytes + P.lv[C.base].off;
+    sstride = P.lv[C.base].pitch;
+  }
+  src += (long long)by.lo * sstride + bx.lo;
+  const bool dwordRows = (sstride & 3) == 0;
+  int padA = dwordRows ? (int)(reinterpret_cast<uintptr_t>(src) & 3) : 0;
+  int pitchA = (padA + (bx.hi - bx.lo + 1) + 3) & ~3;
+  // ---- every global read of the block is issued here, before the first wait: the coefficient slices of all levels
+  //      (thread t < 512: column t of every level, thread 512 + t: row t) and the base region ----
+  {
+    int cofs[kMaxLevels], cwgt[kMaxLevels];
+#pragma unroll
+    for (int l = 1; l < kMaxLevels; l++) {
+      cofs[l] = 0; cwgt[l] = 0;
+      if (l <= C.base || l > C.top) continue;
+      const LevelGeom& D = P.lv[l];
+      const int pad = rx[l].lo & 3;
+      if (tid < 512) {
+        const int c = tid - pad;
+        if (c >= 0 && c <= rx[l].hi - rx[l].lo) {
+          cofs[l] = D.xofs[rx[l].lo + c];
+          cwgt[l] = reinterpret_cast<const int*>(D.xalpha)[rx[l].lo + c];
+        }
+      } else if (tid - 512 <= ry[l].hi - ry[l].lo) {
+        cofs[l] = D.yofs[ry[l].lo + tid - 512];
+        cwgt[l] = reinterpret_cast<const int*>(D.ybeta)[ry[l].lo + tid - 512];
+      }
+    }
+    const int w = bx.hi - bx.lo + 1, h = by.hi - by.lo + 1;
+    if (dwordRows) {
+      const int ndw = pitchA >> 2;
+      const int cw = ndw <= 32 ? 32 : ndw <= 64 ? 64 : 128;
+      const int c = tid & (cw - 1), rstep = kConeThreads / cw;
+      if (c < ndw) {
+        const uint8_t* g = src - padA + 4 * c;
+        for (int r = tid / cw; r < h; r += 4 * rstep) {
+          uint32_t v[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) v[u] = r + u * rstep < h ? *reinterpret_cast<const uint32_t*>(g + m24(r + u * rstep, sstride)) : 0u;
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (r + u * rstep < h) reinterpret_cast<uint32_t*>(A)[m24(r + u * rstep, ndw) + c] = v[u];
+        }
+      }
+    } else {
+      const float rcp = 1.0f / (float)w;
+      const int total = m24(w, h);
+      for (int i = tid; i < total; i += kConeThreads) {
+        const int r = (int)(((float)i + 0.5f) * rcp), c = i - m24(r, w);
+        A[m24(r, pitchA) + c] = src[m24(r, sstride) + c];
+      }
+    }
+    int prevPad = padA;
+#pragma unroll
+    for (int l = 1; l < kMaxLevels; l++) {
+      if (l <= C.base || l > C.top) continue;
+      const LevelGeom& S = P.lv[l - 1];
+      const int dw = rx[l].hi - rx[l].lo + 1, dh = ry[l].hi - ry[l].lo + 1, pad = rx[l].lo & 3, pitch = (pad + dw + 3) & ~3;
+      int2* cx = coef + (l * 2) * C.coefLen;
+      int2* cy = cx + C.coefLen;
+      if (tid < pitch) {
+        int2 v = make_int2(0, 0);   // padding columns read offset 0 with weight 0
+        const int c = tid - pad;
+        if (c >= 0 && c < dw) {
+          const int x = cofs[l];
+          v.x = (x - rx[l - 1].lo + prevPad) | ((min(x + 1, S.w - 1) - rx[l - 1].lo + prevPad) << 16);   // a1 == 0 whenever x + 1 is out of range
+          v.y = cwgt[l];
+        }
+        cx[tid] = v;
+      } else if (tid >= 512 && tid - 512 < dh) {
+        const int y = cofs[l];
+        cy[tid - 512] = make_int2((min(max(y, 0), S.h - 1) - ry[l - 1].lo) | ((min(max(y + 1, 0), S.h - 1) - ry[l - 1].lo) << 16), cwgt[l]);
+      }
+      prevPad = pad;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int l = 1; l < kMaxLevels; l++) {
+    if (l <= C.base || l > C.top) continue;
+    const LevelGeom& D = P.lv[l];
+    const ConeRange sy = ry[l - 1], dx = rx[l], dy = ry[l];
+    const int sh = sy.hi - sy.lo + 1, dw = dx.hi - dx.lo + 1, dh = dy.hi - dy.lo + 1;
+    const int pad = dx.lo & 3, pitch = (pad + dw + 3) & ~3;
+    const int2* cx = coef + (l * 2) * C.coefLen;
+    const int2* cy = cx + C.coefLen;
+    // ---- row pass: thread = one (padded) output column, its coefficients in registers, a subset of the rows ----
+    {
+      const int cw = pitch <= 32 ? 32 : pitch <= 64 ? 64 : pitch <= 128 ? 128 : pitch <= 256 ? 256 : 512;
+      const int j = tid & (cw - 1), r0 = tid / cw, rstep = kConeThreads / cw;
+      if (j < pitch) {
+        const int2 k = cx[j];
+        const int a0 = (short)k.y, a1 = k.y >> 16;
+        const uint8_t* p0 = A + (k.x & 0xffff);
+        const uint8_t* p1 = A + (k.x >> 16);
+        uint16_t* h = H + j;
+        for (int r = r0; r < sh; r += 4 * rstep) {   // 4 rows in flight: the LDS reads of a batch precede its writes
+          int v0[4], v1[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int rr = min(r + u * rstep, sh - 1);
+            v0[u] = p0[m24(rr, pitchA)];
+            v1[u] = p1[m24(rr, pitchA)];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (r + u * rstep < sh) h[m24(r + u * rstep, pitch)] = (uint16_t)((m24(v0[u], a0) + m24(v1[u], a1)) >> 4);
+        }
+      }
+    }
+    __syncthreads();
+    // ---- column pass: thread = 4 columns, a subset of the rows; dword stores to the next region buffer and the slab ----
+    {
+      uint8_t* dst = P.slab + (long long)f * P.slabBytes + D.off + (long long)dy.lo * D.pitch + (dx.lo - pad);
+      const int ng = pitch >> 2;
+      const int gw = ng <= 8 ? 8 : ng <= 16 ? 16 : ng <= 32 ? 32 : ng <= 64 ? 64 : 128;
+      const int j = (tid & (gw - 1)) * 4, y0 = tid / gw, ystep = kConeThreads / gw;
+      if (j < pitch) {
+        const bool whole = j >= pad && j + 3 < pad + dw;
+        for (int yb = y0; yb < dh; yb += 2 * ystep) {
+          int2 k[2];
+          uint2 q0[2], q1[2];
+#pragma unroll
+          for (int u = 0; u < 2; u++) k[u] = cy[min(yb + u * ystep, dh - 1)];
+#pragma unroll
+          for (int u = 0; u < 2; u++) {
+            q0[u] = *reinterpret_cast<const uint2*>(H + m24(k[u].x & 0xffff, pitch) + j);
+            q1[u] = *reinterpret_cast<const uint2*>(H + m24(k[u].x >> 16, pitch) + j);
+          }
+#pragma unroll
+          for (int u = 0; u < 2; u++) {
+            const int y = yb + u * ystep;
+            if (y >= dh) break;
+            const unsigned b0 = (unsigned)(int)(short)k[u].y, b1 = (unsigned)(k[u].y >> 16);
+            const unsigned h0[4] = {q0[u].x & 0xffffu, q0[u].x >> 16, q0[u].y & 0xffffu, q0[u].y >> 16};
+            const unsigned h1[4] = {q1[u].x & 0xffffu, q1[u].x >> 16, q1[u].y & 0xffffu, q1[u].y >> 16};
+            uint32_t packed = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+              packed |= (((mulu24(b0, h0[e]) >> 16) + (mulu24(b1, h1[e]) >> 16) + 2) >> 2) << (8 * e);
+            *reinterpret_cast<uint32_t*>(B + m24(y, pitch) + j) = packed;
+            uint8_t* g = dst + m24(y, D.pitch) + j;
+            if (whole) {
+              *reinterpret_cast<uint32_t*>(g) = packed;
+            } else {   // first / last group of the region: the neighbouring block owns the other columns
+#pragma unroll
+              for (int e = 0; e < 4; e++)
+                if (j + e >= pad && j + e < pad + dw) g[e] = (uint8_t)(packed >> (8 * e));
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    uint8_t* t = A; A = B; B = t;
+    padA = pad;
+    pitchA = pitch;
+  }
+}
+
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2 as_u16x2(unsigned v) { return __builtin_bit_cast(u16x2, v); }
@@ -559,12 +758,27 @@ void launch_to_gray(const uint8_t* const* raw, long long rawStride, const uint8_
 // ------------------------------------------------------------------------------------------------
 // Launchers (called by the host engine).
 // ------------------------------------------------------------------------------------------------
-void launch_pyramid(const PyramidParams& P, int nframes, hipStream_t st) {
-  for (int l = 1; l < P.nlevels; l++) {
+int launch_pyramid(const PyramidParams& P, int nframes, hipStream_t st, const ConeParams* cone) {
+  const int last = cone ? cone->base : P.nlevels - 1;   // levels built one launch each
+  if (cone) {
+    static int attrBytes[64] = {};   // per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1;
+    if (cone->ldsBytes > attrBytes[dev]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyramid_cone), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              cone->ldsBytes) != hipSuccess)
+        return 1;
+      attrBytes[dev] = cone->ldsBytes;
+    }
+  }
+  for (int l = 1; l <= last; l++) {
     dim3 grid((P.lv[l].w + kRzTile - 1) / kRzTile, (P.lv[l].h + kRzTile - 1) / kRzTile, nframes);
     hipLaunchKernelGGL(k_resize, grid, dim3(256), (((size_t)P.lv[l].rzPitch * P.lv[l].rzRows + 15) & ~(size_t)15) + (size_t)P.lv[l].rzRows * 64 * 2, st,
                        P, l);
   }
+  if (cone)
+    hipLaunchKernelGGL(k_pyramid_cone, dim3(cone->tilesX, cone->tilesY, nframes), dim3(kConeThreads), cone->ldsBytes, st, P, *cone);
+  return 0;
 }
 
 void launch_compact(const PyramidParams& P, int nframes, hipStream_t st) {

@@ -14,10 +14,11 @@
 //   k_sfi_sort        per frame (as F2): grid cell of every level-0 keypoint (PosInGrid, round()), stable rank
 //                     by (cell, index)  == the order GetFeaturesInArea enumerates candidates in
 //   k_sfi_candidates  one wave per (pair, query): scan F2 in that order, box test, Hamming -> ordered list
-//   k_sfi_resolve     one wave per pair: the reference's sequential bookkeeping (vMatchedDistance, vnMatches21,
-//                     steal-back, rotation histogram, ComputeThreeMaxima) replayed in order; each step's
-//                     best / second-best is a wave reduction over the query's candidate list
+//   k_sfi_resolve     one block per pair: the reference's sequential bookkeeping (vMatchedDistance, vnMatches21,
+//                     steal-back, rotation histogram, ComputeThreeMaxima) as a fixed point -- see the kernel
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 
 #include "orbfe_internal.h"
 
@@ -50,36 +51,61 @@ __device__ __forceinline__ SfiFrame sfi_frame(const SfiParams& S, int f) {
 
 // ---- per frame: candidate enumeration order -------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_sfi_sort(SfiParams S) {
-  extern __shared__ int cellOf[];   // [n0cap]
+  // counting sort by grid cell; inside a cell by keypoint index (the order mGrid's vectors were filled in)
+  constexpr int kCells = kSfiGridCols * kSfiGridRows, kPer = kCells / 256;
+  static_assert(kCells % 256 == 0, "cells per thread");
+  extern __shared__ int dyn[];
+  int* cellOf = dyn;                 // [n0cap]
+  int* arrival = dyn + S.n0cap;      // [n0cap] position among the keypoints of the same cell, in arrival order
+  int* bucket = dyn + 2 * S.n0cap;   // [n0cap] keypoints grouped by cell
+  __shared__ int start[kCells + 1];
+  __shared__ int wsum[4];
   const int f = S.frameBase + blockIdx.x, tid = threadIdx.x;
   const SfiFrame F = sfi_frame(S, f);
+  for (int c = tid; c <= kCells; c += 256) start[c] = 0;
+  __syncthreads();
   for (int k = tid; k < F.n; k += 256) {
     const uint32_t xy = F.sel[k].xy;
     const float x = (float)(xy & 0xffff), y = (float)(xy >> 16);
     const int px = (int)roundf((x - S.minX) * S.invW), py = (int)roundf((y - S.minY) * S.invH);   // Frame.cc:266-267
-    cellOf[k] = (px < 0 || px >= kSfiGridCols || py < 0 || py >= kSfiGridRows) ? -1 : px * kSfiGridRows + py;
+    const int c = (px < 0 || px >= kSfiGridCols || py < 0 || py >= kSfiGridRows) ? -1 : px * kSfiGridRows + py;
+    cellOf[k] = c;
+    if (c >= 0) arrival[k] = atomicAdd(&start[c], 1);
+  }
+  __syncthreads();
+  // exclusive prefix over the cells: kPer consecutive cells per thread, then a block scan of the thread sums
+  int loc[kPer], sum = 0;
+#pragma unroll
+  for (int i = 0; i < kPer; i++) { loc[i] = start[tid * kPer + i]; sum += loc[i]; }
+  int incl = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if ((tid & 63) >= o) incl += t;
+  }
+  if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+  __syncthreads();
+  int base = incl - sum;
+  for (int w = 0; w < (tid >> 6); w++) base += wsum[w];
+#pragma unroll
+  for (int i = 0; i < kPer; i++) { start[tid * kPer + i] = base; base += loc[i]; }
+  if (tid == 255) start[kCells] = base;
+  __syncthreads();
+  for (int k = tid; k < F.n; k += 256) {
+    const int c = cellOf[k];
+    if (c >= 0) bucket[start[c] + arrival[k]] = k;
   }
   __syncthreads();
   uint16_t* order = S.order + (long long)f * S.n0cap;
-  int nin = 0;
   for (int k = tid; k < F.n; k += 256) {
     const int c = cellOf[k];
     if (c < 0) continue;
+    const int b0 = start[c], b1 = start[c + 1];
     int rank = 0;
-    for (int j = 0; j < F.n; j++) {
-      const int cj = cellOf[j];
-      rank += (cj >= 0 && (cj < c || (cj == c && j < k))) ? 1 : 0;
-    }
-    order[rank] = (uint16_t)k;
+    for (int j = b0; j < b1; j++) rank += bucket[j] < k;
+    order[b0 + rank] = (uint16_t)k;
   }
-  for (int k = tid; k < F.n; k += 256) nin += cellOf[k] >= 0;
-  // block sum of nin
-  __shared__ int tot;
-  if (tid == 0) tot = 0;
-  __syncthreads();
-  atomicAdd(&tot, nin);
-  __syncthreads();
-  if (tid == 0) S.orderCount[f] = tot;
+  if (tid == 0) S.orderCount[f] = start[kCells];
 }
 
 // ---- per (pair, query): ordered candidate list with distances -------------------------------------------------
@@ -137,7 +163,7 @@ __device__ __forceinline__ int sfi_rot_bin(float a1, float a2) {   // ORBmatcher
   return bin;
 }
 
-__global__ __launch_bounds__(64) void k_sfi_resolve(SfiParams S) {
+__global__ __launch_bounds__(64) void k_sfi_resolve_seq(SfiParams S) {
   extern __shared__ int sm[];
   const int fr = blockIdx.x, lane = threadIdx.x;
   const int f = S.frameBase + fr;
@@ -261,6 +287,163 @@ __global__ __launch_bounds__(64) void k_sfi_resolve(SfiParams S) {
   (void)n2;
 }
 
+// The same bookkeeping without the serial walk.  Query i1's outcome (its accepted match, or none) is a function of
+// its own candidate list and of vMatchedDistance at the moment the reference reaches i1, and vMatchedDistance[i2] at
+// that moment is the smallest distance among the matches accepted for i2 by queries j < i1 (:439, :455-466: every
+// accepted match lowers it).  So the vector of outcomes M satisfies M[i1] = g(i1, {M[j] : j < i1}); that recurrence
+// has exactly one solution (induction over i1) and the reference's loop computes it.  The kernel iterates
+// M <- g(M) from "no matches" with one thread per query until nothing changes: round k fixes at least queries
+// 0..k-1, in practice the dependency chains (a match taken away from a later query whose second choice then takes a
+// keypoint from a still later one ...) are a handful long.  Afterwards vnMatches12[j] survives iff j is the last
+// query that took its keypoint (steal-back, :457-461) and the rotation histogram holds every accepted match, stolen
+// or not (:468-478 push without ever removing).
+constexpr int kSfiThreads = 512;
+
+__global__ __launch_bounds__(kSfiThreads) void k_sfi_resolve(SfiParams S, int ldsPool) {
+  extern __shared__ int sm[];
+  const int fr = blockIdx.x, tid = threadIdx.x;
+  const int f = S.frameBase + fr;
+  const SfiFrame F2 = sfi_frame(S, f);
+  const SfiFrame F1 = sfi_frame(S, fr == 0 ? -1 : f - 1);
+  int32_t* out = S.matches12 + (long long)f * S.n0cap;
+  if (F1.n < 0) {   // no predecessor: first frame of the stream
+    for (int i = tid; i < S.n0cap; i += kSfiThreads) out[i] = -1;
+    if (tid == 0) S.nmatches[f] = 0;
+    return;
+  }
+  const int n1 = F1.n, n2 = F2.n, cap = S.n0cap;
+  int* Mbuf[2] = {sm, sm + cap};         // outcome of a query: i2 | dist << 16, -1 = none
+  int* head = sm + 2 * cap;              // [cap] per F2 keypoint: first query of its list of takers
+  int* next = sm + 3 * cap;              // [cap] per query: next taker of the same keypoint
+  int* off = sm + 4 * cap;               // [cap + 1] start of a query's candidates in the compacted pool
+  int* pcnt = sm + 5 * cap + 1;          // [cap]
+  int* hist = sm + 6 * cap + 1;          // [32]
+  int* misc = hist + 32;                 // [2] nmatches, unused
+  uint32_t* lpool = reinterpret_cast<uint32_t*>(misc + 2);   // [ldsPool]
+  for (int i = tid; i < cap; i += kSfiThreads) {
+    Mbuf[0][i] = -1;
+    pcnt[i] = i < n1 ? (int)S.pcount[(long long)f * cap + i] : 0;
+  }
+  if (tid < 32) hist[tid] = 0;
+  if (tid == 32) misc[0] = 0;
+  __syncthreads();
+  if (tid < 64) {   // exclusive prefix of the candidate counts
+    int run = 0;
+    for (int b = 0; b < cap; b += 64) {
+      const int v = b + tid < cap ? pcnt[b + tid] : 0;
+      int s = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(s, o, 64);
+        if (tid >= o) s += t;
+      }
+      if (b + tid < cap) off[b + tid] = run + s - v;
+      run += __shfl(s, 63, 64);
+    }
+    if (tid == 0) off[cap] = run;
+  }
+  __syncthreads();
+  const uint32_t* gpool = S.pool + (long long)f * cap * cap;
+  const int total = off[cap];
+  const bool inLds = total <= ldsPool;
+  if (inLds) {
+    for (int e = tid; e < total; e += kSfiThreads) {
+      int lo = 0, hi = n1 - 1;   // last query whose offset is <= e
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (off[mid] <= e) lo = mid; else hi = mid - 1;
+      }
+      lpool[e] = gpool[(long long)lo * cap + (e - off[lo])];
+    }
+  }
+  __syncthreads();
+  int cur = 0;
+  for (;;) {
+    const int* M = Mbuf[cur];
+    int* Mn = Mbuf[cur ^ 1];
+    for (int i = tid; i < n2; i += kSfiThreads) head[i] = -1;
+    __syncthreads();
+    for (int j = tid; j < n1; j += kSfiThreads) {
+      const int m = M[j];
+      if (m >= 0) next[j] = atomicExch(&head[m & 0xffff], j);
+    }
+    __syncthreads();
+    int changed = 0;
+    for (int i1 = tid; i1 < n1; i1 += kSfiThreads) {
+      const int cnt = pcnt[i1];
+      int bestDist = 0x7fffffff, bestDist2 = 0x7fffffff, bestIdx2 = -1;
+      for (int c = 0; c < cnt; c++) {
+        const uint32_t entry = inLds ? lpool[off[i1] + c] : gpool[(long long)i1 * cap + c];
+        const int i2 = (int)(entry & 0xffff), dist = (int)(entry >> 16);
+        int vmd = 0x7fffffff;   // vMatchedDistance[i2] as the reference sees it when it reaches i1
+        for (int j = head[i2]; j >= 0; j = next[j])
+          if (j < i1) vmd = min(vmd, M[j] >> 16);
+        if (vmd <= dist) continue;                                           // :439
+        if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }   // :441-450
+        else if (dist < bestDist2) bestDist2 = dist;
+      }
+      int m = -1;
+      if (bestDist <= kSfiThLow && (float)bestDist < (float)bestDist2 * S.nnratio) m = bestIdx2 | (bestDist << 16);
+      Mn[i1] = m;
+      changed |= m != M[i1];
+    }
+    const int any = __syncthreads_or(changed);
+    cur ^= 1;
+    if (!any) break;
+  }
+  // the lists were built from the outcomes that just reproduced themselves
+  const int* M = Mbuf[cur];
+  int* vn12 = Mbuf[cur ^ 1];
+  int* binOf = off;   // offsets are no longer needed (cap + 1 >= n1)
+  __syncthreads();
+  for (int j = tid; j < n1; j += kSfiThreads) {
+    const int m = M[j];
+    int v = -1, bin = -1;
+    if (m >= 0) {
+      const int i2 = m & 0xffff;
+      bool last = true;
+      for (int k = head[i2]; k >= 0; k = next[k]) last = last && k <= j;
+      if (last) v = i2;
+      if (S.checkOri) {
+        bin = sfi_rot_bin(F1.angle[j], F2.angle[i2]);
+        atomicAdd(&hist[bin], 1);
+      }
+    }
+    vn12[j] = v;
+    binOf[j] = bin;
+  }
+  __syncthreads();
+  int ind1 = -1, ind2 = -1, ind3 = -1;
+  if (S.checkOri) {
+    // ComputeThreeMaxima, ORBmatcher.cc:1554-1595 (every thread evaluates it identically)
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < kSfiHisto; i++) {
+      const int s = hist[i];
+      if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+      else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+      else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+  }
+  int nm = 0;
+  for (int i = tid; i < cap; i += kSfiThreads) {
+    int v = -1;
+    if (i < n1) {
+      v = vn12[i];
+      const int b = binOf[i];
+      if (S.checkOri && b >= 0 && b != ind1 && b != ind2 && b != ind3) v = -1;
+    }
+    out[i] = v;
+    nm += v >= 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nm += __shfl_xor(nm, o, 64);
+  if ((tid & 63) == 0 && nm) atomicAdd(&misc[0], nm);
+  __syncthreads();
+  if (tid == 0) S.nmatches[f] = misc[0];
+}
+
 // Hand the level-0 data of the batch's last frame to the next batch (one small kernel instead of four D2D copies).
 __global__ __launch_bounds__(256) void k_sfi_carry(SfiParams S, int lastFrame, SelKp* cSel, float* cAngle, uint8_t* cDesc,
                                                    uint32_t* cCount) {
@@ -281,9 +464,18 @@ void launch_sfi_carry(const SfiParams& S, int lastFrame, SelKp* cSel, float* cAn
 }
 
 void launch_sfi(const SfiParams& S, int nframes, hipStream_t st) {
-  hipLaunchKernelGGL(k_sfi_sort, dim3(nframes), dim3(256), sizeof(int) * S.n0cap, st, S);
+  hipLaunchKernelGGL(k_sfi_sort, dim3(nframes), dim3(256), sizeof(int) * 3 * S.n0cap, st, S);
   hipLaunchKernelGGL(k_sfi_candidates, dim3(S.n0cap, nframes), dim3(64), 0, st, S);
-  hipLaunchKernelGGL(k_sfi_resolve, dim3(nframes), dim3(64), sizeof(int) * (5 * S.n0cap + 32), st, S);
+  static const bool seq = getenv("ORBFE_SFI_SEQUENTIAL") != nullptr;   // the serial replay, kept for A/B runs
+  if (seq) {
+    hipLaunchKernelGGL(k_sfi_resolve_seq, dim3(nframes), dim3(64), sizeof(int) * (5 * S.n0cap + 32), st, S);
+    return;
+  }
+  const int fixedWords = 6 * S.n0cap + 1 + 32 + 2;
+  int ldsPool = (60 * 1024 / 4) - fixedWords;   // candidate entries kept in LDS; longer pools are read from HBM
+  if (ldsPool > 8192) ldsPool = 8192;
+  if (ldsPool < 0) ldsPool = 0;
+  hipLaunchKernelGGL(k_sfi_resolve, dim3(nframes), dim3(kSfiThreads), sizeof(int) * (fixedWords + ldsPool), st, S, ldsPool);
 }
 
 }  // namespace orbfe

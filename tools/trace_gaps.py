@@ -9,7 +9,8 @@ rows.sort()
 # last complete extract: find the last k_describe and walk back to the preceding k_resize run
 end = max(i for i, r in enumerate(rows) if r[2].startswith('k_describe'))
 start = end
-while start > 0 and not (rows[start][2].startswith('k_resize') and not rows[start - 1][2].startswith('k_resize')):
+pyr = lambda n: n.startswith('k_resize') or n.startswith('k_pyramid_cone')
+while start > 0 and not (pyr(rows[start][2]) and not pyr(rows[start - 1][2])):
     start -= 1
 prev_end = None
 tot_k = tot_g = 0
