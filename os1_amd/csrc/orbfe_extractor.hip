@@ -40,7 +40,7 @@ void launch_describe(const PyramidParams& P, const SelKp* sel, int nsel, float* 
 void launch_sincos(const float* deg, int n, float* c, float* s, hipStream_t st);
 void launch_describe_slots(const PyramidParams& P, const SelKp* sel, int nslots, float* angle, uint8_t* desc,
                            const uint32_t* selCount, int selPerFrame, const int* selOff, hipStream_t st);
-void launch_quadtree(const QtParams& Q, int nframes, hipStream_t st);
+int launch_quadtree(const QtParams& Q, int nframes, hipStream_t st, int ldsBudget);
 // orbfe_bow.hip
 int bow_launch_descend(orbfe_vocabulary* v, const uint8_t* d_desc, int n, int levelsup, uint2* d_out, hipStream_t st);
 int bow_assemble(orbfe_vocabulary* v, const uint2* ln, int n, uint32_t* bow_ids, double* bow_values, int* n_words,
@@ -214,6 +214,7 @@ struct orbfe_extractor {
   DevBuf<ConeRange> d_coneTab;
   ConeParams cone{};
   bool coneOk = false;
+  int qtLdsBudget = 120 * 1024;   // LDS bytes a quadtree problem may use for its candidates in small batches
   int coneTile = 0;        // tile edge on the top level (0 = chosen from the level's size)
   int coneMaxFrames = 2;   // batches up to this size build the pyramid with k_pyramid_cone
   DevBuf<CellInfo> d_cells;
@@ -764,7 +765,8 @@ struct orbfe_extractor {
       HIP_TRY(hipStreamWaitEvent(qs, evQtIn, 0));
     }
     if (prof) HIP_TRY(hipEventRecord(evQt[0], qs));
-    launch_quadtree(QP, nframes, qs);
+    // a one- or two-frame call is latency-bound and alone on the chip: the quadtree keeps its candidates in LDS
+    if (launch_quadtree(QP, nframes, qs, nframes <= coneMaxFrames ? qtLdsBudget : 0)) { set_err("cannot configure the quadtree kernel"); return ORBFE_ERR_HIP; }
     if (prof) HIP_TRY(hipEventRecord(evQt[1], qs));
     if (ownQs) {
       HIP_TRY(hipEventRecord(evQtOut, qs));
@@ -1317,6 +1319,7 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
   if (const char* hv = getenv("ORBFE_HOST_QUADTREE")) h->gpuQuadtree = atoi(hv) == 0;
   if (const char* pv = getenv("ORBFE_FAST_PAIRS")) h->pairCells = atoi(pv) != 0;
   if (const char* cv = getenv("ORBFE_CONE_MAX_FRAMES")) h->coneMaxFrames = atoi(cv);
+  if (const char* qv = getenv("ORBFE_QT_LDS_BYTES")) h->qtLdsBudget = atoi(qv);
   if (const char* cv = getenv("ORBFE_CONE_TILE")) h->coneTile = atoi(cv) <= 0 ? 0 : std::max(8, atoi(cv)) & ~3;
   if (const char* pv = getenv("ORBFE_PROFILE_KERNELS")) h->profileKernels = atoi(pv) != 0;
   h->selPerFrame = 0;

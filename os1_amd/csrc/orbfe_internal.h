@@ -128,7 +128,7 @@ struct QtParams {
   int levW[kMaxLevels], levH[kMaxLevels], nfeat[kMaxLevels];
   int selOff[kMaxLevels];      // first slot of the level inside a frame's selection region
   int selPerFrame;
-  uint16_t* own;               // [nframes][candCap] node id | quadrant << 14 per candidate
+  uint16_t* own;               // [nframes][candCap] node id * 4 + quadrant per candidate
   SelKp* sel;                  // [nframes][selPerFrame]
   uint32_t* selCount;          // [nframes][kMaxLevels]
 };

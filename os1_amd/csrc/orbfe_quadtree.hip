@@ -44,12 +44,15 @@ template <int CAP>
 struct Qt3Shared {
   Qt3Node nodes[2][CAP];
   unsigned short proc[CAP];   // node ids in processing order
-  uint32_t ninfo[CAP];        // midX | midY << 12 | divide << 24
+  uint32_t ninfo[CAP];        // (midX + border) | (midY + border) << 12 | divide << 24
   uint16_t cpos[CAP][4];      // new list position of a candidate of node id that sits in quadrant q (kept nodes: all four equal)
-  union {
-    uint32_t cnt[CAP][4];     // candidates per child of a node divided in this pass (LDS atomics)
-    uint32_t best[CAP];       // final pick: max of score << 24 | (0xffffff - candidate index)
-  };
+  // LDS atomics of the sweeps.  64 lanes adding to one address are served one after the other (about 130 cycles per
+  // wave instruction measured), and neighbouring candidates do share their node while the list is short, so every
+  // counter is replicated R = 2^rlog times in consecutive words (different banks) and lane L uses replica L % R:
+  //   child counts   cnt[((id * 4 + q) << rlog) + rep], R = largest power of two <= 32 with nodes * R <= CAP; the
+  //                  node pass reads replica 0 after a fold;
+  //   final pick     max of score << 24 | (0xffffff - candidate index) in cnt[id * 4 + rep].
+  alignas(16) uint32_t cnt[CAP * 4];
   unsigned long long sortKeys[CAP];
   short tproc[CAP];           // index in processing order, -1 = not divided
   int wsumI[kQt3Threads / 64];
@@ -82,6 +85,34 @@ template <int CAP>
 __device__ void blockSortDesc3(Qt3Shared<CAP>& sh, int n) {
   int m = 1;
   while (m < n) m <<= 1;
+  if (m <= kQt3Threads) {
+    // one key per thread, in a register: the exchange distances below a wave's width go through lane shuffles (no
+    // barrier); only distances >= 64 take a round trip through LDS
+    const int i = threadIdx.x;
+    unsigned long long key = i < n ? sh.sortKeys[i] : 0ull;
+    for (int k = 2; k <= m; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        unsigned long long other;
+        if (j >= 64) {
+          __syncthreads();
+          sh.sortKeys[i] = key;
+          __syncthreads();
+          other = sh.sortKeys[i ^ j];
+        } else {
+          const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)key, j, 64);
+          const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(key >> 32), j, 64);
+          other = ((unsigned long long)hi << 32) | lo;
+        }
+        const bool keepMax = ((i & j) == 0) == ((i & k) == 0);   // lower index of the pair in a descending run
+        const bool otherBigger = other > key;
+        if (keepMax == otherBigger) key = other;
+      }
+    }
+    __syncthreads();
+    if (i < m) sh.sortKeys[i] = key;
+    __syncthreads();
+    return;
+  }
   for (int i = n + threadIdx.x; i < m; i += kQt3Threads) sh.sortKeys[i] = 0ull;
   __syncthreads();
   for (int k = 2; k <= m; k <<= 1) {
@@ -99,10 +130,26 @@ __device__ void blockSortDesc3(Qt3Shared<CAP>& sh, int n) {
   }
 }
 
-template <int CAP>
-__global__ __launch_bounds__(kQt3Threads) void k_quadtree3(QtParams Q) {
-  __shared__ Qt3Shared<CAP> sh;
-  constexpr int IPT = CAP / kQt3Threads;   // node items per thread
+// Candidate words and node ids either stay in HBM (LC = false: batches, where LDS is better spent on the occupancy of
+// the kernels running beside the quadtree) or are copied into LDS by the root pass (LC = true: latency-bound one- or
+// two-frame calls; a sweep then costs LDS round trips instead of L2 ones).
+template <bool LC>
+struct Qt3Cands {
+  const uint32_t* cg;
+  uint16_t* og;
+  uint32_t* cl;
+  uint16_t* ol;
+  __device__ __forceinline__ uint32_t cand(int p) const { return LC ? cl[p] : cg[p]; }
+  __device__ __forceinline__ unsigned own(int p) const { return LC ? ol[p] : og[p]; }
+  __device__ __forceinline__ void setOwn(int p, unsigned v) const {
+    if (LC) ol[p] = (uint16_t)v;
+    else og[p] = (uint16_t)v;
+  }
+};
+
+template <int CAP, bool LC>
+__device__ __forceinline__ void qt3_problem(const QtParams& Q, Qt3Shared<CAP>& sh, uint32_t* candL, uint16_t* ownL) {
+  constexpr int IPT = CAP >= kQt3Threads ? CAP / kQt3Threads : 1;   // node items per thread
   const int level = blockIdx.x, f = Q.frameBase + blockIdx.y, tid = threadIdx.x;
   const uint32_t* ls = Q.levelStart + (long long)f * (kMaxLevels + 1);
   const uint32_t first = ls[level];
@@ -116,19 +163,19 @@ __global__ __launch_bounds__(kQt3Threads) void k_quadtree3(QtParams Q) {
   }
   const long long eo = (long long)f * Q.candCap + first;
   const uint32_t* cand = Q.cand + eo;
-  uint16_t* own = Q.own + eo;              // node id (14 bits) | quadrant inside it (2 bits), per candidate
+  // node id * 4 + quadrant inside it, per candidate (= index into the child table)
+  const Qt3Cands<LC> ca{cand, Q.own + eo, candL, ownL};
   Qt3Node* cur = sh.nodes[0];
   Qt3Node* nxt = sh.nodes[1];
   unsigned short* proc = sh.proc;
   const int maxX = Q.levW[level] - kBorder, maxY = Q.levH[level] - kBorder;
-
   // ---- roots (ORBextractor.cc:574-617): raw root index per candidate, counts by LDS atomics ------------------
   const int nIni = (int)roundf(static_cast<float>(maxX - kBorder) / (maxY - kBorder));
   const float hX = static_cast<float>(maxX - kBorder) / nIni;
   int m = 0;
   uint32_t seq = 0;
   {
-    if (tid < 4) sh.cnt[0][tid] = 0u;
+    if (tid < 128) sh.cnt[tid] = 0u;
     __syncthreads();
     for (int b = 0; b < n; b += kQtEpt * kQt3Threads) {
       uint32_t v[kQtEpt];
@@ -143,14 +190,21 @@ __global__ __launch_bounds__(kQt3Threads) void k_quadtree3(QtParams Q) {
         if (p < n) {
           const int x = (int)(v[j] & 0xfff) - kBorder;
           const int r = min((int)((float)x / hX), nIni - 1);
-          own[p] = (uint16_t)r;
-          atomicAdd(&sh.cnt[0][r], 1u);
+          if (LC) candL[p] = v[j];
+          ca.setOwn(p, (unsigned)r << 2);
+          atomicAdd(&sh.cnt[r * 32 + (tid & 31)], 1u);
         }
       }
     }
     __syncthreads();
+    if (tid < 4) {
+      uint32_t t = 0;
+      for (int k = 0; k < 32; k++) t += sh.cnt[tid * 32 + k];
+      sh.s_int[tid] = (int)t;
+    }
+    __syncthreads();
     uint32_t cnt[4];
-    for (int r = 0; r < 4; r++) cnt[r] = sh.cnt[0][r];
+    for (int r = 0; r < 4; r++) cnt[r] = (uint32_t)sh.s_int[r];
     int rootId[4], nr = 0;
     for (int r = 0; r < 4; r++) rootId[r] = (r < nIni && cnt[r] > 0) ? nr++ : -1;
     __syncthreads();
@@ -172,7 +226,6 @@ __global__ __launch_bounds__(kQt3Threads) void k_quadtree3(QtParams Q) {
     seq = (uint32_t)nIni;
     __syncthreads();
   }
-
   bool finalPhase = false;
   int nRec = 0;
   for (int iter = 0; iter < 64; iter++) {
@@ -214,11 +267,13 @@ __global__ __launch_bounds__(kQt3Threads) void k_quadtree3(QtParams Q) {
     for (int i = tid; i < m; i += kQt3Threads) {
       const Qt3Node nd = cur[i];
       const int midX = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), midY = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
-      sh.ninfo[i] = (uint32_t)midX | ((uint32_t)midY << 12) | (sh.tproc[i] >= 0 ? (1u << 24) : 0u);
-      *reinterpret_cast<uint4*>(sh.cnt[i]) = make_uint4(0u, 0u, 0u, 0u);
+      // image coordinates (candidate words hold x, y with the border included), so the sweep compares fields directly
+      sh.ninfo[i] = (uint32_t)(midX + kBorder) | ((uint32_t)(midY + kBorder) << 12) | (sh.tproc[i] >= 0 ? (1u << 24) : 0u);
     }
+    int rlog = 5;   // counter replicas of this pass
+    while (rlog > 0 && (m << rlog) > CAP) rlog--;
+    for (int i = tid; i < ((m * 4) << rlog); i += kQt3Threads) sh.cnt[i] = 0u;
     __syncthreads();
-
     // ---- candidate sweep: node id in the current list (through the previous pass's child table), quadrant inside
     //      a node that is divided in this pass, one count per candidate ----------------------------------------
     {
@@ -227,9 +282,11 @@ __global__ __launch_bounds__(kQt3Threads) void k_quadtree3(QtParams Q) {
       auto loadStep = [&](int b) {   // the next step's candidates travel while the current step is processed
 #pragma unroll
         for (int j = 0; j < kQtEpt; j++) {
-          const int p = min(b + j * kQt3Threads + tid, n - 1);   // clamped, not predicated: all loads of a step issue back to back
-          owN[j] = own[p];
-          vN[j] = cand[p];
+          // not predicated: all loads of a step issue back to back.  LDS reads past the problem's candidates return
+          // stale or zero words that only ever feed other reads; HBM reads are clamped
+          const int p = LC ? b + j * kQt3Threads + tid : min(b + j * kQt3Threads + tid, n - 1);
+          owN[j] = ca.own(p);
+          vN[j] = ca.cand(p);
         }
       };
       loadStep(0);
@@ -239,24 +296,37 @@ __global__ __launch_bounds__(kQt3Threads) void k_quadtree3(QtParams Q) {
 #pragma unroll
         for (int j = 0; j < kQtEpt; j++) { v[j] = vN[j]; ow[j] = owN[j]; }
         if (b + kQtEpt * kQt3Threads < n) loadStep(b + kQtEpt * kQt3Threads);
+        // three dependent LDS round trips per step, not per candidate: all table reads of a stage are issued before
+        // the first atomic / store of the step (which the compiler must assume to alias them)
+        unsigned id[kQtEpt];
+        uint32_t info[kQtEpt];
+#pragma unroll
+        for (int j = 0; j < kQtEpt; j++) id[j] = (&sh.cpos[0][0])[ow[j] & (CAP * 4 - 1)];
+#pragma unroll
+        for (int j = 0; j < kQtEpt; j++) info[j] = sh.ninfo[id[j] & (CAP - 1)];
 #pragma unroll
         for (int j = 0; j < kQtEpt; j++) {
           const int p = b + j * kQt3Threads + tid;
           if (p < n) {
-            const unsigned id = sh.cpos[ow[j] & 0x3fffu][ow[j] >> 14];
-            const uint32_t info = sh.ninfo[id];
             unsigned q = 0;
-            if (info >> 24) {   // the node is divided in this pass: one count for the child the candidate falls into
-              const int x = (int)(v[j] & 0xfff) - kBorder, y = (int)((v[j] >> 12) & 0xfff) - kBorder;
-              q = (x < (int)(info & 0xfff) ? 0u : 1u) + (y < (int)((info >> 12) & 0xfff) ? 0u : 2u);
-              atomicAdd(&sh.cnt[id][q], 1u);
+            if (info[j] >> 24) {   // the node is divided in this pass: one count for the child the candidate falls into
+              q = ((v[j] & 0xfff) < (info[j] & 0xfff) ? 0u : 1u) + ((v[j] & 0xfff000) < (info[j] & 0xfff000) ? 0u : 2u);
+              atomicAdd(&sh.cnt[((id[j] * 4 + q) << rlog) + (tid & ((1 << rlog) - 1))], 1u);
             }
-            own[p] = (uint16_t)(id | (q << 14));
+            ca.setOwn(p, id[j] * 4 + q);
           }
         }
       }
     }
     __syncthreads();
+    if (rlog > 0) {   // fold the replicas into replica 0 (a group is touched by one thread only)
+      for (int g = tid; g < m * 4; g += kQt3Threads) {
+        uint32_t t = 0;
+        for (int k = 0; k < (1 << rlog); k++) t += sh.cnt[(g << rlog) + k];
+        sh.cnt[g << rlog] = t;
+      }
+      __syncthreads();
+    }
 
     // ---- node pass: children counts, cut, new list positions -----------------------------------------
     int C[IPT], locC = 0, locGrow = 0;
@@ -266,7 +336,7 @@ __global__ __launch_bounds__(kQt3Threads) void k_quadtree3(QtParams Q) {
       C[k] = 0;
       if (t < nproc) {
         const int id = proc[t];
-        for (int q = 0; q < 4; q++) C[k] += sh.cnt[id][q] > 0;
+        for (int q = 0; q < 4; q++) C[k] += sh.cnt[(id * 4 + q) << rlog] > 0;
         locC += C[k];
         locGrow += C[k] - 1;
       }
@@ -331,7 +401,7 @@ __global__ __launch_bounds__(kQt3Threads) void k_quadtree3(QtParams Q) {
             const int midX = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), midY = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
             uint32_t c[4];
             int nonEmptyAfter = 0;
-            for (int q = 0; q < 4; q++) { c[q] = sh.cnt[id][q]; nonEmptyAfter += c[q] > 0; }
+            for (int q = 0; q < 4; q++) { c[q] = sh.cnt[(id * 4 + q) << rlog]; nonEmptyAfter += c[q] > 0; }
             const int groupBase = T - pc - C[k];
             int before = 0;
             for (int q = 0; q < 4; q++) {
@@ -367,7 +437,6 @@ __global__ __launch_bounds__(kQt3Threads) void k_quadtree3(QtParams Q) {
     { Qt3Node* t2 = cur; cur = nxt; nxt = t2; }
     m = mNew;
     seq += (uint32_t)T;
-
     // ---- record of nodes created in this pass with more than one candidate (positions [0,T)) --------
     int recFlag[IPT], locR = 0;
 #pragma unroll
@@ -388,7 +457,6 @@ __global__ __launch_bounds__(kQt3Threads) void k_quadtree3(QtParams Q) {
     }
     nRec = totR;
     __syncthreads();
-
     if (m >= N || m == prevSize) break;
     if (!finalPhase && m + 3 * totR > N) finalPhase = true;
     if (finalPhase && nRec == 0) break;
@@ -396,7 +464,7 @@ __global__ __launch_bounds__(kQt3Threads) void k_quadtree3(QtParams Q) {
 
   // ---- one keypoint per node: highest response, first in candidate order wins (ORBextractor.cc:774-792) --------
   __syncthreads();
-  for (int i = tid; i < m; i += kQt3Threads) sh.best[i] = 0u;
+  for (int i = tid; i < m * 4; i += kQt3Threads) sh.cnt[i] = 0u;
   __syncthreads();
   for (int b = 0; b < n; b += kQtEpt * kQt3Threads) {
     uint32_t v[kQtEpt];
@@ -406,20 +474,22 @@ __global__ __launch_bounds__(kQt3Threads) void k_quadtree3(QtParams Q) {
       const int p = b + j * kQt3Threads + tid;
       v[j] = 0u;
       ow[j] = 0u;
-      if (p < n) { ow[j] = own[p]; v[j] = cand[p]; }
+      if (p < n) { ow[j] = ca.own(p); v[j] = ca.cand(p); }
     }
+    unsigned id[kQtEpt];
+#pragma unroll
+    for (int j = 0; j < kQtEpt; j++) id[j] = (&sh.cpos[0][0])[ow[j] & (CAP * 4 - 1)];
 #pragma unroll
     for (int j = 0; j < kQtEpt; j++) {
       const int p = b + j * kQt3Threads + tid;
-      if (p < n) {
-        const unsigned id = sh.cpos[ow[j] & 0x3fffu][ow[j] >> 14];
-        atomicMax(&sh.best[id], ((v[j] >> 24) << 24) | (0xffffffu - (uint32_t)p));
-      }
+      if (p < n) atomicMax(&sh.cnt[id[j] * 4 + (tid & 3)], ((v[j] >> 24) << 24) | (0xffffffu - (uint32_t)p));
     }
   }
   __syncthreads();
   for (int i = tid; i < m; i += kQt3Threads) {
-    const uint32_t c = cand[0xffffffu - (sh.best[i] & 0xffffffu)];
+    const uint4 b4 = *reinterpret_cast<const uint4*>(&sh.cnt[i * 4]);
+    const uint32_t best = max(max(b4.x, b4.y), max(b4.z, b4.w));
+    const uint32_t c = ca.cand((int)(0xffffffu - (best & 0xffffffu)));
     SelKp s;
     s.xy = (c & 0xfff) | (((c >> 12) & 0xfff) << 16);
     s.lf = (uint32_t)level | ((uint32_t)f << 8) | ((c >> 24) << 24);
@@ -428,17 +498,49 @@ __global__ __launch_bounds__(kQt3Threads) void k_quadtree3(QtParams Q) {
   if (tid == 0) *selCount = (uint32_t)m;
 }
 
-void launch_quadtree(const QtParams& Q, int nframes, hipStream_t st) {
+template <int CAP>
+__global__ __launch_bounds__(kQt3Threads) void k_quadtree3(QtParams Q, int ldsCand) {
+  __shared__ Qt3Shared<CAP> sh;
+  extern __shared__ __align__(16) uint32_t qtDyn[];   // [ldsCand] candidate words, then [ldsCand] u16 node ids
+  const uint32_t* ls = Q.levelStart + (long long)(Q.frameBase + blockIdx.y) * (kMaxLevels + 1);
+  const int n = (int)(ls[blockIdx.x + 1] - ls[blockIdx.x]);
+  if (n <= ldsCand)
+    qt3_problem<CAP, true>(Q, sh, qtDyn, reinterpret_cast<uint16_t*>(qtDyn + ldsCand));
+  else
+    qt3_problem<CAP, false>(Q, sh, nullptr, nullptr);
+}
+
+// ldsBudget: bytes of LDS one problem may take for its candidates on top of the node tables (0 = keep them in HBM)
+template <int CAP>
+static int launch_qt3(const QtParams& Q, int nframes, hipStream_t st, int ldsBudget) {
+  int ldsCand = 0;
+  const int room = 156 * 1024 - (int)sizeof(Qt3Shared<CAP>);
+  if (ldsBudget > room) ldsBudget = room;
+  if (ldsBudget >= 6 * 1024) ldsCand = (ldsBudget / 6) & ~3;
+  const int dynBytes = ldsCand * 6;
+  if (dynBytes) {
+    static int attrBytes[64] = {};   // per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1;
+    if (dynBytes > attrBytes[dev]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree3<CAP>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              dynBytes) != hipSuccess)
+        return 1;
+      attrBytes[dev] = dynBytes;
+    }
+  }
+  hipLaunchKernelGGL(k_quadtree3<CAP>, dim3(Q.nlevels, nframes), dim3(kQt3Threads), dynBytes, st, Q, ldsCand);
+  return 0;
+}
+
+int launch_quadtree(const QtParams& Q, int nframes, hipStream_t st, int ldsBudget) {
   int maxN = 0;
   for (int l = 0; l < Q.nlevels; l++) maxN = Q.nfeat[l] > maxN ? Q.nfeat[l] : maxN;
   // the node-table capacity sets the block's LDS footprint (36 / 72 / 144 KB), and with it how many waves of the
   // kernels that run beside the quadtree still fit on the CU
-  if (maxN + 4 <= 512)
-    hipLaunchKernelGGL(k_quadtree3<512>, dim3(Q.nlevels, nframes), dim3(kQt3Threads), 0, st, Q);
-  else if (maxN + 4 <= 1024)
-    hipLaunchKernelGGL(k_quadtree3<1024>, dim3(Q.nlevels, nframes), dim3(kQt3Threads), 0, st, Q);
-  else
-    hipLaunchKernelGGL(k_quadtree3<2048>, dim3(Q.nlevels, nframes), dim3(kQt3Threads), 0, st, Q);
+  if (maxN + 4 <= 512) return launch_qt3<512>(Q, nframes, st, ldsBudget);
+  if (maxN + 4 <= 1024) return launch_qt3<1024>(Q, nframes, st, ldsBudget);
+  return launch_qt3<2048>(Q, nframes, st, ldsBudget);
 }
 
 }  // namespace orbfe
