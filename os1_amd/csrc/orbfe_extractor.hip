@@ -215,6 +215,7 @@ struct orbfe_extractor {
   ConeParams cone{};
   bool coneOk = false;
   int qtLdsBudget = 120 * 1024;   // LDS bytes a quadtree problem may use for its candidates in small batches
+  bool zeroCopyOut = true;        // small plain batches: results written to host memory by the kernels
   int coneTile = 0;        // tile edge on the top level (0 = chosen from the level's size)
   int coneMaxFrames = 2;   // batches up to this size build the pyramid with k_pyramid_cone
   DevBuf<CellInfo> d_cells;
@@ -710,7 +711,14 @@ struct orbfe_extractor {
     const long long rawStride = onDevice ? (long long)stride : inPitch;
     P.stride0 = ch == 1 ? rawStride : grayPitch;
     P.frameBase = 0;
-    HIP_TRY(hipMemcpyAsync(d_frame0.p, h_frame0.p, sizeof(void*) * nframes * (ch == 1 ? 1 : 2), hipMemcpyHostToDevice, st));
+    if (ch == 1 && nframes <= 2) {   // the level-0 pointers travel in the kernel arguments
+      P.frame0 = nullptr;
+      P.frameInline[0] = h_frame0.p[0];
+      P.frameInline[1] = h_frame0.p[nframes - 1];
+    } else {
+      P.frame0 = d_frame0.p;
+      HIP_TRY(hipMemcpyAsync(d_frame0.p, h_frame0.p, sizeof(void*) * nframes * (ch == 1 ? 1 : 2), hipMemcpyHostToDevice, st));
+    }
     if (ch > 1) {
       // OpenCV RGB2Gray<uchar>: 15-bit coefficients {R 9798, G 19235, B 3735} (>= 4.1.1) or 14-bit {4899, 9617, 1868}
       const bool q15 = grayVariant == ORBFE_GRAY_Q15;
@@ -752,6 +760,12 @@ struct orbfe_extractor {
     QP.cand = d_cand.p; QP.levelStart = d_levelStart.p; QP.candCap = P.candCap; QP.nlevels = nlevels; QP.frameBase = 0;
     QP.own = d_own.p;
     QP.sel = d_sel.p; QP.selCount = d_selCount.p; QP.selPerFrame = selPerFrame;
+    // Latency-bound plain extraction: the kernels write the results straight into the page-locked host arena
+    // (the quadtree a second copy of its selection, the descriptor kernel its only copy), so no copy command follows
+    // the last kernel.  Matching and bag-of-words read angles / descriptors on the device and keep the copy.
+    const bool zeroCopy = zeroCopyOut && nframes <= coneMaxFrames && !voc && !(ms && ms->chain);
+    QP.selHost = zeroCopy ? h_sel.p : nullptr;
+    QP.selCountHost = zeroCopy ? h_selCount.p : nullptr;
     for (int l = 0; l < nlevels; l++) {
       QP.levW[l] = P.lv[l].w; QP.levH[l] = P.lv[l].h; QP.nfeat[l] = nfeat[l]; QP.selOff[l] = selOff[l];
     }
@@ -774,7 +788,8 @@ struct orbfe_extractor {
     }
     const int nslots = nframes * selPerFrame;
     if (prof) HIP_TRY(hipEventRecord(ev[0][4], st));
-    launch_describe_slots(P, d_sel.p, nslots, d_angle.p, d_desc.p, d_selCount.p, selPerFrame, selOff, st);
+    launch_describe_slots(P, d_sel.p, nslots, zeroCopy ? h_angle.p : d_angle.p, zeroCopy ? h_desc.p : d_desc.p, d_selCount.p,
+                          selPerFrame, selOff, st);
     if (prof) HIP_TRY(hipEventRecord(ev[0][5], st));
     HIP_TRY(hipGetLastError());
     pendingBow = false;
@@ -816,7 +831,7 @@ struct orbfe_extractor {
       ch.seq++;
       pendingMatched = true;
     }
-    HIP_TRY(hipMemcpyAsync(h_outArena.p, d_outArena.p, outArenaBytes, hipMemcpyDeviceToHost, st));   // all results, one copy
+    if (!zeroCopy) HIP_TRY(hipMemcpyAsync(h_outArena.p, d_outArena.p, outArenaBytes, hipMemcpyDeviceToHost, st));   // all results, one copy
     submitProfiled = prof;
     tSubmit0 = t0;
     tSubmit1 = now_ms();
@@ -941,6 +956,7 @@ struct orbfe_extractor {
       h_frame0.p[f] = onDevice ? gray[f] : d_in.p + (size_t)inPitch * rows * f;
     }
     P.stride0 = onDevice ? (long long)stride : inPitch;
+    P.frame0 = d_frame0.p;
     HIP_TRY(hipMemcpyAsync(d_frame0.p, h_frame0.p, sizeof(void*) * nframes, hipMemcpyHostToDevice, streams[0]));
     HIP_TRY(hipEventRecord(evFrame0, streams[0]));
     // ---- stage 1 for every sub-batch -----------------------------------------------------
@@ -1319,6 +1335,7 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
   if (const char* hv = getenv("ORBFE_HOST_QUADTREE")) h->gpuQuadtree = atoi(hv) == 0;
   if (const char* pv = getenv("ORBFE_FAST_PAIRS")) h->pairCells = atoi(pv) != 0;
   if (const char* cv = getenv("ORBFE_CONE_MAX_FRAMES")) h->coneMaxFrames = atoi(cv);
+  if (const char* zv = getenv("ORBFE_ZERO_COPY")) h->zeroCopyOut = atoi(zv) != 0;
   if (const char* qv = getenv("ORBFE_QT_LDS_BYTES")) h->qtLdsBudget = atoi(qv);
   if (const char* cv = getenv("ORBFE_CONE_TILE")) h->coneTile = atoi(cv) <= 0 ? 0 : std::max(8, atoi(cv)) & ~3;
   if (const char* pv = getenv("ORBFE_PROFILE_KERNELS")) h->profileKernels = atoi(pv) != 0;
@@ -1547,7 +1564,9 @@ int orbfe_debug_candidates(orbfe_extractor* h, int frame, int level, int32_t* xy
     return ORBFE_ERR_INVALID;
   }
   HIP_TRY(hipSetDevice(h->device));
-  const uint32_t* ls = h->h_levelStart.p + (size_t)frame * (kMaxLevels + 1);
+  // read from the device: small batches hand their results over without copying the whole arena
+  uint32_t ls[kMaxLevels + 1];
+  HIP_TRY(hipMemcpy(ls, h->d_levelStart.p + (size_t)frame * (kMaxLevels + 1), sizeof(ls), hipMemcpyDeviceToHost));
   const int n = (int)(ls[level + 1] - ls[level]);
   *n_out = n;
   if (n <= 0 || !xys) return ORBFE_OK;

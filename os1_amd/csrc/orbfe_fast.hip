@@ -67,7 +67,7 @@ __global__ __launch_bounds__(64) void k_fast_tasks(PyramidParams P, int tpPad) {
   const uint8_t* img;
   long long stride;
   if (level == 0) {
-    img = P.frame0[f];
+    img = level0_of(P, f);
     stride = P.stride0;
   } else {
     img = P.slab + (long long)f * P.slabBytes + L.off;

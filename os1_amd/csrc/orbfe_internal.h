@@ -58,7 +58,9 @@ struct PyramidParams {
   long long slabBytes;              // pyramid slab bytes per frame (levels >= 1)
   long long slotsPerFrame;          // u32 slots per frame
   long long candCap;                // candidate capacity per frame (u32 entries)
-  const uint8_t* const* frame0;     // [nframes] level-0 pointers (device memory)
+  const uint8_t* const* frame0;     // [nframes] level-0 pointers (device memory); nullptr: use frameInline
+  const uint8_t* frameInline[2];    // level-0 pointers of a one- or two-frame call, carried in the kernel arguments
+                                    // (saves the table's H2D copy in front of a latency-bound call)
   long long stride0;                // level-0 row stride in bytes
   uint8_t* slab;                    // [nframes][slabBytes]
   uint32_t* cellCount;              // [nframes][ncells]
@@ -84,6 +86,12 @@ struct ConeParams {
   const ConeRange* regX;            // [tilesX][kMaxLevels] columns of level l a tile column needs
   const ConeRange* regY;            // [tilesY][kMaxLevels]
 };
+
+#ifdef __HIPCC__
+__device__ __forceinline__ const uint8_t* level0_of(const PyramidParams& P, int f) {
+  return P.frame0 ? P.frame0[f] : P.frameInline[f & 1];
+}
+#endif
 
 // One selected keypoint handed to the orientation + descriptor kernel.
 struct SelKp {
@@ -131,6 +139,10 @@ struct QtParams {
   uint16_t* own;               // [nframes][candCap] node id * 4 + quadrant per candidate
   SelKp* sel;                  // [nframes][selPerFrame]
   uint32_t* selCount;          // [nframes][kMaxLevels]
+  // optional second copy of the two outputs in page-locked host memory (latency-bound calls: the result needs no
+  // device-to-host copy command after the last kernel); nullptr = none
+  SelKp* selHost;
+  uint32_t* selCountHost;
 };
 
 

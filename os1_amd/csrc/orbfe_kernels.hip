@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void k_resize(PyramidParams P, int level) {
   const uint8_t* src;
   long long sstride;
   if (level == 1) {
-    src = P.frame0[f];
+    src = level0_of(P, f);
     sstride = P.stride0;
   } else {
     src = P.slab + (long long)f * P.slabBytes + S.off;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(kConeThreads) void k_pyramid_cone(PyramidParams P, 
   const uint8_t* src;
   int sstride;
   if (C.base == 0) {
-    src = P.frame0[f];
+    src = level0_of(P, f);
     sstride = (int)P.stride0;
   } else {
     src = P.slab + (long long)f * P.slabBytes + P.lv[C.base].off;
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(64) void k_describe(PyramidParams P, const SelKp* _
   const uint8_t* img;
   long long stride;
   if (level == 0) {
-    img = P.frame0[f];
+    img = level0_of(P, f);
     stride = P.stride0;
   } else {
     img = P.slab + (long long)f * P.slabBytes + L.off;

@@ -156,9 +156,14 @@ __device__ __forceinline__ void qt3_problem(const QtParams& Q, Qt3Shared<CAP>& s
   const int n = (int)(ls[level + 1] - first);
   const int N = Q.nfeat[level];
   uint32_t* selCount = Q.selCount + (long long)f * kMaxLevels + level;
+  uint32_t* selCountHost = Q.selCountHost ? Q.selCountHost + (long long)f * kMaxLevels + level : nullptr;
+  SelKp* selHost = Q.selHost ? Q.selHost + (long long)f * Q.selPerFrame + Q.selOff[level] : nullptr;
   SelKp* selOut = Q.sel + (long long)f * Q.selPerFrame + Q.selOff[level];
   if (n <= 0) {
-    if (tid == 0) *selCount = 0;
+    if (tid == 0) {
+      *selCount = 0;
+      if (selCountHost) *selCountHost = 0;
+    }
     return;
   }
   const long long eo = (long long)f * Q.candCap + first;
@@ -494,8 +499,12 @@ __device__ __forceinline__ void qt3_problem(const QtParams& Q, Qt3Shared<CAP>& s
     s.xy = (c & 0xfff) | (((c >> 12) & 0xfff) << 16);
     s.lf = (uint32_t)level | ((uint32_t)f << 8) | ((c >> 24) << 24);
     selOut[i] = s;
+    if (selHost) selHost[i] = s;
   }
-  if (tid == 0) *selCount = (uint32_t)m;
+  if (tid == 0) {
+    *selCount = (uint32_t)m;
+    if (selCountHost) *selCountHost = (uint32_t)m;
+  }
 }
 
 template <int CAP>
