@@ -146,6 +146,127 @@ __global__ __launch_bounds__(256) void k_resize(PyramidParams P, int level) {
   }
 }
 
+// k_resize with the LDS geometry fixed at compile time (pitch LP bytes, up to RH footprint rows): every LDS access
+// of the row pass is base + immediate, so an H element costs 3 vector instructions (multiply, multiply-add, shift)
+// instead of 9, and the column pass takes its 16-bit operands with SDWA selects instead of unpacking them.  Chosen by
+// launch_pyramid for every level whose footprints fit (all levels at scale 1.2).
+__device__ __forceinline__ unsigned mulu24_w0(unsigned b, unsigned hh) {   // b * (hh & 0xffff)
+  unsigned r;
+  asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(b), "v"(hh));
+  return r;
+}
+__device__ __forceinline__ unsigned mulu24_w1(unsigned b, unsigned hh) {   // b * (hh >> 16)
+  unsigned r;
+  asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(b), "v"(hh));
+  return r;
+}
+
+// scalar base + 32-bit lane byte offset: one address register, no 64-bit lane arithmetic
+__device__ __forceinline__ int ld32(const void* base, unsigned byteOff) {
+  return *reinterpret_cast<const int*>(reinterpret_cast<const char*>(base) + byteOff);
+}
+
+// a pointer every lane holds the same value of, moved to scalar registers
+__device__ __forceinline__ const uint8_t* uniform_ptr(const uint8_t* p) {
+  const uintptr_t v = reinterpret_cast<uintptr_t>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const uint8_t*>(((uintptr_t)hi << 32) | lo);
+}
+
+template <int LP, int RH>
+__global__ __launch_bounds__(256) void k_resize_fixed(PyramidParams P, int level) {
+  __shared__ __align__(16) uint8_t rz[LP * RH];
+  __shared__ __align__(16) uint16_t H[RH * 64];
+  const LevelGeom& D = P.lv[level];
+  const LevelGeom& S = P.lv[level - 1];
+  const int f = P.frameBase + blockIdx.z;
+  const int tx0 = blockIdx.x * kRzTile, ty0 = blockIdx.y * kRzTile;
+  const int tx1 = min(tx0 + kRzTile, D.w) - 1, ty1 = min(ty0 + kRzTile, D.h) - 1;
+  const uint8_t* src;
+  long long sstride;
+  if (level == 1) {
+    src = level0_of(P, f);
+    sstride = P.stride0;
+  } else {
+    src = P.slab + (long long)f * P.slabBytes + S.off;
+    sstride = S.pitch;
+  }
+  const int tid = threadIdx.x;
+  const int hc = tid & 63;
+  const int hx = min(tx0 + hc, D.w - 1);
+  const int hsx = ld32(D.xofs, (unsigned)hx << 2);
+  const int hal = ld32(D.xalpha, (unsigned)hx << 2);
+  const int cx = tx0 + (tid & 15) * 4, cy = ty0 + (tid >> 4) * 4;
+  int syv[4], be[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const unsigned y = (unsigned)min(cy + i, D.h - 1) << 2;
+    syv[i] = ld32(D.yofs, y);
+    be[i] = ld32(D.ybeta, y);
+  }
+  const int rx0 = D.xofs[tx0], rx1 = min(D.xofs[tx1] + 1, S.w - 1);
+  const int ry0 = min(max(D.yofs[ty0], 0), S.h - 1), ry1 = min(max(D.yofs[ty1] + 1, 0), S.h - 1);
+  const int rw = rx1 - rx0 + 1, rh = ry1 - ry0 + 1;
+  const int istr = (int)sstride;
+  const uint8_t* rbase = uniform_ptr(src + (long long)ry0 * sstride + rx0);   // the same for the whole block
+  const int a = (int)(reinterpret_cast<uintptr_t>(rbase) & 3);
+  if ((sstride & 3) == 0) {
+    // thread (c, r0) = (tid % 32, tid / 32) copies dword column c (LP / 4 <= 32 columns) of rows r0, r0 + 8, ...: all RH / 8
+    // loads are issued before the first LDS write; rows past the footprint repeat its last row (never read back)
+    static_assert(LP <= 128 && RH % 8 == 0, "staging layout");
+    const int ndw = (a + rw + 3) >> 2;
+    const int c = tid & 31, r0 = tid >> 5;
+    if (c < ndw) {
+      const uint8_t* gb = rbase - a;
+      uint32_t v[RH / 8];
+#pragma unroll
+      for (int u = 0; u < RH / 8; u++) v[u] = (uint32_t)ld32(gb, (unsigned)(4 * c + m24(min(r0 + 8 * u, rh - 1), istr)));
+      uint8_t* l = rz + 4 * c + r0 * LP;
+#pragma unroll
+      for (int u = 0; u < RH / 8; u++) *reinterpret_cast<uint32_t*>(l + u * 8 * LP) = v[u];
+    }
+  } else {
+    const float rcp = 1.0f / (float)rw;
+    const int total = rw * rh;
+    for (int i = tid; i < total; i += 256) {
+      const int y = (int)(((float)i + 0.5f) * rcp), x = i - m24(y, rw);
+      rz[y * LP + a + x] = rbase[m24(y, istr) + x];
+    }
+  }
+  __syncthreads();
+  // ---- row pass: all RH rows, unconditionally (rows past the footprint hold stale bytes nobody reads the H of) ----
+  {
+    const int a0 = (short)hal, a1 = hal >> 16;
+    const int o0 = a + hsx - rx0, o1 = a + min(hsx + 1, S.w - 1) - rx0;
+    const uint8_t* p0 = rz + (tid >> 6) * LP + o0;
+    const uint8_t* p1 = rz + (tid >> 6) * LP + o1;
+    uint16_t* h = H + (tid >> 6) * 64 + hc;
+#pragma unroll
+    for (int i = 0; i < RH / 4; i++)
+      h[i * 4 * 64] = (uint16_t)((m24(p0[i * 4 * LP], a0) + m24(p1[i * 4 * LP], a1)) >> 4);
+  }
+  __syncthreads();
+  // ---- column pass ----
+  if (cx > tx1 || cy > ty1) return;
+  uint8_t* dst = P.slab + (long long)f * P.slabBytes + D.off;
+  const uint16_t* hcol = H + (cx - tx0);
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int y = cy + j;
+    if (y > ty1) break;
+    const int sy = syv[j];
+    const int sy0 = min(max(sy, 0), S.h - 1) - ry0, sy1 = min(max(sy + 1, 0), S.h - 1) - ry0;
+    const unsigned b0 = (unsigned)(int)(short)be[j], b1 = (unsigned)(be[j] >> 16);
+    const uint2 q0 = *reinterpret_cast<const uint2*>(hcol + sy0 * 64), q1 = *reinterpret_cast<const uint2*>(hcol + sy1 * 64);
+    // b <= 2048, h <= 32640: the products fit 27 bits
+    const unsigned v0 = ((mulu24_w0(b0, q0.x) >> 16) + (mulu24_w0(b1, q1.x) >> 16) + 2) >> 2;
+    const unsigned v1 = ((mulu24_w1(b0, q0.x) >> 16) + (mulu24_w1(b1, q1.x) >> 16) + 2) >> 2;
+    const unsigned v2 = ((mulu24_w0(b0, q0.y) >> 16) + (mulu24_w0(b1, q1.y) >> 16) + 2) >> 2;
+    const unsigned v3 = ((mulu24_w1(b0, q0.y) >> 16) + (mulu24_w1(b1, q1.y) >> 16) + 2) >> 2;
+    *reinterpret_cast<uint32_t*>(dst + m24(y, D.pitch) + cx) = v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);  // pitch % 64 == 0: in bounds
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Pyramid for small batches: all levels in one launch.  Seven dependent k_resize launches cost 6-9 us each for a
 // single frame whatever the level's size; here one block owns a 32x32 tile of the TOP level and walks down the
@@ -773,6 +894,10 @@ int launch_pyramid(const PyramidParams& P, int nframes, hipStream_t st, const Co
   }
   for (int l = 1; l <= last; l++) {
     dim3 grid((P.lv[l].w + kRzTile - 1) / kRzTile, (P.lv[l].h + kRzTile - 1) / kRzTile, nframes);
+    if (P.lv[l].rzPitch <= 96 && P.lv[l].rzRows <= 80) {
+      hipLaunchKernelGGL((k_resize_fixed<96, 80>), grid, dim3(256), 0, st, P, l);
+      continue;
+    }
     hipLaunchKernelGGL(k_resize, grid, dim3(256), (((size_t)P.lv[l].rzPitch * P.lv[l].rzRows + 15) & ~(size_t)15) + (size_t)P.lv[l].rzRows * 64 * 2, st,
                        P, l);
   }
