@@ -173,6 +173,13 @@ __device__ __forceinline__ const uint8_t* uniform_ptr(const uint8_t* p) {
   return reinterpret_cast<const uint8_t*>(((uintptr_t)hi << 32) | lo);
 }
 
+// both 16-bit halves: (x + y + 2) >> 2
+__device__ __forceinline__ unsigned pk_round2(unsigned x, unsigned y) {
+  unsigned t;
+  asm("v_pk_add_u16 %0, %1, %2\n\tv_pk_add_u16 %0, %0, 2 op_sel_hi:[1,0]\n\tv_pk_lshrrev_b16 %0, 2, %0 op_sel_hi:[0,1]" : "=&v"(t) : "v"(x), "v"(y));
+  return t;
+}
+
 template <int LP, int RH>
 __global__ __launch_bounds__(256) void k_resize_fixed(PyramidParams P, int level) {
   __shared__ __align__(16) uint8_t rz[LP * RH];
@@ -258,12 +265,14 @@ __global__ __launch_bounds__(256) void k_resize_fixed(PyramidParams P, int level
     const int sy0 = min(max(sy, 0), S.h - 1) - ry0, sy1 = min(max(sy + 1, 0), S.h - 1) - ry0;
     const unsigned b0 = (unsigned)(int)(short)be[j], b1 = (unsigned)(be[j] >> 16);
     const uint2 q0 = *reinterpret_cast<const uint2*>(hcol + sy0 * 64), q1 = *reinterpret_cast<const uint2*>(hcol + sy1 * 64);
-    // b <= 2048, h <= 32640: the products fit 27 bits
-    const unsigned v0 = ((mulu24_w0(b0, q0.x) >> 16) + (mulu24_w0(b1, q1.x) >> 16) + 2) >> 2;
-    const unsigned v1 = ((mulu24_w1(b0, q0.x) >> 16) + (mulu24_w1(b1, q1.x) >> 16) + 2) >> 2;
-    const unsigned v2 = ((mulu24_w0(b0, q0.y) >> 16) + (mulu24_w0(b1, q1.y) >> 16) + 2) >> 2;
-    const unsigned v3 = ((mulu24_w1(b0, q0.y) >> 16) + (mulu24_w1(b1, q1.y) >> 16) + 2) >> 2;
-    *reinterpret_cast<uint32_t*>(dst + m24(y, D.pitch) + cx) = v0 | (v1 << 8) | (v2 << 16) | (v3 << 24);  // pitch % 64 == 0: in bounds
+    // b <= 2048, h <= 32640: the products fit 27 bits.  The high halves of two columns' products are gathered into one
+    // register (v_perm) and the rounding runs on both at once: (x + y + 2) >> 2 in packed 16-bit arithmetic.
+    const unsigned x01 = __builtin_amdgcn_perm(mulu24_w1(b0, q0.x), mulu24_w0(b0, q0.x), 0x07060302u);
+    const unsigned y01 = __builtin_amdgcn_perm(mulu24_w1(b1, q1.x), mulu24_w0(b1, q1.x), 0x07060302u);
+    const unsigned x23 = __builtin_amdgcn_perm(mulu24_w1(b0, q0.y), mulu24_w0(b0, q0.y), 0x07060302u);
+    const unsigned y23 = __builtin_amdgcn_perm(mulu24_w1(b1, q1.y), mulu24_w0(b1, q1.y), 0x07060302u);
+    const unsigned v01 = pk_round2(x01, y01), v23 = pk_round2(x23, y23);
+    *reinterpret_cast<uint32_t*>(dst + m24(y, D.pitch) + cx) = __builtin_amdgcn_perm(v23, v01, 0x06040200u);  // pitch % 64 == 0: in bounds
   }
 }
 
