@@ -46,7 +46,8 @@ __device__ __forceinline__ s16x2 as_s16x2(unsigned v) { return __builtin_bit_cas
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 // NPX = pixels per lane in the pre-test (8 or 16); tpPad = extra bytes of tile pitch (LDS bank spreading)
-template <int NPX>
+// PAIRS = false: every task is a single cell (the default task table); the second cell's bookkeeping compiles away
+template <int NPX, bool PAIRS>
 __global__ __launch_bounds__(64) void k_fast_tasks(PyramidParams P, int tpPad) {
   extern __shared__ __align__(16) uint8_t lds[];
   const int chunk = (P.ntasks + 7) >> 3;
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(64) void k_fast_tasks(PyramidParams P, int tpPad) {
   const FastTask tk = P.tasks[tix];
   const int level = tk.level;
   const LevelGeom& L = P.lv[level];
-  const int ex0 = tk.ex0, ey0 = tk.ey0, ew0 = tk.ew0, ew1 = tk.ew1, eh = tk.eh;
+  const int ex0 = tk.ex0, ey0 = tk.ey0, ew0 = tk.ew0, ew1 = PAIRS ? tk.ew1 : 0, eh = tk.eh;
   uint32_t* cnt = P.cellCount + (long long)f * P.ncells + tk.cell0;
   if (ew0 == 0) {
     if (lane == 0) cnt[0] = 0;
@@ -353,7 +354,12 @@ void launch_fast(const PyramidParams& P, int nframes, hipStream_t st) {
   // 16 pixels per lane in the pre-test: one wave iteration covers a 31 x 31 cell (8 pixels per lane take two and are
   // equal in time, 9.9 us per 1080p frame, with more instructions)
   const dim3 grid(8 * ((P.ntasks + 7) / 8), nframes);
-  hipLaunchKernelGGL(k_fast_tasks<16>, grid, dim3(64), fast_lds_bytes(P, 0), st, P, 0);
+  bool pairs = false;
+  for (int l = 0; l < P.nlevels; l++) pairs = pairs || P.lv[l].fastW != P.lv[l].wCell;
+  if (pairs)
+    hipLaunchKernelGGL((k_fast_tasks<16, true>), grid, dim3(64), fast_lds_bytes(P, 0), st, P, 0);
+  else
+    hipLaunchKernelGGL((k_fast_tasks<16, false>), grid, dim3(64), fast_lds_bytes(P, 0), st, P, 0);
 }
 
 }  // namespace orbfe

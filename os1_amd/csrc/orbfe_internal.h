@@ -88,8 +88,13 @@ struct ConeParams {
 };
 
 #ifdef __HIPCC__
+// Level-0 pointer of frame f, in SCALAR registers (f is uniform for a block): a lane-held base would turn every load
+// of the frame into 64-bit vector address arithmetic.
 __device__ __forceinline__ const uint8_t* level0_of(const PyramidParams& P, int f) {
-  return P.frame0 ? P.frame0[f] : P.frameInline[f & 1];
+  const uint8_t* p = P.frame0 ? P.frame0[f] : P.frameInline[f & 1];
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return reinterpret_cast<const uint8_t*>(((unsigned long long)hi << 32) | lo);
 }
 #endif
 

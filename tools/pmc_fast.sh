@@ -1,7 +1,7 @@
 # SQ / SQC counters of the FAST kernel for one setting of the environment (three --pmc passes over tools/quick_bench.py 32).
 # usage: bash tools/pmc_fast.sh <outdir> [ENV=VAL ...]
 cd /tmp && export TMPDIR=/tmp
-out=$1; shift
+out=${1:-/tmp/pmc_fast}; [ $# -gt 0 ] && shift
 for kv in "$@"; do export "$kv"; done
 rm -rf $out
 i=0
