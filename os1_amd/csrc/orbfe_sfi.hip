@@ -466,7 +466,7 @@ void launch_sfi_carry(const SfiParams& S, int lastFrame, SelKp* cSel, float* cAn
 void launch_sfi(const SfiParams& S, int nframes, hipStream_t st) {
   hipLaunchKernelGGL(k_sfi_sort, dim3(nframes), dim3(256), sizeof(int) * 3 * S.n0cap, st, S);
   hipLaunchKernelGGL(k_sfi_candidates, dim3(S.n0cap, nframes), dim3(64), 0, st, S);
-  static const bool seq = getenv("ORBFE_SFI_SEQUENTIAL") != nullptr;   // the serial replay, kept for A/B runs
+  const bool seq = getenv("ORBFE_SFI_SEQUENTIAL") != nullptr;   // the serial replay, kept for A/B runs and tests
   if (seq) {
     hipLaunchKernelGGL(k_sfi_resolve_seq, dim3(nframes), dim3(64), sizeof(int) * (5 * S.n0cap + 32), st, S);
     return;

@@ -547,3 +547,71 @@ def test_fast_cell_pairs_variant_bit_exact(api, oracle, monkeypatch):
             c, oc = ex.candidates(l), ox.candidates(l)
             assert len(c) == len(oc), (seed, l)
             assert (c[:, 0] == oc['x']).all() and (c[:, 1] == oc['y']).all() and (c[:, 2] == oc['response']).all(), (seed, l)
+
+
+def test_latency_path_variants_agree(api, oracle, monkeypatch):
+    """One- and two-frame calls take their own kernels (k_pyramid_cone, LDS-resident quadtree candidates, results written
+    straight to the host arena, level-0 pointers in the kernel arguments).  Every switch of that path, alone and
+    together, reproduces the oracle: cone tile sizes, the per-level pyramid kernels, candidates in HBM, the copied
+    result arena."""
+    cases = [(31, 1920, 1080, 2000, 1.2, 8), (32, 641, 479, 700, 1.2, 8), (33, 1280, 720, 1200, 1.3, 5), (34, 500, 400, 300, 1.5, 3),
+             (35, 900, 500, 400, 2.0, 3)]      # scale 2.0: outside the cone kernel's range, per-level kernels by themselves
+    settings = [{}, {'ORBFE_CONE_MAX_FRAMES': '0'}, {'ORBFE_QT_LDS_BYTES': '0'}, {'ORBFE_ZERO_COPY': '0'}, {'ORBFE_CONE_TILE': '16'},
+                {'ORBFE_CONE_TILE': '48'}, {'ORBFE_QT_LDS_BYTES': '20000'},
+                {'ORBFE_CONE_MAX_FRAMES': '0', 'ORBFE_QT_LDS_BYTES': '0', 'ORBFE_ZERO_COPY': '0'}]
+    for seed, W, H, N, sf, nl in cases:
+        img = synth(seed, W, H)
+        img2 = shifted(img, 5, 3, seed + 100)
+        ox = OracleExtractor(N, sf, nl, 20, 7, oracle)
+        want, want2 = ox.extract(img), ox.extract(img2)
+        for env in settings:
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            ex = api.Extractor(N, sf, nl, 20, 7)
+            _cmp_extract(ex(img), want)
+            dev = api.DeviceFrames([img, img2], 0)
+            kps, desc, n = ex.extract_batch_ptrs(dev.ptrs, H, W, dev.stride, True)
+            _cmp_extract((kps[0, :n[0]], desc[0, :n[0]]), want)
+            _cmp_extract((kps[1, :n[1]], desc[1, :n[1]]), want2)
+            for k in env:
+                monkeypatch.delenv(k)
+
+
+@pytest.mark.parametrize('seq', ['0', '1'])
+def test_stream_matching_dense_clusters(api, oracle, seq, monkeypatch):
+    """SearchForInitialization bookkeeping under stress: many level-0 keypoints in a small image, a window that covers a
+    large part of it and nnratio 1.0, so that almost every query finds a match, keypoints are taken away from earlier
+    queries all the time (ORBmatcher.cc:455-466) and the dependency chains between queries are long.  k_sfi_resolve
+    iterates the bookkeeping to its fixed point; ORBFE_SFI_SEQUENTIAL=1 replays it serially.  Both equal the oracle."""
+    if seq == '1':
+        monkeypatch.setenv('ORBFE_SFI_SEQUENTIAL', '1')
+    W, H, N, nl, B = 420, 300, 1500, 2, 3
+    base = synth(81, W, H)
+    frames = [base] + [shifted(base, (3 * i) % 7 - 3, (5 * i) % 5 - 2, 800 + i) for i in range(1, 2 * B)]
+    dev = api.DeviceFrames(frames, 0)
+    ox = OracleExtractor(N, 1.2, nl, 20, 7, oracle)
+    want = [ox.extract(f) for f in frames]
+    bounds = (0.0, float(W), 0.0, float(H))
+    total = 0
+    for window, ratio, ori in ((150, 1.0, True), (60, 0.95, False), (400, 1.0, True)):
+        st = api.Stream(N, 1.2, nl, 20, 7, 0, B, 2)
+        st.set_matching(bounds, window, ratio, ori)
+        for b in range(2):
+            st.push_ptrs(dev.ptrs[b * B:(b + 1) * B], H, W, dev.stride, True)
+        for b in range(2):
+            kps, desc, n, m12, nm = st.pop(copy=True)
+            for i in range(B):
+                g = b * B + i
+                wk, wd = want[g]
+                assert n[i] == len(wk) and kps[i, :n[i]].tobytes() == wk.tobytes() and desc[i, :n[i]].tobytes() == wd.tobytes()
+                if g == 0:
+                    continue
+                pk, pd = want[g - 1]
+                on, om12, _ = oracle.search_for_initialization(pk, pd, wk, wd, bounds, np.stack([pk['x'], pk['y']], 1).reshape(-1, 2),
+                                                               window, ratio, ori)
+                assert nm[i] == on and (m12[i, :len(pk)] == om12).all(), (window, g)
+                total += on
+        st.close()
+    assert total > 1000
+    if seq == '1':
+        monkeypatch.delenv('ORBFE_SFI_SEQUENTIAL')
