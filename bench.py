@@ -218,6 +218,8 @@ def run_rank(args):
         if have_torch_gpu:
             torch.cuda.synchronize()
 
+    host_cpu = [0.0]
+
     def timed(nsteps, nwarm, source):
         run(nwarm * subs, source)
         del pop_times[:]
@@ -228,8 +230,10 @@ def run_rank(args):
         if dist is not None:
             dist.barrier()
         t0 = time.perf_counter()
+        c0 = time.process_time()
         run(nsteps * subs, source)
         sync()
+        host_cpu[0] = time.process_time() - c0      # CPU seconds of this rank's threads inside the timed region
         if dist is not None:
             dist.barrier()
         el = time.perf_counter() - t0
@@ -252,6 +256,7 @@ def run_rank(args):
 
     head_source = {'pinned': 'pinned', 'pageable': 'pageable', None: 'hbm'}[args.host_input]
     elapsed = timed(args.steps, args.warmup, head_source)
+    head_cpu = host_cpu[0]
     kms, kbatches, kframes = st.kernel_ms()
     wstats = st.stats()
     head_pops = np.array(pop_times)
@@ -332,6 +337,9 @@ def run_rank(args):
                                         zip(('pyramid', 'fast_cells', 'compaction', 'describe', 'quadtree'), kms) if v > 0},
             'ms_per_step_percentiles': (lambda d: {'p10': round(float(np.percentile(d, 10)), 4), 'p50': round(float(np.percentile(d, 50)), 4),
                                                     'p90': round(float(np.percentile(d, 90)), 4), 'max': round(float(d.max()), 4)})(step_ms) if step_ms is not None and len(step_ms) > 1 else None,
+            # CPU time of rank 0's threads over the timed region / its wall time: what a rank needs from the host when
+            # N ranks share the box's cores (Python driver + the stream runner's worker threads)
+            'host_cpu_cores_used_rank0': round(head_cpu / max(elapsed, 1e-9), 2),
             'host_worker_ms_per_submission': {'submit': round(wstats[0] / max(wstats[3], 1), 4), 'collect_incl_gpu_wait': round(wstats[1] / max(wstats[3], 1), 4)},
             'roofline': {'kernel': 'k_fast_tasks', 'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
