@@ -24,6 +24,7 @@ for it in range(R):
     acc += ex.stage_ms()
 dt = time.time() - t
 km, kb, kf = ex.kernel_ms()
-print('gpu us/frame: pyramid %.1f fast %.1f compact %.1f describe %.1f quadtree %.1f' % tuple(km / kf * 1e3))
+if kf and len(sys.argv) > 2:   # per-kernel events are recorded with profiling on and batches of more than two frames
+    print('gpu us/frame: pyramid %.1f fast %.1f compact %.1f describe %.1f quadtree %.1f' % tuple(km / kf * 1e3))
 print('B=%d  %.2f ms/batch  %.1f fps  host(ms) wait1=%.2f quadtree=%.2f wait2=%.2f assemble=%.2f total=%.2f  n=%s' % (
     B, dt / R * 1e3, B * R / dt, *(acc / R), n[:4]))
