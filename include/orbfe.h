@@ -108,6 +108,14 @@ int orbfe_extractor_max_keypoints(const orbfe_extractor* h);
  * than 4.5 : 1 or to size buffers tightly. */
 int orbfe_extractor_max_keypoints_for_size(const orbfe_extractor* h, int rows, int cols);
 
+/* How orbfe_extract_batch_collect* (and the blocking calls built on it) wait for the GPU.  poll_us = 0 (default): the
+ * runtime's own wait, which spins -- lowest latency, one busy host core per waiting thread.  poll_us > 0: poll the
+ * stream and sleep poll_us microseconds between polls; the result arrives up to poll_us later and the core is free in
+ * between.  The stream runner (orbfe_stream_*) sets 50 on its handles (ORBFE_POLL_WAIT_US overrides): with several
+ * batches in flight the delay is hidden and a rank of a multi-GPU run needs 1.5 instead of 2 host cores.  Not allowed
+ * between a submit and its collect. */
+int orbfe_extractor_set_wait_mode(orbfe_extractor* h, int poll_us);
+
 /* Colour input (Tracking::GrabImageMonocular, src/Tracking.cc:96-109: cvtColor(RGB2GRAY / BGR2GRAY) on 3- and
  * 4-channel images before the Frame is built).  After this call `gray` in the extract calls points to interleaved
  * 8-bit pixels of the given format (stride in bytes, cols in pixels); the conversion runs on the GPU in front of the

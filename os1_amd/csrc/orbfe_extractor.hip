@@ -7,6 +7,7 @@
 // geometries the kernel does not hold (more than 4 roots or 2044 features per level) and
 // ORBFE_HOST_QUADTREE=1.  There is no CPU fallback for the kernels.
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 #include <sched.h>
 
 #include <algorithm>
@@ -215,6 +216,7 @@ struct orbfe_extractor {
   ConeParams cone{};
   bool coneOk = false;
   int qtLdsBudget = 120 * 1024;   // LDS bytes a quadtree problem may use for its candidates in small batches
+  int pollWaitUs = 0;             // > 0: collect polls the stream and sleeps this long between polls
   bool zeroCopyOut = true;        // small plain batches: results written to host memory by the kernels
   int coneTile = 0;        // tile edge on the top level (0 = chosen from the level's size)
   int coneMaxFrames = 2;   // batches up to this size build the pyramid with k_pyramid_cone
@@ -848,6 +850,11 @@ struct orbfe_extractor {
     hipStream_t st = streams[0];
     const double t0 = tSubmit0, t1 = tSubmit1;
     const double t1b = now_ms();
+    if (pollWaitUs > 0) {   // sleep-poll instead of the runtime's spinning wait (pipelined callers: the wake-up delay is hidden)
+      hipError_t q;
+      while ((q = hipStreamQuery(st)) == hipErrorNotReady) usleep((useconds_t)pollWaitUs);
+      if (q != hipSuccess) HIP_TRY(q);
+    }
     HIP_TRY(hipStreamSynchronize(st));
     const double t2 = now_ms();
     {
@@ -1239,6 +1246,13 @@ int orbfe_debug_h2d_rate(int device_id, const void* host, size_t bytes, int reps
   return rc;
 }
 
+int orbfe_extractor_set_wait_mode(orbfe_extractor* h, int poll_us) {
+  if (!h || poll_us < 0) { set_err("bad wait mode"); return ORBFE_ERR_INVALID; }
+  if (h->pendingFrames) { set_err("a submitted batch has not been collected yet"); return ORBFE_ERR_INVALID; }
+  h->pollWaitUs = poll_us;
+  return ORBFE_OK;
+}
+
 int orbfe_extractor_set_input_format(orbfe_extractor* h, int format, int gray_variant) {
   if (!h || format < ORBFE_INPUT_GRAY8 || format > ORBFE_INPUT_BGRA8 || (gray_variant != ORBFE_GRAY_Q15 && gray_variant != ORBFE_GRAY_Q14)) {
     set_err("bad input format");
@@ -1335,6 +1349,7 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
   if (const char* hv = getenv("ORBFE_HOST_QUADTREE")) h->gpuQuadtree = atoi(hv) == 0;
   if (const char* pv = getenv("ORBFE_FAST_PAIRS")) h->pairCells = atoi(pv) != 0;
   if (const char* cv = getenv("ORBFE_CONE_MAX_FRAMES")) h->coneMaxFrames = atoi(cv);
+  if (const char* pv = getenv("ORBFE_POLL_WAIT_US")) h->pollWaitUs = atoi(pv);
   if (const char* zv = getenv("ORBFE_ZERO_COPY")) h->zeroCopyOut = atoi(zv) != 0;
   if (const char* qv = getenv("ORBFE_QT_LDS_BYTES")) h->qtLdsBudget = atoi(qv);
   if (const char* cv = getenv("ORBFE_CONE_TILE")) h->coneTile = atoi(cv) <= 0 ? 0 : std::max(8, atoi(cv)) & ~3;

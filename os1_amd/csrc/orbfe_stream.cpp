@@ -12,6 +12,8 @@
 // Everything the GPU computes goes through the same entry points a single-frame caller uses
 // (orbfe_extract_batch_submit/_collect, orbfe_search_for_initialization_batch), so results are
 // identical to calling those one by one.
+#include <pthread.h>
+
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
@@ -258,6 +260,7 @@ int orbfe_stream_create(int nfeatures, float scaleFactor, int nlevels, int iniTh
   for (int d = 0; d < depth; d++) {
     orbfe_extractor* h = nullptr;
     int rc = orbfe_extractor_create(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device_id, &h);
+    if (rc == ORBFE_OK && !getenv("ORBFE_POLL_WAIT_US")) rc = orbfe_extractor_set_wait_mode(h, 50);   // the runner pipelines: do not burn a core on waiting
     if (rc != ORBFE_OK) {
       for (auto* e : s->ext) orbfe_extractor_destroy(e);
       delete s;
@@ -307,8 +310,8 @@ int orbfe_stream_create(int nfeatures, float scaleFactor, int nlevels, int iniTh
     sl.prevxy.resize((size_t)batch * s->cap * 2);
     s->freeQ.push_back(i);
   }
-  s->tExtract = std::thread([s] { s->extractLoop(); });
-  for (int w = 0; w < nMatch; w++) s->tMatch.emplace_back([s, w] { s->matchLoop(w); });
+  s->tExtract = std::thread([s] { pthread_setname_np(pthread_self(), "orbfe-runner"); s->extractLoop(); });
+  for (int w = 0; w < nMatch; w++) s->tMatch.emplace_back([s, w] { pthread_setname_np(pthread_self(), "orbfe-match"); s->matchLoop(w); });
   *out = s;
   return ORBFE_OK;
 }

@@ -19,7 +19,7 @@ prev, tp = sample(), time.time()
 while p.poll() is None:
     time.sleep(2)
     cur, tc = sample(), time.time()
-    rows = [(cur[t][0], round((cur[t][1] - prev[t][1]) / hz / (tc - tp), 2)) for t in cur if t in prev]
+    rows = [(cur[t][0] + ('(main)' if int(t) == p.pid else ''), round((cur[t][1] - prev[t][1]) / hz / (tc - tp), 2)) for t in cur if t in prev]
     tot = sum(r[1] for r in rows)
     if best is None or tot > best[0]: best = (tot, [r for r in rows if r[1] > 0.02])
     prev, tp = cur, tc
