@@ -806,7 +806,10 @@ __global__ __launch_bounds__(64) void k_describe(PyramidParams P, const SelKp* _
 
   const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
   float a, b;
-  sincosf_glibc(angle * factorPI, &b, &a);  // a = cos, b = sin
+  // the angle is the same in every lane (wave sums): as a scalar, the range tests inside sincosf become uniform
+  // branches and only the polynomials of the taken path are evaluated (they are double precision: half rate)
+  const float rad = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, angle * factorPI)));
+  sincosf_glibc(rad, &b, &a);  // a = cos, b = sin
   const uint8_t* center = blT + kBlurRad * kBPT + kBlurRad;   // center[x * kBPT + y]
   unsigned long long words[4];
 #pragma unroll
