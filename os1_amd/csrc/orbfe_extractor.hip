@@ -183,7 +183,7 @@ struct orbfe_extractor {
   hipEvent_t evFront = nullptr;   // end of this handle's last front (FrontLane)
   hipEvent_t evPyr = nullptr;     // end of this handle's last pyramid (FrontLane, two-link mode)
   bool frontSplit = true;         // pyramid and FAST are separate links of the chain (ORBFE_FRONT_SPLIT=0: one link)
-  bool frontLane = true;          // ORBFE_FRONT_LANE=0 disables the chaining
+  bool frontLane = false;         // ORBFE_FRONT_LANE=1 chains the fronts of consecutive batches (default until the pyramid got 40 % cheaper)
   hipEvent_t evFrame0 = nullptr, evS1[kMaxSub] = {};
   int subSel[kMaxSub] = {};
   size_t candHostCap = 0;
