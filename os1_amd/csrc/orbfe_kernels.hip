@@ -5,6 +5,9 @@
 //
 //   k_to_gray       cv::cvtColor RGB/BGR(A) -> gray, 8u fixed point (colour input only)
 //   k_resize        cv::resize INTER_LINEAR 8u (level l <- level l-1), 11-bit fixed point, separable through LDS
+//   k_resize_fixed  the same with the LDS geometry fixed at compile time (every level at scale 1.2): the kernel that runs
+//   k_pyramid_cone  all levels in one launch for one- and two-frame calls (a block walks down the dependency cone of a
+//                   top-level tile)
 //   (k_fast_tasks   per reference FAST cell, one wave per cell pair: orbfe_fast.hip)
 //   k_compact       ordered compaction of the per-cell slots into the reference's candidate order (1 lane/cell)
 //   k_describe      per keypoint (1 wave): IC-angle (dot4), 7x7 fixed-point Gaussian of the 37x37 neighbourhood
