@@ -61,6 +61,8 @@ def parse_args():
     ap.add_argument('--host-input', nargs='?', const='pageable', default=None, choices=['pageable', 'pinned'],
                     help='headline leg from HOST frames instead (developer aid; never the contract value)')
     ap.add_argument('--depth', type=int, default=3, help='extraction batches in flight inside the stream runner')
+    ap.add_argument('--prewarm-seconds', type=float, default=1.5,
+                    help='untimed stream work in front of the W warm-up steps (a box that has just been started runs its first second slower: clocks, first-touch pages)')
     ap.add_argument('--plumbing-only', action='store_true',
                     help='CPU test aid for the N>1 control plane: rendezvous, barrier, max-over-ranks and the JSON line with NO '
                          'hot-path work and no value (tests/test_multiproc.py); never a measurement')
@@ -220,6 +222,11 @@ def run_rank(args):
 
     host_cpu = [0.0]
 
+    def prewarm(source, seconds):
+        t_end = time.perf_counter() + seconds
+        while time.perf_counter() < t_end:
+            run(subs, source)
+
     def timed(nsteps, nwarm, source):
         run(nwarm * subs, source)
         del pop_times[:]
@@ -255,6 +262,8 @@ def run_rank(args):
             verify['verified'] = int(flag[0]) == world
 
     head_source = {'pinned': 'pinned', 'pageable': 'pageable', None: 'hbm'}[args.host_input]
+    if args.prewarm_seconds > 0:
+        prewarm(head_source, args.prewarm_seconds)
     elapsed = timed(args.steps, args.warmup, head_source)
     head_cpu = host_cpu[0]
     kms, kbatches, kframes = st.kernel_ms()
