@@ -197,12 +197,16 @@ def run_rank(args):
     nmatch_total = [0]
     pop_times = []
 
+    # batches pushed ahead of the pops: `depth` are on the GPU, the rest wait in the runner's queue, so that a hiccup of this
+    # (Python) thread does not drain the GPU -- such hiccups of 4-8 ms happen about once a second on the test boxes
+    lookahead = int(os.environ.get('ORBFE_BENCH_LOOKAHEAD', args.depth + 11))
+
     def run(nbatches, source, on_pop=None):
         """nbatches submissions through the runner: push (async extraction + SearchForInitialization of every frame
-        against its predecessor on the GPU), pop keypoints / descriptors / matches in host memory.  Up to depth+2
+        against its predecessor on the GPU), pop keypoints / descriptors / matches in host memory.  Up to `lookahead`
         batches are in the pipeline; every push and pop of the nbatches batches is inside this call."""
         pushed = 0
-        while pushed < min(args.depth + 2, nbatches):
+        while pushed < min(lookahead, nbatches):
             push(source)
             pushed += 1
         for _ in range(nbatches):
