@@ -198,8 +198,8 @@ def run_rank(args):
     pop_times = []
 
     # batches pushed ahead of the pops: `depth` are on the GPU, the rest wait in the runner's queue, so that a hiccup of this
-    # (Python) thread does not drain the GPU -- such hiccups of 4-8 ms happen about once a second on the test boxes
-    lookahead = int(os.environ.get('ORBFE_BENCH_LOOKAHEAD', args.depth + 11))
+    # (Python) thread does not drain the GPU -- such hiccups of 4-12 ms happen about once a second on some test boxes
+    lookahead = int(os.environ.get('ORBFE_BENCH_LOOKAHEAD', args.depth + 27))
 
     def run(nbatches, source, on_pop=None):
         """nbatches submissions through the runner: push (async extraction + SearchForInitialization of every frame

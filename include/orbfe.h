@@ -235,7 +235,7 @@ int orbfe_stream_bow_raw(orbfe_stream* s, int frame, const uint32_t** leaf_node,
 /* Per-frame output capacity (keypoints) of the arrays returned by orbfe_stream_pop. */
 int orbfe_stream_capacity(const orbfe_stream* s);
 /* Enqueue one batch (`batch` frame pointers; device pointers if in_device_memory != 0).  Returns at once
- * unless depth+12 batches are already queued (ORBFE_STREAM_SLOTS changes the number of result slots).  The frames must stay valid until their batch is popped. */
+ * unless depth+28 batches are already queued (ORBFE_STREAM_SLOTS changes the number of result slots).  The frames must stay valid until their batch is popped. */
 int orbfe_stream_push(orbfe_stream* s, const uint8_t* const* gray, int in_device_memory, int rows, int cols,
                       size_t stride_bytes);
 /* Wait for the oldest batch; ORBFE_ERR_INVALID if no pushed batch is outstanding.  Output pointers stay valid until

@@ -299,8 +299,9 @@ int orbfe_stream_create(int nfeatures, float scaleFactor, int nlevels, int iniTh
   s->cap = orbfe_extractor_max_keypoints(s->ext[0]);
   // result slots: `depth` batches on the GPU, one in the caller's hands, the rest queued in front of the worker.  A deep
   // queue is what keeps the GPU fed when the CALLER's thread is held up for a few milliseconds (seen about once a second
-  // on the test boxes): 12 queued batches are 6 ms of GPU work at 1080p.
-  int nslots = depth + 13;
+  // on the test boxes, up to 12 ms long): 28 queued batches are 15 ms of GPU work at 1080p.  A slot is host memory only
+  // (4 MB at 1080p / 2000 features / 32 frames).
+  int nslots = depth + 29;
   if (const char* sv = getenv("ORBFE_STREAM_SLOTS")) nslots = std::max(depth + 2, atoi(sv));
   s->slots.resize(nslots);
   for (int i = 0; i < nslots; i++) {
