@@ -200,6 +200,8 @@ def run_rank(args):
     # batches pushed ahead of the pops: `depth` are on the GPU, the rest wait in the runner's queue, so that a hiccup of this
     # (Python) thread does not drain the GPU -- such hiccups of 4-12 ms happen about once a second on some test boxes
     lookahead = int(os.environ.get('ORBFE_BENCH_LOOKAHEAD', args.depth + 27))
+    st.set_queue_slots(lookahead + 2)          # the library's default queue is short (depth + 4 slots)
+    lookahead = min(lookahead, st.queue_slots() - 2)   # never more ahead than the runner can hold (push would block forever)
 
     def run(nbatches, source, on_pop=None):
         """nbatches submissions through the runner: push (async extraction + SearchForInitialization of every frame
@@ -428,9 +430,10 @@ def cpu_baseline(frames, nframes, do_match):
 
 def cpu_baseline_all_cores(frames, do_match):
     """The same oracle on EVERY host core: one extractor instance per core over independent
-    pieces of the stream, 4 consecutive frames each, every frame matched against its predecessor.  Worker processes
-    of 4 threads (tools/cpu_oracle_worker.py); they start together at a wall-clock instant and the rate is frames
-    over the time until the last one finishes."""
+    pieces of the stream, 16 consecutive frames each, every frame matched against its predecessor.  Worker processes
+    of 4 threads (tools/cpu_oracle_worker.py) start together at a wall-clock instant; every worker reports its own
+    start and end, `value` = sum of the workers' own rates (a worker that was ready late does not stretch the others'
+    clocks), `wall_value` = all frames over first start .. last end.  A failed worker fails the leg (reported)."""
     import tempfile
     import numpy as np
     try:
@@ -454,7 +457,7 @@ def cpu_baseline_all_cores(frames, do_match):
     visible = cores
     if quota:
         cores = min(cores, quota)
-    tpp, per = 4, 4
+    tpp, per = 4, 16
     nproc = max(1, cores // tpp)
     shm = '/dev/shm' if os.path.isdir('/dev/shm') else tempfile.gettempdir()
     path = os.path.join(shm, 'orbfe_cpu_frames_%d.npy' % os.getpid())
@@ -464,25 +467,30 @@ def cpu_baseline_all_cores(frames, do_match):
         procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tools', 'cpu_oracle_worker.py'), path, str(p * tpp * per),
                                    str(tpp), str(per), repr(t0), str(int(do_match))], stdout=subprocess.PIPE, text=True,
                                   env=dict(os.environ, OMP_NUM_THREADS='1')) for p in range(nproc)]
-        ends, total = [], 0
+        starts, ends, total, rate, failed = [], [], 0, 0.0, 0
         for p in procs:
             out, _ = p.communicate()
-            if p.returncode == 0 and out.strip():
-                te, nf = out.split()
+            if p.returncode == 0 and len(out.split()) == 3:
+                ts, te, nf = out.split()
+                starts.append(float(ts))
                 ends.append(float(te))
                 total += int(nf)
-        if not ends:
-            return None
-        dt = max(ends) - t0
+                rate += int(nf) / max(float(te) - float(ts), 1e-9)
+            else:
+                failed += 1
+        if failed or not ends:
+            return {'error': '%d of %d oracle workers failed' % (failed, nproc), 'cores': nproc * tpp, 'kind': 'port'}
+        dt = max(ends) - min(starts)
     finally:
         try:
             os.unlink(path)
         except OSError:
             pass
-    return {'value': round(total / dt, 2), 'unit': 'frames/s', 'cores': nproc * tpp, 'kind': 'port',
-            'cpus_visible': visible, 'cgroup_cpu_quota': quota,
+    return {'value': round(rate, 2), 'wall_value': round(total / dt, 2), 'unit': 'frames/s', 'cores': nproc * tpp,
+            'kind': 'port', 'cpus_visible': visible, 'cgroup_cpu_quota': quota,
+            'start_skew_s': round(max(starts) - min(starts), 3),
             'sample': '%d processes x %d threads x %d consecutive frames, extract%s, %.1f s' % (
-                nproc, tpp, per, '+SearchForInitialization (3 of 4 frames have a predecessor)' if do_match else '', dt)}
+                nproc, tpp, per, '+SearchForInitialization (15 of 16 frames have a predecessor)' if do_match else '', dt)}
 
 
 if __name__ == '__main__':

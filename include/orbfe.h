@@ -188,8 +188,10 @@ int orbfe_debug_stage_ms(const orbfe_extractor* h, float out[5]);
  * reset: out_ms[0]=pyramid (k_resize x (nlevels-1)), [1]=k_fast_tasks, [2]=k_compact,
  * [3]=k_describe, [4]=k_quadtree; *batches = launches of each group, *frames = frames processed. */
 int orbfe_debug_kernel_ms(orbfe_extractor* h, double out_ms[5], long long* batches, long long* frames, int reset);
-/* k_fast_cells (the dominant kernel) is always timed; enable != 0 also times the other groups, at the
- * price of an event (a few microseconds of stream gap) between them.  Env: ORBFE_PROFILE_KERNELS=1. */
+/* k_fast_tasks (the dominant kernel) is timed in every call of MORE than ORBFE_CONE_MAX_FRAMES (default 2) frames;
+ * calls with one or two frames take the latency route, which records no events (each costs a dependent-launch gap),
+ * so orbfe_debug_kernel_ms reports frames = 0 for them.  enable != 0 also times the other groups, at the price of an
+ * event (a few microseconds of stream gap) between them.  Env: ORBFE_PROFILE_KERNELS=1. */
 int orbfe_debug_set_profiling(orbfe_extractor* h, int enable);
 /* Device-side restatement of (cosf, sinf)(angle_deg * pi/180) used by the rBRIEF kernel, evaluated
  * on the GPU for n angles (parity test against host libm). */
@@ -234,8 +236,16 @@ int orbfe_stream_set_vocabulary(orbfe_stream* s, orbfe_vocabulary* v, int levels
 int orbfe_stream_bow_raw(orbfe_stream* s, int frame, const uint32_t** leaf_node, const uint32_t** level_node, int* n);
 /* Per-frame output capacity (keypoints) of the arrays returned by orbfe_stream_pop. */
 int orbfe_stream_capacity(const orbfe_stream* s);
-/* Enqueue one batch (`batch` frame pointers; device pointers if in_device_memory != 0).  Returns at once
- * unless depth+28 batches are already queued (ORBFE_STREAM_SLOTS changes the number of result slots).  The frames must stay valid until their batch is popped. */
+/* Result slots of the runner = batches that can be pushed ahead of the pops before orbfe_stream_push blocks, plus 2
+ * (one is in the caller's hands after a pop, one is being filled).  Default depth+4; a caller whose own thread may be
+ * held up for milliseconds asks for more (only while no batch is in flight; the number never shrinks;
+ * depth+2 <= nslots <= 256).  A caller must never push more than orbfe_stream_queue_slots()-2 batches ahead of its
+ * pops from the popping thread: no slot could become free and the push would wait forever. */
+int orbfe_stream_set_queue_slots(orbfe_stream* s, int nslots);
+int orbfe_stream_queue_slots(const orbfe_stream* s);
+/* Enqueue one batch (`batch` frame pointers; device pointers if in_device_memory != 0).  Returns at once unless every
+ * result slot is taken (see orbfe_stream_set_queue_slots; the environment variable ORBFE_STREAM_SLOTS sets the initial
+ * number).  The frames must stay valid until their batch is popped. */
 int orbfe_stream_push(orbfe_stream* s, const uint8_t* const* gray, int in_device_memory, int rows, int cols,
                       size_t stride_bytes);
 /* Wait for the oldest batch; ORBFE_ERR_INVALID if no pushed batch is outstanding.  Output pointers stay valid until

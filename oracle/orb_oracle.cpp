@@ -30,6 +30,7 @@
 //
 // Citations "ORBextractor.cc:NNN" etc. are relative to /root/reference/src.
 
+#include <dlfcn.h>
 #include <algorithm>
 #include <cfloat>
 #include <climits>
@@ -1095,54 +1096,37 @@ void* orc_vocab_create(int k, int L, int scoring, int weighting, const uint8_t* 
 }
 void orc_vocab_destroy(void* h) { delete (BowVocabulary*)h; }
 
-// transform(features, v, fv, levelsup).  Outputs: BowVector as (ascending word id, value) pairs; FeatureVector as
-// ascending node ids with CSR offsets into the feature-index list; per-feature word / node / weight for debugging.
-int orc_bow_transform(void* h, const uint8_t* desc, int n, int levelsup, uint32_t* bow_ids, double* bow_vals,
-                      int* n_words, uint32_t* fv_nodes, uint32_t* fv_off, uint32_t* fv_feat, int* n_fv,
-                      uint32_t* word_of_feature, uint32_t* node_of_feature) {
-  const BowVocabulary& V = *(BowVocabulary*)h;
+// Accumulation half of transform(features, v, fv, levelsup) (TemplatedVocabulary.h:1136-1204): per-feature
+// (word id, weight, node id) -> BowVector / FeatureVector.  Two interchangeable implementations:
+//  * the restatement below (BowVector.cpp:34-90 addWeight / addIfNotExist / normalize, FeatureVector.cpp:31-46);
+//  * the REFERENCE'S OWN BowVector.cpp + FeatureVector.cpp, compiled from /root/reference into
+//    oracle/_ref/libdbow2_vec.so (oracle/Makefile, wrapper oracle/dbow2_ref_wrap.cpp) and switched in with
+//    orc_use_dbow2_ref().  tests/test_bow_oracle.py checks both against each other; tests/golden/vga_seed1_bow.npz
+//    is generated through the reference code (tools/gen_golden.py).
+typedef int (*BowAccumFn)(const uint32_t* word, const double* weight, const uint32_t* node, int n, int weighting,
+                          int must, int norm_l2, uint32_t* bow_ids, double* bow_vals, int* n_words, uint32_t* fv_nodes,
+                          uint32_t* fv_off, uint32_t* fv_feat, int* n_fv);
+static int bow_accumulate_restated(const uint32_t* word, const double* weight, const uint32_t* node, int n,
+                                   int weighting, int must, int norm_l2, uint32_t* bow_ids, double* bow_vals,
+                                   int* n_words, uint32_t* fv_nodes, uint32_t* fv_off, uint32_t* fv_feat, int* n_fv) {
   std::map<uint32_t, double> v;
   std::map<uint32_t, std::vector<unsigned>> fv;
-  const bool must = V.scoring != 5;                 // DotProductScoring does not normalise (ScoringObject.h:74-89)
-  const bool normL2 = V.scoring == 1;
-  if (V.nodes.size() > 1) {
-    for (int i = 0; i < n; i++) {
-      const uint8_t* feature = desc + 32 * (size_t)i;
-      // TemplatedVocabulary.h:1306-1347
-      const int nid_level = V.L - levelsup;
-      uint32_t nid = 0;
-      int final_id = 0, current_level = 0;
-      do {
-        ++current_level;
-        const std::vector<int>& nodes = V.nodes[final_id].children;
-        final_id = nodes[0];
-        double best_d = descriptor_distance(feature, V.nodes[final_id].descriptor);
-        for (size_t c = 1; c < nodes.size(); c++) {
-          double d = descriptor_distance(feature, V.nodes[nodes[c]].descriptor);
-          if (d < best_d) { best_d = d; final_id = nodes[c]; }
-        }
-        if (current_level == nid_level) nid = final_id;
-      } while (!V.nodes[final_id].isLeaf());
-      const uint32_t id = V.nodes[final_id].word_id;
-      const double w = V.nodes[final_id].weight;
-      if (word_of_feature) word_of_feature[i] = id;
-      if (node_of_feature) node_of_feature[i] = nid;
-      if (w > 0) {
-        if (V.weighting == 0 || V.weighting == 1) v[id] += w;   // addWeight
-        else v.insert({id, w});                                 // addIfNotExist
-        fv[nid].push_back(i);
-      }
-    }
-    if ((V.weighting == 0 || V.weighting == 1) && !v.empty() && !must) {
-      const double nd = v.size();
-      for (auto& e : v) e.second /= nd;
-    }
-    if (must) {
-      double norm = 0.0;
-      if (!normL2) { for (auto& e : v) norm += fabs(e.second); }
-      else { for (auto& e : v) norm += e.second * e.second; norm = sqrt(norm); }
-      if (norm > 0.0) for (auto& e : v) e.second /= norm;
-    }
+  const bool tf = weighting == 0 || weighting == 1;
+  for (int i = 0; i < n; i++) {
+    if (!(weight[i] > 0)) continue;                            // stopped word
+    if (tf) v[word[i]] += weight[i];                           // addWeight
+    else v.insert({word[i], weight[i]});                       // addIfNotExist
+    fv[node[i]].push_back(i);                                  // addFeature
+  }
+  if (tf && !v.empty() && !must) {
+    const double nd = v.size();
+    for (auto& e : v) e.second /= nd;
+  }
+  if (must) {
+    double norm = 0.0;
+    if (!norm_l2) { for (auto& e : v) norm += fabs(e.second); }
+    else { for (auto& e : v) norm += e.second * e.second; norm = sqrt(norm); }
+    if (norm > 0.0) for (auto& e : v) e.second /= norm;
   }
   int nw = 0;
   for (auto& e : v) { bow_ids[nw] = e.first; bow_vals[nw] = e.second; nw++; }
@@ -1157,6 +1141,59 @@ int orc_bow_transform(void* h, const uint8_t* desc, int n, int levelsup, uint32_
   fv_off[nn] = pos;
   *n_fv = nn;
   return 0;
+}
+static BowAccumFn g_bow_accum = bow_accumulate_restated;
+static void* g_dbow2_ref = nullptr;
+// Switch the accumulation to the reference's own code (path of oracle/_ref/libdbow2_vec.so), or back with NULL.
+// Returns 0 on success, -1 if the library or its entry point is missing.
+int orc_use_dbow2_ref(const char* so_path) {
+  if (!so_path) { g_bow_accum = bow_accumulate_restated; return 0; }
+  if (!g_dbow2_ref) g_dbow2_ref = dlopen(so_path, RTLD_NOW | RTLD_LOCAL);
+  if (!g_dbow2_ref) return -1;
+  BowAccumFn f = (BowAccumFn)dlsym(g_dbow2_ref, "dbow2ref_accumulate");
+  if (!f) return -1;
+  g_bow_accum = f;
+  return 0;
+}
+int orc_bow_accumulator_is_reference() { return g_bow_accum != bow_accumulate_restated; }
+
+// transform(features, v, fv, levelsup).  Outputs: BowVector as (ascending word id, value) pairs; FeatureVector as
+// ascending node ids with CSR offsets into the feature-index list; per-feature word / node for debugging.
+int orc_bow_transform(void* h, const uint8_t* desc, int n, int levelsup, uint32_t* bow_ids, double* bow_vals,
+                      int* n_words, uint32_t* fv_nodes, uint32_t* fv_off, uint32_t* fv_feat, int* n_fv,
+                      uint32_t* word_of_feature, uint32_t* node_of_feature) {
+  const BowVocabulary& V = *(BowVocabulary*)h;
+  const bool must = V.scoring != 5;                 // DotProductScoring does not normalise (ScoringObject.h:74-89)
+  const bool normL2 = V.scoring == 1;
+  *n_words = 0; *n_fv = 0; fv_off[0] = 0;
+  if (V.nodes.size() <= 1) return 0;                // empty(): v and fv stay clear (TemplatedVocabulary.h:1143-1146)
+  std::vector<uint32_t> word(n), node(n);
+  std::vector<double> weight(n);
+  for (int i = 0; i < n; i++) {
+    const uint8_t* feature = desc + 32 * (size_t)i;
+    // TemplatedVocabulary.h:1306-1347
+    const int nid_level = V.L - levelsup;
+    uint32_t nid = 0;
+    int final_id = 0, current_level = 0;
+    do {
+      ++current_level;
+      const std::vector<int>& nodes = V.nodes[final_id].children;
+      final_id = nodes[0];
+      double best_d = descriptor_distance(feature, V.nodes[final_id].descriptor);
+      for (size_t c = 1; c < nodes.size(); c++) {
+        double d = descriptor_distance(feature, V.nodes[nodes[c]].descriptor);
+        if (d < best_d) { best_d = d; final_id = nodes[c]; }
+      }
+      if (current_level == nid_level) nid = final_id;
+    } while (!V.nodes[final_id].isLeaf());
+    word[i] = V.nodes[final_id].word_id;
+    weight[i] = V.nodes[final_id].weight;
+    node[i] = nid;
+    if (word_of_feature) word_of_feature[i] = word[i];
+    if (node_of_feature) node_of_feature[i] = nid;
+  }
+  return g_bow_accum(word.data(), weight.data(), node.data(), n, V.weighting, must ? 1 : 0, normL2 ? 1 : 0, bow_ids,
+                     bow_vals, n_words, fv_nodes, fv_off, fv_feat, n_fv);
 }
 
 // ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) -- ORBmatcher.cc:154-283.
@@ -1503,8 +1540,12 @@ void decomposeScw(const float S[16], float Rcw[9], float tcw[3], float Ow[3]) {
   for (int i = 0; i < 3; i++) tcw[i] = st[i] * inv;           // Scw...col(3)/scw
   cvGemmT3(Rcw, tcw, -1.0, Ow);                                // -Rcw.t()*tcw
 }
-int predictScale(float maxDistance, float currentDist, float logScaleFactor) {   // MapPoint.cc:370-379
-  const float ratio = maxDistance / currentDist;
+// MapPoint::GetMinDistanceInvariance / GetMaxDistanceInvariance (MapPoint.cc:358-368): 0.8f / 1.2f times the RAW fields;
+// MapPoint::PredictScale (MapPoint.cc:370-379) divides the raw mfMaxDistance -- two different values, kept apart here.
+inline float minDistanceInvariance(const OrcPoints* P, int i) { return 0.8f * P->mfMinDistance[i]; }
+inline float maxDistanceInvariance(const OrcPoints* P, int i) { return 1.2f * P->mfMaxDistance[i]; }
+int predictScale(float mfMaxDistance, float currentDist, float logScaleFactor) {   // MapPoint.cc:370-379
+  const float ratio = mfMaxDistance / currentDist;
   return (int)ceilf(logf(ratio) / logScaleFactor);
 }
 bool isInImage(const OrcView* v, float x, float y) {   // KeyFrame.cc:678-681
@@ -1627,9 +1668,9 @@ int orc_sbp_keyframe(const OrcView* cur, const float Tcw[16], const OrcKp* kfKey
     if (v < cur->bounds[2] || v > cur->bounds[3]) continue;
     const float PO[3] = {x3Dw[0] - Ow[0], x3Dw[1] - Ow[1], x3Dw[2] - Ow[2]};
     float dist3D = (float)cvNorm3(PO);
-    const float maxDistance = P->maxDist[pMP], minDistance = P->minDist[pMP];
+    const float maxDistance = maxDistanceInvariance(P, pMP), minDistance = minDistanceInvariance(P, pMP);
     if (dist3D < minDistance || dist3D > maxDistance) continue;
-    int nPredictedLevel = predictScale(maxDistance, dist3D, cur->logScaleFactor);
+    int nPredictedLevel = predictScale(P->mfMaxDistance[pMP], dist3D, cur->logScaleFactor);
     const float radius = th * cur->scaleFactors[nPredictedLevel];
     const std::vector<size_t> vIndices2 = F.getFeaturesInArea(u, v, radius, nPredictedLevel - 1, nPredictedLevel + 1);
     if (vIndices2.empty()) continue;
@@ -1676,12 +1717,12 @@ int orc_sbp_scw(const OrcView* kf, const float Scw[16], const int32_t* points, i
     const float x = p3Dc[0] * invz, y = p3Dc[1] * invz;
     const float u = kf->fx * x + kf->cx, v = kf->fy * y + kf->cy;
     if (!isInImage(kf, u, v)) continue;
-    const float maxDistance = P->maxDist[pMP], minDistance = P->minDist[pMP];
+    const float maxDistance = maxDistanceInvariance(P, pMP), minDistance = minDistanceInvariance(P, pMP);
     const float PO[3] = {p3Dw[0] - Ow[0], p3Dw[1] - Ow[1], p3Dw[2] - Ow[2]};
     const float dist = (float)cvNorm3(PO);
     if (dist < minDistance || dist > maxDistance) continue;
     if (cvDot3(PO, P->normal + 3 * pMP) < 0.5 * dist) continue;
-    int nPredictedLevel = predictScale(maxDistance, dist, kf->logScaleFactor);
+    int nPredictedLevel = predictScale(P->mfMaxDistance[pMP], dist, kf->logScaleFactor);
     const float radius = th * kf->scaleFactors[nPredictedLevel];
     int bestDist;
     const int bestIdx = bestInWindow(G, kf, u, v, radius, nPredictedLevel, P->desc + 32 * (size_t)pMP, vpMatched, false, 256, bestDist);
@@ -1712,12 +1753,12 @@ int orc_fuse(const OrcView* kf, const float Tcw[16], const int32_t* cand, int nc
     const float x = p3Dc[0] * invz, y = p3Dc[1] * invz;
     const float u = kf->fx * x + kf->cx, v = kf->fy * y + kf->cy;
     if (!isInImage(kf, u, v)) continue;
-    const float maxDistance = P->maxDist[pMP], minDistance = P->minDist[pMP];
+    const float maxDistance = maxDistanceInvariance(P, pMP), minDistance = minDistanceInvariance(P, pMP);
     const float PO[3] = {p3Dw[0] - Ow[0], p3Dw[1] - Ow[1], p3Dw[2] - Ow[2]};
     const float dist3D = (float)cvNorm3(PO);
     if (dist3D < minDistance || dist3D > maxDistance) continue;
     if (cvDot3(PO, P->normal + 3 * pMP) < 0.5 * dist3D) continue;
-    int nPredictedLevel = predictScale(maxDistance, dist3D, kf->logScaleFactor);
+    int nPredictedLevel = predictScale(P->mfMaxDistance[pMP], dist3D, kf->logScaleFactor);
     const float radius = th * kf->scaleFactors[nPredictedLevel];
     int bestDist;
     const int bestIdx = bestInWindow(G, kf, u, v, radius, nPredictedLevel, P->desc + 32 * (size_t)pMP, nullptr, true, 256, bestDist);
@@ -1758,12 +1799,12 @@ int orc_fuse_scw(const OrcView* kf, const float Scw[16], const int32_t* points, 
     const float x = p3Dc[0] * invz, y = p3Dc[1] * invz;
     const float u = kf->fx * x + kf->cx, v = kf->fy * y + kf->cy;
     if (!isInImage(kf, u, v)) continue;
-    const float maxDistance = P->maxDist[pMP], minDistance = P->minDist[pMP];
+    const float maxDistance = maxDistanceInvariance(P, pMP), minDistance = minDistanceInvariance(P, pMP);
     const float PO[3] = {p3Dw[0] - Ow[0], p3Dw[1] - Ow[1], p3Dw[2] - Ow[2]};
     const float dist3D = (float)cvNorm3(PO);
     if (dist3D < minDistance || dist3D > maxDistance) continue;
     if (cvDot3(PO, P->normal + 3 * pMP) < 0.5 * dist3D) continue;
-    const int nPredictedLevel = predictScale(maxDistance, dist3D, kf->logScaleFactor);
+    const int nPredictedLevel = predictScale(P->mfMaxDistance[pMP], dist3D, kf->logScaleFactor);
     const float radius = th * kf->scaleFactors[nPredictedLevel];
     int bestDist;
     const int bestIdx = bestInWindow(G, kf, u, v, radius, nPredictedLevel, P->desc + 32 * (size_t)pMP, nullptr, false, INT_MAX, bestDist);
@@ -1816,10 +1857,10 @@ int orc_search_by_sim3(const OrcView* kf1, const float T1w[16], const int32_t* m
     const float x = p3Dc2[0] * invz, y = p3Dc2[1] * invz;
     const float u = kf1->fx * x + kf1->cx, v = kf1->fy * y + kf1->cy;   // fx.. of pKF1 (:1069-1072)
     if (!isInImage(kf2, u, v)) continue;
-    const float maxDistance = P->maxDist[pMP], minDistance = P->minDist[pMP];
+    const float maxDistance = maxDistanceInvariance(P, pMP), minDistance = minDistanceInvariance(P, pMP);
     const float dist3D = (float)cvNorm3(p3Dc2);
     if (dist3D < minDistance || dist3D > maxDistance) continue;
-    const int nPredictedLevel = predictScale(maxDistance, dist3D, kf2->logScaleFactor);
+    const int nPredictedLevel = predictScale(P->mfMaxDistance[pMP], dist3D, kf2->logScaleFactor);
     const float radius = th * kf2->scaleFactors[nPredictedLevel];
     int bestDist;
     const int bestIdx = bestInWindow(G2, kf2, u, v, radius, nPredictedLevel, P->desc + 32 * (size_t)pMP, nullptr, false, INT_MAX, bestDist);
@@ -1837,10 +1878,10 @@ int orc_search_by_sim3(const OrcView* kf1, const float T1w[16], const int32_t* m
     const float x = p3Dc1[0] * invz, y = p3Dc1[1] * invz;
     const float u = kf1->fx * x + kf1->cx, v = kf1->fy * y + kf1->cy;
     if (!isInImage(kf1, u, v)) continue;
-    const float maxDistance = P->maxDist[pMP], minDistance = P->minDist[pMP];
+    const float maxDistance = maxDistanceInvariance(P, pMP), minDistance = minDistanceInvariance(P, pMP);
     const float dist3D = (float)cvNorm3(p3Dc1);
     if (dist3D < minDistance || dist3D > maxDistance) continue;
-    const int nPredictedLevel = predictScale(maxDistance, dist3D, kf1->logScaleFactor);
+    const int nPredictedLevel = predictScale(P->mfMaxDistance[pMP], dist3D, kf1->logScaleFactor);
     const float radius = th * kf1->scaleFactors[nPredictedLevel];
     int bestDist;
     const int bestIdx = bestInWindow(G1, kf1, u, v, radius, nPredictedLevel, P->desc + 32 * (size_t)pMP, nullptr, false, INT_MAX, bestDist);

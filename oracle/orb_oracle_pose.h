@@ -29,8 +29,9 @@ typedef struct {
   int M;
   const float* pos;            /* 3M  GetWorldPos()                 */
   const float* normal;         /* 3M  GetNormal()                   */
-  const float* minDist;        /* M   GetMinDistanceInvariance()    */
-  const float* maxDist;        /* M   GetMaxDistanceInvariance()    */
+  const float* mfMinDistance;  /* M   raw field: GetMinDistanceInvariance() = 0.8f * it (MapPoint.cc:358-362) */
+  const float* mfMaxDistance;  /* M   raw field: GetMaxDistanceInvariance() = 1.2f * it (:364-368); PredictScale
+                                      divides THIS, not the invariance bound (:370-379) */
   const uint8_t* desc;         /* 32M GetDescriptor()               */
   uint8_t* bad;                /* M   isBad()            (in/out)   */
   int32_t* nObs;               /* M   Observations()     (in/out)   */

@@ -7,6 +7,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, 'liborb_oracle.so')
+# the reference's own DBoW2 BowVector.cpp + FeatureVector.cpp, built by oracle/Makefile where /root/reference exists
+DBOW2_REF_SO = os.path.join(_HERE, '_ref', 'libdbow2_vec.so')
 
 KP_DTYPE = np.dtype([('x', 'f4'), ('y', 'f4'), ('size', 'f4'), ('angle', 'f4'), ('response', 'f4'),
                      ('octave', 'i4'), ('class_id', 'i4')])
@@ -67,6 +69,7 @@ class Oracle:
         L.orc_vocab_create.restype = C.c_void_p
         L.orc_vocab_create.argtypes = [C.c_int] * 4 + [C.c_void_p, C.c_int]
         L.orc_vocab_destroy.argtypes = [C.c_void_p]
+        L.orc_use_dbow2_ref.argtypes = [C.c_char_p]
         L.orc_bow_transform.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 2 + \
             [C.POINTER(C.c_int)] + [C.c_void_p] * 3 + [C.POINTER(C.c_int)] + [C.c_void_p] * 2
         L.orc_search_by_bow.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] + \
@@ -77,6 +80,23 @@ class Oracle:
         L.orc_undistort_pinhole.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int]
         L.orc_image_bounds.argtypes = [C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p,
                                        C.c_int, C.c_void_p]
+
+    # ---- reference-built pieces --------------------------------------------------------------
+    def have_dbow2_ref(self):
+        return os.path.exists(DBOW2_REF_SO)
+
+    def use_dbow2_ref(self, on=True):
+        """Accumulate BowVector / FeatureVector through the reference's own DBoW2 code (oracle/_ref/libdbow2_vec.so)
+        instead of the restatement.  Process-wide switch of the oracle library; returns True if now active."""
+        if not on:
+            self.L.orc_use_dbow2_ref(None)
+            return False
+        if not self.have_dbow2_ref():
+            return False
+        return self.L.orc_use_dbow2_ref(DBOW2_REF_SO.encode()) == 0
+
+    def bow_accumulator_is_reference(self):
+        return bool(self.L.orc_bow_accumulator_is_reference())
 
     # ---- primitives -------------------------------------------------------------------------
     def fast_atan2(self, y, x):

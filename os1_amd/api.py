@@ -123,6 +123,8 @@ def load_library():
     L.orbfe_stream_destroy.restype = None
     L.orbfe_stream_set_matching.argtypes = [vp, vp, ci, cf, ci]
     L.orbfe_stream_capacity.argtypes = [vp]
+    L.orbfe_stream_set_queue_slots.argtypes = [vp, ci]
+    L.orbfe_stream_queue_slots.argtypes = [vp]
     L.orbfe_stream_push.argtypes = [vp, vp, ci, ci, ci, C.c_size_t]
     L.orbfe_stream_pop.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.orbfe_stream_stats.argtypes = [vp, vp, ci]
@@ -715,6 +717,13 @@ class Stream:
         self.h = h
         self.batch = batch
         self.cap = self.L.orbfe_stream_capacity(h)
+
+    def set_queue_slots(self, nslots):
+        """Result slots = batches that may be pushed ahead of the pops + 2 (default depth + 4)."""
+        _check(self.L.orbfe_stream_set_queue_slots(self.h, int(nslots)))
+
+    def queue_slots(self):
+        return int(self.L.orbfe_stream_queue_slots(self.h))
 
     def close(self):
         if getattr(self, 'h', None):

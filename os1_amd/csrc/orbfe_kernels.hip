@@ -13,6 +13,7 @@
 //   k_describe      per keypoint (1 wave): IC-angle (dot4), 7x7 fixed-point Gaussian of the 37x37 neighbourhood
 //                   (dot4 rows, dot2 columns), steered BRIEF with __ballot packing
 //   k_sincos        test hook for the device (cosf,sinf)
+#include <mutex>
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
@@ -897,9 +898,11 @@ void launch_to_gray(const uint8_t* const* raw, long long rawStride, const uint8_
 int launch_pyramid(const PyramidParams& P, int nframes, hipStream_t st, const ConeParams* cone) {
   const int last = cone ? cone->base : P.nlevels - 1;   // levels built one launch each
   if (cone) {
+    static std::mutex mu;            // see launch_qt3: check + set + record is one critical section
     static int attrBytes[64] = {};   // per device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1;
+    std::lock_guard<std::mutex> lk(mu);
     if (cone->ldsBytes > attrBytes[dev]) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_pyramid_cone), hipFuncAttributeMaxDynamicSharedMemorySize,
                               cone->ldsBytes) != hipSuccess)

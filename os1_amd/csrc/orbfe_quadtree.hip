@@ -23,6 +23,7 @@
 // one fully parallel sweep -- new node id through the previous pass's child table, quadrant in the new node, one LDS
 // atomic on the node's child counter -- and the final pick is an LDS atomic max on (score, lowest index) keys.
 // Creation order (seq) = processing order, n1..n4 inside a parent.
+#include <mutex>
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -287,9 +288,9 @@ __device__ __forceinline__ void qt3_problem(const QtParams& Q, Qt3Shared<CAP>& s
       auto loadStep = [&](int b) {   // the next step's candidates travel while the current step is processed
 #pragma unroll
         for (int j = 0; j < kQtEpt; j++) {
-          // not predicated: all loads of a step issue back to back.  LDS reads past the problem's candidates return
-          // stale or zero words that only ever feed other reads; HBM reads are clamped
-          const int p = LC ? b + j * kQt3Threads + tid : min(b + j * kQt3Threads + tid, n - 1);
+          // not predicated: all loads of a step issue back to back; the index is clamped to the last candidate in both
+          // modes (LDS-resident or HBM), so no read leaves the problem's arrays
+          const int p = min(b + j * kQt3Threads + tid, n - 1);
           owN[j] = ca.own(p);
           vN[j] = ca.cand(p);
         }
@@ -528,9 +529,13 @@ static int launch_qt3(const QtParams& Q, int nframes, hipStream_t st, int ldsBud
   if (ldsBudget >= 6 * 1024) ldsCand = (ldsBudget / 6) & ~3;
   const int dynBytes = ldsCand * 6;
   if (dynBytes) {
+    // handles on different host threads launch this kernel: the (check, set, record) sequence is one critical section,
+    // so nobody launches on the strength of a record whose hipFuncSetAttribute has not returned yet
+    static std::mutex mu;
     static int attrBytes[64] = {};   // per device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1;
+    std::lock_guard<std::mutex> lk(mu);
     if (dynBytes > attrBytes[dev]) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree3<CAP>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               dynBytes) != hipSuccess)

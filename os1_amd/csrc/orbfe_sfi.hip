@@ -299,7 +299,56 @@ __global__ __launch_bounds__(64) void k_sfi_resolve_seq(SfiParams S) {
 // or not (:468-478 push without ever removing).
 constexpr int kSfiThreads = 512;
 
-__global__ __launch_bounds__(kSfiThreads) void k_sfi_resolve(SfiParams S, int ldsPool) {
+// Serial replay of :430-466 by ONE wave, lanes over a query's candidates: the outcome M[i1] (i2 | dist << 16, -1 = none)
+// of every query in order, vMatchedDistance in `vmd`.  k_sfi_resolve falls back to it when the fixed point has not
+// settled after `maxRounds` rounds (adversarial inputs can need up to n1 + 1), so the worst case is one serial pass, as
+// it was before the fixed point existed.
+template <class PoolAt>
+__device__ void sfi_serial_outcomes(int lane, int n1, const int* pcnt, PoolAt poolAt, float nnratio, int* vmd, int* M) {
+  for (int i1 = 0; i1 < n1; i1++) {
+    const int cnt = pcnt[i1];
+    int bestDist = 0x7fffffff, bestDist2 = 0x7fffffff, bestIdx2 = -1;
+    for (int c0 = 0; c0 < cnt; c0 += 64) {
+      int d = 0x7fffffff, i2 = -1;
+      if (c0 + lane < cnt) {
+        const uint32_t entry = poolAt(i1, c0 + lane);
+        i2 = (int)(entry & 0xffff);
+        const int dist = (int)(entry >> 16);
+        if (!(vmd[i2] <= dist)) d = dist;   // :439
+      }
+      const unsigned dd = (d == 0x7fffffff) ? 511u : (unsigned)d;
+      unsigned long long c1 = ~0ull;
+#pragma unroll
+      for (int b = 8; b >= 0; b--) {
+        const unsigned long long z = __ballot(((dd >> b) & 1u) == 0u) & c1;
+        if (z) c1 = z;
+      }
+      const int ml = (int)__builtin_ctzll(c1);
+      const unsigned d1 = (unsigned)__shfl((int)dd, ml, 64);
+      unsigned long long c2 = ~(1ull << ml);
+#pragma unroll
+      for (int b = 8; b >= 0; b--) {
+        const unsigned long long z = __ballot(((dd >> b) & 1u) == 0u) & c2;
+        if (z) c2 = z;
+      }
+      const unsigned d2 = (unsigned)__shfl((int)dd, (int)__builtin_ctzll(c2), 64);
+      const int md = d1 >= 511u ? 0x7fffffff : (int)d1;
+      const int sd = d2 >= 511u ? 0x7fffffff : (int)d2;
+      const int mi2 = __shfl(i2, ml, 64);
+      if (md < bestDist) { bestDist2 = min(bestDist, sd); bestDist = md; bestIdx2 = mi2; }   // :441-450, earlier chunk wins ties
+      else bestDist2 = min(bestDist2, md);
+    }
+    int m = -1;
+    if (bestDist <= kSfiThLow && (float)bestDist < (float)bestDist2 * nnratio) {
+      m = bestIdx2 | (bestDist << 16);
+      if (lane == 0) vmd[bestIdx2] = bestDist;
+    }
+    if (lane == 0) M[i1] = m;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // lane 0's LDS stores land before the wave's next reads
+  }
+}
+
+__global__ __launch_bounds__(kSfiThreads) void k_sfi_resolve(SfiParams S, int ldsPool, int maxRounds) {
   extern __shared__ int sm[];
   const int fr = blockIdx.x, tid = threadIdx.x;
   const int f = S.frameBase + fr;
@@ -357,7 +406,7 @@ __global__ __launch_bounds__(kSfiThreads) void k_sfi_resolve(SfiParams S, int ld
     }
   }
   __syncthreads();
-  int cur = 0;
+  int cur = 0, rounds = 0;
   for (;;) {
     const int* M = Mbuf[cur];
     int* Mn = Mbuf[cur ^ 1];
@@ -390,6 +439,25 @@ __global__ __launch_bounds__(kSfiThreads) void k_sfi_resolve(SfiParams S, int ld
     const int any = __syncthreads_or(changed);
     cur ^= 1;
     if (!any) break;
+    if (++rounds >= maxRounds) {   // long steal chains: finish with one serial pass, then rebuild the taker lists from it
+      int* M2 = Mbuf[cur];
+      int* vmd = head;             // [cap] >= n2 entries, lists are rebuilt below
+      for (int i = tid; i < n2; i += kSfiThreads) vmd[i] = 0x7fffffff;
+      __syncthreads();
+      if (tid < 64) {
+        if (inLds) sfi_serial_outcomes(tid, n1, pcnt, [&](int q, int c) { return lpool[off[q] + c]; }, S.nnratio, vmd, M2);
+        else sfi_serial_outcomes(tid, n1, pcnt, [&](int q, int c) { return gpool[(long long)q * cap + c]; }, S.nnratio, vmd, M2);
+      }
+      __syncthreads();
+      for (int i = tid; i < n2; i += kSfiThreads) head[i] = -1;
+      __syncthreads();
+      for (int j = tid; j < n1; j += kSfiThreads) {
+        const int m = M2[j];
+        if (m >= 0) next[j] = atomicExch(&head[m & 0xffff], j);
+      }
+      __syncthreads();
+      break;
+    }
   }
   // the lists were built from the outcomes that just reproduced themselves
   const int* M = Mbuf[cur];
@@ -475,7 +543,12 @@ void launch_sfi(const SfiParams& S, int nframes, hipStream_t st) {
   int ldsPool = (60 * 1024 / 4) - fixedWords;   // candidate entries kept in LDS; longer pools are read from HBM
   if (ldsPool > 8192) ldsPool = 8192;
   if (ldsPool < 0) ldsPool = 0;
-  hipLaunchKernelGGL(k_sfi_resolve, dim3(nframes), dim3(kSfiThreads), sizeof(int) * (fixedWords + ldsPool), st, S, ldsPool);
+  // rounds of the fixed point before the kernel finishes with one serial pass on the device (typical inputs settle in
+  // 3-6 rounds; a round costs O(queries x candidates x takers), so a cap keeps adversarial steal chains bounded)
+  int maxRounds = 32;
+  if (const char* e = getenv("ORBFE_SFI_MAX_ROUNDS")) maxRounds = atoi(e) < 1 ? 1 : atoi(e);
+  hipLaunchKernelGGL(k_sfi_resolve, dim3(nframes), dim3(kSfiThreads), sizeof(int) * (fixedWords + ldsPool), st, S, ldsPool,
+                     maxRounds);
 }
 
 }  // namespace orbfe

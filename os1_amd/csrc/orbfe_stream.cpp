@@ -71,6 +71,22 @@ struct orbfe_stream {
   orbfe_sfi_chain* chain = nullptr;       // GPU-resident matching path (default)
   bool gpuMatch = true;
   std::vector<Slot> slots;
+  void growSlots(int nslots) {     // caller holds no batch in flight (or is the constructor)
+    const int old = (int)slots.size();
+    if (nslots <= old) return;
+    slots.resize(nslots);
+    for (int i = old; i < nslots; i++) {
+      Slot& sl = slots[i];
+      sl.frames.resize(batch);
+      sl.kps.resize((size_t)batch * cap);
+      sl.desc.resize((size_t)batch * cap * 32);
+      sl.n.assign(batch, 0);
+      sl.m12.assign((size_t)batch * cap, -1);
+      sl.nm.assign(batch, 0);
+      sl.prevxy.resize((size_t)batch * cap * 2);
+      freeQ.push_back(i);
+    }
+  }
 
   std::mutex mu;
   std::condition_variable cv;
@@ -297,24 +313,12 @@ int orbfe_stream_create(int nfeatures, float scaleFactor, int nlevels, int iniTh
     }
   }
   s->cap = orbfe_extractor_max_keypoints(s->ext[0]);
-  // result slots: `depth` batches on the GPU, one in the caller's hands, the rest queued in front of the worker.  A deep
-  // queue is what keeps the GPU fed when the CALLER's thread is held up for a few milliseconds (seen about once a second
-  // on the test boxes, up to 12 ms long): 28 queued batches are 15 ms of GPU work at 1080p.  A slot is host memory only
-  // (4 MB at 1080p / 2000 features / 32 frames).
-  int nslots = depth + 29;
+  // result slots: `depth` batches on the GPU, one in the caller's hands, a few queued in front of the worker.  A caller
+  // whose own thread can be held up for milliseconds (bench.py's Python driver) asks for a deeper queue with
+  // orbfe_stream_set_queue_slots; a slot is host memory only (4 MB at 1080p / 2000 features / 32 frames).
+  int nslots = depth + 4;
   if (const char* sv = getenv("ORBFE_STREAM_SLOTS")) nslots = std::max(depth + 2, atoi(sv));
-  s->slots.resize(nslots);
-  for (int i = 0; i < nslots; i++) {
-    Slot& sl = s->slots[i];
-    sl.frames.resize(batch);
-    sl.kps.resize((size_t)batch * s->cap);
-    sl.desc.resize((size_t)batch * s->cap * 32);
-    sl.n.assign(batch, 0);
-    sl.m12.assign((size_t)batch * s->cap, -1);
-    sl.nm.assign(batch, 0);
-    sl.prevxy.resize((size_t)batch * s->cap * 2);
-    s->freeQ.push_back(i);
-  }
+  s->growSlots(nslots);
   s->tExtract = std::thread([s] { pthread_setname_np(pthread_self(), "orbfe-runner"); s->extractLoop(); });
   for (int w = 0; w < nMatch; w++) s->tMatch.emplace_back([s, w] { pthread_setname_np(pthread_self(), "orbfe-match"); s->matchLoop(w); });
   *out = s;
@@ -386,6 +390,16 @@ int orbfe_stream_bow_raw(orbfe_stream* s, int frame, const uint32_t** leaf_node,
 }
 
 int orbfe_stream_capacity(const orbfe_stream* s) { return s ? s->cap : 0; }
+
+int orbfe_stream_set_queue_slots(orbfe_stream* s, int nslots) {
+  if (!s) { set_err("stream is NULL"); return ORBFE_ERR_INVALID; }
+  std::lock_guard<std::mutex> lk(s->mu);
+  if (s->popSeq != s->pushSeq) { set_err("orbfe_stream_set_queue_slots: batches in flight"); return ORBFE_ERR_INVALID; }
+  if (nslots < s->depth + 2 || nslots > 256) { set_err("orbfe_stream_set_queue_slots: need depth+2 <= nslots <= 256"); return ORBFE_ERR_INVALID; }
+  s->growSlots(nslots);
+  return ORBFE_OK;
+}
+int orbfe_stream_queue_slots(const orbfe_stream* s) { return s ? (int)s->slots.size() : 0; }
 
 int orbfe_stream_push(orbfe_stream* s, const uint8_t* const* gray, int in_device_memory, int rows, int cols,
                       size_t stride_bytes) {

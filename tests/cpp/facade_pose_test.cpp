@@ -37,7 +37,7 @@ static MatF vecMat(const float* p) { MatF m; m.rows = 3; m.cols = 1; memcpy(m.v,
 struct KeyFrame;
 struct MapPoint {
   int id = 0;
-  float pos[3], normal[3], minD = 0, maxD = 0;
+  float pos[3], normal[3], mfMinDistance = 0, mfMaxDistance = 0;   // the raw fields of MapPoint.h
   unsigned char desc[32];
   bool bad = false;
   int nObs = 0, idxInKF = -1;
@@ -45,10 +45,10 @@ struct MapPoint {
   MatF GetWorldPos() { return vecMat(pos); }
   MatF GetNormal() { return vecMat(normal); }
   MatF GetDescriptor() { MatF m; m.data = desc; m.step = 32; m.rows = 1; return m; }
-  float GetMaxDistanceInvariance() { return maxD; }
-  float GetMinDistanceInvariance() { return minD; }
+  float GetMaxDistanceInvariance() { return 1.2f * mfMaxDistance; }   // MapPoint.cc:364-368
+  float GetMinDistanceInvariance() { return 0.8f * mfMinDistance; }   // MapPoint.cc:358-362
   int PredictScale(const float& currentDist, const float& logScaleFactor) {   // MapPoint.cc:370-379
-    const float ratio = maxD / currentDist;
+    const float ratio = mfMaxDistance / currentDist;                      // the raw field, not the bound
     return (int)std::ceil(std::log(ratio) / logScaleFactor);
   }
   bool isBad() { return bad; }
@@ -173,9 +173,10 @@ static void makePoint(Rng& r, MapPoint& p, const F& f, int k, const float T[16],
   int L = kp.octave + (r.uni() < 0.3 ? 1 : 0);
   if (L > NLEV - 1) L = NLEV - 1;
   const double q = r.uni();
-  p.maxD = (float)(dist * std::pow(1.2, L - 0.35));
-  p.minD = p.maxD / 6.0f;
-  if (q < 0.03) p.maxD = (float)(dist * 0.9), p.minD = p.maxD / 6.0f;   // too far: depth outside the invariance region
+  // MapPoint::UpdateNormalAndDepth (MapPoint.cc:345-356): mfMaxDistance = dist * scale[level], mfMinDistance = mfMaxDistance / scale[nLevels-1]
+  p.mfMaxDistance = (float)(dist * std::pow(1.2, L - 0.35));
+  p.mfMinDistance = p.mfMaxDistance / 3.583f;
+  if (q < 0.03) p.mfMaxDistance = (float)(dist * 0.9 / 1.2), p.mfMinDistance = p.mfMaxDistance / 3.583f;   // too far: depth outside the invariance region
   const int flips = r.below(36);
   memcpy(p.desc, &f.descStore[(size_t)k * 32], 32);
   for (int b = 0; b < flips; b++) { const int bit = r.below(256); p.desc[bit >> 3] ^= (unsigned char)(1u << (bit & 7)); }
@@ -204,10 +205,10 @@ struct Table {   // flat copy of the MapPoints for the oracle
     pos.resize(3 * M); normal.resize(3 * M); minD.resize(M); maxD.resize(M); desc.resize(32 * M); bad.resize(M); nObs.resize(M); idxInKF.resize(M);
     for (size_t i = 0; i < M; i++) {
       memcpy(&pos[3 * i], mp[i].pos, 12); memcpy(&normal[3 * i], mp[i].normal, 12);
-      minD[i] = mp[i].minD; maxD[i] = mp[i].maxD; memcpy(&desc[32 * i], mp[i].desc, 32);
+      minD[i] = mp[i].mfMinDistance; maxD[i] = mp[i].mfMaxDistance; memcpy(&desc[32 * i], mp[i].desc, 32);
       bad[i] = mp[i].bad; nObs[i] = mp[i].nObs; idxInKF[i] = mp[i].idxInKF;
     }
-    P.M = (int)M; P.pos = pos.data(); P.normal = normal.data(); P.minDist = minD.data(); P.maxDist = maxD.data();
+    P.M = (int)M; P.pos = pos.data(); P.normal = normal.data(); P.mfMinDistance = minD.data(); P.mfMaxDistance = maxD.data();
     P.desc = desc.data(); P.bad = bad.data(); P.nObs = nObs.data(); P.idxInKF = idxInKF.data();
   }
   bool sameState(const std::vector<MapPoint>& mp) const {

@@ -33,6 +33,44 @@ def test_transform_matches_python_restatement(oracle, scoring, weighting):
             assert wof.tolist() == pw and nof.tolist() == pn
 
 
+def test_restated_accumulation_equals_reference_dbow2(oracle):
+    """The oracle's restated BowVector / FeatureVector accumulation against the REFERENCE'S OWN BowVector.cpp +
+    FeatureVector.cpp (oracle/_ref/libdbow2_vec.so, built from /root/reference by oracle/Makefile): every weighting /
+    scoring combination, doubles bit for bit.  Skipped only where the reference-built object is absent."""
+    if not oracle.have_dbow2_ref():
+        pytest.skip('oracle/_ref/libdbow2_vec.so not built (no /root/reference on this box)')
+    try:
+        for scoring in range(6):
+            for weighting in range(4):
+                for image, lu in [(synth_vocabulary(3, 10, 3, stop_fraction=0.1), 1), (ragged_vocabulary(4), 2)]:
+                    image = with_header(image, scoring, weighting)
+                    v = oracle.vocabulary(image)
+                    d = _descs(scoring * 10 + weighting + 100, image, 400)
+                    assert not oracle.use_dbow2_ref(False) and not oracle.bow_accumulator_is_reference()
+                    a = v.transform(d, lu)
+                    assert oracle.use_dbow2_ref(True) and oracle.bow_accumulator_is_reference()
+                    b = v.transform(d, lu)
+                    assert a[0].tolist() == b[0].tolist()
+                    assert a[1].tobytes() == b[1].tobytes()
+                    assert all(x.tolist() == y.tolist() for x, y in zip(a[2], b[2]))
+    finally:
+        oracle.use_dbow2_ref(False)
+
+
+def test_golden_bow_vector_was_accumulated_by_reference_code(oracle):
+    """tests/golden/vga_seed1_bow.npz carries BowVector / FeatureVector produced through the reference's DBoW2 code
+    (flag in the fixture); the restatement must reproduce them here, wherever the test runs."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'vga_seed1_bow.npz'))
+    assert int(g['bow_accumulated_by_reference']) == 1
+    v0 = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'vga_seed1.npz'))
+    ov = oracle.vocabulary(synth_vocabulary(3, 10, 4))
+    oracle.use_dbow2_ref(False)
+    t1 = ov.transform(v0['desc1'], 2)
+    assert t1[0].tolist() == g['bow1_ids'].tolist() and t1[1].tobytes() == g['bow1_vals'].tobytes()
+    assert t1[2][0].tolist() == g['fv1_nodes'].tolist() and t1[2][2].tolist() == g['fv1_feat'].tolist()
+
+
 def test_transform_empty_and_stopped(oracle):
     image = synth_vocabulary(5, 4, 2, stop_fraction=1.0)      # every word stopped
     v = oracle.vocabulary(image)

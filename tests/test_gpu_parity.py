@@ -577,14 +577,18 @@ def test_latency_path_variants_agree(api, oracle, monkeypatch):
                 monkeypatch.delenv(k)
 
 
-@pytest.mark.parametrize('seq', ['0', '1'])
+@pytest.mark.parametrize('seq', ['0', '1', 'cap1', 'cap3'])
 def test_stream_matching_dense_clusters(api, oracle, seq, monkeypatch):
     """SearchForInitialization bookkeeping under stress: many level-0 keypoints in a small image, a window that covers a
     large part of it and nnratio 1.0, so that almost every query finds a match, keypoints are taken away from earlier
     queries all the time (ORBmatcher.cc:455-466) and the dependency chains between queries are long.  k_sfi_resolve
-    iterates the bookkeeping to its fixed point; ORBFE_SFI_SEQUENTIAL=1 replays it serially.  Both equal the oracle."""
+    iterates the bookkeeping to its fixed point; ORBFE_SFI_SEQUENTIAL=1 replays it serially; ORBFE_SFI_MAX_ROUNDS=1 / 3
+    stops the fixed point early, so the kernel's serial finish (the bound on adversarial steal chains) does the work.
+    All equal the oracle."""
     if seq == '1':
         monkeypatch.setenv('ORBFE_SFI_SEQUENTIAL', '1')
+    if seq.startswith('cap'):
+        monkeypatch.setenv('ORBFE_SFI_MAX_ROUNDS', seq[3:])
     W, H, N, nl, B = 420, 300, 1500, 2, 3
     base = synth(81, W, H)
     frames = [base] + [shifted(base, (3 * i) % 7 - 3, (5 * i) % 5 - 2, 800 + i) for i in range(1, 2 * B)]
@@ -615,3 +619,5 @@ def test_stream_matching_dense_clusters(api, oracle, seq, monkeypatch):
     assert total > 1000
     if seq == '1':
         monkeypatch.delenv('ORBFE_SFI_SEQUENTIAL')
+    if seq.startswith('cap'):
+        monkeypatch.delenv('ORBFE_SFI_MAX_ROUNDS')

@@ -3,7 +3,9 @@
 frames of the stream (extract + SearchForInitialization against the predecessor), all starting at wall-clock `t0`.
 Separate processes because 256 threads inside one process serialise on its address-space lock (every extract call
 allocates pyramid buffers): 256 threads x 1 process ran at 38 frames/s where 64 threads reached 65.
-usage: cpu_oracle_worker.py <frames.npy> <first_frame> <threads> <per> <t0> <do_match>   -> prints "<t_end> <frames>" """
+usage: cpu_oracle_worker.py <frames.npy> <first_frame> <threads> <per> <t0> <do_match>
+       -> prints "<t_start> <t_end> <frames>" (t_start = when this worker's threads really started: t0, or later if its
+          interpreter was not ready by then) """
 import os
 import sys
 import threading
@@ -35,8 +37,9 @@ def work(i):
 ths = [threading.Thread(target=work, args=(i,)) for i in range(threads)]
 while time.time() < t0:
     time.sleep(0.002)
+t_start = time.time()
 for t in ths:
     t.start()
 for t in ths:
     t.join()
-print('%.6f %d' % (time.time(), threads * per), flush=True)
+print('%.6f %.6f %d' % (t_start, time.time(), threads * per), flush=True)

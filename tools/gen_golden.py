@@ -65,7 +65,13 @@ ov = o.vocabulary(voc)
 _v = np.load(os.path.join(out, 'vga_seed1.npz'))
 k1, d1, k2, d2 = _v['kps1'], _v['desc1'], _v['kps2'], _v['desc2']
 ox = OracleExtractor(1000, 1.2, 8, 20, 7, o)
+# BowVector / FeatureVector accumulate through the REFERENCE'S OWN DBoW2 BowVector.cpp / FeatureVector.cpp
+# (oracle/_ref/libdbow2_vec.so, see oracle/Makefile); refuse to write the fixture otherwise.
+assert o.use_dbow2_ref(True), 'oracle/_ref/libdbow2_vec.so missing: run make -C oracle where /root/reference exists'
 t1, t2 = ov.transform(d1, 2), ov.transform(d2, 2)
+o.use_dbow2_ref(False)
+r1 = ov.transform(d1, 2)
+assert r1[1].tobytes() == t1[1].tobytes() and r1[0].tolist() == t1[0].tolist()
 rng = np.random.default_rng(17)
 v1 = (rng.random(len(k1)) < 0.85).astype(np.uint8)
 v2 = (rng.random(len(k2)) < 0.85).astype(np.uint8)
@@ -90,5 +96,6 @@ np.savez_compressed(os.path.join(out, 'vga_seed1_bow.npz'),
                     sbb_kf_f=mb1, sbb_kf_f_n=np.int32(nb1), sbb_kf_kf=mb2, sbb_kf_kf_n=np.int32(nb2),
                     tri_pairs=tp, tri_n=np.int32(nt), F12=F12,
                     proj_uv=uv, proj_level=lvl, proj_radius=rad, proj_desc=sd, proj_best=bi, proj_dist=bd, proj_n=np.int32(np_),
+                    bow_accumulated_by_reference=np.int32(1),
                     voc_sha=np.frombuffer(hashlib.sha256(voc).digest(), np.uint8))
 print('vga_seed1_bow: %d words, SearchByBoW %d / %d, triangulation %d, projected %d' % (len(t1[0]), nb1, nb2, nt, np_))
