@@ -184,14 +184,23 @@ __device__ __forceinline__ unsigned pk_round2(unsigned x, unsigned y) {
   return t;
 }
 
+// Launch shape: grid.x = 8 * chunk blocks per frame (chunk = ceil(tiles / 8)), grid.y = frames.  The hardware deals
+// consecutive block ids to the 8 XCDs in turn, so block b runs on XCD b % 8; tile = (b % 8) * chunk + b / 8 hands every
+// XCD a CONSECUTIVE run of the frame's tiles in row-major order (a horizontal band): the 128-byte lines two horizontally
+// adjacent footprints share are fetched into one L2 once instead of into two L2s (profiles/r02n_pmc_summary.csv: the
+// plain (x, y, frame) grid fetched 2.3x the level it reads).  tile -> (tx, ty) by a scalar multiply-high.
 template <int LP, int RH>
-__global__ __launch_bounds__(256) void k_resize_fixed(PyramidParams P, int level) {
+__global__ __launch_bounds__(256) void k_resize_fixed(PyramidParams P, int level, int tilesX, int ntiles, unsigned rcpTilesX) {
   __shared__ __align__(16) uint8_t rz[LP * RH];
   __shared__ __align__(16) uint16_t H[RH * 64];
   const LevelGeom& D = P.lv[level];
   const LevelGeom& S = P.lv[level - 1];
-  const int f = P.frameBase + blockIdx.z;
-  const int tx0 = blockIdx.x * kRzTile, ty0 = blockIdx.y * kRzTile;
+  const int f = P.frameBase + blockIdx.y;
+  const int chunk = (ntiles + 7) >> 3;
+  const int tileIx = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (tileIx >= ntiles) return;
+  const int tyI = (int)(((unsigned long long)(unsigned)tileIx * rcpTilesX) >> 32);   // tileIx / tilesX (exact: host-checked range)
+  const int tx0 = (tileIx - tyI * tilesX) * kRzTile, ty0 = tyI * kRzTile;
   const int tx1 = min(tx0 + kRzTile, D.w) - 1, ty1 = min(ty0 + kRzTile, D.h) - 1;
   const uint8_t* src;
   long long sstride;
@@ -668,7 +677,12 @@ __global__ __launch_bounds__(64) void k_describe(PyramidParams P, const SelKp* _
   // one (the next batches' FAST) fit on the CU.
   static_assert(kBlurW * kBPT <= kRawW * kRawP, "the blurred patch must fit into the raw patch");
   uint8_t* blT = raw;
-  const int k = blockIdx.x;
+  // XCD b % 8 works through a CONSECUTIVE eighth of the slots (frame-major, level by level): the keypoints of one
+  // frame's level meet in one L2, where each 128-byte line of the level is fetched once however many 43-byte patch
+  // rows touch it (the plain mapping spread neighbouring keypoints over all eight L2s: 3.1x the algorithmic bytes,
+  // profiles/r02n_pmc_summary.csv)
+  const int chunk = (nsel + 7) >> 3;
+  const int k = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
   if (k >= nsel) return;
   if (SI.selCount) {
     const int fr = k / SI.selPerFrame, within = k - fr * SI.selPerFrame;
@@ -913,8 +927,12 @@ int launch_pyramid(const PyramidParams& P, int nframes, hipStream_t st, const Co
   for (int l = 1; l <= last; l++) {
     dim3 grid((P.lv[l].w + kRzTile - 1) / kRzTile, (P.lv[l].h + kRzTile - 1) / kRzTile, nframes);
     if (P.lv[l].rzPitch <= 96 && P.lv[l].rzRows <= 80) {
-      hipLaunchKernelGGL((k_resize_fixed<96, 80>), grid, dim3(256), 0, st, P, l);
-      continue;
+      const int tilesX = (int)grid.x, ntiles = (int)(grid.x * grid.y);
+      const unsigned rcp = (unsigned)(0x100000000ull / (unsigned)tilesX) + 1u;   // floor(t * rcp / 2^32) = t / tilesX for t * tilesX < 2^32
+      if ((unsigned long long)ntiles * tilesX < (1ull << 31)) {
+        hipLaunchKernelGGL((k_resize_fixed<96, 80>), dim3(8 * ((ntiles + 7) / 8), nframes), dim3(256), 0, st, P, l, tilesX, ntiles, rcp);
+        continue;
+      }
     }
     hipLaunchKernelGGL(k_resize, grid, dim3(256), (((size_t)P.lv[l].rzPitch * P.lv[l].rzRows + 15) & ~(size_t)15) + (size_t)P.lv[l].rzRows * 64 * 2, st,
                        P, l);
@@ -933,7 +951,7 @@ void launch_describe(const PyramidParams& P, const SelKp* sel, int nsel, float* 
   if (nsel <= 0) return;
   SlotInfo si{};
   si.selCount = nullptr;
-  hipLaunchKernelGGL(k_describe, dim3(nsel), dim3(64), 0, st, P, sel, nsel, angle, desc, si);
+  hipLaunchKernelGGL(k_describe, dim3(8 * ((nsel + 7) / 8)), dim3(64), 0, st, P, sel, nsel, angle, desc, si);
 }
 
 // sel/angle/desc point at the first slot of frame P.frameBase; nslots = nframes * selPerFrame
@@ -945,7 +963,7 @@ void launch_describe_slots(const PyramidParams& P, const SelKp* sel, int nslots,
   si.selPerFrame = selPerFrame;
   si.nlevels = P.nlevels;
   for (int l = 0; l <= P.nlevels; l++) si.selOff[l] = selOff[l];
-  hipLaunchKernelGGL(k_describe, dim3(nslots), dim3(64), 0, st, P, sel, nslots, angle, desc, si);
+  hipLaunchKernelGGL(k_describe, dim3(8 * ((nslots + 7) / 8)), dim3(64), 0, st, P, sel, nslots, angle, desc, si);
 }
 
 void launch_sincos(const float* deg, int n, float* c, float* s, hipStream_t st) {
