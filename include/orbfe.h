@@ -379,6 +379,61 @@ int orbfe_search_projected(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, const 
                            const float* inv_level_sigma2, int nlevels, double chi2, int max_dist, int32_t* best_idx,
                            int32_t* best_dist, int* nmatches);
 
+/* ---------------------------------------------------------------------------------------------
+ * Device-resident frames.  The reference builds a frame's grid once (Frame::AssignFeaturesToGrid, src/Frame.cc:114-129,
+ * from the constructor :111) and every search of that frame reuses it: 2-3 searches per tracked frame
+ * (src/Tracking.cc:608, 614, 824), many more per keyframe.  An orbfe_frame is that object in HBM -- mvKeysUn (x, y,
+ * octave, angle), mDescriptors and the cell-sorted table Frame / KeyFrame::GetFeaturesInArea walks (Frame.cc:209-262,
+ * KeyFrame.cc:637-676) -- built once; the `_frame` searches below upload only their queries and return only their
+ * result vector: candidate lists AND the reference's sequential bookkeeping stay on the GPU.
+ * A frame belongs to one device; it may be searched through any matcher of that device, one search at a time.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct orbfe_frame orbfe_frame;
+/* From host arrays (kps_un = mvKeysUn in cv::KeyPoint layout, desc = mDescriptors rows, bounds = mnMinX, mnMaxX, mnMinY,
+ * mnMaxY): one upload + the grid build, on the matcher's stream; returns without waiting. */
+int orbfe_frame_create(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, const uint8_t* desc, int n, const float bounds[4],
+                       orbfe_frame** out);
+/* From frame `frame_index` of the extractor's LAST COLLECTED batch (orbfe_extract / _batch / _collect): keypoints and
+ * descriptors are taken where the kernels left them -- nothing is uploaded but, optionally, xy_un: the undistorted
+ * coordinates [2 * n] of Frame::UndistortKeyPoints (Frame.cc:286-320; NULL = mvKeysUn = mvKeys, the camera without
+ * distortion, :288-292).  Keypoint order = the order the extract call returned.  Must be called before the next
+ * submit / extract on that handle (its arena is reused); the frame itself then lives on independently. */
+int orbfe_frame_create_from_extract(orbfe_extractor* h, int frame_index, const float bounds[4], const float* xy_un,
+                                    orbfe_frame** out);
+void orbfe_frame_destroy(orbfe_frame* f);
+int orbfe_frame_size(const orbfe_frame* f);
+/* Test / debug: the resident content back on the host -- keypoints (x, y, angle, octave; other fields zeroed) and
+ * descriptor rows in keypoint order, the keypoint indices in grid order (capacity n) and the 64*48+1 cell offsets into
+ * that order (mGrid flattened: cell = ix * 48 + iy).  Any pointer may be NULL. */
+int orbfe_frame_download(orbfe_frame* f, OrbfeKeyPoint* kps_un, uint8_t* desc, int32_t* grid_order, int32_t* cell_start);
+
+/* orbfe_search_by_projection / _uv / orbfe_search_projected on a resident frame: same arguments minus the frame's
+ * arrays, same results.  (The host-array forms above run through these with a transient frame owned by the matcher;
+ * ORBFE_MATCH_HOST_RESOLVE=1 keeps their round-2 route -- candidate lists to the host, bookkeeping there -- for A/B
+ * runs and the parity tests.)  Query descriptor rows in page-locked memory (orbfe_host_alloc) are fetched by DMA
+ * straight from the caller's buffer. */
+int orbfe_search_by_projection_frame(orbfe_matcher* m, orbfe_frame* f, const float* scale_factors, int nlevels,
+                                     const uint8_t* kp_occupied, const float* mp_proj_xy, const int32_t* mp_level,
+                                     const float* mp_viewcos, const uint8_t* mp_flags, const uint8_t* mp_desc, int n_mp,
+                                     float th, float nnratio, int32_t* kp_assigned, int* nmatches);
+int orbfe_search_by_projection_uv_frame(orbfe_matcher* m, orbfe_frame* f, const float* scale_factors, int nlevels,
+                                        const uint8_t* kp_occupied, const float* src_uv, const int32_t* src_level,
+                                        const float* src_angle, const uint8_t* src_flags, const uint8_t* src_valid,
+                                        const uint8_t* src_desc, int n_src, float th, int max_dist, int skip_any_occupied,
+                                        int check_orientation, int32_t* kp_assigned, int* nmatches);
+int orbfe_search_projected_frame(orbfe_matcher* m, orbfe_frame* f, int n_src, const float* src_uv, const float* src_radius,
+                                 const int32_t* src_level, const uint8_t* src_valid, const uint8_t* src_desc,
+                                 const uint8_t* kp_skip, int claim, const float* inv_level_sigma2, int nlevels, double chi2,
+                                 int max_dist, int32_t* best_idx, int32_t* best_dist, int* nmatches);
+/* Rounds the bookkeeping kernel of the last `_frame` search needed (negative: the bound ORBFE_RESOLVE_MAX_ROUNDS,
+ * default 48, was hit and a serial pass on the device finished the job). */
+int orbfe_debug_resolve_rounds(const orbfe_matcher* m);
+/* Where that kernel kept its state: 2 = tables and candidate entries in LDS, 1 = tables in LDS, 0 = global scratch (problems
+ * beyond 152 KB of tables, or ORBFE_RESOLVE_GENERIC=1). */
+int orbfe_debug_resolve_route(const orbfe_matcher* m);
+/* Shader-clock readings (low 32 bits) at the kernel's start, after its set-up, after the fixed point, at its end. */
+int orbfe_debug_resolve_phases(const orbfe_matcher* m, int out[4]);
+
 /* void MapPoint::ComputeDistinctiveDescriptors()  (src/MapPoint.cc:227-292), from the gathered descriptor list
  * onwards, batched over MapPoints: MapPoint p owns descriptor rows [offsets[p], offsets[p+1]) of `descs`
  * (32-byte rows, the non-bad observations in std::map order); best_idx[p] = index inside its own list of the

@@ -74,6 +74,20 @@ def load_library():
     L.orbfe_matcher_destroy.restype = None
     L.orbfe_search_for_initialization.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, ci, cf, ci, C.POINTER(ci)]
     L.orbfe_search_for_initialization_batch.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, cf, ci, vp]
+    L.orbfe_frame_create.argtypes = [vp, vp, vp, ci, vp, C.POINTER(vp)]
+    L.orbfe_frame_create_from_extract.argtypes = [vp, ci, vp, vp, C.POINTER(vp)]
+    L.orbfe_frame_destroy.argtypes = [vp]
+    L.orbfe_frame_destroy.restype = None
+    L.orbfe_frame_size.argtypes = [vp]
+    L.orbfe_frame_download.argtypes = [vp, vp, vp, vp, vp]
+    L.orbfe_search_by_projection_frame.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp, C.POINTER(ci)]
+    L.orbfe_search_by_projection_uv_frame.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, ci, ci, ci, vp,
+                                                      C.POINTER(ci)]
+    L.orbfe_search_projected_frame.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp, ci, C.c_double, ci, vp, vp,
+                                               C.POINTER(ci)]
+    L.orbfe_debug_resolve_rounds.argtypes = [vp]
+    L.orbfe_debug_resolve_route.argtypes = [vp]
+    L.orbfe_debug_resolve_phases.argtypes = [vp, vp]
     L.orbfe_search_by_projection.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp,
                                              C.POINTER(ci)]
     L.orbfe_search_by_projection_uv.argtypes = [vp, vp, vp, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, ci,
@@ -311,8 +325,76 @@ class Extractor:
         return c, s
 
 
+class Frame:
+    """A Frame's features resident on the GPU (orbfe_frame): mvKeysUn, mDescriptors and the grid, built once.  Pass it
+    as the `kps` argument of Matcher.search_by_projection / _uv / search_projected (desc and bounds are then ignored)."""
+
+    def __init__(self, handle, n):
+        self.L = load_library()
+        self.h = handle
+        self.n = n
+
+    @classmethod
+    def from_host(cls, matcher, kps_un, desc, bounds):
+        L = load_library()
+        kps_un = np.ascontiguousarray(kps_un, KP_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8)
+        b = np.asarray(bounds, np.float32)
+        h = C.c_void_p()
+        _check(L.orbfe_frame_create(matcher.h, _p(kps_un), _p(desc), len(kps_un), _p(b), C.byref(h)))
+        return cls(h, len(kps_un))
+
+    @classmethod
+    def from_extract(cls, extractor, frame_index, bounds, xy_un=None):
+        """Frame `frame_index` of the extractor's last collected batch, taken where the kernels left it."""
+        L = load_library()
+        b = np.asarray(bounds, np.float32)
+        xy = None if xy_un is None else np.ascontiguousarray(xy_un, np.float32)
+        h = C.c_void_p()
+        _check(L.orbfe_frame_create_from_extract(extractor.h, frame_index, _p(b), None if xy is None else _p(xy), C.byref(h)))
+        return cls(h, L.orbfe_frame_size(h))
+
+    def __len__(self):
+        return self.n
+
+    def download(self):
+        """(kps [x, y, angle, octave filled], desc, grid_order, cell_start) as they lie on the device."""
+        k = np.zeros(max(self.n, 1), KP_DTYPE)
+        d = np.zeros((max(self.n, 1), 32), np.uint8)
+        order = np.zeros(max(self.n, 1), np.int32)
+        cs = np.zeros(64 * 48 + 1, np.int32)
+        _check(self.L.orbfe_frame_download(self.h, _p(k), _p(d), _p(order), _p(cs)))
+        return k[:self.n], d[:self.n], order[:int(cs[-1])], cs
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.L.orbfe_frame_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Matcher:
     """Hot subset of ORBmatcher on one GPU."""
+
+    def frame(self, kps_un, desc, bounds):
+        return Frame.from_host(self, kps_un, desc, bounds)
+
+    def resolve_rounds(self):
+        return int(self.L.orbfe_debug_resolve_rounds(self.h))
+
+    def resolve_route(self):
+        return int(self.L.orbfe_debug_resolve_route(self.h))
+
+    def resolve_phases(self):
+        """Shader-clock ticks spent in k_resolve's set-up, fixed point and output phases."""
+        o = np.zeros(4, np.int32)
+        _check(self.L.orbfe_debug_resolve_phases(self.h, _p(o)))
+        return np.diff(o.astype(np.int64)) & 0xffffffff
 
     def __init__(self, device=0):
         self.L = load_library()
@@ -368,6 +450,20 @@ class Matcher:
 
     def search_by_projection(self, kps, desc, bounds, scale_factors, kp_occupied, mp_xy, mp_level, mp_viewcos,
                              mp_flags, mp_desc, th, nnratio):
+        if isinstance(kps, Frame):
+            sf = np.ascontiguousarray(scale_factors, np.float32)
+            occ = np.ascontiguousarray(kp_occupied, np.uint8)
+            mp_xy = np.ascontiguousarray(mp_xy, np.float32)
+            mp_level = np.ascontiguousarray(mp_level, np.int32)
+            mp_viewcos = np.ascontiguousarray(mp_viewcos, np.float32)
+            mp_flags = np.ascontiguousarray(mp_flags, np.uint8)
+            mp_desc = np.ascontiguousarray(mp_desc, np.uint8)
+            assigned = np.full(max(len(kps), 1), -1, np.int32)
+            n = C.c_int(0)
+            _check(self.L.orbfe_search_by_projection_frame(self.h, kps.h, _p(sf), len(sf), _p(occ), _p(mp_xy), _p(mp_level),
+                                                           _p(mp_viewcos), _p(mp_flags), _p(mp_desc), len(mp_level), th,
+                                                           nnratio, _p(assigned), C.byref(n)))
+            return n.value, assigned[:len(kps)]
         kps = np.ascontiguousarray(kps, KP_DTYPE)
         desc = np.ascontiguousarray(desc, np.uint8)
         b = np.asarray(bounds, np.float32)
@@ -387,6 +483,22 @@ class Matcher:
 
     def search_by_projection_uv(self, kps, desc, bounds, scale_factors, kp_occupied, src_uv, src_level, src_angle,
                                 src_flags, src_valid, src_desc, th, max_dist, skip_any_occupied, check_ori):
+        if isinstance(kps, Frame):
+            sf = np.ascontiguousarray(scale_factors, np.float32)
+            occ = np.ascontiguousarray(kp_occupied, np.uint8)
+            src_uv = np.ascontiguousarray(src_uv, np.float32)
+            src_level = np.ascontiguousarray(src_level, np.int32)
+            src_angle = np.ascontiguousarray(src_angle, np.float32)
+            src_flags = np.ascontiguousarray(src_flags, np.uint8)
+            src_valid = np.ascontiguousarray(src_valid, np.uint8)
+            src_desc = np.ascontiguousarray(src_desc, np.uint8)
+            assigned = np.full(max(len(kps), 1), -1, np.int32)
+            n = C.c_int(0)
+            _check(self.L.orbfe_search_by_projection_uv_frame(self.h, kps.h, _p(sf), len(sf), _p(occ), _p(src_uv), _p(src_level),
+                                                              _p(src_angle), _p(src_flags), _p(src_valid), _p(src_desc),
+                                                              len(src_level), th, max_dist, int(skip_any_occupied),
+                                                              int(check_ori), _p(assigned), C.byref(n)))
+            return n.value, assigned[:len(kps)]
         kps = np.ascontiguousarray(kps, KP_DTYPE)
         desc = np.ascontiguousarray(desc, np.uint8)
         b = np.asarray(bounds, np.float32)
@@ -446,6 +558,23 @@ class Matcher:
     def search_projected(self, kps, desc, bounds, uv, radius, level, valid, sdesc, kp_skip=None, claim=False,
                          inv_sigma2=None, chi2=5.99, max_dist=50):
         """Projected best-match loop of SearchByProjection(KF, Scw) / Fuse / SearchBySim3 -> (n, best_idx, best_dist)."""
+        if isinstance(kps, Frame):
+            uv = np.ascontiguousarray(uv, np.float32)
+            radius = np.ascontiguousarray(radius, np.float32)
+            level = np.ascontiguousarray(level, np.int32)
+            valid = np.ascontiguousarray(valid, np.uint8)
+            sdesc = np.ascontiguousarray(sdesc, np.uint8)
+            ns = len(radius)
+            skip = None if kp_skip is None else np.ascontiguousarray(kp_skip, np.uint8)
+            inv = None if inv_sigma2 is None else np.ascontiguousarray(inv_sigma2, np.float32)
+            bi = np.full(max(ns, 1), -1, np.int32)
+            bd = np.full(max(ns, 1), -1, np.int32)
+            nm = C.c_int(0)
+            _check(self.L.orbfe_search_projected_frame(self.h, kps.h, ns, _p(uv), _p(radius), _p(level), _p(valid), _p(sdesc),
+                                                       None if skip is None else _p(skip), int(claim),
+                                                       None if inv is None else _p(inv), 0 if inv is None else len(inv), chi2,
+                                                       max_dist, _p(bi), _p(bd), C.byref(nm)))
+            return nm.value, bi[:ns], bd[:ns]
         kps = np.ascontiguousarray(kps)
         desc = np.ascontiguousarray(desc, np.uint8)
         b = np.asarray(bounds, np.float32)
@@ -622,6 +751,33 @@ class Vocabulary:
     def __del__(self):
         try:
             self.close()
+        except Exception:
+            pass
+
+
+class PinnedArray:
+    """A numpy array in page-locked HOST memory (orbfe_host_alloc): `.a` is the view.  Query descriptor rows kept in one
+    are fetched by DMA straight from it by the `_frame` searches."""
+
+    def __init__(self, shape, dtype=np.uint8):
+        L = load_library()
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape))
+        p = C.c_void_p()
+        _check(L.orbfe_host_alloc(max(n * dt.itemsize, 1), C.byref(p)))
+        self.base = p.value
+        raw = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(max(n * dt.itemsize, 1),))
+        self.a = raw[:n * dt.itemsize].view(dt).reshape(shape)
+
+    def free(self):
+        if getattr(self, 'base', None):
+            self.a = None
+            load_library().orbfe_host_free(C.c_void_p(self.base))
+            self.base = None
+
+    def __del__(self):
+        try:
+            self.free()
         except Exception:
             pass
 

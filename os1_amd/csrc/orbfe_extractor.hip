@@ -249,6 +249,7 @@ struct orbfe_extractor {
   DevBuf<uint8_t> d_gray;   // level 0 of colour input
   bool inLinear = false;   // host frames are uploaded with linear copies (inPitch == host stride)
   int lastFrames = 0;
+  bool lastGpuQt = false, lastZeroCopy = false, submitZeroCopy = false;   // route of the last collected / submitted batch
   float stageMs[5] = {0, 0, 0, 0, 0};
   hipEvent_t ev[kMaxSub][6] = {};
   double kernMs[5] = {0, 0, 0, 0, 0};
@@ -766,6 +767,7 @@ struct orbfe_extractor {
     // (the quadtree a second copy of its selection, the descriptor kernel its only copy), so no copy command follows
     // the last kernel.  Matching and bag-of-words read angles / descriptors on the device and keep the copy.
     const bool zeroCopy = zeroCopyOut && nframes <= coneMaxFrames && !voc && !(ms && ms->chain);
+    submitZeroCopy = zeroCopy;
     QP.selHost = zeroCopy ? h_sel.p : nullptr;
     QP.selCountHost = zeroCopy ? h_selCount.p : nullptr;
     for (int l = 0; l < nlevels; l++) {
@@ -929,6 +931,8 @@ struct orbfe_extractor {
     stageMs[3] = (float)(t3 - t2);   // output assembly
     stageMs[4] = (float)(t3 - t0);
     lastFrames = nframes;
+    lastGpuQt = true;
+    lastZeroCopy = submitZeroCopy;
     return status;
   }
 
@@ -1123,6 +1127,7 @@ struct orbfe_extractor {
     stageMs[3] = (float)(t5 - t4);      // output assembly
     stageMs[4] = (float)(t5 - t0);
     lastFrames = nframes;
+    lastGpuQt = false;
     return status;
   }
 };
@@ -1131,6 +1136,38 @@ extern "C" {
 
 const char* orbfe_last_error(void) { return g_err.c_str(); }
 
+}  // extern "C" (reopened below)
+
+namespace orbfe {
+// orbfe_frame_create_from_extract (orbfe_frame.hip): where frame `frame` of the last collected batch lies.
+int extractor_view(orbfe_extractor* h, int frame, ExtractView* out) {
+  if (!h || !out) { set_err("NULL argument"); return ORBFE_ERR_INVALID; }
+  if (h->pendingFrames) { set_err("a submitted batch has not been collected yet"); return ORBFE_ERR_INVALID; }
+  if (frame < 0 || frame >= h->lastFrames) { set_err("frame %d is not part of the last collected batch (%d frames)", frame, h->lastFrames); return ORBFE_ERR_INVALID; }
+  if (!h->lastGpuQt) {
+    set_err("the last batch took the host-quadtree route, whose selections are not kept per slot: build the frame with orbfe_frame_create");
+    return ORBFE_ERR_INVALID;
+  }
+  const size_t base = (size_t)frame * h->selPerFrame;
+  const bool z = h->lastZeroCopy;
+  out->sel = (z ? h->h_sel.p : h->d_sel.p) + base;
+  out->angle = (z ? h->h_angle.p : h->d_angle.p) + base;
+  out->desc = (z ? h->h_desc.p : h->d_desc.p) + base * 32;
+  out->nlevels = h->nlevels;
+  out->n = 0;
+  for (int l = 0; l <= h->nlevels; l++) out->selOff[l] = h->selOff[l];
+  for (int l = 0; l < h->nlevels; l++) {
+    out->count[l] = (int)h->h_selCount.p[(size_t)frame * kMaxLevels + l];
+    out->sf[l] = h->sf[l];
+    out->n += out->count[l];
+  }
+  out->device = h->device;
+  out->stream = (void*)h->streams[0];
+  return ORBFE_OK;
+}
+}  // namespace orbfe
+
+extern "C" {
 int orbfe_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -1,0 +1,920 @@
+// orbfe_frame.hip -- a Frame's features resident on the GPU, and the searches that run on them without leaving it.
+//
+// The reference builds a frame's grid once (Frame::AssignFeaturesToGrid, src/Frame.cc:114-129, called from the
+// constructor :111) and every search of that frame reuses it -- 2-3 searches per tracked frame
+// (src/Tracking.cc:608, 614, 824).  An orbfe_frame is that object on the device: undistorted keypoints (x, y, octave,
+// angle), descriptors, and the cell-sorted table GetFeaturesInArea (Frame.cc:209-262) walks, built ONCE -- from host
+// arrays (one upload) or straight from the extractor's result arena, where the features were produced microseconds
+// earlier (orbfe_frame_create_from_extract: no descriptor ever crosses PCIe again).
+//
+// A search on a resident frame is one stream submission: upload of the queries -> k_window_match (candidate lists in
+// reference order, in HBM) -> k_resolve (the reference's sequential bookkeeping) -> download of the result vector.
+// The bookkeeping of ORBmatcher::SearchByProjection (src/ORBmatcher.cc:45-124), the Frame / KeyFrame projection
+// searches (:1292-1552) and the projected best-match loops (:357-392, :872-936, :1014-1050, :1066-1290) is sequential
+// only through ONE mechanism: an accepted match may make its keypoint unavailable to LATER queries (mvpMapPoints
+// occupancy with Observations() > 0, :89-91 / :1364-1366 / :1493-1494; vpMatched, :376-377).  The outcome of query i is
+// therefore a function of its own candidate list and of {outcomes of queries j < i}, a recurrence with exactly one
+// solution; k_resolve iterates all queries in parallel until nothing changes (round k fixes at least queries 0..k-1, in
+// practice a handful of rounds) and finishes with a serial pass if a bound on the rounds is hit -- the same scheme as
+// k_sfi_resolve (orbfe_sfi.hip).
+#include "orbfe_matcher_internal.h"
+#include "orbfe_internal.h"
+
+struct orbfe_extractor;
+namespace orbfe {
+int extractor_view(orbfe_extractor* h, int frame, ExtractView* out);
+}
+
+namespace {
+
+constexpr int kCells = kGridCols * kGridRows;   // 3072
+
+struct FrameDev {   // device pointers of a resident frame
+  float* x; float* y; float* angle; int* oct; uint8_t* desc;                       // keypoint order
+  float* sx; float* sy; int* soct; int* sidx; uint8_t* tdesc; int* cellStart;      // grid order (Frame.cc:114-129)
+  PairInfo* pair;
+  int* tmpCell; int* tmpArr; int* tmpBucket;                                       // build scratch
+  int n;
+};
+
+__device__ __forceinline__ void copy32(uint8_t* dst, const uint8_t* src) {
+  const uint4 a = reinterpret_cast<const uint4*>(src)[0], b = reinterpret_cast<const uint4*>(src)[1];
+  reinterpret_cast<uint4*>(dst)[0] = a;
+  reinterpret_cast<uint4*>(dst)[1] = b;
+}
+
+// keypoints (cv::KeyPoint layout, mvKeysUn) + descriptor rows uploaded by the host -> keypoint-order arrays
+// (the descriptor rows are uploaded straight to F.desc)
+__global__ __launch_bounds__(256) void k_frame_from_host(const OrbfeKeyPoint* __restrict__ kps, FrameDev F) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= F.n) return;
+  const OrbfeKeyPoint k = kps[i];
+  F.x[i] = k.x; F.y[i] = k.y; F.angle[i] = k.angle; F.oct[i] = k.octave;
+}
+
+struct ExtractViewDev {
+  const orbfe::SelKp* sel; const float* angle; const uint8_t* desc;
+  int selOff[orbfe::kMaxLevels + 1], count[orbfe::kMaxLevels];
+  float sf[orbfe::kMaxLevels];
+  int nlevels;
+};
+
+// one frame of an extractor's result arena -> keypoint-order arrays, in the order orbfe_extract returns the keypoints
+// (levels 0..n-1, list order inside a level; ORBextractor.cc:959-967: pt *= mvScaleFactor[level] for level > 0).
+// xyUn != nullptr: the caller's undistorted coordinates (Frame::UndistortKeyPoints, Frame.cc:286-320) replace pt.
+__global__ __launch_bounds__(256) void k_frame_from_extract(ExtractViewDev V, const float* __restrict__ xyUn, FrameDev F) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= F.n) return;
+  int l = 0, first = 0;
+  while (l + 1 < V.nlevels && i >= first + V.count[l]) { first += V.count[l]; l++; }
+  const int slot = V.selOff[l] + (i - first);
+  const orbfe::SelKp s = V.sel[slot];
+  float x = (float)(s.xy & 0xffff), y = (float)(s.xy >> 16);
+  if (l != 0) { x *= V.sf[l]; y *= V.sf[l]; }
+  if (xyUn) { x = xyUn[2 * i]; y = xyUn[2 * i + 1]; }
+  F.x[i] = x; F.y[i] = y; F.angle[i] = V.angle[slot]; F.oct[i] = l;
+  copy32(F.desc + (size_t)i * 32, V.desc + (size_t)slot * 32);
+}
+
+// Frame::AssignFeaturesToGrid / PosInGrid (Frame.cc:114-129, 264-274) as a stable counting sort by cell: cell = ix * 48 +
+// iy ascending, insertion (= keypoint index) order inside a cell -- the order GetFeaturesInArea's loops visit.  One block.
+__global__ __launch_bounds__(1024) void k_frame_grid(FrameDev F, float minX, float minY, float invW, float invH) {
+  constexpr int kPer = kCells / 1024;
+  static_assert(kCells % 1024 == 0, "cells per thread");
+  __shared__ int start[kCells + 1];
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, n = F.n;
+  for (int c = tid; c <= kCells; c += 1024) start[c] = 0;
+  __syncthreads();
+  for (int k = tid; k < n; k += 1024) {
+    const int px = (int)roundf((F.x[k] - minX) * invW), py = (int)roundf((F.y[k] - minY) * invH);   // Frame.cc:266-267
+    const int c = (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) ? -1 : px * kGridRows + py;
+    F.tmpCell[k] = c;
+    if (c >= 0) F.tmpArr[k] = atomicAdd(&start[c], 1);
+  }
+  __syncthreads();
+  int loc[kPer], sum = 0;
+#pragma unroll
+  for (int i = 0; i < kPer; i++) { loc[i] = start[tid * kPer + i]; sum += loc[i]; }
+  int incl = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if ((tid & 63) >= o) incl += t;
+  }
+  if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+  __syncthreads();
+  int base = incl - sum;
+  for (int w = 0; w < (tid >> 6); w++) base += wsum[w];
+#pragma unroll
+  for (int i = 0; i < kPer; i++) { start[tid * kPer + i] = base; base += loc[i]; }
+  if (tid == 1023) start[kCells] = base;
+  __syncthreads();
+  for (int k = tid; k < n; k += 1024) {
+    const int c = F.tmpCell[k];
+    if (c >= 0) F.tmpBucket[start[c] + F.tmpArr[k]] = k;
+  }
+  __syncthreads();   // block-scope visibility of the bucket writes
+  for (int k = tid; k < n; k += 1024) {
+    const int c = F.tmpCell[k];
+    if (c < 0) continue;
+    const int b0 = start[c], b1 = start[c + 1];
+    int rank = 0;
+    for (int j = b0; j < b1; j++) rank += F.tmpBucket[j] < k;
+    const int p = b0 + rank;
+    F.sx[p] = F.x[k]; F.sy[p] = F.y[k]; F.soct[p] = F.oct[k]; F.sidx[p] = k;
+    copy32(F.tdesc + (size_t)p * 32, F.desc + (size_t)k * 32);
+  }
+  for (int c = tid; c <= kCells; c += 1024) F.cellStart[c] = start[c];
+  if (tid == 0) {
+    PairInfo pi;
+    pi.trainOff = 0; pi.cellOff = 0; pi.tdescOff = 0;
+    pi.minX = minX; pi.minY = minY; pi.invW = invW; pi.invH = invH;
+    *F.pair = pi;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The sequential bookkeeping on the device.
+// ---------------------------------------------------------------------------------------------------------------------
+enum { kModeMapPoints = 0, kModeUv = 1, kModeProjected = 2 };
+
+// Candidate entries as k_window_match leaves them for a resident frame: keypoint index | Hamming distance << 16 |
+// keypoint octave << 25, in GetFeaturesInArea order; candidates failing Fuse's chi-square gate are already gone.  Per
+// query a 16-byte record {count, first three entries}; longer lists lie in the pool at qoff.
+struct ResolveParams {
+  const uint32_t* rec; const uint32_t* qoff; const uint32_t* pool; uint32_t* total; uint32_t poolCap;
+  int nq, n;
+  const uint8_t* qclaim;    // != 0: an accepted match of this query makes its keypoint unavailable to later queries
+  const uint8_t* occ0;      // [n] keypoints unavailable from the start (mvpMapPoints occupancy / kp_skip); nullptr: none
+  const float* qangle; const float* kangle;
+  float nnratio; int maxDist; int checkOri;
+  int* scratch;             // generic kernel: [3 n] two table generations + kp_assigned
+  int* outHost;             // page-locked host memory, written by the kernel itself (no copy command behind it):
+                            // kp_assigned[n] (modes 0, 1) or best_idx[nq], best_dist[nq] (mode 2)
+  int* hdrHost;             // [kHdr] result header, page-locked host memory
+  int maxRounds;
+};
+
+// Best / second best of one query given the keypoints taken by earlier queries: fc[idx] = first query that claimed the
+// keypoint (-1: unavailable from the start, INT_MAX: free); query i may use idx iff fc[idx] >= i.
+template <int MODE>
+struct Best {
+  int bestDist = MODE == kModeProjected ? INT_MAX : 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+  __device__ __forceinline__ void consider(uint32_t e, int fcv, int i) {
+    if (fcv < i) return;                                   // ORBmatcher.cc:89-91, :1364-1366, :1493-1494, :376-377
+    const int idx = (int)(e & 0xffff), dist = (int)((e >> 16) & 0x1ff), oct = (int)(e >> 25);
+    if (MODE == kModeMapPoints) {                          // :95-109
+      if (dist < bestDist) {
+        bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel;
+        bestLevel = oct; bestIdx = idx;
+      } else if (dist < bestDist2) {
+        bestLevel2 = oct; bestDist2 = dist;
+      }
+    } else if (dist < bestDist) {
+      bestDist = dist; bestIdx = idx;
+    }
+  }
+  __device__ __forceinline__ int accept(const ResolveParams& R, int& distOut) const {
+    distOut = -1;
+    if (MODE == kModeMapPoints) {
+      if (bestDist > TH_HIGH) return -1;
+      if (bestLevel == bestLevel2 && (float)bestDist > R.nnratio * (float)bestDist2) return -1;   // :113-114
+    } else if (bestDist > R.maxDist) {
+      return -1;
+    }
+    distOut = bestDist;
+    return bestIdx;
+  }
+};
+
+__device__ __forceinline__ int rot_bin_dev(float a1, float a2) {   // ORBmatcher.cc:1385-1390 (factor = 1/HISTO_LENGTH quirk kept)
+  const float factor = 1.0f / HISTO_LENGTH;
+  float rot = a1 - a2;
+  if (rot < 0.0f) rot += 360.0f;
+  int bin = (int)roundf(rot * factor);
+  if (bin == HISTO_LENGTH) bin = 0;
+  return bin;
+}
+
+constexpr int kResolveThreads = 1024;
+
+// One block.  LDS = true (the launcher checks that the fixed tables fit the budget): per-query offsets into a
+// query-contiguous copy of the candidate entries, two generations of the "first claiming query" table, kp_assigned, the
+// claim and occupancy flags as bits -- all in LDS; the entries join them when `ldsEntries` has room for all of them, else
+// they are read from the records / the pool.  A round evaluates every query against the previous round's table and builds
+// the next one with LDS atomics; the fixed point is reached when two generations are equal.  LDS = false keeps the tables
+// in global scratch (any size).
+template <int MODE, bool LDS>
+__global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, int ldsEntries) {
+  extern __shared__ int dyn[];
+  __shared__ int hist[32];
+  __shared__ int acc[2];
+  __shared__ int wsum[kResolveThreads / 64];
+  const int tid = threadIdx.x, nq = R.nq, n = R.n;
+  const uint32_t tot = *R.total;
+  auto stamp = [&](int k) { if (tid == 0) R.hdrHost[16 + k] = (int)__builtin_readcyclecounter(); };   // phase clock (debug)
+  stamp(0);
+  if (tid < 32) hist[tid] = 0;
+  if (tid < 2) acc[tid] = 0;
+  __syncthreads();
+  if (tid == 0) {
+    R.hdrHost[4] = (int)tot;
+    *R.total = 0u;        // the counter is ready for the next search (every thread has read it)
+    R.hdrHost[1] = tot > R.poolCap ? 1 : 0;
+  }
+  if (tot > R.poolCap) return;   // candidate pool too small: the host grows it and submits again
+  int* offs = LDS ? dyn : nullptr;                       // [nq + 1]
+  int* fcA = LDS ? dyn + nq + 1 : R.scratch;            // [n]
+  int* fcB = fcA + n;                                    // [n]
+  int* kpAssigned = fcB + n;                             // [n]
+  uint32_t* claimBits = LDS ? reinterpret_cast<uint32_t*>(kpAssigned + n) : nullptr;   // [2 * ceil(nq / 64)]
+  uint32_t* occBits = LDS ? claimBits + 2 * ((nq + 63) >> 6) : nullptr;                 // [2 * ceil(n / 64)]
+  uint32_t* ent = LDS ? occBits + 2 * ((n + 63) >> 6) : nullptr;                        // [ldsEntries]
+  auto occupied = [&](int k) -> bool {
+    if (!R.occ0) return false;
+    return LDS ? ((occBits[k >> 5] >> (k & 31)) & 1u) != 0 : R.occ0[k] != 0;
+  };
+  if (LDS) {
+    if (tid == 0) offs[0] = 0;
+    // counts (from the records), claim and occupancy flags, coalesced; the flags become ballot words
+    for (int i0 = 0; i0 < nq; i0 += kResolveThreads) {
+      const int i = i0 + tid;
+      const bool in = i < nq;
+      if (in) offs[i + 1] = (int)R.rec[(size_t)i * 4];
+      const unsigned long long b = __ballot(in && R.qclaim[i] != 0);
+      if ((tid & 63) == 0 && in) {
+        claimBits[i >> 5] = (uint32_t)b;
+        claimBits[(i >> 5) + 1] = (uint32_t)(b >> 32);
+      }
+    }
+    if (R.occ0)
+      for (int k0 = 0; k0 < n; k0 += kResolveThreads) {
+        const int k = k0 + tid;
+        const unsigned long long b = __ballot(k < n && R.occ0[k] != 0);
+        if ((tid & 63) == 0 && k < n) {
+          occBits[k >> 5] = (uint32_t)b;
+          occBits[(k >> 5) + 1] = (uint32_t)(b >> 32);
+        }
+      }
+    __syncthreads();
+    // exclusive scan of the counts: a contiguous chunk per thread, wave scans of the chunk sums
+    const int chunk = (nq + kResolveThreads - 1) / kResolveThreads;
+    const int c0 = min(tid * chunk, nq), c1 = min(c0 + chunk, nq);
+    int sum = 0;
+    for (int i = c0; i < c1; i++) sum += offs[i + 1];
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if ((tid & 63) >= o) incl += t;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    int run = incl - sum;
+    for (int w = 0; w < (tid >> 6); w++) run += wsum[w];
+    for (int i = c0; i < c1; i++) { run += offs[i + 1]; offs[i + 1] = run; }
+    __syncthreads();
+  }
+  const bool entLds = LDS && offs[nq] <= ldsEntries;
+  for (int k = tid; k < n; k += kResolveThreads) {
+    const int base = occupied(k) ? -1 : INT_MAX;
+    fcA[k] = base; fcB[k] = base; kpAssigned[k] = -1;
+  }
+  if (entLds) {   // query-contiguous copy of the entries: one 16-byte record per query, all of a thread's loads independent
+#pragma unroll 4
+    for (int i = tid; i < nq; i += kResolveThreads) {
+      const int b = offs[i], c = offs[i + 1] - b;
+      if (c == 0) continue;
+      if (c <= kRecEntries) {
+        const uint4 r = reinterpret_cast<const uint4*>(R.rec)[i];
+        ent[b] = r.y;
+        if (c > 1) ent[b + 1] = r.z;
+        if (c > 2) ent[b + 2] = r.w;
+      } else {
+        const uint32_t* src = R.pool + R.qoff[i];
+        for (int j = 0; j < c; j++) ent[b + j] = src[j];
+      }
+    }
+  }
+  __syncthreads();
+  stamp(1);
+  auto claims = [&](int i) -> bool { return LDS ? ((claimBits[i >> 5] >> (i & 31)) & 1u) != 0 : R.qclaim[i] != 0; };
+  auto eval = [&](int i, const int* fc, int& d) -> int {
+    Best<MODE> B;
+    if (entLds) {
+      const int b = offs[i], cnt = offs[i + 1] - b;
+      d = -1;
+      if (cnt == 0) return -1;
+      // the first two entries and their table words travel together (two LDS round trips for the common short list)
+      const uint32_t e0 = ent[b], e1 = cnt > 1 ? ent[b + 1] : 0u;
+      const int f0 = fc[e0 & 0xffff], f1 = fc[e1 & 0xffff];
+      B.consider(e0, f0, i);
+      if (cnt > 1) B.consider(e1, f1, i);
+      for (int c = 2; c < cnt; c++) {
+        const uint32_t e = ent[b + c];
+        B.consider(e, fc[e & 0xffff], i);
+      }
+      return B.accept(R, d);
+    }
+    const uint4 r = reinterpret_cast<const uint4*>(R.rec)[i];
+    const int cnt = (int)r.x;
+    d = -1;
+    if (cnt == 0) return -1;
+    if (cnt <= kRecEntries) {
+      B.consider(r.y, fc[r.y & 0xffff], i);
+      if (cnt > 1) B.consider(r.z, fc[r.z & 0xffff], i);
+      if (cnt > 2) B.consider(r.w, fc[r.w & 0xffff], i);
+    } else {
+      const uint32_t* g = R.pool + R.qoff[i];
+      for (int c = 0; c < cnt; c++) {
+        const uint32_t e = g[c];
+        B.consider(e, fc[e & 0xffff], i);
+      }
+    }
+    return B.accept(R, d);
+  };
+  int* cur = fcA;     // the table the queries are evaluated against
+  int* next = fcB;    // the table their outcomes build (at its base state at the start of a round)
+  int rounds = 0;
+  for (;;) {
+    for (int i = tid; i < nq; i += kResolveThreads) {
+      int d;
+      const int m = eval(i, cur, d);
+      if (m >= 0 && claims(i)) atomicMin(&next[m], i);
+    }
+    __syncthreads();
+    int changed = 0;
+    for (int k = tid; k < n; k += kResolveThreads) {
+      changed |= next[k] != cur[k];
+      cur[k] = occupied(k) ? -1 : INT_MAX;          // becomes the next round's `next`
+    }
+    const int any = __syncthreads_or(changed);
+    { int* t = cur; cur = next; next = t; }
+    rounds++;
+    if (!any) break;             // outcomes are a function of the table: equal tables = the fixed point
+    if (rounds >= R.maxRounds) {   // long chains of keypoints taken from later queries: one serial pass finishes
+      for (int k = tid; k < n; k += kResolveThreads) cur[k] = occupied(k) ? -1 : INT_MAX;
+      __syncthreads();
+      if (tid == 0) {
+        for (int i = 0; i < nq; i++) {
+          int d;
+          const int m = eval(i, cur, d);
+          if (m >= 0 && claims(i) && cur[m] == INT_MAX) cur[m] = i;
+        }
+      }
+      __syncthreads();
+      rounds = -rounds;
+      break;
+    }
+  }
+  stamp(2);
+  // ---- outputs: every query once more against the settled table -------------------------------------------------
+  int nm = 0;
+  for (int i = tid; i < nq; i += kResolveThreads) {
+    int d;
+    const int m = eval(i, cur, d);
+    if (MODE == kModeProjected) { R.outHost[i] = m; R.outHost[nq + i] = d; }
+    if (m < 0) continue;
+    nm++;
+    if (MODE != kModeProjected) atomicMax(&kpAssigned[m], i);   // F.mvpMapPoints[bestIdx] = pMP: the last writer stays
+    if (MODE == kModeUv && R.checkOri) atomicAdd(&hist[rot_bin_dev(R.qangle[i], R.kangle[m])], 1);
+  }
+  __syncthreads();
+  if (MODE == kModeUv && R.checkOri) {
+    // ComputeThreeMaxima, ORBmatcher.cc:1554-1595 (every thread evaluates it identically); every push of a losing bin
+    // resets its keypoint and takes one off the count (:1404-1416)
+    int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
+    for (int i = 0; i < HISTO_LENGTH; i++) {
+      const int s = hist[i];
+      if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+      else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+      else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+    for (int i = tid; i < nq; i += kResolveThreads) {
+      int d;
+      const int m = eval(i, cur, d);
+      if (m < 0) continue;
+      const int b = rot_bin_dev(R.qangle[i], R.kangle[m]);
+      if (b != ind1 && b != ind2 && b != ind3) { kpAssigned[m] = -2; nm--; }
+    }
+    __syncthreads();
+  }
+  if (MODE != kModeProjected)
+    for (int k = tid; k < n; k += kResolveThreads) R.outHost[k] = kpAssigned[k];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nm += __shfl_xor(nm, o, 64);
+  if ((tid & 63) == 0 && nm) atomicAdd(&acc[0], nm);
+  __syncthreads();
+  if (tid == 0) { R.hdrHost[0] = acc[0]; R.hdrHost[2] = rounds; R.hdrHost[3] = LDS ? (entLds ? 2 : 1) : 0; }
+  stamp(3);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+struct orbfe_frame {
+  int device = 0, n = 0, maxOctave = 0;
+  float bounds[4] = {0, 0, 0, 0};
+  float invW = 0, invH = 0;
+  DevBuf<uint8_t> buf;
+  PinBuf<uint8_t> stage;
+  FrameDev D{};
+  hipEvent_t ready = nullptr;
+  ~orbfe_frame() {
+    (void)hipSetDevice(device);
+    if (ready) { (void)hipEventSynchronize(ready); (void)hipEventDestroy(ready); }
+    buf.release(); stage.release();
+  }
+  int carve(int count) {
+    const size_t c = (size_t)std::max(count, 1);
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += al(bytes); return at; };
+    const size_t ox = take(4 * c), oy = take(4 * c), oa = take(4 * c), oo = take(4 * c), od = take(32 * c), osx = take(4 * c),
+                 osy = take(4 * c), oso = take(4 * c), osi = take(4 * c), otd = take(32 * c), ocs = take(4 * (kCells + 1)),
+                 op = take(sizeof(PairInfo)), ot1 = take(4 * c), ot2 = take(4 * c), ot3 = take(4 * c);
+    int rc;
+    if ((rc = buf.ensure(o))) return rc;
+    uint8_t* B = buf.p;
+    D.x = (float*)(B + ox); D.y = (float*)(B + oy); D.angle = (float*)(B + oa); D.oct = (int*)(B + oo); D.desc = B + od;
+    D.sx = (float*)(B + osx); D.sy = (float*)(B + osy); D.soct = (int*)(B + oso); D.sidx = (int*)(B + osi); D.tdesc = B + otd;
+    D.cellStart = (int*)(B + ocs); D.pair = (PairInfo*)(B + op);
+    D.tmpCell = (int*)(B + ot1); D.tmpArr = (int*)(B + ot2); D.tmpBucket = (int*)(B + ot3);
+    D.n = count;
+    n = count;
+    return ORBFE_OK;
+  }
+  void setBounds(const float b[4]) {
+    for (int i = 0; i < 4; i++) bounds[i] = b[i];
+    invW = static_cast<float>(kGridCols) / static_cast<float>(b[1] - b[0]);   // Frame.cc:98
+    invH = static_cast<float>(kGridRows) / static_cast<float>(b[3] - b[2]);   // Frame.cc:99
+  }
+  int grid(hipStream_t st) {
+    hipLaunchKernelGGL(k_frame_grid, dim3(1), dim3(1024), 0, st, D, bounds[0], bounds[2], invW, invH);
+    HIP_TRY(hipGetLastError());
+    if (!ready) HIP_TRY(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ready, st));
+    return ORBFE_OK;
+  }
+  // (re)fill from host arrays on stream st
+  int fromHost(const OrbfeKeyPoint* kps, const uint8_t* desc, int count, const float b[4], hipStream_t st) {
+    int rc;
+    if ((rc = carve(count))) return rc;
+    setBounds(b);
+    maxOctave = 0;
+    for (int i = 0; i < count; i++) maxOctave = std::max(maxOctave, kps[i].octave < 0 ? INT_MAX : kps[i].octave);
+    if (count > 0) {
+      const size_t kb = al(sizeof(OrbfeKeyPoint) * (size_t)count), total = kb + 32 * (size_t)count;
+      if ((rc = stage.ensure(total))) return rc;
+      memcpy(stage.p, kps, sizeof(OrbfeKeyPoint) * (size_t)count);
+      memcpy(stage.p + kb, desc, 32 * (size_t)count);
+      // the keypoint records (28 B each) are staged in the grid-order descriptor array (32 B per keypoint), which the
+      // grid kernel fills only afterwards; the descriptor rows go straight to their final place
+      HIP_TRY(hipMemcpyAsync(D.tdesc, stage.p, sizeof(OrbfeKeyPoint) * (size_t)count, hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(D.desc, stage.p + kb, 32 * (size_t)count, hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(k_frame_from_host, dim3((count + 255) / 256), dim3(256), 0, st, (const OrbfeKeyPoint*)D.tdesc, D);
+    }
+    return grid(st);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One search on a resident frame: query arena (page-locked) -> device, k_window_match, k_resolve, result vector back.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct SearchPlan {
+  int nq = 0, n = 0, mode = 0, nlevels = 0;
+  float *qx = nullptr, *qy = nullptr, *qr = nullptr, *qangle = nullptr, *invSigma2 = nullptr;
+  int *qa = nullptr, *qb = nullptr;
+  uint8_t *qclaim = nullptr, *occ0 = nullptr, *qdesc = nullptr;
+  size_t oQx = 0, oQy = 0, oQr = 0, oQang = 0, oQa = 0, oQb = 0, oQc = 0, oOcc = 0, oSig = 0, oQd = 0, head = 0, total = 0;
+};
+
+// carve the query arena for nq queries against a frame of n keypoints; the caller fills the host views
+int plan_search(orbfe_matcher* m, const orbfe_frame* f, int mode, int nq, bool withOcc, int nlevelsSigma, SearchPlan* P) {
+  P->nq = nq; P->n = f->n; P->mode = mode; P->nlevels = nlevelsSigma;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += al(bytes); return at; };
+  const size_t q = (size_t)std::max(nq, 1);
+  P->oQx = take(4 * q); P->oQy = take(4 * q); P->oQr = take(4 * q); P->oQang = take(4 * q); P->oQa = take(4 * q); P->oQb = take(4 * q);
+  P->oQc = take(q); P->oOcc = take((size_t)std::max(f->n, 1)); P->oSig = take(4 * (size_t)std::max(nlevelsSigma, 1));
+  P->head = o;                 // everything up to here travels in one copy; the descriptors follow (or come from the caller's page-locked rows)
+  P->oQd = take(32 * q);
+  P->total = o;
+  int rc;
+  if ((rc = m->h_q.ensure(P->total))) return rc;
+  if ((rc = m->d_q.ensure(P->total))) return rc;
+  uint8_t* H = m->h_q.p;
+  P->qx = (float*)(H + P->oQx); P->qy = (float*)(H + P->oQy); P->qr = (float*)(H + P->oQr); P->qangle = (float*)(H + P->oQang);
+  P->qa = (int*)(H + P->oQa); P->qb = (int*)(H + P->oQb); P->qclaim = H + P->oQc;
+  P->occ0 = withOcc ? H + P->oOcc : nullptr;
+  P->invSigma2 = nlevelsSigma > 0 ? (float*)(H + P->oSig) : nullptr;
+  P->qdesc = H + P->oQd;
+  return ORBFE_OK;
+}
+
+// result header (ints): [0] nmatches, [1] candidate pool overflow, [2] rounds of the fixed point (< 0: finished serially),
+// [4] candidate entries needed, [8] the window kernel's running entry counter (zero between searches)
+constexpr int kHdr = 64;
+
+// out: pointer into the page-locked result area: kp_assigned[n] (modes 0, 1) or best_idx[nq], best_dist[nq] (mode 2)
+int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint8_t* qdescHost, float rmax, float nnratio,
+               int maxDist, double chi2, int checkOri, const int** out, int* nmatches) {
+  HIP_TRY(hipSetDevice(m->device));
+  if (f->device != m->device) { set_err("frame and matcher live on different devices"); return ORBFE_ERR_INVALID; }
+  const double tA = orbfe_matcher::nowMs();
+  hipStream_t st = m->stream;
+  const int nq = P.nq, n = P.n;
+  int rc;
+  const size_t outInts = P.mode == kModeProjected ? 2 * (size_t)nq : (size_t)n;
+  const size_t oCnt = kHdr, oOff = oCnt + nq, oRec = (oOff + nq + 3) & ~(size_t)3, oFc = oRec + 4 * (size_t)nq,
+               oFlags = oFc + 3 * (size_t)n, words = oFlags + ((size_t)nq + (size_t)n + 16) / 4 + 64;
+  if (m->d_r.n < words) {
+    if ((rc = m->d_r.ensure(words + words / 2))) return rc;
+    HIP_TRY(hipMemsetAsync(m->d_r.p, 0, kHdr * sizeof(int), st));   // a fresh allocation: the running counter starts at zero
+  }
+  if ((rc = m->h_r.ensure(kHdr + outInts + 64))) return rc;
+  if (f->ready) HIP_TRY(hipStreamWaitEvent(st, f->ready, 0));
+  // queries: one copy for the scalar arrays; descriptor rows straight from the caller's memory when it is page-locked
+  hipPointerAttribute_t attr;
+  const bool pinned = qdescHost && hipPointerGetAttributes(&attr, qdescHost) == hipSuccess && attr.type == hipMemoryTypeHost;
+  if (!pinned) (void)hipGetLastError();
+  // No upload command at all by default: the kernels read the page-locked query arena (and the caller's page-locked
+  // descriptor rows) over PCIe themselves -- every query word is read once, and a DMA in front of the first kernel costs its
+  // own latency plus a copy-engine -> compute hand-over (16 + 8 us measured for the 490 KB of 10 000 MapPoints).
+  // ORBFE_FRAME_ZEROCOPY=0 brings the upload back.
+  const char* zc = getenv("ORBFE_FRAME_ZEROCOPY");
+  const bool zeroCopy = !(zc && atoi(zc) == 0);
+  const uint8_t* qdescDev = m->d_q.p + P.oQd;
+  if (zeroCopy) {
+    if (pinned) qdescDev = qdescHost;
+    else { memcpy(P.qdesc, qdescHost, 32 * (size_t)nq); qdescDev = P.qdesc; }
+  } else if (pinned) {
+    HIP_TRY(hipMemcpyAsync(m->d_q.p, m->h_q.p, P.head, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(m->d_q.p + P.oQd, qdescHost, 32 * (size_t)nq, hipMemcpyHostToDevice, st));
+  } else {
+    memcpy(P.qdesc, qdescHost, 32 * (size_t)nq);
+    HIP_TRY(hipMemcpyAsync(m->d_q.p, m->h_q.p, P.oQd + 32 * (size_t)nq, hipMemcpyHostToDevice, st));
+  }
+  const double tB = orbfe_matcher::nowMs();
+  m->stageMs[0] = tB - tA;
+  uint8_t* Dq = zeroCopy ? m->h_q.p : m->d_q.p;
+  int* Dr = (int*)m->d_r.p;
+  size_t poolCap = m->d_pool.n ? m->d_pool.n : std::max<size_t>(1 << 16, (size_t)nq * 32);
+  for (int attempt = 0; attempt < 2; attempt++) {
+    if ((rc = m->d_pool.ensure(poolCap))) return rc;
+    MatchParams M;
+    M.sx = f->D.sx; M.sy = f->D.sy; M.soct = f->D.soct; M.sidx = f->D.sidx; M.cellStart = f->D.cellStart; M.tdesc = f->D.tdesc;
+    M.pairs = f->D.pair; M.qpair = nullptr;
+    M.qx = (const float*)(Dq + P.oQx); M.qy = (const float*)(Dq + P.oQy); M.qr = (const float*)(Dq + P.oQr);
+    M.qminL = (const int*)(Dq + P.oQa); M.qmaxL = (const int*)(Dq + P.oQb); M.qdesc = qdescDev;
+    M.nq = nq;
+    M.total = (uint32_t*)(Dr + 8); M.qcount = (uint32_t*)(Dr + oCnt); M.qoff = (uint32_t*)(Dr + oOff);
+    M.pool = m->d_pool.p; M.poolCap = (uint32_t)m->d_pool.n;
+    M.rec = (uint32_t*)(Dr + oRec);
+    uint8_t* dClaim = (uint8_t*)(Dr + oFlags);
+    uint8_t* dOcc = dClaim + ((nq + 7) & ~7);
+    M.copySrc[0] = Dq + P.oQc; M.copyDst[0] = dClaim; M.copyN[0] = nq;
+    if (P.occ0) { M.copySrc[1] = Dq + P.oOcc; M.copyDst[1] = dOcc; M.copyN[1] = n; }
+    M.invSigma2 = P.invSigma2 ? (const float*)(Dq + P.oSig) : nullptr;
+    M.chi2 = chi2;
+    M.packOctave = 1;
+    {
+      const float cols = 2.f * rmax * f->invW + 3.f;   // widest window in grid columns (+3: floor / ceil slack of the cell range)
+      const int maxCols = cols >= 64.f ? 64 : std::max(1, (int)std::ceil(cols));
+      int lpq = 8;
+      while (lpq < 64 && lpq < maxCols) lpq <<= 1;
+      const unsigned nblk = (unsigned)((nq + (kWinThreads / lpq) - 1) / (kWinThreads / lpq));
+      if (lpq == 8) hipLaunchKernelGGL(k_window_match<8>, dim3(nblk), dim3(kWinThreads), 0, st, M);
+      else if (lpq == 16) hipLaunchKernelGGL(k_window_match<16>, dim3(nblk), dim3(kWinThreads), 0, st, M);
+      else if (lpq == 32) hipLaunchKernelGGL(k_window_match<32>, dim3(nblk), dim3(kWinThreads), 0, st, M);
+      else hipLaunchKernelGGL(k_window_match<64>, dim3(nblk), dim3(kWinThreads), 0, st, M);
+    }
+    ResolveParams R;
+    R.rec = M.rec; R.qoff = M.qoff; R.pool = M.pool; R.total = M.total; R.poolCap = M.poolCap;
+    R.nq = nq; R.n = n;
+    R.occ0 = P.occ0 ? dOcc : nullptr;
+    R.qclaim = dClaim; R.qangle = (const float*)(Dq + P.oQang); R.kangle = f->D.angle;
+    R.nnratio = nnratio; R.maxDist = maxDist; R.checkOri = checkOri;
+    R.scratch = Dr + oFc;
+    R.hdrHost = m->h_r.p; R.outHost = m->h_r.p + kHdr;
+    const char* mr = getenv("ORBFE_RESOLVE_MAX_ROUNDS");   // rounds of the fixed point before the serial finish
+    R.maxRounds = mr ? std::max(1, atoi(mr)) : 48;
+    // LDS-resident tables when they fit (152 KB of the CU's 160): offsets, two table generations, claim bits; what is
+    // left holds the candidate entries (the kernel checks their number at run time)
+    const size_t fixedBytes = 4 * ((size_t)nq + 1 + 3 * (size_t)n + 2 * (((size_t)nq + 63) >> 6) + 2 * (((size_t)n + 63) >> 6) + 4);
+    const size_t budget = 152 * 1024;
+    const char* gen = getenv("ORBFE_RESOLVE_GENERIC");      // 1: tables in global scratch whatever the size (tests)
+    const bool lds = fixedBytes + 4096 <= budget && !(gen && atoi(gen) != 0);
+    const int ldsEntries = lds ? (int)((budget - fixedBytes) / 4) : 0;
+    const size_t dynBytes = lds ? budget : 0;
+#define ORBFE_LAUNCH_RESOLVE(MODE)                                                                                          \
+    do {                                                                                                                      \
+      if (lds) {                                                                                                              \
+        if (!m->resolveAttr[MODE]) {                                                                                          \
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resolve<MODE, true>),                                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget));                            \
+          m->resolveAttr[MODE] = true;                                                                                        \
+        }                                                                                                                     \
+        hipLaunchKernelGGL((k_resolve<MODE, true>), dim3(1), dim3(kResolveThreads), dynBytes, st, R, ldsEntries);             \
+      } else {                                                                                                                \
+        hipLaunchKernelGGL((k_resolve<MODE, false>), dim3(1), dim3(kResolveThreads), 0, st, R, 0);                            \
+      }                                                                                                                       \
+    } while (0)
+    if (P.mode == kModeMapPoints) ORBFE_LAUNCH_RESOLVE(kModeMapPoints);
+    else if (P.mode == kModeUv) ORBFE_LAUNCH_RESOLVE(kModeUv);
+    else ORBFE_LAUNCH_RESOLVE(kModeProjected);
+#undef ORBFE_LAUNCH_RESOLVE
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));   // the kernel wrote header and result vector into page-locked host memory itself
+    if (!m->h_r.p[1]) {
+      m->stageMs[1] = orbfe_matcher::nowMs() - tB;
+      m->stageMs[2] = 0;
+      m->lastRounds = m->h_r.p[2];
+      m->lastResolveRoute = m->h_r.p[3];
+      *nmatches = m->h_r.p[0];
+      *out = m->h_r.p + kHdr;
+      return ORBFE_OK;
+    }
+    poolCap = (size_t)(uint32_t)m->h_r.p[4] + 1024;   // pool too small: grow to the demand and submit again
+  }
+  set_err("candidate pool sizing failed");
+  return ORBFE_ERR_HIP;
+}
+
+// the transient frame behind the host-array call forms
+int scratch_frame(orbfe_matcher* m, const OrbfeKeyPoint* kps, const uint8_t* desc, int n, const float bounds[4], orbfe_frame** out) {
+  HIP_TRY(hipSetDevice(m->device));
+  if (!m->scratch) {
+    m->scratch = new orbfe_frame();
+    m->scratch->device = m->device;
+  }
+  const int rc = m->scratch->fromHost(kps, desc, n, bounds, m->stream);
+  *out = m->scratch;
+  return rc;
+}
+
+}  // namespace
+
+namespace orbfe {
+bool match_host_resolve() {   // ORBFE_MATCH_HOST_RESOLVE=1: the host-array searches keep the round-2 route (candidate lists to the host, bookkeeping there)
+  const char* e = getenv("ORBFE_MATCH_HOST_RESOLVE");   // read per call: the parity tests run both routes in one process
+  return e && atoi(e) != 0;
+}
+}  // namespace orbfe
+
+extern "C" {
+
+int orbfe_frame_create(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, const uint8_t* desc, int n, const float bounds[4],
+                       orbfe_frame** out) {
+  if (!m || !out || !bounds || n < 0 || n > 65535 || (n && (!kps_un || !desc))) {
+    set_err("bad argument (note: at most 65535 keypoints per frame)");
+    return ORBFE_ERR_INVALID;
+  }
+  *out = nullptr;
+  HIP_TRY(hipSetDevice(m->device));
+  orbfe_frame* f = new orbfe_frame();
+  f->device = m->device;
+  const int rc = f->fromHost(kps_un, desc, n, bounds, m->stream);
+  if (rc) { delete f; return rc; }
+  *out = f;
+  return ORBFE_OK;
+}
+
+int orbfe_frame_create_from_extract(orbfe_extractor* h, int frame_index, const float bounds[4], const float* xy_un,
+                                    orbfe_frame** out) {
+  if (!h || !out || !bounds) { set_err("NULL argument"); return ORBFE_ERR_INVALID; }
+  *out = nullptr;
+  orbfe::ExtractView V;
+  int rc = orbfe::extractor_view(h, frame_index, &V);
+  if (rc) return rc;
+  if (V.n > 65535) { set_err("at most 65535 keypoints per frame"); return ORBFE_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(V.device));
+  hipStream_t st = (hipStream_t)V.stream;
+  orbfe_frame* f = new orbfe_frame();
+  f->device = V.device;
+  if ((rc = f->carve(V.n))) { delete f; return rc; }
+  f->setBounds(bounds);
+  f->maxOctave = V.nlevels - 1;
+  if (V.n > 0) {
+    const float* dxy = nullptr;
+    if (xy_un) {   // undistorted coordinates: 8 bytes per keypoint, staged in the (not yet filled) grid-order x array
+      if ((rc = f->stage.ensure(8 * (size_t)V.n))) { delete f; return rc; }
+      memcpy(f->stage.p, xy_un, 8 * (size_t)V.n);
+      hipError_t e = hipMemcpyAsync(f->D.tdesc, f->stage.p, 8 * (size_t)V.n, hipMemcpyHostToDevice, st);
+      if (e != hipSuccess) { delete f; set_err("hipMemcpyAsync failed: %s", hipGetErrorString(e)); return ORBFE_ERR_HIP; }
+      dxy = (const float*)f->D.tdesc;
+    }
+    ExtractViewDev D;
+    D.sel = V.sel; D.angle = V.angle; D.desc = V.desc; D.nlevels = V.nlevels;
+    for (int l = 0; l <= orbfe::kMaxLevels; l++) D.selOff[l] = l <= V.nlevels ? V.selOff[l] : 0;
+    for (int l = 0; l < orbfe::kMaxLevels; l++) { D.count[l] = l < V.nlevels ? V.count[l] : 0; D.sf[l] = l < V.nlevels ? V.sf[l] : 1.f; }
+    hipLaunchKernelGGL(k_frame_from_extract, dim3((V.n + 255) / 256), dim3(256), 0, st, D, dxy, f->D);
+  }
+  if ((rc = f->grid(st))) { delete f; return rc; }
+  *out = f;
+  return ORBFE_OK;
+}
+
+void orbfe_frame_destroy(orbfe_frame* f) { delete f; }
+int orbfe_frame_size(const orbfe_frame* f) { return f ? f->n : 0; }
+
+int orbfe_frame_download(orbfe_frame* f, OrbfeKeyPoint* kps_un, uint8_t* desc, int32_t* grid_order, int32_t* cell_start) {
+  if (!f) { set_err("frame is NULL"); return ORBFE_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(f->device));
+  if (f->ready) HIP_TRY(hipEventSynchronize(f->ready));
+  const int n = f->n;
+  std::vector<float> x(n), y(n), a(n);
+  std::vector<int> o(n);
+  if (n) {
+    HIP_TRY(hipMemcpy(x.data(), f->D.x, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(y.data(), f->D.y, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(a.data(), f->D.angle, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(o.data(), f->D.oct, 4 * (size_t)n, hipMemcpyDeviceToHost));
+    if (desc) HIP_TRY(hipMemcpy(desc, f->D.desc, 32 * (size_t)n, hipMemcpyDeviceToHost));
+  }
+  if (kps_un)
+    for (int i = 0; i < n; i++) {
+      kps_un[i].x = x[i]; kps_un[i].y = y[i]; kps_un[i].angle = a[i]; kps_un[i].octave = o[i];
+      kps_un[i].size = 0.f; kps_un[i].response = 0.f; kps_un[i].class_id = -1;
+    }
+  int cs[kCells + 1];
+  HIP_TRY(hipMemcpy(cs, f->D.cellStart, sizeof cs, hipMemcpyDeviceToHost));
+  if (cell_start) memcpy(cell_start, cs, sizeof cs);
+  if (grid_order && cs[kCells] > 0) HIP_TRY(hipMemcpy(grid_order, f->D.sidx, 4 * (size_t)cs[kCells], hipMemcpyDeviceToHost));
+  return ORBFE_OK;
+}
+
+int orbfe_debug_resolve_rounds(const orbfe_matcher* m) { return m ? m->lastRounds : 0; }
+int orbfe_debug_resolve_route(const orbfe_matcher* m) { return m ? m->lastResolveRoute : -1; }
+int orbfe_debug_resolve_phases(const orbfe_matcher* m, int out[4]) {
+  if (!m || !out || !m->h_r.p) { set_err("bad argument"); return ORBFE_ERR_INVALID; }
+  for (int k = 0; k < 4; k++) out[k] = m->h_r.p[16 + k];
+  return ORBFE_OK;
+}
+
+// int ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, const float th)  (ORBmatcher.cc:45-132)
+int orbfe_search_by_projection_frame(orbfe_matcher* m, orbfe_frame* f, const float* scale_factors, int nlevels,
+                                     const uint8_t* kp_occupied, const float* mp_proj_xy, const int32_t* mp_level,
+                                     const float* mp_viewcos, const uint8_t* mp_flags, const uint8_t* mp_desc, int n_mp,
+                                     float th, float nnratio, int32_t* kp_assigned, int* nmatches) {
+  if (!m || !f || !nmatches || n_mp < 0 || !scale_factors || (f->n && (!kp_occupied || !kp_assigned)) ||
+      (n_mp && (!mp_proj_xy || !mp_level || !mp_viewcos || !mp_flags || !mp_desc))) {
+    set_err("bad argument");
+    return ORBFE_ERR_INVALID;
+  }
+  const int n = f->n;
+  *nmatches = 0;
+  for (int i = 0; i < n; i++) kp_assigned[i] = -1;
+  if (n_mp == 0 || n == 0) return ORBFE_OK;
+  SearchPlan P;
+  int rc = plan_search(m, f, kModeMapPoints, n_mp, true, 0, &P);
+  if (rc) return rc;
+  const bool bFactor = th != 1.0;
+  float rmax = 0.f;
+  for (int i = 0; i < n_mp; i++) {
+    const uint8_t fl = mp_flags[i];
+    P.qx[i] = mp_proj_xy[2 * i];
+    P.qy[i] = mp_proj_xy[2 * i + 1];
+    const int lvl = mp_level[i];
+    P.qa[i] = lvl - 1;       // F.GetFeaturesInArea(x, y, r * scale, nPredictedLevel - 1, nPredictedLevel), :72-73
+    P.qb[i] = lvl;
+    P.qclaim[i] = (fl & ORBFE_MP_OBSERVED) ? 1 : 0;
+    P.qangle[i] = 0.f;
+    if (!(fl & ORBFE_MP_IN_VIEW) || (fl & ORBFE_MP_BAD)) { P.qr[i] = -1.f; continue; }
+    if (lvl < 0 || lvl >= nlevels) { set_err("MapPoint %d: level %d out of range", i, lvl); return ORBFE_ERR_INVALID; }
+    float r = (fl & ORBFE_MP_CANDIDATO) ? 4.0 : (mp_viewcos[i] > 0.998 ? 2.5 : 4.0);  // ORBmatcher.cc:63-65, 126-132
+    if (bFactor) r *= th;
+    P.qr[i] = r * scale_factors[lvl];
+    rmax = std::max(rmax, P.qr[i]);
+  }
+  memcpy(P.occ0, kp_occupied, (size_t)n);
+  const int* out = nullptr;
+  if ((rc = run_search(m, f, P, mp_desc, rmax, nnratio, TH_HIGH, 0.0, 0, &out, nmatches))) return rc;
+  memcpy(kp_assigned, out, sizeof(int32_t) * (size_t)n);
+  return ORBFE_OK;
+}
+
+// SearchByProjection(Frame&, const Frame&, th) / (Frame&, KeyFrame*, set, th, ORBdist) from the projection onwards
+// (ORBmatcher.cc:1292-1423, 1425-1552)
+int orbfe_search_by_projection_uv_frame(orbfe_matcher* m, orbfe_frame* f, const float* scale_factors, int nlevels,
+                                        const uint8_t* kp_occupied, const float* src_uv, const int32_t* src_level,
+                                        const float* src_angle, const uint8_t* src_flags, const uint8_t* src_valid,
+                                        const uint8_t* src_desc, int n_src, float th, int max_dist, int skip_any_occupied,
+                                        int check_orientation, int32_t* kp_assigned, int* nmatches) {
+  if (!m || !f || !nmatches || n_src < 0 || !scale_factors || (f->n && (!kp_occupied || !kp_assigned)) ||
+      (n_src && (!src_uv || !src_level || !src_angle || !src_flags || !src_valid || !src_desc))) {
+    set_err("bad argument");
+    return ORBFE_ERR_INVALID;
+  }
+  const int n = f->n;
+  *nmatches = 0;
+  for (int i = 0; i < n; i++) kp_assigned[i] = -1;
+  if (n_src == 0 || n == 0) return ORBFE_OK;
+  SearchPlan P;
+  int rc = plan_search(m, f, kModeUv, n_src, true, 0, &P);
+  if (rc) return rc;
+  float rmax = 0.f;
+  for (int i = 0; i < n_src; i++) {
+    P.qx[i] = src_uv[2 * i];
+    P.qy[i] = src_uv[2 * i + 1];
+    const int lvl = src_level[i];
+    P.qa[i] = lvl - 1;       // GetFeaturesInArea(u, v, radius, nLastOctave - 1, nLastOctave + 1), :1356
+    P.qb[i] = lvl + 1;
+    P.qangle[i] = src_angle[i];
+    P.qclaim[i] = skip_any_occupied ? 1 : ((src_flags[i] & ORBFE_MP_OBSERVED) ? 1 : 0);
+    if (!src_valid[i]) { P.qr[i] = -1.f; continue; }
+    if (lvl < 0 || lvl >= nlevels) { set_err("source %d: level %d out of range", i, lvl); return ORBFE_ERR_INVALID; }
+    P.qr[i] = th * scale_factors[lvl];
+    rmax = std::max(rmax, P.qr[i]);
+  }
+  memcpy(P.occ0, kp_occupied, (size_t)n);
+  const int* out = nullptr;
+  if ((rc = run_search(m, f, P, src_desc, rmax, 0.f, max_dist, 0.0, check_orientation, &out, nmatches))) return rc;
+  memcpy(kp_assigned, out, sizeof(int32_t) * (size_t)n);
+  return ORBFE_OK;
+}
+
+// the projected best-match loop of SearchByProjection(KeyFrame*, Scw, ...), Fuse x2 and SearchBySim3
+// (ORBmatcher.cc:357-392, 872-936, 1014-1050, 1066-1290)
+int orbfe_search_projected_frame(orbfe_matcher* m, orbfe_frame* f, int n_src, const float* src_uv, const float* src_radius,
+                                 const int32_t* src_level, const uint8_t* src_valid, const uint8_t* src_desc,
+                                 const uint8_t* kp_skip, int claim, const float* inv_level_sigma2, int nlevels, double chi2,
+                                 int max_dist, int32_t* best_idx, int32_t* best_dist, int* nmatches) {
+  if (!m || !f || !nmatches || n_src < 0 ||
+      (n_src && (!src_uv || !src_radius || !src_level || !src_valid || !src_desc || !best_idx)) ||
+      (inv_level_sigma2 && (nlevels < 1 || nlevels > 64))) {
+    set_err("bad argument");
+    return ORBFE_ERR_INVALID;
+  }
+  const int n = f->n;
+  *nmatches = 0;
+  for (int i = 0; i < n_src; i++) {
+    best_idx[i] = -1;
+    if (best_dist) best_dist[i] = -1;
+  }
+  if (n_src == 0 || n == 0) return ORBFE_OK;
+  if (inv_level_sigma2 && f->maxOctave >= nlevels) { set_err("keypoint octave out of range"); return ORBFE_ERR_INVALID; }
+  SearchPlan P;
+  int rc = plan_search(m, f, kModeProjected, n_src, kp_skip != nullptr, inv_level_sigma2 ? nlevels : 0, &P);
+  if (rc) return rc;
+  float rmax = 0.f;
+  for (int i = 0; i < n_src; i++) {
+    P.qx[i] = src_uv[2 * i];
+    P.qy[i] = src_uv[2 * i + 1];
+    P.qa[i] = src_level[i] - 1;                      // kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel => skip
+    P.qb[i] = src_level[i];
+    P.qangle[i] = 0.f;
+    P.qclaim[i] = claim ? 1 : 0;
+    P.qr[i] = (src_valid[i] && src_level[i] >= 0) ? src_radius[i] : -1.f;   // no octave lies in [level-1, level] for level < 0
+    rmax = std::max(rmax, P.qr[i]);
+  }
+  if (kp_skip) memcpy(P.occ0, kp_skip, (size_t)n);
+  if (inv_level_sigma2) memcpy(P.invSigma2, inv_level_sigma2, sizeof(float) * (size_t)nlevels);
+  const int* out = nullptr;
+  if ((rc = run_search(m, f, P, src_desc, rmax, 0.f, max_dist, chi2, 0, &out, nmatches))) return rc;
+  memcpy(best_idx, out, sizeof(int32_t) * (size_t)n_src);
+  if (best_dist) memcpy(best_dist, out + n_src, sizeof(int32_t) * (size_t)n_src);
+  return ORBFE_OK;
+}
+
+}  // extern "C"
+
+// host-array forms (orbfe_matcher.hip) route here: a transient frame owned by the matcher, then the search above
+namespace orbfe {
+int sbp_via_frame(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, const uint8_t* desc, int n, const float bounds[4],
+                  const float* scale_factors, int nlevels, const uint8_t* kp_occupied, const float* mp_proj_xy,
+                  const int32_t* mp_level, const float* mp_viewcos, const uint8_t* mp_flags, const uint8_t* mp_desc, int n_mp,
+                  float th, float nnratio, int32_t* kp_assigned, int* nmatches) {
+  orbfe_frame* f = nullptr;
+  const int rc = scratch_frame(m, kps_un, desc, n, bounds, &f);
+  if (rc) return rc;
+  return orbfe_search_by_projection_frame(m, f, scale_factors, nlevels, kp_occupied, mp_proj_xy, mp_level, mp_viewcos, mp_flags,
+                                          mp_desc, n_mp, th, nnratio, kp_assigned, nmatches);
+}
+int sbp_uv_via_frame(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, const uint8_t* desc, int n, const float bounds[4],
+                     const float* scale_factors, int nlevels, const uint8_t* kp_occupied, const float* src_uv,
+                     const int32_t* src_level, const float* src_angle, const uint8_t* src_flags, const uint8_t* src_valid,
+                     const uint8_t* src_desc, int n_src, float th, int max_dist, int skip_any_occupied, int check_orientation,
+                     int32_t* kp_assigned, int* nmatches) {
+  orbfe_frame* f = nullptr;
+  const int rc = scratch_frame(m, kps_un, desc, n, bounds, &f);
+  if (rc) return rc;
+  return orbfe_search_by_projection_uv_frame(m, f, scale_factors, nlevels, kp_occupied, src_uv, src_level, src_angle, src_flags,
+                                             src_valid, src_desc, n_src, th, max_dist, skip_any_occupied, check_orientation,
+                                             kp_assigned, nmatches);
+}
+int projected_via_frame(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, const uint8_t* desc, int n, const float bounds[4], int n_src,
+                        const float* src_uv, const float* src_radius, const int32_t* src_level, const uint8_t* src_valid,
+                        const uint8_t* src_desc, const uint8_t* kp_skip, int claim, const float* inv_level_sigma2, int nlevels,
+                        double chi2, int max_dist, int32_t* best_idx, int32_t* best_dist, int* nmatches) {
+  orbfe_frame* f = nullptr;
+  const int rc = scratch_frame(m, kps_un, desc, n, bounds, &f);
+  if (rc) return rc;
+  return orbfe_search_projected_frame(m, f, n_src, src_uv, src_radius, src_level, src_valid, src_desc, kp_skip, claim,
+                                      inv_level_sigma2, nlevels, chi2, max_dist, best_idx, best_dist, nmatches);
+}
+}  // namespace orbfe

@@ -104,6 +104,20 @@ struct SelKp {
   uint32_t lf;     // level | frame << 8
 };
 
+// ---- view of one frame of an extractor's last collected batch, for building a device-resident orbfe_frame from it
+// (orbfe_frame.hip): the result arena's slots as the kernels left them -- in device memory, or in page-locked host
+// memory (device-readable) when the latency route wrote the results there.
+struct ExtractView {
+  const SelKp* sel;            // first slot of the frame
+  const float* angle;
+  const uint8_t* desc;
+  int selOff[kMaxLevels + 1];  // first slot of every level inside the frame's slot region
+  int count[kMaxLevels];       // keypoints per level (host copy of selCount)
+  float sf[kMaxLevels];        // mvScaleFactor
+  int nlevels, n, device;
+  void* stream;                // hipStream_t the arena is ordered on
+};
+
 // ---- GPU-resident SearchForInitialization over consecutive frames (orbfe_sfi.hip) ------------------------
 struct SfiParams {
   // result arena of the batch (device): level-0 slots are the first region of every frame

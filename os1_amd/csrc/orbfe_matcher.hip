@@ -16,165 +16,27 @@
 // the order Frame::GetFeaturesInArea would return them -- is one kernel (one wave per query,
 // ballot-ordered compaction).  The order-dependent bookkeeping is replayed on the host over those
 // short candidate lists, statement for statement.
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <chrono>
-#include <climits>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <memory>
-#include <string>
-#include <thread>
-#include <vector>
-
-#include "../../include/orbfe.h"
-#include "host_pool.h"
+#include "orbfe_matcher_internal.h"
 
 namespace orbfe {
-void set_err(const char* fmt, ...);
-}
-using orbfe::set_err;
-
-#define HIP_TRY(expr)                                                                        \
-  do {                                                                                       \
-    hipError_t e_ = (expr);                                                                  \
-    if (e_ != hipSuccess) {                                                                  \
-      set_err("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);    \
-      return ORBFE_ERR_HIP;                                                                  \
-    }                                                                                        \
-  } while (0)
+// orbfe_frame.hip: the host-array searches run on a transient device-resident frame + GPU-side bookkeeping
+bool match_host_resolve();
+int sbp_via_frame(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, const uint8_t* desc, int n, const float bounds[4],
+                  const float* scale_factors, int nlevels, const uint8_t* kp_occupied, const float* mp_proj_xy,
+                  const int32_t* mp_level, const float* mp_viewcos, const uint8_t* mp_flags, const uint8_t* mp_desc, int n_mp,
+                  float th, float nnratio, int32_t* kp_assigned, int* nmatches);
+int sbp_uv_via_frame(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, const uint8_t* desc, int n, const float bounds[4],
+                     const float* scale_factors, int nlevels, const uint8_t* kp_occupied, const float* src_uv,
+                     const int32_t* src_level, const float* src_angle, const uint8_t* src_flags, const uint8_t* src_valid,
+                     const uint8_t* src_desc, int n_src, float th, int max_dist, int skip_any_occupied, int check_orientation,
+                     int32_t* kp_assigned, int* nmatches);
+int projected_via_frame(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, const uint8_t* desc, int n, const float bounds[4], int n_src,
+                        const float* src_uv, const float* src_radius, const int32_t* src_level, const uint8_t* src_valid,
+                        const uint8_t* src_desc, const uint8_t* kp_skip, int claim, const float* inv_level_sigma2, int nlevels,
+                        double chi2, int max_dist, int32_t* best_idx, int32_t* best_dist, int* nmatches);
+}  // namespace orbfe
 
 namespace {
-
-constexpr int kGridCols = 64, kGridRows = 48;  // FRAME_GRID_COLS / FRAME_GRID_ROWS (Frame.h:36-37)
-constexpr int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;  // ORBmatcher.cc:37-39
-
-// One "pair" = one train frame (grid-sorted keypoints + descriptors) and a run of queries against it.
-struct PairInfo {
-  int trainOff;    // first entry of the pair in sx/sy/soct/sidx
-  int cellOff;     // first entry of the pair's cellStart table ([64*48+1] ints)
-  int tdescOff;    // first descriptor row of the pair's train frame in tdesc
-  float minX, minY, invW, invH;
-};
-
-struct MatchParams {
-  // train frames, keypoints permuted into grid order (cell = ix*48+iy ascending, insertion order inside)
-  const float* sx;
-  const float* sy;
-  const int* soct;
-  const int* sidx;        // original keypoint index inside its frame
-  const int* cellStart;   // per pair [64*48+1], values relative to the pair's trainOff
-  const uint8_t* tdesc;   // descriptor rows in the same grid-sorted order as sx/sy/soct/sidx
-  const PairInfo* pairs;
-  // queries (all pairs concatenated)
-  const int* qpair;       // pair of each query
-  const float* qx;
-  const float* qy;
-  const float* qr;        // < 0 : inactive query
-  const int* qminL;
-  const int* qmaxL;
-  const uint8_t* qdesc;   // [nq][32]
-  int nq;
-  // outputs
-  uint32_t* qcount;       // [nq]
-  uint32_t* qoff;         // [nq] offset into pool
-  uint32_t* pool;         // entries: idx | dist << 16, reference candidate order per query
-  uint32_t poolCap;
-  uint32_t* total;        // [1] pool entries claimed (may exceed poolCap: host retries with a larger pool)
-};
-
-__device__ __forceinline__ int hamming256(const uint32_t* __restrict__ a, const uint32_t q[8]) {
-  int d = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) d += __popc(a[i] ^ q[i]);
-  return d;
-}
-
-// LPQ lanes per query (64/LPQ queries per wave), one LANE per grid column of the window.  Window
-// semantics: Frame::GetFeaturesInArea, Frame.cc:209-262: columns ix ascending, rows iy ascending inside a
-// column, insertion order inside a cell -- i.e. for column ix the contiguous run
-// [cellStart[ix*48+cy0], cellStart[ix*48+cy1+1]) of the cell-sorted keypoint table.  Lane l of a query's
-// group walks the run of column cx0+l (a handful of entries), a prefix sum over the group's hit counts
-// gives every lane its output offset, so the candidate list comes out in exactly the reference order in
-// a single pass with all columns in flight at once.  The host picks LPQ >= the widest window in columns.
-template <int LPQ>
-__global__ __launch_bounds__(64) void k_window_match(MatchParams M) {
-  const int lane = threadIdx.x;
-  const int sub = lane & (LPQ - 1);
-  const int q = blockIdx.x * (64 / LPQ) + lane / LPQ;
-  const bool live = q < M.nq;
-  float r = -1.f, x = 0.f, y = 0.f;
-  int minL = 0, maxL = -1;
-  PairInfo pi = M.pairs[0];
-  if (live) {
-    r = M.qr[q]; x = M.qx[q]; y = M.qy[q]; minL = M.qminL[q]; maxL = M.qmaxL[q];
-    pi = M.pairs[M.qpair[q]];
-  }
-  const float* sx = M.sx + pi.trainOff;
-  const float* sy = M.sy + pi.trainOff;
-  const int* soct = M.soct + pi.trainOff;
-  const int* sidx = M.sidx + pi.trainOff;
-  const int* cellStart = M.cellStart + pi.cellOff;
-  const uint8_t* tdesc = M.tdesc + (size_t)pi.tdescOff * 32;
-  int cx0 = 0, cx1 = -1, cy0 = 0, cy1 = -1;
-  if (live && r >= 0.f) {
-    cx0 = max(0, (int)floorf((x - pi.minX - r) * pi.invW));
-    cx1 = min(kGridCols - 1, (int)ceilf((x - pi.minX + r) * pi.invW));
-    cy0 = max(0, (int)floorf((y - pi.minY - r) * pi.invH));
-    cy1 = min(kGridRows - 1, (int)ceilf((y - pi.minY + r) * pi.invH));
-    if (cx0 >= kGridCols || cx1 < 0 || cy0 >= kGridRows || cy1 < 0) cx1 = cx0 - 1;  // empty window
-  }
-  const bool checkLevels = (minL > 0) || (maxL >= 0);
-  const int ix = cx0 + sub;
-  int b = 0, e1 = 0;
-  if (ix <= cx1) {
-    b = cellStart[ix * kGridRows + cy0];
-    e1 = cellStart[ix * kGridRows + cy1 + 1];
-  }
-  auto inWindow = [&](int e) -> bool {
-    if (checkLevels) {
-      const int o = soct[e];
-      if (o < minL) return false;
-      if (maxL >= 0 && o > maxL) return false;
-    }
-    const float dx = sx[e] - x, dy = sy[e] - y;
-    return fabsf(dx) < r && fabsf(dy) < r;
-  };
-  // pass 1: hits per column, prefix sum inside the query's lane group
-  int hits = 0;
-  for (int e = b; e < e1; e++) hits += inWindow(e) ? 1 : 0;
-  int incl = hits;
-#pragma unroll
-  for (int o = 1; o < LPQ; o <<= 1) {
-    const int t = __shfl_up(incl, o, LPQ);
-    if (sub >= o) incl += t;
-  }
-  const uint32_t count = (uint32_t)__shfl(incl, LPQ - 1, LPQ);
-  uint32_t off = 0;
-  if (live && sub == 0) {
-    if (count) off = atomicAdd(M.total, count);
-    M.qcount[q] = count;
-    M.qoff[q] = off;
-  }
-  off = __shfl(off, 0, LPQ);
-  if (hits == 0) return;
-  uint32_t qd[8];
-  const uint32_t* qp = reinterpret_cast<const uint32_t*>(M.qdesc + (size_t)q * 32);
-#pragma unroll
-  for (int i = 0; i < 8; i++) qd[i] = qp[i];
-  // pass 2: distances, written at the lane's offset in column order
-  uint32_t pos = off + (uint32_t)(incl - hits);
-  for (int e = b; e < e1; e++) {
-    if (!inWindow(e)) continue;
-    const int idx = sidx[e];
-    const int d = hamming256(reinterpret_cast<const uint32_t*>(tdesc + (size_t)e * 32), qd);  // descriptors are grid-sorted
-    if (pos < M.poolCap) M.pool[pos] = (uint32_t)idx | ((uint32_t)d << 16);
-    pos++;
-  }
-}
 
 // MapPoint::ComputeDistinctiveDescriptors (MapPoint.cc:258-286): one wave per MapPoint.  Lane i owns row i of
 // the N x N distance matrix (rows beyond 64 in further passes); the row median (element of rank (N-1)/2) is the
@@ -220,36 +82,6 @@ __global__ __launch_bounds__(64) void k_distinctive(const int* __restrict__ offs
   if (lane == 0) best[p] = bestIdx;
 }
 
-template <class T>
-struct DevBuf {
-  T* p = nullptr;
-  size_t n = 0;
-  int ensure(size_t count) {
-    if (count <= n) return ORBFE_OK;
-    if (p) (void)hipFree(p);
-    p = nullptr; n = 0;
-    HIP_TRY(hipMalloc((void**)&p, count * sizeof(T)));
-    n = count;
-    return ORBFE_OK;
-  }
-  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
-};
-template <class T>
-struct PinBuf {
-  T* p = nullptr;
-  size_t n = 0;
-  int ensure(size_t count) {
-    if (count <= n) return ORBFE_OK;
-    if (p) (void)hipHostFree(p);
-    p = nullptr; n = 0;
-    HIP_TRY(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault));
-    n = count;
-    return ORBFE_OK;
-  }
-  void release() { if (p) (void)hipHostFree(p); p = nullptr; n = 0; }
-};
-
-inline size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 
 void computeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3) {
   int max1 = 0, max2 = 0, max3 = 0;
@@ -274,234 +106,6 @@ inline int rotBin(float a1, float a2) {  // ORBmatcher.cc:470-475 (factor = 1/HI
 
 }  // namespace
 
-struct orbfe_matcher {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  std::shared_ptr<void> bow;   // scratch of orbfe_search_by_bow (orbfe_bow.hip)
-  DevBuf<uint8_t> d_in;    // packed upload arena
-  PinBuf<uint8_t> h_in;
-  DevBuf<uint32_t> d_out;  // [total(1) pad][qcount nq][qoff nq]
-  PinBuf<uint32_t> h_out;
-  DevBuf<uint32_t> d_pool;
-  PinBuf<uint32_t> h_pool;
-  ~orbfe_matcher() {
-    (void)hipSetDevice(device);
-    d_in.release(); h_in.release(); d_out.release(); h_out.release(); d_pool.release(); h_pool.release();
-    if (stream) (void)hipStreamDestroy(stream);
-  }
-
-  // One search job: a train frame and a run of queries against it (host pointers).
-  struct Job {
-    const OrbfeKeyPoint* kps; const uint8_t* desc; int n; const float* bounds;
-    const float* qx; const float* qy; const float* qr; const int* qminL; const int* qmaxL; const uint8_t* qdesc; int nq;
-  };
-  // Results of the last candidates() call: per job the first query index; per query count/offset; pool.
-  std::vector<int> jobQ0;
-  const uint32_t* qcount = nullptr;
-  const uint32_t* qoff = nullptr;
-
-  double stageMs[4] = {0, 0, 0, 0};  // arena build, upload+kernel+download, (resolve: filled by callers), total
-  static double nowMs() {
-    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-  }
-
-  // Results of candidates(), indexed by ORIGINAL query number (all jobs concatenated)
-  std::vector<uint32_t> qcountFull, qoffFull;
-  std::vector<int> qmap;        // compact (launched) query -> original query
-  struct JobPlan { int lo, hi; size_t trainOff, q0c; int nTrain, nqc; };
-  std::vector<JobPlan> plan;
-
-  // Runs the window kernel for all jobs in ONE upload + ONE launch.  Only what can influence a result is
-  // uploaded: active queries (r >= 0) and the train keypoints whose octave some active query of the job
-  // accepts (e.g. SearchForInitialization touches level-0 keypoints only, ORBmatcher.cc:416-420).
-  // Dropping the others cannot change any candidate list: Frame::GetFeaturesInArea would skip them.
-  int candidates(const Job* jobs, int njobs) {
-    const double tA = nowMs();
-    HIP_TRY(hipSetDevice(device));
-    int rc;
-    const int ncell = kGridCols * kGridRows;
-    jobQ0.assign(njobs + 1, 0);
-    plan.assign(njobs, JobPlan{});
-    size_t nTrain = 0, nqOrig = 0, nq = 0;
-    for (int j = 0; j < njobs; j++) {
-      const Job& J = jobs[j];
-      jobQ0[j] = (int)nqOrig;
-      nqOrig += J.nq;
-      JobPlan& pl = plan[j];
-      pl.lo = INT_MAX; pl.hi = INT_MIN; pl.nqc = 0;
-      for (int q = 0; q < J.nq; q++) {
-        if (!(J.qr[q] >= 0.f)) continue;
-        pl.nqc++;
-        const bool check = (J.qminL[q] > 0) || (J.qmaxL[q] >= 0);
-        const int lo = check ? J.qminL[q] : INT_MIN, hi = (check && J.qmaxL[q] >= 0) ? J.qmaxL[q] : INT_MAX;
-        pl.lo = std::min(pl.lo, lo);
-        pl.hi = std::max(pl.hi, hi);
-      }
-      pl.trainOff = nTrain;
-      pl.q0c = nq;
-      nq += pl.nqc;
-      int cnt = 0;
-      if (pl.nqc)
-        for (int i = 0; i < J.n; i++) cnt += (J.kps[i].octave >= pl.lo && J.kps[i].octave <= pl.hi) ? 1 : 0;
-      pl.nTrain = cnt;   // upper bound (keypoints outside the grid are dropped below)
-      nTrain += cnt;
-    }
-    int maxCols = 1;
-    for (int j = 0; j < njobs; j++) {
-      const Job& J = jobs[j];
-      const float invW = static_cast<float>(kGridCols) / static_cast<float>(J.bounds[1] - J.bounds[0]);
-      float rmax = 0.f;
-      for (int q = 0; q < J.nq; q++) rmax = std::max(rmax, J.qr[q]);
-      const float cols = 2.f * rmax * invW + 3.f;
-      maxCols = std::max(maxCols, cols >= 64.f ? 64 : (int)std::ceil(cols));
-    }
-    jobQ0[njobs] = (int)nqOrig;
-    qcountFull.assign(nqOrig, 0);
-    qoffFull.assign(nqOrig, 0);
-    qmap.resize(nq);
-    if (nq == 0) {
-      qcount = qcountFull.data();
-      qoff = qoffFull.data();
-      stageMs[0] = nowMs() - tA;
-      stageMs[1] = 0;
-      return ORBFE_OK;
-    }
-    // arena layout (one H2D copy); train descriptors are stored in grid-sorted order
-    const size_t oSx = 0, oSy = oSx + al(4 * nTrain), oOct = oSy + al(4 * nTrain), oIdx = oOct + al(4 * nTrain),
-                 oCell = oIdx + al(4 * nTrain), oTd = oCell + al(4 * (size_t)(ncell + 1) * njobs),
-                 oPair = oTd + al(32 * nTrain), oQp = oPair + al(sizeof(PairInfo) * (size_t)njobs),
-                 oQx = oQp + al(4 * nq), oQy = oQx + al(4 * nq), oQr = oQy + al(4 * nq), oQa = oQr + al(4 * nq),
-                 oQb = oQa + al(4 * nq), oQd = oQb + al(4 * nq), total = oQd + al(32 * nq);
-    if ((rc = h_in.ensure(total))) return rc;
-    if ((rc = d_in.ensure(total))) return rc;
-    uint8_t* H = h_in.p;
-    pool->parallelFor(njobs, [&](int j, int) {
-      const Job& J = jobs[j];
-      const JobPlan& pl = plan[j];
-      const float minX = J.bounds[0], maxX = J.bounds[1], minY = J.bounds[2], maxY = J.bounds[3];
-      const float invW = static_cast<float>(kGridCols) / static_cast<float>(maxX - minX);   // Frame.cc:98
-      const float invH = static_cast<float>(kGridRows) / static_cast<float>(maxY - minY);   // Frame.cc:99
-      int* cellCnt = (int*)(H + oCell) + (size_t)(ncell + 1) * j;
-      for (int c = 0; c <= ncell; c++) cellCnt[c] = 0;
-      PairInfo pi;
-      pi.trainOff = (int)pl.trainOff; pi.cellOff = (ncell + 1) * j; pi.tdescOff = (int)pl.trainOff;
-      pi.minX = minX; pi.minY = minY; pi.invW = invW; pi.invH = invH;
-      ((PairInfo*)(H + oPair))[j] = pi;
-      if (pl.nqc == 0) return;
-      // AssignFeaturesToGrid / PosInGrid (Frame.cc:114-129, 264-274) as a stable counting sort by cell
-      std::vector<int> cellOf(J.n);
-      for (int i = 0; i < J.n; i++) {
-        cellOf[i] = -1;
-        if (J.kps[i].octave < pl.lo || J.kps[i].octave > pl.hi) continue;
-        const int px = (int)roundf((J.kps[i].x - minX) * invW);
-        const int py = (int)roundf((J.kps[i].y - minY) * invH);
-        if (px < 0 || px >= kGridCols || py < 0 || py >= kGridRows) continue;
-        cellOf[i] = px * kGridRows + py;
-        cellCnt[cellOf[i] + 1]++;
-      }
-      for (int c = 0; c < ncell; c++) cellCnt[c + 1] += cellCnt[c];
-      std::vector<int> order(cellCnt, cellCnt + ncell);
-      float* sx = (float*)(H + oSx) + pl.trainOff;
-      float* sy = (float*)(H + oSy) + pl.trainOff;
-      int* so = (int*)(H + oOct) + pl.trainOff;
-      int* si = (int*)(H + oIdx) + pl.trainOff;
-      uint8_t* td = H + oTd + 32 * pl.trainOff;
-      for (int i = 0; i < J.n; i++) {
-        if (cellOf[i] < 0) continue;
-        const int p = order[cellOf[i]]++;
-        sx[p] = J.kps[i].x; sy[p] = J.kps[i].y; so[p] = J.kps[i].octave; si[p] = i;
-        memcpy(td + 32 * (size_t)p, J.desc + 32 * (size_t)i, 32);
-      }
-      // active queries, compacted
-      int* qp = (int*)(H + oQp) + pl.q0c;
-      float* qxo = (float*)(H + oQx) + pl.q0c;
-      float* qyo = (float*)(H + oQy) + pl.q0c;
-      float* qro = (float*)(H + oQr) + pl.q0c;
-      int* qao = (int*)(H + oQa) + pl.q0c;
-      int* qbo = (int*)(H + oQb) + pl.q0c;
-      uint8_t* qdo = H + oQd + 32 * pl.q0c;
-      int c = 0;
-      for (int q = 0; q < J.nq; q++) {
-        if (!(J.qr[q] >= 0.f)) continue;
-        qp[c] = j; qxo[c] = J.qx[q]; qyo[c] = J.qy[q]; qro[c] = J.qr[q]; qao[c] = J.qminL[q]; qbo[c] = J.qmaxL[q];
-        memcpy(qdo + 32 * (size_t)c, J.qdesc + 32 * (size_t)q, 32);
-        qmap[pl.q0c + c] = jobQ0[j] + q;
-        c++;
-      }
-    });
-    const double tB = nowMs();
-    stageMs[0] = tB - tA;
-    // ORBFE_MATCH_ZEROCOPY=1: the kernel reads the pinned host arena directly over PCIe instead of a DMA upload
-    static const bool zeroCopy = getenv("ORBFE_MATCH_ZEROCOPY") && atoi(getenv("ORBFE_MATCH_ZEROCOPY")) != 0;
-    if (!zeroCopy) HIP_TRY(hipMemcpyAsync(d_in.p, H, total, hipMemcpyHostToDevice, stream));
-
-    const size_t outWords = 64 + 2 * nq;
-    if ((rc = d_out.ensure(outWords))) return rc;
-    if ((rc = h_out.ensure(outWords))) return rc;
-    size_t poolCap = d_pool.n ? d_pool.n : std::max<size_t>(1 << 16, nq * 32);
-    for (int attempt = 0; attempt < 2; attempt++) {
-      if ((rc = d_pool.ensure(poolCap))) return rc;
-      HIP_TRY(hipMemsetAsync(d_out.p, 0, 64 * sizeof(uint32_t), stream));
-      MatchParams M;
-      uint8_t* D = zeroCopy ? H : d_in.p;
-      M.sx = (const float*)(D + oSx); M.sy = (const float*)(D + oSy); M.soct = (const int*)(D + oOct);
-      M.sidx = (const int*)(D + oIdx); M.cellStart = (const int*)(D + oCell); M.tdesc = D + oTd;
-      M.pairs = (const PairInfo*)(D + oPair); M.qpair = (const int*)(D + oQp);
-      M.qx = (const float*)(D + oQx); M.qy = (const float*)(D + oQy); M.qr = (const float*)(D + oQr);
-      M.qminL = (const int*)(D + oQa); M.qmaxL = (const int*)(D + oQb); M.qdesc = D + oQd;
-      M.nq = (int)nq;
-      M.total = d_out.p; M.qcount = d_out.p + 64; M.qoff = d_out.p + 64 + nq;
-      M.pool = d_pool.p; M.poolCap = (uint32_t)d_pool.n;
-      {
-        // widest window in grid columns over all active queries (+3: floor/ceil slack of the cell range)
-        int lpq = 8;
-        while (lpq < 64 && lpq < maxCols) lpq <<= 1;
-        const unsigned nblk = (unsigned)((nq + (64 / lpq) - 1) / (64 / lpq));
-        if (lpq == 8) hipLaunchKernelGGL(k_window_match<8>, dim3(nblk), dim3(64), 0, stream, M);
-        else if (lpq == 16) hipLaunchKernelGGL(k_window_match<16>, dim3(nblk), dim3(64), 0, stream, M);
-        else if (lpq == 32) hipLaunchKernelGGL(k_window_match<32>, dim3(nblk), dim3(64), 0, stream, M);
-        else hipLaunchKernelGGL(k_window_match<64>, dim3(nblk), dim3(64), 0, stream, M);
-      }
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipMemcpyAsync(h_out.p, d_out.p, outWords * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-      // optimistic: fetch a generous prefix of the pool in the same round trip
-      const size_t guess = std::min<size_t>(d_pool.n, std::max<size_t>(lastTotal + lastTotal / 4 + 1024, 4096));
-      if ((rc = h_pool.ensure(guess + 1))) return rc;
-      HIP_TRY(hipMemcpyAsync(h_pool.p, d_pool.p, guess * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-      HIP_TRY(hipStreamSynchronize(stream));
-      const size_t tot = h_out.p[0];
-      if (tot <= d_pool.n) {
-        if (tot > guess) {
-          if ((rc = h_pool.ensure(tot + 1))) return rc;
-          HIP_TRY(hipMemcpyAsync(h_pool.p, d_pool.p, tot * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-          HIP_TRY(hipStreamSynchronize(stream));
-        }
-        lastTotal = tot;
-        stageMs[1] = nowMs() - tB;
-        const uint32_t* qc = h_out.p + 64;
-        const uint32_t* qo = h_out.p + 64 + nq;
-        for (size_t c = 0; c < nq; c++) {
-          qcountFull[qmap[c]] = qc[c];
-          qoffFull[qmap[c]] = qo[c];
-        }
-        qcount = qcountFull.data();
-        qoff = qoffFull.data();
-        return ORBFE_OK;
-      }
-      poolCap = tot;  // pool too small: grow to the exact demand and rerun once
-    }
-    set_err("candidate pool sizing failed");
-    return ORBFE_ERR_HIP;
-  }
-
-  int candidates(const OrbfeKeyPoint* kps, const uint8_t* desc, int n, const float bounds[4], const float* qx,
-                 const float* qy, const float* qr, const int* qminL, const int* qmaxL, const uint8_t* qdesc, int nq) {
-    Job j{kps, desc, n, bounds, qx, qy, qr, qminL, qmaxL, qdesc, nq};
-    return candidates(&j, 1);
-  }
-  size_t lastTotal = 0;
-  std::unique_ptr<orbfe::HostPool> pool;
-};
 
 // sequential bookkeeping of SearchForInitialization, ORBmatcher.cc:402-512, over one job's candidate lists
 static int resolveSearchForInitialization(const orbfe_matcher* m, int q0, const OrbfeKeyPoint* kps1, int n1,
@@ -828,6 +432,9 @@ int orbfe_search_by_projection(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, co
     set_err("bad argument (note: at most 65535 keypoints per frame)");
     return ORBFE_ERR_INVALID;
   }
+  if (!orbfe::match_host_resolve())
+    return orbfe::sbp_via_frame(m, kps_un, desc, n, bounds, scale_factors, nlevels, kp_occupied, mp_proj_xy, mp_level, mp_viewcos,
+                                mp_flags, mp_desc, n_mp, th, nnratio, kp_assigned, nmatches);
   *nmatches = 0;
   for (int i = 0; i < n; i++) kp_assigned[i] = -1;
   if (n_mp == 0 || n == 0) return ORBFE_OK;
@@ -892,6 +499,10 @@ int orbfe_search_by_projection_uv(orbfe_matcher* m, const OrbfeKeyPoint* kps_un,
     set_err("bad argument (note: at most 65535 keypoints per frame)");
     return ORBFE_ERR_INVALID;
   }
+  if (!orbfe::match_host_resolve())
+    return orbfe::sbp_uv_via_frame(m, kps_un, desc, n, bounds, scale_factors, nlevels, kp_occupied, src_uv, src_level, src_angle,
+                                   src_flags, src_valid, src_desc, n_src, th, max_dist, skip_any_occupied, check_orientation,
+                                   kp_assigned, nmatches);
   *nmatches = 0;
   for (int i = 0; i < n; i++) kp_assigned[i] = -1;
   if (n_src == 0 || n == 0) return ORBFE_OK;
@@ -968,6 +579,9 @@ int orbfe_search_projected(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, const 
   if (inv_level_sigma2)
     for (int i = 0; i < n; i++)
       if (kps_un[i].octave < 0 || kps_un[i].octave >= nlevels) { set_err("keypoint octave out of range"); return ORBFE_ERR_INVALID; }
+  if (!orbfe::match_host_resolve())
+    return orbfe::projected_via_frame(m, kps_un, desc, n, bounds, n_src, src_uv, src_radius, src_level, src_valid, src_desc, kp_skip,
+                                      claim, inv_level_sigma2, nlevels, chi2, max_dist, best_idx, best_dist, nmatches);
   std::vector<float> qx(n_src), qy(n_src), qr(n_src);
   std::vector<int> qa(n_src), qb(n_src);
   for (int i = 0; i < n_src; i++) {

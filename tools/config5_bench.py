@@ -55,6 +55,39 @@ viewcos = rng.uniform(0.9, 1.0, n_mp).astype(np.float32)
 flags = np.full(n_mp, 1 | 8, np.uint8)
 occ = np.zeros(len(k), np.uint8)
 m = api.Matcher()
+# resident frame (orbfe_frame_create_from_extract: nothing but 8 bytes per keypoint of undistorted coordinates goes up) and
+# a prepared C call -- what a C++ caller (orb_shim.hpp) pays: no numpy marshalling inside the timed region
+k, d = ex(img)
+fr = api.Frame.from_extract(ex, 0, bounds, xy)
+pin = api.PinnedArray((n_mp, 32), np.uint8)
+pin.a[:] = mdesc
+import ctypes as C
+assigned = np.full(len(k), -1, np.int32)
+nmat = C.c_int(0)
+P = lambda a: a.ctypes.data_as(C.c_void_p)
+sfa = np.ascontiguousarray(sf, np.float32)
+
+
+def c_call(th, rows):
+    rc = m.L.orbfe_search_by_projection_frame(m.h, fr.h, P(sfa), len(sfa), P(occ), P(mxy), P(level), P(viewcos), P(flags), P(rows),
+                                              n_mp, th, 0.8, P(assigned), C.byref(nmat))
+    assert rc == 0
+
+
+for th in (1.0, 5.0):
+    want = oracle.search_by_projection(kun, d, bounds, sf, occ, mxy, level, viewcos, flags, mdesc, th, 0.8)
+    for name, rows in (('pageable descriptor rows', mdesc), ('page-locked descriptor rows', pin.a)):
+        c_call(th, rows)
+        assert nmat.value == want[0] and (assigned == want[1]).all()
+        lat = []
+        for _ in range(200):
+            t0 = time.perf_counter()
+            c_call(th, rows)
+            lat.append(time.perf_counter() - t0)
+        lat = np.array(lat[20:]) * 1e3
+        print('SearchByProjection on a RESIDENT frame, 10k MapPoints th=%g, %s: median %.4f ms  p90 %.4f ms  (%d matches, %d rounds)  stages %s'
+              % (th, name, np.median(lat), np.percentile(lat, 90), nmat.value, m.resolve_rounds(), np.round(m.stage_ms(), 4)))
+        print('   resolve route %d, phase clocks %s' % (m.resolve_route(), m.resolve_phases()))
 for th in (1.0, 5.0):
     g = t(lambda: m.search_by_projection(kun, d, bounds, sf, occ, mxy, level, viewcos, flags, mdesc, th, 0.8), 20)
     o = t(lambda: oracle.search_by_projection(kun, d, bounds, sf, occ, mxy, level, viewcos, flags, mdesc, th, 0.8), 3)
