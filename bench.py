@@ -317,6 +317,27 @@ def run_rank(args):
             lat = np.array(lat[10:]) * 1e3
             single = {'ms_median': round(float(np.median(lat)), 4), 'ms_p90': round(float(np.percentile(lat, 90)), 4),
                       'call': 'blocking orbfe_extract_batch of ONE resident 1080p frame (extract only), 60 calls'}
+        # ... and what Frame.cc:133 really hands over: a HOST cv::Mat.  One blocking orbfe_extract per frame, host pointer in
+        # -> keypoints / descriptors in host memory out, from (a) pageable and (b) page-locked memory; 60 calls on distinct frames
+        single_host = None
+        if world == 1 and not args.no_latency:
+            single_host = {}
+            kbuf = np.zeros((1, ex.cap), api.KP_DTYPE)
+            dbuf = np.zeros((1, ex.cap, 32), np.uint8)
+            nlat = 64
+            pin_lat = api.PinnedFrames([frames[i % len(frames)] for i in range(nlat)])
+            for name, ptr_of in (('pageable', lambda i: frames[i % len(frames)].ctypes.data), ('page_locked', lambda i: pin_lat.ptrs[i])):
+                lat = []
+                for i in range(nlat + 10):
+                    p = ptr_of(i % nlat)
+                    t_a = time.perf_counter()
+                    ex.extract_batch_ptrs([p], H, W, W, False, kbuf, dbuf)
+                    lat.append(time.perf_counter() - t_a)
+                lat = np.array(lat[10:]) * 1e3
+                single_host[name] = {'ms_median': round(float(np.median(lat)), 4), 'ms_p90': round(float(np.percentile(lat, 90)), 4)}
+            single_host['call'] = ('blocking orbfe_extract_batch of ONE 1080p frame in HOST memory (the cv::Mat of Frame.cc:133), '
+                                   'keypoints + descriptors returned to host memory, %d calls on distinct frames' % nlat)
+            pin_lat.free()
         fast_bytes_per_frame = px + 4 * ncand
         fast_ms_per_launch = kms[1] / max(kbatches, 1)
         achieved = fast_bytes_per_frame * B / (fast_ms_per_launch * 1e-3) / 1e9 if fast_ms_per_launch > 0 else 0.0
@@ -346,6 +367,7 @@ def run_rank(args):
             'verified': verify['verified'], 'outputs_sha256': verify['outputs_sha256'], 'verify': verify,
             'pcie_inclusive': pcie,
             'single_frame_latency': single,
+            'single_frame_latency_host': single_host,
             # HIP-event time of the kernels in the pipeline (they overlap other batches' kernels); only k_fast_tasks is
             # always timed (roofline), the others appear with ORBFE_PROFILE_KERNELS=1 (costs about 1 % of the rate)
             'gpu_kernel_ms_per_frame': {k: round(v / max(kframes, 1), 5) for k, v in

@@ -79,16 +79,78 @@ class Extractor {
 
 // One GPU matcher context per thread that runs searches (Tracking constructs ORBmatcher objects on
 // the stack per use, Tracking.cc:383,596,818; the context is the long-lived part).
+//
+// The context also keeps the DEVICE-RESIDENT copies of the frames it has searched (orbfe_frame): the reference builds a
+// frame's grid once (Frame.cc:111, 114-129) and reuses it in every search of that frame -- 2-3 per tracked frame
+// (Tracking.cc:608, 614, 824), dozens per keyframe (Fuse, SearchBySim3, relocalisation).  A Frame / KeyFrame is
+// identified by (kind, mnId, N): mnId is unique per constructed object (Frame.cc:78 / KeyFrame.cc:45 nNextId++), the
+// copy constructor keeps it together with the identical mvKeysUn / mDescriptors (Frame.cc:39-62), and neither is modified
+// after construction.  First use uploads the features once (one DMA + the grid build on the GPU); later searches upload
+// only their queries.  Least-recently-used entries are dropped beyond `capacity` (default 48; 0 disables the cache and
+// every search takes the host-array call form).
 class MatcherContext {
  public:
-  explicit MatcherContext(int device = 0) { check(orbfe_matcher_create(device, &m_)); }
-  ~MatcherContext() { orbfe_matcher_destroy(m_); }
+  explicit MatcherContext(int device = 0, size_t frame_cache_capacity = 48) : cap_(frame_cache_capacity) {
+    check(orbfe_matcher_create(device, &m_));
+  }
+  ~MatcherContext() {
+    for (auto& e : cache_) orbfe_frame_destroy(e.frame);
+    orbfe_matcher_destroy(m_);
+  }
   MatcherContext(const MatcherContext&) = delete;
   MatcherContext& operator=(const MatcherContext&) = delete;
   orbfe_matcher* get() const { return m_; }
+  void setFrameCacheCapacity(size_t c) { cap_ = c; trim(); }
+  size_t residentFrames() const { return cache_.size(); }
+  size_t residentUploads() const { return uploads_; }
+
+  // the resident copy of F (a Frame: kind 0, a KeyFrame: kind 1), created on first use; nullptr when the cache is off
+  template <class FrameLike>
+  orbfe_frame* resident(const FrameLike& F, int kind) {
+    if (cap_ == 0) return nullptr;
+    const unsigned long long id = (unsigned long long)F.mnId;
+    const int n = (int)F.mvKeysUn.size();
+    for (auto it = cache_.begin(); it != cache_.end(); ++it)
+      if (it->kind == kind && it->id == id && it->n == n) {
+        if (it != cache_.begin()) {   // most recently used first
+          Entry e = *it;
+          cache_.erase(it);
+          cache_.insert(cache_.begin(), e);
+        }
+        return cache_.front().frame;
+      }
+    static_assert(sizeof(F.mvKeysUn[0]) == sizeof(OrbfeKeyPoint), "mvKeysUn must hold cv::KeyPoint-layout records");
+    std::vector<uint8_t> tmp;
+    const uint8_t* desc = nullptr;
+    if (n) {
+      if ((size_t)F.mDescriptors.step == 32) desc = F.mDescriptors.data;
+      else {
+        tmp.resize((size_t)n * 32);
+        for (int i = 0; i < n; i++) std::memcpy(&tmp[(size_t)i * 32], F.mDescriptors.data + (size_t)i * F.mDescriptors.step, 32);
+        desc = tmp.data();
+      }
+    }
+    const float b[4] = {(float)F.mnMinX, (float)F.mnMaxX, (float)F.mnMinY, (float)F.mnMaxY};
+    Entry e;
+    e.kind = kind; e.id = id; e.n = n;
+    check(orbfe_frame_create(m_, reinterpret_cast<const OrbfeKeyPoint*>(F.mvKeysUn.data()), desc, n, b, &e.frame));
+    uploads_++;
+    cache_.insert(cache_.begin(), e);
+    trim();
+    return cache_.front().frame;
+  }
 
  private:
+  struct Entry { int kind = 0; unsigned long long id = 0; int n = 0; orbfe_frame* frame = nullptr; };
+  void trim() {
+    while (cache_.size() > cap_) {
+      orbfe_frame_destroy(cache_.back().frame);
+      cache_.pop_back();
+    }
+  }
   orbfe_matcher* m_ = nullptr;
+  size_t cap_ = 48, uploads_ = 0;
+  std::vector<Entry> cache_;
 };
 
 namespace detail {
@@ -162,10 +224,15 @@ inline int SearchByProjection(MatcherContext& ctx, float mfNNratio, FrameT& F,
   float b[4];
   detail::frameBounds(F, b);
   int nmatches = 0;
-  check(orbfe_search_by_projection(ctx.get(), reinterpret_cast<const OrbfeKeyPoint*>(F.mvKeysUn.data()),
-                                   detail::packedDescriptors(F.mDescriptors, n, tmp), n, b, F.mvScaleFactors.data(),
-                                   (int)F.mvScaleFactors.size(), occ.data(), xy.data(), lvl.data(), vcos.data(),
-                                   flags.data(), mdesc.data(), nmp, th, mfNNratio, assigned.data(), &nmatches));
+  if (orbfe_frame* rf = ctx.resident(F, 0))
+    check(orbfe_search_by_projection_frame(ctx.get(), rf, F.mvScaleFactors.data(), (int)F.mvScaleFactors.size(), occ.data(),
+                                           xy.data(), lvl.data(), vcos.data(), flags.data(), mdesc.data(), nmp, th, mfNNratio,
+                                           assigned.data(), &nmatches));
+  else
+    check(orbfe_search_by_projection(ctx.get(), reinterpret_cast<const OrbfeKeyPoint*>(F.mvKeysUn.data()),
+                                     detail::packedDescriptors(F.mDescriptors, n, tmp), n, b, F.mvScaleFactors.data(),
+                                     (int)F.mvScaleFactors.size(), occ.data(), xy.data(), lvl.data(), vcos.data(),
+                                     flags.data(), mdesc.data(), nmp, th, mfNNratio, assigned.data(), &nmatches));
   for (int i = 0; i < n; i++)
     if (assigned[i] >= 0) F.mvpMapPoints[i] = vpMapPoints[assigned[i]];
   return nmatches;
@@ -253,11 +320,17 @@ inline int searchProjected(MatcherContext& ctx, KeyFrameT* pKF, ProjectedSources
   float b[4];
   frameBounds(*pKF, b);
   int nm = 0;
-  check(orbfe_search_projected(ctx.get(), reinterpret_cast<const OrbfeKeyPoint*>(pKF->mvKeysUn.data()),
-                               packedDescriptors(pKF->mDescriptors, n, tmp), n, b, ns, S.uv.data(), S.radius.data(),
-                               S.level.data(), S.valid.data(), S.desc.data(), kp_skip, claim,
-                               chi2 ? pKF->mvInvLevelSigma2.data() : nullptr, chi2 ? (int)pKF->mvInvLevelSigma2.size() : 0, 5.99,
-                               max_dist, S.bestIdx.data(), S.bestDist.data(), &nm));
+  if (orbfe_frame* rf = ctx.resident(*pKF, 1))
+    check(orbfe_search_projected_frame(ctx.get(), rf, ns, S.uv.data(), S.radius.data(), S.level.data(), S.valid.data(), S.desc.data(),
+                                       kp_skip, claim, chi2 ? pKF->mvInvLevelSigma2.data() : nullptr,
+                                       chi2 ? (int)pKF->mvInvLevelSigma2.size() : 0, 5.99, max_dist, S.bestIdx.data(),
+                                       S.bestDist.data(), &nm));
+  else
+    check(orbfe_search_projected(ctx.get(), reinterpret_cast<const OrbfeKeyPoint*>(pKF->mvKeysUn.data()),
+                                 packedDescriptors(pKF->mDescriptors, n, tmp), n, b, ns, S.uv.data(), S.radius.data(),
+                                 S.level.data(), S.valid.data(), S.desc.data(), kp_skip, claim,
+                                 chi2 ? pKF->mvInvLevelSigma2.data() : nullptr, chi2 ? (int)pKF->mvInvLevelSigma2.size() : 0, 5.99,
+                                 max_dist, S.bestIdx.data(), S.bestDist.data(), &nm));
   return nm;
 }
 // the part of the KeyFrame-side loops between GetWorldPos and GetFeaturesInArea (:322-355, 826-873, 972-1013): fills
@@ -327,12 +400,18 @@ inline int SearchByProjection(MatcherContext& ctx, bool mbCheckOrientation, Fram
   float b[4];
   detail::frameBounds(CurrentFrame, b);
   int nmatches = 0;
-  check(orbfe_search_by_projection_uv(ctx.get(), reinterpret_cast<const OrbfeKeyPoint*>(CurrentFrame.mvKeysUn.data()),
-                                      detail::packedDescriptors(CurrentFrame.mDescriptors, n, tmp), n, b,
-                                      CurrentFrame.mvScaleFactors.data(), (int)CurrentFrame.mvScaleFactors.size(), occ.data(),
-                                      uv.data(), lvl.data(), ang.data(), flags.data(), valid.data(), sdesc.data(), ns, th,
-                                      /*TH_HIGH*/ 100, /*skip_any_occupied*/ 0, mbCheckOrientation ? 1 : 0, assigned.data(),
-                                      &nmatches));
+  if (orbfe_frame* rf = ctx.resident(CurrentFrame, 0))
+    check(orbfe_search_by_projection_uv_frame(ctx.get(), rf, CurrentFrame.mvScaleFactors.data(), (int)CurrentFrame.mvScaleFactors.size(),
+                                              occ.data(), uv.data(), lvl.data(), ang.data(), flags.data(), valid.data(), sdesc.data(),
+                                              ns, th, /*TH_HIGH*/ 100, /*skip_any_occupied*/ 0, mbCheckOrientation ? 1 : 0,
+                                              assigned.data(), &nmatches));
+  else
+    check(orbfe_search_by_projection_uv(ctx.get(), reinterpret_cast<const OrbfeKeyPoint*>(CurrentFrame.mvKeysUn.data()),
+                                        detail::packedDescriptors(CurrentFrame.mDescriptors, n, tmp), n, b,
+                                        CurrentFrame.mvScaleFactors.data(), (int)CurrentFrame.mvScaleFactors.size(), occ.data(),
+                                        uv.data(), lvl.data(), ang.data(), flags.data(), valid.data(), sdesc.data(), ns, th,
+                                        /*TH_HIGH*/ 100, /*skip_any_occupied*/ 0, mbCheckOrientation ? 1 : 0, assigned.data(),
+                                        &nmatches));
   for (int i = 0; i < n; i++) {
     if (assigned[i] >= 0) CurrentFrame.mvpMapPoints[i] = LastFrame.mvpMapPoints[assigned[i]];
     else if (assigned[i] == -2) CurrentFrame.mvpMapPoints[i] = nullptr;    // rotation check, :1409-1419
@@ -382,11 +461,17 @@ inline int SearchByProjection(MatcherContext& ctx, bool mbCheckOrientation, Fram
   float b[4];
   detail::frameBounds(CurrentFrame, b);
   int nmatches = 0;
-  check(orbfe_search_by_projection_uv(ctx.get(), reinterpret_cast<const OrbfeKeyPoint*>(CurrentFrame.mvKeysUn.data()),
-                                      detail::packedDescriptors(CurrentFrame.mDescriptors, n, tmp), n, b,
-                                      CurrentFrame.mvScaleFactors.data(), (int)CurrentFrame.mvScaleFactors.size(), occ.data(),
-                                      uv.data(), lvl.data(), ang.data(), flags.data(), valid.data(), sdesc.data(), ns, th, ORBdist,
-                                      /*skip_any_occupied*/ 1, mbCheckOrientation ? 1 : 0, assigned.data(), &nmatches));
+  if (orbfe_frame* rf = ctx.resident(CurrentFrame, 0))
+    check(orbfe_search_by_projection_uv_frame(ctx.get(), rf, CurrentFrame.mvScaleFactors.data(), (int)CurrentFrame.mvScaleFactors.size(),
+                                              occ.data(), uv.data(), lvl.data(), ang.data(), flags.data(), valid.data(), sdesc.data(),
+                                              ns, th, ORBdist, /*skip_any_occupied*/ 1, mbCheckOrientation ? 1 : 0, assigned.data(),
+                                              &nmatches));
+  else
+    check(orbfe_search_by_projection_uv(ctx.get(), reinterpret_cast<const OrbfeKeyPoint*>(CurrentFrame.mvKeysUn.data()),
+                                        detail::packedDescriptors(CurrentFrame.mDescriptors, n, tmp), n, b,
+                                        CurrentFrame.mvScaleFactors.data(), (int)CurrentFrame.mvScaleFactors.size(), occ.data(),
+                                        uv.data(), lvl.data(), ang.data(), flags.data(), valid.data(), sdesc.data(), ns, th, ORBdist,
+                                        /*skip_any_occupied*/ 1, mbCheckOrientation ? 1 : 0, assigned.data(), &nmatches));
   for (int i = 0; i < n; i++) {
     if (assigned[i] >= 0) CurrentFrame.mvpMapPoints[i] = vpMPs[assigned[i]];
     else if (assigned[i] == -2) CurrentFrame.mvpMapPoints[i] = nullptr;

@@ -62,7 +62,9 @@ struct MapPoint {
   }
   void Replace(MapPoint* pMP);
 };
+static unsigned long g_nextId = 0;
 struct FrameBase {
+  unsigned long mnId = g_nextId++;   // Frame.cc:78 / KeyFrame.cc:45: unique per constructed object, kept by copies
   int N = 0;
   std::vector<KeyPoint> mvKeys, mvKeysUn;
   std::vector<unsigned char> descStore;

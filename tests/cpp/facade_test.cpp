@@ -30,7 +30,9 @@ struct MapPoint {
 };
 typedef std::map<unsigned, double> BowVector;                         // DBoW2::BowVector
 typedef std::map<unsigned, std::vector<unsigned> > FeatureVector;     // DBoW2::FeatureVector
+static unsigned long g_nextFrameId = 0;
 struct Frame {
+  unsigned long mnId = g_nextFrameId++;   // Frame.cc:78: unique per constructed object (the shim's resident-frame cache key)
   int N = 0;
   BowVector mBowVec;
   FeatureVector mFeatVec;

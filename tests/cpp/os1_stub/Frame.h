@@ -32,6 +32,7 @@ class MapPoint {
 };
 class Frame {
  public:
+  long unsigned int mnId;   // Frame.h:399
   int N;
   std::vector<cv::KeyPoint> mvKeys, mvKeysUn;
   cv::Mat mDescriptors, mTcw;
@@ -45,6 +46,7 @@ class Frame {
 };
 class KeyFrame {
  public:
+  long unsigned int mnId;   // KeyFrame.h:574
   const int N;
   const std::vector<cv::KeyPoint> mvKeysUn;
   const cv::Mat mDescriptors;

@@ -573,6 +573,14 @@ def test_latency_path_variants_agree(api, oracle, monkeypatch):
             kps, desc, n = ex.extract_batch_ptrs(dev.ptrs, H, W, dev.stride, True)
             _cmp_extract((kps[0, :n[0]], desc[0, :n[0]]), want)
             _cmp_extract((kps[1, :n[1]], desc[1, :n[1]]), want2)
+            # host input, as Frame.cc:133 hands it over: pageable (ex(img) above) and page-locked, one and two frames
+            pin = api.PinnedFrames([img, img2])
+            kps, desc, n = ex.extract_batch_ptrs(pin.ptrs[1:], H, W, W, False)
+            _cmp_extract((kps[0, :n[0]], desc[0, :n[0]]), want2)
+            kps, desc, n = ex.extract_batch_ptrs(pin.ptrs, H, W, W, False)
+            _cmp_extract((kps[0, :n[0]], desc[0, :n[0]]), want)
+            _cmp_extract((kps[1, :n[1]], desc[1, :n[1]]), want2)
+            pin.free()
             for k in env:
                 monkeypatch.delenv(k)
 
