@@ -272,6 +272,11 @@ def run_rank(args):
         prewarm(head_source, args.prewarm_seconds)
     elapsed = timed(args.steps, args.warmup, head_source)
     head_cpu = host_cpu[0]
+    cpu_all = head_cpu                            # CPU seconds of every rank's threads inside the timed region, summed
+    if dist is not None:
+        t = torch.tensor([head_cpu], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        cpu_all = float(t[0])
     kms, kbatches, kframes = st.kernel_ms()
     wstats = st.stats()
     head_pops = np.array(pop_times)
@@ -377,6 +382,7 @@ def run_rank(args):
             # CPU time of rank 0's threads over the timed region / its wall time: what a rank needs from the host when
             # N ranks share the box's cores (Python driver + the stream runner's worker threads)
             'host_cpu_cores_used_rank0': round(head_cpu / max(elapsed, 1e-9), 2),
+            'host_cpu_cores_used_all_ranks': round(cpu_all / max(elapsed, 1e-9), 2),
             'host_worker_ms_per_submission': {'submit': round(wstats[0] / max(wstats[3], 1), 4), 'collect_incl_gpu_wait': round(wstats[1] / max(wstats[3], 1), 4)},
             'roofline': {'kernel': 'k_fast_tasks', 'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,

@@ -234,7 +234,9 @@ int orbfe_stream_set_input_format(orbfe_stream* s, int format, int gray_variant)
  * pairs (pointers into the runner's buffers, valid until the next pop; feed them to orbfe_bow_assemble). */
 int orbfe_stream_set_vocabulary(orbfe_stream* s, orbfe_vocabulary* v, int levelsup);
 int orbfe_stream_bow_raw(orbfe_stream* s, int frame, const uint32_t** leaf_node, const uint32_t** level_node, int* n);
-/* Per-frame output capacity (keypoints) of the arrays returned by orbfe_stream_pop. */
+/* Per-frame output capacity (keypoints) of the arrays returned by orbfe_stream_pop = their row stride.  It grows when a
+ * push brings frames of a geometry that can return more keypoints (orbfe_extractor_max_keypoints_for_size); such a push
+ * is only accepted while no batch is in flight. */
 int orbfe_stream_capacity(const orbfe_stream* s);
 /* Result slots of the runner = batches that can be pushed ahead of the pops before orbfe_stream_push blocks, plus 2
  * (one is in the caller's hands after a pop, one is being filled).  Default depth+4; a caller whose own thread may be

@@ -914,6 +914,7 @@ class Stream:
         assert len(ptrs) == self.batch
         arr = (C.c_void_p * self.batch)(*ptrs)
         _check(self.L.orbfe_stream_push(self.h, arr, int(on_device), rows, cols, stride))
+        self.cap = self.L.orbfe_stream_capacity(self.h)      # grows with a geometry that returns more keypoints
 
     def pop(self, copy=False):
         """-> (kps[B,cap], desc[B,cap,32], n[B], matches12[B,cap], nmatches[B]) as views valid until the next pop."""

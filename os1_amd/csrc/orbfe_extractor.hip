@@ -125,8 +125,15 @@ struct orbfe_sfi_chain {
   DevBuf<uint32_t> count;      // [0],[1]: level-0 count of the buffers; [2]: constant 0xffffffff ("none")
   hipEvent_t ready[2] = {};
   long long seq = 0;           // batches submitted so far
+  // host-quadtree route (geometries outside the GPU quadtree's limits): the predecessor frame lives on the host and the
+  // searches go through an ordinary matcher handle
+  orbfe_matcher* hostMatcher = nullptr;
+  std::vector<OrbfeKeyPoint> hostPrevKps;
+  std::vector<uint8_t> hostPrevDesc;
+  bool hostPrevValid = false;
   ~orbfe_sfi_chain() {
     (void)hipSetDevice(device);
+    if (hostMatcher) orbfe_matcher_destroy(hostMatcher);
     for (int i = 0; i < 2; i++) { sel[i].release(); angle[i].release(); desc[i].release(); if (ready[i]) (void)hipEventDestroy(ready[i]); }
     count.release();
   }
@@ -249,6 +256,14 @@ struct orbfe_extractor {
   DevBuf<uint8_t> d_gray;   // level 0 of colour input
   bool inLinear = false;   // host frames are uploaded with linear copies (inPitch == host stride)
   int lastFrames = 0;
+  // deferred route of _submit / _submit_matched when the GPU quadtree cannot take the geometry: the batch is extracted by the
+  // blocking host-quadtree path at submit time (and matched through a matcher handle), _collect hands the results out
+  int deferredFrames = 0, deferredCap = 0;
+  bool deferredMatched = false;
+  std::vector<OrbfeKeyPoint> defKps;
+  std::vector<uint8_t> defDesc;
+  std::vector<int> defN, defNm;
+  std::vector<int32_t> defM12;
   bool lastGpuQt = false, lastZeroCopy = false, submitZeroCopy = false;   // route of the last collected / submitted batch
   float stageMs[5] = {0, 0, 0, 0, 0};
   hipEvent_t ev[kMaxSub][6] = {};
@@ -1510,18 +1525,77 @@ int orbfe_extract_batch(orbfe_extractor* h, int nframes, const uint8_t* const* g
   return h->run(nframes, gray, in_device_memory != 0, rows, cols, stride_bytes, kps, desc, cap, n_out);
 }
 
+// The GPU quadtree takes 1..4 root nodes per level and at most 2 044 features per level; outside that (very wide strips,
+// nfeatures beyond about 9 000) the asynchronous entry points run the batch through the blocking host-quadtree path at
+// submit time and keep the results for _collect: same results, no overlap.
+static bool gpu_route_ok(orbfe_extractor* h, int rows, int cols, int* rc) {
+  *rc = ORBFE_OK;
+  if (!h->gpuQuadtree) return false;
+  if (hipSetDevice(h->device) != hipSuccess) { set_err("hipSetDevice failed"); *rc = ORBFE_ERR_HIP; return false; }
+  if (h->pendingFrames || h->deferredFrames) return true;   // reported by the submit itself
+  *rc = h->setGeometry(rows, cols);
+  return *rc == ORBFE_OK && h->geomGpuQtOk;
+}
+
+static int deferred_extract(orbfe_extractor* h, int nframes, const uint8_t* const* gray, int in_device_memory, int rows, int cols,
+                            size_t stride_bytes) {
+  if (h->pendingFrames || h->deferredFrames) { set_err("a submitted batch has not been collected yet"); return ORBFE_ERR_INVALID; }
+  const int cap = orbfe_extractor_max_keypoints_for_size(h, rows, cols);
+  h->deferredCap = cap;
+  h->defKps.resize((size_t)nframes * cap);
+  h->defDesc.resize((size_t)nframes * cap * 32);
+  h->defN.assign(nframes, 0);
+  const int rc = orbfe_extract_batch(h, nframes, gray, in_device_memory, rows, cols, stride_bytes, h->defKps.data(), h->defDesc.data(),
+                                     cap, h->defN.data());
+  if (rc) return rc;
+  h->deferredFrames = nframes;
+  h->deferredMatched = false;
+  return ORBFE_OK;
+}
+
+static int deferred_collect(orbfe_extractor* h, OrbfeKeyPoint* kps, uint8_t* desc, int cap, int* n_out, int32_t* matches12,
+                            int* nmatches) {
+  const int nframes = h->deferredFrames, dcap = h->deferredCap;
+  h->deferredFrames = 0;
+  int status = ORBFE_OK;
+  for (int f = 0; f < nframes; f++) {
+    const int n = h->defN[f];
+    n_out[f] = n;
+    if (n > cap) { set_err("frame %d produced %d keypoints, cap is %d", f, n, cap); status = ORBFE_ERR_OVERFLOW; }
+    const int m = std::min(n, cap);
+    memcpy(kps + (size_t)f * cap, h->defKps.data() + (size_t)f * dcap, sizeof(OrbfeKeyPoint) * (size_t)m);
+    memcpy(desc + (size_t)f * cap * 32, h->defDesc.data() + (size_t)f * dcap * 32, 32 * (size_t)m);
+    if (matches12 && nmatches) {
+      int32_t* row = matches12 + (size_t)f * cap;
+      for (int i = 0; i < cap; i++) row[i] = -1;
+      nmatches[f] = 0;
+      if (h->deferredMatched) {
+        memcpy(row, h->defM12.data() + (size_t)f * dcap, sizeof(int32_t) * (size_t)std::min(cap, dcap));
+        nmatches[f] = h->defNm[f];
+      }
+    }
+  }
+  return status;
+}
+
 int orbfe_extract_batch_submit(orbfe_extractor* h, int nframes, const uint8_t* const* gray, int in_device_memory,
                                int rows, int cols, size_t stride_bytes) {
   if (!h || !gray || nframes <= 0 || rows <= 0 || cols <= 0 || stride_bytes < (size_t)cols * h->inChannels()) {
     set_err("invalid arguments");
     return ORBFE_ERR_INVALID;
   }
-  if (!h->gpuQuadtree) { set_err("asynchronous submission needs the GPU quadtree path"); return ORBFE_ERR_INVALID; }
+  int rc;
+  if (!gpu_route_ok(h, rows, cols, &rc)) {
+    if (rc) return rc;
+    return deferred_extract(h, nframes, gray, in_device_memory, rows, cols, stride_bytes);
+  }
+  if (h->deferredFrames) { set_err("a submitted batch has not been collected yet"); return ORBFE_ERR_INVALID; }
   return h->submitGpuQt(nframes, gray, in_device_memory != 0, rows, cols, stride_bytes);
 }
 
 int orbfe_extract_batch_collect(orbfe_extractor* h, OrbfeKeyPoint* kps, uint8_t* desc, int cap, int* n_out) {
   if (!h || !kps || !desc || !n_out || cap <= 0) { set_err("invalid arguments"); return ORBFE_ERR_INVALID; }
+  if (h->deferredFrames) return deferred_collect(h, kps, desc, cap, n_out, nullptr, nullptr);
   return h->waitGpuQt(kps, desc, cap, n_out);
 }
 
@@ -1558,7 +1632,56 @@ int orbfe_extract_batch_submit_matched(orbfe_extractor* h, orbfe_sfi_chain* chai
     set_err("invalid arguments");
     return ORBFE_ERR_INVALID;
   }
-  if (!h->gpuQuadtree) { set_err("GPU matching needs the GPU quadtree path"); return ORBFE_ERR_INVALID; }
+  int rc;
+  if (!gpu_route_ok(h, rows, cols, &rc)) {
+    if (rc) return rc;
+    // host-quadtree route: extract now, then SearchForInitialization of every frame against its predecessor (the chain
+    // carries the previous batch's last frame on the host) as one batched matcher call
+    if ((rc = deferred_extract(h, nframes, gray, in_device_memory, rows, cols, stride_bytes))) return rc;
+    if (!chain->hostMatcher && (rc = orbfe_matcher_create(h->device, &chain->hostMatcher))) { h->deferredFrames = 0; return rc; }
+    const int cap = h->deferredCap;
+    h->defM12.assign((size_t)nframes * cap, -1);
+    h->defNm.assign(nframes, 0);
+    std::vector<const OrbfeKeyPoint*> k1, k2;
+    std::vector<const uint8_t*> d1, d2;
+    std::vector<int> n1, n2, frameOf, nm;
+    std::vector<std::vector<float>> pxy;
+    std::vector<float*> prev;
+    std::vector<int32_t*> m12;
+    for (int f = 0; f < nframes; f++) {
+      const OrbfeKeyPoint* pk;
+      const uint8_t* pd;
+      int pn;
+      if (f == 0) {
+        if (!chain->hostPrevValid) continue;   // very first frame of the stream: no predecessor
+        pk = chain->hostPrevKps.data(); pd = chain->hostPrevDesc.data(); pn = (int)chain->hostPrevKps.size();
+      } else {
+        pk = h->defKps.data() + (size_t)(f - 1) * cap; pd = h->defDesc.data() + (size_t)(f - 1) * cap * 32; pn = h->defN[f - 1];
+      }
+      pxy.emplace_back((size_t)std::max(pn, 1) * 2);
+      for (int j = 0; j < pn; j++) { pxy.back()[2 * j] = pk[j].x; pxy.back()[2 * j + 1] = pk[j].y; }   // vbPrevMatched := F1's keypoints (Tracking.cc:355-357)
+      k1.push_back(pk); d1.push_back(pd); n1.push_back(pn);
+      k2.push_back(h->defKps.data() + (size_t)f * cap); d2.push_back(h->defDesc.data() + (size_t)f * cap * 32); n2.push_back(h->defN[f]);
+      m12.push_back(h->defM12.data() + (size_t)f * cap);
+      frameOf.push_back(f);
+    }
+    for (auto& v : pxy) prev.push_back(v.data());
+    nm.assign(k1.size(), 0);
+    if (!k1.empty()) {
+      rc = orbfe_search_for_initialization_batch(chain->hostMatcher, (int)k1.size(), k1.data(), d1.data(), n1.data(), k2.data(), d2.data(),
+                                                 n2.data(), bounds, prev.data(), m12.data(), window_size, nnratio, check_orientation,
+                                                 nm.data());
+      if (rc) { h->deferredFrames = 0; return rc; }
+      for (size_t p = 0; p < frameOf.size(); p++) h->defNm[frameOf[p]] = nm[p];
+    }
+    const int last = nframes - 1, ln = h->defN[last];
+    chain->hostPrevKps.assign(h->defKps.begin() + (size_t)last * cap, h->defKps.begin() + (size_t)last * cap + ln);
+    chain->hostPrevDesc.assign(h->defDesc.begin() + (size_t)last * cap * 32, h->defDesc.begin() + ((size_t)last * cap + ln) * 32);
+    chain->hostPrevValid = true;
+    h->deferredMatched = true;
+    return ORBFE_OK;
+  }
+  if (h->deferredFrames) { set_err("a submitted batch has not been collected yet"); return ORBFE_ERR_INVALID; }
   orbfe_extractor::MatchSpec ms;
   ms.chain = chain;
   memcpy(ms.bounds, bounds, sizeof ms.bounds);
@@ -1571,6 +1694,7 @@ int orbfe_extract_batch_submit_matched(orbfe_extractor* h, orbfe_sfi_chain* chai
 int orbfe_extract_batch_collect_matched(orbfe_extractor* h, OrbfeKeyPoint* kps, uint8_t* desc, int cap, int* n_out,
                                         int32_t* matches12, int* nmatches) {
   if (!h || !kps || !desc || !n_out || !matches12 || !nmatches || cap <= 0) { set_err("invalid arguments"); return ORBFE_ERR_INVALID; }
+  if (h->deferredFrames) return deferred_collect(h, kps, desc, cap, n_out, matches12, nmatches);
   return h->waitGpuQt(kps, desc, cap, n_out, matches12, nmatches);
 }
 

@@ -404,6 +404,23 @@ int orbfe_stream_queue_slots(const orbfe_stream* s) { return s ? (int)s->slots.s
 int orbfe_stream_push(orbfe_stream* s, const uint8_t* const* gray, int in_device_memory, int rows, int cols,
                       size_t stride_bytes) {
   if (!s || !gray || rows <= 0 || cols <= 0 || stride_bytes < (size_t)cols * s->channels) { set_err("invalid arguments"); return ORBFE_ERR_INVALID; }
+  // a geometry whose levels return more keypoints than the slots hold (strips wider than 4.5 : 1: every root node of a level
+  // yields keypoints, ORBextractor.cc:620-700): grow every slot -- only while the pipeline is empty, the row stride changes
+  const int need = orbfe_extractor_max_keypoints_for_size(s->ext[0], rows, cols);
+  if (need > s->cap) {
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (s->popSeq != s->pushSeq) {
+      set_err("frames of %dx%d need %d keypoint slots per frame, the runner holds %d: pop every pushed batch before changing the frame size", cols, rows, need, s->cap);
+      return ORBFE_ERR_INVALID;
+    }
+    s->cap = need;
+    for (Slot& sl : s->slots) {
+      sl.kps.resize((size_t)s->batch * need);
+      sl.desc.resize((size_t)s->batch * need * 32);
+      sl.m12.assign((size_t)s->batch * need, -1);
+      sl.prevxy.resize((size_t)s->batch * need * 2);
+    }
+  }
   int slot;
   {
     std::unique_lock<std::mutex> lk(s->mu);

@@ -348,10 +348,14 @@ def test_stream_runner_parity(api, oracle, mode, monkeypatch):
     st.close()
 
 
-@pytest.mark.parametrize('cfg', [(640, 480, 25, 8, 2), (1000, 300, 60, 4, 3), (333, 251, 300, 3, 2)])
+@pytest.mark.parametrize('cfg', [(640, 480, 25, 8, 2), (1000, 300, 60, 4, 3), (333, 251, 300, 3, 2), (1500, 260, 200, 3, 2),
+                                 (1280, 720, 12000, 4, 2)])
 def test_stream_runner_small_quotas_and_odd_sizes(api, oracle, cfg):
     """The streamed path (GPU quadtree, slot-mode descriptors, GPU SearchForInitialization chain) with tiny per-level
-    quotas (a level returns 4 x roots keypoints, more than its quota), 3-4 quadtree roots and odd image sizes."""
+    quotas (a level returns 4 x roots keypoints, more than its quota), 3-4 quadtree roots and odd image sizes -- and the two
+    geometries OUTSIDE the GPU quadtree's limits, which the asynchronous entry points route through the host quadtree and
+    a matcher handle by themselves: a strip with 6 root nodes per level (1500 x 260) and 12 000 features (more than 2 044
+    on a level)."""
     W, H, N, nl, B = cfg
     base = synth(70 + W, W, H)
     frames = [base] + [shifted(base, 2 * i, i, 700 + i) for i in range(1, 3 * B)]

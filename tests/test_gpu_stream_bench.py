@@ -122,6 +122,19 @@ def test_bench_two_ranks_on_one_gpu(api):
     assert res['value'] > 1000 and res['config']['parallelism'].startswith('independent streams')
 
 
+def test_bench_eight_ranks_on_one_gpu(api):
+    """The launcher at N = 8: bench.py --gpus 8 spawns eight fresh child ranks before any GPU call (never a re-exec of an
+    initialised process), ORBFE_BENCH_DEVICE=0 puts all of them on the one GPU of this box.  Every rank runs its own camera
+    stream (seeds 100..107) through the product and checks it against that seed's committed digests
+    (tests/golden/stream1080_digests.json); the line reports the host cores all ranks used together."""
+    res = _bench(['--gpus', '8', '--steps', '1', '--warmup', '1', '--no-pcie', '--no-latency', '--cpu-frames', '0', '--prewarm-seconds', '0'],
+                 {'ORBFE_BENCH_DEVICE': '0'})
+    assert res['n_gpus'] == 8
+    assert res['verified'] is True and res['verify']['ranks_verified'] == 8
+    assert res['value'] > 1000 and res['config']['parallelism'].startswith('independent streams')
+    assert 0 < res['host_cpu_cores_used_all_ranks'] < 64
+
+
 def test_stream_runner_4k_4000_features(api, oracle):
     """BASELINE configs[4] geometry through the streaming path: 3840x2160, 4000 features (the 1 024-node quadtree variant,
     869 level-0 queries per SearchForInitialization), 2-frame submissions on 2 handles, against the live oracle."""
