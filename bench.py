@@ -350,10 +350,19 @@ def run_rank(args):
         traffic = prof.get('traffic_bytes_per_launch')
         valu = None
         if prof.get('valu_insts_per_launch') and fast_ms_per_launch > 0:
+            # the binding roof of this kernel: vector-instruction issue.  Cycles per wave64 instruction are MEASURED, twice:
+            # tools/ubench/valu_rate.hip (profiles/r03_valu_rate.txt) -- 2 cycles for v_fma/add/mul_f32, v_add/sub_u32, and/or/xor,
+            # right shifts and the unpacked 16-bit ops once two waves share a SIMD (the guide's figure), 4 cycles for every packed
+            # 16-bit op, v_alignbyte, v_perm, v_lshlrev_b32, min/max_u32, 24-bit multiplies, DPP / SDWA forms, compares and any
+            # op with a scalar source -- and for the kernel's own mix by the SQ counters (4 * SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU)
+            cpi = prof.get('valu_cycles_per_inst') or 4.0
+            peak = 1024 * 2.4e9 / cpi
             rate = prof['valu_insts_per_launch'] / (fast_ms_per_launch * 1e-3)
             valu = {'insts_per_launch': prof['valu_insts_per_launch'], 'insts_per_cell_wave': prof.get('valu_insts_per_cell_wave'),
-                    'issue_peak_per_s': VALU_ISSUE_PEAK, 'achieved_per_s': round(rate, 1), 'frac': round(rate / VALU_ISSUE_PEAK, 4),
-                    'note': 'wave64 VALU instructions (SQ_INSTS_VALU, separate rocprofv3 --pmc pass); peak = 1024 SIMDs x 2.4 GHz / 4 cycles'}
+                    'cycles_per_inst': cpi, 'cycles_per_inst_source': 'SQ counters of this kernel (' + str(prof.get('source', ''))[:28] + '...) and profiles/r03_valu_rate.txt per opcode',
+                    'issue_peak_per_s': round(peak, 1), 'achieved_per_s': round(rate, 1), 'frac': round(rate / peak, 4),
+                    'frac_if_all_ops_were_2_cycle': round(rate / (1024 * 2.4e9 / 2.0), 4),
+                    'note': 'wave64 VALU instructions (SQ_INSTS_VALU, separate rocprofv3 --pmc pass); peak = 1024 SIMDs x 2.4 GHz / cycles_per_inst'}
         step_ms = np.diff(head_pops[subs - 1::subs]) * 1e3 if len(head_pops) >= 3 * subs else None
         out = {
             'metric': 'frames/sec extract+match, 1920x1080 @ 2000 ORB feats',
@@ -384,12 +393,14 @@ def run_rank(args):
             'host_cpu_cores_used_rank0': round(head_cpu / max(elapsed, 1e-9), 2),
             'host_cpu_cores_used_all_ranks': round(cpu_all / max(elapsed, 1e-9), 2),
             'host_worker_ms_per_submission': {'submit': round(wstats[0] / max(wstats[3], 1), 4), 'collect_incl_gpu_wait': round(wstats[1] / max(wstats[3], 1), 4)},
-            'roofline': {'kernel': 'k_fast_tasks', 'bound': 'hbm', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
+            'roofline': {'kernel': 'k_fast_tasks', 'bound': 'hbm', 'binding_roof': 'valu-issue (see roofline.valu)', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
                          'traffic_source': prof.get('source'),
                          'algorithmic_bytes_per_launch': fast_bytes_per_frame * B,
                          'launch_ms': round(fast_ms_per_launch, 4), 'valu': valu},
         }
+        if world == 1 and not args.no_latency:
+            out['config5_search_by_projection'] = config5_leg(api, local_rank, args.cpu_frames > 0)
         if world == 1 and args.cpu_frames > 0:
             out['cpu_baseline'] = cpu_baseline(frames, args.cpu_frames, not args.no_match)
             out['cpu_baseline_all_cores'] = cpu_baseline_all_cores(frames, not args.no_match)
@@ -431,6 +442,68 @@ def load_profile_counters(B):
     if c.get('batch') != B:
         return {}
     return c
+
+
+def config5_leg(api, device, with_oracle):
+    """BASELINE.json configs[4], outside the timed region: one 3840x2160 frame, 4000 features, camera modo 1 (keypoints
+    undistorted on the host), ORBmatcher::SearchByProjection(Frame&, MapPoints, th) against 10 000 MapPoints on the frame's
+    device-resident features (orbfe_frame_create_from_extract): blocking C calls, median of 100, host arrays in -> kp_assigned
+    out.  The oracle (1 core) runs the same search beside it and must agree."""
+    import ctypes as C
+    import numpy as np
+    from os1_amd.synth import synth
+    W, H, N, n_mp = 3840, 2160, 4000, 10000
+    fx = fy = 2196.0
+    cx, cy = 1839.0, 1155.0
+    ex = api.Extractor(N, 1.2, 8, 20, 7, device=device)
+    img = synth(5, W, H)
+    k, d = ex(img)
+    xy = api.undistort_equidistant(np.stack([k['x'], k['y']], 1), fx, fy, cx, cy)
+    kun = k.copy()
+    kun['x'], kun['y'] = xy[:, 0], xy[:, 1]
+    bounds = api.compute_image_bounds(W, H, 1, fx, fy, cx, cy)
+    fr = api.Frame.from_extract(ex, 0, bounds, xy)
+    sf = np.ascontiguousarray(ex.tables()['sf'], np.float32)
+    rng = np.random.default_rng(55)
+    src = rng.integers(0, len(k), n_mp)
+    mdesc = d[src].copy()
+    flips = rng.integers(0, 41, n_mp)
+    for i in range(n_mp):
+        for b in rng.integers(0, 256, flips[i]):
+            mdesc[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    mxy = (np.stack([kun['x'][src], kun['y'][src]], 1) + rng.uniform(-3, 3, (n_mp, 2))).astype(np.float32)
+    level = np.minimum(k['octave'][src] + rng.integers(0, 2, n_mp), 7).astype(np.int32)
+    viewcos = rng.uniform(0.9, 1.0, n_mp).astype(np.float32)
+    flags = np.full(n_mp, 1 | 8, np.uint8)
+    occ = np.zeros(len(k), np.uint8)
+    m = api.Matcher(device)
+    assigned = np.full(len(k), -1, np.int32)
+    nmat = C.c_int(0)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    out = {'frame': '3840x2160, %d keypoints, fisheye-undistorted on the host' % len(k), 'mappoints': n_mp,
+           'call': 'blocking orbfe_search_by_projection_frame (resident frame built by orbfe_frame_create_from_extract), 100 calls'}
+    if with_oracle:
+        from oracle.pyoracle import Oracle
+        oracle = Oracle()
+    for th in (1.0, 5.0):
+        lat = []
+        for _ in range(110):
+            t0 = time.perf_counter()
+            rc = m.L.orbfe_search_by_projection_frame(m.h, fr.h, P(sf), len(sf), P(occ), P(mxy), P(level), P(viewcos), P(flags), P(mdesc),
+                                                      n_mp, th, 0.8, P(assigned), C.byref(nmat))
+            lat.append(time.perf_counter() - t0)
+            assert rc == 0
+        lat = np.array(lat[10:]) * 1e3
+        row = {'gpu_ms_median': round(float(np.median(lat)), 4), 'gpu_ms_p90': round(float(np.percentile(lat, 90)), 4), 'matches': int(nmat.value)}
+        if with_oracle:
+            t0 = time.perf_counter()
+            for _ in range(3):
+                on, oa = oracle.search_by_projection(kun, d, bounds, sf, occ, mxy, level, viewcos, flags, mdesc, th, 0.8)
+            row['oracle_1core_ms'] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+            row['equal_to_oracle'] = bool(on == nmat.value and (oa == assigned).all())
+            row['speedup_vs_oracle_1core'] = round(row['oracle_1core_ms'] / row['gpu_ms_median'], 1)
+        out['th_%g' % th] = row
+    return out
 
 
 def cpu_baseline(frames, nframes, do_match):

@@ -199,24 +199,26 @@ __device__ __forceinline__ int rot_bin_dev(float a1, float a2) {   // ORBmatcher
 
 constexpr int kResolveThreads = 1024;
 
-// One block.  LDS = true (the launcher checks that the fixed tables fit the budget): per-query offsets into a
-// query-contiguous copy of the candidate entries, two generations of the "first claiming query" table, kp_assigned, the
-// claim and occupancy flags as bits -- all in LDS; the entries join them when `ldsEntries` has room for all of them, else
-// they are read from the records / the pool.  A round evaluates every query against the previous round's table and builds
-// the next one with LDS atomics; the fixed point is reached when two generations are equal.  LDS = false keeps the tables
-// in global scratch (any size).
+// One block.  A query's outcome for every subset of its (at most three) candidates being available was tabulated by the
+// window kernel (decision_code), so a round is a table lookup per query: fetch the candidates' table words, form the
+// availability pattern, read the outcome.  LDS = true (the launcher checks that everything fits the budget): the packed
+// query words (3 x 16-bit keypoint index + 16-bit code), two generations of the "first claiming query" table, kp_assigned
+// and the claim / occupancy flags as bits live in LDS.  A round evaluates every query against the previous round's table
+// and builds the next one with LDS atomics; the fixed point is reached when two generations are equal.  Lists longer than
+// the record (wide windows) are evaluated from the pool in global memory.  LDS = false keeps everything in global scratch.
 template <int MODE, bool LDS>
 __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, int ldsEntries) {
-  extern __shared__ int dyn[];
+  extern __shared__ __align__(16) int dyn[];
   __shared__ int hist[32];
   __shared__ int acc[2];
-  __shared__ int wsum[kResolveThreads / 64];
+  __shared__ int ovfUsed;
   const int tid = threadIdx.x, nq = R.nq, n = R.n;
   const uint32_t tot = *R.total;
   auto stamp = [&](int k) { if (tid == 0) R.hdrHost[16 + k] = (int)__builtin_readcyclecounter(); };   // phase clock (debug)
   stamp(0);
   if (tid < 32) hist[tid] = 0;
   if (tid < 2) acc[tid] = 0;
+  if (tid == 0) ovfUsed = 0;
   __syncthreads();
   if (tid == 0) {
     R.hdrHost[4] = (int)tot;
@@ -224,24 +226,43 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
     R.hdrHost[1] = tot > R.poolCap ? 1 : 0;
   }
   if (tot > R.poolCap) return;   // candidate pool too small: the host grows it and submits again
-  int* offs = LDS ? dyn : nullptr;                       // [nq + 1]
-  int* fcA = LDS ? dyn + nq + 1 : R.scratch;            // [n]
-  int* fcB = fcA + n;                                    // [n]
-  int* kpAssigned = fcB + n;                             // [n]
-  uint32_t* claimBits = LDS ? reinterpret_cast<uint32_t*>(kpAssigned + n) : nullptr;   // [2 * ceil(nq / 64)]
-  uint32_t* occBits = LDS ? claimBits + 2 * ((nq + 63) >> 6) : nullptr;                 // [2 * ceil(n / 64)]
-  uint32_t* ent = LDS ? occBits + 2 * ((n + 63) >> 6) : nullptr;                        // [ldsEntries]
+  uint2* q8 = LDS ? reinterpret_cast<uint2*>(dyn) : nullptr;                         // [nq] idx0 | idx1 << 16, idx2 | code << 16
+  int* fcA = LDS ? dyn + 2 * nq : R.scratch;                                         // [n]
+  int* fcB = fcA + n;                                                                 // [n]
+  int* kpAssigned = fcB + n;                                                          // [n]
+  uint32_t* claimBits = LDS ? reinterpret_cast<uint32_t*>(kpAssigned + n) : nullptr; // [2 * ceil(nq / 64)]
+  uint32_t* occBits = LDS ? claimBits + 2 * ((nq + 63) >> 6) : nullptr;               // [2 * ceil(n / 64)]
+  uint32_t* ovf = LDS ? occBits + 2 * ((n + 63) >> 6) : nullptr;                       // [ldsEntries] lists longer than a record
+  const uint4* rec4 = reinterpret_cast<const uint4*>(R.rec);
+  auto pack = [](const uint4& r) -> uint2 {
+    const uint32_t cnt = r.x & 0xffffu, code = cnt ? (r.x >> 16) : 0u;
+    return make_uint2((r.y & 0xffffu) | (r.z << 16), (r.w & 0xffffu) | (code << 16));
+  };
   auto occupied = [&](int k) -> bool {
     if (!R.occ0) return false;
     return LDS ? ((occBits[k >> 5] >> (k & 31)) & 1u) != 0 : R.occ0[k] != 0;
   };
   if (LDS) {
-    if (tid == 0) offs[0] = 0;
-    // counts (from the records), claim and occupancy flags, coalesced; the flags become ballot words
+    // packed query words from the records, claim and occupancy flags as ballot words: coalesced, every load independent
     for (int i0 = 0; i0 < nq; i0 += kResolveThreads) {
       const int i = i0 + tid;
       const bool in = i < nq;
-      if (in) offs[i + 1] = (int)R.rec[(size_t)i * 4];
+      if (in) {
+        const uint4 r = rec4[i];
+        uint2 w = pack(r);
+        if ((w.y >> 16) == kCodeLongList) {   // the list moves to LDS while there is room (x = its offset there), else it stays in the pool
+          const int cnt = (int)(r.x & 0xffffu);
+          const int at = atomicAdd(&ovfUsed, cnt);
+          w.x = 0xffffffffu;
+          w.y = (uint32_t)cnt | (kCodeLongList << 16);
+          if (at + cnt <= ldsEntries) {
+            w.x = (uint32_t)at;
+            const uint32_t* src = R.pool + R.qoff[i];
+            for (int c = 0; c < cnt; c++) ovf[at + c] = src[c];
+          }
+        }
+        q8[i] = w;
+      }
       const unsigned long long b = __ballot(in && R.qclaim[i] != 0);
       if ((tid & 63) == 0 && in) {
         claimBits[i >> 5] = (uint32_t)b;
@@ -258,89 +279,61 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
         }
       }
     __syncthreads();
-    // exclusive scan of the counts: a contiguous chunk per thread, wave scans of the chunk sums
-    const int chunk = (nq + kResolveThreads - 1) / kResolveThreads;
-    const int c0 = min(tid * chunk, nq), c1 = min(c0 + chunk, nq);
-    int sum = 0;
-    for (int i = c0; i < c1; i++) sum += offs[i + 1];
-    int incl = sum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int t = __shfl_up(incl, o, 64);
-      if ((tid & 63) >= o) incl += t;
-    }
-    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
-    __syncthreads();
-    int run = incl - sum;
-    for (int w = 0; w < (tid >> 6); w++) run += wsum[w];
-    for (int i = c0; i < c1; i++) { run += offs[i + 1]; offs[i + 1] = run; }
-    __syncthreads();
   }
-  const bool entLds = LDS && offs[nq] <= ldsEntries;
   for (int k = tid; k < n; k += kResolveThreads) {
     const int base = occupied(k) ? -1 : INT_MAX;
     fcA[k] = base; fcB[k] = base; kpAssigned[k] = -1;
   }
-  if (entLds) {   // query-contiguous copy of the entries: one 16-byte record per query, all of a thread's loads independent
-#pragma unroll 4
-    for (int i = tid; i < nq; i += kResolveThreads) {
-      const int b = offs[i], c = offs[i + 1] - b;
-      if (c == 0) continue;
-      if (c <= kRecEntries) {
-        const uint4 r = reinterpret_cast<const uint4*>(R.rec)[i];
-        ent[b] = r.y;
-        if (c > 1) ent[b + 1] = r.z;
-        if (c > 2) ent[b + 2] = r.w;
-      } else {
-        const uint32_t* src = R.pool + R.qoff[i];
-        for (int j = 0; j < c; j++) ent[b + j] = src[j];
-      }
-    }
-  }
   __syncthreads();
   stamp(1);
   auto claims = [&](int i) -> bool { return LDS ? ((claimBits[i >> 5] >> (i & 31)) & 1u) != 0 : R.qclaim[i] != 0; };
-  auto eval = [&](int i, const int* fc, int& d) -> int {
-    Best<MODE> B;
-    if (entLds) {
-      const int b = offs[i], cnt = offs[i + 1] - b;
-      d = -1;
-      if (cnt == 0) return -1;
-      // the first two entries and their table words travel together (two LDS round trips for the common short list)
-      const uint32_t e0 = ent[b], e1 = cnt > 1 ? ent[b + 1] : 0u;
-      const int f0 = fc[e0 & 0xffff], f1 = fc[e1 & 0xffff];
-      B.consider(e0, f0, i);
-      if (cnt > 1) B.consider(e1, f1, i);
-      for (int c = 2; c < cnt; c++) {
-        const uint32_t e = ent[b + c];
+  // outcome of query i against table fc: accepted keypoint or -1; `which` = 1 + position of the accepted candidate in the
+  // query's list (fast path) or -(distance) - 1 (long lists), for the callers that need the distance
+  auto eval = [&](int i, const int* fc, int& which) -> int {
+    const uint2 r = LDS ? q8[i] : pack(rec4[i]);
+    const uint32_t code = r.y >> 16;
+    which = 0;
+    if (code == 0u) return -1;
+    if (code != kCodeLongList) {
+      const int i0 = (int)(r.x & 0xffffu), i1 = (int)(r.x >> 16), i2 = (int)(r.y & 0xffffu);
+      const int f0 = fc[i0], f1 = fc[i1], f2 = fc[i2];   // unused slots hold index 0: their bit does not change the outcome
+      const unsigned p = (f0 >= i ? 1u : 0u) | (f1 >= i ? 2u : 0u) | (f2 >= i ? 4u : 0u);
+      const int o = (int)((code >> (2 * p)) & 3u);
+      which = o;
+      return o == 0 ? -1 : (o == 1 ? i0 : (o == 2 ? i1 : i2));
+    }
+    Best<MODE> B;                                        // list longer than the record: walk it (LDS copy, else the pool)
+    if (LDS && r.x != 0xffffffffu) {
+      const int cnt = (int)(r.y & 0xffffu);
+      const uint32_t* l = ovf + r.x;
+      for (int c = 0; c < cnt; c++) {
+        const uint32_t e = l[c];
         B.consider(e, fc[e & 0xffff], i);
       }
-      return B.accept(R, d);
-    }
-    const uint4 r = reinterpret_cast<const uint4*>(R.rec)[i];
-    const int cnt = (int)r.x;
-    d = -1;
-    if (cnt == 0) return -1;
-    if (cnt <= kRecEntries) {
-      B.consider(r.y, fc[r.y & 0xffff], i);
-      if (cnt > 1) B.consider(r.z, fc[r.z & 0xffff], i);
-      if (cnt > 2) B.consider(r.w, fc[r.w & 0xffff], i);
     } else {
+      const int cnt = (int)(R.rec[(size_t)i * 4] & 0xffffu);
       const uint32_t* g = R.pool + R.qoff[i];
       for (int c = 0; c < cnt; c++) {
         const uint32_t e = g[c];
         B.consider(e, fc[e & 0xffff], i);
       }
     }
-    return B.accept(R, d);
+    int d;
+    const int m = B.accept(R, d);
+    which = -d - 1;
+    return m;
+  };
+  auto dist_of = [&](int i, int which) -> int {
+    if (which < 0) return -which - 1;
+    return (int)((R.rec[(size_t)i * 4 + which] >> 16) & 0x1ffu);
   };
   int* cur = fcA;     // the table the queries are evaluated against
   int* next = fcB;    // the table their outcomes build (at its base state at the start of a round)
   int rounds = 0;
   for (;;) {
     for (int i = tid; i < nq; i += kResolveThreads) {
-      int d;
-      const int m = eval(i, cur, d);
+      int w;
+      const int m = eval(i, cur, w);
       if (m >= 0 && claims(i)) atomicMin(&next[m], i);
     }
     __syncthreads();
@@ -358,8 +351,8 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
       __syncthreads();
       if (tid == 0) {
         for (int i = 0; i < nq; i++) {
-          int d;
-          const int m = eval(i, cur, d);
+          int w;
+          const int m = eval(i, cur, w);
           if (m >= 0 && claims(i) && cur[m] == INT_MAX) cur[m] = i;
         }
       }
@@ -372,9 +365,9 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
   // ---- outputs: every query once more against the settled table -------------------------------------------------
   int nm = 0;
   for (int i = tid; i < nq; i += kResolveThreads) {
-    int d;
-    const int m = eval(i, cur, d);
-    if (MODE == kModeProjected) { R.outHost[i] = m; R.outHost[nq + i] = d; }
+    int w;
+    const int m = eval(i, cur, w);
+    if (MODE == kModeProjected) { R.outHost[i] = m; R.outHost[nq + i] = m >= 0 ? dist_of(i, w) : -1; }
     if (m < 0) continue;
     nm++;
     if (MODE != kModeProjected) atomicMax(&kpAssigned[m], i);   // F.mvpMapPoints[bestIdx] = pMP: the last writer stays
@@ -394,8 +387,8 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
     if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
     else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
     for (int i = tid; i < nq; i += kResolveThreads) {
-      int d;
-      const int m = eval(i, cur, d);
+      int w;
+      const int m = eval(i, cur, w);
       if (m < 0) continue;
       const int b = rot_bin_dev(R.qangle[i], R.kangle[m]);
       if (b != ind1 && b != ind2 && b != ind3) { kpAssigned[m] = -2; nm--; }
@@ -408,7 +401,7 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
   for (int o = 32; o > 0; o >>= 1) nm += __shfl_xor(nm, o, 64);
   if ((tid & 63) == 0 && nm) atomicAdd(&acc[0], nm);
   __syncthreads();
-  if (tid == 0) { R.hdrHost[0] = acc[0]; R.hdrHost[2] = rounds; R.hdrHost[3] = LDS ? (entLds ? 2 : 1) : 0; }
+  if (tid == 0) { R.hdrHost[0] = acc[0]; R.hdrHost[2] = rounds; R.hdrHost[3] = LDS ? (ovfUsed <= ldsEntries ? 2 : 1) : 0; }
   stamp(3);
 }
 
@@ -582,6 +575,7 @@ int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint
     M.invSigma2 = P.invSigma2 ? (const float*)(Dq + P.oSig) : nullptr;
     M.chi2 = chi2;
     M.packOctave = 1;
+    M.codeMode = P.mode; M.nnratio = nnratio; M.maxDist = maxDist;
     {
       const float cols = 2.f * rmax * f->invW + 3.f;   // widest window in grid columns (+3: floor / ceil slack of the cell range)
       const int maxCols = cols >= 64.f ? 64 : std::max(1, (int)std::ceil(cols));
@@ -605,11 +599,11 @@ int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint
     R.maxRounds = mr ? std::max(1, atoi(mr)) : 48;
     // LDS-resident tables when they fit (152 KB of the CU's 160): offsets, two table generations, claim bits; what is
     // left holds the candidate entries (the kernel checks their number at run time)
-    const size_t fixedBytes = 4 * ((size_t)nq + 1 + 3 * (size_t)n + 2 * (((size_t)nq + 63) >> 6) + 2 * (((size_t)n + 63) >> 6) + 4);
+    const size_t fixedBytes = 4 * (2 * (size_t)nq + 3 * (size_t)n + 2 * (((size_t)nq + 63) >> 6) + 2 * (((size_t)n + 63) >> 6) + 8);
     const size_t budget = 152 * 1024;
     const char* gen = getenv("ORBFE_RESOLVE_GENERIC");      // 1: tables in global scratch whatever the size (tests)
-    const bool lds = fixedBytes + 4096 <= budget && !(gen && atoi(gen) != 0);
-    const int ldsEntries = lds ? (int)((budget - fixedBytes) / 4) : 0;
+    const bool lds = fixedBytes <= budget && !(gen && atoi(gen) != 0);
+    const int ldsEntries = lds ? (int)((budget - fixedBytes) / 4) : 0;   // room for the lists longer than a record
     const size_t dynBytes = lds ? budget : 0;
 #define ORBFE_LAUNCH_RESOLVE(MODE)                                                                                          \
     do {                                                                                                                      \

@@ -74,7 +74,13 @@ struct MatchParams {
   uint32_t* total;        // [1] pool entries claimed (may exceed poolCap: host retries with a larger pool)
   // searches on a resident frame (orbfe_frame.hip) filter and annotate the candidates where they are produced, so the
   // bookkeeping kernel needs nothing but the entries themselves (per-candidate tests, independent of order):
-  uint32_t* rec = nullptr;            // [nq][4]: {count, entry 0, entry 1, entry 2}; lists of <= kRecEntries live only here
+  uint32_t* rec = nullptr;            // [nq][4]: {count | decision code << 16, entry 0, entry 1, entry 2}; lists of <= kRecEntries
+                                      // live only here.  The decision code (decision_code below) tabulates the query's outcome for
+                                      // every subset of its candidates being available, so the bookkeeping kernel's rounds are a
+                                      // table lookup
+  int codeMode = 0;                   // acceptance rule of the search: 0 SearchByProjection(MapPoints), 1 / 2 best <= maxDist
+  float nnratio = 0.f;
+  int maxDist = 0;
   const float* invSigma2 = nullptr;   // Fuse's gate e2 * mvInvLevelSigma2[octave] > chi2 (ORBmatcher.cc:896-903): dropped
   double chi2 = 0.0;
   int packOctave = 0;                 // entries carry the keypoint's octave in bits 25..30
@@ -92,6 +98,41 @@ __device__ __forceinline__ int hamming256(const uint32_t* __restrict__ a, const 
   return d;
 }
 
+// Outcome of a query restricted to the candidates whose bit is set in `avail`: 0 = no match, c + 1 = candidate c.
+// mode 0: ORBmatcher::SearchByProjection(Frame&, MapPoints, th), src/ORBmatcher.cc:95-120 -- best / second best with their
+// levels, TH_HIGH, the ratio test only when both lie on the same level; modes 1, 2: best <= maxDist (:1373-1383, :376-392).
+// Entries: index | distance << 16 | octave << 25.
+__device__ __forceinline__ int outcome_of(int mode, int cnt, const uint32_t e[3], unsigned avail, float nnratio, int maxDist) {
+  int bestDist = mode == 2 ? INT_MAX : 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, best = -1;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    if (c >= cnt || !((avail >> c) & 1u)) continue;
+    const int dist = (int)((e[c] >> 16) & 0x1ff), oct = (int)(e[c] >> 25);
+    if (mode == 0) {
+      if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = oct; best = c; }
+      else if (dist < bestDist2) { bestLevel2 = oct; bestDist2 = dist; }
+    } else if (dist < bestDist) {
+      bestDist = dist; best = c;
+    }
+  }
+  if (mode == 0) {
+    if (bestDist > TH_HIGH) return 0;
+    if (bestLevel == bestLevel2 && (float)bestDist > nnratio * (float)bestDist2) return 0;
+  } else if (bestDist > maxDist) {
+    return 0;
+  }
+  return best + 1;
+}
+// 8 x 2 bits: field p = outcome when exactly the candidates of bit pattern p are available (bits beyond cnt do not matter)
+__device__ __forceinline__ uint32_t decision_code(int mode, int cnt, const uint32_t e[3], float nnratio, int maxDist) {
+  uint32_t code = 0;
+  const unsigned mask = (1u << cnt) - 1u;
+#pragma unroll
+  for (unsigned p = 1; p < 8; p++) code |= (uint32_t)outcome_of(mode, cnt, e, p & mask, nnratio, maxDist) << (2 * p);
+  return code;
+}
+constexpr uint32_t kCodeLongList = 0xffffu;   // (field 0 of a real code is always 0) the list is longer than the record: read the pool
+
 // LPQ lanes per query (64/LPQ queries per wave), one LANE per grid column of the window.  Window
 // semantics: Frame::GetFeaturesInArea, Frame.cc:209-262: columns ix ascending, rows iy ascending inside a
 // column, insertion order inside a cell -- i.e. for column ix the contiguous run
@@ -107,6 +148,7 @@ template <int LPQ>
 __global__ __launch_bounds__(kWinThreads) void k_window_match(MatchParams M) {
   __shared__ uint32_t wtot[kWinThreads / 64];
   __shared__ uint32_t blockBase;
+  __shared__ uint32_t recTmp[(kWinThreads / LPQ) * kRecEntries];   // short lists gathered per query (resident-frame searches)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane & (LPQ - 1);
   const int q = blockIdx.x * (kWinThreads / LPQ) + threadIdx.x / LPQ;
@@ -216,14 +258,16 @@ __global__ __launch_bounds__(kWinThreads) void k_window_match(MatchParams M) {
   if (live && sub == 0) {
     M.qcount[q] = count;
     M.qoff[q] = off;
-    if (M.rec) M.rec[q * 4] = count;
   }
   off = __shfl(off, 0, LPQ);
-  if (hits == 0) return;
-  uint32_t qd[8];
-  const uint32_t* qp = reinterpret_cast<const uint32_t*>(M.qdesc + (size_t)q * 32);
+  if (hits == 0 && !M.rec) return;
+  const int qlocal = threadIdx.x / LPQ;
+  uint32_t qd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hits) {
+    const uint32_t* qp = reinterpret_cast<const uint32_t*>(M.qdesc + (size_t)q * 32);
 #pragma unroll
-  for (int i = 0; i < 8; i++) qd[i] = qp[i];
+    for (int i = 0; i < 8; i++) qd[i] = qp[i];
+  }
   // pass 2: distances, written at the lane's position in column order; the hits of the mask are fetched two at a time
   uint32_t pos = (uint32_t)(incl - hits);   // position inside the query's list
   auto emit = [&](int e, int idx, int oct, const uint4& d0, const uint4& d1) {
@@ -231,7 +275,7 @@ __global__ __launch_bounds__(kWinThreads) void k_window_match(MatchParams M) {
                   __popc(d1.y ^ qd[5]) + __popc(d1.z ^ qd[6]) + __popc(d1.w ^ qd[7]);
     uint32_t entry = (uint32_t)idx | ((uint32_t)d << 16);
     if (M.packOctave) entry |= (uint32_t)oct << 25;
-    if (inRec) M.rec[q * 4 + 1 + pos] = entry;
+    if (inRec) recTmp[qlocal * kRecEntries + pos] = entry;
     else if (off + pos < M.poolCap) M.pool[off + pos] = entry;
     pos++;
   };
@@ -251,6 +295,21 @@ __global__ __launch_bounds__(kWinThreads) void k_window_match(MatchParams M) {
   for (int e = b + 64; e < e1; e++) {   // runs beyond the mask (very wide windows)
     if (!inWindow(e)) continue;
     emit(e, sidx[e], soct[e], td4[(size_t)e * 2], td4[(size_t)e * 2 + 1]);
+  }
+  if (M.rec) {
+    // the query's record: its lanes' entries meet in LDS (a query's lanes are one wave's: a wave-level fence is enough),
+    // lane 0 of the group tabulates the outcomes and writes the 16 bytes at once
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (live && sub == 0) {
+      uint32_t e3[3] = {0u, 0u, 0u};
+      uint32_t code = kCodeLongList;
+      if (inRec) {
+#pragma unroll
+        for (int c = 0; c < kRecEntries; c++) e3[c] = (uint32_t)c < count ? recTmp[qlocal * kRecEntries + c] : 0u;
+        code = decision_code(M.codeMode, (int)count, e3, M.nnratio, M.maxDist);
+      }
+      reinterpret_cast<uint4*>(M.rec)[q] = make_uint4(count | (code << 16), e3[0], e3[1], e3[2]);
+    }
   }
 }
 

@@ -48,6 +48,10 @@ with open(os.path.join(dst, tag + '_pmc_summary.csv'), 'w') as f:
 fast = [k for k in agg if 'k_fast' in k][0]
 fetch, write = steady(agg[fast]['FETCH_SIZE']) * 1024, steady(agg[fast]['WRITE_SIZE']) * 1024
 valu, waves = steady(agg[fast]['SQ_INSTS_VALU']), steady(agg[fast]['SQ_WAVES'])
+# SQ_ACTIVE_INST_VALU counts quad-cycles (4 shader cycles) a SIMD spends issuing vector instructions: 4 * ACTIVE / INSTS is
+# the measured issue cost of the kernel's own instruction mix; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+active = steady(agg[fast]['SQ_ACTIVE_INST_VALU']) if agg[fast].get('SQ_ACTIVE_INST_VALU') else 0.0
+gui = steady(agg[fast]['GRBM_GUI_ACTIVE']) / 8.0 if agg[fast].get('GRBM_GUI_ACTIVE') else 0.0
 factor, calib = 1.0, 'no calibration run'
 cal = os.path.join(src, 'fetch_calibration.txt')
 if os.path.exists(cal):
@@ -65,6 +69,8 @@ out = {
     'fetch_size_raw_bytes': int(fetch), 'write_size_raw_bytes': int(write), 'fetch_correction_factor': round(factor, 3),
     'fetch_calibration': calib,
     'valu_insts_per_launch': int(valu), 'valu_insts_per_cell_wave': round(valu / waves, 1), 'waves_per_launch': int(waves),
+    'valu_cycles_per_inst': round(4.0 * active / valu, 3) if valu and active else None,
+    'valu_busy_frac_under_profiler': round(4.0 * active / 1024.0 / gui, 4) if gui and active else None,
     'source': 'profiles/%s_pmc_summary.csv (rocprofv3 --pmc, separate passes over `python3 bench.py`), measured at commit %s' % (tag, commit),
 }
 json.dump(out, open(os.path.join(dst, 'counters.json'), 'w'), indent=1)
