@@ -508,6 +508,17 @@ int orbfe_search_by_bow(orbfe_matcher* m, const uint8_t* desc1, const float* ang
                         const uint32_t* fv2_nodes, const uint32_t* fv2_offsets, const uint32_t* fv2_features, int n_fv2,
                         float nnratio, int check_orientation, int strict_threshold, int32_t* matches12, int* nmatches);
 
+/* The SearchByBoW loop of Tracking::Relocalization (src/Tracking.cc:1005-1030: one SearchByBoW(pKF, mCurrentFrame, ...) per
+ * candidate keyframe) as one call: n_kf keyframes (side 1: arrays of per-keyframe pointers / sizes) against ONE frame (side 2),
+ * one upload, one kernel launch over every (keyframe, common vocabulary node) pair, one download.  matches12[k] / nmatches[k]
+ * are exactly what orbfe_search_by_bow returns for keyframe k. */
+int orbfe_search_by_bow_batch(orbfe_matcher* m, int n_kf, const uint8_t* const* desc1, const float* const* angle1,
+                              const uint8_t* const* valid1, const int* n1, const uint32_t* const* fv1_nodes,
+                              const uint32_t* const* fv1_offsets, const uint32_t* const* fv1_features, const int* n_fv1,
+                              const uint8_t* desc2, const float* angle2, const uint8_t* valid2, int n2, const uint32_t* fv2_nodes,
+                              const uint32_t* fv2_offsets, const uint32_t* fv2_features, int n_fv2, float nnratio,
+                              int check_orientation, int strict_threshold, int32_t* const* matches12, int* nmatches);
+
 /* int ORBmatcher::SearchForTriangulation(KeyFrame* pKF1, KeyFrame* pKF2, cv::Mat F12, vector<pair<size_t,size_t>>&
  * vMatchedPairs)  (ORBmatcher.cc:652-804, with CheckDistEpipolarLine :135-152), from the epipole onwards: the caller
  * computes (ex, ey) (:657-666) and passes F12 row-major.  has_mpX[i] != 0: the keypoint already has a MapPoint and is

@@ -786,6 +786,59 @@ inline int SearchByBoW(MatcherContext& ctx, float mfNNratio, bool mbCheckOrienta
   return nmatches;
 }
 
+// The SearchByBoW loop of Tracking::Relocalization (Tracking.cc:1005-1030) as ONE GPU submission: every candidate keyframe
+// against the current frame.  vvpMapPointMatches[k] and the returned counts are what the per-keyframe function above gives;
+// keyframes for which `skip[k]` is set (pKF->isBad(), :1010-1011) are left out (count 0, matches untouched).  Optional: an
+// integration that keeps Tracking.cc unchanged simply keeps calling the per-keyframe member.
+template <class KeyFrameT, class FrameT, class MapPointT>
+inline std::vector<int> SearchByBoW(MatcherContext& ctx, float mfNNratio, bool mbCheckOrientation, const std::vector<KeyFrameT*>& vpKFs,
+                                    const std::vector<bool>& skip, FrameT& F, std::vector<std::vector<MapPointT*> >& vvpMapPointMatches) {
+  const int K = (int)vpKFs.size(), n2 = (int)F.N;
+  std::vector<int> counts(K, 0);
+  vvpMapPointMatches.resize(K);
+  struct Side { std::vector<MapPointT*> mps; std::vector<uint8_t> valid, tmp; std::vector<float> ang; std::vector<uint32_t> nodes, offs, feats;
+                std::vector<int32_t> m12; const uint8_t* desc = nullptr; };
+  std::vector<Side> S(K);
+  std::vector<const uint8_t*> d1, v1;
+  std::vector<const float*> a1;
+  std::vector<const uint32_t*> fn, fo, ff;
+  std::vector<int> n1, nf, which;
+  std::vector<int32_t*> out;
+  for (int k = 0; k < K; k++) {
+    if (k < (int)skip.size() && skip[k]) continue;
+    Side& s = S[k];
+    s.mps = vpKFs[k]->GetMapPointMatches();
+    const int n = (int)s.mps.size();
+    detail::validFlags(s.mps, s.valid);
+    detail::angles(vpKFs[k]->mvKeysUn, s.ang);
+    detail::flattenFeatureVector(vpKFs[k]->mFeatVec, s.nodes, s.offs, s.feats);
+    s.desc = detail::packedDescriptors(vpKFs[k]->mDescriptors, n, s.tmp);
+    s.m12.assign(n > 0 ? n : 1, -1);
+    d1.push_back(s.desc); v1.push_back(s.valid.data()); a1.push_back(s.ang.data()); n1.push_back(n);
+    fn.push_back(s.nodes.data()); fo.push_back(s.offs.data()); ff.push_back(s.feats.data()); nf.push_back((int)s.nodes.size());
+    out.push_back(s.m12.data());
+    which.push_back(k);
+    vvpMapPointMatches[k].assign(n2, static_cast<MapPointT*>(nullptr));
+  }
+  if (which.empty()) return counts;
+  std::vector<uint8_t> t2;
+  std::vector<float> a2;
+  std::vector<uint32_t> n2v, o2v, f2v;
+  detail::angles(F.mvKeys, a2);
+  detail::flattenFeatureVector(F.mFeatVec, n2v, o2v, f2v);
+  std::vector<int> nm(which.size(), 0);
+  check(orbfe_search_by_bow_batch(ctx.get(), (int)which.size(), d1.data(), a1.data(), v1.data(), n1.data(), fn.data(), fo.data(), ff.data(),
+                                  nf.data(), detail::packedDescriptors(F.mDescriptors, n2, t2), a2.data(), nullptr, n2, n2v.data(), o2v.data(),
+                                  f2v.data(), (int)n2v.size(), mfNNratio, mbCheckOrientation ? 1 : 0, 0, out.data(), nm.data()));
+  for (size_t j = 0; j < which.size(); j++) {
+    const int k = which[j];
+    counts[k] = nm[j];
+    for (int i = 0; i < n1[j]; i++)
+      if (S[k].m12[i] >= 0) vvpMapPointMatches[k][S[k].m12[i]] = S[k].mps[i];
+  }
+  return counts;
+}
+
 // int ORBmatcher::SearchByBoW(KeyFrame* pKF1, KeyFrame* pKF2, vector<MapPoint*>& vpMatches12)  (ORBmatcher.cc:517-650)
 template <class KeyFrameT, class MapPointT>
 inline int SearchByBoW(MatcherContext& ctx, float mfNNratio, bool mbCheckOrientation, KeyFrameT* pKF1, KeyFrameT* pKF2,

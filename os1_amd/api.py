@@ -119,6 +119,7 @@ def load_library():
     L.orbfe_bow_transform.argtypes = [vp, vp, ci, ci, ci, vp, vp, C.POINTER(ci), vp, vp, vp, C.POINTER(ci), vp, vp]
     L.orbfe_search_by_bow.argtypes = [vp, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, ci, cf, ci, ci, vp,
                                       C.POINTER(ci)]
+    L.orbfe_search_by_bow_batch.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, ci, cf, ci, ci, vp, vp]
     L.orbfe_debug_matcher_ms.argtypes = [vp, vp]
     L.orbfe_debug_features_in_area.argtypes = [vp, vp, ci, vp, cf, cf, cf, ci, ci, vp, ci, C.POINTER(ci)]
     L.orbfe_debug_kernel_ms.argtypes = [vp, vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), ci]
@@ -637,6 +638,29 @@ class Matcher:
                                           len(desc2), _p(f2[0]), _p(f2[1]), _p(f2[2]), len(f2[0]), nnratio,
                                           int(check_ori), int(strict), _p(m12), C.byref(nm)))
         return nm.value, m12[:len(desc1)]
+
+    def search_by_bow_batch(self, sides1, desc2, angle2, valid2, fv2, nnratio=0.7, check_ori=True, strict=False):
+        """Tracking::Relocalization's SearchByBoW loop in one GPU submission: sides1 = [(desc1, angle1, valid1, fv1)] per
+        candidate keyframe, all against one frame (side 2).  Returns [(nmatches, matches12)] per keyframe."""
+        K = len(sides1)
+        d1 = [np.ascontiguousarray(s[0], np.uint8) for s in sides1]
+        a1 = [np.ascontiguousarray(s[1], np.float32) for s in sides1]
+        v1 = [np.ascontiguousarray(s[2], np.uint8) for s in sides1]
+        f1 = [[np.ascontiguousarray(a, np.uint32) for a in s[3]] for s in sides1]
+        desc2 = np.ascontiguousarray(desc2, np.uint8)
+        angle2 = np.ascontiguousarray(angle2, np.float32)
+        v2 = None if valid2 is None else np.ascontiguousarray(valid2, np.uint8)
+        f2 = [np.ascontiguousarray(a, np.uint32) for a in fv2]
+        m12 = [np.full(max(len(d), 1), -1, np.int32) for d in d1]
+        arr = lambda xs: (C.c_void_p * max(K, 1))(*[x.ctypes.data for x in xs])
+        n1 = np.array([len(d) for d in d1] or [0], np.int32)
+        nf1 = np.array([len(f[0]) for f in f1] or [0], np.int32)
+        nm = np.zeros(max(K, 1), np.int32)
+        _check(self.L.orbfe_search_by_bow_batch(self.h, K, arr(d1), arr(a1), arr(v1), _p(n1), arr([f[0] for f in f1]),
+                                                arr([f[1] for f in f1]), arr([f[2] for f in f1]), _p(nf1), _p(desc2), _p(angle2),
+                                                None if v2 is None else _p(v2), len(desc2), _p(f2[0]), _p(f2[1]), _p(f2[2]), len(f2[0]),
+                                                nnratio, int(check_ori), int(strict), arr(m12), _p(nm)))
+        return [(int(nm[k]), m12[k][:len(d1[k])]) for k in range(K)]
 
     def stage_ms(self):
         out = np.zeros(3, np.float64)

@@ -144,7 +144,8 @@ __global__ void __launch_bounds__(256) k_bow_descend(const uint4* __restrict__ d
 // are visited in order; for each, lanes scan the node's frame-2 features (skipping matched / invalid ones), the wave
 // takes best (first minimum) and second-best distance, applies the reference's acceptance test and marks the winner
 // matched (LDS bitmap) before the next frame-1 feature.
-struct BowPair { int b1, e1, b2, e2; };   // [b,e) ranges into fv1_feat / fv2_feat
+struct BowPair { int b1, e1, b2, e2, base1; };   // [b,e) ranges into fv1_feat / fv2_feat; base1 = first descriptor row of side 1's
+                                                   // frame in desc1 / valid1 / matches12 (several keyframes against one frame in one launch)
 
 __global__ void __launch_bounds__(64) k_bow_match(const uint4* __restrict__ desc1, const uint8_t* __restrict__ valid1,
                                                   const uint32_t* __restrict__ feat1, const uint4* __restrict__ desc2,
@@ -158,7 +159,7 @@ __global__ void __launch_bounds__(64) k_bow_match(const uint4* __restrict__ desc
   for (int i = lane; i < (n2g + 31) / 32; i += 64) matched[i] = 0;
   __syncthreads();
   for (int i1 = P.b1; i1 < P.e1; i1++) {
-    const unsigned idx1 = feat1[i1];
+    const unsigned idx1 = (unsigned)P.base1 + feat1[i1];
     if (!valid1[idx1]) continue;   // wave-uniform
     const uint4 a0 = desc1[2 * (size_t)idx1], a1 = desc1[2 * (size_t)idx1 + 1];
     unsigned k1 = (256u << 16) | 0xffffu, k2 = k1;   // lane-local least and second-least key (distance << 16 | position)
@@ -491,6 +492,8 @@ struct BowScratch {
   DevBuf<int32_t> d_m12;
   PinBuf<int32_t> h_m12;
   DevBuf<OrbfeKeyPoint> d_kps1, d_kps2;
+  DevBuf<uint8_t> d_arena;    // batched search: everything that goes up in one copy
+  PinBuf<uint8_t> h_arena;
 };
 
 // common vocabulary nodes of two FeatureVectors (the lower_bound zig-zag of ORBmatcher.cc:175-258 visits exactly the
@@ -500,7 +503,7 @@ int common_nodes(const uint32_t* fv1_nodes, const uint32_t* fv1_offsets, int n_f
   pairs.clear();
   for (int a = 0, b = 0; a < n_fv1 && b < n_fv2;) {
     if (fv1_nodes[a] == fv2_nodes[b]) {
-      BowPair p = {(int)fv1_offsets[a], (int)fv1_offsets[a + 1], (int)fv2_offsets[b], (int)fv2_offsets[b + 1]};
+      BowPair p = {(int)fv1_offsets[a], (int)fv1_offsets[a + 1], (int)fv2_offsets[b], (int)fv2_offsets[b + 1], 0};
       if (p.e2 - p.b2 > kMaxGroup) { set_err("a vocabulary node holds %d features (max %d)", p.e2 - p.b2, kMaxGroup); return ORBFE_ERR_OVERFLOW; }
       if (p.e1 > p.b1 && p.e2 > p.b2) pairs.push_back(p);
       a++; b++;
@@ -540,6 +543,92 @@ int prune_by_orientation(const float* angle1, size_t stride1, const float* angle
 
 }  // namespace
 
+// int ORBmatcher::SearchByBoW(KeyFrame* pKF, Frame& F, ...) for SEVERAL keyframes against one frame -- the loop of
+// Tracking::Relocalization (src/Tracking.cc:1005-1030: one SearchByBoW per candidate keyframe, all against mCurrentFrame) --
+// as ONE upload, ONE launch of k_bow_match over every (keyframe, common vocabulary node) pair and ONE download.  The
+// searches are independent (each has its own vpMapPointMatches / matched set), so results equal the per-keyframe calls.
+extern "C" int orbfe_search_by_bow_batch(orbfe_matcher* m, int n_kf, const uint8_t* const* desc1, const float* const* angle1,
+                                         const uint8_t* const* valid1, const int* n1, const uint32_t* const* fv1_nodes,
+                                         const uint32_t* const* fv1_offsets, const uint32_t* const* fv1_features, const int* n_fv1,
+                                         const uint8_t* desc2, const float* angle2, const uint8_t* valid2, int n2,
+                                         const uint32_t* fv2_nodes, const uint32_t* fv2_offsets, const uint32_t* fv2_features,
+                                         int n_fv2, float nnratio, int check_orientation, int strict_threshold,
+                                         int32_t* const* matches12, int* nmatches) {
+  if (!m || n_kf < 0 || n2 < 0 || n_fv2 < 0 || (n_kf && (!desc1 || !valid1 || !n1 || !fv1_nodes || !fv1_offsets || !fv1_features || !n_fv1 ||
+      !matches12 || !nmatches)) || (n2 > 0 && !desc2) || (n_fv2 > 0 && (!fv2_nodes || !fv2_offsets || !fv2_features)) ||
+      (check_orientation && (!angle2 || !angle1))) {
+    set_err("bad argument");
+    return ORBFE_ERR_INVALID;
+  }
+  const int nf2 = n_fv2 ? (int)fv2_offsets[n_fv2] : 0;
+  for (int i = 0; i < nf2; i++) if (fv2_features[i] >= (uint32_t)n2) { set_err("fv2 feature index out of range"); return ORBFE_ERR_INVALID; }
+  std::vector<BowPair> pairs, all;
+  std::vector<size_t> rowBase(n_kf + 1, 0), featBase(n_kf + 1, 0);
+  int rc;
+  for (int k = 0; k < n_kf; k++) {
+    nmatches[k] = 0;
+    if (n1[k] < 0 || n_fv1[k] < 0 || (n1[k] > 0 && (!desc1[k] || !valid1[k] || !matches12[k])) ||
+        (n_fv1[k] > 0 && (!fv1_nodes[k] || !fv1_offsets[k] || !fv1_features[k])) || (check_orientation && n1[k] > 0 && !angle1[k])) {
+      set_err("bad argument for keyframe %d", k);
+      return ORBFE_ERR_INVALID;
+    }
+    for (int i = 0; i < n1[k]; i++) matches12[k][i] = -1;
+    const int nf1 = n_fv1[k] ? (int)fv1_offsets[k][n_fv1[k]] : 0;
+    for (int i = 0; i < nf1; i++) if (fv1_features[k][i] >= (uint32_t)n1[k]) { set_err("fv1 feature index out of range"); return ORBFE_ERR_INVALID; }
+    if ((rc = common_nodes(fv1_nodes[k], fv1_offsets[k], n_fv1[k], fv2_nodes, fv2_offsets, n_fv2, pairs))) return rc;
+    for (BowPair p : pairs) {
+      p.b1 += (int)featBase[k]; p.e1 += (int)featBase[k]; p.base1 = (int)rowBase[k];
+      all.push_back(p);
+    }
+    rowBase[k + 1] = rowBase[k] + (size_t)n1[k];
+    featBase[k + 1] = featBase[k] + (size_t)nf1;
+  }
+  if (all.empty()) return ORBFE_OK;
+  const size_t rows1 = rowBase[n_kf], feats1 = featBase[n_kf];
+  HIP_TRY(hipSetDevice(orbfe::matcher_device(m)));
+  std::shared_ptr<void>& slot = orbfe::matcher_bow_slot(m);
+  if (!slot) slot = std::make_shared<BowScratch>();
+  BowScratch* S = static_cast<BowScratch*>(slot.get());
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t oD1 = 0, oD2 = oD1 + al(32 * rows1), oV1 = oD2 + al(32 * (size_t)n2), oV2 = oV1 + al(rows1), oF1 = oV2 + al((size_t)std::max(n2, 1)),
+               oF2 = oF1 + al(4 * feats1), oP = oF2 + al(4 * (size_t)nf2), total = oP + al(sizeof(BowPair) * all.size());
+  if ((rc = S->h_arena.ensure(total)) || (rc = S->d_arena.ensure(total)) || (rc = S->d_m12.ensure(rows1)) || (rc = S->h_m12.ensure(rows1))) return rc;
+  uint8_t* H = S->h_arena.p;
+  for (int k = 0; k < n_kf; k++) {
+    if (n1[k]) {
+      memcpy(H + oD1 + 32 * rowBase[k], desc1[k], 32 * (size_t)n1[k]);
+      memcpy(H + oV1 + rowBase[k], valid1[k], (size_t)n1[k]);
+    }
+    const size_t nf1 = featBase[k + 1] - featBase[k];
+    if (nf1) memcpy(H + oF1 + 4 * featBase[k], fv1_features[k], 4 * nf1);
+  }
+  if (n2) memcpy(H + oD2, desc2, 32 * (size_t)n2);
+  if (valid2 && n2) memcpy(H + oV2, valid2, (size_t)n2);
+  if (nf2) memcpy(H + oF2, fv2_features, 4 * (size_t)nf2);
+  memcpy(H + oP, all.data(), sizeof(BowPair) * all.size());
+  hipStream_t st = orbfe::matcher_stream(m);
+  uint8_t* D = S->d_arena.p;
+  HIP_TRY(hipMemcpyAsync(D, H, total, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(S->d_m12.p, 0xff, sizeof(int32_t) * rows1, st));
+  hipLaunchKernelGGL(k_bow_match, dim3((unsigned)all.size()), dim3(64), 0, st, (const uint4*)(D + oD1), (const uint8_t*)(D + oV1),
+                     (const uint32_t*)(D + oF1), (const uint4*)(D + oD2), valid2 ? (const uint8_t*)(D + oV2) : (const uint8_t*)nullptr,
+                     (const uint32_t*)(D + oF2), (const BowPair*)(D + oP), strict_threshold ? TH_LOW - 1 : TH_LOW, nnratio, S->d_m12.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(S->h_m12.p, S->d_m12.p, sizeof(int32_t) * rows1, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  for (int k = 0; k < n_kf; k++) {
+    int nm = 0;
+    const int32_t* src = S->h_m12.p + rowBase[k];
+    for (int i = 0; i < n1[k]; i++) {
+      matches12[k][i] = src[i];
+      if (src[i] >= 0) nm++;
+    }
+    if (check_orientation && n1[k]) nm -= prune_by_orientation(angle1[k], sizeof(float), angle2, sizeof(float), n1[k], matches12[k]);
+    nmatches[k] = nm;
+  }
+  return ORBFE_OK;
+}
+
 extern "C" int orbfe_search_by_bow(orbfe_matcher* m, const uint8_t* desc1, const float* angle1, const uint8_t* valid1, int n1,
                                    const uint32_t* fv1_nodes, const uint32_t* fv1_offsets, const uint32_t* fv1_features,
                                    int n_fv1, const uint8_t* desc2, const float* angle2, const uint8_t* valid2, int n2,
@@ -553,45 +642,9 @@ extern "C" int orbfe_search_by_bow(orbfe_matcher* m, const uint8_t* desc1, const
     return ORBFE_ERR_INVALID;
   }
   *nmatches = 0;
-  for (int i = 0; i < n1; i++) matches12[i] = -1;
-  std::vector<BowPair> pairs;
-  int rc = common_nodes(fv1_nodes, fv1_offsets, n_fv1, fv2_nodes, fv2_offsets, n_fv2, pairs);
-  if (rc) return rc;
-  const int nf1 = n_fv1 ? (int)fv1_offsets[n_fv1] : 0, nf2 = n_fv2 ? (int)fv2_offsets[n_fv2] : 0;
-  for (int i = 0; i < nf1; i++) if (fv1_features[i] >= (uint32_t)n1) { set_err("fv1 feature index out of range"); return ORBFE_ERR_INVALID; }
-  for (int i = 0; i < nf2; i++) if (fv2_features[i] >= (uint32_t)n2) { set_err("fv2 feature index out of range"); return ORBFE_ERR_INVALID; }
-  if (pairs.empty()) return ORBFE_OK;
-  HIP_TRY(hipSetDevice(orbfe::matcher_device(m)));
-  std::shared_ptr<void>& slot = orbfe::matcher_bow_slot(m);
-  if (!slot) slot = std::make_shared<BowScratch>();
-  BowScratch* S = static_cast<BowScratch*>(slot.get());
-  if ((rc = S->d_desc1.ensure((size_t)n1 * 2)) || (rc = S->d_desc2.ensure((size_t)n2 * 2)) || (rc = S->d_valid1.ensure(n1)) ||
-      (rc = S->d_valid2.ensure(std::max(n2, 1))) || (rc = S->d_feat1.ensure(nf1)) || (rc = S->d_feat2.ensure(nf2)) ||
-      (rc = S->d_pairs.ensure(pairs.size())) || (rc = S->d_m12.ensure(n1)) || (rc = S->h_m12.ensure(n1)))
-    return rc;
-  hipStream_t st = orbfe::matcher_stream(m);
-  HIP_TRY(hipMemcpyAsync(S->d_desc1.p, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(S->d_desc2.p, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(S->d_valid1.p, valid1, n1, hipMemcpyHostToDevice, st));
-  if (valid2) HIP_TRY(hipMemcpyAsync(S->d_valid2.p, valid2, n2, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(S->d_feat1.p, fv1_features, sizeof(uint32_t) * nf1, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(S->d_feat2.p, fv2_features, sizeof(uint32_t) * nf2, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(S->d_pairs.p, pairs.data(), sizeof(BowPair) * pairs.size(), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemsetAsync(S->d_m12.p, 0xff, sizeof(int32_t) * n1, st));
-  hipLaunchKernelGGL(k_bow_match, dim3((unsigned)pairs.size()), dim3(64), 0, st, S->d_desc1.p, S->d_valid1.p, S->d_feat1.p,
-                     S->d_desc2.p, valid2 ? S->d_valid2.p : (const uint8_t*)nullptr, S->d_feat2.p, S->d_pairs.p,
-                     strict_threshold ? TH_LOW - 1 : TH_LOW, nnratio, S->d_m12.p);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(S->h_m12.p, S->d_m12.p, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  int nm = 0;
-  for (int i = 0; i < n1; i++) {
-    matches12[i] = S->h_m12.p[i];
-    if (matches12[i] >= 0) nm++;
-  }
-  if (check_orientation) nm -= prune_by_orientation(angle1, sizeof(float), angle2, sizeof(float), n1, matches12);
-  *nmatches = nm;
-  return ORBFE_OK;
+  return orbfe_search_by_bow_batch(m, 1, &desc1, &angle1, &valid1, &n1, &fv1_nodes, &fv1_offsets, &fv1_features, &n_fv1, desc2, angle2,
+                                   valid2, n2, fv2_nodes, fv2_offsets, fv2_features, n_fv2, nnratio, check_orientation, strict_threshold,
+                                   &matches12, nmatches);
 }
 
 extern "C" int orbfe_search_for_triangulation(orbfe_matcher* m, const OrbfeKeyPoint* kps1_un, const uint8_t* desc1,

@@ -157,6 +157,13 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < r1.size(); i++)
       if (vpMapPointMatches[i]) r1[i] = (int)(vpMapPointMatches[i] - own[0].data());
     writeFile(dir + "/bow1.matches", r1.data(), r1.size() * sizeof(int));
+    {   // the relocalisation loop in one submission (Tracking.cc:1005-1030): the same keyframe twice + one skipped
+      std::vector<KeyFrame*> kfs = {&F[0], &F[0], &F[0]};
+      std::vector<bool> skip = {false, true, false};
+      std::vector<std::vector<MapPoint*> > vv;
+      const std::vector<int> cnt = orbfe::SearchByBoW(ctx, 0.7f, true, kfs, skip, static_cast<Frame&>(F[1]), vv);
+      if (cnt.size() != 3 || cnt[0] != nbow1 || cnt[2] != nbow1 || cnt[1] != 0 || vv[0] != vpMapPointMatches || vv[2] != vpMapPointMatches) return 4;
+    }
     nbow2 = orbfe::SearchByBoW(ctx, 0.75f, true, &F[0], &F[1], vpMatches12);
     r2.assign(vpMatches12.size(), -1);
     for (size_t i = 0; i < r2.size(); i++)

@@ -94,6 +94,36 @@ def test_search_by_bow_parity(api, oracle, levelsup):
     assert nm == 0 and (m12 == -1).all()
 
 
+def test_search_by_bow_batch_is_the_relocalisation_loop(api, oracle):
+    """Tracking::Relocalization (Tracking.cc:1005-1030): SearchByBoW of several candidate keyframes against the current frame,
+    one GPU submission; every keyframe's result equals its own oracle call (and the single-keyframe entry point)."""
+    image = synth_vocabulary(6, 10, 3)
+    ov = oracle.vocabulary(image)
+    m = api.Matcher()
+    sides, frame = [], None
+    for seed, n1 in [(21, 500), (22, 1), (23, 800), (24, 0), (25, 350)]:
+        d1, a1, v1, d2, a2, v2 = make_bow_pair(seed, image, max(n1, 1), 600)
+        if n1 == 0:
+            d1, a1, v1 = d1[:0], a1[:0], v1[:0]
+        if frame is None:
+            frame = (d2, a2, ov.transform(d2, 1)[2])
+        sides.append((d1, a1, v1, ov.transform(d1, 1)[2] if len(d1) else (np.zeros(0, np.uint32), np.zeros(1, np.uint32), np.zeros(0, np.uint32))))
+    d2, a2, fv2 = frame
+    total = 0
+    for ratio, ori in [(0.75, True), (0.9, False)]:
+        got = m.search_by_bow_batch(sides, d2, a2, None, fv2, ratio, ori, False)
+        assert len(got) == len(sides)
+        for (d1, a1, v1, fv1), (nm, m12) in zip(sides, got):
+            wn, w12 = oracle.search_by_bow(d1, a1, v1, fv1, d2, a2, None, fv2, ratio, ori) if len(d1) else (0, np.zeros(0, np.int32))
+            assert nm == wn and m12.tobytes() == w12.tobytes()
+            if len(d1):
+                sn, s12 = m.search_by_bow(d1, a1, v1, fv1, d2, a2, None, fv2, ratio, ori, False)
+                assert sn == nm and s12.tobytes() == m12.tobytes()
+            total += nm
+    assert total > 100
+    assert m.search_by_bow_batch([], d2, a2, None, fv2) == []
+
+
 def test_search_for_triangulation_parity(api, oracle):
     """LocalMapping::CreateNewMapPoints' matcher: two extracted frames related by an image translation t, F12 = [t]x
     (true correspondences lie on their epipolar lines), an epipole placed inside the image so the epipole-distance
