@@ -401,6 +401,7 @@ def run_rank(args):
         }
         if world == 1 and not args.no_latency:
             out['config5_search_by_projection'] = config5_leg(api, local_rank, args.cpu_frames > 0)
+            out['tracking_step'] = tracking_step_leg(api, local_rank, frames, W, H, wl)
         if world == 1 and args.cpu_frames > 0:
             out['cpu_baseline'] = cpu_baseline(frames, args.cpu_frames, not args.no_match)
             out['cpu_baseline_all_cores'] = cpu_baseline_all_cores(frames, not args.no_match)
@@ -442,6 +443,62 @@ def load_profile_counters(B):
     if c.get('batch') != B:
         return {}
     return c
+
+
+def tracking_step_leg(api, device, frames, W, H, wl):
+    """The front end of ONE tracked frame as Tracking.cc drives it (Frame.cc:133, Tracking.cc:608, 824), blocking calls, outside
+    the timed region: ORBextractor::operator() on a page-locked host frame -> the frame's features stay on the GPU
+    (orbfe_frame_create_from_extract) -> SearchByProjection(CurrentFrame, LastFrame, th) with the last frame's keypoints as
+    sources -> SearchByProjection(CurrentFrame, local MapPoints, th) with 3 000 MapPoints.  Median ms per stage over 60 frames."""
+    import ctypes as C
+    import numpy as np
+    nfr = 61
+    pin = api.PinnedFrames([frames[i] for i in range(nfr)])
+    ex = api.Extractor(wl.NFEAT, wl.SCALE, wl.NLEVELS, wl.INI_TH, wl.MIN_TH, device=device)
+    m = api.Matcher(device)
+    sf = np.ascontiguousarray(ex.tables()['sf'], np.float32)
+    bounds = (0.0, float(W), 0.0, float(H))
+    kbuf = np.zeros((1, ex.cap), api.KP_DTYPE)
+    dbuf = np.zeros((1, ex.cap, 32), np.uint8)
+    rng = np.random.default_rng(3)
+    t_ex, t_fr, t_ff, t_mp, nm1, nm2 = [], [], [], [], [], []
+    prev = None
+    for i in range(nfr):
+        t0 = time.perf_counter()
+        _, _, n = ex.extract_batch_ptrs([pin.ptrs[i]], H, W, W, False, kbuf, dbuf)
+        t1 = time.perf_counter()
+        fr = api.Frame.from_extract(ex, 0, bounds)
+        t2 = time.perf_counter()
+        k, d = kbuf[0, :n[0]].copy(), dbuf[0, :n[0]].copy()
+        if prev is not None:
+            pk, pd = prev
+            uv = np.stack([pk['x'] + 2, pk['y'] + 1], 1).astype(np.float32)       # the stream moves by (2, 1) px per frame
+            valid = np.ones(len(pk), np.uint8)
+            sflags = np.full(len(pk), 8, np.uint8)
+            occ = np.zeros(len(k), np.uint8)
+            t3 = time.perf_counter()
+            a = m.search_by_projection_uv(fr, None, None, sf, occ, uv, pk['octave'], pk['angle'], sflags, valid, pd, 15.0, 100, 0, True)
+            t4 = time.perf_counter()
+            src = rng.integers(0, len(k), 3000)
+            mxy = (np.stack([k['x'][src], k['y'][src]], 1) + rng.uniform(-2, 2, (3000, 2))).astype(np.float32)
+            lvl = k['octave'][src].astype(np.int32)
+            vcos = np.full(3000, 0.95, np.float32)
+            fl = np.full(3000, 1 | 8, np.uint8)
+            occ2 = (a[1] >= 0).astype(np.uint8)
+            md = np.ascontiguousarray(d[src])
+            t5 = time.perf_counter()
+            b = m.search_by_projection(fr, None, None, sf, occ2, mxy, lvl, vcos, fl, md, 3.0, 0.8)
+            t6 = time.perf_counter()
+            t_ex.append(t1 - t0); t_fr.append(t2 - t1); t_ff.append(t4 - t3); t_mp.append(t6 - t5)
+            nm1.append(a[0]); nm2.append(b[0])
+        prev = (k, d)
+        fr.close()
+    pin.free()
+    med = lambda v: round(float(np.median(v)) * 1e3, 4)
+    return {'extract_host_frame_ms': med(t_ex), 'resident_frame_from_extract_ms': med(t_fr), 'search_by_projection_last_frame_ms': med(t_ff),
+            'search_by_projection_mappoints_ms': med(t_mp), 'front_end_total_ms': round(med(t_ex) + med(t_fr) + med(t_ff) + med(t_mp), 4),
+            'matches_last_frame_median': int(np.median(nm1)), 'matches_mappoints_median': int(np.median(nm2)),
+            'note': '1080p / 2000 features, 60 frames; the search timings include the Python marshalling of the test harness (about 0.02 ms per call)'}
 
 
 def config5_leg(api, device, with_oracle):
