@@ -418,8 +418,11 @@ struct orbfe_frame {
   hipEvent_t ready = nullptr;
   ~orbfe_frame() {
     (void)hipSetDevice(device);
+    // `ready` may have been recorded on the stream of an extractor that no longer exists (its destructor waited for the
+    // stream's work, so the build is complete): errors of these two calls are not errors of the frame
     if (ready) { (void)hipEventSynchronize(ready); (void)hipEventDestroy(ready); }
     buf.release(); stage.release();
+    (void)hipGetLastError();
   }
   int carve(int count) {
     const size_t c = (size_t)std::max(count, 1);
@@ -517,6 +520,7 @@ constexpr int kHdr = 64;
 int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint8_t* qdescHost, float rmax, float nnratio,
                int maxDist, double chi2, int checkOri, const int** out, int* nmatches) {
   HIP_TRY(hipSetDevice(m->device));
+  (void)hipGetLastError();
   if (f->device != m->device) { set_err("frame and matcher live on different devices"); return ORBFE_ERR_INVALID; }
   const double tA = orbfe_matcher::nowMs();
   hipStream_t st = m->stream;
@@ -530,7 +534,7 @@ int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint
     HIP_TRY(hipMemsetAsync(m->d_r.p, 0, kHdr * sizeof(int), st));   // a fresh allocation: the running counter starts at zero
   }
   if ((rc = m->h_r.ensure(kHdr + outInts + 64))) return rc;
-  if (f->ready) HIP_TRY(hipStreamWaitEvent(st, f->ready, 0));
+  if (f->ready && hipStreamWaitEvent(st, f->ready, 0) != hipSuccess) (void)hipGetLastError();   // (the recording stream is gone: the build is complete)
   // queries: one copy for the scalar arrays; descriptor rows straight from the caller's memory when it is page-locked
   hipPointerAttribute_t attr;
   const bool pinned = qdescHost && hipPointerGetAttributes(&attr, qdescHost) == hipSuccess && attr.type == hipMemoryTypeHost;
@@ -670,6 +674,7 @@ int orbfe_frame_create(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, const uint
   }
   *out = nullptr;
   HIP_TRY(hipSetDevice(m->device));
+  (void)hipGetLastError();
   orbfe_frame* f = new orbfe_frame();
   f->device = m->device;
   const int rc = f->fromHost(kps_un, desc, n, bounds, m->stream);
@@ -687,6 +692,7 @@ int orbfe_frame_create_from_extract(orbfe_extractor* h, int frame_index, const f
   if (rc) return rc;
   if (V.n > 65535) { set_err("at most 65535 keypoints per frame"); return ORBFE_ERR_INVALID; }
   HIP_TRY(hipSetDevice(V.device));
+  (void)hipGetLastError();
   hipStream_t st = (hipStream_t)V.stream;
   orbfe_frame* f = new orbfe_frame();
   f->device = V.device;

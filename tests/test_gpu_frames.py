@@ -104,6 +104,23 @@ def test_frame_content_and_grid(api, oracle):
         assert gk['x'].tobytes() == kk['x'].tobytes() and gd.tobytes() == dd.tobytes()
     with pytest.raises(api.OrbfeError):
         api.Frame.from_extract(ex2, 1, (0.0, 800.0, 0.0, 600.0))   # the last batch has one frame
+    # a frame outlives the extractor it was taken from (its build was recorded on that extractor's stream)
+    ex3 = api.Extractor(400, 1.2, 4, 20, 7)
+    k3, d3 = ex3(imgs[1])
+    fr3 = api.Frame.from_extract(ex3, 0, (0.0, 800.0, 0.0, 600.0))
+    ex3.close()
+    del ex3
+    sf3 = api.Extractor(400, 1.2, 4, 20, 7).tables()['sf']
+    occ3 = np.zeros(len(k3), np.uint8)
+    q = np.stack([k3['x'], k3['y']], 1)
+    got = m.search_by_projection(fr3, None, None, sf3, occ3, q, k3['octave'], np.ones(len(k3), np.float32),
+                                 np.full(len(k3), 9, np.uint8), d3, 1.0, 0.8)
+    want = oracle.search_by_projection(k3, d3, (0.0, 800.0, 0.0, 600.0), sf3, occ3, q, k3['octave'], np.ones(len(k3), np.float32),
+                                       np.full(len(k3), 9, np.uint8), d3, 1.0, 0.8)
+    assert got[0] == want[0] and (got[1] == want[1]).all() and got[0] > 300
+    fr3.close()
+    fr4 = api.Frame.from_host(m, k3, d3, (0.0, 800.0, 0.0, 600.0))    # no stale error is left behind for the next call
+    assert len(fr4) == len(k3)
 
 
 def test_search_by_projection_all_call_forms(api, oracle, monkeypatch):
