@@ -70,6 +70,18 @@ def worker(tid):
         n, m12, _ = m.search_for_initialization(g[0], g[1], g[0], g[1], (0.0, float(k[0]), 0.0, float(k[1])),
                                                 np.stack([g[0]['x'], g[0]['y']], 1), 100, 0.9, True)
         good &= n > 100
+        # a resident frame per iteration, two searches on it, destroyed while other threads run theirs
+        b = (0.0, float(k[0]), 0.0, float(k[1]))
+        fr = api.Frame.from_extract(e, 0, b) if it % 2 else api.Frame.from_host(m, g[0], g[1], b)
+        sf = e.tables()['sf']
+        nk = len(g[0])
+        q = np.stack([g[0]['x'], g[0]['y']], 1)
+        occ = np.zeros(nk, np.uint8)
+        a = m.search_by_projection(fr, None, None, sf, occ, q, g[0]['octave'], np.ones(nk, np.float32), np.full(nk, 9, np.uint8), g[1], 1.0, 0.8)
+        bres = m.search_by_projection_uv(fr, None, None, sf, occ, q, g[0]['octave'], g[0]['angle'], np.full(nk, 8, np.uint8),
+                                         np.ones(nk, np.uint8), g[1], 7.0, 100, 0, True)
+        good &= a[0] > nk * 0.8 and bres[0] > nk * 0.7
+        fr.close()
     res[tid] = good
 
 
