@@ -143,13 +143,15 @@ enum { kModeMapPoints = 0, kModeUv = 1, kModeProjected = 2 };
 // keypoint octave << 25, in GetFeaturesInArea order; candidates failing Fuse's chi-square gate are already gone.  Per
 // query a 16-byte record {count, first three entries}; longer lists lie in the pool at qoff.
 struct ResolveParams {
-  const uint32_t* rec; const uint32_t* qoff; const uint32_t* pool; uint32_t* total; uint32_t poolCap;
+  const uint2* qword;       // [nq] packed query words as k_window_match leaves them (MatchParams::qword)
+  const uint32_t* rec;      // [nq][4] full records (the distances of the accepted candidates are read from here)
+  const uint32_t* qoff; const uint32_t* pool; uint32_t* total; uint32_t poolCap;
   int nq, n;
-  const uint8_t* qclaim;    // != 0: an accepted match of this query makes its keypoint unavailable to later queries
-  const uint8_t* occ0;      // [n] keypoints unavailable from the start (mvpMapPoints occupancy / kp_skip); nullptr: none
+  const uint32_t* claimBits;   // bit i: an accepted match of query i makes its keypoint unavailable to later queries
+  const uint32_t* occBits;     // bit k: keypoint k unavailable from the start (mvpMapPoints occupancy / kp_skip); nullptr: none
   const float* qangle; const float* kangle;
   float nnratio; int maxDist; int checkOri;
-  int* scratch;             // generic kernel: [3 n] two table generations + kp_assigned
+  int* scratch;             // generic kernel: [2 n] the table + kp_assigned
   int* outHost;             // page-locked host memory, written by the kernel itself (no copy command behind it):
                             // kp_assigned[n] (modes 0, 1) or best_idx[nq], best_dist[nq] (mode 2)
   int* hdrHost;             // [kHdr] result header, page-locked host memory
@@ -202,121 +204,94 @@ constexpr int kResolveThreads = 1024;
 // One block.  A query's outcome for every subset of its (at most three) candidates being available was tabulated by the
 // window kernel (decision_code), so a round is a table lookup per query: fetch the candidates' table words, form the
 // availability pattern, read the outcome.  LDS = true (the launcher checks that everything fits the budget): the packed
-// query words (3 x 16-bit keypoint index + 16-bit code), two generations of the "first claiming query" table, kp_assigned
-// and the claim / occupancy flags as bits live in LDS.  A round evaluates every query against the previous round's table
-// and builds the next one with LDS atomics; the fixed point is reached when two generations are equal.  Lists longer than
-// the record (wide windows) are evaluated from the pool in global memory.  LDS = false keeps everything in global scratch.
-template <int MODE, bool LDS>
+// query words (3 x 16-bit keypoint index + 16-bit code), the "first claiming query" table, kp_assigned and the claim /
+// occupancy flags as bits live in LDS.  The queries are settled chunk by chunk in query order (kResolveThreads * QPT at a
+// time, see below).  Lists longer than the record (wide windows) are walked from an LDS copy while there is room, else from
+// the pool in global memory.  LDS = false keeps everything in global scratch.
+template <int MODE, bool LDS, int QPT>
 __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, int ldsEntries) {
   extern __shared__ __align__(16) int dyn[];
   __shared__ int hist[32];
   __shared__ int acc[2];
-  __shared__ int ovfUsed;
+  __shared__ int orFlag[3];
+  __shared__ int dbgT[40];
   const int tid = threadIdx.x, nq = R.nq, n = R.n;
   const uint32_t tot = *R.total;
   auto stamp = [&](int k) { if (tid == 0) R.hdrHost[16 + k] = (int)__builtin_readcyclecounter(); };   // phase clock (debug)
   stamp(0);
   if (tid < 32) hist[tid] = 0;
   if (tid < 2) acc[tid] = 0;
-  if (tid == 0) ovfUsed = 0;
-  __syncthreads();
+  if (tid < 3) orFlag[tid] = 0;
+  const int claimWords = (nq + 31) >> 5, occWords = (n + 31) >> 5;
+  uint2* q8 = LDS ? reinterpret_cast<uint2*>(dyn) : nullptr;                         // [nq] packed query words, later the outcomes
+  int* fcA = LDS ? dyn + 2 * nq : R.scratch;                                         // [n]
+  int* kpAssigned = fcA + n;                                                          // [n]
+  uint32_t* claimL = LDS ? reinterpret_cast<uint32_t*>(kpAssigned + n) : nullptr;    // [claimWords]
+  uint32_t* occL = LDS ? claimL + claimWords : nullptr;                               // [occWords]
+  uint32_t* ovf = LDS ? occL + occWords : nullptr;                                    // [ldsEntries] the pool's copy
+  const uint32_t* claimW = LDS ? claimL : R.claimBits;
+  const uint32_t* occW = LDS ? occL : R.occBits;
+  auto occupied = [&](int k) -> bool { return R.occBits && ((occW[k >> 5] >> (k & 31)) & 1u) != 0; };
+  if (LDS) {
+    // straight copies, every load independent of every other (and of the counter's): query words, flag masks
+    for (int i = tid; i < nq; i += kResolveThreads) q8[i] = R.qword[i];
+    for (int w = tid; w < claimWords; w += kResolveThreads) claimL[w] = R.claimBits[w];
+    if (R.occBits)
+      for (int w = tid; w < occWords; w += kResolveThreads) occL[w] = R.occBits[w];
+  }
+  __syncthreads();        // (every thread has read the counter)
   if (tid == 0) {
     R.hdrHost[4] = (int)tot;
-    *R.total = 0u;        // the counter is ready for the next search (every thread has read it)
+    *R.total = 0u;        // ready for the next search
     R.hdrHost[1] = tot > R.poolCap ? 1 : 0;
   }
   if (tot > R.poolCap) return;   // candidate pool too small: the host grows it and submits again
-  uint2* q8 = LDS ? reinterpret_cast<uint2*>(dyn) : nullptr;                         // [nq] idx0 | idx1 << 16, idx2 | code << 16
-  int* fcA = LDS ? dyn + 2 * nq : R.scratch;                                         // [n]
-  int* fcB = fcA + n;                                                                 // [n]
-  int* kpAssigned = fcB + n;                                                          // [n]
-  uint32_t* claimBits = LDS ? reinterpret_cast<uint32_t*>(kpAssigned + n) : nullptr; // [2 * ceil(nq / 64)]
-  uint32_t* occBits = LDS ? claimBits + 2 * ((nq + 63) >> 6) : nullptr;               // [2 * ceil(n / 64)]
-  uint32_t* ovf = LDS ? occBits + 2 * ((n + 63) >> 6) : nullptr;                       // [ldsEntries] lists longer than a record
-  const uint4* rec4 = reinterpret_cast<const uint4*>(R.rec);
-  auto pack = [](const uint4& r) -> uint2 {
-    const uint32_t cnt = r.x & 0xffffu, code = cnt ? (r.x >> 16) : 0u;
-    return make_uint2((r.y & 0xffffu) | (r.z << 16), (r.w & 0xffffu) | (code << 16));
-  };
-  auto occupied = [&](int k) -> bool {
-    if (!R.occ0) return false;
-    return LDS ? ((occBits[k >> 5] >> (k & 31)) & 1u) != 0 : R.occ0[k] != 0;
-  };
-  if (LDS) {
-    // packed query words from the records, claim and occupancy flags as ballot words: coalesced, every load independent
-    for (int i0 = 0; i0 < nq; i0 += kResolveThreads) {
-      const int i = i0 + tid;
-      const bool in = i < nq;
-      if (in) {
-        const uint4 r = rec4[i];
-        uint2 w = pack(r);
-        if ((w.y >> 16) == kCodeLongList) {   // the list moves to LDS while there is room (x = its offset there), else it stays in the pool
-          const int cnt = (int)(r.x & 0xffffu);
-          const int at = atomicAdd(&ovfUsed, cnt);
-          w.x = 0xffffffffu;
-          w.y = (uint32_t)cnt | (kCodeLongList << 16);
-          if (at + cnt <= ldsEntries) {
-            w.x = (uint32_t)at;
-            const uint32_t* src = R.pool + R.qoff[i];
-            for (int c = 0; c < cnt; c++) ovf[at + c] = src[c];
-          }
-        }
-        q8[i] = w;
-      }
-      const unsigned long long b = __ballot(in && R.qclaim[i] != 0);
-      if ((tid & 63) == 0 && in) {
-        claimBits[i >> 5] = (uint32_t)b;
-        claimBits[(i >> 5) + 1] = (uint32_t)(b >> 32);
-      }
-    }
-    if (R.occ0)
-      for (int k0 = 0; k0 < n; k0 += kResolveThreads) {
-        const int k = k0 + tid;
-        const unsigned long long b = __ballot(k < n && R.occ0[k] != 0);
-        if ((tid & 63) == 0 && k < n) {
-          occBits[k >> 5] = (uint32_t)b;
-          occBits[(k >> 5) + 1] = (uint32_t)(b >> 32);
-        }
-      }
-    __syncthreads();
-  }
+  // the lists beyond the records (and the wide records) are walked from LDS when the whole pool fits, else from the pool
+  const bool poolInLds = LDS && tot <= (uint32_t)ldsEntries;
+  const uint32_t* lists = poolInLds ? ovf : R.pool;
+  if (poolInLds)
+    for (uint32_t e = (uint32_t)tid; e < tot; e += kResolveThreads) ovf[e] = R.pool[e];
   for (int k = tid; k < n; k += kResolveThreads) {
-    const int base = occupied(k) ? -1 : INT_MAX;
-    fcA[k] = base; fcB[k] = base; kpAssigned[k] = -1;
+    fcA[k] = occupied(k) ? -1 : INT_MAX;
+    kpAssigned[k] = -1;
   }
   __syncthreads();
   stamp(1);
-  auto claims = [&](int i) -> bool { return LDS ? ((claimBits[i >> 5] >> (i & 31)) & 1u) != 0 : R.qclaim[i] != 0; };
-  // outcome of query i against table fc: accepted keypoint or -1; `which` = 1 + position of the accepted candidate in the
-  // query's list (fast path) or -(distance) - 1 (long lists), for the callers that need the distance
-  auto eval = [&](int i, const int* fc, int& which) -> int {
-    const uint2 r = LDS ? q8[i] : pack(rec4[i]);
+  auto claims = [&](int i) -> bool { return ((claimW[i >> 5] >> (i & 31)) & 1u) != 0; };
+  auto query_word = [&](int i) -> uint2 { return LDS ? q8[i] : R.qword[i]; };
+  // outcome of query i (packed word r) against table fc: accepted keypoint or -1; `which` = 1 + position of the accepted
+  // candidate in the record, 9 + position for a wide record, -(distance) - 1 for a walked list
+  auto eval = [&](int i, const uint2 r, const int* fc, int& which) -> int {
     const uint32_t code = r.y >> 16;
-    which = 0;
-    if (code == 0u) return -1;
-    if (code != kCodeLongList) {
+    if (code < kCodeWide) {
+      // branch-free (code 0 = no candidates = outcome 0 for every pattern; unused slots hold index 0: their bit does not
+      // change the outcome)
       const int i0 = (int)(r.x & 0xffffu), i1 = (int)(r.x >> 16), i2 = (int)(r.y & 0xffffu);
-      const int f0 = fc[i0], f1 = fc[i1], f2 = fc[i2];   // unused slots hold index 0: their bit does not change the outcome
-      const unsigned p = (f0 >= i ? 1u : 0u) | (f1 >= i ? 2u : 0u) | (f2 >= i ? 4u : 0u);
-      const int o = (int)((code >> (2 * p)) & 3u);
-      which = o;
-      return o == 0 ? -1 : (o == 1 ? i0 : (o == 2 ? i1 : i2));
+      const int f0 = fc[i0], f1 = fc[i1], f2 = fc[i2];
+      const unsigned p = (f0 >= i ? 1u : 0u) + (f1 >= i ? 2u : 0u) + (f2 >= i ? 4u : 0u);
+      const unsigned o = (code >> (2u * p)) & 3u;
+      const unsigned long long pk = (unsigned long long)r.x | ((unsigned long long)(uint32_t)i2 << 32);
+      const int sel = (int)((uint32_t)(pk >> (16u * ((o + 3u) & 3u))) & 0xffffu);   // candidate o - 1 (o = 0: unused)
+      which = (int)o;
+      return o ? sel : -1;
     }
-    Best<MODE> B;                                        // list longer than the record: walk it (LDS copy, else the pool)
-    if (LDS && r.x != 0xffffffffu) {
-      const int cnt = (int)(r.y & 0xffffu);
-      const uint32_t* l = ovf + r.x;
-      for (int c = 0; c < cnt; c++) {
-        const uint32_t e = l[c];
-        B.consider(e, fc[e & 0xffff], i);
-      }
-    } else {
-      const int cnt = (int)(R.rec[(size_t)i * 4] & 0xffffu);
-      const uint32_t* g = R.pool + R.qoff[i];
-      for (int c = 0; c < cnt; c++) {
-        const uint32_t e = g[c];
-        B.consider(e, fc[e & 0xffff], i);
-      }
+    which = 0;
+    if (code == kCodeWide) {                             // four candidates: the same lookup over 16 patterns
+      const uint32_t* wr = lists + r.x;
+      const uint32_t a = wr[0], b = wr[1], lo = wr[2], hi = wr[3];
+      const int i0 = (int)(a & 0xffffu), i1 = (int)(a >> 16), i2 = (int)(b & 0xffffu), i3 = (int)(b >> 16);
+      const int f0 = fc[i0], f1 = fc[i1], f2 = fc[i2], f3 = fc[i3];
+      const unsigned p = (f0 >= i ? 1u : 0u) | (f1 >= i ? 2u : 0u) | (f2 >= i ? 4u : 0u);
+      const int o = (int)(((f3 >= i ? hi : lo) >> (3 * p)) & 7u);
+      which = o ? 8 + o : 0;
+      return o == 0 ? -1 : (o == 1 ? i0 : (o == 2 ? i1 : (o == 3 ? i2 : i3)));
+    }
+    Best<MODE> B;                                        // a longer list: walk it
+    const int cnt = (int)(r.y & 0xffffu);
+    const uint32_t* l = lists + r.x;
+    for (int c = 0; c < cnt; c++) {
+      const uint32_t e = l[c];
+      B.consider(e, fc[e & 0xffff], i);
     }
     int d;
     const int m = B.accept(R, d);
@@ -325,48 +300,113 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
   };
   auto dist_of = [&](int i, int which) -> int {
     if (which < 0) return -which - 1;
+    if (which >= 8) return (int)((R.pool[R.qoff[i] + (uint32_t)(which - 9)] >> 16) & 0x1ffu);   // wide record: entries in the pool
     return (int)((R.rec[(size_t)i * 4 + which] >> 16) & 0x1ffu);
   };
-  int* cur = fcA;     // the table the queries are evaluated against
-  int* next = fcB;    // the table their outcomes build (at its base state at the start of a round)
-  int rounds = 0;
-  for (;;) {
-    for (int i = tid; i < nq; i += kResolveThreads) {
-      int w;
-      const int m = eval(i, cur, w);
-      if (m >= 0 && claims(i)) atomicMin(&next[m], i);
-    }
+  // ---- the recurrence, chunk by chunk in query order ----------------------------------------------------------------
+  // Query i depends on queries j < i only, so once every earlier chunk is final a chunk of kResolveThreads * QPT queries
+  // settles in (longest chain inside the chunk) + 1 rounds -- two for almost every chunk at tracking radii: outcomes
+  // against the table, claims, outcomes again = unchanged.  One table: a round takes the chunk's claims of the previous
+  // round back (a claim landed iff the table word is the query's own index) and applies the new ones.
+  int* fc = fcA;
+  // block-wide OR with ONE barrier: three rotating flags (the one of this call is set, the next one cleared, the third may
+  // still be read by a wave that has not left the previous call)
+  int orPhase = 0;
+  auto block_or = [&](int v) -> int {
+    if (__ballot(v != 0) != 0ull && (tid & 63) == 0) orFlag[orPhase] = 1;
+    const int nextPhase = orPhase == 2 ? 0 : orPhase + 1;
+    if (tid == 0) orFlag[nextPhase] = 0;
     __syncthreads();
-    int changed = 0;
-    for (int k = tid; k < n; k += kResolveThreads) {
-      changed |= next[k] != cur[k];
-      cur[k] = occupied(k) ? -1 : INT_MAX;          // becomes the next round's `next`
+    const int r = orFlag[orPhase];
+    orPhase = nextPhase;
+    return r;
+  };
+  int dbgSlot = 24;
+  int rounds = 0;
+  bool serialUsed = false;
+  for (int c0 = 0; c0 < nq; c0 += kResolveThreads * QPT) {
+    int mPrev[QPT], mNew[QPT], wNew[QPT];
+    uint2 rq[QPT];        // the chunk's query words and claim flags stay in registers: a round is one dependent LDS trip
+    bool cl[QPT];
+#pragma unroll
+    for (int u = 0; u < QPT; u++) {
+      const int i = c0 + u * kResolveThreads + tid;
+      mPrev[u] = -1; mNew[u] = -1; wNew[u] = 0;
+      rq[u] = make_uint2(0u, 0u);
+      cl[u] = false;
+      if (i < nq) { rq[u] = query_word(i); cl[u] = claims(i); }
     }
-    const int any = __syncthreads_or(changed);
-    { int* t = cur; cur = next; next = t; }
-    rounds++;
-    if (!any) break;             // outcomes are a function of the table: equal tables = the fixed point
-    if (rounds >= R.maxRounds) {   // long chains of keypoints taken from later queries: one serial pass finishes
-      for (int k = tid; k < n; k += kResolveThreads) cur[k] = occupied(k) ? -1 : INT_MAX;
-      __syncthreads();
-      if (tid == 0) {
-        for (int i = 0; i < nq; i++) {
-          int w;
-          const int m = eval(i, cur, w);
-          if (m >= 0 && claims(i) && cur[m] == INT_MAX) cur[m] = i;
+    int it = 0;
+    bool serial = false;
+    for (;;) {
+      int changed = 0;
+      if (tid == 0 && dbgSlot < 60) dbgT[dbgSlot++ - 24] = (int)__builtin_readcyclecounter();
+#pragma unroll
+      for (int u = 0; u < QPT; u++) {
+        const int i = c0 + u * kResolveThreads + tid;
+        if (i < nq) {
+          mNew[u] = eval(i, rq[u], fc, wNew[u]);
+          changed |= mNew[u] != mPrev[u];
         }
       }
+      if (tid == 0 && dbgSlot < 60) dbgT[dbgSlot++ - 24] = (int)__builtin_readcyclecounter();
+      const int any = block_or(changed);
+      if (tid == 0 && dbgSlot < 60) dbgT[dbgSlot++ - 24] = (int)__builtin_readcyclecounter();
+      it++;
+      if (!any) break;                   // outcomes are a function of the table and the table of the outcomes: the fixed point
+      serial = it >= R.maxRounds;        // a long chain inside the chunk: one serial pass over it
+      if (it > 1 || serial) {
+#pragma unroll
+        for (int u = 0; u < QPT; u++) {
+          const int i = c0 + u * kResolveThreads + tid;
+          if (mPrev[u] >= 0 && cl[u] && fc[mPrev[u]] == i) fc[mPrev[u]] = INT_MAX;
+        }
+        __syncthreads();
+      }
+      if (serial) {
+        if (tid == 0) {
+          const int cEnd = min(nq, c0 + kResolveThreads * QPT);
+          for (int i = c0; i < cEnd; i++) {
+            int w;
+            const int m = eval(i, query_word(i), fc, w);
+            if (m >= 0 && claims(i) && fc[m] == INT_MAX) fc[m] = i;
+            if (LDS) q8[i] = make_uint2((uint32_t)m, (uint32_t)w);
+          }
+        }
+        __syncthreads();
+        break;
+      }
+#pragma unroll
+      for (int u = 0; u < QPT; u++) {
+        const int i = c0 + u * kResolveThreads + tid;
+        if (mNew[u] >= 0 && cl[u]) atomicMin(&fc[mNew[u]], i);
+        mPrev[u] = mNew[u];
+      }
       __syncthreads();
-      rounds = -rounds;
-      break;
     }
+    if (LDS && !serial) {                // the settled outcome replaces the query word (nobody reads that again)
+#pragma unroll
+      for (int u = 0; u < QPT; u++) {
+        const int i = c0 + u * kResolveThreads + tid;
+        if (i < nq) q8[i] = make_uint2((uint32_t)mNew[u], (uint32_t)wNew[u]);
+      }
+    }
+    serialUsed |= serial;
+    rounds = max(rounds, it);
   }
+  if (serialUsed) rounds = -rounds;
+  __syncthreads();
   stamp(2);
-  // ---- outputs: every query once more against the settled table -------------------------------------------------
+  // the settled outcome of query i: kept in LDS, or evaluated once more against the final table (global-scratch route)
+  auto outcome = [&](int i, int& which) -> int {
+    if (LDS) { const uint2 r = q8[i]; which = (int)r.y; return (int)r.x; }
+    return eval(i, query_word(i), fc, which);
+  };
+  // ---- outputs -----------------------------------------------------------------------------------------------------
   int nm = 0;
   for (int i = tid; i < nq; i += kResolveThreads) {
     int w;
-    const int m = eval(i, cur, w);
+    const int m = outcome(i, w);
     if (MODE == kModeProjected) { R.outHost[i] = m; R.outHost[nq + i] = m >= 0 ? dist_of(i, w) : -1; }
     if (m < 0) continue;
     nm++;
@@ -388,7 +428,7 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
     else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
     for (int i = tid; i < nq; i += kResolveThreads) {
       int w;
-      const int m = eval(i, cur, w);
+      const int m = outcome(i, w);
       if (m < 0) continue;
       const int b = rot_bin_dev(R.qangle[i], R.kangle[m]);
       if (b != ind1 && b != ind2 && b != ind3) { kpAssigned[m] = -2; nm--; }
@@ -401,7 +441,8 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
   for (int o = 32; o > 0; o >>= 1) nm += __shfl_xor(nm, o, 64);
   if ((tid & 63) == 0 && nm) atomicAdd(&acc[0], nm);
   __syncthreads();
-  if (tid == 0) { R.hdrHost[0] = acc[0]; R.hdrHost[2] = rounds; R.hdrHost[3] = LDS ? (ovfUsed <= ldsEntries ? 2 : 1) : 0; }
+  if (tid == 0) { R.hdrHost[0] = acc[0]; R.hdrHost[2] = rounds; R.hdrHost[3] = LDS ? (poolInLds ? 2 : 1) : 0; }
+  if (tid < 36) R.hdrHost[24 + tid] = dbgT[tid];
   stamp(3);
 }
 
@@ -527,8 +568,11 @@ int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint
   const int nq = P.nq, n = P.n;
   int rc;
   const size_t outInts = P.mode == kModeProjected ? 2 * (size_t)nq : (size_t)n;
-  const size_t oCnt = kHdr, oOff = oCnt + nq, oRec = (oOff + nq + 3) & ~(size_t)3, oFc = oRec + 4 * (size_t)nq,
-               oFlags = oFc + 3 * (size_t)n, words = oFlags + ((size_t)nq + (size_t)n + 16) / 4 + 64;
+  // device result area (ints): header | qcount[nq] | qoff[nq] | records[4 nq] | query words[2 nq] | generic tables[2 n] |
+  // claim mask, occupancy mask (64-bit words)
+  const size_t oCnt = kHdr, oOff = oCnt + nq, oRec = (oOff + nq + 3) & ~(size_t)3, oQw = oRec + 4 * (size_t)nq,
+               oFc = oQw + 2 * (size_t)nq, oFlags = (oFc + 2 * (size_t)n + 1) & ~(size_t)1,
+               claimW64 = ((size_t)nq + 63) / 64, occW64 = ((size_t)n + 63) / 64, words = oFlags + 2 * (claimW64 + occW64) + 64;
   if (m->d_r.n < words) {
     if ((rc = m->d_r.ensure(words + words / 2))) return rc;
     HIP_TRY(hipMemsetAsync(m->d_r.p, 0, kHdr * sizeof(int), st));   // a fresh allocation: the running counter starts at zero
@@ -557,7 +601,7 @@ int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint
     HIP_TRY(hipMemcpyAsync(m->d_q.p, m->h_q.p, P.oQd + 32 * (size_t)nq, hipMemcpyHostToDevice, st));
   }
   const double tB = orbfe_matcher::nowMs();
-  m->stageMs[0] = tB - tA;
+  m->stageMs[0] = tB - (m->tEntry > 0 ? m->tEntry : tA);   // query marshalling (the caller's loop) + arena set-up
   uint8_t* Dq = zeroCopy ? m->h_q.p : m->d_q.p;
   int* Dr = (int*)m->d_r.p;
   size_t poolCap = m->d_pool.n ? m->d_pool.n : std::max<size_t>(1 << 16, (size_t)nq * 32);
@@ -572,10 +616,11 @@ int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint
     M.total = (uint32_t*)(Dr + 8); M.qcount = (uint32_t*)(Dr + oCnt); M.qoff = (uint32_t*)(Dr + oOff);
     M.pool = m->d_pool.p; M.poolCap = (uint32_t)m->d_pool.n;
     M.rec = (uint32_t*)(Dr + oRec);
-    uint8_t* dClaim = (uint8_t*)(Dr + oFlags);
-    uint8_t* dOcc = dClaim + ((nq + 7) & ~7);
-    M.copySrc[0] = Dq + P.oQc; M.copyDst[0] = dClaim; M.copyN[0] = nq;
-    if (P.occ0) { M.copySrc[1] = Dq + P.oOcc; M.copyDst[1] = dOcc; M.copyN[1] = n; }
+    M.qword = (uint2*)(Dr + oQw);
+    unsigned long long* dClaim = (unsigned long long*)(Dr + oFlags);
+    unsigned long long* dOcc = dClaim + claimW64;
+    M.bitSrc[0] = Dq + P.oQc; M.bitDst[0] = dClaim; M.bitN[0] = nq;
+    if (P.occ0) { M.bitSrc[1] = Dq + P.oOcc; M.bitDst[1] = dOcc; M.bitN[1] = n; }
     M.invSigma2 = P.invSigma2 ? (const float*)(Dq + P.oSig) : nullptr;
     M.chi2 = chi2;
     M.packOctave = 1;
@@ -592,10 +637,10 @@ int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint
       else hipLaunchKernelGGL(k_window_match<64>, dim3(nblk), dim3(kWinThreads), 0, st, M);
     }
     ResolveParams R;
-    R.rec = M.rec; R.qoff = M.qoff; R.pool = M.pool; R.total = M.total; R.poolCap = M.poolCap;
+    R.qword = M.qword; R.rec = M.rec; R.qoff = M.qoff; R.pool = M.pool; R.total = M.total; R.poolCap = M.poolCap;
     R.nq = nq; R.n = n;
-    R.occ0 = P.occ0 ? dOcc : nullptr;
-    R.qclaim = dClaim; R.qangle = (const float*)(Dq + P.oQang); R.kangle = f->D.angle;
+    R.occBits = P.occ0 ? (const uint32_t*)dOcc : nullptr;
+    R.claimBits = (const uint32_t*)dClaim; R.qangle = (const float*)(Dq + P.oQang); R.kangle = f->D.angle;
     R.nnratio = nnratio; R.maxDist = maxDist; R.checkOri = checkOri;
     R.scratch = Dr + oFc;
     R.hdrHost = m->h_r.p; R.outHost = m->h_r.p + kHdr;
@@ -603,34 +648,44 @@ int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint
     R.maxRounds = mr ? std::max(1, atoi(mr)) : 48;
     // LDS-resident tables when they fit (152 KB of the CU's 160): offsets, two table generations, claim bits; what is
     // left holds the candidate entries (the kernel checks their number at run time)
-    const size_t fixedBytes = 4 * (2 * (size_t)nq + 3 * (size_t)n + 2 * (((size_t)nq + 63) >> 6) + 2 * (((size_t)n + 63) >> 6) + 8);
+    const size_t fixedBytes = 4 * (2 * (size_t)nq + 2 * (size_t)n + (((size_t)nq + 31) >> 5) + (((size_t)n + 31) >> 5) + 8);
     const size_t budget = 152 * 1024;
     const char* gen = getenv("ORBFE_RESOLVE_GENERIC");      // 1: tables in global scratch whatever the size (tests)
     const bool lds = fixedBytes <= budget && !(gen && atoi(gen) != 0);
     const int ldsEntries = lds ? (int)((budget - fixedBytes) / 4) : 0;   // room for the lists longer than a record
     const size_t dynBytes = lds ? budget : 0;
-#define ORBFE_LAUNCH_RESOLVE(MODE)                                                                                          \
+    const char* qe = getenv("ORBFE_RESOLVE_QPT");
+    const int qpt = qe ? atoi(qe) : 1;
+#define ORBFE_LAUNCH_RESOLVE_Q(MODE, Q)                                                                                     \
     do {                                                                                                                      \
       if (lds) {                                                                                                              \
-        if (!m->resolveAttr[MODE]) {                                                                                          \
-          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resolve<MODE, true>),                                   \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget));                            \
-          m->resolveAttr[MODE] = true;                                                                                        \
-        }                                                                                                                     \
-        hipLaunchKernelGGL((k_resolve<MODE, true>), dim3(1), dim3(kResolveThreads), dynBytes, st, R, ldsEntries);             \
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resolve<MODE, true, Q>),                                  \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget));                              \
+        hipLaunchKernelGGL((k_resolve<MODE, true, Q>), dim3(1), dim3(kResolveThreads), dynBytes, st, R, ldsEntries);          \
       } else {                                                                                                                \
-        hipLaunchKernelGGL((k_resolve<MODE, false>), dim3(1), dim3(kResolveThreads), 0, st, R, 0);                            \
+        hipLaunchKernelGGL((k_resolve<MODE, false, Q>), dim3(1), dim3(kResolveThreads), 0, st, R, 0);                         \
       }                                                                                                                       \
+    } while (0)
+#define ORBFE_LAUNCH_RESOLVE(MODE)                                                                                          \
+    do {                                                                                                                      \
+      if (qpt == 2) ORBFE_LAUNCH_RESOLVE_Q(MODE, 2);                                                                          \
+      else if (qpt == 4) ORBFE_LAUNCH_RESOLVE_Q(MODE, 4);                                                                     \
+      else if (qpt == 6) ORBFE_LAUNCH_RESOLVE_Q(MODE, 6);                                                                     \
+      else if (qpt == 10) ORBFE_LAUNCH_RESOLVE_Q(MODE, 10);                                                                   \
+      else ORBFE_LAUNCH_RESOLVE_Q(MODE, 1);                                                                                   \
     } while (0)
     if (P.mode == kModeMapPoints) ORBFE_LAUNCH_RESOLVE(kModeMapPoints);
     else if (P.mode == kModeUv) ORBFE_LAUNCH_RESOLVE(kModeUv);
     else ORBFE_LAUNCH_RESOLVE(kModeProjected);
+#undef ORBFE_LAUNCH_RESOLVE_Q
 #undef ORBFE_LAUNCH_RESOLVE
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));   // the kernel wrote header and result vector into page-locked host memory itself
     if (!m->h_r.p[1]) {
-      m->stageMs[1] = orbfe_matcher::nowMs() - tB;
+      m->tSynced = orbfe_matcher::nowMs();
+      m->stageMs[1] = m->tSynced - tB;
       m->stageMs[2] = 0;
+      m->tEntry = 0;
       m->lastRounds = m->h_r.p[2];
       m->lastResolveRoute = m->h_r.p[3];
       *nmatches = m->h_r.p[0];
@@ -750,6 +805,10 @@ int orbfe_frame_download(orbfe_frame* f, OrbfeKeyPoint* kps_un, uint8_t* desc, i
 
 int orbfe_debug_resolve_rounds(const orbfe_matcher* m) { return m ? m->lastRounds : 0; }
 int orbfe_debug_resolve_route(const orbfe_matcher* m) { return m ? m->lastResolveRoute : -1; }
+int orbfe_debug_resolve_raw(const orbfe_matcher* m, int out[64]) {
+  for (int k = 0; k < 64; k++) out[k] = m->h_r.p[k];
+  return 0;
+}
 int orbfe_debug_resolve_phases(const orbfe_matcher* m, int out[4]) {
   if (!m || !out || !m->h_r.p) { set_err("bad argument"); return ORBFE_ERR_INVALID; }
   for (int k = 0; k < 4; k++) out[k] = m->h_r.p[16 + k];
@@ -761,6 +820,7 @@ int orbfe_search_by_projection_frame(orbfe_matcher* m, orbfe_frame* f, const flo
                                      const uint8_t* kp_occupied, const float* mp_proj_xy, const int32_t* mp_level,
                                      const float* mp_viewcos, const uint8_t* mp_flags, const uint8_t* mp_desc, int n_mp,
                                      float th, float nnratio, int32_t* kp_assigned, int* nmatches) {
+  const double tEntry = orbfe_matcher::nowMs();
   if (!m || !f || !nmatches || n_mp < 0 || !scale_factors || (f->n && (!kp_occupied || !kp_assigned)) ||
       (n_mp && (!mp_proj_xy || !mp_level || !mp_viewcos || !mp_flags || !mp_desc))) {
     set_err("bad argument");
@@ -770,6 +830,7 @@ int orbfe_search_by_projection_frame(orbfe_matcher* m, orbfe_frame* f, const flo
   *nmatches = 0;
   for (int i = 0; i < n; i++) kp_assigned[i] = -1;
   if (n_mp == 0 || n == 0) return ORBFE_OK;
+  m->tEntry = tEntry;
   SearchPlan P;
   int rc = plan_search(m, f, kModeMapPoints, n_mp, true, 0, &P);
   if (rc) return rc;
@@ -795,6 +856,7 @@ int orbfe_search_by_projection_frame(orbfe_matcher* m, orbfe_frame* f, const flo
   const int* out = nullptr;
   if ((rc = run_search(m, f, P, mp_desc, rmax, nnratio, TH_HIGH, 0.0, 0, &out, nmatches))) return rc;
   memcpy(kp_assigned, out, sizeof(int32_t) * (size_t)n);
+  m->stageMs[2] = orbfe_matcher::nowMs() - m->tSynced;
   return ORBFE_OK;
 }
 
@@ -805,6 +867,7 @@ int orbfe_search_by_projection_uv_frame(orbfe_matcher* m, orbfe_frame* f, const 
                                         const float* src_angle, const uint8_t* src_flags, const uint8_t* src_valid,
                                         const uint8_t* src_desc, int n_src, float th, int max_dist, int skip_any_occupied,
                                         int check_orientation, int32_t* kp_assigned, int* nmatches) {
+  const double tEntry = orbfe_matcher::nowMs();
   if (!m || !f || !nmatches || n_src < 0 || !scale_factors || (f->n && (!kp_occupied || !kp_assigned)) ||
       (n_src && (!src_uv || !src_level || !src_angle || !src_flags || !src_valid || !src_desc))) {
     set_err("bad argument");
@@ -814,6 +877,7 @@ int orbfe_search_by_projection_uv_frame(orbfe_matcher* m, orbfe_frame* f, const 
   *nmatches = 0;
   for (int i = 0; i < n; i++) kp_assigned[i] = -1;
   if (n_src == 0 || n == 0) return ORBFE_OK;
+  m->tEntry = tEntry;
   SearchPlan P;
   int rc = plan_search(m, f, kModeUv, n_src, true, 0, &P);
   if (rc) return rc;
@@ -835,6 +899,7 @@ int orbfe_search_by_projection_uv_frame(orbfe_matcher* m, orbfe_frame* f, const 
   const int* out = nullptr;
   if ((rc = run_search(m, f, P, src_desc, rmax, 0.f, max_dist, 0.0, check_orientation, &out, nmatches))) return rc;
   memcpy(kp_assigned, out, sizeof(int32_t) * (size_t)n);
+  m->stageMs[2] = orbfe_matcher::nowMs() - m->tSynced;
   return ORBFE_OK;
 }
 
@@ -844,6 +909,7 @@ int orbfe_search_projected_frame(orbfe_matcher* m, orbfe_frame* f, int n_src, co
                                  const int32_t* src_level, const uint8_t* src_valid, const uint8_t* src_desc,
                                  const uint8_t* kp_skip, int claim, const float* inv_level_sigma2, int nlevels, double chi2,
                                  int max_dist, int32_t* best_idx, int32_t* best_dist, int* nmatches) {
+  const double tEntry = orbfe_matcher::nowMs();
   if (!m || !f || !nmatches || n_src < 0 ||
       (n_src && (!src_uv || !src_radius || !src_level || !src_valid || !src_desc || !best_idx)) ||
       (inv_level_sigma2 && (nlevels < 1 || nlevels > 64))) {
@@ -858,6 +924,7 @@ int orbfe_search_projected_frame(orbfe_matcher* m, orbfe_frame* f, int n_src, co
   }
   if (n_src == 0 || n == 0) return ORBFE_OK;
   if (inv_level_sigma2 && f->maxOctave >= nlevels) { set_err("keypoint octave out of range"); return ORBFE_ERR_INVALID; }
+  m->tEntry = tEntry;
   SearchPlan P;
   int rc = plan_search(m, f, kModeProjected, n_src, kp_skip != nullptr, inv_level_sigma2 ? nlevels : 0, &P);
   if (rc) return rc;

@@ -84,11 +84,14 @@ struct MatchParams {
   const float* invSigma2 = nullptr;   // Fuse's gate e2 * mvInvLevelSigma2[octave] > chi2 (ORBmatcher.cc:896-903): dropped
   double chi2 = 0.0;
   int packOctave = 0;                 // entries carry the keypoint's octave in bits 25..30
-  // two small byte arrays the single-block bookkeeping kernel needs (claim flags, occupancy) are moved from the page-locked
-  // query arena into device memory by this kernel's many blocks on the way
-  const uint8_t* copySrc[2] = {nullptr, nullptr};
-  uint8_t* copyDst[2] = {nullptr, nullptr};
-  int copyN[2] = {0, 0};
+  uint2* qword = nullptr;             // [nq] the record as the bookkeeping kernel keeps it in LDS: {idx0 | idx1 << 16, idx2 | code << 16};
+                                      // lists beyond the record: {offset in the pool (of the wide record for four candidates),
+                                      // count | kCodeWide / kCodeLongList << 16}
+  // two small byte arrays of the page-locked query arena (claim flags, occupancy) reach the single-block bookkeeping kernel
+  // as bit masks in device memory, packed by this kernel's many blocks on the way (64 flags per ballot)
+  const uint8_t* bitSrc[2] = {nullptr, nullptr};
+  unsigned long long* bitDst[2] = {nullptr, nullptr};
+  int bitN[2] = {0, 0};
 };
 
 __device__ __forceinline__ int hamming256(const uint32_t* __restrict__ a, const uint32_t q[8]) {
@@ -102,10 +105,11 @@ __device__ __forceinline__ int hamming256(const uint32_t* __restrict__ a, const 
 // mode 0: ORBmatcher::SearchByProjection(Frame&, MapPoints, th), src/ORBmatcher.cc:95-120 -- best / second best with their
 // levels, TH_HIGH, the ratio test only when both lie on the same level; modes 1, 2: best <= maxDist (:1373-1383, :376-392).
 // Entries: index | distance << 16 | octave << 25.
-__device__ __forceinline__ int outcome_of(int mode, int cnt, const uint32_t e[3], unsigned avail, float nnratio, int maxDist) {
+template <int NC>
+__device__ __forceinline__ int outcome_of(int mode, int cnt, const uint32_t e[NC], unsigned avail, float nnratio, int maxDist) {
   int bestDist = mode == 2 ? INT_MAX : 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, best = -1;
 #pragma unroll
-  for (int c = 0; c < 3; c++) {
+  for (int c = 0; c < NC; c++) {
     if (c >= cnt || !((avail >> c) & 1u)) continue;
     const int dist = (int)((e[c] >> 16) & 0x1ff), oct = (int)(e[c] >> 25);
     if (mode == 0) {
@@ -128,10 +132,21 @@ __device__ __forceinline__ uint32_t decision_code(int mode, int cnt, const uint3
   uint32_t code = 0;
   const unsigned mask = (1u << cnt) - 1u;
 #pragma unroll
-  for (unsigned p = 1; p < 8; p++) code |= (uint32_t)outcome_of(mode, cnt, e, p & mask, nnratio, maxDist) << (2 * p);
+  for (unsigned p = 1; p < 8; p++) code |= (uint32_t)outcome_of<3>(mode, cnt, e, p & mask, nnratio, maxDist) << (2 * p);
   return code;
 }
+// lists of exactly four candidates: 16 x 3 bits, patterns 0..7 in the first word, 8..15 in the second
+__device__ __forceinline__ uint2 decision_code4(int mode, const uint32_t e[4], float nnratio, int maxDist) {
+  uint32_t lo = 0, hi = 0;
+#pragma unroll
+  for (unsigned p = 1; p < 8; p++) lo |= (uint32_t)outcome_of<4>(mode, 4, e, p, nnratio, maxDist) << (3 * p);
+#pragma unroll
+  for (unsigned p = 8; p < 16; p++) hi |= (uint32_t)outcome_of<4>(mode, 4, e, p, nnratio, maxDist) << (3 * (p - 8));
+  return make_uint2(lo, hi);
+}
 constexpr uint32_t kCodeLongList = 0xffffu;   // (field 0 of a real code is always 0) the list is longer than the record: read the pool
+constexpr uint32_t kCodeWide = 0xfffeu;       // four candidates: the pool holds the entries and, behind them, a four-word wide record
+                                              // {idx0 | idx1 << 16, idx2 | idx3 << 16, decision_code4}
 
 // LPQ lanes per query (64/LPQ queries per wave), one LANE per grid column of the window.  Window
 // semantics: Frame::GetFeaturesInArea, Frame.cc:209-262: columns ix ascending, rows iy ascending inside a
@@ -144,18 +159,23 @@ constexpr uint32_t kCodeLongList = 0xffffu;   // (field 0 of a real code is alwa
 // same-address atomics with return (one per query) serialise in the L2 and took longer than the search itself.
 constexpr int kWinThreads = 256;
 constexpr int kRecEntries = 3;
+constexpr int kTmpEntries = 4;   // lists gathered in LDS: those of the record, and the four-candidate lists for their wide record
 template <int LPQ>
 __global__ __launch_bounds__(kWinThreads) void k_window_match(MatchParams M) {
   __shared__ uint32_t wtot[kWinThreads / 64];
   __shared__ uint32_t blockBase;
-  __shared__ uint32_t recTmp[(kWinThreads / LPQ) * kRecEntries];   // short lists gathered per query (resident-frame searches)
+  __shared__ uint32_t recTmp[(kWinThreads / LPQ) * kTmpEntries];   // short lists gathered per query (resident-frame searches)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane & (LPQ - 1);
   const int q = blockIdx.x * (kWinThreads / LPQ) + threadIdx.x / LPQ;
   const bool live = q < M.nq;
 #pragma unroll
   for (int c = 0; c < 2; c++)
-    for (int g = blockIdx.x * kWinThreads + threadIdx.x; g < M.copyN[c]; g += gridDim.x * kWinThreads) M.copyDst[c][g] = M.copySrc[c][g];
+    for (int g0 = blockIdx.x * kWinThreads + wave * 64; g0 < M.bitN[c]; g0 += gridDim.x * kWinThreads) {
+      const int g = g0 + lane;
+      const unsigned long long bits = __ballot(g < M.bitN[c] && M.bitSrc[c][g] != 0);
+      if (lane == 0) M.bitDst[c][g0 >> 6] = bits;
+    }
   float r = -1.f, x = 0.f, y = 0.f;
   int minL = 0, maxL = -1;
   PairInfo pi = M.pairs[0];
@@ -237,8 +257,9 @@ __global__ __launch_bounds__(kWinThreads) void k_window_match(MatchParams M) {
   // a resident-frame search keeps lists of up to kRecEntries candidates in the query's fixed 16-byte record (no pool space,
   // no offset to chase); longer lists go to the pool like every list of the host-resolved searches
   const bool inRec = M.rec != nullptr && count <= (uint32_t)kRecEntries;
+  const bool wide = M.rec != nullptr && count == 4u;   // four candidates: entries to the pool AND (via LDS) a wide record behind them
   // offsets: exclusive scan of the queries' counts inside the wave, of the wave totals inside the block, one atomic
-  const uint32_t mine = (live && sub == 0 && !inRec) ? count : 0u;
+  const uint32_t mine = (live && sub == 0 && !inRec) ? (wide ? 8u : count) : 0u;
   uint32_t wincl = mine;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -275,8 +296,8 @@ __global__ __launch_bounds__(kWinThreads) void k_window_match(MatchParams M) {
                   __popc(d1.y ^ qd[5]) + __popc(d1.z ^ qd[6]) + __popc(d1.w ^ qd[7]);
     uint32_t entry = (uint32_t)idx | ((uint32_t)d << 16);
     if (M.packOctave) entry |= (uint32_t)oct << 25;
-    if (inRec) recTmp[qlocal * kRecEntries + pos] = entry;
-    else if (off + pos < M.poolCap) M.pool[off + pos] = entry;
+    if (inRec || wide) recTmp[qlocal * kTmpEntries + pos] = entry;
+    if (!inRec && off + pos < M.poolCap) M.pool[off + pos] = entry;
     pos++;
   };
   const uint4* td4 = reinterpret_cast<const uint4*>(tdesc);   // descriptors are grid-sorted, 32-byte rows
@@ -305,10 +326,25 @@ __global__ __launch_bounds__(kWinThreads) void k_window_match(MatchParams M) {
       uint32_t code = kCodeLongList;
       if (inRec) {
 #pragma unroll
-        for (int c = 0; c < kRecEntries; c++) e3[c] = (uint32_t)c < count ? recTmp[qlocal * kRecEntries + c] : 0u;
+        for (int c = 0; c < kRecEntries; c++) e3[c] = (uint32_t)c < count ? recTmp[qlocal * kTmpEntries + c] : 0u;
         code = decision_code(M.codeMode, (int)count, e3, M.nnratio, M.maxDist);
+      } else if (wide) {
+        uint32_t e4[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) e4[c] = recTmp[qlocal * kTmpEntries + c];
+        const uint2 c4 = decision_code4(M.codeMode, e4, M.nnratio, M.maxDist);
+        if (off + 8u <= M.poolCap) {
+          M.pool[off + 4] = (e4[0] & 0xffffu) | (e4[1] << 16);
+          M.pool[off + 5] = (e4[2] & 0xffffu) | (e4[3] << 16);
+          M.pool[off + 6] = c4.x;
+          M.pool[off + 7] = c4.y;
+        }
+        code = kCodeWide;
       }
       reinterpret_cast<uint4*>(M.rec)[q] = make_uint4(count | (code << 16), e3[0], e3[1], e3[2]);
+      if (M.qword)
+        M.qword[q] = inRec ? make_uint2((e3[0] & 0xffffu) | (e3[1] << 16), (e3[2] & 0xffffu) | ((count ? code : 0u) << 16))
+                           : make_uint2(wide ? off + 4u : off, count | (code << 16));
     }
   }
 }
@@ -386,6 +422,7 @@ struct orbfe_matcher {
   const uint32_t* qcount = nullptr;
   const uint32_t* qoff = nullptr;
 
+  double tEntry = 0, tSynced = 0;   // frame searches: clock at the entry of the C call / when the results were seen
   double stageMs[4] = {0, 0, 0, 0};  // arena build, upload+kernel+download, (resolve: filled by callers), total
   static double nowMs() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
