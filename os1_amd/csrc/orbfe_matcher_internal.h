@@ -92,6 +92,20 @@ struct MatchParams {
   const uint8_t* bitSrc[2] = {nullptr, nullptr};
   unsigned long long* bitDst[2] = {nullptr, nullptr};
   int bitN[2] = {0, 0};
+  uint8_t bitMask[2] = {0xff, 0xff};  // flag = (byte & mask) != 0
+  int bitConst[2] = {-1, -1};         // >= 0: no source array, every flag has this value
+  // raw queries: the kernel derives window and level range from the caller's own arrays (read in place when they are
+  // page-locked) instead of from marshalled qx / qy / qr / qminL / qmaxL
+  int rawKind = 0;                    // 0 marshalled; 1 SearchByProjection(F, MapPoints, th) (ORBmatcher.cc:55-73, 126-132);
+                                      // 2 SearchByProjection(F, LastFrame / KeyFrame) from the projection on (:1353-1356, :1483-1485);
+                                      // 3 the projected loops (radius given)
+  const float* rawXY = nullptr;       // [nq][2]
+  const int* rawLevel = nullptr;      // [nq]
+  const float* rawAux = nullptr;      // kind 1: mTrackViewCos; kind 3: radius
+  const uint8_t* rawFlags = nullptr;  // kind 1: ORBFE_MP_* bits; kinds 2, 3: valid
+  const float* rawSf = nullptr;       // [32] mvScaleFactors in device memory
+  float rawTh = 1.f;
+  int rawFactor = 0;                  // kind 1: th != 1.0 (ORBmatcher.cc:49, 67-68)
 };
 
 __device__ __forceinline__ int hamming256(const uint32_t* __restrict__ a, const uint32_t q[8]) {
@@ -173,13 +187,32 @@ __global__ __launch_bounds__(kWinThreads) void k_window_match(MatchParams M) {
   for (int c = 0; c < 2; c++)
     for (int g0 = blockIdx.x * kWinThreads + wave * 64; g0 < M.bitN[c]; g0 += gridDim.x * kWinThreads) {
       const int g = g0 + lane;
-      const unsigned long long bits = __ballot(g < M.bitN[c] && M.bitSrc[c][g] != 0);
+      const unsigned long long bits =
+          M.bitConst[c] >= 0 ? (M.bitConst[c] ? ~0ull : 0ull) : __ballot(g < M.bitN[c] && (M.bitSrc[c][g] & M.bitMask[c]) != 0);
       if (lane == 0) M.bitDst[c][g0 >> 6] = bits;
     }
   float r = -1.f, x = 0.f, y = 0.f;
   int minL = 0, maxL = -1;
   PairInfo pi = M.pairs[0];
-  if (live) {
+  if (live && M.rawKind) {
+    const float2 p = reinterpret_cast<const float2*>(M.rawXY)[q];
+    const int lvl = M.rawLevel[q];
+    const unsigned fl = M.rawFlags[q];
+    x = p.x; y = p.y;
+    minL = lvl - 1;
+    if (M.rawKind == 1) {
+      maxL = lvl;                                      // GetFeaturesInArea(x, y, r * scale, nPredictedLevel - 1, nPredictedLevel)
+      float rr = (fl & ORBFE_MP_CANDIDATO) ? 4.0f : ((double)M.rawAux[q] > 0.998 ? 2.5f : 4.0f);   // RadiusByViewingCos
+      if (M.rawFactor) rr *= M.rawTh;
+      r = ((fl & ORBFE_MP_IN_VIEW) && !(fl & ORBFE_MP_BAD)) ? rr * M.rawSf[lvl & 31] : -1.f;
+    } else if (M.rawKind == 2) {
+      maxL = lvl + 1;                                  // GetFeaturesInArea(u, v, radius, nLastOctave - 1, nLastOctave + 1)
+      r = fl ? M.rawTh * M.rawSf[lvl & 31] : -1.f;
+    } else {
+      maxL = lvl;
+      r = (fl && lvl >= 0) ? M.rawAux[q] : -1.f;       // no octave lies in [level - 1, level] for level < 0
+    }
+  } else if (live) {
     r = M.qr[q]; x = M.qx[q]; y = M.qy[q]; minL = M.qminL[q]; maxL = M.qmaxL[q];
     pi = M.pairs[M.qpair ? M.qpair[q] : 0];   // qpair == nullptr: every query searches pair 0 (a resident frame)
   }
@@ -407,7 +440,7 @@ struct orbfe_matcher {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
     orbfe_frame_destroy(scratch);
-    d_q.release(); h_q.release(); d_r.release(); h_r.release();
+    d_q.release(); h_q.release(); d_r.release(); h_r.release(); d_sf.release();
     d_in.release(); h_in.release(); d_out.release(); h_out.release(); d_pool.release(); h_pool.release();
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -422,6 +455,10 @@ struct orbfe_matcher {
   const uint32_t* qcount = nullptr;
   const uint32_t* qoff = nullptr;
 
+  DevBuf<float> d_sf;            // raw queries: mvScaleFactors in device memory (and the host copy they were made from)
+  float sfHost[32] = {};
+  int sfN = -1;
+  int seq = 0;                   // number of the last frame search (k_resolve reports it back through page-locked memory)
   double tEntry = 0, tSynced = 0;   // frame searches: clock at the entry of the C call / when the results were seen
   double stageMs[4] = {0, 0, 0, 0};  // arena build, upload+kernel+download, (resolve: filled by callers), total
   static double nowMs() {

@@ -63,7 +63,9 @@ def _routes(api, m, ex, k, d, bounds, monkeypatch, xy_un=None):
     """(name, first-argument factory) per call form; `ex` has just extracted (k, d) as frame 0 of its last batch."""
     fr_host = api.Frame.from_host(m, k, d, bounds)
     fr_ex = api.Frame.from_extract(ex, 0, bounds, xy_un)
-    return [('host', k, None), ('hostres', k, '1'), ('frame', fr_host, None), ('extract', fr_ex, None)]
+    return [('host', k, None), ('hostres', k, ('ORBFE_MATCH_HOST_RESOLVE', '1')), ('frame', fr_host, None), ('extract', fr_ex, None),
+            # marshalled query arrays + an upload instead of raw arrays read in place by the window kernel
+            ('upload', fr_host, ('ORBFE_FRAME_ZEROCOPY', '0'))]
 
 
 def test_frame_content_and_grid(api, oracle):
@@ -136,7 +138,7 @@ def test_search_by_projection_all_call_forms(api, oracle, monkeypatch):
     occ = (rng.random(len(k)) < 0.1).astype(np.uint8)
     for name, first, env in _routes(api, m, ex, k, d, bounds, monkeypatch):
         if env:
-            monkeypatch.setenv('ORBFE_MATCH_HOST_RESOLVE', env)
+            monkeypatch.setenv(*env)
         for th, ratio in [(1.0, 0.8), (5.0, 0.8), (3.0, 0.6), (12.0, 0.9)]:
             n, a = m.search_by_projection(first, d, bounds, sf, occ, xy, level, viewcos, flags, mdesc, th, ratio)
             on, oa = oracle.search_by_projection(k, d, bounds, sf, occ, xy, level, viewcos, flags, mdesc, th, ratio)
@@ -145,7 +147,28 @@ def test_search_by_projection_all_call_forms(api, oracle, monkeypatch):
         n, a = m.search_by_projection(first, d, bounds, sf, occ, xy[:0], level[:0], viewcos[:0], flags[:0], mdesc[:0], 1.0, 0.8)
         assert n == 0 and (a == -1).all()
         if env:
-            monkeypatch.delenv('ORBFE_MATCH_HOST_RESOLVE')
+            monkeypatch.delenv(env[0])
+    # every input array page-locked: the window kernel reads them where they are, nothing is staged
+    arrays = (occ, xy, level.astype(np.int32), viewcos.astype(np.float32), flags, mdesc)
+    pins = [api.PinnedArray(a.shape, a.dtype) for a in arrays]
+    for p_, a_ in zip(pins, arrays):
+        p_.a[...] = a_
+    fr = api.Frame.from_host(m, k, d, bounds)
+    for th in (1.0, 5.0):
+        n, a = m.search_by_projection(fr, d, bounds, sf, *[p_.a for p_ in pins], th, 0.8)
+        on, oa = oracle.search_by_projection(k, d, bounds, sf, occ, xy, level, viewcos, flags, mdesc, th, 0.8)
+        assert n == on and (a == oa).all(), th
+    # an out-of-range level is an error only on an active MapPoint (ORBmatcher.cc:55-61 skips the others before using it)
+    lv = level.astype(np.int32).copy()
+    lv[7] = 99
+    fl = flags.copy()
+    fl[7] = 0
+    n, a = m.search_by_projection(fr, d, bounds, sf, occ, xy, lv, viewcos, fl, mdesc, 1.0, 0.8)
+    on, oa = oracle.search_by_projection(k, d, bounds, sf, occ, xy, np.where(np.arange(len(lv)) == 7, 0, lv), viewcos, fl, mdesc, 1.0, 0.8)
+    assert n == on and (a == oa).all()
+    fl[7] = 1
+    with pytest.raises(api.OrbfeError):
+        m.search_by_projection(fr, d, bounds, sf, occ, xy, lv, viewcos, fl, mdesc, 1.0, 0.8)
 
 
 def test_search_by_projection_uv_and_projected_all_call_forms(api, oracle, monkeypatch):
@@ -177,7 +200,7 @@ def test_search_by_projection_uv_and_projected_all_call_forms(api, oracle, monke
     total = 0
     for name, first, env in _routes(api, m, ex, k2, d2, bounds, monkeypatch):
         if env:
-            monkeypatch.setenv('ORBFE_MATCH_HOST_RESOLVE', env)
+            monkeypatch.setenv(*env)
         for th, maxd, skip_any, ori in [(15.0, 100, 0, True), (30.0, 100, 0, False), (10.0, 64, 1, True), (3.0, 100, 1, True),
                                         (60.0, 100, 0, True)]:
             n, a = m.search_by_projection_uv(first, d2, bounds, sf, occ, uv, k1['octave'], k1['angle'], sflags, valid, d1,
@@ -196,7 +219,7 @@ def test_search_by_projection_uv_and_projected_all_call_forms(api, oracle, monke
             assert got[0] == want[0] and got[1].tobytes() == want[1].tobytes() and got[2].tobytes() == want[2].tobytes(), (name, th)
             total += got[0]
         if env:
-            monkeypatch.delenv('ORBFE_MATCH_HOST_RESOLVE')
+            monkeypatch.delenv(env[0])
     assert total > 20000
 
 

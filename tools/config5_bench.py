@@ -66,12 +66,23 @@ assigned = np.full(len(k), -1, np.int32)
 nmat = C.c_int(0)
 P = lambda a: a.ctypes.data_as(C.c_void_p)
 sfa = np.ascontiguousarray(sf, np.float32)
+th_c = {1.0: C.c_float(1.0), 5.0: C.c_float(5.0)}
+
+
+# the argument list is converted once: a C++ caller passes plain pointers, ctypes' per-call conversions (about 1 us per array) are
+# not part of the library
+_fixed = {}
 
 
 def c_call(th, rows):
-    rc = m.L.orbfe_search_by_projection_frame(m.h, fr.h, P(sfa), len(sfa), P(occ), P(mxy), P(level), P(viewcos), P(flags), P(rows),
-                                              n_mp, th, 0.8, P(assigned), C.byref(nmat))
+    key = id(rows)
+    if key not in _fixed:
+        _fixed[key] = (m.h, fr.h, P(sfa), len(sfa), P(occ), P(mxy), P(level), P(viewcos), P(flags), P(rows), n_mp)
+    rc = m.L.orbfe_search_by_projection_frame(*_fixed[key], th, 0.8, _out[0], _out[1])
     assert rc == 0
+
+
+_out = (P(assigned), C.byref(nmat))
 
 
 for th in (1.0, 5.0):
