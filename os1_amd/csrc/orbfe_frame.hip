@@ -237,7 +237,14 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
   auto occupied = [&](int k) -> bool { return R.occBits && ((occW[k >> 5] >> (k & 31)) & 1u) != 0; };
   if (LDS) {
     // straight copies, every load independent of every other (and of the counter's): query words, flag masks
-    for (int i = tid; i < nq; i += kResolveThreads) q8[i] = R.qword[i];
+    for (int i0 = tid; i0 < nq; i0 += 8 * kResolveThreads) {   // eight loads in flight per thread before the first LDS store
+      uint2 w[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) w[u] = R.qword[min(i0 + u * kResolveThreads, nq - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (i0 + u * kResolveThreads < nq) q8[i0 + u * kResolveThreads] = w[u];
+    }
     for (int w = tid; w < claimWords; w += kResolveThreads) claimL[w] = R.claimBits[w];
     if (R.occBits)
       for (int w = tid; w < occWords; w += kResolveThreads) occL[w] = R.occBits[w];
@@ -362,7 +369,8 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
 #pragma unroll
         for (int u = 0; u < QPT; u++) {
           const int i = c0 + u * kResolveThreads + tid;
-          if (mPrev[u] >= 0 && cl[u] && fc[mPrev[u]] == i) fc[mPrev[u]] = INT_MAX;
+          // (an unchanged query keeps its claim; the serial pass starts from the earlier chunks' claims only)
+          if (mPrev[u] >= 0 && (serial || mPrev[u] != mNew[u]) && cl[u] && fc[mPrev[u]] == i) fc[mPrev[u]] = INT_MAX;
         }
         __syncthreads();
       }
@@ -640,7 +648,8 @@ int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint
   if (f->ready && hipStreamWaitEvent(st, f->ready, 0) != hipSuccess) (void)hipGetLastError();   // (the recording stream is gone: the build is complete)
   // queries: one copy for the scalar arrays; descriptor rows straight from the caller's memory when it is page-locked
   hipPointerAttribute_t attr;
-  const bool pinned = qdescHost && hipPointerGetAttributes(&attr, qdescHost) == hipSuccess && attr.type == hipMemoryTypeHost;
+  const bool pinned = qdescHost && ((uintptr_t)qdescHost & 15u) == 0 &&   // (the kernel fetches rows as two 16-byte words)
+                      hipPointerGetAttributes(&attr, qdescHost) == hipSuccess && attr.type == hipMemoryTypeHost;
   if (!pinned) (void)hipGetLastError();
   // No upload command at all by default: the kernels read the page-locked query arena (and the caller's page-locked
   // descriptor rows) over PCIe themselves -- every query word is read once, and a DMA in front of the first kernel costs its

@@ -141,23 +141,9 @@ __device__ __forceinline__ int outcome_of(int mode, int cnt, const uint32_t e[NC
   }
   return best + 1;
 }
-// 8 x 2 bits: field p = outcome when exactly the candidates of bit pattern p are available (bits beyond cnt do not matter)
-__device__ __forceinline__ uint32_t decision_code(int mode, int cnt, const uint32_t e[3], float nnratio, int maxDist) {
-  uint32_t code = 0;
-  const unsigned mask = (1u << cnt) - 1u;
-#pragma unroll
-  for (unsigned p = 1; p < 8; p++) code |= (uint32_t)outcome_of<3>(mode, cnt, e, p & mask, nnratio, maxDist) << (2 * p);
-  return code;
-}
-// lists of exactly four candidates: 16 x 3 bits, patterns 0..7 in the first word, 8..15 in the second
-__device__ __forceinline__ uint2 decision_code4(int mode, const uint32_t e[4], float nnratio, int maxDist) {
-  uint32_t lo = 0, hi = 0;
-#pragma unroll
-  for (unsigned p = 1; p < 8; p++) lo |= (uint32_t)outcome_of<4>(mode, 4, e, p, nnratio, maxDist) << (3 * p);
-#pragma unroll
-  for (unsigned p = 8; p < 16; p++) hi |= (uint32_t)outcome_of<4>(mode, 4, e, p, nnratio, maxDist) << (3 * (p - 8));
-  return make_uint2(lo, hi);
-}
+// Decision codes.  Record (up to three candidates): 8 x 2 bits, field p = outcome when exactly the candidates of bit pattern p
+// are available (bits beyond the count do not matter).  Wide record (exactly four candidates): 16 x 3 bits, patterns 0..7 in the
+// first word, 8..15 in the second.  Field 0 is always 0 (nothing available: no match).
 constexpr uint32_t kCodeLongList = 0xffffu;   // (field 0 of a real code is always 0) the list is longer than the record: read the pool
 constexpr uint32_t kCodeWide = 0xfffeu;       // four candidates: the pool holds the entries and, behind them, a four-word wide record
                                               // {idx0 | idx1 << 16, idx2 | idx3 << 16, decision_code4}
@@ -229,6 +215,14 @@ __global__ __launch_bounds__(kWinThreads) void k_window_match(MatchParams M) {
     cy0 = max(0, (int)floorf((y - pi.minY - r) * pi.invH));
     cy1 = min(kGridRows - 1, (int)ceilf((y - pi.minY + r) * pi.invH));
     if (cx0 >= kGridCols || cx1 < 0 || cy0 >= kGridRows || cy1 < 0) cx1 = cx0 - 1;  // empty window
+  }
+  // the query's descriptor is fetched now, with the window still unknown: it may come over PCIe (page-locked rows read in
+  // place), and that round trip then overlaps the walk of the grid instead of following it
+  uint32_t qd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (live && r >= 0.f) {
+    const uint4* qp = reinterpret_cast<const uint4*>(M.qdesc + (size_t)q * 32);
+    const uint4 a = qp[0], b4 = qp[1];
+    qd[0] = a.x; qd[1] = a.y; qd[2] = a.z; qd[3] = a.w; qd[4] = b4.x; qd[5] = b4.y; qd[6] = b4.z; qd[7] = b4.w;
   }
   const bool checkLevels = (minL > 0) || (maxL >= 0);
   const int ix = cx0 + sub;
@@ -316,12 +310,6 @@ __global__ __launch_bounds__(kWinThreads) void k_window_match(MatchParams M) {
   off = __shfl(off, 0, LPQ);
   if (hits == 0 && !M.rec) return;
   const int qlocal = threadIdx.x / LPQ;
-  uint32_t qd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (hits) {
-    const uint32_t* qp = reinterpret_cast<const uint32_t*>(M.qdesc + (size_t)q * 32);
-#pragma unroll
-    for (int i = 0; i < 8; i++) qd[i] = qp[i];
-  }
   // pass 2: distances, written at the lane's position in column order; the hits of the mask are fetched two at a time
   uint32_t pos = (uint32_t)(incl - hits);   // position inside the query's list
   auto emit = [&](int e, int idx, int oct, const uint4& d0, const uint4& d1) {
@@ -351,33 +339,47 @@ __global__ __launch_bounds__(kWinThreads) void k_window_match(MatchParams M) {
     emit(e, sidx[e], soct[e], td4[(size_t)e * 2], td4[(size_t)e * 2 + 1]);
   }
   if (M.rec) {
-    // the query's record: its lanes' entries meet in LDS (a query's lanes are one wave's: a wave-level fence is enough),
-    // lane 0 of the group tabulates the outcomes and writes the 16 bytes at once
+    // the query's record: its lanes' entries meet in LDS (a query's lanes are one wave's: a wave-level fence is enough).
+    // The outcomes are tabulated by the group's first eight lanes, ONE availability pattern each (two for a wide record),
+    // and OR-ed together by three shuffles; lane 0 writes the 16 bytes at once.
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (live && sub == 0) {
-      uint32_t e3[3] = {0u, 0u, 0u};
-      uint32_t code = kCodeLongList;
-      if (inRec) {
+    if (live && (inRec || wide)) {
+      uint32_t e4[4];
 #pragma unroll
-        for (int c = 0; c < kRecEntries; c++) e3[c] = (uint32_t)c < count ? recTmp[qlocal * kTmpEntries + c] : 0u;
-        code = decision_code(M.codeMode, (int)count, e3, M.nnratio, M.maxDist);
-      } else if (wide) {
-        uint32_t e4[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) e4[c] = recTmp[qlocal * kTmpEntries + c];
-        const uint2 c4 = decision_code4(M.codeMode, e4, M.nnratio, M.maxDist);
-        if (off + 8u <= M.poolCap) {
-          M.pool[off + 4] = (e4[0] & 0xffffu) | (e4[1] << 16);
-          M.pool[off + 5] = (e4[2] & 0xffffu) | (e4[3] << 16);
-          M.pool[off + 6] = c4.x;
-          M.pool[off + 7] = c4.y;
+      for (int c = 0; c < 4; c++) e4[c] = (uint32_t)c < count ? recTmp[qlocal * kTmpEntries + c] : 0u;
+      const unsigned p = (unsigned)sub & 7u;
+      uint32_t lo = 0u, hi = 0u;
+      if (sub < 8) {
+        if (inRec) {
+          if (p) lo = (uint32_t)outcome_of<3>(M.codeMode, (int)count, e4, p & ((1u << count) - 1u), M.nnratio, M.maxDist) << (2u * p);
+        } else {
+          if (p) lo = (uint32_t)outcome_of<4>(M.codeMode, 4, e4, p, M.nnratio, M.maxDist) << (3u * p);
+          hi = (uint32_t)outcome_of<4>(M.codeMode, 4, e4, p + 8u, M.nnratio, M.maxDist) << (3u * p);
         }
-        code = kCodeWide;
       }
-      reinterpret_cast<uint4*>(M.rec)[q] = make_uint4(count | (code << 16), e3[0], e3[1], e3[2]);
-      if (M.qword)
-        M.qword[q] = inRec ? make_uint2((e3[0] & 0xffffu) | (e3[1] << 16), (e3[2] & 0xffffu) | ((count ? code : 0u) << 16))
-                           : make_uint2(wide ? off + 4u : off, count | (code << 16));
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) {
+        lo |= (uint32_t)__shfl_xor((int)lo, o, LPQ);
+        hi |= (uint32_t)__shfl_xor((int)hi, o, LPQ);
+      }
+      if (sub == 0) {
+        if (inRec) {
+          reinterpret_cast<uint4*>(M.rec)[q] = make_uint4(count | (lo << 16), e4[0], e4[1], e4[2]);
+          if (M.qword) M.qword[q] = make_uint2((e4[0] & 0xffffu) | (e4[1] << 16), (e4[2] & 0xffffu) | (lo << 16));
+        } else {
+          if (off + 8u <= M.poolCap) {
+            M.pool[off + 4] = (e4[0] & 0xffffu) | (e4[1] << 16);
+            M.pool[off + 5] = (e4[2] & 0xffffu) | (e4[3] << 16);
+            M.pool[off + 6] = lo;
+            M.pool[off + 7] = hi;
+          }
+          reinterpret_cast<uint4*>(M.rec)[q] = make_uint4(count | (kCodeWide << 16), 0u, 0u, 0u);
+          if (M.qword) M.qword[q] = make_uint2(off + 4u, count | (kCodeWide << 16));
+        }
+      }
+    } else if (live && sub == 0) {
+      reinterpret_cast<uint4*>(M.rec)[q] = make_uint4(count | (kCodeLongList << 16), 0u, 0u, 0u);
+      if (M.qword) M.qword[q] = make_uint2(off, count | (kCodeLongList << 16));
     }
   }
 }
