@@ -449,7 +449,9 @@ def tracking_step_leg(api, device, frames, W, H, wl):
     """The front end of ONE tracked frame as Tracking.cc drives it (Frame.cc:133, Tracking.cc:608, 824), blocking calls, outside
     the timed region: ORBextractor::operator() on a page-locked host frame -> the frame's features stay on the GPU
     (orbfe_frame_create_from_extract) -> SearchByProjection(CurrentFrame, LastFrame, th) with the last frame's keypoints as
-    sources -> SearchByProjection(CurrentFrame, local MapPoints, th) with 3 000 MapPoints.  Median ms per stage over 60 frames."""
+    sources (their descriptors stand in for the MapPoints' descriptors; handed over from host memory, as include/orbfe/orb_shim.hpp
+    does, and -- second figure -- read from device memory, the rows of the last frame's resident copy) -> SearchByProjection(
+    CurrentFrame, local MapPoints, th) with 3 000 MapPoints.  Median ms per stage over 60 frames."""
     import ctypes as C
     import numpy as np
     nfr = 61
@@ -461,8 +463,9 @@ def tracking_step_leg(api, device, frames, W, H, wl):
     kbuf = np.zeros((1, ex.cap), api.KP_DTYPE)
     dbuf = np.zeros((1, ex.cap, 32), np.uint8)
     rng = np.random.default_rng(3)
-    t_ex, t_fr, t_ff, t_mp, nm1, nm2 = [], [], [], [], [], []
+    t_ex, t_fr, t_ff, t_ffd, t_mp, nm1, nm2 = [], [], [], [], [], [], []
     prev = None
+    prev_fr = None
     for i in range(nfr):
         t0 = time.perf_counter()
         _, _, n = ex.extract_batch_ptrs([pin.ptrs[i]], H, W, W, False, kbuf, dbuf)
@@ -476,9 +479,14 @@ def tracking_step_leg(api, device, frames, W, H, wl):
             valid = np.ones(len(pk), np.uint8)
             sflags = np.full(len(pk), 8, np.uint8)
             occ = np.zeros(len(k), np.uint8)
+            rows = prev_fr.descriptors_device()
             t3 = time.perf_counter()
             a = m.search_by_projection_uv(fr, None, None, sf, occ, uv, pk['octave'], pk['angle'], sflags, valid, pd, 15.0, 100, 0, True)
             t4 = time.perf_counter()
+            a2 = m.search_by_projection_uv(fr, None, None, sf, occ, uv, pk['octave'], pk['angle'], sflags, valid, rows, 15.0, 100, 0, True)
+            t_ffd.append(time.perf_counter() - t4)
+            if a2[0] != a[0] or not (a2[1] == a[1]).all():
+                raise SystemExit('bench: device-resident and host descriptor rows disagree')
             src = rng.integers(0, len(k), 3000)
             mxy = (np.stack([k['x'][src], k['y'][src]], 1) + rng.uniform(-2, 2, (3000, 2))).astype(np.float32)
             lvl = k['octave'][src].astype(np.int32)
@@ -492,10 +500,13 @@ def tracking_step_leg(api, device, frames, W, H, wl):
             t_ex.append(t1 - t0); t_fr.append(t2 - t1); t_ff.append(t4 - t3); t_mp.append(t6 - t5)
             nm1.append(a[0]); nm2.append(b[0])
         prev = (k, d)
-        fr.close()
+        if prev_fr is not None:
+            prev_fr.close()
+        prev_fr = fr
+    prev_fr.close()
     pin.free()
     med = lambda v: round(float(np.median(v)) * 1e3, 4)
-    return {'extract_host_frame_ms': med(t_ex), 'resident_frame_from_extract_ms': med(t_fr), 'search_by_projection_last_frame_ms': med(t_ff),
+    return {'extract_host_frame_ms': med(t_ex), 'resident_frame_from_extract_ms': med(t_fr), 'search_by_projection_last_frame_ms': med(t_ff), 'search_by_projection_last_frame_device_rows_ms': med(t_ffd),
             'search_by_projection_mappoints_ms': med(t_mp), 'front_end_total_ms': round(med(t_ex) + med(t_fr) + med(t_ff) + med(t_mp), 4),
             'matches_last_frame_median': int(np.median(nm1)), 'matches_mappoints_median': int(np.median(nm2)),
             'note': '1080p / 2000 features, 60 frames; the search timings include the Python marshalling of the test harness (about 0.02 ms per call)'}

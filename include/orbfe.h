@@ -404,6 +404,11 @@ int orbfe_frame_create_from_extract(orbfe_extractor* h, int frame_index, const f
                                     orbfe_frame** out);
 void orbfe_frame_destroy(orbfe_frame* f);
 int orbfe_frame_size(const orbfe_frame* f);
+/* The frame's descriptor rows [n][32] in DEVICE memory, keypoint order; valid while the frame lives.  Returns when the
+ * rows are complete.  Usable as the query descriptor rows of a search on another frame of the same device (a caller that
+ * keeps descriptors on the GPU -- its own table of MapPoint descriptors, or a frame's rows -- passes device pointers and no
+ * descriptor crosses PCIe). */
+const uint8_t* orbfe_frame_descriptors_device(orbfe_frame* f);
 /* Test / debug: the resident content back on the host -- keypoints (x, y, angle, octave; other fields zeroed) and
  * descriptor rows in keypoint order, the keypoint indices in grid order (capacity n) and the 64*48+1 cell offsets into
  * that order (mGrid flattened: cell = ix * 48 + iy).  Any pointer may be NULL. */
@@ -412,8 +417,13 @@ int orbfe_frame_download(orbfe_frame* f, OrbfeKeyPoint* kps_un, uint8_t* desc, i
 /* orbfe_search_by_projection / _uv / orbfe_search_projected on a resident frame: same arguments minus the frame's
  * arrays, same results.  (The host-array forms above run through these with a transient frame owned by the matcher;
  * ORBFE_MATCH_HOST_RESOLVE=1 keeps their round-2 route -- candidate lists to the host, bookkeeping there -- for A/B
- * runs and the parity tests.)  Query descriptor rows in page-locked memory (orbfe_host_alloc) are fetched by DMA
- * straight from the caller's buffer. */
+ * runs and the parity tests.)  WHERE THE INPUT ARRAYS MAY LIVE: every per-query array (coordinates, levels, viewing
+ * cosines / radii, flags, descriptor rows) and kp_occupied / kp_skip is read by the search kernel in place when it lies in
+ * page-locked host memory (orbfe_host_alloc) or in the memory of the frame's device (descriptor rows there must be 16-byte
+ * aligned, e.g. orbfe_frame_descriptors_device); arrays in ordinary host memory are first copied into a page-locked
+ * arena (a plain memcpy each -- there is no per-query loop on the host).  ORBFE_FRAME_ZEROCOPY=0: marshal the queries on
+ * the host and upload them instead.  The call returns when the kernel's last store -- the call's number, into page-locked
+ * memory -- has been seen (ORBFE_FRAME_POLL=0: wait on the stream instead). */
 int orbfe_search_by_projection_frame(orbfe_matcher* m, orbfe_frame* f, const float* scale_factors, int nlevels,
                                      const uint8_t* kp_occupied, const float* mp_proj_xy, const int32_t* mp_level,
                                      const float* mp_viewcos, const uint8_t* mp_flags, const uint8_t* mp_desc, int n_mp,
@@ -427,8 +437,8 @@ int orbfe_search_projected_frame(orbfe_matcher* m, orbfe_frame* f, int n_src, co
                                  const int32_t* src_level, const uint8_t* src_valid, const uint8_t* src_desc,
                                  const uint8_t* kp_skip, int claim, const float* inv_level_sigma2, int nlevels, double chi2,
                                  int max_dist, int32_t* best_idx, int32_t* best_dist, int* nmatches);
-/* Rounds the bookkeeping kernel of the last `_frame` search needed (negative: the bound ORBFE_RESOLVE_MAX_ROUNDS,
- * default 48, was hit and a serial pass on the device finished the job). */
+/* Rounds the bookkeeping kernel of the last `_frame` search needed -- the most any chunk of 2 048 consecutive queries took
+ * (negative: a chunk hit the bound ORBFE_RESOLVE_MAX_ROUNDS, default 48, and a serial pass on the device finished it). */
 int orbfe_debug_resolve_rounds(const orbfe_matcher* m);
 /* Where that kernel kept its state: 2 = tables and candidate entries in LDS, 1 = tables in LDS, 0 = global scratch (problems
  * beyond 152 KB of tables, or ORBFE_RESOLVE_GENERIC=1). */

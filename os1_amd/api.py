@@ -79,6 +79,8 @@ def load_library():
     L.orbfe_frame_destroy.argtypes = [vp]
     L.orbfe_frame_destroy.restype = None
     L.orbfe_frame_size.argtypes = [vp]
+    L.orbfe_frame_descriptors_device.argtypes = [vp]
+    L.orbfe_frame_descriptors_device.restype = vp
     L.orbfe_frame_download.argtypes = [vp, vp, vp, vp, vp]
     L.orbfe_search_by_projection_frame.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp, C.POINTER(ci)]
     L.orbfe_search_by_projection_uv_frame.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, ci, ci, ci, vp,
@@ -152,6 +154,25 @@ def load_library():
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+class DeviceRows:
+    """Descriptor rows [n][32] in device memory (Frame.descriptors_device()); accepted wherever the searches on resident
+    frames take query descriptor rows."""
+
+    def __init__(self, ptr, n):
+        self.ptr, self.n = int(ptr), int(n)
+
+    def __len__(self):
+        return self.n
+
+
+def _rows(a):
+    """(argument for the C call, object to keep alive) for query descriptor rows: numpy array or DeviceRows."""
+    if isinstance(a, DeviceRows):
+        return C.c_void_p(a.ptr), a
+    a = np.ascontiguousarray(a, np.uint8)
+    return _p(a), a
 
 
 def _check(rc):
@@ -358,6 +379,10 @@ class Frame:
     def __len__(self):
         return self.n
 
+    def descriptors_device(self):
+        """The frame's descriptor rows in device memory, keypoint order (valid while the frame lives)."""
+        return DeviceRows(self.L.orbfe_frame_descriptors_device(self.h) or 0, self.n)
+
     def download(self):
         """(kps [x, y, angle, octave filled], desc, grid_order, cell_start) as they lie on the device."""
         k = np.zeros(max(self.n, 1), KP_DTYPE)
@@ -458,11 +483,11 @@ class Matcher:
             mp_level = np.ascontiguousarray(mp_level, np.int32)
             mp_viewcos = np.ascontiguousarray(mp_viewcos, np.float32)
             mp_flags = np.ascontiguousarray(mp_flags, np.uint8)
-            mp_desc = np.ascontiguousarray(mp_desc, np.uint8)
+            mp_desc_p, _keep = _rows(mp_desc)
             assigned = np.full(max(len(kps), 1), -1, np.int32)
             n = C.c_int(0)
             _check(self.L.orbfe_search_by_projection_frame(self.h, kps.h, _p(sf), len(sf), _p(occ), _p(mp_xy), _p(mp_level),
-                                                           _p(mp_viewcos), _p(mp_flags), _p(mp_desc), len(mp_level), th,
+                                                           _p(mp_viewcos), _p(mp_flags), mp_desc_p, len(mp_level), th,
                                                            nnratio, _p(assigned), C.byref(n)))
             return n.value, assigned[:len(kps)]
         kps = np.ascontiguousarray(kps, KP_DTYPE)
@@ -492,11 +517,11 @@ class Matcher:
             src_angle = np.ascontiguousarray(src_angle, np.float32)
             src_flags = np.ascontiguousarray(src_flags, np.uint8)
             src_valid = np.ascontiguousarray(src_valid, np.uint8)
-            src_desc = np.ascontiguousarray(src_desc, np.uint8)
+            src_desc_p, _keep = _rows(src_desc)
             assigned = np.full(max(len(kps), 1), -1, np.int32)
             n = C.c_int(0)
             _check(self.L.orbfe_search_by_projection_uv_frame(self.h, kps.h, _p(sf), len(sf), _p(occ), _p(src_uv), _p(src_level),
-                                                              _p(src_angle), _p(src_flags), _p(src_valid), _p(src_desc),
+                                                              _p(src_angle), _p(src_flags), _p(src_valid), src_desc_p,
                                                               len(src_level), th, max_dist, int(skip_any_occupied),
                                                               int(check_ori), _p(assigned), C.byref(n)))
             return n.value, assigned[:len(kps)]
@@ -564,14 +589,14 @@ class Matcher:
             radius = np.ascontiguousarray(radius, np.float32)
             level = np.ascontiguousarray(level, np.int32)
             valid = np.ascontiguousarray(valid, np.uint8)
-            sdesc = np.ascontiguousarray(sdesc, np.uint8)
+            sdesc_p, _keep = _rows(sdesc)
             ns = len(radius)
             skip = None if kp_skip is None else np.ascontiguousarray(kp_skip, np.uint8)
             inv = None if inv_sigma2 is None else np.ascontiguousarray(inv_sigma2, np.float32)
             bi = np.full(max(ns, 1), -1, np.int32)
             bd = np.full(max(ns, 1), -1, np.int32)
             nm = C.c_int(0)
-            _check(self.L.orbfe_search_projected_frame(self.h, kps.h, ns, _p(uv), _p(radius), _p(level), _p(valid), _p(sdesc),
+            _check(self.L.orbfe_search_projected_frame(self.h, kps.h, ns, _p(uv), _p(radius), _p(level), _p(valid), sdesc_p,
                                                        None if skip is None else _p(skip), int(claim),
                                                        None if inv is None else _p(inv), 0 if inv is None else len(inv), chi2,
                                                        max_dist, _p(bi), _p(bd), C.byref(nm)))

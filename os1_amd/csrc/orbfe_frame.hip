@@ -568,11 +568,17 @@ bool frame_zero_copy() {   // ORBFE_FRAME_ZEROCOPY=0: upload the (marshalled) qu
   const char* zc = getenv("ORBFE_FRAME_ZEROCOPY");
   return !(zc && atoi(zc) == 0);
 }
-bool is_page_locked(const void* p) {
+// > 0: the kernels can read p in place (1: page-locked host memory, 2: memory of device `device`); 0: ordinary host memory
+// (the caller copies it into the arena); -1: memory of another device
+int gpu_readable(const void* p, int device) {
   hipPointerAttribute_t attr;
-  if (p && hipPointerGetAttributes(&attr, p) == hipSuccess && attr.type == hipMemoryTypeHost) return true;
+  if (p && hipPointerGetAttributes(&attr, p) == hipSuccess) {
+    if (attr.type == hipMemoryTypeHost || attr.type == hipMemoryTypeManaged) return 1;
+    if (attr.type == hipMemoryTypeDevice) return attr.device == device ? 2 : -1;
+    return 0;
+  }
   (void)hipGetLastError();
-  return false;
+  return 0;
 }
 // levels of the active queries -- (flags[i] & need) == want, or flags[i] != 0 when need == 0 -- all inside [0, nlevels)?  *maxSf = the largest scale
 // factor among them.  One pass of min / max over ALL levels first (vectorised; enough when no level is out of range).
@@ -647,10 +653,13 @@ int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint
   if ((rc = m->h_r.ensure(kHdr + outInts + 64))) return rc;
   if (f->ready && hipStreamWaitEvent(st, f->ready, 0) != hipSuccess) (void)hipGetLastError();   // (the recording stream is gone: the build is complete)
   // queries: one copy for the scalar arrays; descriptor rows straight from the caller's memory when it is page-locked
-  hipPointerAttribute_t attr;
-  const bool pinned = qdescHost && ((uintptr_t)qdescHost & 15u) == 0 &&   // (the kernel fetches rows as two 16-byte words)
-                      hipPointerGetAttributes(&attr, qdescHost) == hipSuccess && attr.type == hipMemoryTypeHost;
-  if (!pinned) (void)hipGetLastError();
+  // (the kernel fetches rows as two 16-byte words: rows it reads in place must be 16-byte aligned)
+  const int rowsWhere = gpu_readable(qdescHost, m->device);
+  if (rowsWhere < 0 || (rowsWhere == 2 && ((uintptr_t)qdescHost & 15u) != 0)) {
+    set_err(rowsWhere < 0 ? "the descriptor rows live in the memory of another device" : "device-resident descriptor rows must be 16-byte aligned");
+    return ORBFE_ERR_INVALID;
+  }
+  const bool pinned = rowsWhere > 0 && ((uintptr_t)qdescHost & 15u) == 0;
   // No upload command at all by default: the kernels read the page-locked query arena (and the caller's page-locked
   // descriptor rows) over PCIe themselves -- every query word is read once, and a DMA in front of the first kernel costs its
   // own latency plus a copy-engine -> compute hand-over (16 + 8 us measured for the 490 KB of 10 000 MapPoints).
@@ -663,7 +672,7 @@ int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint
     else { memcpy(P.qdesc, qdescHost, 32 * (size_t)nq); qdescDev = P.qdesc; }
   } else if (pinned) {
     HIP_TRY(hipMemcpyAsync(m->d_q.p, m->h_q.p, P.head, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(m->d_q.p + P.oQd, qdescHost, 32 * (size_t)nq, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(m->d_q.p + P.oQd, qdescHost, 32 * (size_t)nq, hipMemcpyDefault, st));
   } else {
     memcpy(P.qdesc, qdescHost, 32 * (size_t)nq);
     HIP_TRY(hipMemcpyAsync(m->d_q.p, m->h_q.p, P.oQd + 32 * (size_t)nq, hipMemcpyHostToDevice, st));
@@ -673,8 +682,12 @@ int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint
   if (raw) {
     W = *raw;
     uint8_t* H = m->h_q.p;
+    bool foreign = false;
     auto view = [&](const void* src, size_t bytes, size_t at) -> const void* {
-      if (!src || is_page_locked(src)) return src;
+      if (!src) return src;
+      const int g = gpu_readable(src, m->device);
+      if (g > 0) return src;
+      if (g < 0) { foreign = true; return src; }
       memcpy(H + at, src, bytes);
       return H + at;
     };
@@ -685,6 +698,7 @@ int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint
     W.claimSrc = raw->claimSrc == raw->flags ? W.flags : (const uint8_t*)view(raw->claimSrc, (size_t)nq, P.oQb);
     W.angle = (const float*)view(raw->angle, 4 * (size_t)nq, P.oQang);
     W.occ = (const uint8_t*)view(raw->occ, (size_t)n, P.oOcc);
+    if (foreign) { set_err("an input array lives in the memory of another device"); return ORBFE_ERR_INVALID; }
     if (raw->sf) {   // scale factors in device memory, refreshed when the caller's differ from the copy there
       if (raw->nlevels > 32) { set_err("more than 32 levels"); return ORBFE_ERR_INVALID; }
       if (!m->d_sf.p) { if ((rc = m->d_sf.ensure(32))) return rc; m->sfN = -1; }
@@ -893,6 +907,13 @@ int orbfe_frame_create_from_extract(orbfe_extractor* h, int frame_index, const f
 
 void orbfe_frame_destroy(orbfe_frame* f) { delete f; }
 int orbfe_frame_size(const orbfe_frame* f) { return f ? f->n : 0; }
+
+const uint8_t* orbfe_frame_descriptors_device(orbfe_frame* f) {
+  if (!f || !f->n) return nullptr;
+  (void)hipSetDevice(f->device);
+  if (f->ready && hipEventSynchronize(f->ready) != hipSuccess) (void)hipGetLastError();   // the rows are complete when this returns
+  return f->D.desc;
+}
 
 int orbfe_frame_download(orbfe_frame* f, OrbfeKeyPoint* kps_un, uint8_t* desc, int32_t* grid_order, int32_t* cell_start) {
   if (!f) { set_err("frame is NULL"); return ORBFE_ERR_INVALID; }

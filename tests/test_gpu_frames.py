@@ -301,6 +301,25 @@ def test_tracking_shaped_sequence_on_one_resident_frame(api, oracle):
     for (gn, ga), (wn, wa) in zip(got, want):
         assert gn == wn and (ga == wa).all()
     assert got[0][0] > 200 and got[2][0] > 300
+    # LastFrame's descriptors are compared where they already are: the resident copy of the last frame (device memory)
+    ex(A)
+    last = api.Frame.from_extract(ex, 0, bounds)
+    rows = last.descriptors_device()
+    assert len(rows) == len(k1) and rows.ptr % 16 == 0
+    occ = np.zeros(len(k2), np.uint8)
+    for th in (7.0, 14.0):
+        n, a = m.search_by_projection_uv(fr, None, None, sf, occ, uv, k1['octave'], k1['angle'], sflags, valid, rows, th, 100, 0, True)
+        wn, wa = oracle.search_by_projection_uv(k2, d2, bounds, sf, occ, uv, k1['octave'], k1['angle'], sflags, valid, d1, th, 100, 0, True)
+        assert n == wn and (a == wa).all()
+    # ... and so may any other per-query array (here: all of them page-locked)
+    arrays = [occ, uv, k1['octave'].astype(np.int32), k1['angle'].astype(np.float32), sflags, valid]
+    pins = [api.PinnedArray(x.shape, x.dtype) for x in arrays]
+    for p_, x in zip(pins, arrays):
+        p_.a[...] = x
+    n, a = m.search_by_projection_uv(fr, None, None, sf, *[p_.a for p_ in pins], rows, 7.0, 100, 1, False)
+    wn, wa = oracle.search_by_projection_uv(k2, d2, bounds, sf, occ, uv, k1['octave'], k1['angle'], sflags, valid, d1, 7.0, 100, 1, False)
+    assert n == wn and (a == wa).all()
+    last.close()
 
 
 def test_config5_4k_fisheye_resident_frame(api, oracle):
