@@ -30,6 +30,13 @@ namespace {
 
 constexpr int kCells = kGridCols * kGridRows;   // 3072
 
+// ORBFE_FRAME_ZEROCOPY=0: copy commands (query arena marshalled on the host, frame arrays) instead of kernels reading
+// page-locked host memory in place
+bool frame_zero_copy() {
+  const char* zc = getenv("ORBFE_FRAME_ZEROCOPY");
+  return !(zc && atoi(zc) == 0);
+}
+
 struct FrameDev {   // device pointers of a resident frame
   float* x; float* y; float* angle; int* oct; uint8_t* desc;                       // keypoint order
   float* sx; float* sy; int* soct; int* sidx; uint8_t* tdesc; int* cellStart;      // grid order (Frame.cc:114-129)
@@ -44,13 +51,15 @@ __device__ __forceinline__ void copy32(uint8_t* dst, const uint8_t* src) {
   reinterpret_cast<uint4*>(dst)[1] = b;
 }
 
-// keypoints (cv::KeyPoint layout, mvKeysUn) + descriptor rows uploaded by the host -> keypoint-order arrays
-// (the descriptor rows are uploaded straight to F.desc)
-__global__ __launch_bounds__(256) void k_frame_from_host(const OrbfeKeyPoint* __restrict__ kps, FrameDev F) {
+// keypoints (cv::KeyPoint layout, mvKeysUn) + descriptor rows -> keypoint-order arrays.  desc != nullptr: the rows are
+// fetched by this kernel too (page-locked staging memory read over PCIe: no copy command in front of the build);
+// nullptr: they were uploaded straight to F.desc.
+__global__ __launch_bounds__(256) void k_frame_from_host(const OrbfeKeyPoint* __restrict__ kps, const uint8_t* __restrict__ desc, FrameDev F) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= F.n) return;
   const OrbfeKeyPoint k = kps[i];
   F.x[i] = k.x; F.y[i] = k.y; F.angle[i] = k.angle; F.oct[i] = k.octave;
+  if (desc) copy32(F.desc + (size_t)i * 32, desc + (size_t)i * 32);
 }
 
 struct ExtractViewDev {
@@ -522,11 +531,15 @@ struct orbfe_frame {
       if ((rc = stage.ensure(total))) return rc;
       memcpy(stage.p, kps, sizeof(OrbfeKeyPoint) * (size_t)count);
       memcpy(stage.p + kb, desc, 32 * (size_t)count);
-      // the keypoint records (28 B each) are staged in the grid-order descriptor array (32 B per keypoint), which the
-      // grid kernel fills only afterwards; the descriptor rows go straight to their final place
-      HIP_TRY(hipMemcpyAsync(D.tdesc, stage.p, sizeof(OrbfeKeyPoint) * (size_t)count, hipMemcpyHostToDevice, st));
-      HIP_TRY(hipMemcpyAsync(D.desc, stage.p + kb, 32 * (size_t)count, hipMemcpyHostToDevice, st));
-      hipLaunchKernelGGL(k_frame_from_host, dim3((count + 255) / 256), dim3(256), 0, st, (const OrbfeKeyPoint*)D.tdesc, D);
+      if (frame_zero_copy()) {
+        hipLaunchKernelGGL(k_frame_from_host, dim3((count + 255) / 256), dim3(256), 0, st, (const OrbfeKeyPoint*)stage.p, stage.p + kb, D);
+      } else {
+        // the keypoint records (28 B each) are staged in the grid-order descriptor array (32 B per keypoint), which the
+        // grid kernel fills only afterwards; the descriptor rows go straight to their final place
+        HIP_TRY(hipMemcpyAsync(D.tdesc, stage.p, sizeof(OrbfeKeyPoint) * (size_t)count, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(D.desc, stage.p + kb, 32 * (size_t)count, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_frame_from_host, dim3((count + 255) / 256), dim3(256), 0, st, (const OrbfeKeyPoint*)D.tdesc, (const uint8_t*)nullptr, D);
+      }
     }
     return grid(st);
   }
@@ -564,10 +577,6 @@ struct RawQ {
   int factor = 0;
 };
 
-bool frame_zero_copy() {   // ORBFE_FRAME_ZEROCOPY=0: upload the (marshalled) query arena instead of reading host memory from the kernels
-  const char* zc = getenv("ORBFE_FRAME_ZEROCOPY");
-  return !(zc && atoi(zc) == 0);
-}
 // > 0: the kernels can read p in place (1: page-locked host memory, 2: memory of device `device`); 0: ordinary host memory
 // (the caller copies it into the arena); -1: memory of another device
 int gpu_readable(const void* p, int device) {
