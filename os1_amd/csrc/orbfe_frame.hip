@@ -156,6 +156,7 @@ struct ResolveParams {
   const uint2* qword;       // [nq] packed query words as k_window_match leaves them (MatchParams::qword)
   const uint32_t* rec;      // [nq][4] full records (the distances of the accepted candidates are read from here)
   const uint32_t* qoff; const uint32_t* pool; uint32_t* total; uint32_t poolCap;
+  const uint32_t* wpool; uint32_t* wtotal;   // wide records (four to six candidates) and the words of them in use
   int nq, n;
   const uint32_t* claimBits;   // bit i: an accepted match of query i makes its keypoint unavailable to later queries
   const uint32_t* occBits;     // bit k: keypoint k unavailable from the start (mvpMapPoints occupancy / kp_skip); nullptr: none
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
   __shared__ int acc[2];
   __shared__ int orFlag[3];
   const int tid = threadIdx.x, nq = R.nq, n = R.n;
-  const uint32_t tot = *R.total;
+  const uint32_t tot = *R.total, wtot = *R.wtotal;
   auto stamp = [&](int k) { if (tid == 0) R.hdrHost[16 + k] = (int)__builtin_readcyclecounter(); };   // phase clock (debug)
   stamp(0);
   if (tid < 32) hist[tid] = 0;
@@ -262,6 +263,7 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
   if (tid == 0) {
     R.hdrHost[4] = (int)tot;
     *R.total = 0u;        // ready for the next search
+    *R.wtotal = 0u;
     R.hdrHost[1] = tot > R.poolCap ? 1 : 0;
     if (tot > R.poolCap) {
       __threadfence_system();
@@ -269,11 +271,16 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
     }
   }
   if (tot > R.poolCap) return;   // candidate pool too small: the host grows it and submits again
-  // the lists beyond the records (and the wide records) are walked from LDS when the whole pool fits, else from the pool
-  const bool poolInLds = LDS && tot <= (uint32_t)ldsEntries;
-  const uint32_t* lists = poolInLds ? ovf : R.pool;
+  // what lies beyond the records moves to LDS while there is room: the wide records first (every round looks them up), then
+  // the pool (the lists that are walked)
+  const bool wideInLds = LDS && wtot <= (uint32_t)ldsEntries;
+  const bool poolInLds = wideInLds && wtot + tot <= (uint32_t)ldsEntries;
+  const uint32_t* wides = wideInLds ? ovf : R.wpool;
+  const uint32_t* lists = poolInLds ? ovf + wtot : R.pool;
+  if (wideInLds)
+    for (uint32_t e = (uint32_t)tid; e < wtot; e += kResolveThreads) ovf[e] = R.wpool[e];
   if (poolInLds)
-    for (uint32_t e = (uint32_t)tid; e < tot; e += kResolveThreads) ovf[e] = R.pool[e];
+    for (uint32_t e = (uint32_t)tid; e < tot; e += kResolveThreads) ovf[wtot + e] = R.pool[e];
   for (int k = tid; k < n; k += kResolveThreads) {
     fcA[k] = occupied(k) ? -1 : INT_MAX;
     kpAssigned[k] = -1;
@@ -299,22 +306,31 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
       return o ? sel : -1;
     }
     which = 0;
-    if (code == kCodeWide) {                             // four candidates: the same lookup over 16 patterns
-      const uint32_t* wr = lists + r.x;
-      const uint32_t a = wr[0], b = wr[1], lo = wr[2], hi = wr[3];
-      const int i0 = (int)(a & 0xffffu), i1 = (int)(a >> 16), i2 = (int)(b & 0xffffu), i3 = (int)(b >> 16);
-      const int f0 = fc[i0], f1 = fc[i1], f2 = fc[i2], f3 = fc[i3];
-      const unsigned p = (f0 >= i ? 1u : 0u) | (f1 >= i ? 2u : 0u) | (f2 >= i ? 4u : 0u);
-      const int o = (int)(((f3 >= i ? hi : lo) >> (3 * p)) & 7u);
-      which = o ? 8 + o : 0;
-      return o == 0 ? -1 : (o == 1 ? i0 : (o == 2 ? i1 : (o == 3 ? i2 : i3)));
+    if (code == kCodeWide) {                             // four to six candidates: the same lookup over 2^N patterns
+      const uint32_t* wr = wides + r.x;
+      const unsigned N = r.y & 0xffffu;
+      const uint32_t a = wr[0], b = wr[1], c = wr[2];
+      const int f0 = fc[a & 0xffffu], f1 = fc[a >> 16], f2 = fc[b & 0xffffu], f3 = fc[b >> 16], f4 = fc[c & 0xffffu], f5 = fc[c >> 16];
+      const unsigned p = ((f0 >= i ? 1u : 0u) | (f1 >= i ? 2u : 0u) | (f2 >= i ? 4u : 0u) | (f3 >= i ? 8u : 0u) | (f4 >= i ? 16u : 0u) |
+                          (f5 >= i ? 32u : 0u)) & ((1u << N) - 1u);   // (slots beyond N hold index 0)
+      const unsigned o = (wr[3 + (p >> 3)] >> (3u * (p & 7u))) & 7u;
+      const uint32_t pair = o <= 2u ? a : (o <= 4u ? b : c);
+      which = o ? 8 + (int)o : 0;
+      return o ? (int)((pair >> (16u * ((o - 1u) & 1u))) & 0xffffu) : -1;
     }
     Best<MODE> B;                                        // a longer list: walk it
     const int cnt = (int)(r.y & 0xffffu);
     const uint32_t* l = lists + r.x;
-    for (int c = 0; c < cnt; c++) {
-      const uint32_t e = l[c];
-      B.consider(e, fc[e & 0xffff], i);
+    for (int c = 0; c < cnt; c += 4) {   // four entries, then their four table words, per pair of dependent trips
+      uint32_t e[4];
+      int fv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) e[u] = l[min(c + u, cnt - 1)];
+#pragma unroll
+      for (int u = 0; u < 4; u++) fv[u] = fc[e[u] & 0xffff];
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (c + u < cnt) B.consider(e[u], fv[u], i);
     }
     int d;
     const int m = B.accept(R, d);
@@ -636,7 +652,8 @@ int plan_search(orbfe_matcher* m, const orbfe_frame* f, int mode, int nq, bool w
 }
 
 // result header (ints): [0] nmatches, [1] candidate pool overflow, [2] rounds of the fixed point (< 0: finished serially),
-// [4] candidate entries needed, [8] the window kernel's running entry counter (zero between searches)
+// [4] candidate entries needed, [8] / [9] the window kernel's running counters of pool entries / wide-record words (zero
+// between searches)
 constexpr int kHdr = 64;
 
 // out: pointer into the page-locked result area: kp_assigned[n] (modes 0, 1) or best_idx[nq], best_dist[nq] (mode 2)
@@ -734,6 +751,8 @@ int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint
     M.nq = nq;
     M.total = (uint32_t*)(Dr + 8); M.qcount = (uint32_t*)(Dr + oCnt); M.qoff = (uint32_t*)(Dr + oOff);
     M.pool = m->d_pool.p; M.poolCap = (uint32_t)m->d_pool.n;
+    if ((rc = m->d_wpool.ensure(wide_words(kWideMax) * (size_t)std::max(nq, 1)))) return rc;   // every query a six-candidate list
+    M.wpool = m->d_wpool.p; M.wtotal = (uint32_t*)(Dr + 9);
     M.rec = (uint32_t*)(Dr + oRec);
     M.qword = (uint2*)(Dr + oQw);
     unsigned long long* dClaim = (unsigned long long*)(Dr + oFlags);
@@ -767,6 +786,7 @@ int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint
     }
     ResolveParams R;
     R.qword = M.qword; R.rec = M.rec; R.qoff = M.qoff; R.pool = M.pool; R.total = M.total; R.poolCap = M.poolCap;
+    R.wpool = M.wpool; R.wtotal = M.wtotal;
     R.nq = nq; R.n = n;
     R.occBits = withOcc ? (const uint32_t*)dOcc : nullptr;
     R.claimBits = (const uint32_t*)dClaim; R.qangle = qangleDev; R.kangle = f->D.angle;

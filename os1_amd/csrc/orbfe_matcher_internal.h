@@ -72,6 +72,8 @@ struct MatchParams {
   uint32_t* pool;         // entries: idx | dist << 16, reference candidate order per query
   uint32_t poolCap;
   uint32_t* total;        // [1] pool entries claimed (may exceed poolCap: host retries with a larger pool)
+  uint32_t* wpool = nullptr;   // wide records (resident-frame searches; sized for the worst case by the host)
+  uint32_t* wtotal = nullptr;  // [1] words of it claimed
   // searches on a resident frame (orbfe_frame.hip) filter and annotate the candidates where they are produced, so the
   // bookkeeping kernel needs nothing but the entries themselves (per-candidate tests, independent of order):
   uint32_t* rec = nullptr;            // [nq][4]: {count | decision code << 16, entry 0, entry 1, entry 2}; lists of <= kRecEntries
@@ -142,11 +144,12 @@ __device__ __forceinline__ int outcome_of(int mode, int cnt, const uint32_t e[NC
   return best + 1;
 }
 // Decision codes.  Record (up to three candidates): 8 x 2 bits, field p = outcome when exactly the candidates of bit pattern p
-// are available (bits beyond the count do not matter).  Wide record (exactly four candidates): 16 x 3 bits, patterns 0..7 in the
-// first word, 8..15 in the second.  Field 0 is always 0 (nothing available: no match).
+// are available (bits beyond the count do not matter).  Wide record (N = four to six candidates): 2^N x 3 bits, eight
+// patterns per word (word p >> 3, field p & 7).  Field 0 is always 0 (nothing available: no match).
 constexpr uint32_t kCodeLongList = 0xffffu;   // (field 0 of a real code is always 0) the list is longer than the record: read the pool
-constexpr uint32_t kCodeWide = 0xfffeu;       // four candidates: the pool holds the entries and, behind them, a four-word wide record
-                                              // {idx0 | idx1 << 16, idx2 | idx3 << 16, decision_code4}
+constexpr uint32_t kCodeWide = 0xfffeu;       // four to six candidates: entries in the pool, and in the wide pool a wide record
+                                              // {idx0 | idx1 << 16, idx2 | idx3 << 16, idx4 | idx5 << 16, 2^N / 8 code words}
+__host__ __device__ constexpr uint32_t wide_words(uint32_t n) { return 3u + (1u << (n - 3u)); }   // 5, 7, 11
 
 // LPQ lanes per query (64/LPQ queries per wave), one LANE per grid column of the window.  Window
 // semantics: Frame::GetFeaturesInArea, Frame.cc:209-262: columns ix ascending, rows iy ascending inside a
@@ -159,11 +162,12 @@ constexpr uint32_t kCodeWide = 0xfffeu;       // four candidates: the pool holds
 // same-address atomics with return (one per query) serialise in the L2 and took longer than the search itself.
 constexpr int kWinThreads = 256;
 constexpr int kRecEntries = 3;
-constexpr int kTmpEntries = 4;   // lists gathered in LDS: those of the record, and the four-candidate lists for their wide record
+constexpr int kTmpEntries = 6;   // lists gathered in LDS: those of the record, and the lists of four to six candidates for their wide record
+constexpr int kWideMax = 6;
 template <int LPQ>
 __global__ __launch_bounds__(kWinThreads) void k_window_match(MatchParams M) {
   __shared__ uint32_t wtot[kWinThreads / 64];
-  __shared__ uint32_t blockBase;
+  __shared__ uint32_t blockBase, blockBaseW;
   __shared__ uint32_t recTmp[(kWinThreads / LPQ) * kTmpEntries];   // short lists gathered per query (resident-frame searches)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane & (LPQ - 1);
@@ -284,9 +288,11 @@ __global__ __launch_bounds__(kWinThreads) void k_window_match(MatchParams M) {
   // a resident-frame search keeps lists of up to kRecEntries candidates in the query's fixed 16-byte record (no pool space,
   // no offset to chase); longer lists go to the pool like every list of the host-resolved searches
   const bool inRec = M.rec != nullptr && count <= (uint32_t)kRecEntries;
-  const bool wide = M.rec != nullptr && count == 4u;   // four candidates: entries to the pool AND (via LDS) a wide record behind them
-  // offsets: exclusive scan of the queries' counts inside the wave, of the wave totals inside the block, one atomic
-  const uint32_t mine = (live && sub == 0 && !inRec) ? (wide ? 8u : count) : 0u;
+  const bool wide = M.rec != nullptr && count >= 4u && count <= (uint32_t)kWideMax;   // entries to the pool AND (via LDS) a wide record
+  // offsets: exclusive scan of the queries' counts inside the wave, of the wave totals inside the block, one atomic per pool.
+  // Both sums travel in one word: pool entries in the low 24 bits, wide-record words in the high 8 (a wave has at most
+  // eight queries: 8 x 65 535 entries, 8 x 11 words).
+  const uint32_t mine = (live && sub == 0 && !inRec) ? (count | (wide ? wide_words(count) << 24 : 0u)) : 0u;
   uint32_t wincl = mine;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -296,13 +302,14 @@ __global__ __launch_bounds__(kWinThreads) void k_window_match(MatchParams M) {
   if (lane == 63) wtot[wave] = wincl;
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t s = 0;
-    for (int w = 0; w < kWinThreads / 64; w++) s += wtot[w];
+    uint32_t s = 0, sw = 0;
+    for (int w = 0; w < kWinThreads / 64; w++) { s += wtot[w] & 0xffffffu; sw += wtot[w] >> 24; }
     blockBase = s ? atomicAdd(M.total, s) : 0u;
+    blockBaseW = sw ? atomicAdd(M.wtotal, sw) : 0u;
   }
   __syncthreads();
-  uint32_t off = blockBase + (wincl - mine);
-  for (int w = 0; w < wave; w++) off += wtot[w];
+  uint32_t off = blockBase + ((wincl - mine) & 0xffffffu), offW = blockBaseW + ((wincl - mine) >> 24);
+  for (int w = 0; w < wave; w++) { off += wtot[w] & 0xffffffu; offW += wtot[w] >> 24; }
   if (live && sub == 0) {
     M.qcount[q] = count;
     M.qoff[q] = off;
@@ -340,42 +347,44 @@ __global__ __launch_bounds__(kWinThreads) void k_window_match(MatchParams M) {
   }
   if (M.rec) {
     // the query's record: its lanes' entries meet in LDS (a query's lanes are one wave's: a wave-level fence is enough).
-    // The outcomes are tabulated by the group's first eight lanes, ONE availability pattern each (two for a wide record),
-    // and OR-ed together by three shuffles; lane 0 writes the 16 bytes at once.
+    // The outcomes are tabulated by the group's first eight lanes, ONE availability pattern each (one per code word for a
+    // wide record), and OR-ed together by three shuffles; lane 0 writes the 16 bytes at once.
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (live && (inRec || wide)) {
-      uint32_t e4[4];
+    if (live && inRec) {
+      uint32_t e3[3];
 #pragma unroll
-      for (int c = 0; c < 4; c++) e4[c] = (uint32_t)c < count ? recTmp[qlocal * kTmpEntries + c] : 0u;
+      for (int c = 0; c < 3; c++) e3[c] = (uint32_t)c < count ? recTmp[qlocal * kTmpEntries + c] : 0u;
       const unsigned p = (unsigned)sub & 7u;
-      uint32_t lo = 0u, hi = 0u;
-      if (sub < 8) {
-        if (inRec) {
-          if (p) lo = (uint32_t)outcome_of<3>(M.codeMode, (int)count, e4, p & ((1u << count) - 1u), M.nnratio, M.maxDist) << (2u * p);
-        } else {
-          if (p) lo = (uint32_t)outcome_of<4>(M.codeMode, 4, e4, p, M.nnratio, M.maxDist) << (3u * p);
-          hi = (uint32_t)outcome_of<4>(M.codeMode, 4, e4, p + 8u, M.nnratio, M.maxDist) << (3u * p);
-        }
-      }
+      uint32_t code = 0u;
+      if (sub < 8 && p) code = (uint32_t)outcome_of<3>(M.codeMode, (int)count, e3, p & ((1u << count) - 1u), M.nnratio, M.maxDist) << (2u * p);
 #pragma unroll
-      for (int o = 1; o < 8; o <<= 1) {
-        lo |= (uint32_t)__shfl_xor((int)lo, o, LPQ);
-        hi |= (uint32_t)__shfl_xor((int)hi, o, LPQ);
+      for (int o = 1; o < 8; o <<= 1) code |= (uint32_t)__shfl_xor((int)code, o, LPQ);
+      if (sub == 0) {
+        reinterpret_cast<uint4*>(M.rec)[q] = make_uint4(count | (code << 16), e3[0], e3[1], e3[2]);
+        if (M.qword) M.qword[q] = make_uint2((e3[0] & 0xffffu) | (e3[1] << 16), (e3[2] & 0xffffu) | (code << 16));
+      }
+    } else if (live && wide) {
+      uint32_t e6[kWideMax];
+#pragma unroll
+      for (int c = 0; c < kWideMax; c++) e6[c] = (uint32_t)c < count ? recTmp[qlocal * kTmpEntries + c] : 0u;
+      const unsigned p = (unsigned)sub & 7u;
+      const int nW = 1 << ((int)count - 3);     // code words: 2, 4, 8
+      uint32_t* wr = M.wpool + offW;
+#pragma unroll
+      for (int w = 0; w < 8; w++) {
+        if (w >= nW) break;                      // (uniform inside the group)
+        uint32_t word = 0u;
+        if (sub < 8 && (w | p)) word = (uint32_t)outcome_of<kWideMax>(M.codeMode, (int)count, e6, 8u * w + p, M.nnratio, M.maxDist) << (3u * p);
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) word |= (uint32_t)__shfl_xor((int)word, o, LPQ);
+        if (sub == 0) wr[3 + w] = word;
       }
       if (sub == 0) {
-        if (inRec) {
-          reinterpret_cast<uint4*>(M.rec)[q] = make_uint4(count | (lo << 16), e4[0], e4[1], e4[2]);
-          if (M.qword) M.qword[q] = make_uint2((e4[0] & 0xffffu) | (e4[1] << 16), (e4[2] & 0xffffu) | (lo << 16));
-        } else {
-          if (off + 8u <= M.poolCap) {
-            M.pool[off + 4] = (e4[0] & 0xffffu) | (e4[1] << 16);
-            M.pool[off + 5] = (e4[2] & 0xffffu) | (e4[3] << 16);
-            M.pool[off + 6] = lo;
-            M.pool[off + 7] = hi;
-          }
-          reinterpret_cast<uint4*>(M.rec)[q] = make_uint4(count | (kCodeWide << 16), 0u, 0u, 0u);
-          if (M.qword) M.qword[q] = make_uint2(off + 4u, count | (kCodeWide << 16));
-        }
+        wr[0] = (e6[0] & 0xffffu) | (e6[1] << 16);
+        wr[1] = (e6[2] & 0xffffu) | (e6[3] << 16);
+        wr[2] = (e6[4] & 0xffffu) | (e6[5] << 16);
+        reinterpret_cast<uint4*>(M.rec)[q] = make_uint4(count | (kCodeWide << 16), 0u, 0u, 0u);
+        if (M.qword) M.qword[q] = make_uint2(offW, count | (kCodeWide << 16));
       }
     } else if (live && sub == 0) {
       reinterpret_cast<uint4*>(M.rec)[q] = make_uint4(count | (kCodeLongList << 16), 0u, 0u, 0u);
@@ -442,7 +451,7 @@ struct orbfe_matcher {
     (void)hipSetDevice(device);
     if (stream) (void)hipStreamSynchronize(stream);
     orbfe_frame_destroy(scratch);
-    d_q.release(); h_q.release(); d_r.release(); h_r.release(); d_sf.release();
+    d_q.release(); h_q.release(); d_r.release(); h_r.release(); d_sf.release(); d_wpool.release();
     d_in.release(); h_in.release(); d_out.release(); h_out.release(); d_pool.release(); h_pool.release();
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -457,6 +466,7 @@ struct orbfe_matcher {
   const uint32_t* qcount = nullptr;
   const uint32_t* qoff = nullptr;
 
+  DevBuf<uint32_t> d_wpool;      // wide records of the frame searches
   DevBuf<float> d_sf;            // raw queries: mvScaleFactors in device memory (and the host copy they were made from)
   float sfHost[32] = {};
   int sfN = -1;
