@@ -170,13 +170,13 @@ struct ResolveParams {
   int seq;                  // the call's number: written to hdrHost[5] last of all (the host polls it instead of waiting on the stream)
 };
 
-// Best / second best of one query given the keypoints taken by earlier queries: fc[idx] = first query that claimed the
-// keypoint (-1: unavailable from the start, INT_MAX: free); query i may use idx iff fc[idx] >= i.
+// Best / second best of one query over the candidates earlier queries have left it (`taken`: the keypoint's table word says
+// an earlier query holds it, or it was unavailable from the start).
 template <int MODE>
 struct Best {
   int bestDist = MODE == kModeProjected ? INT_MAX : 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
-  __device__ __forceinline__ void consider(uint32_t e, int fcv, int i) {
-    if (fcv < i) return;                                   // ORBmatcher.cc:89-91, :1364-1366, :1493-1494, :376-377
+  __device__ __forceinline__ void consider(uint32_t e, bool taken) {
+    if (taken) return;                                     // ORBmatcher.cc:89-91, :1364-1366, :1493-1494, :376-377
     const int idx = (int)(e & 0xffff), dist = (int)((e >> 16) & 0x1ff), oct = (int)(e >> 25);
     if (MODE == kModeMapPoints) {                          // :95-109
       if (dist < bestDist) {
@@ -212,6 +212,8 @@ __device__ __forceinline__ int rot_bin_dev(float a1, float a2) {   // ORBmatcher
 }
 
 constexpr int kResolveThreads = 1024;
+constexpr uint32_t kFree = 0xffffffffu;   // claim table: no claim
+constexpr uint32_t kTagMax = 0xffeu;      // first round tag (12 bits above 20 bits of query index + 1)
 constexpr int kResolveQpt = 2;   // queries per thread and chunk: 2 048 queries settle together (measured: 1 -> 66 k cycles for config 5's
                                  // 10 000 MapPoints, 2 -> 52 k, 4 -> 56 k, 6 -> 48 k, 10 -> 56 k; 2 keeps a tracking-sized search in one chunk)
 
@@ -237,8 +239,8 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
   if (tid < 3) orFlag[tid] = 0;
   const int claimWords = (nq + 31) >> 5, occWords = (n + 31) >> 5;
   uint2* q8 = LDS ? reinterpret_cast<uint2*>(dyn) : nullptr;                         // [nq] packed query words, later the outcomes
-  int* fcA = LDS ? dyn + 2 * nq : R.scratch;                                         // [n]
-  int* kpAssigned = fcA + n;                                                          // [n]
+  uint32_t* fc = reinterpret_cast<uint32_t*>(LDS ? dyn + 2 * nq : R.scratch);        // [n] the claim table (below)
+  int* kpAssigned = reinterpret_cast<int*>(fc) + n;                                   // [n]
   uint32_t* claimL = LDS ? reinterpret_cast<uint32_t*>(kpAssigned + n) : nullptr;    // [claimWords]
   uint32_t* occL = LDS ? claimL + claimWords : nullptr;                               // [occWords]
   uint32_t* ovf = LDS ? occL + occWords : nullptr;                                    // [ldsEntries] the pool's copy
@@ -282,25 +284,32 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
   if (poolInLds)
     for (uint32_t e = (uint32_t)tid; e < tot; e += kResolveThreads) ovf[wtot + e] = R.pool[e];
   for (int k = tid; k < n; k += kResolveThreads) {
-    fcA[k] = occupied(k) ? -1 : INT_MAX;
+    fc[k] = occupied(k) ? 0u : kFree;
     kpAssigned[k] = -1;
   }
   __syncthreads();
   stamp(1);
   auto claims = [&](int i) -> bool { return ((claimW[i >> 5] >> (i & 31)) & 1u) != 0; };
   auto query_word = [&](int i) -> uint2 { return LDS ? q8[i] : R.qword[i]; };
-  // outcome of query i (packed word r) against table fc: accepted keypoint or -1; `which` = 1 + position of the accepted
-  // candidate in the record, 9 + position for a wide record, -(distance) - 1 for a walked list
-  auto eval = [&](int i, const uint2 r, const int* fc, int& which) -> int {
+  // The claim table.  Word of keypoint k = tag << 20 | (claiming query + 1), kept minimal by atomicMin: tag 0 = a settled claim
+  // (0 itself: unavailable from the start), tag T > 0 = a claim made in the round with tag T; rounds count their tags DOWN, so
+  // a newer claim overwrites any older tentative one, and a reader in the round with tag T holds
+  //   keypoint taken for query i  <=>  word < (T << 20 | i + 1):
+  // settled claims (all by earlier chunks' queries or, inside a serial pass, by earlier queries), this round's input claims by
+  // queries j < i, and nothing else -- claims of older rounds that were not renewed carry a larger tag and drop out by
+  // themselves, nobody has to take them back.  kFree = no claim.
+  // outcome of query i (packed word r) given thr = T << 20 | i + 1: accepted keypoint or -1; `which` = 1 + position of the
+  // accepted candidate in the record, 9 + position for a wide record, -(distance) - 1 for a walked list
+  auto eval = [&](const uint2 r, const uint32_t thr, int& which) -> int {
     const uint32_t code = r.y >> 16;
     if (code < kCodeWide) {
       // branch-free (code 0 = no candidates = outcome 0 for every pattern; unused slots hold index 0: their bit does not
       // change the outcome)
-      const int i0 = (int)(r.x & 0xffffu), i1 = (int)(r.x >> 16), i2 = (int)(r.y & 0xffffu);
-      const int f0 = fc[i0], f1 = fc[i1], f2 = fc[i2];
-      const unsigned p = (f0 >= i ? 1u : 0u) + (f1 >= i ? 2u : 0u) + (f2 >= i ? 4u : 0u);
+      const uint32_t i0 = r.x & 0xffffu, i1 = r.x >> 16, i2 = r.y & 0xffffu;
+      const uint32_t f0 = fc[i0], f1 = fc[i1], f2 = fc[i2];
+      const unsigned p = (f0 >= thr ? 1u : 0u) + (f1 >= thr ? 2u : 0u) + (f2 >= thr ? 4u : 0u);
       const unsigned o = (code >> (2u * p)) & 3u;
-      const unsigned long long pk = (unsigned long long)r.x | ((unsigned long long)(uint32_t)i2 << 32);
+      const unsigned long long pk = (unsigned long long)r.x | ((unsigned long long)i2 << 32);
       const int sel = (int)((uint32_t)(pk >> (16u * ((o + 3u) & 3u))) & 0xffffu);   // candidate o - 1 (o = 0: unused)
       which = (int)o;
       return o ? sel : -1;
@@ -310,9 +319,9 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
       const uint32_t* wr = wides + r.x;
       const unsigned N = r.y & 0xffffu;
       const uint32_t a = wr[0], b = wr[1], c = wr[2];
-      const int f0 = fc[a & 0xffffu], f1 = fc[a >> 16], f2 = fc[b & 0xffffu], f3 = fc[b >> 16], f4 = fc[c & 0xffffu], f5 = fc[c >> 16];
-      const unsigned p = ((f0 >= i ? 1u : 0u) | (f1 >= i ? 2u : 0u) | (f2 >= i ? 4u : 0u) | (f3 >= i ? 8u : 0u) | (f4 >= i ? 16u : 0u) |
-                          (f5 >= i ? 32u : 0u)) & ((1u << N) - 1u);   // (slots beyond N hold index 0)
+      const uint32_t f0 = fc[a & 0xffffu], f1 = fc[a >> 16], f2 = fc[b & 0xffffu], f3 = fc[b >> 16], f4 = fc[c & 0xffffu], f5 = fc[c >> 16];
+      const unsigned p = ((f0 >= thr ? 1u : 0u) | (f1 >= thr ? 2u : 0u) | (f2 >= thr ? 4u : 0u) | (f3 >= thr ? 8u : 0u) |
+                          (f4 >= thr ? 16u : 0u) | (f5 >= thr ? 32u : 0u)) & ((1u << N) - 1u);   // (slots beyond N hold index 0)
       const unsigned o = (wr[3 + (p >> 3)] >> (3u * (p & 7u))) & 7u;
       const uint32_t pair = o <= 2u ? a : (o <= 4u ? b : c);
       which = o ? 8 + (int)o : 0;
@@ -322,15 +331,14 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
     const int cnt = (int)(r.y & 0xffffu);
     const uint32_t* l = lists + r.x;
     for (int c = 0; c < cnt; c += 4) {   // four entries, then their four table words, per pair of dependent trips
-      uint32_t e[4];
-      int fv[4];
+      uint32_t e[4], fv[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) e[u] = l[min(c + u, cnt - 1)];
 #pragma unroll
       for (int u = 0; u < 4; u++) fv[u] = fc[e[u] & 0xffff];
 #pragma unroll
       for (int u = 0; u < 4; u++)
-        if (c + u < cnt) B.consider(e[u], fv[u], i);
+        if (c + u < cnt) B.consider(e[u], fv[u] < thr);
     }
     int d;
     const int m = B.accept(R, d);
@@ -343,11 +351,10 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
     return (int)((R.rec[(size_t)i * 4 + which] >> 16) & 0x1ffu);
   };
   // ---- the recurrence, chunk by chunk in query order ----------------------------------------------------------------
-  // Query i depends on queries j < i only, so once every earlier chunk is final a chunk of kResolveThreads * QPT queries
-  // settles in (longest chain inside the chunk) + 1 rounds -- two for almost every chunk at tracking radii: outcomes
-  // against the table, claims, outcomes again = unchanged.  One table: a round takes the chunk's claims of the previous
-  // round back (a claim landed iff the table word is the query's own index) and applies the new ones.
-  int* fc = fcA;
+  // Query i depends on queries j < i only, so once every earlier chunk is settled a chunk of kResolveThreads * QPT queries
+  // settles in (longest chain inside the chunk) + 1 rounds -- two or three for most chunks at tracking radii: outcomes
+  // against the table, claims, outcomes again = unchanged.  A round is: outcomes (one dependent LDS trip: the chunk's query
+  // words and claim flags stay in registers) | barrier carrying the block-wide "any outcome changed" | claims | barrier.
   // block-wide OR with ONE barrier: three rotating flags (the one of this call is set, the next one cleared, the third may
   // still be read by a wave that has not left the previous call)
   int orPhase = 0;
@@ -360,11 +367,19 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
     orPhase = nextPhase;
     return r;
   };
+  const int maxRounds = min(R.maxRounds, 2000);
+  uint32_t tag = kTagMax;       // tag of the claims the NEXT round reads (none carry it yet)
   int rounds = 0;
   bool serialUsed = false;
   for (int c0 = 0; c0 < nq; c0 += kResolveThreads * QPT) {
+    if (tag < (uint32_t)maxRounds + 4u) {   // the tags are used up (thousands of rounds): forget every unsettled claim, start over
+      for (int k = tid; k < n; k += kResolveThreads)
+        if (fc[k] >> 20) fc[k] = kFree;
+      tag = kTagMax;
+      __syncthreads();
+    }
     int mPrev[QPT], mNew[QPT], wNew[QPT];
-    uint2 rq[QPT];        // the chunk's query words and claim flags stay in registers: a round is one dependent LDS trip
+    uint2 rq[QPT];
     bool cl[QPT];
 #pragma unroll
     for (int u = 0; u < QPT; u++) {
@@ -382,30 +397,22 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
       for (int u = 0; u < QPT; u++) {
         const int i = c0 + u * kResolveThreads + tid;
         if (i < nq) {
-          mNew[u] = eval(i, rq[u], fc, wNew[u]);
+          mNew[u] = eval(rq[u], (tag << 20) | (uint32_t)(i + 1), wNew[u]);
           changed |= mNew[u] != mPrev[u];
         }
       }
       const int any = block_or(changed);
       it++;
       if (!any) break;                   // outcomes are a function of the table and the table of the outcomes: the fixed point
-      serial = it >= R.maxRounds;        // a long chain inside the chunk: one serial pass over it
-      if (it > 1 || serial) {
-#pragma unroll
-        for (int u = 0; u < QPT; u++) {
-          const int i = c0 + u * kResolveThreads + tid;
-          // (an unchanged query keeps its claim; the serial pass starts from the earlier chunks' claims only)
-          if (mPrev[u] >= 0 && (serial || mPrev[u] != mNew[u]) && cl[u] && fc[mPrev[u]] == i) fc[mPrev[u]] = INT_MAX;
-        }
-        __syncthreads();
-      }
-      if (serial) {
+      tag--;                             // this round's claims; everything tentative so far drops out of sight with it
+      if (it >= maxRounds) {             // a long chain inside the chunk: one serial pass over it, settling claims as it goes
+        serial = true;
         if (tid == 0) {
           const int cEnd = min(nq, c0 + kResolveThreads * QPT);
           for (int i = c0; i < cEnd; i++) {
             int w;
-            const int m = eval(i, query_word(i), fc, w);
-            if (m >= 0 && claims(i) && fc[m] == INT_MAX) fc[m] = i;
+            const int m = eval(query_word(i), (tag << 20) | (uint32_t)(i + 1), w);
+            if (m >= 0 && claims(i) && fc[m] >= (tag << 20)) fc[m] = (uint32_t)(i + 1);
             if (LDS) q8[i] = make_uint2((uint32_t)m, (uint32_t)w);
           }
         }
@@ -415,17 +422,21 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
 #pragma unroll
       for (int u = 0; u < QPT; u++) {
         const int i = c0 + u * kResolveThreads + tid;
-        if (mNew[u] >= 0 && cl[u]) atomicMin(&fc[mNew[u]], i);
+        if (mNew[u] >= 0 && cl[u]) atomicMin(&fc[mNew[u]], (tag << 20) | (uint32_t)(i + 1));
         mPrev[u] = mNew[u];
       }
       __syncthreads();
     }
-    if (LDS && !serial) {                // the settled outcome replaces the query word (nobody reads that again)
+    if (!serial) {
+      // settled: the claims lose their tag (the table word of a keypoint two of the chunk's queries accept is the earlier one's
+      // either way), and the outcome replaces the query word (nobody reads that again)
 #pragma unroll
       for (int u = 0; u < QPT; u++) {
         const int i = c0 + u * kResolveThreads + tid;
-        if (i < nq) q8[i] = make_uint2((uint32_t)mNew[u], (uint32_t)wNew[u]);
+        if (mNew[u] >= 0 && cl[u]) atomicMin(&fc[mNew[u]], (uint32_t)(i + 1));
+        if (LDS && i < nq) q8[i] = make_uint2((uint32_t)mNew[u], (uint32_t)wNew[u]);
       }
+      __syncthreads();
     }
     serialUsed |= serial;
     rounds = max(rounds, it);
@@ -436,7 +447,7 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
   // the settled outcome of query i: kept in LDS, or evaluated once more against the final table (global-scratch route)
   auto outcome = [&](int i, int& which) -> int {
     if (LDS) { const uint2 r = q8[i]; which = (int)r.y; return (int)r.x; }
-    return eval(i, query_word(i), fc, which);
+    return eval(query_word(i), (uint32_t)(i + 1), which);   // (tag 0: settled claims only)
   };
   // ---- outputs -----------------------------------------------------------------------------------------------------
   int nm = 0;
@@ -662,6 +673,7 @@ int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint
   HIP_TRY(hipSetDevice(m->device));
   (void)hipGetLastError();
   if (f->device != m->device) { set_err("frame and matcher live on different devices"); return ORBFE_ERR_INVALID; }
+  if (P.nq >= (1 << 20) - 1) { set_err("at most 1 048 574 queries per search"); return ORBFE_ERR_INVALID; }
   const double tA = orbfe_matcher::nowMs();
   hipStream_t st = m->stream;
   const int nq = P.nq, n = P.n;
