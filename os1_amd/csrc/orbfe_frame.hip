@@ -487,7 +487,9 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) nm += __shfl_xor(nm, o, 64);
   if ((tid & 63) == 0 && nm) atomicAdd(&acc[0], nm);
-  __threadfence_system();   // this thread's result words are in host memory before ...
+  // this thread's result words (stores to uncached page-locked memory: no cache to write back -- a system-scope fence per
+  // wave would write the whole L2 back sixteen times) are acknowledged before ...
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
     R.hdrHost[0] = acc[0]; R.hdrHost[2] = rounds; R.hdrHost[3] = LDS ? (poolInLds ? 2 : 1) : 0;

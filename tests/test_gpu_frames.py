@@ -349,3 +349,38 @@ def test_config5_4k_fisheye_resident_frame(api, oracle):
             n, a = m.search_by_projection(fr, None, None, sf, occ, mxy, level, viewcos, flags, desc_rows, th, 0.8)
             assert n == on and (a == oa).all()
         assert n > 1000
+
+
+def test_frame_searches_from_three_threads(api, oracle):
+    """One matcher + resident frame per host thread (a handle is single-threaded, handles are independent): every call's result
+    is the oracle's while three threads search at once; the calls return on the kernels' completion word, not on the stream."""
+    import threading
+    W, H, N = 960, 540, 1000
+    ex = api.Extractor(N, 1.2, 8, 20, 7)
+    k, d = ex(synth(77, W, H))
+    bounds = (0.0, float(W), 0.0, float(H))
+    sf = ex.tables()['sf']
+    occ = np.zeros(len(k), np.uint8)
+    cases = []
+    for t in range(3):
+        rng = np.random.default_rng(100 + t)
+        xy, level, viewcos, flags, mdesc = _mappoints(k, d, 2500 + 700 * t, rng)
+        want = oracle.search_by_projection(k, d, bounds, sf, occ, xy, level, viewcos, flags, mdesc, 2.0 + t, 0.8)
+        cases.append((xy, level, viewcos, flags, mdesc, 2.0 + t, want))
+    bad = [0, 0, 0]
+
+    def work(t):
+        m = api.Matcher()
+        fr = api.Frame.from_host(m, k, d, bounds)
+        xy, level, viewcos, flags, mdesc, th, want = cases[t]
+        for _ in range(150):
+            n, a = m.search_by_projection(fr, None, None, sf, occ, xy, level, viewcos, flags, mdesc, th, 0.8)
+            if n != want[0] or not (a == want[1]).all():
+                bad[t] += 1
+        fr.close()
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(3)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert bad == [0, 0, 0]

@@ -74,10 +74,17 @@ th_c = {1.0: C.c_float(1.0), 5.0: C.c_float(5.0)}
 _fixed = {}
 
 
+# the MapPoints' descriptors kept on the device by the caller (here: as the rows of a resident table built once)
+_kp = np.zeros(n_mp, api.KP_DTYPE)
+_table = api.Frame.from_host(m, _kp, mdesc, bounds)
+dev_rows = _table.descriptors_device()
+
+
 def c_call(th, rows):
     key = id(rows)
     if key not in _fixed:
-        _fixed[key] = (m.h, fr.h, P(sfa), len(sfa), P(occ), P(mxy), P(level), P(viewcos), P(flags), P(rows), n_mp)
+        rp = C.c_void_p(rows.ptr) if isinstance(rows, api.DeviceRows) else P(rows)
+        _fixed[key] = (m.h, fr.h, P(sfa), len(sfa), P(occ), P(mxy), P(level), P(viewcos), P(flags), rp, n_mp)
     rc = m.L.orbfe_search_by_projection_frame(*_fixed[key], th, 0.8, _out[0], _out[1])
     assert rc == 0
 
@@ -87,7 +94,7 @@ _out = (P(assigned), C.byref(nmat))
 
 for th in (1.0, 5.0):
     want = oracle.search_by_projection(kun, d, bounds, sf, occ, mxy, level, viewcos, flags, mdesc, th, 0.8)
-    for name, rows in (('pageable descriptor rows', mdesc), ('page-locked descriptor rows', pin.a)):
+    for name, rows in (('pageable descriptor rows', mdesc), ('page-locked descriptor rows', pin.a), ('device-resident descriptor rows', dev_rows)):
         c_call(th, rows)
         assert nmat.value == want[0] and (assigned == want[1]).all()
         lat = []
