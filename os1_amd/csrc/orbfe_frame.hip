@@ -227,7 +227,7 @@ constexpr int kResolveQpt = 2;   // queries per thread and chunk: 2 048 queries 
 template <int MODE, bool LDS, int QPT>
 __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, int ldsEntries) {
   extern __shared__ __align__(16) int dyn[];
-  __shared__ int hist[32];
+  __shared__ int hist[36];   // 30 bins of the rotation histogram, then the three kept bins
   __shared__ int acc[2];
   __shared__ int orFlag[3];
   const int tid = threadIdx.x, nq = R.nq, n = R.n;
@@ -243,7 +243,8 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
   int* kpAssigned = reinterpret_cast<int*>(fc) + n;                                   // [n]
   uint32_t* claimL = LDS ? reinterpret_cast<uint32_t*>(kpAssigned + n) : nullptr;    // [claimWords]
   uint32_t* occL = LDS ? claimL + claimWords : nullptr;                               // [occWords]
-  uint32_t* ovf = LDS ? occL + occWords : nullptr;                                    // [ldsEntries] the pool's copy
+  const bool withOri = MODE == kModeUv && R.checkOri;
+  uint32_t* ovf = LDS ? occL + occWords : nullptr;                                    // [ldsEntries] the pools' copy
   const uint32_t* claimW = LDS ? claimL : R.claimBits;
   const uint32_t* occW = LDS ? occL : R.occBits;
   auto occupied = [&](int k) -> bool { return R.occBits && ((occW[k >> 5] >> (k & 31)) & 1u) != 0; };
@@ -357,12 +358,26 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
   // words and claim flags stay in registers) | barrier carrying the block-wide "any outcome changed" | claims | barrier.
   // block-wide OR with ONE barrier: three rotating flags (the one of this call is set, the next one cleared, the third may
   // still be read by a wave that has not left the previous call)
+  // a round communicates through LDS only (LDS = true): its barriers wait for the LDS counter, not for vector memory -- the
+  // angle prefetch below stays in flight across the rounds
+  auto round_barrier = [&]() {
+    if (LDS) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else __syncthreads();
+  };
+  // Frame / KeyFrame searches with the rotation check: the angles of the first sources of every thread (they may lie in
+  // page-locked host memory: a PCIe round trip) are requested now and used after the rounds
+  float qaPre[4] = {0.f, 0.f, 0.f, 0.f};
+  if (withOri) {
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+      if (tid + u * kResolveThreads < nq) qaPre[u] = R.qangle[tid + u * kResolveThreads];
+  }
   int orPhase = 0;
   auto block_or = [&](int v) -> int {
     if (__ballot(v != 0) != 0ull && (tid & 63) == 0) orFlag[orPhase] = 1;
     const int nextPhase = orPhase == 2 ? 0 : orPhase + 1;
     if (tid == 0) orFlag[nextPhase] = 0;
-    __syncthreads();
+    round_barrier();
     const int r = orFlag[orPhase];
     orPhase = nextPhase;
     return r;
@@ -425,7 +440,7 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
         if (mNew[u] >= 0 && cl[u]) atomicMin(&fc[mNew[u]], (tag << 20) | (uint32_t)(i + 1));
         mPrev[u] = mNew[u];
       }
-      __syncthreads();
+      round_barrier();
     }
     if (!serial) {
       // settled: the claims lose their tag (the table word of a keypoint two of the chunk's queries accept is the earlier one's
@@ -436,7 +451,7 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
         if (mNew[u] >= 0 && cl[u]) atomicMin(&fc[mNew[u]], (uint32_t)(i + 1));
         if (LDS && i < nq) q8[i] = make_uint2((uint32_t)mNew[u], (uint32_t)wNew[u]);
       }
-      __syncthreads();
+      round_barrier();
     }
     serialUsed |= serial;
     rounds = max(rounds, it);
@@ -450,34 +465,81 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
     return eval(query_word(i), (uint32_t)(i + 1), which);   // (tag 0: settled claims only)
   };
   // ---- outputs -----------------------------------------------------------------------------------------------------
+  // (four queries per thread and step: the angles of the rotation histogram -- the sources' may lie in page-locked host
+  // memory -- are requested together, one PCIe round trip per step instead of one per query; the bin is kept in the query's
+  // LDS word for the second sweep)
   int nm = 0;
-  for (int i = tid; i < nq; i += kResolveThreads) {
-    int w;
-    const int m = outcome(i, w);
-    if (MODE == kModeProjected) { R.outHost[i] = m; R.outHost[nq + i] = m >= 0 ? dist_of(i, w) : -1; }
-    if (m < 0) continue;
-    nm++;
-    if (MODE != kModeProjected) atomicMax(&kpAssigned[m], i);   // F.mvpMapPoints[bestIdx] = pMP: the last writer stays
-    if (MODE == kModeUv && R.checkOri) atomicAdd(&hist[rot_bin_dev(R.qangle[i], R.kangle[m])], 1);
+  for (int i0 = tid; i0 < nq; i0 += 4 * kResolveThreads) {
+    int mm[4], ww[4];
+    float qa[4] = {0.f, 0.f, 0.f, 0.f}, ka[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = i0 + u * kResolveThreads;
+      mm[u] = -1; ww[u] = 0;
+      if (i < nq) mm[u] = outcome(i, ww[u]);
+    }
+    if (withOri) {
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (mm[u] >= 0) { qa[u] = i0 == tid ? qaPre[u] : R.qangle[i0 + u * kResolveThreads]; ka[u] = R.kangle[mm[u]]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = i0 + u * kResolveThreads, m = mm[u];
+      if (i >= nq) continue;
+      if (MODE == kModeProjected) { R.outHost[i] = m; R.outHost[nq + i] = m >= 0 ? dist_of(i, ww[u]) : -1; }
+      if (m < 0) continue;
+      nm++;
+      if (MODE != kModeProjected) atomicMax(&kpAssigned[m], i);   // F.mvpMapPoints[bestIdx] = pMP: the last writer stays
+      if (withOri) {
+        const int bin = rot_bin_dev(qa[u], ka[u]);
+        if (LDS) q8[i].y = (uint32_t)bin;
+        // most matches of a frame-to-frame search share one or two bins: one LDS atomic per distinct bin of the wave
+        // (64 lanes on one address are served one after the other)
+        unsigned long long todo = __ballot(1);
+        while (todo) {
+          const int lead = __builtin_ctzll(todo);
+          const int b0 = __builtin_amdgcn_readlane(bin, lead);
+          const unsigned long long same = __ballot(bin == b0);
+          if ((int)(threadIdx.x & 63) == lead) atomicAdd(&hist[b0], (int)__popcll(same));
+          todo &= ~same;
+          if (bin == b0) break;
+        }
+      }
+    }
   }
   __syncthreads();
-  if (MODE == kModeUv && R.checkOri) {
-    // ComputeThreeMaxima, ORBmatcher.cc:1554-1595 (every thread evaluates it identically); every push of a losing bin
-    // resets its keypoint and takes one off the count (:1404-1416)
-    int max1 = 0, max2 = 0, max3 = 0, ind1 = -1, ind2 = -1, ind3 = -1;
-    for (int i = 0; i < HISTO_LENGTH; i++) {
-      const int s = hist[i];
-      if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
-      else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
-      else if (s > max3) { max3 = s; ind3 = i; }
+  if (withOri) {
+    // ComputeThreeMaxima, ORBmatcher.cc:1554-1595: its sequential scan with strict comparisons keeps the three largest
+    // non-empty bins ordered by (count descending, index ascending) -- three wave-wide maxima over count << 8 | 31 - bin by
+    // the first wave, one lane per bin; every push of a losing bin resets its keypoint and takes one off the count (:1404-1416)
+    if (tid < 64) {
+      const int cnt = tid < HISTO_LENGTH ? hist[tid] : 0;
+      int key = cnt > 0 ? (cnt << 8) | (31 - tid) : 0;
+      int top[3];
+#pragma unroll
+      for (int t = 0; t < 3; t++) {
+        int mx = key;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o, 64));
+        top[t] = mx;
+        if (key == mx) key = 0;
+      }
+      if (tid == 0) {
+        const int max1 = top[0] >> 8, max2 = top[1] >> 8, max3 = top[2] >> 8;
+        int ind1 = top[0] ? 31 - (top[0] & 0xff) : -1, ind2 = top[1] ? 31 - (top[1] & 0xff) : -1, ind3 = top[2] ? 31 - (top[2] & 0xff) : -1;
+        if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+        else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+        hist[30] = ind1; hist[31] = ind2; hist[32] = ind3;
+      }
     }
-    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
-    else if (max3 < 0.1f * (float)max1) { ind3 = -1; }
+    __syncthreads();
+    const int ind1 = hist[30], ind2 = hist[31], ind3 = hist[32];
     for (int i = tid; i < nq; i += kResolveThreads) {
       int w;
       const int m = outcome(i, w);
       if (m < 0) continue;
-      const int b = rot_bin_dev(R.qangle[i], R.kangle[m]);
+      const int b = LDS ? w : rot_bin_dev(R.qangle[i], R.kangle[m]);
       if (b != ind1 && b != ind2 && b != ind3) { kpAssigned[m] = -2; nm--; }
     }
     __syncthreads();

@@ -278,6 +278,33 @@ __global__ __launch_bounds__(kWinThreads) void k_window_match(MatchParams M) {
       if (h && e + u - b < 64) hm |= 1ull << (e + u - b);
     }
   }
+  // pass 1b (searches on a resident frame): candidates whose distance rules them out whatever the other queries do never
+  // enter the list -- shorter lists mean records instead of walked lists and fewer rounds of the bookkeeping, with the
+  // same outcome.  Modes 1, 2 (best <= maxDist decides alone, ORBmatcher.cc:1373-1383, :376-392): dist > maxDist.  Mode 0
+  // (:95-120): a candidate with nnratio * dist >= TH_HIGH can neither be accepted (dist > TH_HIGH) nor, as second best, make
+  // the ratio test reject an acceptable best (bestDist <= TH_HIGH <= nnratio * dist); dropping it leaves, in its place, a
+  // second best that is at least as far, i.e. as irrelevant.  Distances are computed here for the verdict only; the
+  // survivors' entries are produced by pass 2 as before.  Runs beyond the 64-entry mask are left as they are.
+  const uint4* td4 = reinterpret_cast<const uint4*>(tdesc);   // descriptors are grid-sorted, 32-byte rows
+  if (M.rec && hm) {
+    unsigned long long left = hm;
+    while (left) {
+      const int a0 = __builtin_ctzll(left);
+      left &= left - 1;
+      const int a1 = left ? __builtin_ctzll(left) : a0;
+      left &= left - 1;   // (no-op when a1 == a0 was the last bit: left is 0)
+      const uint4 da0 = td4[(size_t)(b + a0) * 2], da1 = td4[(size_t)(b + a0) * 2 + 1], db0 = td4[(size_t)(b + a1) * 2],
+                  db1 = td4[(size_t)(b + a1) * 2 + 1];
+      const int d0 = __popc(da0.x ^ qd[0]) + __popc(da0.y ^ qd[1]) + __popc(da0.z ^ qd[2]) + __popc(da0.w ^ qd[3]) + __popc(da1.x ^ qd[4]) +
+                     __popc(da1.y ^ qd[5]) + __popc(da1.z ^ qd[6]) + __popc(da1.w ^ qd[7]);
+      const int d1 = __popc(db0.x ^ qd[0]) + __popc(db0.y ^ qd[1]) + __popc(db0.z ^ qd[2]) + __popc(db0.w ^ qd[3]) + __popc(db1.x ^ qd[4]) +
+                     __popc(db1.y ^ qd[5]) + __popc(db1.z ^ qd[6]) + __popc(db1.w ^ qd[7]);
+      const bool drop0 = M.codeMode == 0 ? M.nnratio * (float)d0 >= (float)TH_HIGH : d0 > M.maxDist;
+      const bool drop1 = M.codeMode == 0 ? M.nnratio * (float)d1 >= (float)TH_HIGH : d1 > M.maxDist;
+      if (drop0) { hm &= ~(1ull << a0); hits--; }
+      if (drop1 && a1 != a0) { hm &= ~(1ull << a1); hits--; }
+    }
+  }
   int incl = hits;
 #pragma unroll
   for (int o = 1; o < LPQ; o <<= 1) {
@@ -328,7 +355,6 @@ __global__ __launch_bounds__(kWinThreads) void k_window_match(MatchParams M) {
     if (!inRec && off + pos < M.poolCap) M.pool[off + pos] = entry;
     pos++;
   };
-  const uint4* td4 = reinterpret_cast<const uint4*>(tdesc);   // descriptors are grid-sorted, 32-byte rows
   while (hm) {
     const int a0 = __builtin_ctzll(hm);
     hm &= hm - 1;
