@@ -384,3 +384,30 @@ def test_frame_searches_from_three_threads(api, oracle):
     for t in ths:
         t.join()
     assert bad == [0, 0, 0]
+
+
+def test_candidate_pool_grows_on_demand(api, oracle):
+    """Image-sized windows: every source lists hundreds of candidates, far beyond a fresh matcher's candidate pool.  The
+    bookkeeping kernel reports the demand through its header, the call submits again with a pool of that size (the kernels'
+    running counters are back at zero), and the lists -- all of them walked from global memory: they do not fit LDS -- give
+    the oracle's result."""
+    W, H, N = 800, 600, 900
+    ex = api.Extractor(N, 1.2, 6, 20, 7)
+    k, d = ex(synth(91, W, H))
+    bounds = (0.0, float(W), 0.0, float(H))
+    m = api.Matcher()                                          # fresh: the pool has its initial size
+    fr = api.Frame.from_extract(ex, 0, bounds)
+    rng = np.random.default_rng(5)
+    NS = 2500
+    src = rng.integers(0, len(k), NS)
+    sdesc = d[src].copy()
+    puv = np.stack([k['x'][src], k['y'][src]], 1).astype(np.float32)
+    plevel = np.clip(k['octave'][src] + rng.integers(0, 2, NS), 0, 5).astype(np.int32)
+    radius = np.full(NS, 2000.0, np.float32)
+    ok = np.ones(NS, np.uint8)
+    for claim in (False, True):
+        got = m.search_projected(fr, None, None, puv, radius, plevel, ok, sdesc, None, claim, None, 5.99, 256)
+        want = oracle.search_projected(k, d, bounds, puv, radius, plevel, ok, sdesc, None, claim, None, 5.99, 256)
+        assert got[0] == want[0] and got[1].tobytes() == want[1].tobytes() and got[2].tobytes() == want[2].tobytes()
+        assert m.resolve_route() == 1                          # tables in LDS, lists in the pool
+    assert got[0] > 800
