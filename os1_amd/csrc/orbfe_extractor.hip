@@ -40,7 +40,7 @@ void launch_describe(const PyramidParams& P, const SelKp* sel, int nsel, float* 
                      hipStream_t st);
 void launch_sincos(const float* deg, int n, float* c, float* s, hipStream_t st);
 void launch_describe_slots(const PyramidParams& P, const SelKp* sel, int nslots, float* angle, uint8_t* desc,
-                           const uint32_t* selCount, int selPerFrame, const int* selOff, hipStream_t st);
+                           const uint32_t* selCount, int selPerFrame, const int* selOff, hipStream_t st, bool fourWaves);
 int launch_quadtree(const QtParams& Q, int nframes, hipStream_t st, int ldsBudget);
 // orbfe_bow.hip
 int bow_launch_descend(orbfe_vocabulary* v, const uint8_t* d_desc, int n, int levelsup, uint2* d_out, hipStream_t st);
@@ -265,6 +265,7 @@ struct orbfe_extractor {
   std::vector<int> defN, defNm;
   std::vector<int32_t> defM12;
   bool lastGpuQt = false, lastZeroCopy = false, submitZeroCopy = false;   // route of the last collected / submitted batch
+  bool describe4 = true;         // ORBFE_DESCRIBE_WAVES=1: one wave per keypoint in one- / two-frame calls too
   float stageMs[5] = {0, 0, 0, 0, 0};
   hipEvent_t ev[kMaxSub][6] = {};
   double kernMs[5] = {0, 0, 0, 0, 0};
@@ -807,8 +808,9 @@ struct orbfe_extractor {
     }
     const int nslots = nframes * selPerFrame;
     if (prof) HIP_TRY(hipEventRecord(ev[0][4], st));
+    // a one- or two-frame call is alone on the chip and waits for single keypoints: four waves share each one
     launch_describe_slots(P, d_sel.p, nslots, zeroCopy ? h_angle.p : d_angle.p, zeroCopy ? h_desc.p : d_desc.p, d_selCount.p,
-                          selPerFrame, selOff, st);
+                          selPerFrame, selOff, st, describe4 && nframes <= coneMaxFrames);
     if (prof) HIP_TRY(hipEventRecord(ev[0][5], st));
     HIP_TRY(hipGetLastError());
     pendingBow = false;
@@ -1402,6 +1404,7 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
   if (const char* pv = getenv("ORBFE_FAST_PAIRS")) h->pairCells = atoi(pv) != 0;
   if (const char* cv = getenv("ORBFE_CONE_MAX_FRAMES")) h->coneMaxFrames = atoi(cv);
   if (const char* pv = getenv("ORBFE_POLL_WAIT_US")) h->pollWaitUs = atoi(pv);
+  if (const char* dw = getenv("ORBFE_DESCRIBE_WAVES")) h->describe4 = atoi(dw) != 1;
   if (const char* zv = getenv("ORBFE_ZERO_COPY")) h->zeroCopyOut = atoi(zv) != 0;
   if (const char* qv = getenv("ORBFE_QT_LDS_BYTES")) h->qtLdsBudget = atoi(qv);
   if (const char* cv = getenv("ORBFE_CONE_TILE")) h->coneTile = atoi(cv) <= 0 ? 0 : std::max(8, atoi(cv)) & ~3;

@@ -667,9 +667,14 @@ struct SlotInfo {
   int nlevels;
 };
 
-__global__ __launch_bounds__(64) void k_describe(PyramidParams P, const SelKp* __restrict__ sel, int nsel,
-                                                  float* __restrict__ angleOut, uint8_t* __restrict__ descOut,
-                                                  SlotInfo SI) {
+// WAVES = 1: one wave per keypoint (batches: throughput).  WAVES = 4: the same passes spread over a block of four waves
+// (one- and two-frame calls: a keypoint's 760 dependent-ish instructions are the latency of the whole kernel there).
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_describe(PyramidParams P, const SelKp* __restrict__ sel, int nsel,
+                                                          float* __restrict__ angleOut, uint8_t* __restrict__ descOut,
+                                                          SlotInfo SI) {
+  constexpr int NT = 64 * WAVES;
+  __shared__ int icSum[3 * WAVES];
   __shared__ __align__(16) uint8_t raw[kRawW * kRawP + 16];   // + 16: the last row's 4-dword reads
   __shared__ __align__(16) uint16_t hbT[40 * kHPT];            // horizontal pass, transposed: hbT[x][y]
   // blurred 37x37 patch, transposed: blT[x][y].  It reuses the raw patch, which is dead once the horizontal pass
@@ -691,7 +696,7 @@ __global__ __launch_bounds__(64) void k_describe(PyramidParams P, const SelKp* _
     const int frameAbs = P.frameBase + fr;
     if ((uint32_t)(within - SI.selOff[l]) >= SI.selCount[(long long)frameAbs * kMaxLevels + l]) return;
   }
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const SelKp s = sel[k];
   const int cx = s.xy & 0xffff, cy = s.xy >> 16;
   const int level = s.lf & 0xff, f = (s.lf >> 8) & 0xffff;
@@ -714,25 +719,26 @@ __global__ __launch_bounds__(64) void k_describe(PyramidParams P, const SelKp* _
     const uint8_t* rbase = img + m24(cy - kRawRad, istr) + (cx - kRawRad);
     pa = (int)(reinterpret_cast<uintptr_t>(rbase) & 3);
     const int ndw = (pa + kRawW + 3) >> 2;  // 11 or 12
-    // lane (c, r0) = (lane % 16, lane / 16) copies dword column c of rows r0, r0+4, ..., r0+40: 11 loads in flight
-    const int c = lane & 15, r0 = lane >> 4;
+    // thread (c, r0) = (tid % 16, tid / 16) copies dword column c of rows r0, r0 + RS, ...: all loads in flight at once
+    constexpr int RS = NT / 16, NL = (kRawW + RS - 1) / RS;   // 4 rows apart, 11 loads (one wave); 16 apart, 3 loads (four)
+    const int c = tid & 15, r0 = tid >> 4;
     if (c < ndw) {
       const uint8_t* g = rbase - pa + 4 * c + m24(r0, istr);
       uint8_t* l = raw + 4 * c + m24(r0, kRawP);
-      const int gstep = 4 * istr;
-      uint32_t v[11];
+      const int gstep = RS * istr;
+      uint32_t v[NL];
 #pragma unroll
-      for (int u = 0; u < 11; u++) v[u] = (r0 + 4 * u < kRawW) ? *reinterpret_cast<const uint32_t*>(g + u * gstep) : 0u;
+      for (int u = 0; u < NL; u++) v[u] = (r0 + RS * u < kRawW) ? *reinterpret_cast<const uint32_t*>(g + u * gstep) : 0u;
 #pragma unroll
-      for (int u = 0; u < 11; u++)
-        if (r0 + 4 * u < kRawW) *reinterpret_cast<uint32_t*>(l + u * 4 * kRawP) = v[u];
+      for (int u = 0; u < NL; u++)
+        if (r0 + RS * u < kRawW) *reinterpret_cast<uint32_t*>(l + u * RS * kRawP) = v[u];
     }
   } else {
-    for (int i0 = lane; i0 < kRawW * kRawW; i0 += 64 * 8) {
+    for (int i0 = tid; i0 < kRawW * kRawW; i0 += NT * 8) {
       uint8_t v[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) {
-        const int i = i0 + u * 64;
+        const int i = i0 + u * NT;
         v[u] = 0;
         if (i < kRawW * kRawW) {
           const int y = i / kRawW, x = i - y * kRawW;
@@ -742,7 +748,7 @@ __global__ __launch_bounds__(64) void k_describe(PyramidParams P, const SelKp* _
       }
 #pragma unroll
       for (int u = 0; u < 8; u++) {
-        const int i = i0 + u * 64;
+        const int i = i0 + u * NT;
         if (i < kRawW * kRawW) {
           const int y = i / kRawW, x = i - y * kRawW;
           raw[y * kRawP + x] = v[u];
@@ -757,8 +763,8 @@ __global__ __launch_bounds__(64) void k_describe(PyramidParams P, const SelKp* _
   const int sIc = (pa + 6) & 3, qIc = (pa + 6) & ~3;   // patch column u = -15 is raw byte pa + 6 of a row
   int S1 = 0, S2 = 0, S3 = 0;
 #pragma unroll
-  for (int it = 0; it < kIcItems / 64 + 1; it++) {
-    const int i = it * 64 + lane;
+  for (int it = 0; it < (kIcItems + NT - 1) / NT; it++) {
+    const int i = it * NT + tid;
     if (i < kIcItems) {
       const int r = i >> 3, kk = i & 7;
       const uint32_t* rp = reinterpret_cast<const uint32_t*>(raw + m24(r + (kRawRad - 15), kRawP) + qIc + 4 * kk);
@@ -772,6 +778,13 @@ __global__ __launch_bounds__(64) void k_describe(PyramidParams P, const SelKp* _
   S1 = wave_sum_i32(S1);
   S2 = wave_sum_i32(S2);
   S3 = wave_sum_i32(S3);
+  if (WAVES > 1) {   // the waves' partial sums meet in LDS
+    if (lane == 0) { icSum[3 * wave] = S1; icSum[3 * wave + 1] = S2; icSum[3 * wave + 2] = S3; }
+    __syncthreads();
+    S1 = 0; S2 = 0; S3 = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; w++) { S1 += icSum[3 * w]; S2 += icSum[3 * w + 1]; S3 += icSum[3 * w + 2]; }
+  }
   const int m10 = S2 - 15 * S1, m01 = S3 - 15 * S1;
   const float angle = fast_atan2_deg((float)m01, (float)m10);
 
@@ -781,7 +794,7 @@ __global__ __launch_bounds__(64) void k_describe(PyramidParams P, const SelKp* _
   // taps in one dword and runs on v_dot2_u32_u16 (4 outputs per lane, one dword store into the transposed patch).
   {
     const unsigned K0 = 0x38302212u, K1 = 0x00122230u;   // taps 0..3 and 4..6 as bytes
-    for (int i = lane; i < kRawW * 10; i += 64) {
+    for (int i = tid; i < kRawW * 10; i += NT) {
       const int y = (int)(mulu24((unsigned)i, 205u) >> 11), g = i - y * 10;   // i / 10 for i < 1029
       const uint32_t* rp = reinterpret_cast<const uint32_t*>(raw + m24(y, kRawP) + 4 * g);
       const uint32_t d0 = rp[0], d1 = rp[1], d2 = rp[2], d3 = rp[3];
@@ -801,7 +814,7 @@ __global__ __launch_bounds__(64) void k_describe(PyramidParams P, const SelKp* _
     // (lo, hi) tap pairs for an output whose first tap is the LOW half of p0 (even) or the HIGH half (odd)
     const u16x2 E0 = {18, 34}, E1 = {48, 56}, E2 = {48, 34}, E3 = {18, 0};
     const u16x2 O0 = {0, 18}, O1 = {34, 48}, O2 = {56, 48}, O3 = {34, 18};
-    for (int i = lane; i < kBlurW * 10; i += 64) {
+    for (int i = tid; i < kBlurW * 10; i += NT) {
       const int x = (int)(mulu24((unsigned)i, 205u) >> 11), yq = i - x * 10;
       const uint32_t* cp = reinterpret_cast<const uint32_t*>(hbT + m24(x, kHPT) + 4 * yq);
       u16x2 p[5];
@@ -829,9 +842,10 @@ __global__ __launch_bounds__(64) void k_describe(PyramidParams P, const SelKp* _
   const float rad = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, angle * factorPI)));
   sincosf_glibc(rad, &b, &a);  // a = cos, b = sin
   const uint8_t* center = blT + kBlurRad * kBPT + kBlurRad;   // center[x * kBPT + y]
-  unsigned long long words[4];
+  unsigned long long words[4] = {0ull, 0ull, 0ull, 0ull};
 #pragma unroll
   for (int j = 0; j < 4; j++) {
+    if (WAVES == 4 && j != wave) continue;   // four waves: wave j tests bits 64 j .. 64 j + 63
     const int bit = j * 64 + lane;
     const int8_t* p = &c_pattern[4 * bit];
     const float x1 = (float)p[0], y1 = (float)p[1], x2 = (float)p[2], y2 = (float)p[3];
@@ -839,8 +853,12 @@ __global__ __launch_bounds__(64) void k_describe(PyramidParams P, const SelKp* _
     const int t1 = center[__float2int_rn(x2 * a - y2 * b) * kBPT + __float2int_rn(x2 * b + y2 * a)];
     words[j] = __ballot(t0 < t1);
   }
-  if (lane < 4) reinterpret_cast<unsigned long long*>(descOut + (long long)k * 32)[lane] = words[lane];
-  if (lane == 0) angleOut[k] = angle;
+  if (WAVES == 4) {
+    if (lane == 0) reinterpret_cast<unsigned long long*>(descOut + (long long)k * 32)[wave] = words[wave];
+  } else if (lane < 4) {
+    reinterpret_cast<unsigned long long*>(descOut + (long long)k * 32)[lane] = words[lane];
+  }
+  if (tid == 0) angleOut[k] = angle;
 }
 
 __global__ void k_sincos(const float* deg, int n, float* c, float* s) {
@@ -951,19 +969,20 @@ void launch_describe(const PyramidParams& P, const SelKp* sel, int nsel, float* 
   if (nsel <= 0) return;
   SlotInfo si{};
   si.selCount = nullptr;
-  hipLaunchKernelGGL(k_describe, dim3(8 * ((nsel + 7) / 8)), dim3(64), 0, st, P, sel, nsel, angle, desc, si);
+  hipLaunchKernelGGL(k_describe<1>, dim3(8 * ((nsel + 7) / 8)), dim3(64), 0, st, P, sel, nsel, angle, desc, si);
 }
 
 // sel/angle/desc point at the first slot of frame P.frameBase; nslots = nframes * selPerFrame
 void launch_describe_slots(const PyramidParams& P, const SelKp* sel, int nslots, float* angle, uint8_t* desc,
-                           const uint32_t* selCount, int selPerFrame, const int* selOff, hipStream_t st) {
+                           const uint32_t* selCount, int selPerFrame, const int* selOff, hipStream_t st, bool fourWaves) {
   if (nslots <= 0) return;
   SlotInfo si{};
   si.selCount = selCount;
   si.selPerFrame = selPerFrame;
   si.nlevels = P.nlevels;
   for (int l = 0; l <= P.nlevels; l++) si.selOff[l] = selOff[l];
-  hipLaunchKernelGGL(k_describe, dim3(8 * ((nslots + 7) / 8)), dim3(64), 0, st, P, sel, nslots, angle, desc, si);
+  if (fourWaves) hipLaunchKernelGGL(k_describe<4>, dim3(8 * ((nslots + 7) / 8)), dim3(256), 0, st, P, sel, nslots, angle, desc, si);
+  else hipLaunchKernelGGL(k_describe<1>, dim3(8 * ((nslots + 7) / 8)), dim3(64), 0, st, P, sel, nslots, angle, desc, si);
 }
 
 void launch_sincos(const float* deg, int n, float* c, float* s, hipStream_t st) {
