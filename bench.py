@@ -401,7 +401,7 @@ def run_rank(args):
         }
         if world == 1 and not args.no_latency:
             out['config5_search_by_projection'] = config5_leg(api, local_rank, args.cpu_frames > 0)
-            out['tracking_step'] = tracking_step_leg(api, local_rank, frames, W, H, wl)
+            out['tracking_step'] = tracking_step_leg(api, local_rank, frames, W, H, wl, args.cpu_frames > 0)
         if world == 1 and args.cpu_frames > 0:
             out['cpu_baseline'] = cpu_baseline(frames, args.cpu_frames, not args.no_match)
             out['cpu_baseline_all_cores'] = cpu_baseline_all_cores(frames, not args.no_match)
@@ -445,7 +445,7 @@ def load_profile_counters(B):
     return c
 
 
-def tracking_step_leg(api, device, frames, W, H, wl):
+def tracking_step_leg(api, device, frames, W, H, wl, with_oracle_check=True):
     """The front end of ONE tracked frame as Tracking.cc drives it (Frame.cc:133, Tracking.cc:608, 824), blocking calls, outside
     the timed region: ORBextractor::operator() on a page-locked host frame -> the frame's features stay on the GPU
     (orbfe_frame_create_from_extract) -> SearchByProjection(CurrentFrame, LastFrame, th) with the last frame's keypoints as
@@ -454,6 +454,7 @@ def tracking_step_leg(api, device, frames, W, H, wl):
     CurrentFrame, local MapPoints, th) with 3 000 MapPoints.  Median ms per stage over 60 frames."""
     import ctypes as C
     import numpy as np
+    P = lambda a_: a_.ctypes.data_as(C.c_void_p)
     nfr = 61
     pin = api.PinnedFrames([frames[i] for i in range(nfr)])
     ex = api.Extractor(wl.NFEAT, wl.SCALE, wl.NLEVELS, wl.INI_TH, wl.MIN_TH, device=device)
@@ -480,23 +481,48 @@ def tracking_step_leg(api, device, frames, W, H, wl):
             sflags = np.full(len(pk), 8, np.uint8)
             occ = np.zeros(len(k), np.uint8)
             rows = prev_fr.descriptors_device()
+            # the searches are timed as C calls with their arguments prepared, as orb_shim.hpp issues them (the numpy marshalling
+            # of os1_amd.api costs about 0.02 ms per call and is not the library's)
+            lv1 = np.ascontiguousarray(pk['octave'], np.int32)
+            an1 = np.ascontiguousarray(pk['angle'], np.float32)
+            asg = np.full(max(len(k), 1), -1, np.int32)
+            asg2 = np.full(max(len(k), 1), -1, np.int32)
+            nmc = C.c_int(0)
+            uv_args = [m.h, fr.h, P(sf), len(sf), P(occ), P(uv), P(lv1), P(an1), P(sflags), P(valid), P(pd), len(pk), C.c_float(15.0),
+                       100, 0, 1, P(asg), C.byref(nmc)]
             t3 = time.perf_counter()
-            a = m.search_by_projection_uv(fr, None, None, sf, occ, uv, pk['octave'], pk['angle'], sflags, valid, pd, 15.0, 100, 0, True)
+            rc = m.L.orbfe_search_by_projection_uv_frame(*uv_args)
             t4 = time.perf_counter()
-            a2 = m.search_by_projection_uv(fr, None, None, sf, occ, uv, pk['octave'], pk['angle'], sflags, valid, rows, 15.0, 100, 0, True)
-            t_ffd.append(time.perf_counter() - t4)
-            if a2[0] != a[0] or not (a2[1] == a[1]).all():
+            a = (nmc.value, asg[:len(k)].copy())
+            uv_args[10] = C.c_void_p(rows.ptr)
+            uv_args[16] = P(asg2)
+            t4b = time.perf_counter()
+            rc |= m.L.orbfe_search_by_projection_uv_frame(*uv_args)
+            t_ffd.append(time.perf_counter() - t4b)
+            if rc or nmc.value != a[0] or not (asg2[:len(k)] == a[1]).all():
                 raise SystemExit('bench: device-resident and host descriptor rows disagree')
             src = rng.integers(0, len(k), 3000)
             mxy = (np.stack([k['x'][src], k['y'][src]], 1) + rng.uniform(-2, 2, (3000, 2))).astype(np.float32)
-            lvl = k['octave'][src].astype(np.int32)
+            lvl = np.ascontiguousarray(k['octave'][src], np.int32)
             vcos = np.full(3000, 0.95, np.float32)
             fl = np.full(3000, 1 | 8, np.uint8)
             occ2 = (a[1] >= 0).astype(np.uint8)
             md = np.ascontiguousarray(d[src])
+            mp_args = (m.h, fr.h, P(sf), len(sf), P(occ2), P(mxy), P(lvl), P(vcos), P(fl), P(md), 3000, C.c_float(3.0), C.c_float(0.8),
+                       P(asg), C.byref(nmc))
             t5 = time.perf_counter()
-            b = m.search_by_projection(fr, None, None, sf, occ2, mxy, lvl, vcos, fl, md, 3.0, 0.8)
+            rc = m.L.orbfe_search_by_projection_frame(*mp_args)
             t6 = time.perf_counter()
+            if rc:
+                raise SystemExit('bench: SearchByProjection failed')
+            b = (nmc.value, asg[:len(k)].copy())
+            if i == 1 and with_oracle_check:   # one frame of the sequence against the oracle (the parity tests cover the rest)
+                from oracle.pyoracle import Oracle
+                o = Oracle()
+                ou = o.search_by_projection_uv(k, d, bounds, sf, occ, uv, lv1, an1, sflags, valid, pd, 15.0, 100, 0, True)
+                om = o.search_by_projection(k, d, bounds, sf, occ2, mxy, lvl, vcos, fl, md, 3.0, 0.8)
+                if ou[0] != a[0] or not (ou[1] == a[1]).all() or om[0] != b[0] or not (om[1] == b[1]).all():
+                    raise SystemExit('bench: tracking-step searches differ from the oracle')
             t_ex.append(t1 - t0); t_fr.append(t2 - t1); t_ff.append(t4 - t3); t_mp.append(t6 - t5)
             nm1.append(a[0]); nm2.append(b[0])
         prev = (k, d)
@@ -509,7 +535,7 @@ def tracking_step_leg(api, device, frames, W, H, wl):
     return {'extract_host_frame_ms': med(t_ex), 'resident_frame_from_extract_ms': med(t_fr), 'search_by_projection_last_frame_ms': med(t_ff), 'search_by_projection_last_frame_device_rows_ms': med(t_ffd),
             'search_by_projection_mappoints_ms': med(t_mp), 'front_end_total_ms': round(med(t_ex) + med(t_fr) + med(t_ff) + med(t_mp), 4),
             'matches_last_frame_median': int(np.median(nm1)), 'matches_mappoints_median': int(np.median(nm2)),
-            'note': '1080p / 2000 features, 60 frames; the search timings include the Python marshalling of the test harness (about 0.02 ms per call)'}
+            'note': '1080p / 2000 features, 60 frames; blocking C calls (extract from a page-locked host frame; searches with prepared arguments)'}
 
 
 def config5_leg(api, device, with_oracle):
