@@ -96,6 +96,24 @@ class MatcherContext {
   ~MatcherContext() {
     for (auto& e : cache_) orbfe_frame_destroy(e.frame);
     orbfe_matcher_destroy(m_);
+    for (auto& s : scratch_)
+      if (s.p) orbfe_host_free(s.p);
+  }
+  // Page-locked scratch array `slot` of at least n elements, zero-filled on request: what the per-frame searches marshal their
+  // MapPoint snapshots into.  The search kernels read page-locked arrays in place (no copy inside the library), and the
+  // arrays are reused from call to call (no allocation per search).  Valid until the next request for the same slot.
+  template <class T>
+  T* scratch(int slot, size_t n, bool zero) {
+    Scratch& s = scratch_[slot];
+    const size_t bytes = (n ? n : 1) * sizeof(T);
+    if (bytes > s.bytes) {
+      if (s.p) orbfe_host_free(s.p);
+      s.p = nullptr; s.bytes = 0;
+      check(orbfe_host_alloc(bytes + bytes / 2, &s.p));
+      s.bytes = bytes + bytes / 2;
+    }
+    if (zero) std::memset(s.p, 0, bytes);
+    return static_cast<T*>(s.p);
   }
   MatcherContext(const MatcherContext&) = delete;
   MatcherContext& operator=(const MatcherContext&) = delete;
@@ -151,6 +169,8 @@ class MatcherContext {
   orbfe_matcher* m_ = nullptr;
   size_t cap_ = 48, uploads_ = 0;
   std::vector<Entry> cache_;
+  struct Scratch { void* p = nullptr; size_t bytes = 0; };
+  Scratch scratch_[8];
 };
 
 namespace detail {
@@ -203,13 +223,21 @@ template <class FrameT, class MapPointT>
 inline int SearchByProjection(MatcherContext& ctx, float mfNNratio, FrameT& F,
                               const std::vector<MapPointT*>& vpMapPoints, const float th) {
   const int n = (int)F.mvKeysUn.size(), nmp = (int)vpMapPoints.size();
-  std::vector<uint8_t> occ(n, 0), flags(nmp, 0), mdesc((size_t)nmp * 32, 0), tmp;
-  std::vector<float> xy((size_t)nmp * 2, 0.f), vcos(nmp, 0.f);
-  std::vector<int32_t> lvl(nmp, 0), assigned(n, -1);
+  // snapshots go into the context's page-locked arrays (flags and levels zeroed: an absent MapPoint is "not in view", level 0)
+  uint8_t* occ = ctx.scratch<uint8_t>(0, n, true);
+  uint8_t* flags = ctx.scratch<uint8_t>(1, nmp, true);
+  uint8_t* mdesc = ctx.scratch<uint8_t>(2, (size_t)nmp * 32, false);
+  float* xy = ctx.scratch<float>(3, (size_t)nmp * 2, false);
+  float* vcos = ctx.scratch<float>(4, nmp, false);
+  int32_t* lvl = ctx.scratch<int32_t>(5, nmp, true);
+  int32_t* assigned = ctx.scratch<int32_t>(6, n, false);
+  std::vector<uint8_t> tmp;
+  for (int i = 0; i < n; i++) assigned[i] = -1;
   for (int i = 0; i < n; i++)
     if (F.mvpMapPoints[i] && F.mvpMapPoints[i]->Observations() > 0) occ[i] = 1;
   for (int i = 0; i < nmp; i++) {
     MapPointT* p = vpMapPoints[i];
+    xy[2 * i] = 0.f; xy[2 * i + 1] = 0.f; vcos[i] = 0.f;
     if (!p->mbTrackInView) continue;
     if (p->isBad()) { flags[i] = ORBFE_MP_IN_VIEW | ORBFE_MP_BAD; continue; }
     flags[i] = ORBFE_MP_IN_VIEW | (p->plCandidato ? ORBFE_MP_CANDIDATO : 0) |
@@ -225,14 +253,13 @@ inline int SearchByProjection(MatcherContext& ctx, float mfNNratio, FrameT& F,
   detail::frameBounds(F, b);
   int nmatches = 0;
   if (orbfe_frame* rf = ctx.resident(F, 0))
-    check(orbfe_search_by_projection_frame(ctx.get(), rf, F.mvScaleFactors.data(), (int)F.mvScaleFactors.size(), occ.data(),
-                                           xy.data(), lvl.data(), vcos.data(), flags.data(), mdesc.data(), nmp, th, mfNNratio,
-                                           assigned.data(), &nmatches));
+    check(orbfe_search_by_projection_frame(ctx.get(), rf, F.mvScaleFactors.data(), (int)F.mvScaleFactors.size(), occ,
+                                           xy, lvl, vcos, flags, mdesc, nmp, th, mfNNratio, assigned, &nmatches));
   else
     check(orbfe_search_by_projection(ctx.get(), reinterpret_cast<const OrbfeKeyPoint*>(F.mvKeysUn.data()),
                                      detail::packedDescriptors(F.mDescriptors, n, tmp), n, b, F.mvScaleFactors.data(),
-                                     (int)F.mvScaleFactors.size(), occ.data(), xy.data(), lvl.data(), vcos.data(),
-                                     flags.data(), mdesc.data(), nmp, th, mfNNratio, assigned.data(), &nmatches));
+                                     (int)F.mvScaleFactors.size(), occ, xy, lvl, vcos, flags, mdesc, nmp, th, mfNNratio,
+                                     assigned, &nmatches));
   for (int i = 0; i < n; i++)
     if (assigned[i] >= 0) F.mvpMapPoints[i] = vpMapPoints[assigned[i]];
   return nmatches;
@@ -371,9 +398,17 @@ inline int SearchByProjection(MatcherContext& ctx, bool mbCheckOrientation, Fram
   float Rcw[9], tcw[3];
   detail::poseRt(CurrentFrame.mTcw, Rcw, tcw);
   const int n = (int)CurrentFrame.mvKeysUn.size(), ns = (int)LastFrame.N;
-  std::vector<float> uv((size_t)ns * 2, 0.f), ang(ns, 0.f);
-  std::vector<int32_t> lvl(ns, 0), assigned(n > 0 ? n : 1, -1);
-  std::vector<uint8_t> valid(ns, 0), flags(ns, 0), sdesc((size_t)ns * 32, 0), occ(n > 0 ? n : 1, 0), tmp;
+  // the context's page-locked arrays (see SearchByProjection(F, MapPoints) above); valid / flags / levels zeroed
+  float* uv = ctx.scratch<float>(3, (size_t)ns * 2, true);
+  float* ang = ctx.scratch<float>(4, ns, true);
+  int32_t* lvl = ctx.scratch<int32_t>(5, ns, true);
+  int32_t* assigned = ctx.scratch<int32_t>(6, n, false);
+  uint8_t* valid = ctx.scratch<uint8_t>(7, ns, true);
+  uint8_t* flags = ctx.scratch<uint8_t>(1, ns, true);
+  uint8_t* sdesc = ctx.scratch<uint8_t>(2, (size_t)ns * 32, false);
+  uint8_t* occ = ctx.scratch<uint8_t>(0, n, true);
+  std::vector<uint8_t> tmp;
+  for (int i = 0; i < n; i++) assigned[i] = -1;
   for (int i = 0; i < n; i++)
     if (CurrentFrame.mvpMapPoints[i] && CurrentFrame.mvpMapPoints[i]->Observations() > 0) occ[i] = 1;   // :1364-1366
   for (int i = 0; i < ns; i++) {
@@ -402,15 +437,15 @@ inline int SearchByProjection(MatcherContext& ctx, bool mbCheckOrientation, Fram
   int nmatches = 0;
   if (orbfe_frame* rf = ctx.resident(CurrentFrame, 0))
     check(orbfe_search_by_projection_uv_frame(ctx.get(), rf, CurrentFrame.mvScaleFactors.data(), (int)CurrentFrame.mvScaleFactors.size(),
-                                              occ.data(), uv.data(), lvl.data(), ang.data(), flags.data(), valid.data(), sdesc.data(),
+                                              occ, uv, lvl, ang, flags, valid, sdesc,
                                               ns, th, /*TH_HIGH*/ 100, /*skip_any_occupied*/ 0, mbCheckOrientation ? 1 : 0,
-                                              assigned.data(), &nmatches));
+                                              assigned, &nmatches));
   else
     check(orbfe_search_by_projection_uv(ctx.get(), reinterpret_cast<const OrbfeKeyPoint*>(CurrentFrame.mvKeysUn.data()),
                                         detail::packedDescriptors(CurrentFrame.mDescriptors, n, tmp), n, b,
-                                        CurrentFrame.mvScaleFactors.data(), (int)CurrentFrame.mvScaleFactors.size(), occ.data(),
-                                        uv.data(), lvl.data(), ang.data(), flags.data(), valid.data(), sdesc.data(), ns, th,
-                                        /*TH_HIGH*/ 100, /*skip_any_occupied*/ 0, mbCheckOrientation ? 1 : 0, assigned.data(),
+                                        CurrentFrame.mvScaleFactors.data(), (int)CurrentFrame.mvScaleFactors.size(), occ,
+                                        uv, lvl, ang, flags, valid, sdesc, ns, th,
+                                        /*TH_HIGH*/ 100, /*skip_any_occupied*/ 0, mbCheckOrientation ? 1 : 0, assigned,
                                         &nmatches));
   for (int i = 0; i < n; i++) {
     if (assigned[i] >= 0) CurrentFrame.mvpMapPoints[i] = LastFrame.mvpMapPoints[assigned[i]];
