@@ -222,6 +222,7 @@ struct orbfe_extractor {
   DevBuf<ConeRange> d_coneTab;
   ConeParams cone{};
   bool coneOk = false;
+  bool qtJump = true;             // ORBFE_QT_JUMP=0: every pass of the quadtree is an ordinary sweep
   int qtLdsBudget = 120 * 1024;   // LDS bytes a quadtree problem may use for its candidates in small batches
   int pollWaitUs = 0;             // > 0: collect polls the stream and sleeps this long between polls
   bool zeroCopyOut = true;        // small plain batches: results written to host memory by the kernels
@@ -784,6 +785,7 @@ struct orbfe_extractor {
     // the last kernel.  Matching and bag-of-words read angles / descriptors on the device and keep the copy.
     const bool zeroCopy = zeroCopyOut && nframes <= coneMaxFrames && !voc && !(ms && ms->chain);
     submitZeroCopy = zeroCopy;
+    QP.jump = qtJump ? 1 : 0;
     QP.selHost = zeroCopy ? h_sel.p : nullptr;
     QP.selCountHost = zeroCopy ? h_selCount.p : nullptr;
     for (int l = 0; l < nlevels; l++) {
@@ -1407,6 +1409,7 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
   if (const char* dw = getenv("ORBFE_DESCRIBE_WAVES")) h->describe4 = atoi(dw) != 1;
   if (const char* zv = getenv("ORBFE_ZERO_COPY")) h->zeroCopyOut = atoi(zv) != 0;
   if (const char* qv = getenv("ORBFE_QT_LDS_BYTES")) h->qtLdsBudget = atoi(qv);
+  if (const char* qj = getenv("ORBFE_QT_JUMP")) h->qtJump = atoi(qj) != 0;
   if (const char* cv = getenv("ORBFE_CONE_TILE")) h->coneTile = atoi(cv) <= 0 ? 0 : std::max(8, atoi(cv)) & ~3;
   if (const char* pv = getenv("ORBFE_PROFILE_KERNELS")) h->profileKernels = atoi(pv) != 0;
   h->selPerFrame = 0;

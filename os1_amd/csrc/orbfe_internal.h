@@ -162,6 +162,7 @@ struct QtParams {
   // device-to-host copy command after the last kernel); nullptr = none
   SelKp* selHost;
   uint32_t* selCountHost;
+  int jump;                    // != 0: the first passes of a dense level (every node divides) in one sweep (orbfe_quadtree.hip)
 };
 
 

@@ -180,7 +180,122 @@ __device__ __forceinline__ void qt3_problem(const QtParams& Q, Qt3Shared<CAP>& s
   const float hX = static_cast<float>(maxX - kBorder) / nIni;
   int m = 0;
   uint32_t seq = 0;
-  {
+  bool finalPhase = false;
+  int nRec = 0;
+  // ---- the first passes of a dense level in one sweep -------------------------------------------------------------
+  // While every node holds more than one candidate and all four children of every node are non-empty, the walk's result
+  // after pass t is known in closed form: the list has nIni * 4^t nodes, the child q of the node at list position i is
+  // created (4 i + q)-th in its pass and -- children go to the FRONT -- sits at position (m_t - 1) - (4 i + q); boxes follow
+  // from DivideNode's ceil-halving along the path.  So instead of the root pass and T full sweeps (new node through the
+  // child table, quadrant, one count each) ONE sweep walks every candidate T levels down by arithmetic and counts it at its
+  // leaf.  T = the passes the reference runs before its final phase when every node divides (pass t + 1 is an ordinary one
+  // iff t == 0 or 4 m_t <= N, ORBextractor.cc:642-731); the jump is taken only if every leaf received a candidate,
+  // otherwise the ordinary passes start from the roots as always.
+  bool jumped = false;
+  int T = 0, mT = nIni;
+  if (Q.jump) {
+    int mt = nIni;
+    while (T < 3 && (T == 0 || 4 * mt <= N) && mt * 4 <= CAP) { mt *= 4; T++; }
+    mT = mt;
+  }
+  if (T >= 2 && n >= 8 * mT) {
+    int rl = 5;
+    while (rl > 0 && (mT << rl) > CAP * 4) rl--;
+    for (int i = tid; i < (mT << rl); i += kQt3Threads) sh.cnt[i] = 0u;
+    __syncthreads();
+    const int yTop = maxY - kBorder;
+    for (int b = 0; b < n; b += kQtEpt * kQt3Threads) {
+      uint32_t v[kQtEpt];
+#pragma unroll
+      for (int j = 0; j < kQtEpt; j++) {
+        const int p = b + j * kQt3Threads + tid;
+        v[j] = p < n ? cand[p] : 0u;
+      }
+#pragma unroll
+      for (int j = 0; j < kQtEpt; j++) {
+        const int p = b + j * kQt3Threads + tid;
+        if (p < n) {
+          const int x = (int)(v[j] & 0xfff) - kBorder, y = (int)((v[j] >> 12) & 0xfff) - kBorder;
+          const int r = min((int)((float)x / hX), nIni - 1);
+          int x0 = (int)(hX * static_cast<float>(r)), x1 = (int)(hX * static_cast<float>(r + 1)), y0 = 0, y1 = yTop;
+          int pos = r, mt = nIni, created = 0, q = 0;
+          for (int t = 1; t <= T; t++) {
+            const int midX = x0 + ((x1 - x0 + 1) >> 1), midY = y0 + ((y1 - y0 + 1) >> 1);
+            const int qx = x < midX ? 0 : 1, qy = y < midY ? 0 : 1;
+            q = qx + 2 * qy;
+            x0 = qx ? midX : x0; x1 = qx ? x1 : midX; y0 = qy ? midY : y0; y1 = qy ? y1 : midY;
+            created = 4 * pos + q;
+            mt *= 4;
+            if (t < T) pos = (mt - 1) - created;
+          }
+          if (LC) candL[p] = v[j];
+          ca.setOwn(p, (unsigned)created);          // parent's position * 4 + quadrant: what an ordinary sweep leaves
+          atomicAdd(&sh.cnt[(((mT - 1) - created) << rl) + (tid & ((1 << rl) - 1))], 1u);
+        }
+      }
+    }
+    __syncthreads();
+    int empty = 0;
+    for (int g = tid; g < mT; g += kQt3Threads) {
+      uint32_t t = 0;
+      for (int k = 0; k < (1 << rl); k++) t += sh.cnt[(g << rl) + k];
+      sh.cnt[g << rl] = t;
+      empty |= t == 0u;
+    }
+    jumped = __syncthreads_or(empty) == 0;
+    if (jumped) {
+      // the nodes of the list after pass T, their child table, and the record of those with more than one candidate
+      const int mPrev = mT >> 2;
+      uint32_t seqBase = (uint32_t)nIni;
+      for (int t = 1, mt = nIni; t < T; t++) { mt *= 4; seqBase += (uint32_t)mt; }
+      for (int p = tid; p < mT; p += kQt3Threads) {
+        int digits[3], c = (mT - 1) - p, mt = mT;
+        for (int t = T; t >= 1; t--) {      // created index at pass t -> quadrant and the parent's position
+          digits[t - 1] = c & 3;
+          const int parentPos = c >> 2;
+          mt >>= 2;
+          c = t > 1 ? (mt - 1) - parentPos : parentPos;   // (pass 0: the position is the root index)
+        }
+        const int r = c;
+        int x0 = (int)(hX * static_cast<float>(r)), x1 = (int)(hX * static_cast<float>(r + 1)), y0 = 0, y1 = yTop;
+        for (int t = 0; t < T; t++) {
+          const int midX = x0 + ((x1 - x0 + 1) >> 1), midY = y0 + ((y1 - y0 + 1) >> 1);
+          const int qd = digits[t];
+          x0 = (qd & 1) ? midX : x0; x1 = (qd & 1) ? x1 : midX; y0 = (qd & 2) ? midY : y0; y1 = (qd & 2) ? y1 : midY;
+        }
+        Qt3Node nd;
+        nd.x0 = (short)x0; nd.x1 = (short)x1; nd.y0 = (short)y0; nd.y1 = (short)y1;
+        nd.size = sh.cnt[p << rl];
+        nd.seq = seqBase + (uint32_t)((mT - 1) - p);
+        cur[p] = nd;
+      }
+      for (int i = tid; i < mPrev * 4; i += kQt3Threads) (&sh.cpos[0][0])[i] = (uint16_t)((mT - 1) - i);
+      __syncthreads();
+      m = mT;
+      seq = seqBase + (uint32_t)mT;
+      int recFlag[IPT], locR = 0;
+#pragma unroll
+      for (int k = 0; k < IPT; k++) {
+        const int i = IPT * tid + k;
+        recFlag[k] = (i < mT && cur[i].size > 1) ? 1 : 0;
+        locR += recFlag[k];
+      }
+      int totR;
+      int exR = blockScanInt3<CAP>(sh, locR, totR);
+#pragma unroll
+      for (int k = 0; k < IPT; k++) {
+        const int i = IPT * tid + k;
+        if (recFlag[k]) {
+          const Qt3Node nd = cur[i];
+          sh.sortKeys[exR++] = ((unsigned long long)nd.size << 40) | ((unsigned long long)nd.seq << 16) | (unsigned long long)i;
+        }
+      }
+      nRec = totR;
+      __syncthreads();
+      finalPhase = m + 3 * totR > N;   // (what the end of pass T decides; m < N or m == N are handled by the loop's entry test below)
+    }
+  }
+  if (!jumped) {
     if (tid < 128) sh.cnt[tid] = 0u;
     __syncthreads();
     for (int b = 0; b < n; b += kQtEpt * kQt3Threads) {
@@ -232,9 +347,10 @@ __device__ __forceinline__ void qt3_problem(const QtParams& Q, Qt3Shared<CAP>& s
     seq = (uint32_t)nIni;
     __syncthreads();
   }
-  bool finalPhase = false;
-  int nRec = 0;
+  // (after a jump the walk continues where pass T's end-of-pass tests leave it: done when the list reached N -- ORBextractor.cc:
+  // 642-650 -- or nothing is left to divide)
   for (int iter = 0; iter < 64; iter++) {
+    if (jumped && iter == 0 && (m >= N || (finalPhase && nRec == 0))) break;
     const int prevSize = m;
     int nproc = 0;
     // ---- processing order + per-node split info ----------------------------------------------------
