@@ -167,6 +167,7 @@ struct ResolveParams {
                             // kp_assigned[n] (modes 0, 1) or best_idx[nq], best_dist[nq] (mode 2)
   int* hdrHost;             // [kHdr] result header, page-locked host memory
   int maxRounds;
+  uint32_t tagMax;          // first round tag (kTagMax; the tests start lower to exercise the re-basing of used-up tags)
   int seq;                  // the call's number: written to hdrHost[5] last of all (the host polls it instead of waiting on the stream)
 };
 
@@ -383,14 +384,14 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(ResolveParams R, in
     return r;
   };
   const int maxRounds = min(R.maxRounds, 2000);
-  uint32_t tag = kTagMax;       // tag of the claims the NEXT round reads (none carry it yet)
+  uint32_t tag = R.tagMax;      // tag of the claims the NEXT round reads (none carry it yet)
   int rounds = 0;
   bool serialUsed = false;
   for (int c0 = 0; c0 < nq; c0 += kResolveThreads * QPT) {
     if (tag < (uint32_t)maxRounds + 4u) {   // the tags are used up (thousands of rounds): forget every unsettled claim, start over
       for (int k = tid; k < n; k += kResolveThreads)
         if (fc[k] >> 20) fc[k] = kFree;
-      tag = kTagMax;
+      tag = R.tagMax;
       __syncthreads();
     }
     int mPrev[QPT], mNew[QPT], wNew[QPT];
@@ -871,6 +872,8 @@ int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint
     R.hdrHost = m->h_r.p; R.outHost = m->h_r.p + kHdr;
     const char* mr = getenv("ORBFE_RESOLVE_MAX_ROUNDS");   // rounds of the fixed point before the serial finish
     R.maxRounds = mr ? std::max(1, atoi(mr)) : 48;
+    const char* tm = getenv("ORBFE_RESOLVE_TAG_MAX");     // (tests) first round tag: a small one makes the kernel run out of tags
+    R.tagMax = tm ? (uint32_t)std::min(std::max(atoi(tm), R.maxRounds + 8), (int)kTagMax) : kTagMax;
     m->seq = m->seq == INT_MAX ? 1 : m->seq + 1;
     R.seq = m->seq;
     // LDS-resident tables when they fit (152 KB of the CU's 160): offsets, two table generations, claim bits; what is

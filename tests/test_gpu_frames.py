@@ -260,6 +260,12 @@ def test_bookkeeping_bound_and_serial_finish(api, oracle, monkeypatch):
         w = oracle.search_projected(k, d, bounds, xy, radius, level, ok, mdesc, None, True, None, 5.99, 100)
         assert g[0] == w[0] and g[1].tobytes() == w[1].tobytes() and g[2].tobytes() == w[2].tobytes()
     monkeypatch.delenv('ORBFE_RESOLVE_MAX_ROUNDS')
+    # the round tags of the claim table run out (here after a handful of rounds instead of four thousand): unsettled claims
+    # are forgotten and the tags start over, chunk after chunk
+    monkeypatch.setenv('ORBFE_RESOLVE_TAG_MAX', '57')
+    got = m.search_by_projection(fr, d, bounds, sf, occ, xy, level, viewcos, flags, mdesc, 8.0, 0.95)
+    assert got[0] == want[0] and (got[1] == want[1]).all() and m.resolve_rounds() == free_rounds
+    monkeypatch.delenv('ORBFE_RESOLVE_TAG_MAX')
 
 
 def test_tracking_shaped_sequence_on_one_resident_frame(api, oracle):
