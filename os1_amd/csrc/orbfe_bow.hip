@@ -13,6 +13,8 @@
 // (double, so the order is part of the result), the L1/L2 normalisation in ascending word order, grouping feature
 // indices by node, and the rotation-histogram pruning.
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <chrono>
 
 #include <algorithm>
 #include <cmath>
@@ -147,22 +149,133 @@ __global__ void __launch_bounds__(256) k_bow_descend(const uint4* __restrict__ d
 struct BowPair { int b1, e1, b2, e2, base1; };   // [b,e) ranges into fv1_feat / fv2_feat; base1 = first descriptor row of side 1's
                                                    // frame in desc1 / valid1 / matches12 (several keyframes against one frame in one launch)
 
-__global__ void __launch_bounds__(64) k_bow_match(const uint4* __restrict__ desc1, const uint8_t* __restrict__ valid1,
-                                                  const uint32_t* __restrict__ feat1, const uint4* __restrict__ desc2,
-                                                  const uint8_t* __restrict__ valid2, const uint32_t* __restrict__ feat2,
-                                                  const BowPair* __restrict__ pairs, int maxDist, float nnratio,
-                                                  int32_t* __restrict__ matches12) {
+// Round 3: the distances of a node's pairs do not depend on the bookkeeping, so they are computed first, all pairs in
+// parallel by the block's four waves, into an LDS matrix (nodes of up to kBowMatrix pairs; larger ones compute them inside
+// the walk as before); the sequential walk over the node's frame-1 features -- which F feature is already matched decides
+// what the next one may take, ORBmatcher.cc:196-222 -- then costs one LDS row and two wave-wide minima per feature instead
+// of a chain of global loads (84 -> 12 us for two 2 000-feature frames over 100 nodes).
+constexpr int kBowThreads = 256;
+constexpr int kBowMatrix = 12288;
+constexpr int kBowSide = 256;      // features of one frame under a node handled from LDS (lists, descriptors, distances)
+__global__ void __launch_bounds__(kBowThreads) k_bow_match(const uint4* __restrict__ desc1, const uint8_t* __restrict__ valid1,
+                                                           const uint32_t* __restrict__ feat1, const uint4* __restrict__ desc2,
+                                                           const uint8_t* __restrict__ valid2, const uint32_t* __restrict__ feat2,
+                                                           const BowPair* __restrict__ pairs, int maxDist, float nnratio,
+                                                           int32_t* __restrict__ matches12, unsigned* doneCounter, int* doneHost,
+                                                           int doneSeq) {
   __shared__ unsigned matched[(kMaxGroup + 1) / 32];
+  __shared__ uint16_t dmat[kBowMatrix];
+  __shared__ uint32_t row1[kBowSide], row2[kBowSide];   // descriptor rows of the node's features; | 0x80000000: not valid
+  __shared__ uint4 d1s[2 * kBowSide], d2s[2 * kBowSide];   // their descriptors
   const BowPair P = pairs[blockIdx.x];
-  const int lane = threadIdx.x;
-  const int n2g = P.e2 - P.b2;
-  for (int i = lane; i < (n2g + 31) / 32; i += 64) matched[i] = 0;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int n1g = P.e1 - P.b1, n2g = P.e2 - P.b2;
+  for (int i = tid; i < (n2g + 31) / 32; i += kBowThreads) matched[i] = 0;
+  const bool inLds = n1g <= kBowSide && n2g <= kBowSide;
+  // completion word (the route without copy commands: inputs read from, matches written to page-locked host memory): the
+  // block's stores are acknowledged, it counts itself off, the last one writes the call's number for the polling host
+  auto done = [&]() {
+    if (!doneCounter || tid != 0) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (atomicAdd(doneCounter, 1u) != gridDim.x - 1u) return;
+    *doneCounter = 0u;
+    __threadfence_system();
+    __hip_atomic_store(doneHost, doneSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  };
+  auto accept = [&](unsigned k1, unsigned k2, unsigned idx1, auto row2Of) {
+    const unsigned best = wave_min(k1);
+    const unsigned second = wave_min(k1 == best ? k2 : k1) >> 16;   // least distance among everything but the winner
+    const int bestDist = (int)(best >> 16);
+    if (bestDist <= maxDist && static_cast<float>(bestDist) < nnratio * static_cast<float>((int)second)) {
+      const int p = (int)(best & 0xffffu);
+      if (lane == 0) {
+        matches12[idx1] = (int32_t)row2Of(p);
+        matched[p >> 5] |= 1u << (p & 31);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the update is in LDS before the next feature's scan reads it
+    }
+  };
+  if (inLds) {
+    // the node's feature lists and descriptors first -- the walk below must not chase global pointers: every dependent
+    // load there is a microsecond per frame-1 feature --
+    for (int i = tid; i < n1g; i += kBowThreads) {
+      const unsigned idx1 = (unsigned)P.base1 + feat1[P.b1 + i];
+      row1[i] = idx1 | (valid1[idx1] ? 0u : 0x80000000u);
+      d1s[2 * i] = desc1[2 * (size_t)idx1]; d1s[2 * i + 1] = desc1[2 * (size_t)idx1 + 1];
+    }
+    for (int i = tid; i < n2g; i += kBowThreads) {
+      const unsigned idx2 = feat2[P.b2 + i];
+      row2[i] = idx2 | ((valid2 && !valid2[idx2]) ? 0x80000000u : 0u);
+      d2s[2 * i] = desc2[2 * (size_t)idx2]; d2s[2 * i + 1] = desc2[2 * (size_t)idx2 + 1];
+    }
+    __syncthreads();
+    // ... then, for as many frame-1 features at a time as the matrix holds: the distances of all their pairs by the whole
+    // block, the walk over them by the first wave
+    const int rowsPer = min(kBowThreads, max(1, kBowMatrix / n2g));
+    for (int r0 = 0; r0 < n1g; r0 += rowsPer) {
+      const int rows = min(rowsPer, n1g - r0);
+      int r = tid / n2g, p = tid - r * n2g;
+      for (int t = tid; t < rows * n2g; t += kBowThreads) {
+        int d = 256;   // (a pair that the walk skips: it can neither win nor pull the second-best below its initial 256)
+        if (!((row1[r0 + r] | row2[p]) & 0x80000000u)) d = hamming256(d1s[2 * (r0 + r)], d1s[2 * (r0 + r) + 1], d2s[2 * p], d2s[2 * p + 1]);
+        dmat[t] = (uint16_t)d;
+        p += kBowThreads;
+        while (p >= n2g) { p -= n2g; r++; }
+      }
+      __syncthreads();
+      if (tid < 64) {   // (one wave: its LDS operations execute in order)
+        // a lane's (up to four) distances of the NEXT feature's row and its row word travel while the current feature is
+        // decided; the matched bits are the only thing read after the previous feature's update (ds_or, not waited for)
+        constexpr int kPer = kBowSide / 64;
+        unsigned dn[kPer], idxN = row1[r0];
+#pragma unroll
+        for (int j = 0; j < kPer; j++) dn[j] = (lane + 64 * j < n2g) ? dmat[lane + 64 * j] : 256u;
+        for (int rr = 0; rr < rows; rr++) {
+          unsigned dc[kPer];
+          const unsigned idx1 = idxN;
+#pragma unroll
+          for (int j = 0; j < kPer; j++) dc[j] = dn[j];
+          if (rr + 1 < rows) {
+            idxN = row1[r0 + rr + 1];
+            const uint16_t* nrow = dmat + (rr + 1) * n2g;
+#pragma unroll
+            for (int j = 0; j < kPer; j++) dn[j] = (lane + 64 * j < n2g) ? nrow[lane + 64 * j] : 256u;
+          }
+          if (idx1 & 0x80000000u) continue;   // wave-uniform
+          unsigned k1 = (256u << 16) | 0xffffu, k2 = k1;   // lane-local least and second-least key (distance << 16 | position)
+#pragma unroll
+          for (int j = 0; j < kPer; j++) {
+            const int pp = lane + 64 * j;
+            if (dc[j] >= 256u || ((matched[(pp >> 5) & (kBowSide / 32 - 1)] >> (pp & 31)) & 1u)) continue;
+            const unsigned key = (dc[j] << 16) | (unsigned)pp;
+            if (key < k1) { k2 = k1; k1 = key; }
+            else if (key < k2) k2 = key;
+          }
+          const unsigned best = wave_min(k1);
+          const unsigned second = wave_min(k1 == best ? k2 : k1) >> 16;   // least distance among everything but the winner
+          const int bestDist = (int)(best >> 16);
+          if (bestDist <= maxDist && static_cast<float>(bestDist) < nnratio * static_cast<float>((int)second)) {
+            const int q = (int)(best & 0xffffu);
+            if (lane == 0) {
+              matches12[idx1] = (int32_t)row2[q];
+              atomicOr(&matched[q >> 5], 1u << (q & 31));
+            }
+            asm volatile("" ::: "memory");
+          }
+        }
+      }
+      __syncthreads();
+    }
+    done();
+    return;
+  }
   __syncthreads();
+  if (tid >= 64) return;   // larger nodes: the walk computes its distances itself
   for (int i1 = P.b1; i1 < P.e1; i1++) {
     const unsigned idx1 = (unsigned)P.base1 + feat1[i1];
     if (!valid1[idx1]) continue;   // wave-uniform
     const uint4 a0 = desc1[2 * (size_t)idx1], a1 = desc1[2 * (size_t)idx1 + 1];
-    unsigned k1 = (256u << 16) | 0xffffu, k2 = k1;   // lane-local least and second-least key (distance << 16 | position)
+    unsigned k1 = (256u << 16) | 0xffffu, k2 = k1;
     for (int p = lane; p < n2g; p += 64) {
       const unsigned idx2 = feat2[P.b2 + p];
       const bool skip = ((matched[p >> 5] >> (p & 31)) & 1u) || (valid2 && !valid2[idx2]);
@@ -171,18 +284,9 @@ __global__ void __launch_bounds__(64) k_bow_match(const uint4* __restrict__ desc
       if (key < k1) { k2 = k1; k1 = key; }
       else if (key < k2) k2 = key;
     }
-    const unsigned best = wave_min(k1);
-    const unsigned second = wave_min(k1 == best ? k2 : k1) >> 16;   // least distance among everything but the winner
-    const int bestDist = (int)(best >> 16);
-    if (bestDist <= maxDist && static_cast<float>(bestDist) < nnratio * static_cast<float>((int)second)) {
-      const int p = (int)(best & 0xffffu);
-      if (lane == 0) {
-        matches12[idx1] = (int32_t)feat2[P.b2 + p];
-        matched[p >> 5] |= 1u << (p & 31);
-      }
-      __syncthreads();   // one wave per block: orders the LDS update before the next scan
-    }
+    accept(k1, k2, idx1, [&](int q) { return feat2[P.b2 + q]; });
   }
+  done();
 }
 
 // SearchForTriangulation inner search (ORBmatcher.cc:695-747): the reference never sets vbMatched2, so every
@@ -494,6 +598,9 @@ struct BowScratch {
   DevBuf<OrbfeKeyPoint> d_kps1, d_kps2;
   DevBuf<uint8_t> d_arena;    // batched search: everything that goes up in one copy
   PinBuf<uint8_t> h_arena;
+  DevBuf<unsigned> d_done;    // route without copy commands: block counter, the call's number (page-locked)
+  PinBuf<int> h_done;
+  int seq = 0;
 };
 
 // common vocabulary nodes of two FeatureVectors (the lower_bound zig-zag of ORBmatcher.cc:175-258 visits exactly the
@@ -607,15 +714,49 @@ extern "C" int orbfe_search_by_bow_batch(orbfe_matcher* m, int n_kf, const uint8
   if (nf2) memcpy(H + oF2, fv2_features, 4 * (size_t)nf2);
   memcpy(H + oP, all.data(), sizeof(BowPair) * all.size());
   hipStream_t st = orbfe::matcher_stream(m);
-  uint8_t* D = S->d_arena.p;
-  HIP_TRY(hipMemcpyAsync(D, H, total, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemsetAsync(S->d_m12.p, 0xff, sizeof(int32_t) * rows1, st));
-  hipLaunchKernelGGL(k_bow_match, dim3((unsigned)all.size()), dim3(64), 0, st, (const uint4*)(D + oD1), (const uint8_t*)(D + oV1),
-                     (const uint32_t*)(D + oF1), (const uint4*)(D + oD2), valid2 ? (const uint8_t*)(D + oV2) : (const uint8_t*)nullptr,
-                     (const uint32_t*)(D + oF2), (const BowPair*)(D + oP), strict_threshold ? TH_LOW - 1 : TH_LOW, nnratio, S->d_m12.p);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(S->h_m12.p, S->d_m12.p, sizeof(int32_t) * rows1, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  // Nodes whose two feature lists fit the kernel's LDS (up to kBowSide features per side: every node of a real vocabulary at
+  // levelsup 4) are read ONCE per feature, so the kernel reads the page-locked arena itself and writes the matches into
+  // page-locked memory: no copy command, no fill, and the host polls the kernel's completion word instead of waiting on the
+  // stream (ORBFE_BOW_ZEROCOPY=0, or a larger node: upload, fill, launch, download as before).
+  bool small = true;
+  for (const BowPair& p : all) small = small && p.e1 - p.b1 <= kBowSide && p.e2 - p.b2 <= kBowSide;
+  const char* zce = getenv("ORBFE_BOW_ZEROCOPY");   // (read per call: the parity tests run both routes in one process)
+  const bool zc = !(zce && atoi(zce) == 0);
+  if (small && zc) {
+    if (!S->d_done.p) {
+      if ((rc = S->d_done.ensure(16)) || (rc = S->h_done.ensure(16))) return rc;
+      HIP_TRY(hipMemsetAsync(S->d_done.p, 0, 16 * sizeof(unsigned), st));
+      S->h_done.p[0] = 0;
+    }
+    memset(S->h_m12.p, 0xff, sizeof(int32_t) * rows1);
+    S->seq = S->seq == INT_MAX ? 1 : S->seq + 1;
+    hipLaunchKernelGGL(k_bow_match, dim3((unsigned)all.size()), dim3(kBowThreads), 0, st, (const uint4*)(H + oD1), (const uint8_t*)(H + oV1),
+                       (const uint32_t*)(H + oF1), (const uint4*)(H + oD2), valid2 ? (const uint8_t*)(H + oV2) : (const uint8_t*)nullptr,
+                       (const uint32_t*)(H + oF2), (const BowPair*)(H + oP), strict_threshold ? TH_LOW - 1 : TH_LOW, nnratio, S->h_m12.p,
+                       S->d_done.p, S->h_done.p, S->seq);
+    HIP_TRY(hipGetLastError());
+    const volatile int* flag = S->h_done.p;
+    bool seen = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 1;; spin++) {
+      if (*flag == S->seq) { seen = true; break; }
+      if ((spin & 255u) == 0 && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 2.0) break;
+      __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (!seen) HIP_TRY(hipStreamSynchronize(st));
+  } else {
+    uint8_t* D = S->d_arena.p;
+    HIP_TRY(hipMemcpyAsync(D, H, total, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(S->d_m12.p, 0xff, sizeof(int32_t) * rows1, st));
+    hipLaunchKernelGGL(k_bow_match, dim3((unsigned)all.size()), dim3(kBowThreads), 0, st, (const uint4*)(D + oD1), (const uint8_t*)(D + oV1),
+                       (const uint32_t*)(D + oF1), (const uint4*)(D + oD2), valid2 ? (const uint8_t*)(D + oV2) : (const uint8_t*)nullptr,
+                       (const uint32_t*)(D + oF2), (const BowPair*)(D + oP), strict_threshold ? TH_LOW - 1 : TH_LOW, nnratio, S->d_m12.p,
+                       (unsigned*)nullptr, (int*)nullptr, 0);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(S->h_m12.p, S->d_m12.p, sizeof(int32_t) * rows1, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
   for (int k = 0; k < n_kf; k++) {
     int nm = 0;
     const int32_t* src = S->h_m12.p + rowBase[k];

@@ -70,14 +70,18 @@ def test_compute_bow_of_extracted_frames_full_size_vocabulary(api, oracle):
     v.close()
 
 
-@pytest.mark.parametrize('levelsup', [0, 1, 3])
-def test_search_by_bow_parity(api, oracle, levelsup):
+@pytest.mark.parametrize('levelsup', [0, 1, 2, 3])
+def test_search_by_bow_parity(api, oracle, levelsup, monkeypatch):
     """Synthetic descriptor sets with many true correspondences; levelsup 3 on an L=3 tree puts every feature under
-    the root (one group of several hundred features per side)."""
+    the root (one group of several hundred features per side: the kernel's walk computes its distances itself, inputs go up by
+    a copy command); levelsup 2 with 2 000 features gives ten groups of about 200 x 220 (lists and descriptors in LDS, the
+    distance matrix in tiles of rows); lower levels: small groups, everything in LDS, no copy command at all."""
     image = synth_vocabulary(6, 10, 3)
     ov = oracle.vocabulary(image)
     m = api.Matcher()
-    for seed, n1, n2 in [(7, 400, 450), (9, 1, 300), (10, 900, 70)]:
+    if levelsup == 1:
+        monkeypatch.setenv('ORBFE_BOW_ZEROCOPY', '0')          # small groups through the upload / download route too
+    for seed, n1, n2 in [(7, 400, 450), (9, 1, 300), (10, 900, 70), (11, 2000, 2200)]:
         d1, a1, v1, d2, a2, v2 = make_bow_pair(seed, image, n1, n2)
         fv1, fv2 = ov.transform(d1, levelsup)[2], ov.transform(d2, levelsup)[2]
         total = 0
