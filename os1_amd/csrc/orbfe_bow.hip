@@ -252,9 +252,10 @@ __global__ void __launch_bounds__(kBowThreads) k_bow_match(const uint4* __restri
             else if (key < k2) k2 = key;
           }
           const unsigned best = wave_min(k1);
-          const unsigned second = wave_min(k1 == best ? k2 : k1) >> 16;   // least distance among everything but the winner
           const int bestDist = (int)(best >> 16);
-          if (bestDist <= maxDist && static_cast<float>(bestDist) < nnratio * static_cast<float>((int)second)) {
+          if (bestDist > maxDist) continue;   // (wave-uniform; most features end here: the second-best is not needed)
+          const unsigned second = wave_min(k1 == best ? k2 : k1) >> 16;   // least distance among everything but the winner
+          if (static_cast<float>(bestDist) < nnratio * static_cast<float>((int)second)) {
             const int q = (int)(best & 0xffffu);
             if (lane == 0) {
               matches12[idx1] = (int32_t)row2[q];
