@@ -402,6 +402,7 @@ def run_rank(args):
         if world == 1 and not args.no_latency:
             out['config5_search_by_projection'] = config5_leg(api, local_rank, args.cpu_frames > 0)
             out['tracking_step'] = tracking_step_leg(api, local_rank, frames, W, H, wl, args.cpu_frames > 0)
+            out['bow'] = bow_leg(api, local_rank, frames, W, H, wl, args.cpu_frames > 0)
         if world == 1 and args.cpu_frames > 0:
             out['cpu_baseline'] = cpu_baseline(frames, args.cpu_frames, not args.no_match)
             out['cpu_baseline_all_cores'] = cpu_baseline_all_cores(frames, not args.no_match)
@@ -536,6 +537,45 @@ def tracking_step_leg(api, device, frames, W, H, wl, with_oracle_check=True):
             'search_by_projection_mappoints_ms': med(t_mp), 'front_end_total_ms': round(med(t_ex) + med(t_fr) + med(t_ff) + med(t_mp), 4),
             'matches_last_frame_median': int(np.median(nm1)), 'matches_mappoints_median': int(np.median(nm2)),
             'note': '1080p / 2000 features, 60 frames; blocking C calls (extract from a page-locked host frame; searches with prepared arguments)'}
+
+
+def bow_leg(api, device, frames, W, H, wl, with_oracle):
+    """The bag-of-words calls of the keyframe / relocalisation path, outside the timed region: Frame::ComputeBoW (DBoW2 transform
+    at levelsup 4 on a k = 10, L = 6 vocabulary of synthetic words -- ORBvoc's shape; the real file is not on the box) and
+    ORBmatcher::SearchByBoW between two consecutive frames of the stream, blocking calls through os1_amd.api, median ms of 60."""
+    import numpy as np
+    from os1_amd.synth import synth_vocabulary
+    image = synth_vocabulary(1, 10, 6)
+    v = api.Vocabulary(image, device)
+    ex = api.Extractor(wl.NFEAT, wl.SCALE, wl.NLEVELS, wl.INI_TH, wl.MIN_TH, device=device)
+    (k1, d1), (k2, d2) = ex(frames[0]), ex(frames[1])
+    m = api.Matcher(device)
+
+    def med(fn, reps):
+        fn()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return round(float(np.median(ts)) * 1e3, 4)
+    t1, t2 = v.transform(d1, 4), v.transform(d2, 4)
+    v1 = np.ones(len(k1), np.uint8)
+    out = {'compute_bow_ms': med(lambda: v.transform(d1, 4), 60),
+           'search_by_bow_ms': med(lambda: m.search_by_bow(d1, k1['angle'], v1, t1[2], d2, k2['angle'], None, t2[2], 0.7, True), 60),
+           'features': [int(len(k1)), int(len(k2))], 'common_nodes': int(len(np.intersect1d(t1[2][0], t2[2][0])))}
+    got = m.search_by_bow(d1, k1['angle'], v1, t1[2], d2, k2['angle'], None, t2[2], 0.7, True)
+    out['matches'] = int(got[0])
+    if with_oracle:
+        from oracle.pyoracle import Oracle
+        o = Oracle()
+        ov = o.vocabulary(image)
+        out['oracle_1core_compute_bow_ms'] = med(lambda: ov.transform(d1, 4), 3)
+        out['oracle_1core_search_by_bow_ms'] = med(lambda: o.search_by_bow(d1, k1['angle'], v1, t1[2], d2, k2['angle'], None, t2[2], 0.7, True), 3)
+        want = o.search_by_bow(d1, k1['angle'], v1, t1[2], d2, k2['angle'], None, t2[2], 0.7, True)
+        out['equal_to_oracle'] = bool(want[0] == got[0] and (want[1] == got[1]).all())
+    v.close()
+    return out
 
 
 def config5_leg(api, device, with_oracle):
