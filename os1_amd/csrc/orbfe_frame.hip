@@ -7,16 +7,18 @@
 // arrays (one upload) or straight from the extractor's result arena, where the features were produced microseconds
 // earlier (orbfe_frame_create_from_extract: no descriptor ever crosses PCIe again).
 //
-// A search on a resident frame is one stream submission: upload of the queries -> k_window_match (candidate lists in
-// reference order, in HBM) -> k_resolve (the reference's sequential bookkeeping) -> download of the result vector.
+// A search on a resident frame is one stream submission of two kernels, without a copy command: k_window_match reads the
+// caller's query arrays where they are (page-locked or device memory; ordinary memory is first memcpy'd into a page-locked
+// arena) and leaves the candidate lists in reference order as packed records -> k_resolve (the reference's sequential
+// bookkeeping) writes the result vector and, last of all, the call's number into page-locked memory, which the host polls.
 // The bookkeeping of ORBmatcher::SearchByProjection (src/ORBmatcher.cc:45-124), the Frame / KeyFrame projection
 // searches (:1292-1552) and the projected best-match loops (:357-392, :872-936, :1014-1050, :1066-1290) is sequential
 // only through ONE mechanism: an accepted match may make its keypoint unavailable to LATER queries (mvpMapPoints
 // occupancy with Observations() > 0, :89-91 / :1364-1366 / :1493-1494; vpMatched, :376-377).  The outcome of query i is
 // therefore a function of its own candidate list and of {outcomes of queries j < i}, a recurrence with exactly one
-// solution; k_resolve iterates all queries in parallel until nothing changes (round k fixes at least queries 0..k-1, in
-// practice a handful of rounds) and finishes with a serial pass if a bound on the rounds is hit -- the same scheme as
-// k_sfi_resolve (orbfe_sfi.hip).
+// solution; k_resolve settles it chunk by chunk in query order, each chunk by rounds of "outcomes against the claim
+// table -> claims" until nothing changes, and finishes a chunk with a serial pass if a bound on the rounds is hit -- the
+// same idea as k_sfi_resolve (orbfe_sfi.hip).
 #include "orbfe_matcher_internal.h"
 #include <atomic>
 #include "orbfe_internal.h"
@@ -876,7 +878,7 @@ int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint
     R.tagMax = tm ? (uint32_t)std::min(std::max(atoi(tm), R.maxRounds + 8), (int)kTagMax) : kTagMax;
     m->seq = m->seq == INT_MAX ? 1 : m->seq + 1;
     R.seq = m->seq;
-    // LDS-resident tables when they fit (152 KB of the CU's 160): offsets, two table generations, claim bits; what is
+    // LDS-resident tables when they fit (152 KB of the CU's 160): query words, claim table, kp_assigned, flag masks; what is
     // left holds the candidate entries (the kernel checks their number at run time)
     const size_t fixedBytes = 4 * (2 * (size_t)nq + 2 * (size_t)n + (((size_t)nq + 31) >> 5) + (((size_t)n + 31) >> 5) + 8);
     const size_t budget = 152 * 1024;
