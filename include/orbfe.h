@@ -511,7 +511,9 @@ int orbfe_bow_assemble(orbfe_vocabulary* v, const uint32_t* leaf_node, const uin
  * not bad; valid2 likewise for side 2 (NULL = every keypoint is a candidate, as for a Frame).  angle1 / angle2: the
  * keypoints' angles (needed when check_orientation).  fvX_*: the FeatureVectors in the layout
  * orbfe_bow_transform writes.  matches12[i1] = matched index on side 2 or -1 (capacity n1); for the Frame overload
- * vpMapPointMatches[matches12[i1]] = vpMapPointsKF[i1].  *nmatches = the function's return value. */
+ * vpMapPointMatches[matches12[i1]] = vpMapPointsKF[i1].  *nmatches = the function's return value.
+ * desc1 / desc2 may point to host memory or to 16-byte aligned rows in the matcher's device memory (a resident frame's
+ * descriptors, orbfe_frame_descriptors_device): such a side is not copied anywhere. */
 int orbfe_search_by_bow(orbfe_matcher* m, const uint8_t* desc1, const float* angle1, const uint8_t* valid1, int n1,
                         const uint32_t* fv1_nodes, const uint32_t* fv1_offsets, const uint32_t* fv1_features, int n_fv1,
                         const uint8_t* desc2, const float* angle2, const uint8_t* valid2, int n2,

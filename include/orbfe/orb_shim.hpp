@@ -183,6 +183,16 @@ inline const uint8_t* packedDescriptors(const MatT& m, int n, std::vector<uint8_
   for (int i = 0; i < n; i++) std::memcpy(&tmp[(size_t)i * 32], m.data + (size_t)i * m.step, 32);
   return tmp.data();
 }
+
+// The descriptor rows of F for the bag-of-words searches: its resident copy's rows in device memory when the context's cache
+// is on (nothing is copied then), else the packed host rows.
+template <class FrameLike>
+inline const uint8_t* descriptorRows(MatcherContext& ctx, const FrameLike& F, int kind, int n, std::vector<uint8_t>& tmp) {
+  if (n > 0)
+    if (orbfe_frame* rf = ctx.resident(F, kind))
+      if (const uint8_t* rows = orbfe_frame_descriptors_device(rf)) return rows;
+  return packedDescriptors(F.mDescriptors, n, tmp);
+}
 template <class FrameT>
 inline void frameBounds(const FrameT& F, float b[4]) {
   b[0] = F.mnMinX; b[1] = F.mnMaxX; b[2] = F.mnMinY; b[3] = F.mnMaxY;
@@ -811,9 +821,9 @@ inline int SearchByBoW(MatcherContext& ctx, float mfNNratio, bool mbCheckOrienta
   detail::flattenFeatureVector(F.mFeatVec, n2v, o2v, f2v);
   std::vector<int32_t> m12(n1 > 0 ? n1 : 1, -1);
   int nmatches = 0;
-  check(orbfe_search_by_bow(ctx.get(), detail::packedDescriptors(pKF->mDescriptors, n1, t1), a1.data(), valid1.data(), n1,
+  check(orbfe_search_by_bow(ctx.get(), detail::descriptorRows(ctx, *pKF, 1, n1, t1), a1.data(), valid1.data(), n1,
                             n1v.data(), o1v.data(), f1v.data(), (int)n1v.size(),
-                            detail::packedDescriptors(F.mDescriptors, n2, t2), a2.data(), nullptr, n2, n2v.data(),
+                            detail::descriptorRows(ctx, F, 0, n2, t2), a2.data(), nullptr, n2, n2v.data(),
                             o2v.data(), f2v.data(), (int)n2v.size(), mfNNratio, mbCheckOrientation ? 1 : 0, 0, m12.data(),
                             &nmatches));
   for (int i = 0; i < n1; i++)
@@ -894,9 +904,9 @@ inline int SearchByBoW(MatcherContext& ctx, float mfNNratio, bool mbCheckOrienta
   std::vector<int32_t> m12(n1 > 0 ? n1 : 1, -1);
   if (valid2.empty()) valid2.push_back(0);
   int nmatches = 0;
-  check(orbfe_search_by_bow(ctx.get(), detail::packedDescriptors(pKF1->mDescriptors, n1, t1), a1.data(), valid1.data(), n1,
+  check(orbfe_search_by_bow(ctx.get(), detail::descriptorRows(ctx, *pKF1, 1, n1, t1), a1.data(), valid1.data(), n1,
                             n1v.data(), o1v.data(), f1v.data(), (int)n1v.size(),
-                            detail::packedDescriptors(pKF2->mDescriptors, n2, t2), a2.data(), valid2.data(), n2,
+                            detail::descriptorRows(ctx, *pKF2, 1, n2, t2), a2.data(), valid2.data(), n2,
                             n2v.data(), o2v.data(), f2v.data(), (int)n2v.size(), mfNNratio, mbCheckOrientation ? 1 : 0, 1,
                             m12.data(), &nmatches));
   for (int i = 0; i < n1; i++)

@@ -648,21 +648,22 @@ class Matcher:
         """ORBmatcher::SearchByBoW; fvX = (nodes, offsets, features) as returned by Vocabulary.transform.
         valid2=None is the (KeyFrame, Frame) overload, strict=True + valid2 the (KeyFrame, KeyFrame) one.
         Returns (nmatches, matches12)."""
-        desc1 = np.ascontiguousarray(desc1, np.uint8)
-        desc2 = np.ascontiguousarray(desc2, np.uint8)
+        n1, n2 = len(desc1), len(desc2)                       # (numpy rows or DeviceRows: a resident frame's descriptors)
+        d1p, _k1 = _rows(desc1)
+        d2p, _k2 = _rows(desc2)
         angle1 = np.ascontiguousarray(angle1, np.float32)
         angle2 = np.ascontiguousarray(angle2, np.float32)
         valid1 = np.ascontiguousarray(valid1, np.uint8)
         v2 = None if valid2 is None else np.ascontiguousarray(valid2, np.uint8)
         f1 = [np.ascontiguousarray(a, np.uint32) for a in fv1]
         f2 = [np.ascontiguousarray(a, np.uint32) for a in fv2]
-        m12 = np.full(max(len(desc1), 1), -1, np.int32)
+        m12 = np.full(max(n1, 1), -1, np.int32)
         nm = C.c_int(0)
-        _check(self.L.orbfe_search_by_bow(self.h, _p(desc1), _p(angle1), _p(valid1), len(desc1), _p(f1[0]), _p(f1[1]),
-                                          _p(f1[2]), len(f1[0]), _p(desc2), _p(angle2), None if v2 is None else _p(v2),
-                                          len(desc2), _p(f2[0]), _p(f2[1]), _p(f2[2]), len(f2[0]), nnratio,
+        _check(self.L.orbfe_search_by_bow(self.h, d1p, _p(angle1), _p(valid1), n1, _p(f1[0]), _p(f1[1]),
+                                          _p(f1[2]), len(f1[0]), d2p, _p(angle2), None if v2 is None else _p(v2),
+                                          n2, _p(f2[0]), _p(f2[1]), _p(f2[2]), len(f2[0]), nnratio,
                                           int(check_ori), int(strict), _p(m12), C.byref(nm)))
-        return nm.value, m12[:len(desc1)]
+        return nm.value, m12[:n1]
 
     def search_by_bow_batch(self, sides1, desc2, angle2, valid2, fv2, nnratio=0.7, check_ori=True, strict=False):
         """Tracking::Relocalization's SearchByBoW loop in one GPU submission: sides1 = [(desc1, angle1, valid1, fv1)] per

@@ -655,13 +655,15 @@ int prune_by_orientation(const float* angle1, size_t stride1, const float* angle
 // Tracking::Relocalization (src/Tracking.cc:1005-1030: one SearchByBoW per candidate keyframe, all against mCurrentFrame) --
 // as ONE upload, ONE launch of k_bow_match over every (keyframe, common vocabulary node) pair and ONE download.  The
 // searches are independent (each has its own vpMapPointMatches / matched set), so results equal the per-keyframe calls.
-extern "C" int orbfe_search_by_bow_batch(orbfe_matcher* m, int n_kf, const uint8_t* const* desc1, const float* const* angle1,
-                                         const uint8_t* const* valid1, const int* n1, const uint32_t* const* fv1_nodes,
-                                         const uint32_t* const* fv1_offsets, const uint32_t* const* fv1_features, const int* n_fv1,
-                                         const uint8_t* desc2, const float* angle2, const uint8_t* valid2, int n2,
-                                         const uint32_t* fv2_nodes, const uint32_t* fv2_offsets, const uint32_t* fv2_features,
-                                         int n_fv2, float nnratio, int check_orientation, int strict_threshold,
-                                         int32_t* const* matches12, int* nmatches) {
+// dev1 / dev2 != nullptr (single keyframe only): that side's descriptor rows already lie in device memory (a resident
+// frame's, orbfe_frame_descriptors_device) -- they are neither copied into the arena nor read from it
+static int bow_batch_core(orbfe_matcher* m, int n_kf, const uint8_t* const* desc1, const float* const* angle1,
+                          const uint8_t* const* valid1, const int* n1, const uint32_t* const* fv1_nodes,
+                          const uint32_t* const* fv1_offsets, const uint32_t* const* fv1_features, const int* n_fv1,
+                          const uint8_t* desc2, const float* angle2, const uint8_t* valid2, int n2,
+                          const uint32_t* fv2_nodes, const uint32_t* fv2_offsets, const uint32_t* fv2_features,
+                          int n_fv2, float nnratio, int check_orientation, int strict_threshold,
+                          int32_t* const* matches12, int* nmatches, const uint4* dev1, const uint4* dev2) {
   if (!m || n_kf < 0 || n2 < 0 || n_fv2 < 0 || (n_kf && (!desc1 || !valid1 || !n1 || !fv1_nodes || !fv1_offsets || !fv1_features || !n_fv1 ||
       !matches12 || !nmatches)) || (n2 > 0 && !desc2) || (n_fv2 > 0 && (!fv2_nodes || !fv2_offsets || !fv2_features)) ||
       (check_orientation && (!angle2 || !angle1))) {
@@ -704,13 +706,13 @@ extern "C" int orbfe_search_by_bow_batch(orbfe_matcher* m, int n_kf, const uint8
   uint8_t* H = S->h_arena.p;
   for (int k = 0; k < n_kf; k++) {
     if (n1[k]) {
-      memcpy(H + oD1 + 32 * rowBase[k], desc1[k], 32 * (size_t)n1[k]);
+      if (!dev1) memcpy(H + oD1 + 32 * rowBase[k], desc1[k], 32 * (size_t)n1[k]);
       memcpy(H + oV1 + rowBase[k], valid1[k], (size_t)n1[k]);
     }
     const size_t nf1 = featBase[k + 1] - featBase[k];
     if (nf1) memcpy(H + oF1 + 4 * featBase[k], fv1_features[k], 4 * nf1);
   }
-  if (n2) memcpy(H + oD2, desc2, 32 * (size_t)n2);
+  if (n2 && !dev2) memcpy(H + oD2, desc2, 32 * (size_t)n2);
   if (valid2 && n2) memcpy(H + oV2, valid2, (size_t)n2);
   if (nf2) memcpy(H + oF2, fv2_features, 4 * (size_t)nf2);
   memcpy(H + oP, all.data(), sizeof(BowPair) * all.size());
@@ -731,8 +733,8 @@ extern "C" int orbfe_search_by_bow_batch(orbfe_matcher* m, int n_kf, const uint8
     }
     memset(S->h_m12.p, 0xff, sizeof(int32_t) * rows1);
     S->seq = S->seq == INT_MAX ? 1 : S->seq + 1;
-    hipLaunchKernelGGL(k_bow_match, dim3((unsigned)all.size()), dim3(kBowThreads), 0, st, (const uint4*)(H + oD1), (const uint8_t*)(H + oV1),
-                       (const uint32_t*)(H + oF1), (const uint4*)(H + oD2), valid2 ? (const uint8_t*)(H + oV2) : (const uint8_t*)nullptr,
+    hipLaunchKernelGGL(k_bow_match, dim3((unsigned)all.size()), dim3(kBowThreads), 0, st, dev1 ? dev1 : (const uint4*)(H + oD1), (const uint8_t*)(H + oV1),
+                       (const uint32_t*)(H + oF1), dev2 ? dev2 : (const uint4*)(H + oD2), valid2 ? (const uint8_t*)(H + oV2) : (const uint8_t*)nullptr,
                        (const uint32_t*)(H + oF2), (const BowPair*)(H + oP), strict_threshold ? TH_LOW - 1 : TH_LOW, nnratio, S->h_m12.p,
                        S->d_done.p, S->h_done.p, S->seq);
     HIP_TRY(hipGetLastError());
@@ -750,8 +752,8 @@ extern "C" int orbfe_search_by_bow_batch(orbfe_matcher* m, int n_kf, const uint8
     uint8_t* D = S->d_arena.p;
     HIP_TRY(hipMemcpyAsync(D, H, total, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(S->d_m12.p, 0xff, sizeof(int32_t) * rows1, st));
-    hipLaunchKernelGGL(k_bow_match, dim3((unsigned)all.size()), dim3(kBowThreads), 0, st, (const uint4*)(D + oD1), (const uint8_t*)(D + oV1),
-                       (const uint32_t*)(D + oF1), (const uint4*)(D + oD2), valid2 ? (const uint8_t*)(D + oV2) : (const uint8_t*)nullptr,
+    hipLaunchKernelGGL(k_bow_match, dim3((unsigned)all.size()), dim3(kBowThreads), 0, st, dev1 ? dev1 : (const uint4*)(D + oD1), (const uint8_t*)(D + oV1),
+                       (const uint32_t*)(D + oF1), dev2 ? dev2 : (const uint4*)(D + oD2), valid2 ? (const uint8_t*)(D + oV2) : (const uint8_t*)nullptr,
                        (const uint32_t*)(D + oF2), (const BowPair*)(D + oP), strict_threshold ? TH_LOW - 1 : TH_LOW, nnratio, S->d_m12.p,
                        (unsigned*)nullptr, (int*)nullptr, 0);
     HIP_TRY(hipGetLastError());
@@ -771,6 +773,27 @@ extern "C" int orbfe_search_by_bow_batch(orbfe_matcher* m, int n_kf, const uint8
   return ORBFE_OK;
 }
 
+extern "C" int orbfe_search_by_bow_batch(orbfe_matcher* m, int n_kf, const uint8_t* const* desc1, const float* const* angle1,
+                                         const uint8_t* const* valid1, const int* n1, const uint32_t* const* fv1_nodes,
+                                         const uint32_t* const* fv1_offsets, const uint32_t* const* fv1_features, const int* n_fv1,
+                                         const uint8_t* desc2, const float* angle2, const uint8_t* valid2, int n2,
+                                         const uint32_t* fv2_nodes, const uint32_t* fv2_offsets, const uint32_t* fv2_features,
+                                         int n_fv2, float nnratio, int check_orientation, int strict_threshold,
+                                         int32_t* const* matches12, int* nmatches) {
+  return bow_batch_core(m, n_kf, desc1, angle1, valid1, n1, fv1_nodes, fv1_offsets, fv1_features, n_fv1, desc2, angle2, valid2, n2,
+                        fv2_nodes, fv2_offsets, fv2_features, n_fv2, nnratio, check_orientation, strict_threshold, matches12, nmatches,
+                        nullptr, nullptr);
+}
+
+// descriptor rows in the memory of device `device` (16-byte aligned)?
+static bool bow_rows_on_device(const uint8_t* p, int device) {
+  hipPointerAttribute_t attr;
+  if (p && hipPointerGetAttributes(&attr, p) == hipSuccess)
+    return attr.type == hipMemoryTypeDevice && attr.device == device && ((uintptr_t)p & 15u) == 0;
+  (void)hipGetLastError();
+  return false;
+}
+
 extern "C" int orbfe_search_by_bow(orbfe_matcher* m, const uint8_t* desc1, const float* angle1, const uint8_t* valid1, int n1,
                                    const uint32_t* fv1_nodes, const uint32_t* fv1_offsets, const uint32_t* fv1_features,
                                    int n_fv1, const uint8_t* desc2, const float* angle2, const uint8_t* valid2, int n2,
@@ -784,9 +807,13 @@ extern "C" int orbfe_search_by_bow(orbfe_matcher* m, const uint8_t* desc1, const
     return ORBFE_ERR_INVALID;
   }
   *nmatches = 0;
-  return orbfe_search_by_bow_batch(m, 1, &desc1, &angle1, &valid1, &n1, &fv1_nodes, &fv1_offsets, &fv1_features, &n_fv1, desc2, angle2,
-                                   valid2, n2, fv2_nodes, fv2_offsets, fv2_features, n_fv2, nnratio, check_orientation, strict_threshold,
-                                   &matches12, nmatches);
+  // a side whose rows are a resident frame's (orbfe_frame_descriptors_device) stays where it is
+  const int dev = orbfe::matcher_device(m);
+  const uint4* dev1 = bow_rows_on_device(desc1, dev) ? (const uint4*)desc1 : nullptr;
+  const uint4* dev2 = bow_rows_on_device(desc2, dev) ? (const uint4*)desc2 : nullptr;
+  return bow_batch_core(m, 1, &desc1, &angle1, &valid1, &n1, &fv1_nodes, &fv1_offsets, &fv1_features, &n_fv1, desc2, angle2,
+                        valid2, n2, fv2_nodes, fv2_offsets, fv2_features, n_fv2, nnratio, check_orientation, strict_threshold,
+                        &matches12, nmatches, dev1, dev2);
 }
 
 extern "C" int orbfe_search_for_triangulation(orbfe_matcher* m, const OrbfeKeyPoint* kps1_un, const uint8_t* desc1,

@@ -98,6 +98,31 @@ def test_search_by_bow_parity(api, oracle, levelsup, monkeypatch):
     assert nm == 0 and (m12 == -1).all()
 
 
+def test_search_by_bow_with_resident_descriptor_rows(api, oracle):
+    """SearchByBoW(KeyFrame, Frame) with the descriptor rows of one side, the other, or both read from resident frames (device
+    memory, orbfe_frame_descriptors_device): the same matches as with host rows and as the oracle."""
+    from os1_amd.synth import synth, shifted
+    W, H = 1280, 720
+    image = synth_vocabulary(6, 10, 4)
+    v = api.Vocabulary(image)
+    ex = api.Extractor(1200, 1.2, 8, 20, 7)
+    A = synth(44, W, H)
+    k1, d1 = ex(A)
+    bounds = (0.0, float(W), 0.0, float(H))
+    fr1 = api.Frame.from_extract(ex, 0, bounds)
+    k2, d2 = ex(shifted(A, -7, 3, 44))
+    fr2 = api.Frame.from_extract(ex, 0, bounds)
+    m = api.Matcher()
+    fv1, fv2 = v.transform(d1, 2)[2], v.transform(d2, 2)[2]
+    v1 = np.ones(len(k1), np.uint8)
+    want = oracle.search_by_bow(d1, k1['angle'], v1, fv1, d2, k2['angle'], None, fv2, 0.7, True)
+    assert want[0] > 100
+    for a, b in [(d1, d2), (fr1.descriptors_device(), d2), (d1, fr2.descriptors_device()), (fr1.descriptors_device(), fr2.descriptors_device())]:
+        got = m.search_by_bow(a, k1['angle'], v1, fv1, b, k2['angle'], None, fv2, 0.7, True)
+        assert got[0] == want[0] and got[1].tobytes() == want[1].tobytes()
+    v.close()
+
+
 def test_search_by_bow_batch_is_the_relocalisation_loop(api, oracle):
     """Tracking::Relocalization (Tracking.cc:1005-1030): SearchByBoW of several candidate keyframes against the current frame,
     one GPU submission; every keyframe's result equals its own oracle call (and the single-keyframe entry point)."""
