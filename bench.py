@@ -566,6 +566,15 @@ def bow_leg(api, device, frames, W, H, wl, with_oracle):
            'features': [int(len(k1)), int(len(k2))], 'common_nodes': int(len(np.intersect1d(t1[2][0], t2[2][0])))}
     got = m.search_by_bow(d1, k1['angle'], v1, t1[2], d2, k2['angle'], None, t2[2], 0.7, True)
     out['matches'] = int(got[0])
+    # both sides as resident frames (what orb_shim.hpp's MatcherContext passes): no descriptor row is copied
+    bounds = (0.0, float(W), 0.0, float(H))
+    f1, f2 = api.Frame.from_host(m, k1, d1, bounds), api.Frame.from_host(m, k2, d2, bounds)
+    r1, r2 = f1.descriptors_device(), f2.descriptors_device()
+    out['search_by_bow_resident_rows_ms'] = med(lambda: m.search_by_bow(r1, k1['angle'], v1, t1[2], r2, k2['angle'], None, t2[2], 0.7, True), 60)
+    got2 = m.search_by_bow(r1, k1['angle'], v1, t1[2], r2, k2['angle'], None, t2[2], 0.7, True)
+    if got2[0] != got[0] or not (got2[1] == got[1]).all():
+        raise SystemExit('bench: SearchByBoW with resident rows differs')
+    f1.close(); f2.close()
     if with_oracle:
         from oracle.pyoracle import Oracle
         o = Oracle()
