@@ -224,12 +224,18 @@ __global__ void __launch_bounds__(kBowThreads) k_bow_match(const uint4* __restri
       }
       __syncthreads();
       if (tid < 64) {   // (one wave: its LDS operations execute in order)
-        // a lane's (up to four) distances of the NEXT feature's row and its row word travel while the current feature is
-        // decided; the matched bits are the only thing read after the previous feature's update (ds_or, not waited for)
+        // a lane's (up to four) distances of the NEXT feature's row and its row word travel while the current feature is decided
         constexpr int kPer = kBowSide / 64;
         unsigned dn[kPer], idxN = row1[r0];
+        // (the matched flags of a lane's own positions -- pp = lane + 64 j -- as bits of a register: the walk's only
+        // dependent LDS trip per feature was reading them back; the LDS bitmap is kept for the next tile)
+        unsigned mineTaken = 0;
 #pragma unroll
-        for (int j = 0; j < kPer; j++) dn[j] = (lane + 64 * j < n2g) ? dmat[lane + 64 * j] : 256u;
+        for (int j = 0; j < kPer; j++) {
+          const int pp = lane + 64 * j;
+          dn[j] = pp < n2g ? dmat[pp] : 256u;
+          if (pp < n2g && ((matched[pp >> 5] >> (pp & 31)) & 1u)) mineTaken |= 1u << j;
+        }
         for (int rr = 0; rr < rows; rr++) {
           unsigned dc[kPer];
           const unsigned idx1 = idxN;
@@ -245,9 +251,8 @@ __global__ void __launch_bounds__(kBowThreads) k_bow_match(const uint4* __restri
           unsigned k1 = (256u << 16) | 0xffffu, k2 = k1;   // lane-local least and second-least key (distance << 16 | position)
 #pragma unroll
           for (int j = 0; j < kPer; j++) {
-            const int pp = lane + 64 * j;
-            if (dc[j] >= 256u || ((matched[(pp >> 5) & (kBowSide / 32 - 1)] >> (pp & 31)) & 1u)) continue;
-            const unsigned key = (dc[j] << 16) | (unsigned)pp;
+            if (dc[j] >= 256u || ((mineTaken >> j) & 1u)) continue;
+            const unsigned key = (dc[j] << 16) | (unsigned)(lane + 64 * j);
             if (key < k1) { k2 = k1; k1 = key; }
             else if (key < k2) k2 = key;
           }
@@ -257,11 +262,11 @@ __global__ void __launch_bounds__(kBowThreads) k_bow_match(const uint4* __restri
           const unsigned second = wave_min(k1 == best ? k2 : k1) >> 16;   // least distance among everything but the winner
           if (static_cast<float>(bestDist) < nnratio * static_cast<float>((int)second)) {
             const int q = (int)(best & 0xffffu);
+            if ((q & 63) == lane) mineTaken |= 1u << (q >> 6);
             if (lane == 0) {
               matches12[idx1] = (int32_t)row2[q];
               atomicOr(&matched[q >> 5], 1u << (q & 31));
             }
-            asm volatile("" ::: "memory");
           }
         }
       }
