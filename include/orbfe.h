@@ -423,7 +423,8 @@ int orbfe_frame_download(orbfe_frame* f, OrbfeKeyPoint* kps_un, uint8_t* desc, i
  * aligned, e.g. orbfe_frame_descriptors_device); arrays in ordinary host memory are first copied into a page-locked
  * arena (a plain memcpy each -- there is no per-query loop on the host).  ORBFE_FRAME_ZEROCOPY=0: marshal the queries on
  * the host and upload them instead.  The call returns when the kernel's last store -- the call's number, into page-locked
- * memory -- has been seen (ORBFE_FRAME_POLL=0: wait on the stream instead). */
+ * memory -- has been seen (ORBFE_FRAME_POLL=0: wait on the stream instead).  Limits: at most 65 535 keypoints per frame,
+ * 1 048 574 queries per search, 32 pyramid levels for the in-place route (more: the queries are marshalled on the host). */
 int orbfe_search_by_projection_frame(orbfe_matcher* m, orbfe_frame* f, const float* scale_factors, int nlevels,
                                      const uint8_t* kp_occupied, const float* mp_proj_xy, const int32_t* mp_level,
                                      const float* mp_viewcos, const uint8_t* mp_flags, const uint8_t* mp_desc, int n_mp,
