@@ -7,6 +7,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <algorithm>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -130,13 +132,13 @@ int main(int argc, char** argv) {
   // Relocalisation / TrackReferenceKeyFrame (Tracking.cc:543-548): ComputeBoW of both, SearchByBoW(KF, F) and the
   // keyframe-keyframe overload (LoopClosing.cc:242).  A and B carry "MapPoints" flagged in <dir>/bow.valid.
   int nbow1 = -1, nbow2 = -1, ntri = -1;
+  std::vector<MapPoint> own[2];   // the keyframes' MapPoints of the bag-of-words part (they outlive it: the timing mode reuses them)
   FILE* vf = fopen((dir + "/voc.bin").c_str(), "rb");
   if (vf) {
     fclose(vf);
     orbfe::Vocabulary voc;
     if (!voc.loadFromBinaryFile(dir + "/voc.bin")) return 3;
     std::vector<unsigned char> valid = readFile(dir + "/bow.valid");   // n1 + n2 bytes: 0 none, 1 MapPoint, 2 bad MapPoint
-    std::vector<MapPoint> own[2];
     for (int i = 0; i < 2; i++) {
       orbfe::ComputeBoW(voc, F[i]);
       std::vector<double> bv;
@@ -178,5 +180,36 @@ int main(int argc, char** argv) {
     writeFile(dir + "/tri.pairs", tp.data(), tp.size() * sizeof(int));
   }
   printf("%zu %zu %d %d %d %d %d\n", F[0].mvKeys.size(), F[1].mvKeys.size(), nm, nsbp, nbow1, nbow2, ntri);
+  if (argc > 2 && std::string(argv[2]) == "time") {
+    // what an integrated build pays per call THROUGH the facade (marshalling of the mock Frame / MapPoint objects included;
+    // their accessors take no mutex, unlike the reference's): median of 200 blocking calls each
+    auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    std::vector<unsigned char> img = readFile(dir + "/B.gray");
+    std::vector<KeyPoint> kk;
+    std::vector<unsigned char> dd;
+    std::vector<double> tEx, tSbp, tBow;
+    for (int r = 0; r < 200; r++) {
+      double t0 = now();
+      extractor.extract(img.data(), H, W, (size_t)W, kk, dd);
+      tEx.push_back(now() - t0);
+      std::vector<MapPoint*> keep = F[1].mvpMapPoints;
+      F[1].mvpMapPoints.assign(F[1].mvKeys.size(), nullptr);
+      t0 = now();
+      const int n2 = orbfe::SearchByProjection(ctx, 0.8f, F[1], vp, 1.0f);
+      tSbp.push_back(now() - t0);
+      if (n2 != nsbp) return 5;
+      F[1].mvpMapPoints = keep;
+      if (nbow1 >= 0) {
+        std::vector<MapPoint*> vv;
+        t0 = now();
+        const int nb = orbfe::SearchByBoW(ctx, 0.7f, true, &F[0], static_cast<Frame&>(F[1]), vv);
+        tBow.push_back(now() - t0);
+        if (nb != nbow1) return 6;
+      }
+    }
+    printf("TIMING extract_host_frame_ms %.4f search_by_projection_%d_mappoints_ms %.4f search_by_bow_ms %.4f\n", med(tEx), nmp, med(tSbp),
+           tBow.empty() ? -1.0 : med(tBow));
+  }
   return 0;
 }
