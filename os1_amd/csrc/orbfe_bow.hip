@@ -305,44 +305,109 @@ struct TriParams {
   float scale2[16], sigma2[16];
 };
 
-__global__ void __launch_bounds__(64) k_bow_triangulate(const OrbfeKeyPoint* __restrict__ kps1, const uint4* __restrict__ desc1,
-                                                        const uint8_t* __restrict__ hasMP1, const uint32_t* __restrict__ feat1,
-                                                        const OrbfeKeyPoint* __restrict__ kps2, const uint4* __restrict__ desc2,
-                                                        const uint8_t* __restrict__ hasMP2, const uint32_t* __restrict__ feat2,
-                                                        const BowPair* __restrict__ pairs, TriParams T,
-                                                        int32_t* __restrict__ matches12) {
+// Round 3: a block of four waves per node.  Both feature lists with their flags, descriptors and keypoint coordinates are
+// fetched once into LDS (nodes of up to kBowSide features per side; from the page-locked arena directly on the route
+// without copy commands); the frame-1 features are independent (see above), so the four waves take every fourth one and
+// scan the node's frame-2 features from LDS.  Larger nodes: one wave, everything from global memory, as before.
+__global__ void __launch_bounds__(kBowThreads) k_bow_triangulate(const OrbfeKeyPoint* __restrict__ kps1, const uint4* __restrict__ desc1,
+                                                                 const uint8_t* __restrict__ hasMP1, const uint32_t* __restrict__ feat1,
+                                                                 const OrbfeKeyPoint* __restrict__ kps2, const uint4* __restrict__ desc2,
+                                                                 const uint8_t* __restrict__ hasMP2, const uint32_t* __restrict__ feat2,
+                                                                 const BowPair* __restrict__ pairs, TriParams T,
+                                                                 int32_t* __restrict__ matches12, unsigned* doneCounter, int* doneHost,
+                                                                 int doneSeq) {
+  __shared__ uint4 d1s[2 * kBowSide], d2s[2 * kBowSide];
+  __shared__ float x1s[kBowSide], y1s[kBowSide], x2s[kBowSide], y2s[kBowSide];
+  __shared__ uint32_t row1[kBowSide], row2[kBowSide];   // descriptor row | 0x80000000: has a MapPoint (skipped)
+  __shared__ int o2s[kBowSide];
   const BowPair P = pairs[blockIdx.x];
-  const int lane = threadIdx.x;
-  const int n2g = P.e2 - P.b2;
-  for (int i1 = P.b1; i1 < P.e1; i1++) {
-    const unsigned idx1 = feat1[i1];
-    if (hasMP1[idx1]) continue;   // wave-uniform
-    const uint4 a0 = desc1[2 * (size_t)idx1], a1 = desc1[2 * (size_t)idx1 + 1];
-    const float x1 = kps1[idx1].x, y1 = kps1[idx1].y;
-    // epipolar line in image 2, l = x1' F12 (ORBmatcher.cc:138-140)
-    const float la = x1 * T.F12[0] + y1 * T.F12[3] + T.F12[6];
-    const float lb = x1 * T.F12[1] + y1 * T.F12[4] + T.F12[7];
-    const float lc = x1 * T.F12[2] + y1 * T.F12[5] + T.F12[8];
-    const float den = la * la + lb * lb;
-    unsigned key = 0xffffffffu;
-    for (int p = lane; p < n2g; p += 64) {
-      const unsigned idx2 = feat2[P.b2 + p];
-      if (hasMP2[idx2]) continue;
-      const int dist = hamming256(a0, a1, desc2[2 * (size_t)idx2], desc2[2 * (size_t)idx2 + 1]);
-      if (dist > TH_LOW) continue;
-      const float x2 = kps2[idx2].x, y2 = kps2[idx2].y;
-      const int oct = kps2[idx2].octave;
-      const float distex = T.ex - x2, distey = T.ey - y2;
-      if (distex * distex + distey * distey < 100 * T.scale2[oct]) continue;
-      const float num = la * x2 + lb * y2 + lc;
-      if (den == 0) continue;
-      const float dsqr = num * num / den;
-      if (!((double)dsqr < 3.84 * (double)T.sigma2[oct])) continue;
-      key = min(key, ((unsigned)dist << 16) | (0xffffu - (unsigned)p));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n1g = P.e1 - P.b1, n2g = P.e2 - P.b2;
+  auto done = [&]() {   // (every wave's stores are acknowledged before the block counts itself off)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (!doneCounter || tid != 0) return;
+    if (atomicAdd(doneCounter, 1u) != gridDim.x - 1u) return;
+    *doneCounter = 0u;
+    __threadfence_system();
+    __hip_atomic_store(doneHost, doneSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  };
+  if (n1g <= kBowSide && n2g <= kBowSide) {
+    for (int i = tid; i < n1g; i += kBowThreads) {
+      const unsigned idx1 = feat1[P.b1 + i];
+      row1[i] = idx1 | (hasMP1[idx1] ? 0x80000000u : 0u);
+      d1s[2 * i] = desc1[2 * (size_t)idx1]; d1s[2 * i + 1] = desc1[2 * (size_t)idx1 + 1];
+      x1s[i] = kps1[idx1].x; y1s[i] = kps1[idx1].y;
     }
-    key = wave_min(key);
-    if (key != 0xffffffffu && lane == 0) matches12[idx1] = (int32_t)feat2[P.b2 + (int)(0xffffu - (key & 0xffffu))];
+    for (int i = tid; i < n2g; i += kBowThreads) {
+      const unsigned idx2 = feat2[P.b2 + i];
+      row2[i] = idx2 | (hasMP2[idx2] ? 0x80000000u : 0u);
+      d2s[2 * i] = desc2[2 * (size_t)idx2]; d2s[2 * i + 1] = desc2[2 * (size_t)idx2 + 1];
+      x2s[i] = kps2[idx2].x; y2s[i] = kps2[idx2].y; o2s[i] = kps2[idx2].octave;
+    }
+    __syncthreads();
+    for (int r = wave; r < n1g; r += kBowThreads / 64) {
+      const unsigned idx1 = row1[r];
+      if (idx1 & 0x80000000u) continue;   // wave-uniform
+      const uint4 a0 = d1s[2 * r], a1 = d1s[2 * r + 1];
+      const float x1 = x1s[r], y1 = y1s[r];
+      // epipolar line in image 2, l = x1' F12 (ORBmatcher.cc:138-140)
+      const float la = x1 * T.F12[0] + y1 * T.F12[3] + T.F12[6];
+      const float lb = x1 * T.F12[1] + y1 * T.F12[4] + T.F12[7];
+      const float lc = x1 * T.F12[2] + y1 * T.F12[5] + T.F12[8];
+      const float den = la * la + lb * lb;
+      unsigned key = 0xffffffffu;
+      for (int p = lane; p < n2g; p += 64) {
+        if (row2[p] & 0x80000000u) continue;
+        const int dist = hamming256(a0, a1, d2s[2 * p], d2s[2 * p + 1]);
+        if (dist > TH_LOW) continue;
+        const float x2 = x2s[p], y2 = y2s[p];
+        const int oct = o2s[p];
+        const float distex = T.ex - x2, distey = T.ey - y2;
+        if (distex * distex + distey * distey < 100 * T.scale2[oct]) continue;
+        const float num = la * x2 + lb * y2 + lc;
+        if (den == 0) continue;
+        const float dsqr = num * num / den;
+        if (!((double)dsqr < 3.84 * (double)T.sigma2[oct])) continue;
+        key = min(key, ((unsigned)dist << 16) | (0xffffu - (unsigned)p));
+      }
+      key = wave_min(key);
+      if (key != 0xffffffffu && lane == 0) matches12[idx1] = (int32_t)row2[(int)(0xffffu - (key & 0xffffu))];
+    }
+    done();
+    return;
   }
+  if (wave == 0) {
+    for (int i1 = P.b1; i1 < P.e1; i1++) {
+      const unsigned idx1 = feat1[i1];
+      if (hasMP1[idx1]) continue;   // wave-uniform
+      const uint4 a0 = desc1[2 * (size_t)idx1], a1 = desc1[2 * (size_t)idx1 + 1];
+      const float x1 = kps1[idx1].x, y1 = kps1[idx1].y;
+      const float la = x1 * T.F12[0] + y1 * T.F12[3] + T.F12[6];
+      const float lb = x1 * T.F12[1] + y1 * T.F12[4] + T.F12[7];
+      const float lc = x1 * T.F12[2] + y1 * T.F12[5] + T.F12[8];
+      const float den = la * la + lb * lb;
+      unsigned key = 0xffffffffu;
+      for (int p = lane; p < n2g; p += 64) {
+        const unsigned idx2 = feat2[P.b2 + p];
+        if (hasMP2[idx2]) continue;
+        const int dist = hamming256(a0, a1, desc2[2 * (size_t)idx2], desc2[2 * (size_t)idx2 + 1]);
+        if (dist > TH_LOW) continue;
+        const float x2 = kps2[idx2].x, y2 = kps2[idx2].y;
+        const int oct = kps2[idx2].octave;
+        const float distex = T.ex - x2, distey = T.ey - y2;
+        if (distex * distex + distey * distey < 100 * T.scale2[oct]) continue;
+        const float num = la * x2 + lb * y2 + lc;
+        if (den == 0) continue;
+        const float dsqr = num * num / den;
+        if (!((double)dsqr < 3.84 * (double)T.sigma2[oct])) continue;
+        key = min(key, ((unsigned)dist << 16) | (0xffffu - (unsigned)p));
+      }
+      key = wave_min(key);
+      if (key != 0xffffffffu && lane == 0) matches12[idx1] = (int32_t)feat2[P.b2 + (int)(0xffffu - (key & 0xffffu))];
+    }
+  }
+  done();
 }
 
 }  // namespace
@@ -848,31 +913,69 @@ extern "C" int orbfe_search_for_triangulation(orbfe_matcher* m, const OrbfeKeyPo
   std::shared_ptr<void>& slot = orbfe::matcher_bow_slot(m);
   if (!slot) slot = std::make_shared<BowScratch>();
   BowScratch* S = static_cast<BowScratch*>(slot.get());
-  if ((rc = S->d_desc1.ensure((size_t)n1 * 2)) || (rc = S->d_desc2.ensure((size_t)n2 * 2)) || (rc = S->d_valid1.ensure(n1)) ||
-      (rc = S->d_valid2.ensure(n2)) || (rc = S->d_feat1.ensure(nf1)) || (rc = S->d_feat2.ensure(nf2)) ||
-      (rc = S->d_pairs.ensure(pairs.size())) || (rc = S->d_m12.ensure(n1)) || (rc = S->h_m12.ensure(n1)) ||
-      (rc = S->d_kps1.ensure(n1)) || (rc = S->d_kps2.ensure(n2)))
-    return rc;
+  // everything the kernel reads in ONE page-locked arena (nine copy commands from ordinary memory, about 12 us each, were
+  // half of the call): read in place by the kernel when every node fits its LDS -- each item is then fetched once --, else
+  // uploaded with one copy
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t oK1 = 0, oK2 = oK1 + al(sizeof(OrbfeKeyPoint) * (size_t)n1), oD1 = oK2 + al(sizeof(OrbfeKeyPoint) * (size_t)n2),
+               oD2 = oD1 + al(32 * (size_t)n1), oV1 = oD2 + al(32 * (size_t)n2), oV2 = oV1 + al((size_t)std::max(n1, 1)),
+               oF1 = oV2 + al((size_t)std::max(n2, 1)), oF2 = oF1 + al(4 * (size_t)nf1), oP = oF2 + al(4 * (size_t)nf2),
+               total = oP + al(sizeof(BowPair) * pairs.size());
+  if ((rc = S->h_arena.ensure(total)) || (rc = S->d_arena.ensure(total)) || (rc = S->d_m12.ensure(n1)) || (rc = S->h_m12.ensure(n1))) return rc;
+  uint8_t* H = S->h_arena.p;
+  memcpy(H + oK1, kps1_un, sizeof(OrbfeKeyPoint) * (size_t)n1);
+  memcpy(H + oK2, kps2_un, sizeof(OrbfeKeyPoint) * (size_t)n2);
+  memcpy(H + oD1, desc1, 32 * (size_t)n1);
+  memcpy(H + oD2, desc2, 32 * (size_t)n2);
+  memcpy(H + oV1, has_mp1, (size_t)n1);
+  memcpy(H + oV2, has_mp2, (size_t)n2);
+  memcpy(H + oF1, fv1_features, 4 * (size_t)nf1);
+  memcpy(H + oF2, fv2_features, 4 * (size_t)nf2);
+  memcpy(H + oP, pairs.data(), sizeof(BowPair) * pairs.size());
   hipStream_t st = orbfe::matcher_stream(m);
-  HIP_TRY(hipMemcpyAsync(S->d_kps1.p, kps1_un, sizeof(OrbfeKeyPoint) * n1, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(S->d_kps2.p, kps2_un, sizeof(OrbfeKeyPoint) * n2, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(S->d_desc1.p, desc1, (size_t)n1 * 32, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(S->d_desc2.p, desc2, (size_t)n2 * 32, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(S->d_valid1.p, has_mp1, n1, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(S->d_valid2.p, has_mp2, n2, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(S->d_feat1.p, fv1_features, sizeof(uint32_t) * nf1, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(S->d_feat2.p, fv2_features, sizeof(uint32_t) * nf2, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(S->d_pairs.p, pairs.data(), sizeof(BowPair) * pairs.size(), hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemsetAsync(S->d_m12.p, 0xff, sizeof(int32_t) * n1, st));
   TriParams T;
   memcpy(T.F12, F12, sizeof T.F12);
   T.ex = ex; T.ey = ey;
   for (int i = 0; i < 16; i++) { T.scale2[i] = scale_factors2[std::min(i, nlevels2 - 1)]; T.sigma2[i] = level_sigma2_2[std::min(i, nlevels2 - 1)]; }
-  hipLaunchKernelGGL(k_bow_triangulate, dim3((unsigned)pairs.size()), dim3(64), 0, st, S->d_kps1.p, S->d_desc1.p, S->d_valid1.p,
-                     S->d_feat1.p, S->d_kps2.p, S->d_desc2.p, S->d_valid2.p, S->d_feat2.p, S->d_pairs.p, T, S->d_m12.p);
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(S->h_m12.p, S->d_m12.p, sizeof(int32_t) * n1, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  bool small = true;
+  for (const BowPair& p : pairs) small = small && p.e1 - p.b1 <= kBowSide && p.e2 - p.b2 <= kBowSide;
+  const char* zce = getenv("ORBFE_BOW_ZEROCOPY");
+  const bool zc = !(zce && atoi(zce) == 0);
+  if (small && zc) {
+    if (!S->d_done.p) {
+      if ((rc = S->d_done.ensure(16)) || (rc = S->h_done.ensure(16))) return rc;
+      HIP_TRY(hipMemsetAsync(S->d_done.p, 0, 16 * sizeof(unsigned), st));
+      S->h_done.p[0] = 0;
+    }
+    memset(S->h_m12.p, 0xff, sizeof(int32_t) * (size_t)n1);
+    S->seq = S->seq == INT_MAX ? 1 : S->seq + 1;
+    hipLaunchKernelGGL(k_bow_triangulate, dim3((unsigned)pairs.size()), dim3(kBowThreads), 0, st, (const OrbfeKeyPoint*)(H + oK1),
+                       (const uint4*)(H + oD1), (const uint8_t*)(H + oV1), (const uint32_t*)(H + oF1), (const OrbfeKeyPoint*)(H + oK2),
+                       (const uint4*)(H + oD2), (const uint8_t*)(H + oV2), (const uint32_t*)(H + oF2), (const BowPair*)(H + oP), T,
+                       S->h_m12.p, S->d_done.p, S->h_done.p, S->seq);
+    HIP_TRY(hipGetLastError());
+    const volatile int* flag = S->h_done.p;
+    bool seen = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 1;; spin++) {
+      if (*flag == S->seq) { seen = true; break; }
+      if ((spin & 255u) == 0 && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > 2.0) break;
+      __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (!seen) HIP_TRY(hipStreamSynchronize(st));
+  } else {
+    uint8_t* D = S->d_arena.p;
+    HIP_TRY(hipMemcpyAsync(D, H, total, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(S->d_m12.p, 0xff, sizeof(int32_t) * (size_t)n1, st));
+    hipLaunchKernelGGL(k_bow_triangulate, dim3((unsigned)pairs.size()), dim3(kBowThreads), 0, st, (const OrbfeKeyPoint*)(D + oK1),
+                       (const uint4*)(D + oD1), (const uint8_t*)(D + oV1), (const uint32_t*)(D + oF1), (const OrbfeKeyPoint*)(D + oK2),
+                       (const uint4*)(D + oD2), (const uint8_t*)(D + oV2), (const uint32_t*)(D + oF2), (const BowPair*)(D + oP), T,
+                       S->d_m12.p, (unsigned*)nullptr, (int*)nullptr, 0);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(S->h_m12.p, S->d_m12.p, sizeof(int32_t) * (size_t)n1, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
   int nm = 0;
   for (int i = 0; i < n1; i++) if (S->h_m12.p[i] >= 0) nm++;
   if (check_orientation)

@@ -153,7 +153,7 @@ def test_search_by_bow_batch_is_the_relocalisation_loop(api, oracle):
     assert m.search_by_bow_batch([], d2, a2, None, fv2) == []
 
 
-def test_search_for_triangulation_parity(api, oracle):
+def test_search_for_triangulation_parity(api, oracle, monkeypatch):
     """LocalMapping::CreateNewMapPoints' matcher: two extracted frames related by an image translation t, F12 = [t]x
     (true correspondences lie on their epipolar lines), an epipole placed inside the image so the epipole-distance
     test rejects some, random 'already has a MapPoint' flags."""
@@ -167,7 +167,13 @@ def test_search_for_triangulation_parity(api, oracle):
     m = api.Matcher()
     rng = np.random.default_rng(4)
     total = 0
-    for levelsup, t, epi in [(2, (18.0, -5.0), (600.0, 300.0)), (3, (-18.0, 5.0), (-1e4, 50.0)), (2, (3.0, 40.0), (640.0, 360.0))]:
+    # levelsup 2 / 3: groups of about 15 / 150 features (lists, descriptors and coordinates in LDS, four waves per group, inputs read
+    # from the page-locked arena); levelsup 4 on this L = 4 tree: ONE group of 1 500 x 1 500 (one wave, everything from global memory,
+    # inputs uploaded); the last case runs the small groups through the upload route as well
+    for levelsup, t, epi, zc in [(2, (18.0, -5.0), (600.0, 300.0), None), (3, (-18.0, 5.0), (-1e4, 50.0), None),
+                                 (4, (18.0, -5.0), (600.0, 300.0), None), (2, (3.0, 40.0), (640.0, 360.0), '0')]:
+        if zc:
+            monkeypatch.setenv('ORBFE_BOW_ZEROCOPY', zc)
         fv1, fv2 = ov.transform(d1, levelsup)[2], ov.transform(d2, levelsup)[2]
         tx, ty = t
         F12 = np.array([[0, 0, ty], [0, 0, -tx], [-ty, tx, 0]], np.float32) * np.float32(1e-3)
@@ -180,6 +186,8 @@ def test_search_for_triangulation_parity(api, oracle):
                                                      tab['s2'], ori)
             assert nm == wn and pairs.tobytes() == wp.tobytes()
             total += nm
+        if zc:
+            monkeypatch.delenv('ORBFE_BOW_ZEROCOPY')
     assert total > 200
     # zero fundamental matrix: den == 0 everywhere -> nothing matches
     nm, _ = m.search_for_triangulation(k1, d1, h1, fv1, k2, d2, h2, fv2, np.zeros(9, np.float32), 0.0, 0.0, tab['sf'], tab['s2'])
