@@ -308,7 +308,7 @@ struct TriParams {
 // Round 3: a block of four waves per node.  Both feature lists with their flags, descriptors and keypoint coordinates are
 // fetched once into LDS (nodes of up to kBowSide features per side; from the page-locked arena directly on the route
 // without copy commands); the frame-1 features are independent (see above), so the four waves take every fourth one and
-// scan the node's frame-2 features from LDS.  Larger nodes: one wave, everything from global memory, as before.
+// scan the node's frame-2 features from LDS.  Larger nodes: the same split, everything from global memory.
 __global__ void __launch_bounds__(kBowThreads) k_bow_triangulate(const OrbfeKeyPoint* __restrict__ kps1, const uint4* __restrict__ desc1,
                                                                  const uint8_t* __restrict__ hasMP1, const uint32_t* __restrict__ feat1,
                                                                  const OrbfeKeyPoint* __restrict__ kps2, const uint4* __restrict__ desc2,
@@ -377,8 +377,8 @@ __global__ void __launch_bounds__(kBowThreads) k_bow_triangulate(const OrbfeKeyP
     done();
     return;
   }
-  if (wave == 0) {
-    for (int i1 = P.b1; i1 < P.e1; i1++) {
+  {   // (a node too large for LDS: the four waves still share its frame-1 features, everything comes from global memory)
+    for (int i1 = P.b1 + wave; i1 < P.e1; i1 += kBowThreads / 64) {
       const unsigned idx1 = feat1[i1];
       if (hasMP1[idx1]) continue;   // wave-uniform
       const uint4 a0 = desc1[2 * (size_t)idx1], a1 = desc1[2 * (size_t)idx1 + 1];

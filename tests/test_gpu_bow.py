@@ -168,7 +168,7 @@ def test_search_for_triangulation_parity(api, oracle, monkeypatch):
     rng = np.random.default_rng(4)
     total = 0
     # levelsup 2 / 3: groups of about 15 / 150 features (lists, descriptors and coordinates in LDS, four waves per group, inputs read
-    # from the page-locked arena); levelsup 4 on this L = 4 tree: ONE group of 1 500 x 1 500 (one wave, everything from global memory,
+    # from the page-locked arena); levelsup 4 on this L = 4 tree: ONE group of 1 500 x 1 500 (four waves, everything from global memory,
     # inputs uploaded); the last case runs the small groups through the upload route as well
     for levelsup, t, epi, zc in [(2, (18.0, -5.0), (600.0, 300.0), None), (3, (-18.0, 5.0), (-1e4, 50.0), None),
                                  (4, (18.0, -5.0), (600.0, 300.0), None), (2, (3.0, 40.0), (640.0, 360.0), '0')]:
