@@ -182,19 +182,6 @@ __global__ void __launch_bounds__(kBowThreads) k_bow_match(const uint4* __restri
     __threadfence_system();
     __hip_atomic_store(doneHost, doneSeq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   };
-  auto accept = [&](unsigned k1, unsigned k2, unsigned idx1, auto row2Of) {
-    const unsigned best = wave_min(k1);
-    const unsigned second = wave_min(k1 == best ? k2 : k1) >> 16;   // least distance among everything but the winner
-    const int bestDist = (int)(best >> 16);
-    if (bestDist <= maxDist && static_cast<float>(bestDist) < nnratio * static_cast<float>((int)second)) {
-      const int p = (int)(best & 0xffffu);
-      if (lane == 0) {
-        matches12[idx1] = (int32_t)row2Of(p);
-        matched[p >> 5] |= 1u << (p & 31);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the update is in LDS before the next feature's scan reads it
-    }
-  };
   if (inLds) {
     // the node's feature lists and descriptors first -- the walk below must not chase global pointers: every dependent
     // load there is a microsecond per frame-1 feature --
@@ -276,13 +263,16 @@ __global__ void __launch_bounds__(kBowThreads) k_bow_match(const uint4* __restri
     return;
   }
   __syncthreads();
-  if (tid >= 64) return;   // larger nodes: the walk computes its distances itself
+  // larger nodes: the walk computes its distances itself, all four waves scanning the node's frame-2 features for ONE frame-1
+  // feature at a time (least / second-least key per wave, then across the waves through LDS: two barriers per feature)
+  __shared__ unsigned wk[2][kBowThreads / 64];
+  const int wave = tid >> 6;
   for (int i1 = P.b1; i1 < P.e1; i1++) {
     const unsigned idx1 = (unsigned)P.base1 + feat1[i1];
-    if (!valid1[idx1]) continue;   // wave-uniform
+    if (!valid1[idx1]) continue;   // block-uniform
     const uint4 a0 = desc1[2 * (size_t)idx1], a1 = desc1[2 * (size_t)idx1 + 1];
     unsigned k1 = (256u << 16) | 0xffffu, k2 = k1;
-    for (int p = lane; p < n2g; p += 64) {
+    for (int p = tid; p < n2g; p += kBowThreads) {
       const unsigned idx2 = feat2[P.b2 + p];
       const bool skip = ((matched[p >> 5] >> (p & 31)) & 1u) || (valid2 && !valid2[idx2]);
       if (skip) continue;
@@ -290,7 +280,28 @@ __global__ void __launch_bounds__(kBowThreads) k_bow_match(const uint4* __restri
       if (key < k1) { k2 = k1; k1 = key; }
       else if (key < k2) k2 = key;
     }
-    accept(k1, k2, idx1, [&](int q) { return feat2[P.b2 + q]; });
+    const unsigned wbest = wave_min(k1);
+    if (lane == 0) wk[0][wave] = wbest;
+    __syncthreads();
+    unsigned best = wk[0][0];
+#pragma unroll
+    for (int w = 1; w < kBowThreads / 64; w++) best = min(best, wk[0][w]);
+    const unsigned wsecond = wave_min(k1 == best ? k2 : k1);   // least key among everything but the winner, per wave
+    if (lane == 0) wk[1][wave] = wsecond;
+    __syncthreads();
+    unsigned second = wk[1][0];
+#pragma unroll
+    for (int w = 1; w < kBowThreads / 64; w++) second = min(second, wk[1][w]);
+    second >>= 16;
+    const int bestDist = (int)(best >> 16);
+    if (bestDist <= maxDist && static_cast<float>(bestDist) < nnratio * static_cast<float>((int)second)) {
+      const int q = (int)(best & 0xffffu);
+      if (tid == 0) {
+        matches12[idx1] = (int32_t)feat2[P.b2 + q];
+        matched[q >> 5] |= 1u << (q & 31);
+      }
+    }
+    __syncthreads();   // (the matched bit and the exchange words are settled before the next feature)
   }
   done();
 }
