@@ -50,7 +50,7 @@ def parse_args():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=32, help='frames per submission to the stream runner')
+    ap.add_argument('--batch', type=int, default=None, help='frames per submission to the stream runner (default: stream_workload.BATCH)')
     ap.add_argument('--pool', type=int, default=256, help='distinct frames per stream (= frames per step)')
     ap.add_argument('--cpu-frames', type=int, default=64, help='frames of the CPU-oracle baseline sample (0 = skip)')
     ap.add_argument('--bow', action='store_true', help='also run Frame::ComputeBoW (k=10, L=6 synthetic vocabulary) behind the descriptor kernel (not the headline value)')
@@ -164,7 +164,7 @@ def run_rank(args):
     numa_node = api.device_numa_node(local_rank)
     numa_cpus = api.bind_thread_to_device(local_rank)
 
-    W, H, B = wl.W, wl.H, args.batch
+    W, H, B = wl.W, wl.H, (args.batch or wl.BATCH)
     assert args.pool % B == 0, '--pool must be a multiple of --batch'
     subs = args.pool // B                       # submissions per step
     seed = wl.stream_seed(rank)                 # config 4: stream g -> GPU g, seeds 100+g
