@@ -91,6 +91,7 @@ void orbfe_extractor_destroy(orbfe_extractor* h);
 
 /* GetLevels / GetScaleFactor (include/ORBextractor.h:194-207). */
 int orbfe_extractor_levels(const orbfe_extractor* h);
+int orbfe_extractor_device(const orbfe_extractor* h);   /* the device_id given at creation; -1 for NULL */
 float orbfe_extractor_scale_factor(const orbfe_extractor* h);
 /* GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares / GetInverseScaleSigmaSquares
  * (include/ORBextractor.h:213-239).  Each output has nlevels floats; any may be NULL. */
@@ -275,6 +276,14 @@ int orbfe_hamming(const uint8_t a[32], const uint8_t b[32]);
 
 int orbfe_matcher_create(int device_id, orbfe_matcher** out);
 void orbfe_matcher_destroy(orbfe_matcher* m);
+int orbfe_matcher_device(const orbfe_matcher* m);       /* the device_id given at creation; -1 for NULL */
+/* For callers that keep query-side tables in device memory across searches (the local map's MapPoint descriptors,
+ * src/Tracking.cc:818-824 sends the same few thousand every frame; include/orbfe/orb_shim.hpp's MatcherContext does):
+ * a host-to-device copy enqueued on the matcher's own stream, i.e. ordered BEFORE the matcher's next search and after its
+ * previous one.  Returns at once; `src_host` must be page-locked (orbfe_host_alloc) and unchanged until
+ * orbfe_matcher_synchronize(m) or the next search through m has returned. */
+int orbfe_matcher_upload_async(orbfe_matcher* m, void* dst_device, const void* src_host, size_t bytes);
+int orbfe_matcher_synchronize(orbfe_matcher* m);
 
 /* int ORBmatcher::SearchForInitialization(Frame& F1, Frame& F2, vector<cv::Point2f>& vbPrevMatched,
  *                                         vector<int>& vnMatches12, int windowSize)
@@ -404,6 +413,16 @@ int orbfe_frame_create_from_extract(orbfe_extractor* h, int frame_index, const f
                                     orbfe_frame** out);
 void orbfe_frame_destroy(orbfe_frame* f);
 int orbfe_frame_size(const orbfe_frame* f);
+int orbfe_frame_device(const orbfe_frame* f);
+/* Process-wide generation number of "which host object a resident frame stands for".  A caller that caches orbfe_frame
+ * handles per reference object (include/orbfe/orb_shim.hpp does, per Frame / KeyFrame) compares the generation it saw when
+ * it filled its cache with the current one and drops the cache when they differ.  orbfe_resident_invalidate() starts a new
+ * generation (returns it): call it where the reference recycles identities -- Tracking::Reset() sets Frame::nNextId and
+ * KeyFrame::nNextId back to 0 (src/Tracking.cc:1159-1160), Osmap's map load re-creates KeyFrames with the ids stored in the
+ * file and rewrites KeyFrame::nNextId (src/Osmap.cpp:586) -- from any thread; every thread's cache notices at its next
+ * search.  (The shim's cache is keyed by CONTENT, so a missing call costs memory, not correctness.)  Both are lock-free. */
+unsigned long long orbfe_resident_epoch(void);
+unsigned long long orbfe_resident_invalidate(void);
 /* The frame's descriptor rows [n][32] in DEVICE memory, keypoint order; valid while the frame lives.  Returns when the
  * rows are complete.  Usable as the query descriptor rows of a search on another frame of the same device (a caller that
  * keeps descriptors on the GPU -- its own table of MapPoint descriptors, or a frame's rows -- passes device pointers and no
@@ -417,11 +436,14 @@ int orbfe_frame_download(orbfe_frame* f, OrbfeKeyPoint* kps_un, uint8_t* desc, i
 /* orbfe_search_by_projection / _uv / orbfe_search_projected on a resident frame: same arguments minus the frame's
  * arrays, same results.  (The host-array forms above run through these with a transient frame owned by the matcher;
  * ORBFE_MATCH_HOST_RESOLVE=1 keeps their round-2 route -- candidate lists to the host, bookkeeping there -- for A/B
- * runs and the parity tests.)  WHERE THE INPUT ARRAYS MAY LIVE: every per-query array (coordinates, levels, viewing
- * cosines / radii, flags, descriptor rows) and kp_occupied / kp_skip is read by the search kernel in place when it lies in
- * page-locked host memory (orbfe_host_alloc) or in the memory of the frame's device (descriptor rows there must be 16-byte
- * aligned, e.g. orbfe_frame_descriptors_device); arrays in ordinary host memory are first copied into a page-locked
- * arena (a plain memcpy each -- there is no per-query loop on the host).  ORBFE_FRAME_ZEROCOPY=0: marshal the queries on
+ * runs and the parity tests.)  WHERE THE INPUT ARRAYS MAY LIVE: the DESCRIPTOR ROWS may lie in ordinary host memory,
+ * in page-locked host memory (orbfe_host_alloc) or in the memory of the frame's device (16-byte aligned there, e.g.
+ * orbfe_frame_descriptors_device, or a table the caller maintains with orbfe_matcher_upload_async); page-locked and
+ * device rows are read by the search kernel in place.  EVERY OTHER per-query array (coordinates, levels, viewing cosines /
+ * radii, angles, flags) and kp_occupied / kp_skip must be HOST memory -- the library reads them too (level range, largest
+ * radius) -- page-locked ones are read by the kernel in place, ordinary ones are first copied into a page-locked
+ * arena (a plain memcpy each -- there is no per-query loop on the host); a device pointer for one of them is refused with
+ * ORBFE_ERR_INVALID before anything is read.  ORBFE_FRAME_ZEROCOPY=0: marshal the queries on
  * the host and upload them instead.  The call returns when the kernel's last store -- the call's number, into page-locked
  * memory -- has been seen (ORBFE_FRAME_POLL=0: wait on the stream instead).  Limits: at most 65 535 keypoints per frame,
  * 1 048 574 queries per search, 32 pyramid levels for the in-place route (more: the queries are marshalled on the host). */
@@ -429,6 +451,19 @@ int orbfe_search_by_projection_frame(orbfe_matcher* m, orbfe_frame* f, const flo
                                      const uint8_t* kp_occupied, const float* mp_proj_xy, const int32_t* mp_level,
                                      const float* mp_viewcos, const uint8_t* mp_flags, const uint8_t* mp_desc, int n_mp,
                                      float th, float nnratio, int32_t* kp_assigned, int* nmatches);
+/* orbfe_search_by_projection_frame with the MapPoints' descriptors in a TABLE THE CALLER KEEPS ON THE DEVICE across searches
+ * (Tracking::SearchLocalPoints, src/Tracking.cc:818-824, sends the same few thousand MapPoints frame after frame; their
+ * descriptors change only in MapPoint::ComputeDistinctiveDescriptors, src/MapPoint.cc:227-292).  The table has two copies of
+ * 32-byte rows: desc_table_device (memory of the frame's device, orbfe_device_malloc) and desc_table_host (page-locked,
+ * orbfe_host_alloc; complete and current).  MapPoint i's descriptor is row (mp_desc_row[i] & 0x7fffffff): read from the
+ * device copy when bit 31 is clear, from the host copy -- over PCIe, in place -- when it is set (a row the device has not
+ * received yet; the caller sends it afterwards with orbfe_matcher_upload_async).  Per MapPoint 4 bytes of index cross PCIe
+ * instead of 32 of descriptor.  mp_desc_row is host memory (page-locked: read in place).  Same results as the plain form. */
+int orbfe_search_by_projection_frame_rows(orbfe_matcher* m, orbfe_frame* f, const float* scale_factors, int nlevels,
+                                          const uint8_t* kp_occupied, const float* mp_proj_xy, const int32_t* mp_level,
+                                          const float* mp_viewcos, const uint8_t* mp_flags, const uint8_t* desc_table_device,
+                                          const uint8_t* desc_table_host, const int32_t* mp_desc_row, int n_mp, float th,
+                                          float nnratio, int32_t* kp_assigned, int* nmatches);
 int orbfe_search_by_projection_uv_frame(orbfe_matcher* m, orbfe_frame* f, const float* scale_factors, int nlevels,
                                         const uint8_t* kp_occupied, const float* src_uv, const int32_t* src_level,
                                         const float* src_angle, const uint8_t* src_flags, const uint8_t* src_valid,

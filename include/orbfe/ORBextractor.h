@@ -17,7 +17,7 @@ namespace ORB_SLAM2 {
 class ORBextractor {
  public:
   ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
-      : impl_(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, /*device=*/0) {
+      : impl_(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, orbfe::detail::defaultDevice()) {   // ORBFE_DEVICE, as the matcher
     mvImagePyramid.resize(nlevels);  // kept for source compatibility; the pyramid lives in HBM
   }
   ~ORBextractor() {}

@@ -54,7 +54,7 @@ struct CvOps {
   }
 };
 inline orbfe::MatcherContext& context() {   // ORBmatcher objects live on the stack per use; the GPU context is per thread
-  thread_local orbfe::MatcherContext ctx(std::getenv("ORBFE_DEVICE") ? std::atoi(std::getenv("ORBFE_DEVICE")) : 0);
+  thread_local orbfe::MatcherContext ctx(orbfe::detail::defaultDevice());   // ORBFE_DEVICE, as the extractor
   return ctx;
 }
 }  // namespace orbfe_detail

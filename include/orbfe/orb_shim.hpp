@@ -15,9 +15,12 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -29,17 +32,78 @@ inline void check(int rc) {
   if (rc != ORBFE_OK) throw std::runtime_error(std::string("orbfe: ") + orbfe_last_error());
 }
 
+namespace detail {
+// ORBFE_DEVICE (default 0): the GPU the cv-typed facades use -- extractor AND matcher (include/orbfe/ORBextractor.h,
+// ORBmatcher.h), so that an integrated build on GPU != 0 extracts and searches on the same device.
+inline int defaultDevice() {
+  static const int d = [] { const char* e = std::getenv("ORBFE_DEVICE"); return e ? std::atoi(e) : 0; }();
+  return d;
+}
+
+// 128-bit content fingerprint (two independently seeded multiply-xorshift lanes over 8-byte words, four interleaved
+// chains each for throughput: ~10 bytes per cycle, a 2 000-keypoint frame's 120 KB in 3-4 us).  Used as IDENTITY of a
+// frame's searchable content -- not cryptographic, but 2^-128-ish against accidental equality of distinct frames.
+struct Hash128 {
+  uint64_t a = 0x243F6A8885A308D3ull, b = 0x13198A2E03707344ull;
+  bool operator==(const Hash128& o) const { return a == o.a && b == o.b; }
+  bool operator!=(const Hash128& o) const { return !(*this == o); }
+};
+inline uint64_t mix64(uint64_t h, uint64_t v, uint64_t k) {
+  h = (h ^ v) * k;
+  return h ^ (h >> 29);
+}
+inline void hashBytes(Hash128& H, const void* p, size_t bytes) {
+  const uint64_t K1 = 0x9E3779B97F4A7C15ull, K2 = 0xC2B2AE3D27D4EB4Full;
+  const unsigned char* c = static_cast<const unsigned char*>(p);
+  uint64_t a[4] = {H.a, H.a ^ K2, H.a + K1, ~H.a}, b[4] = {H.b, H.b ^ K1, H.b + K2, ~H.b};
+  size_t i = 0;
+  for (; i + 32 <= bytes; i += 32) {
+    uint64_t w[4];
+    std::memcpy(w, c + i, 32);
+    for (int l = 0; l < 4; l++) { a[l] = mix64(a[l], w[l], K1); b[l] = mix64(b[l], w[l] + (uint64_t)l, K2); }
+  }
+  uint64_t tail[4] = {0, 0, 0, 0};
+  if (i < bytes) std::memcpy(tail, c + i, bytes - i);
+  for (int l = 0; l < 4; l++) { a[l] = mix64(a[l], tail[l] ^ bytes, K1); b[l] = mix64(b[l], tail[l] + bytes, K2); }
+  H.a = mix64(mix64(mix64(a[0], a[1], K2), a[2], K2), a[3], K2);
+  H.b = mix64(mix64(mix64(b[0], b[1], K1), b[2], K1), b[3], K1);
+}
+// the descriptor rows of a CV_8U n x 32 matrix (any step)
+template <class MatT>
+inline void hashDescriptorRows(Hash128& H, const MatT& m, int n) {
+  if (n <= 0) return;
+  if ((size_t)m.step == 32) { hashBytes(H, m.data, (size_t)n * 32); return; }
+  for (int i = 0; i < n; i++) hashBytes(H, m.data + (size_t)i * m.step, 32);
+}
+}  // namespace detail
+
 // ORBextractor (reference include/ORBextractor.h:155-373) minus the cv:: types.
+//
+// Besides extracting, an Extractor remembers WHAT it extracted last (count + fingerprint of the keypoints and descriptor
+// rows it returned) while those results still sit in its device arena: the first search of the Frame built from them
+// (Frame.cc:100-111: ExtractORB, UndistortKeyPoints, AssignFeaturesToGrid -- no other use of the extractor in between)
+// then takes keypoints and descriptors where the kernels left them (MatcherContext::resident ->
+// orbfe_frame_create_from_extract) instead of uploading mvKeysUn / mDescriptors again.
 class Extractor {
  public:
-  Extractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device = 0) {
+  Extractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device = 0) : device_(device) {
     check(orbfe_extractor_create(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device, &h_));
     const int n = orbfe_extractor_levels(h_);
     sf_.resize(n); isf_.resize(n); s2_.resize(n); is2_.resize(n);
     check(orbfe_extractor_scale_tables(h_, sf_.data(), isf_.data(), s2_.data(), is2_.data()));
     cap_ = orbfe_extractor_max_keypoints(h_);
+    std::lock_guard<std::mutex> g(registryMutex());
+    registry().push_back(this);
   }
-  ~Extractor() { orbfe_extractor_destroy(h_); }
+  ~Extractor() {
+    {
+      std::lock_guard<std::mutex> g(registryMutex());
+      auto& r = registry();
+      r.erase(std::remove(r.begin(), r.end(), this), r.end());
+    }
+    std::lock_guard<std::mutex> g(mu_);
+    orbfe_extractor_destroy(h_);
+  }
   Extractor(const Extractor&) = delete;
   Extractor& operator=(const Extractor&) = delete;
 
@@ -49,6 +113,8 @@ class Extractor {
                std::vector<uint8_t>& descriptors) {
     static_assert(sizeof(KeyPointT) == sizeof(OrbfeKeyPoint), "KeyPointT must match cv::KeyPoint's layout");
     if (!gray || rows == 0 || cols == 0) return;  // reference: silent return, outputs untouched
+    std::lock_guard<std::mutex> g(mu_);
+    lastValid_ = false;
     cap_ = std::max(cap_, orbfe_extractor_max_keypoints_for_size(h_, rows, cols));   // strips wider than 4.5 : 1
     kp_.resize(cap_);
     desc_.resize((size_t)cap_ * 32);
@@ -58,6 +124,14 @@ class Extractor {
     keypoints.resize(n);
     if (n) std::memcpy(static_cast<void*>(keypoints.data()), kp_.data(), (size_t)n * sizeof(OrbfeKeyPoint));
     descriptors.assign(desc_.begin(), desc_.begin() + (size_t)n * 32);
+    if (trackLast_ && n > 0) {
+      lastN_ = n;
+      lastKeys_ = detail::Hash128();
+      lastDesc_ = detail::Hash128();
+      detail::hashBytes(lastKeys_, kp_.data(), (size_t)n * sizeof(OrbfeKeyPoint));
+      detail::hashBytes(lastDesc_, desc_.data(), (size_t)n * 32);
+      lastValid_ = true;
+    }
   }
 
   int GetLevels() const { return (int)sf_.size(); }
@@ -68,13 +142,39 @@ class Extractor {
   std::vector<float> GetInverseScaleSigmaSquares() const { return is2_; }
   orbfe_extractor* handle() const { return h_; }
   int capacity() const { return cap_; }
+  int device() const { return device_; }
+  // false: do not fingerprint the outputs (a caller that never searches Frames through a MatcherContext saves the 3-4 us)
+  void setTrackLastOutput(bool on) { std::lock_guard<std::mutex> g(mu_); trackLast_ = on; lastValid_ = false; }
+
+  // A resident frame straight from the arena of whichever live Extractor on `device` produced exactly these outputs last
+  // (n keypoints with fingerprint `keys` of the cv::KeyPoint records as returned, `desc` of the rows); xy_un = the
+  // undistorted coordinates [2n] when they differ from the extracted ones, else nullptr.  nullptr if there is none.
+  static orbfe_frame* residentFromLastExtract(int device, int n, const detail::Hash128& keys, const detail::Hash128& desc,
+                                              const float bounds[4], const float* xy_un) {
+    std::lock_guard<std::mutex> g(registryMutex());
+    for (Extractor* e : registry()) {
+      if (e->device_ != device) continue;
+      std::lock_guard<std::mutex> ge(e->mu_);
+      if (!e->lastValid_ || e->lastN_ != n || e->lastKeys_ != keys || e->lastDesc_ != desc) continue;
+      orbfe_frame* f = nullptr;
+      if (orbfe_frame_create_from_extract(e->h_, 0, bounds, xy_un, &f) == ORBFE_OK && f && orbfe_frame_size(f) == n) return f;
+      if (f) orbfe_frame_destroy(f);
+    }
+    return nullptr;
+  }
 
  private:
+  static std::mutex& registryMutex() { static std::mutex m; return m; }
+  static std::vector<Extractor*>& registry() { static std::vector<Extractor*> r; return r; }
   orbfe_extractor* h_ = nullptr;
-  int cap_ = 0;
+  int cap_ = 0, device_ = 0;
   std::vector<float> sf_, isf_, s2_, is2_;
   std::vector<OrbfeKeyPoint> kp_;
   std::vector<uint8_t> desc_;
+  std::mutex mu_;                       // extract() vs. a search thread taking the arena's content
+  bool trackLast_ = true, lastValid_ = false;
+  int lastN_ = 0;
+  detail::Hash128 lastKeys_, lastDesc_;
 };
 
 // One GPU matcher context per thread that runs searches (Tracking constructs ORBmatcher objects on
@@ -82,19 +182,32 @@ class Extractor {
 //
 // The context also keeps the DEVICE-RESIDENT copies of the frames it has searched (orbfe_frame): the reference builds a
 // frame's grid once (Frame.cc:111, 114-129) and reuses it in every search of that frame -- 2-3 per tracked frame
-// (Tracking.cc:608, 614, 824), dozens per keyframe (Fuse, SearchBySim3, relocalisation).  A Frame / KeyFrame is
-// identified by (kind, mnId, N): mnId is unique per constructed object (Frame.cc:78 / KeyFrame.cc:45 nNextId++), the
-// copy constructor keeps it together with the identical mvKeysUn / mDescriptors (Frame.cc:39-62), and neither is modified
-// after construction.  First use uploads the features once (one DMA + the grid build on the GPU); later searches upload
-// only their queries.  Least-recently-used entries are dropped beyond `capacity` (default 48; 0 disables the cache and
-// every search takes the host-array call form).
+// (Tracking.cc:608, 614, 824), dozens per keyframe (Fuse, SearchBySim3, relocalisation).
+//
+// IDENTITY OF A CACHED FRAME = ITS CONTENT.  (kind, mnId, N) is NOT an identity in the reference: Tracking::Reset() sets
+// Frame::nNextId and KeyFrame::nNextId back to 0 (Tracking.cc:1159-1160) -- routine after a failed monocular
+// initialisation -- and Osmap's map load re-creates KeyFrames with the ids stored in the file (Osmap.cpp:586); N sits in
+// 2000-2010 at nFeatures 2000, so a recycled id with an equal N is likely.  An entry is therefore keyed by the keypoint
+// count, the image bounds (they position the grid) and a 128-bit fingerprint of ALL of mvKeysUn and of ALL descriptor rows,
+// recomputed at every lookup (3-4 us against >= 45 us for the search it precedes).  A Frame, its copies (Frame.cc:39-62)
+// and the KeyFrame made from it (KeyFrame.cc:37-60) share content and therefore one resident copy; two different frames
+// never do, whatever their ids.  orbfe_resident_invalidate() (Tracking::Reset, map load) additionally empties every
+// context's cache at its next lookup -- that frees memory; correctness does not depend on it.
+// First use uploads the features once (or takes them from the extractor's arena, Extractor::residentFromLastExtract);
+// later searches upload only their queries.  Least-recently-used entries are dropped beyond `capacity` (default 48, at
+// least the 2 most recent are always kept: a search uses up to two frames; 0 disables the cache and every search takes the
+// host-array call form).
 class MatcherContext {
  public:
-  explicit MatcherContext(int device = 0, size_t frame_cache_capacity = 48) : cap_(frame_cache_capacity) {
+  explicit MatcherContext(int device = 0, size_t frame_cache_capacity = 48) : device_(device), cap_(frame_cache_capacity) {
     check(orbfe_matcher_create(device, &m_));
+    epoch_ = orbfe_resident_epoch();
   }
   ~MatcherContext() {
-    for (auto& e : cache_) orbfe_frame_destroy(e.frame);
+    invalidate();
+    if (table_.pending) orbfe_matcher_synchronize(m_);
+    if (table_.rows) orbfe_device_free(device_, table_.rows);
+    if (table_.mirror) orbfe_host_free(table_.mirror);
     orbfe_matcher_destroy(m_);
     for (auto& s : scratch_)
       if (s.p) orbfe_host_free(s.p);
@@ -118,59 +231,192 @@ class MatcherContext {
   MatcherContext(const MatcherContext&) = delete;
   MatcherContext& operator=(const MatcherContext&) = delete;
   orbfe_matcher* get() const { return m_; }
+  int device() const { return device_; }
   void setFrameCacheCapacity(size_t c) { cap_ = c; trim(); }
   size_t residentFrames() const { return cache_.size(); }
-  size_t residentUploads() const { return uploads_; }
+  size_t residentUploads() const { return uploads_; }          // frames whose features crossed PCIe (orbfe_frame_create)
+  size_t residentFromExtract() const { return fromExtract_; }  // frames taken from an extractor's arena (no upload)
+  size_t residentHits() const { return hits_; }
+  // drop every cached frame (this context).  Tracking::Reset() / a map load call orbfe_resident_invalidate() instead,
+  // which reaches the contexts of all threads.
+  void invalidate() {
+    for (auto& e : cache_) orbfe_frame_destroy(e.frame);
+    cache_.clear();
+  }
 
-  // the resident copy of F (a Frame: kind 0, a KeyFrame: kind 1), created on first use; nullptr when the cache is off
+  // the resident copy of F (a Frame: kind 0, a KeyFrame: kind 1 -- informational, identity is content), created on first
+  // use; nullptr when the cache is off
   template <class FrameLike>
-  orbfe_frame* resident(const FrameLike& F, int kind) {
+  orbfe_frame* resident(const FrameLike& F, int /*kind*/) {
     if (cap_ == 0) return nullptr;
-    const unsigned long long id = (unsigned long long)F.mnId;
+    const unsigned long long ep = orbfe_resident_epoch();
+    if (ep != epoch_) { invalidate(); epoch_ = ep; }
+    static_assert(sizeof(F.mvKeysUn[0]) == sizeof(OrbfeKeyPoint), "mvKeysUn must hold cv::KeyPoint-layout records");
     const int n = (int)F.mvKeysUn.size();
+    const float b[4] = {(float)F.mnMinX, (float)F.mnMaxX, (float)F.mnMinY, (float)F.mnMaxY};
+    detail::Hash128 hk, hd;
+    detail::hashBytes(hk, F.mvKeysUn.data(), (size_t)n * sizeof(OrbfeKeyPoint));
+    detail::hashDescriptorRows(hd, F.mDescriptors, n);
     for (auto it = cache_.begin(); it != cache_.end(); ++it)
-      if (it->kind == kind && it->id == id && it->n == n) {
+      if (it->n == n && it->keys == hk && it->desc == hd && std::memcmp(it->bounds, b, sizeof b) == 0) {
         if (it != cache_.begin()) {   // most recently used first
           Entry e = *it;
           cache_.erase(it);
           cache_.insert(cache_.begin(), e);
         }
+        hits_++;
         return cache_.front().frame;
       }
-    static_assert(sizeof(F.mvKeysUn[0]) == sizeof(OrbfeKeyPoint), "mvKeysUn must hold cv::KeyPoint-layout records");
-    std::vector<uint8_t> tmp;
-    const uint8_t* desc = nullptr;
-    if (n) {
-      if ((size_t)F.mDescriptors.step == 32) desc = F.mDescriptors.data;
-      else {
-        tmp.resize((size_t)n * 32);
-        for (int i = 0; i < n; i++) std::memcpy(&tmp[(size_t)i * 32], F.mDescriptors.data + (size_t)i * F.mDescriptors.step, 32);
-        desc = tmp.data();
-      }
-    }
-    const float b[4] = {(float)F.mnMinX, (float)F.mnMaxX, (float)F.mnMinY, (float)F.mnMaxY};
     Entry e;
-    e.kind = kind; e.id = id; e.n = n;
-    check(orbfe_frame_create(m_, reinterpret_cast<const OrbfeKeyPoint*>(F.mvKeysUn.data()), desc, n, b, &e.frame));
-    uploads_++;
+    e.n = n; e.keys = hk; e.desc = hd;
+    std::memcpy(e.bounds, b, sizeof b);
+    if (n > 0) e.frame = fromExtractor(F, n, hd, b);
+    if (e.frame) fromExtract_++;
+    else {
+      std::vector<uint8_t> tmp;
+      const uint8_t* desc = nullptr;
+      if (n) {
+        if ((size_t)F.mDescriptors.step == 32) desc = F.mDescriptors.data;
+        else {
+          tmp.resize((size_t)n * 32);
+          for (int i = 0; i < n; i++) std::memcpy(&tmp[(size_t)i * 32], F.mDescriptors.data + (size_t)i * F.mDescriptors.step, 32);
+          desc = tmp.data();
+        }
+      }
+      check(orbfe_frame_create(m_, reinterpret_cast<const OrbfeKeyPoint*>(F.mvKeysUn.data()), desc, n, b, &e.frame));
+      uploads_++;
+    }
     cache_.insert(cache_.begin(), e);
     trim();
     return cache_.front().frame;
   }
 
+  // ---- the local map's descriptors on the device.  Tracking::SearchLocalPoints (Tracking.cc:818-824) sends the same few
+  // thousand MapPoints frame after frame; their 32-byte descriptors need not cross PCIe every time.  The context keeps a
+  // table of rows keyed by the MapPoint's ADDRESS, in two copies: a page-locked host MIRROR (always complete and current)
+  // and the DEVICE rows.  Per search the shim asks for each in-view MapPoint's row:
+  //   rowFor(pMP, bytes)   compares GetDescriptor()'s bytes with the mirror row of that MapPoint.  Equal: returns the row
+  //                        number -- the kernel reads the device copy.  Different (the descriptor was recomputed,
+  //                        MapPoint::ComputeDistinctiveDescriptors, MapPoint.cc:227-292; a new MapPoint; a new object at
+  //                        a recycled address): the mirror row is rewritten and the number comes back with bit 31 set --
+  //                        the kernel reads THAT row from the mirror, over PCIe, exactly what a search without the table
+  //                        does for every row.  The comparison is of the BYTES, so the device copy can never be stale.
+  //   tableCommit()        after the search: rows that changed go to the device asynchronously on the matcher's stream
+  //                        (runs of neighbouring rows as one copy), ready for the next frame.
+  // The local map's order may change from frame to frame (Tracking::UpdateLocalPoints rebuilds the vector): rows belong to
+  // MapPoints, not to positions.  Rows of MapPoints that are gone are reclaimed by starting over when the table holds more
+  // than 4x the rows one search uses (at least 16 384).
+  void tableBegin(size_t nQueries) {
+    DescTable& t = table_;
+    if (t.pending) { check(orbfe_matcher_synchronize(m_)); t.pending = false; }
+    if (t.slotOf.size() > std::max<size_t>(16384, 4 * std::max(nQueries, t.lastQueries))) { t.slotOf.clear(); t.used = 0; }
+    t.lastQueries = nQueries;
+    t.dirty.clear();
+    if (t.cap == 0) growTable(1);
+  }
+  int32_t rowFor(const void* pMP, const uint8_t* bytes) {
+    DescTable& t = table_;
+    auto it = t.slotOf.find(pMP);
+    uint32_t slot;
+    if (it == t.slotOf.end()) {
+      slot = (uint32_t)t.used++;
+      if (t.used > t.cap) growTable(t.used);
+      t.slotOf.emplace(pMP, slot);
+    } else {
+      slot = it->second;
+      if (std::memcmp(t.mirror + (size_t)slot * 32, bytes, 32) == 0) { t.rowsFromDevice++; return (int32_t)slot; }
+    }
+    std::memcpy(t.mirror + (size_t)slot * 32, bytes, 32);
+    t.dirty.push_back(slot);
+    return (int32_t)(slot | 0x80000000u);
+  }
+  const uint8_t* tableDevice() const { return table_.rows; }
+  const uint8_t* tableMirror() const { return table_.mirror; }
+  void tableCommit() {
+    DescTable& t = table_;
+    if (t.dirty.empty()) { t.cleanSearches++; return; }
+    std::sort(t.dirty.begin(), t.dirty.end());
+    t.dirty.erase(std::unique(t.dirty.begin(), t.dirty.end()), t.dirty.end());
+    size_t i = 0;
+    while (i < t.dirty.size()) {   // runs of changed rows at most 32 rows apart travel as one copy
+      size_t j = i;
+      while (j + 1 < t.dirty.size() && t.dirty[j + 1] - t.dirty[j] <= 32) j++;
+      const size_t lo = t.dirty[i], hi = (size_t)t.dirty[j] + 1;
+      check(orbfe_matcher_upload_async(m_, t.rows + lo * 32, t.mirror + lo * 32, (hi - lo) * 32));
+      t.copies++;
+      i = j + 1;
+    }
+    t.rowsChanged += t.dirty.size();
+    t.pending = true;
+  }
+  size_t tableRowsChanged() const { return table_.rowsChanged; }        // rows that went to the device (first sight or new bytes)
+  size_t tableCleanSearches() const { return table_.cleanSearches; }    // searches that read every descriptor from device memory
+  size_t tableRowsFromDevice() const { return table_.rowsFromDevice; }  // descriptor reads served by the device copy
+  size_t tableRows() const { return table_.used; }
+
  private:
-  struct Entry { int kind = 0; unsigned long long id = 0; int n = 0; orbfe_frame* frame = nullptr; };
+  struct Entry { int n = 0; detail::Hash128 keys, desc; float bounds[4] = {0, 0, 0, 0}; orbfe_frame* frame = nullptr; };
+  // the extractor route: F.mvKeys are the records some live Extractor of this device returned last (same count, same
+  // bytes, same descriptor rows) -> its arena still holds them
+  template <class FrameLike>
+  orbfe_frame* fromExtractor(const FrameLike& F, int n, const detail::Hash128& hd, const float b[4]) {
+    if ((int)F.mvKeys.size() != n) return nullptr;
+    detail::Hash128 hraw;
+    detail::hashBytes(hraw, F.mvKeys.data(), (size_t)n * sizeof(OrbfeKeyPoint));
+    // undistorted coordinates only when they differ from the extracted ones (Frame.cc:288-292: no distortion => mvKeysUn = mvKeys)
+    const bool same = std::memcmp(static_cast<const void*>(F.mvKeys.data()), static_cast<const void*>(F.mvKeysUn.data()),
+                                  (size_t)n * sizeof(OrbfeKeyPoint)) == 0;
+    std::vector<float> xy;
+    if (!same) {
+      xy.resize((size_t)n * 2);
+      for (int i = 0; i < n; i++) std::memcpy(&xy[2 * (size_t)i], &F.mvKeysUn[i], 8);   // pt = the first two floats
+      // everything but pt must be what the extractor returned (UndistortKeyPoints copies the record and replaces pt)
+      for (int i = 0; i < n; i++)
+        if (std::memcmp(reinterpret_cast<const char*>(&F.mvKeys[i]) + 8, reinterpret_cast<const char*>(&F.mvKeysUn[i]) + 8,
+                        sizeof(OrbfeKeyPoint) - 8) != 0)
+          return nullptr;
+    }
+    return Extractor::residentFromLastExtract(device_, n, hraw, hd, b, same ? nullptr : xy.data());
+  }
   void trim() {
-    while (cache_.size() > cap_) {
+    const size_t keep = cap_ == 0 ? 0 : std::max<size_t>(cap_, 2);   // a search uses up to two frames: never evict those
+    while (cache_.size() > keep) {
       orbfe_frame_destroy(cache_.back().frame);
       cache_.pop_back();
     }
   }
   orbfe_matcher* m_ = nullptr;
-  size_t cap_ = 48, uploads_ = 0;
+  int device_ = 0;
+  size_t cap_ = 48, uploads_ = 0, fromExtract_ = 0, hits_ = 0;
+  unsigned long long epoch_ = 0;
   std::vector<Entry> cache_;
   struct Scratch { void* p = nullptr; size_t bytes = 0; };
   Scratch scratch_[8];
+  struct DescTable {
+    uint8_t *rows = nullptr, *mirror = nullptr;   // device rows; page-locked host mirror (complete and current)
+    size_t cap = 0, used = 0, lastQueries = 0;
+    std::unordered_map<const void*, uint32_t> slotOf;   // MapPoint address -> row
+    std::vector<uint32_t> dirty;                  // rows rewritten by the current snapshot
+    size_t rowsChanged = 0, rowsFromDevice = 0, cleanSearches = 0, copies = 0;
+    bool pending = false;                         // an upload from the mirror may still be in flight
+  };
+  void growTable(size_t need) {
+    DescTable& t = table_;
+    const size_t cap = std::max<size_t>(4096, need + need / 2);
+    void *h = nullptr, *d = nullptr;
+    check(orbfe_host_alloc(cap * 32, &h));
+    if (orbfe_device_malloc(device_, cap * 32, &d) != ORBFE_OK) { orbfe_host_free(h); check(ORBFE_ERR_HIP); }
+    if (t.cap) {   // (no upload is in flight here: tableBegin has waited, tableCommit comes after the search)
+      std::memcpy(h, t.mirror, t.cap * 32);
+      check(orbfe_device_upload(device_, d, t.mirror, t.cap * 32));
+      orbfe_device_free(device_, t.rows);
+      orbfe_host_free(t.mirror);
+    }
+    t.mirror = static_cast<uint8_t*>(h);
+    t.rows = static_cast<uint8_t*>(d);
+    t.cap = cap;
+  }
+  DescTable table_;
 };
 
 namespace detail {
@@ -236,11 +482,18 @@ inline int SearchByProjection(MatcherContext& ctx, float mfNNratio, FrameT& F,
   // snapshots go into the context's page-locked arrays (flags and levels zeroed: an absent MapPoint is "not in view", level 0)
   uint8_t* occ = ctx.scratch<uint8_t>(0, n, true);
   uint8_t* flags = ctx.scratch<uint8_t>(1, nmp, true);
-  uint8_t* mdesc = ctx.scratch<uint8_t>(2, (size_t)nmp * 32, false);
   float* xy = ctx.scratch<float>(3, (size_t)nmp * 2, false);
   float* vcos = ctx.scratch<float>(4, nmp, false);
   int32_t* lvl = ctx.scratch<int32_t>(5, nmp, true);
   int32_t* assigned = ctx.scratch<int32_t>(6, n, false);
+  float b[4];
+  detail::frameBounds(F, b);
+  orbfe_frame* rf = ctx.resident(F, 0);
+  // With a resident frame the MapPoints' descriptors come from the context's device table (rows keyed by MapPoint, only
+  // changed rows cross PCIe); the host-array call form takes plain rows.
+  int32_t* drow = rf ? ctx.scratch<int32_t>(2, nmp, true) : nullptr;
+  uint8_t* mdesc = rf ? nullptr : ctx.scratch<uint8_t>(2, (size_t)nmp * 32, false);
+  if (rf) ctx.tableBegin((size_t)nmp);
   std::vector<uint8_t> tmp;
   for (int i = 0; i < n; i++) assigned[i] = -1;
   for (int i = 0; i < n; i++)
@@ -257,15 +510,16 @@ inline int SearchByProjection(MatcherContext& ctx, float mfNNratio, FrameT& F,
     lvl[i] = p->mnTrackScaleLevel;
     vcos[i] = p->mTrackViewCos;
     const auto d = p->GetDescriptor();
-    std::memcpy(&mdesc[(size_t)i * 32], d.data, 32);
+    if (rf) drow[i] = ctx.rowFor(p, d.data);
+    else std::memcpy(&mdesc[(size_t)i * 32], d.data, 32);
   }
-  float b[4];
-  detail::frameBounds(F, b);
   int nmatches = 0;
-  if (orbfe_frame* rf = ctx.resident(F, 0))
-    check(orbfe_search_by_projection_frame(ctx.get(), rf, F.mvScaleFactors.data(), (int)F.mvScaleFactors.size(), occ,
-                                           xy, lvl, vcos, flags, mdesc, nmp, th, mfNNratio, assigned, &nmatches));
-  else
+  if (rf) {
+    check(orbfe_search_by_projection_frame_rows(ctx.get(), rf, F.mvScaleFactors.data(), (int)F.mvScaleFactors.size(), occ, xy, lvl,
+                                                vcos, flags, ctx.tableDevice(), ctx.tableMirror(), drow, nmp, th, mfNNratio,
+                                                assigned, &nmatches));
+    ctx.tableCommit();
+  } else
     check(orbfe_search_by_projection(ctx.get(), reinterpret_cast<const OrbfeKeyPoint*>(F.mvKeysUn.data()),
                                      detail::packedDescriptors(F.mDescriptors, n, tmp), n, b, F.mvScaleFactors.data(),
                                      (int)F.mvScaleFactors.size(), occ, xy, lvl, vcos, flags, mdesc, nmp, th, mfNNratio,

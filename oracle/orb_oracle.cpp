@@ -1496,6 +1496,7 @@ int orc_search_projected(const OrcKeyPoint* kpsUn, const uint8_t* desc, int n, c
 // MapPoint / KeyFrame bookkeeping (Replace, AddObservation, AddMapPoint) follows the simplified model of
 // orb_oracle_pose.h; the search part (which keypoint each point selects) is exact reference logic.
 // =============================================================================================
+#define ORB_ORACLE_IMPLEMENTATION
 #include "orb_oracle_pose.h"
 
 namespace {

@@ -69,6 +69,23 @@ void orc_undistort_pinhole(float* xy, int n, float fx, float fy, float cx, float
 void orc_image_bounds(int cols, int rows, int mode, float fx, float fy, float cx, float cy, const float* dist, int ndist,
                       float bounds[4]);
 
+/* The extractor and the two array-form searches a Tracking-shaped C++ test needs beside the whole-function restatements
+ * above (definitions and line citations in orb_oracle.cpp): ORBextractor ctor + operator() (ORBextractor.cc:442-502, 907-969),
+ * ORBmatcher::SearchForInitialization (ORBmatcher.cc:400-515; prev_xy = vbPrevMatched in/out) and
+ * ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (:45-132; mp_flags bit0 mbTrackInView, bit1 isBad(),
+ * bit2 plCandidato, bit3 Observations() > 0; kp_assigned[idx] = index of the last MapPoint written to mvpMapPoints[idx]). */
+#ifndef ORB_ORACLE_IMPLEMENTATION   /* (orb_oracle.cpp defines them on its own keypoint type of the same layout) */
+void* orc_extractor_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
+void orc_extractor_destroy(void* h);
+int orc_extract(void* h, const uint8_t* gray, int rows, int cols, int stride, OrcKp* kps, uint8_t* desc, int cap);
+int orc_search_for_initialization(const OrcKp* kps1, const uint8_t* desc1, int n1, const OrcKp* kps2, const uint8_t* desc2, int n2,
+                                  const float bounds[4], float* prev_xy, int* vnMatches12, int windowSize, float mfNNratio,
+                                  int mbCheckOrientation);
+int orc_search_by_projection(const OrcKp* kpsUn, const uint8_t* desc, int n, const float bounds[4], const float* mvScaleFactors,
+                             const uint8_t* kp_occupied, const float* mp_proj_xy, const int* mp_level, const float* mp_viewcos,
+                             const uint8_t* mp_flags, const uint8_t* mp_desc, int n_mp, float th, float mfNNratio, int* kp_assigned);
+#endif
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,6 +83,15 @@ def load_library():
     L.orbfe_frame_descriptors_device.restype = vp
     L.orbfe_frame_download.argtypes = [vp, vp, vp, vp, vp]
     L.orbfe_search_by_projection_frame.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp, C.POINTER(ci)]
+    L.orbfe_search_by_projection_frame_rows.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp,
+                                                        C.POINTER(ci)]
+    L.orbfe_matcher_upload_async.argtypes = [vp, vp, vp, C.c_size_t]
+    L.orbfe_matcher_synchronize.argtypes = [vp]
+    L.orbfe_matcher_device.argtypes = [vp]
+    L.orbfe_extractor_device.argtypes = [vp]
+    L.orbfe_frame_device.argtypes = [vp]
+    L.orbfe_resident_epoch.restype = C.c_ulonglong
+    L.orbfe_resident_invalidate.restype = C.c_ulonglong
     L.orbfe_search_by_projection_uv_frame.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, cf, ci, ci, ci, vp,
                                                       C.POINTER(ci)]
     L.orbfe_search_projected_frame.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp, ci, C.c_double, ci, vp, vp,
@@ -507,6 +516,30 @@ class Matcher:
                                                  len(mp_level), th, nnratio, _p(assigned), C.byref(n)))
         return n.value, assigned[:len(kps)]
 
+    def search_by_projection_rows(self, frame, scale_factors, kp_occupied, mp_xy, mp_level, mp_viewcos, mp_flags, table, rows,
+                                  th, nnratio):
+        """orbfe_search_by_projection_frame_rows: the MapPoints' descriptors are rows of a DescTable (device copy + page-locked
+        mirror); rows[i] = row number, bit 31 set = read that row from the mirror."""
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        occ = np.ascontiguousarray(kp_occupied, np.uint8)
+        mp_xy = np.ascontiguousarray(mp_xy, np.float32)
+        mp_level = np.ascontiguousarray(mp_level, np.int32)
+        mp_viewcos = np.ascontiguousarray(mp_viewcos, np.float32)
+        mp_flags = np.ascontiguousarray(mp_flags, np.uint8)
+        rows = np.ascontiguousarray(rows, np.int32)
+        assigned = np.full(max(len(frame), 1), -1, np.int32)
+        n = C.c_int(0)
+        _check(self.L.orbfe_search_by_projection_frame_rows(self.h, frame.h, _p(sf), len(sf), _p(occ), _p(mp_xy), _p(mp_level),
+                                                            _p(mp_viewcos), _p(mp_flags), C.c_void_p(table.dev), C.c_void_p(table.host.base),
+                                                            _p(rows), len(mp_level), th, nnratio, _p(assigned), C.byref(n)))
+        return n.value, assigned[:len(frame)]
+
+    def upload_async(self, dst_device, src_host_ptr, nbytes):
+        _check(self.L.orbfe_matcher_upload_async(self.h, C.c_void_p(dst_device), C.c_void_p(src_host_ptr), nbytes))
+
+    def synchronize(self):
+        _check(self.L.orbfe_matcher_synchronize(self.h))
+
     def search_by_projection_uv(self, kps, desc, bounds, scale_factors, kp_occupied, src_uv, src_level, src_angle,
                                 src_flags, src_valid, src_desc, th, max_dist, skip_any_occupied, check_ori):
         if isinstance(kps, Frame):
@@ -830,6 +863,30 @@ class PinnedArray:
             self.free()
         except Exception:
             pass
+
+
+class DescTable:
+    """A caller-maintained descriptor table for orbfe_search_by_projection_frame_rows: `cap` 32-byte rows in device memory
+    (`dev`) and their page-locked host mirror (`host.a`, a numpy view)."""
+
+    def __init__(self, cap, device=0):
+        self.L = load_library()
+        self.device, self.cap = device, cap
+        self.host = PinnedArray((cap, 32), np.uint8)
+        self.host.a[:] = 0
+        p = C.c_void_p()
+        _check(self.L.orbfe_device_malloc(device, cap * 32, C.byref(p)))
+        self.dev = p.value
+
+    def upload(self, matcher, lo, hi):
+        """rows [lo, hi) of the mirror -> device, asynchronously on the matcher's stream"""
+        matcher.upload_async(self.dev + lo * 32, self.host.base + lo * 32, (hi - lo) * 32)
+
+    def free(self):
+        if self.dev:
+            self.L.orbfe_device_free(self.device, C.c_void_p(self.dev))
+            self.dev = None
+            self.host.free()
 
 
 class PinnedFrames:

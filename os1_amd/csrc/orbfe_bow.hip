@@ -72,7 +72,9 @@ struct PinBuf {
     if (p) (void)hipHostFree(p);
     p = nullptr;
     n = 0;
-    HIP_TRY(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault));
+    // Coherent (fine-grained, uncached on the GPU side) EXPLICITLY: kernels store results and completion words here and the
+    // host polls them while the kernel runs; with hipHostMallocDefault that property would hang on HIP_HOST_COHERENT.
+    HIP_TRY(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocCoherent));
     n = count;
     return ORBFE_OK;
   }
@@ -173,7 +175,10 @@ __global__ void __launch_bounds__(kBowThreads) k_bow_match(const uint4* __restri
   for (int i = tid; i < (n2g + 31) / 32; i += kBowThreads) matched[i] = 0;
   const bool inLds = n1g <= kBowSide && n2g <= kBowSide;
   // completion word (the route without copy commands: inputs read from, matches written to page-locked host memory): the
-  // block's stores are acknowledged, it counts itself off, the last one writes the call's number for the polling host
+  // block's stores are acknowledged, it counts itself off, the last one writes the call's number for the polling host.
+  // Why an acknowledgement wait is enough for the blocks that are not last: matches12 / doneHost live in COHERENT page-locked
+  // memory (PinBuf: hipHostMallocCoherent), which the GPU maps uncached -- a store that has been acknowledged (vmcnt 0) has
+  // left every XCD's L2 and is visible to the host; the counter only orders "all blocks got that far" before the flag.
   auto done = [&]() {
     if (!doneCounter || tid != 0) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -866,13 +871,16 @@ extern "C" int orbfe_search_by_bow_batch(orbfe_matcher* m, int n_kf, const uint8
                         nullptr, nullptr);
 }
 
-// descriptor rows in the memory of device `device` (16-byte aligned)?
-static bool bow_rows_on_device(const uint8_t* p, int device) {
+// descriptor rows: 1 = in the memory of device `device`, 16-byte aligned (read in place); 0 = host memory (copied into the
+// arena); -1 = device memory the kernels cannot take as it is (another device's, or misaligned) -- refused, never memcpy'd
+static int bow_rows_where(const uint8_t* p, int device) {
   hipPointerAttribute_t attr;
-  if (p && hipPointerGetAttributes(&attr, p) == hipSuccess)
-    return attr.type == hipMemoryTypeDevice && attr.device == device && ((uintptr_t)p & 15u) == 0;
+  if (p && hipPointerGetAttributes(&attr, p) == hipSuccess) {
+    if (attr.type != hipMemoryTypeDevice) return 0;
+    return attr.device == device && ((uintptr_t)p & 15u) == 0 ? 1 : -1;
+  }
   (void)hipGetLastError();
-  return false;
+  return 0;
 }
 
 extern "C" int orbfe_search_by_bow(orbfe_matcher* m, const uint8_t* desc1, const float* angle1, const uint8_t* valid1, int n1,
@@ -890,8 +898,13 @@ extern "C" int orbfe_search_by_bow(orbfe_matcher* m, const uint8_t* desc1, const
   *nmatches = 0;
   // a side whose rows are a resident frame's (orbfe_frame_descriptors_device) stays where it is
   const int dev = orbfe::matcher_device(m);
-  const uint4* dev1 = bow_rows_on_device(desc1, dev) ? (const uint4*)desc1 : nullptr;
-  const uint4* dev2 = bow_rows_on_device(desc2, dev) ? (const uint4*)desc2 : nullptr;
+  const int w1 = bow_rows_where(desc1, dev), w2 = bow_rows_where(desc2, dev);
+  if (w1 < 0 || w2 < 0) {
+    set_err("descriptor rows in device memory must belong to the matcher's device and be 16-byte aligned");
+    return ORBFE_ERR_INVALID;
+  }
+  const uint4* dev1 = w1 ? (const uint4*)desc1 : nullptr;
+  const uint4* dev2 = w2 ? (const uint4*)desc2 : nullptr;
   return bow_batch_core(m, 1, &desc1, &angle1, &valid1, &n1, &fv1_nodes, &fv1_offsets, &fv1_features, &n_fv1, desc2, angle2,
                         valid2, n2, fv2_nodes, fv2_offsets, fv2_features, n_fv2, nnratio, check_orientation, strict_threshold,
                         &matches12, nmatches, dev1, dev2);

@@ -1435,6 +1435,7 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
 
 void orbfe_extractor_destroy(orbfe_extractor* h) { delete h; }
 int orbfe_extractor_levels(const orbfe_extractor* h) { return h ? h->nlevels : 0; }
+int orbfe_extractor_device(const orbfe_extractor* h) { return h ? h->device : -1; }
 float orbfe_extractor_scale_factor(const orbfe_extractor* h) { return h ? (float)h->scaleFactor : 0.f; }
 int orbfe_extractor_scale_tables(const orbfe_extractor* h, float* a, float* b, float* c, float* d) {
   if (!h) { set_err("handle is NULL"); return ORBFE_ERR_INVALID; }

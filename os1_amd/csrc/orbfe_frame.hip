@@ -669,6 +669,11 @@ struct RawQ {
   int nlevels = 0;
   float th = 1.f;
   int factor = 0;
+  const int* descRow = nullptr;       // indexed descriptor rows (orbfe_search_by_projection_frame_rows): host array [nq] ...
+  const uint8_t* descHost = nullptr;  // ... and the table's complete page-locked host mirror
+  int descRowWhere = 0;
+  // where each array lives (gpu_readable), filled by classify_host_arrays: xy, level, aux, flags, claimSrc, angle, occ
+  int where[7] = {0, 0, 0, 0, 0, 0, 0};
 };
 
 // > 0: the kernels can read p in place (1: page-locked host memory, 2: memory of device `device`); 0: ordinary host memory
@@ -682,6 +687,29 @@ int gpu_readable(const void* p, int device) {
   }
   (void)hipGetLastError();
   return 0;
+}
+// The per-query arrays other than the descriptor rows, and the occupancy bytes, are also READ BY THE HOST (level range,
+// largest radius, the marshalled routes): they must be host memory -- page-locked (then the kernels read them in place) or
+// ordinary.  A device pointer is refused here, before anything dereferences it (include/orbfe.h states the contract).
+int classify_host_arrays(const orbfe_matcher* m, RawQ* Q) {
+  const void* p[7] = {Q->xy, Q->level, Q->aux, Q->flags, Q->claimSrc, Q->angle, Q->occ};
+  static const char* const name[7] = {"coordinates", "levels", "viewing cosines / radii", "flags", "claim flags", "angles", "occupancy bytes"};
+  for (int k = 0; k < 7; k++) {
+    if (!p[k]) { Q->where[k] = 0; continue; }
+    if (k == 4 && p[4] == p[3]) { Q->where[4] = Q->where[3]; continue; }
+    const int g = gpu_readable(p[k], m->device);
+    if (g == 2 || g < 0) {
+      set_err("the %s live in device memory: of a search's input arrays only the descriptor rows may (the others are read by the host too)", name[k]);
+      return ORBFE_ERR_INVALID;
+    }
+    Q->where[k] = g;
+  }
+  if (Q->descRow) {
+    const int g = gpu_readable(Q->descRow, m->device);
+    if (g == 2 || g < 0) { set_err("the descriptor row indices live in device memory: they must be host memory"); return ORBFE_ERR_INVALID; }
+    Q->descRowWhere = g;
+  }
+  return ORBFE_OK;
 }
 // levels of the active queries -- (flags[i] & need) == want, or flags[i] != 0 when need == 0 -- all inside [0, nlevels)?  *maxSf = the largest scale
 // factor among them.  One pass of min / max over ALL levels first (vectorised; enough when no level is out of range).
@@ -759,7 +787,12 @@ int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint
   if (f->ready && hipStreamWaitEvent(st, f->ready, 0) != hipSuccess) (void)hipGetLastError();   // (the recording stream is gone: the build is complete)
   // queries: one copy for the scalar arrays; descriptor rows straight from the caller's memory when it is page-locked
   // (the kernel fetches rows as two 16-byte words: rows it reads in place must be 16-byte aligned)
+  const bool indexed = raw && raw->descRow;
   const int rowsWhere = gpu_readable(qdescHost, m->device);
+  if (indexed && (rowsWhere != 2 || gpu_readable(raw->descHost, m->device) != 1 || ((uintptr_t)raw->descHost & 15u) != 0)) {
+    set_err("indexed descriptor rows: the table must live in the frame's device memory and its mirror in page-locked host memory, both 16-byte aligned");
+    return ORBFE_ERR_INVALID;
+  }
   if (rowsWhere < 0 || (rowsWhere == 2 && ((uintptr_t)qdescHost & 15u) != 0)) {
     set_err(rowsWhere < 0 ? "the descriptor rows live in the memory of another device" : "device-resident descriptor rows must be 16-byte aligned");
     return ORBFE_ERR_INVALID;
@@ -787,23 +820,20 @@ int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint
   if (raw) {
     W = *raw;
     uint8_t* H = m->h_q.p;
-    bool foreign = false;
-    auto view = [&](const void* src, size_t bytes, size_t at) -> const void* {
-      if (!src) return src;
-      const int g = gpu_readable(src, m->device);
-      if (g > 0) return src;
-      if (g < 0) { foreign = true; return src; }
+    // (classify_host_arrays has vetted them: page-locked = 1, ordinary = 0, nothing device-resident)
+    auto view = [&](const void* src, int where, size_t bytes, size_t at) -> const void* {
+      if (!src || where > 0) return src;
       memcpy(H + at, src, bytes);
       return H + at;
     };
-    W.xy = (const float*)view(raw->xy, 8 * (size_t)nq, P.oQx);          // (the qx and qy regions are adjacent)
-    W.level = (const int*)view(raw->level, 4 * (size_t)nq, P.oQa);
-    W.aux = (const float*)view(raw->aux, 4 * (size_t)nq, P.oQr);
-    W.flags = (const uint8_t*)view(raw->flags, (size_t)nq, P.oQc);
-    W.claimSrc = raw->claimSrc == raw->flags ? W.flags : (const uint8_t*)view(raw->claimSrc, (size_t)nq, P.oQb);
-    W.angle = (const float*)view(raw->angle, 4 * (size_t)nq, P.oQang);
-    W.occ = (const uint8_t*)view(raw->occ, (size_t)n, P.oOcc);
-    if (foreign) { set_err("an input array lives in the memory of another device"); return ORBFE_ERR_INVALID; }
+    W.xy = (const float*)view(raw->xy, raw->where[0], 8 * (size_t)nq, P.oQx);          // (the qx and qy regions are adjacent)
+    W.level = (const int*)view(raw->level, raw->where[1], 4 * (size_t)nq, P.oQa);
+    W.aux = (const float*)view(raw->aux, raw->where[2], 4 * (size_t)nq, P.oQr);
+    W.flags = (const uint8_t*)view(raw->flags, raw->where[3], (size_t)nq, P.oQc);
+    W.claimSrc = raw->claimSrc == raw->flags ? W.flags : (const uint8_t*)view(raw->claimSrc, raw->where[4], (size_t)nq, P.oQb);
+    W.angle = (const float*)view(raw->angle, raw->where[5], 4 * (size_t)nq, P.oQang);
+    W.occ = (const uint8_t*)view(raw->occ, raw->where[6], (size_t)n, P.oOcc);
+    if (indexed) W.descRow = (const int*)view(raw->descRow, raw->descRowWhere, 4 * (size_t)nq, P.oQd);   // (the descriptor region of the arena is free)
     if (raw->sf) {   // scale factors in device memory, refreshed when the caller's differ from the copy there
       if (raw->nlevels > 32) { set_err("more than 32 levels"); return ORBFE_ERR_INVALID; }
       if (!m->d_sf.p) { if ((rc = m->d_sf.ensure(32))) return rc; m->sfN = -1; }
@@ -843,6 +873,7 @@ int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint
     if (raw) {
       M.rawKind = W.kind; M.rawXY = W.xy; M.rawLevel = W.level; M.rawAux = W.aux; M.rawFlags = W.flags;
       M.rawSf = m->d_sf.p; M.rawTh = W.th; M.rawFactor = W.factor;
+      if (indexed) { M.qdescRow = W.descRow; M.qdescAlt = W.descHost; }
       M.bitSrc[0] = W.claimSrc; M.bitMask[0] = W.claimMask; M.bitConst[0] = W.claimConst;
       withOcc = W.occ != nullptr;
       if (withOcc) { M.bitSrc[1] = W.occ; M.bitDst[1] = dOcc; M.bitN[1] = n; }
@@ -1017,6 +1048,12 @@ int orbfe_frame_create_from_extract(orbfe_extractor* h, int frame_index, const f
 
 void orbfe_frame_destroy(orbfe_frame* f) { delete f; }
 int orbfe_frame_size(const orbfe_frame* f) { return f ? f->n : 0; }
+int orbfe_frame_device(const orbfe_frame* f) { return f ? f->device : -1; }
+
+// generation of the host-object <-> resident-frame association (include/orbfe.h)
+static std::atomic<unsigned long long> g_residentEpoch{1};
+unsigned long long orbfe_resident_epoch(void) { return g_residentEpoch.load(std::memory_order_acquire); }
+unsigned long long orbfe_resident_invalidate(void) { return g_residentEpoch.fetch_add(1, std::memory_order_acq_rel) + 1; }
 
 const uint8_t* orbfe_frame_descriptors_device(orbfe_frame* f) {
   if (!f || !f->n) return nullptr;
@@ -1060,15 +1097,30 @@ int orbfe_debug_resolve_phases(const orbfe_matcher* m, int out[4]) {
 }
 
 // int ORBmatcher::SearchByProjection(Frame& F, const vector<MapPoint*>& vpMapPoints, const float th)  (ORBmatcher.cc:45-132)
-int orbfe_search_by_projection_frame(orbfe_matcher* m, orbfe_frame* f, const float* scale_factors, int nlevels,
-                                     const uint8_t* kp_occupied, const float* mp_proj_xy, const int32_t* mp_level,
-                                     const float* mp_viewcos, const uint8_t* mp_flags, const uint8_t* mp_desc, int n_mp,
-                                     float th, float nnratio, int32_t* kp_assigned, int* nmatches) {
+// mp_desc_row == nullptr: MapPoint i's descriptor is row i of mp_desc.  Else: row (mp_desc_row[i] & 0x7fffffff) of the device
+// table mp_desc (bit 31 clear) or of its page-locked host mirror desc_host (bit 31 set) -- orbfe_search_by_projection_frame_rows.
+static int sbp_frame_impl(orbfe_matcher* m, orbfe_frame* f, const float* scale_factors, int nlevels,
+                          const uint8_t* kp_occupied, const float* mp_proj_xy, const int32_t* mp_level,
+                          const float* mp_viewcos, const uint8_t* mp_flags, const uint8_t* mp_desc, const int32_t* mp_desc_row,
+                          const uint8_t* desc_host, int n_mp, float th, float nnratio, int32_t* kp_assigned, int* nmatches) {
   const double tEntry = orbfe_matcher::nowMs();
   if (!m || !f || !nmatches || n_mp < 0 || !scale_factors || (f->n && (!kp_occupied || !kp_assigned)) ||
-      (n_mp && (!mp_proj_xy || !mp_level || !mp_viewcos || !mp_flags || !mp_desc))) {
+      (n_mp && (!mp_proj_xy || !mp_level || !mp_viewcos || !mp_flags || !mp_desc)) || (mp_desc_row && !desc_host)) {
     set_err("bad argument");
     return ORBFE_ERR_INVALID;
+  }
+  if (mp_desc_row && !(frame_zero_copy() && nlevels <= 32)) {
+    // the marshalled routes take plain rows: gathered from the mirror, which holds every row
+    if (gpu_readable(mp_desc_row, m->device) == 2 || gpu_readable(desc_host, m->device) == 2) {
+      set_err("descriptor row indices and the table's mirror must be host memory");
+      return ORBFE_ERR_INVALID;
+    }
+    std::vector<uint8_t> rows(32 * (size_t)std::max(n_mp, 1), 0);
+    for (int i = 0; i < n_mp; i++)
+      if ((mp_flags[i] & ORBFE_MP_IN_VIEW) && !(mp_flags[i] & ORBFE_MP_BAD))
+        memcpy(&rows[32 * (size_t)i], desc_host + 32 * (size_t)((unsigned)mp_desc_row[i] & 0x7fffffffu), 32);
+    return sbp_frame_impl(m, f, scale_factors, nlevels, kp_occupied, mp_proj_xy, mp_level, mp_viewcos, mp_flags, rows.data(), nullptr,
+                          nullptr, n_mp, th, nnratio, kp_assigned, nmatches);
   }
   const int n = f->n;
   *nmatches = 0;
@@ -1080,14 +1132,16 @@ int orbfe_search_by_projection_frame(orbfe_matcher* m, orbfe_frame* f, const flo
   if (rc) return rc;
   const bool bFactor = th != 1.0;
   const int* out = nullptr;
+  RawQ Q;
+  Q.kind = 1; Q.xy = mp_proj_xy; Q.level = mp_level; Q.aux = mp_viewcos; Q.flags = mp_flags;
+  Q.claimSrc = mp_flags; Q.claimMask = ORBFE_MP_OBSERVED;
+  Q.occ = kp_occupied; Q.sf = scale_factors; Q.nlevels = nlevels; Q.th = th; Q.factor = bFactor ? 1 : 0;
+  Q.descRow = mp_desc_row; Q.descHost = desc_host;
+  if ((rc = classify_host_arrays(m, &Q))) return rc;
   if (frame_zero_copy() && nlevels <= 32) {   // no loop over the MapPoints here: the window kernel reads the caller's arrays
     float maxSf = 0.f;
     if ((rc = check_levels(mp_level, mp_flags, ORBFE_MP_IN_VIEW | ORBFE_MP_BAD, ORBFE_MP_IN_VIEW, n_mp, scale_factors, nlevels, &maxSf, "MapPoint")))
       return rc;
-    RawQ Q;
-    Q.kind = 1; Q.xy = mp_proj_xy; Q.level = mp_level; Q.aux = mp_viewcos; Q.flags = mp_flags;
-    Q.claimSrc = mp_flags; Q.claimMask = ORBFE_MP_OBSERVED;
-    Q.occ = kp_occupied; Q.sf = scale_factors; Q.nlevels = nlevels; Q.th = th; Q.factor = bFactor ? 1 : 0;
     float rmaxRaw = 4.0f;
     if (bFactor) rmaxRaw *= th;
     if ((rc = run_search(m, f, P, mp_desc, rmaxRaw * maxSf, nnratio, TH_HIGH, 0.0, 0, &out, nmatches, &Q))) return rc;
@@ -1119,6 +1173,23 @@ int orbfe_search_by_projection_frame(orbfe_matcher* m, orbfe_frame* f, const flo
   return ORBFE_OK;
 }
 
+int orbfe_search_by_projection_frame(orbfe_matcher* m, orbfe_frame* f, const float* scale_factors, int nlevels,
+                                     const uint8_t* kp_occupied, const float* mp_proj_xy, const int32_t* mp_level,
+                                     const float* mp_viewcos, const uint8_t* mp_flags, const uint8_t* mp_desc, int n_mp,
+                                     float th, float nnratio, int32_t* kp_assigned, int* nmatches) {
+  return sbp_frame_impl(m, f, scale_factors, nlevels, kp_occupied, mp_proj_xy, mp_level, mp_viewcos, mp_flags, mp_desc, nullptr, nullptr,
+                        n_mp, th, nnratio, kp_assigned, nmatches);
+}
+int orbfe_search_by_projection_frame_rows(orbfe_matcher* m, orbfe_frame* f, const float* scale_factors, int nlevels,
+                                          const uint8_t* kp_occupied, const float* mp_proj_xy, const int32_t* mp_level,
+                                          const float* mp_viewcos, const uint8_t* mp_flags, const uint8_t* desc_table_device,
+                                          const uint8_t* desc_table_host, const int32_t* mp_desc_row, int n_mp, float th,
+                                          float nnratio, int32_t* kp_assigned, int* nmatches) {
+  if (!mp_desc_row || !desc_table_host || !desc_table_device) { set_err("bad argument"); return ORBFE_ERR_INVALID; }
+  return sbp_frame_impl(m, f, scale_factors, nlevels, kp_occupied, mp_proj_xy, mp_level, mp_viewcos, mp_flags, desc_table_device,
+                        mp_desc_row, desc_table_host, n_mp, th, nnratio, kp_assigned, nmatches);
+}
+
 // SearchByProjection(Frame&, const Frame&, th) / (Frame&, KeyFrame*, set, th, ORBdist) from the projection onwards
 // (ORBmatcher.cc:1292-1423, 1425-1552)
 int orbfe_search_by_projection_uv_frame(orbfe_matcher* m, orbfe_frame* f, const float* scale_factors, int nlevels,
@@ -1141,14 +1212,15 @@ int orbfe_search_by_projection_uv_frame(orbfe_matcher* m, orbfe_frame* f, const 
   int rc = plan_search(m, f, kModeUv, n_src, true, 0, &P);
   if (rc) return rc;
   const int* out = nullptr;
+  RawQ Q;
+  Q.kind = 2; Q.xy = src_uv; Q.level = src_level; Q.flags = src_valid; Q.angle = src_angle;
+  Q.claimSrc = src_flags; Q.claimMask = ORBFE_MP_OBSERVED;
+  Q.occ = kp_occupied; Q.sf = scale_factors; Q.nlevels = nlevels; Q.th = th;
+  if ((rc = classify_host_arrays(m, &Q))) return rc;
+  if (skip_any_occupied) { Q.claimSrc = nullptr; Q.claimMask = 0xff; Q.claimConst = 1; }
   if (frame_zero_copy() && nlevels <= 32) {
     float maxSf = 0.f;
     if ((rc = check_levels(src_level, src_valid, 0, 0, n_src, scale_factors, nlevels, &maxSf, "source"))) return rc;
-    RawQ Q;
-    Q.kind = 2; Q.xy = src_uv; Q.level = src_level; Q.flags = src_valid; Q.angle = src_angle;
-    if (skip_any_occupied) Q.claimConst = 1;
-    else { Q.claimSrc = src_flags; Q.claimMask = ORBFE_MP_OBSERVED; }
-    Q.occ = kp_occupied; Q.sf = scale_factors; Q.nlevels = nlevels; Q.th = th;
     if ((rc = run_search(m, f, P, src_desc, th * maxSf, 0.f, max_dist, 0.0, check_orientation, &out, nmatches, &Q))) return rc;
     memcpy(kp_assigned, out, sizeof(int32_t) * (size_t)n);
     m->stageMs[2] = orbfe_matcher::nowMs() - m->tSynced;
@@ -1201,13 +1273,14 @@ int orbfe_search_projected_frame(orbfe_matcher* m, orbfe_frame* f, int n_src, co
   int rc = plan_search(m, f, kModeProjected, n_src, kp_skip != nullptr, inv_level_sigma2 ? nlevels : 0, &P);
   if (rc) return rc;
   const int* out = nullptr;
+  RawQ Q;
+  Q.kind = 3; Q.xy = src_uv; Q.level = src_level; Q.aux = src_radius; Q.flags = src_valid;
+  Q.claimConst = claim ? 1 : 0;
+  Q.occ = kp_skip;
+  if ((rc = classify_host_arrays(m, &Q))) return rc;
   if (frame_zero_copy()) {
     float rmaxRaw = 0.f;
     for (int i = 0; i < n_src; i++) rmaxRaw = std::max(rmaxRaw, src_radius[i]);   // (of all sources: an upper bound)
-    RawQ Q;
-    Q.kind = 3; Q.xy = src_uv; Q.level = src_level; Q.aux = src_radius; Q.flags = src_valid;
-    Q.claimConst = claim ? 1 : 0;
-    Q.occ = kp_skip;
     if (inv_level_sigma2) memcpy(P.invSigma2, inv_level_sigma2, sizeof(float) * (size_t)nlevels);
     if ((rc = run_search(m, f, P, src_desc, rmaxRaw, 0.f, max_dist, chi2, 0, &out, nmatches, &Q))) return rc;
     memcpy(best_idx, out, sizeof(int32_t) * (size_t)n_src);

@@ -944,7 +944,9 @@ int launch_pyramid(const PyramidParams& P, int nframes, hipStream_t st, const Co
   }
   for (int l = 1; l <= last; l++) {
     dim3 grid((P.lv[l].w + kRzTile - 1) / kRzTile, (P.lv[l].h + kRzTile - 1) / kRzTile, nframes);
-    if (P.lv[l].rzPitch <= 96 && P.lv[l].rzRows <= 80) {
+    // (tilesX == 1 -- a level at most 64 px wide -- takes the generic kernel: 2^32 / 1 + 1 wraps to rcp = 1 and the multiply-high
+    // below would return row 0 for every tile; exact only for tilesX >= 2)
+    if (P.lv[l].rzPitch <= 96 && P.lv[l].rzRows <= 80 && grid.x >= 2) {
       const int tilesX = (int)grid.x, ntiles = (int)(grid.x * grid.y);
       const unsigned rcp = (unsigned)(0x100000000ull / (unsigned)tilesX) + 1u;   // floor(t * rcp / 2^32) = t / tilesX for t * tilesX < 2^32
       if ((unsigned long long)ntiles * tilesX < (1ull << 31)) {

@@ -332,6 +332,20 @@ int orbfe_matcher_create(int device_id, orbfe_matcher** out) {
 }
 
 void orbfe_matcher_destroy(orbfe_matcher* m) { delete m; }
+int orbfe_matcher_device(const orbfe_matcher* m) { return m ? m->device : -1; }
+int orbfe_matcher_upload_async(orbfe_matcher* m, void* dst_device, const void* src_host, size_t bytes) {
+  if (!m || !dst_device || !src_host) { set_err("NULL argument"); return ORBFE_ERR_INVALID; }
+  if (bytes == 0) return ORBFE_OK;
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipMemcpyAsync(dst_device, src_host, bytes, hipMemcpyHostToDevice, m->stream));
+  return ORBFE_OK;
+}
+int orbfe_matcher_synchronize(orbfe_matcher* m) {
+  if (!m) { set_err("matcher is NULL"); return ORBFE_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return ORBFE_OK;
+}
 
 extern "C++" {
 namespace orbfe {

@@ -65,6 +65,11 @@ struct MatchParams {
   const int* qminL;
   const int* qmaxL;
   const uint8_t* qdesc;   // [nq][32]
+  // indexed descriptor rows (a caller-maintained table, orbfe_search_by_projection_frame_rows): query q's descriptor is row
+  // (qdescRow[q] & 0x7fffffff) of qdesc (bit 31 clear) or of qdescAlt (bit 31 set: the table's page-locked host mirror, for
+  // rows the device copy has not received yet); nullptr: row q of qdesc
+  const int* qdescRow = nullptr;
+  const uint8_t* qdescAlt = nullptr;
   int nq;
   // outputs
   uint32_t* qcount;       // [nq]
@@ -184,6 +189,8 @@ __global__ __launch_bounds__(kWinThreads) void k_window_match(MatchParams M) {
   float r = -1.f, x = 0.f, y = 0.f;
   int minL = 0, maxL = -1;
   PairInfo pi = M.pairs[0];
+  int drow = 0;   // row of the query's descriptor in an indexed table: requested together with the other query fields
+  if (live && M.qdescRow) drow = M.qdescRow[q];
   if (live && M.rawKind) {
     const float2 p = reinterpret_cast<const float2*>(M.rawXY)[q];
     const int lvl = M.rawLevel[q];
@@ -225,6 +232,10 @@ __global__ __launch_bounds__(kWinThreads) void k_window_match(MatchParams M) {
   uint32_t qd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (live && r >= 0.f) {
     const uint4* qp = reinterpret_cast<const uint4*>(M.qdesc + (size_t)q * 32);
+    if (M.qdescRow) {
+      const unsigned row = (unsigned)drow;
+      qp = reinterpret_cast<const uint4*>(((row >> 31) ? M.qdescAlt : M.qdesc) + (size_t)(row & 0x7fffffffu) * 32);
+    }
     const uint4 a = qp[0], b4 = qp[1];
     qd[0] = a.x; qd[1] = a.y; qd[2] = a.z; qd[3] = a.w; qd[4] = b4.x; qd[5] = b4.y; qd[6] = b4.z; qd[7] = b4.w;
   }
@@ -281,7 +292,7 @@ __global__ __launch_bounds__(kWinThreads) void k_window_match(MatchParams M) {
   // pass 1b (searches on a resident frame): candidates whose distance rules them out whatever the other queries do never
   // enter the list -- shorter lists mean records instead of walked lists and fewer rounds of the bookkeeping, with the
   // same outcome.  Modes 1, 2 (best <= maxDist decides alone, ORBmatcher.cc:1373-1383, :376-392): dist > maxDist.  Mode 0
-  // (:95-120): a candidate with nnratio * dist >= TH_HIGH can neither be accepted (dist > TH_HIGH) nor, as second best, make
+  // (:95-120): a candidate with dist > TH_HIGH and nnratio * dist >= TH_HIGH can neither be accepted nor, as second best, make
   // the ratio test reject an acceptable best (bestDist <= TH_HIGH <= nnratio * dist); dropping it leaves, in its place, a
   // second best that is at least as far, i.e. as irrelevant.  Distances are computed here for the verdict only; the
   // survivors' entries are produced by pass 2 as before.  Runs beyond the 64-entry mask are left as they are.
@@ -299,8 +310,9 @@ __global__ __launch_bounds__(kWinThreads) void k_window_match(MatchParams M) {
                      __popc(da1.y ^ qd[5]) + __popc(da1.z ^ qd[6]) + __popc(da1.w ^ qd[7]);
       const int d1 = __popc(db0.x ^ qd[0]) + __popc(db0.y ^ qd[1]) + __popc(db0.z ^ qd[2]) + __popc(db0.w ^ qd[3]) + __popc(db1.x ^ qd[4]) +
                      __popc(db1.y ^ qd[5]) + __popc(db1.z ^ qd[6]) + __popc(db1.w ^ qd[7]);
-      const bool drop0 = M.codeMode == 0 ? M.nnratio * (float)d0 >= (float)TH_HIGH : d0 > M.maxDist;
-      const bool drop1 = M.codeMode == 0 ? M.nnratio * (float)d1 >= (float)TH_HIGH : d1 > M.maxDist;
+      // (d > TH_HIGH spelled out: for nnratio >= 1 the product alone would drop an acceptable candidate, e.g. d == 100)
+      const bool drop0 = M.codeMode == 0 ? (d0 > TH_HIGH && M.nnratio * (float)d0 >= (float)TH_HIGH) : d0 > M.maxDist;
+      const bool drop1 = M.codeMode == 0 ? (d1 > TH_HIGH && M.nnratio * (float)d1 >= (float)TH_HIGH) : d1 > M.maxDist;
       if (drop0) { hm &= ~(1ull << a0); hits--; }
       if (drop1 && a1 != a0) { hm &= ~(1ull << a1); hits--; }
     }
@@ -441,7 +453,9 @@ struct PinBuf {
     if (count <= n) return ORBFE_OK;
     if (p) (void)hipHostFree(p);
     p = nullptr; n = 0;
-    HIP_TRY(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault));
+    // Coherent (fine-grained, uncached on the GPU side) EXPLICITLY: kernels store results and completion words here and the
+    // host polls them while the kernel runs; with hipHostMallocDefault that property would hang on HIP_HOST_COHERENT.
+    HIP_TRY(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocCoherent));
     n = count;
     return ORBFE_OK;
   }

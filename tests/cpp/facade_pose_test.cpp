@@ -436,5 +436,80 @@ int main(int argc, char** argv) {
     const int got = orbfe::SearchBySim3(ctx, &kf1, &kf2, vpMatches12, s12, R12m, t12m, 7.5f);
     report("SearchBySim3(pKF1, pKF2, vpMatches12, s12, R12, t12, th)", got == want && idsOf(vpMatches12) == m12 && want > 30, got, want, M);
   }
+
+  // ---- 7. recycled identities: Tracking::Reset() sets Frame::nNextId / KeyFrame::nNextId back to 0 (Tracking.cc:1159-1160) and
+  // Osmap's map load re-creates KeyFrames with the ids stored in the file (Osmap.cpp:586).  A DIFFERENT frame / keyframe
+  // with a recycled mnId and the same N must be searched on ITS OWN features: four objects per kind with one id, the same
+  // N and different content, searched in turn and again in reverse order (each one's resident copy must still be its own).
+  {
+    bool ok = true;
+    int total = 0;
+    const size_t uploadsBefore = ctx.residentUploads();
+    std::vector<KeyFrame> kfs(4);
+    std::vector<std::vector<MapPoint> > mps(4);
+    std::vector<std::vector<MapPoint*> > ptsv(4);
+    float Ts[4][16];
+    for (int j = 0; j < 4; j++) {
+      Rng r(seed * 10 + 40 + j);
+      KeyFrame& kf = kfs[j];
+      makeView(r, kf, 1700);
+      kf.mnId = 3;                      // ... every one of them "keyframe 3"
+      makePose(r, 1.35f, Ts[j]);
+      setTcw(kf, Ts[j]);
+      mps[j].resize(1200);
+      for (int i = 0; i < 1200; i++) { mps[j][i].id = i; mps[j][i].kf = &kf; makePoint(r, mps[j][i], kf, r.below(kf.N), Ts[j], 1.35f); ptsv[j].push_back(&mps[j][i]); }
+    }
+    const int order[8] = {0, 1, 2, 3, 3, 1, 0, 2};
+    for (int o = 0; o < 8; o++) {
+      const int j = order[o];
+      Table tab(mps[j]);
+      OrcView kv = viewOf(kfs[j]);
+      std::vector<int32_t> ids = idsOf(ptsv[j]);
+      std::vector<MapPoint*> vpMatched(kfs[j].N, nullptr);
+      std::vector<int32_t> m(kfs[j].N, -1);
+      const int want = orc_sbp_scw(&kv, Ts[j], ids.data(), (int)ids.size(), &tab.P, m.data(), 10);
+      const int got = orbfe::SearchByProjection(ctx, &kfs[j], kfs[j].mTcw, ptsv[j], vpMatched, 10);
+      ok = ok && got == want && idsOf(vpMatched) == m && want > 100;
+      total += got;
+    }
+    // four distinct contents -> four resident copies, each uploaded once; the second visits are hits
+    ok = ok && ctx.residentUploads() == uploadsBefore + 4;
+    report("KeyFrames sharing one mnId and N (map load): each searched on its own features", ok, total, total, 8);
+  }
+  {
+    bool ok = true;
+    int total = 0;
+    for (int round = 0; round < 2; round++)
+      for (int j = 0; j < 3; j++) {
+        Rng r(seed * 10 + 60 + j);
+        Frame cur, last;
+        makeView(r, cur, 1800);
+        makeView(r, last, 1200);
+        cur.mnId = 7; last.mnId = 6;      // after every Reset() the same pair of ids
+        float T[16];
+        makePose(r, 1.f, T);
+        setTcw(cur, T);
+        std::vector<MapPoint> mp(1200);
+        for (int i = 0; i < 1200; i++) {
+          mp[i].id = i;
+          const int k = r.below(cur.N);
+          makePoint(r, mp[i], cur, k, T, 1.f);
+          last.mvpMapPoints[i] = &mp[i];
+          last.mvKeys[i].octave = last.mvKeysUn[i].octave = cur.mvKeysUn[k].octave;
+        }
+        if (round == 1) orbfe_resident_invalidate();   // with the hook: every context drops its frames at its next lookup
+        Table tab(mp);
+        std::vector<int32_t> cur_mp = idsOf(cur.mvpMapPoints), last_mp = idsOf(last.mvpMapPoints);
+        std::vector<uint8_t> outl(last.N, 0);
+        OrcView cv = viewOf(cur);
+        const int want = orc_sbp_frame(&cv, T, reinterpret_cast<const OrcKp*>(last.mvKeys.data()), reinterpret_cast<const OrcKp*>(last.mvKeysUn.data()),
+                                       last.N, last_mp.data(), outl.data(), &tab.P, cur_mp.data(), 15.f, 0);
+        const int got = orbfe::SearchByProjection(ctx, false, cur, last, 15.f);
+        ok = ok && got == want && idsOf(cur.mvpMapPoints) == cur_mp && want > 200;
+        if (round == 1) ok = ok && ctx.residentFrames() == 1;   // the invalidation emptied the cache before this frame went in
+        total += got;
+      }
+    report("Frames sharing one mnId and N (Tracking::Reset): each searched on its own features", ok, total, total, 6);
+  }
   return failures ? 1 : 0;
 }

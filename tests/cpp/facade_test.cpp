@@ -171,6 +171,13 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < r2.size(); i++)
       if (vpMatches12[i]) r2[i] = (int)(vpMatches12[i] - own[1].data());
     writeFile(dir + "/bow2.matches", r2.data(), r2.size() * sizeof(int));
+    {   // a frame cache of ONE entry: both sides' resident rows must survive the call (the two most recent frames are never evicted)
+      ctx.setFrameCacheCapacity(1);
+      std::vector<MapPoint*> again;
+      const int nb = orbfe::SearchByBoW(ctx, 0.75f, true, &F[0], &F[1], again);
+      ctx.setFrameCacheCapacity(48);
+      if (nb != nbow2 || again != vpMatches12) return 7;
+    }
     // LocalMapping::CreateNewMapPoints (LocalMapping.cc:396): F12 = [t]x for the image translation A -> B
     Mat33f F12 = {{0.f, 0.f, 4e-3f, 0.f, 0.f, 10e-3f, -4e-3f, -10e-3f, 0.f}};
     std::vector<std::pair<size_t, size_t> > vMatchedPairs;

@@ -48,7 +48,7 @@ class KeyFrame {
  public:
   long unsigned int mnId;   // KeyFrame.h:574
   const int N;
-  const std::vector<cv::KeyPoint> mvKeysUn;
+  const std::vector<cv::KeyPoint> mvKeys, mvKeysUn;   // KeyFrame.h:653, 662
   const cv::Mat mDescriptors;
   const float fx, fy, cx, cy, mfLogScaleFactor;
   const int mnMinX, mnMinY, mnMaxX, mnMaxY;

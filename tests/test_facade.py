@@ -164,9 +164,57 @@ def test_pose_facade_compiles_and_links(tmp_path):
 def test_pose_driven_searches_match_oracle(tmp_path, seed):
     """SearchByProjection(Frame, Frame), (Frame, KeyFrame, set), (KeyFrame, Scw), Fuse x2 and SearchBySim3 -- the shim
     bodies over the GPU searches against the oracle's whole-function restatements, exact on every output (match
-    counts, MapPoint assignments, replaced / added points, observation counts)."""
+    counts, MapPoint assignments, replaced / added points, observation counts) -- and the resident-frame cache under
+    RECYCLED ids: KeyFrames / Frames that share one mnId and one N but not their features (a map load, Osmap.cpp:586; a
+    Tracking::Reset(), Tracking.cc:1159-1160) are each searched on their own features, with and without the
+    orbfe_resident_invalidate() hook."""
     exe = str(tmp_path / 'facade_pose_test')
     _compile_pose(exe)
     r = subprocess.run([exe, str(seed)], capture_output=True, text=True, timeout=600)
     lines = [l for l in r.stdout.splitlines() if l.startswith(('PASS', 'FAIL'))]
-    assert r.returncode == 0 and len(lines) == 7 and all(l.startswith('PASS') for l in lines), r.stdout + r.stderr[-2000:]
+    assert r.returncode == 0 and len(lines) == 9 and all(l.startswith('PASS') for l in lines), r.stdout + r.stderr[-2000:]
+
+
+# ---- the front end as Tracking.cc drives it, with a Reset() in the middle ---------------------------------------------
+def _compile_tracking(out):
+    from os1_amd import api
+    from oracle import pyoracle
+    if not os.path.exists(api.lib_path()):
+        api.build_library()
+    pyoracle.build()
+    cmd = ['g++', '-std=c++17', '-O1', '-Wall', '-Werror', '-ffp-contract=off', '-I' + os.path.join(ROOT, 'include'),
+           '-I' + os.path.join(ROOT, 'oracle'), os.path.join(ROOT, 'tests', 'cpp', 'tracking_sequence_test.cpp'), '-o', out,
+           os.path.join(ROOT, 'os1_amd', 'liborbfe.so'), os.path.join(ROOT, 'oracle', 'liborb_oracle.so'),
+           '-Wl,-rpath,' + os.path.join(ROOT, 'os1_amd'), '-Wl,-rpath,' + os.path.join(ROOT, 'oracle'),
+           '-Wl,-rpath-link,/opt/rocm/lib']
+    subprocess.check_call(cmd)
+
+
+def test_tracking_sequence_compiles_and_links(tmp_path):
+    exe = str(tmp_path / 'tracking_sequence_test')
+    _compile_tracking(exe)
+    assert os.path.exists(exe)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('invalidate,distort', [(1, 0), (0, 1)])
+def test_tracking_sequence_with_reset_matches_oracle(tmp_path, invalidate, distort):
+    """40 synthetic frames through orbfe::Extractor -> mock Frame (undistortion, bounds) -> SearchForInitialization on the
+    first pair -> per frame SearchByProjection(F, LastFrame, th) with the 2*th retry below 20 matches (Tracking.cc:596-614)
+    and SearchByProjection(F, local MapPoints, th) (:818-824) -> Tracking::Reset() after frame 20 (Frame ids restart at 0,
+    Tracking.cc:1159-1160) -> a second initialisation and more tracking on DIFFERENT images.  Every call's outputs equal the
+    oracle's; no frame's features are uploaded twice (the resident frames come from the extractor's arena); the local map's
+    descriptor rows are read from device memory whenever no row changed.  Run once with the orbfe_resident_invalidate() hook
+    in Reset() and once without (the cache is keyed by content), once with a distorting camera (mvKeysUn != mvKeys)."""
+    from os1_amd.synth import shifted, synth
+    exe = str(tmp_path / 'tracking_sequence_test')
+    _compile_tracking(exe)
+    W, H, NF, N, dx, dy, R = 640, 480, 40, 1000, -3, 1, 20
+    bases = (synth(61, W, H), synth(62, W, H))
+    for k in range(NF):
+        shifted(bases[k >= R], k * dx, k * dy, 900 + k).tofile(tmp_path / ('f%03d.gray' % k))
+    open(tmp_path / 'meta.txt', 'w').write('%d %d %d %d %d %d %d\n' % (W, H, NF, N, dx, dy, R))
+    r = subprocess.run([exe, str(tmp_path), str(invalidate), str(distort)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith('PASS'), r.stdout[-3000:] + r.stderr[-2000:]
+    stats = dict(zip(r.stdout.splitlines()[-3].split()[0::2], r.stdout.splitlines()[-3].split()[1::2]))
+    assert int(stats['searched']) == NF - 4 and int(stats['matches_last']) > 150 * (NF - 4) // 2 and int(stats['matches_local']) > 1000

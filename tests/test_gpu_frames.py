@@ -417,3 +417,110 @@ def test_candidate_pool_grows_on_demand(api, oracle):
         assert got[0] == want[0] and got[1].tobytes() == want[1].tobytes() and got[2].tobytes() == want[2].tobytes()
         assert m.resolve_route() == 1                          # tables in LDS, lists in the pool
     assert got[0] > 800
+
+
+def test_search_by_projection_indexed_descriptor_table(api, oracle, monkeypatch):
+    """orbfe_search_by_projection_frame_rows: the MapPoints' descriptors are rows of a table the caller keeps on the device
+    (the local map across frames, Tracking.cc:818-824).  Rows referenced in a permuted order, some read from the device
+    copy and some -- changed since the last upload -- from the page-locked mirror (bit 31); then a descriptor is mutated
+    between two searches (MapPoint::ComputeDistinctiveDescriptors, MapPoint.cc:227-292) and must be seen.  Results equal the
+    oracle's on the gathered rows; the marshalled route (ORBFE_FRAME_ZEROCOPY=0) gathers from the mirror."""
+    W, H, N = 1280, 720, 1500
+    img = synth(14, W, H)
+    ex = api.Extractor(N, 1.2, 8, 20, 7)
+    k, d = ex(img)
+    bounds = (0.0, float(W), 0.0, float(H))
+    sf = ex.tables()['sf']
+    m = api.Matcher()
+    rng = np.random.default_rng(21)
+    n_mp = 4000
+    xy, level, viewcos, flags, mdesc = _mappoints(k, d, n_mp, rng)
+    occ = (rng.random(len(k)) < 0.1).astype(np.uint8)
+    fr = api.Frame.from_host(m, k, d, bounds)
+    tab = api.DescTable(6000)
+    slot = rng.permutation(6000)[:n_mp].astype(np.int64)          # MapPoint i lives in row slot[i]: order unrelated to the query order
+    tab.host.a[slot] = mdesc
+    tab.upload(m, 0, 6000)
+    want = oracle.search_by_projection(k, d, bounds, sf, occ, xy, level, viewcos, flags, mdesc, 1.0, 0.8)
+    rows = slot.astype(np.int32)
+    n, a = m.search_by_projection_rows(fr, sf, occ, xy, level, viewcos, flags, tab, rows, 1.0, 0.8)
+    assert n == want[0] and (a == want[1]).all() and n > 400
+    # 300 descriptors change: the mirror has them, the device copy does not -> those rows are flagged for the mirror
+    changed = rng.choice(n_mp, 300, replace=False)
+    mdesc2 = mdesc.copy()
+    mdesc2[changed] ^= rng.integers(0, 256, (300, 32), dtype=np.uint8)
+    tab.host.a[slot[changed]] = mdesc2[changed]
+    rows2 = rows.copy()
+    rows2[changed] = (slot[changed] | 0x80000000).astype(np.uint32).view(np.int32)
+    want2 = oracle.search_by_projection(k, d, bounds, sf, occ, xy, level, viewcos, flags, mdesc2, 3.0, 0.8)
+    n, a = m.search_by_projection_rows(fr, sf, occ, xy, level, viewcos, flags, tab, rows2, 3.0, 0.8)
+    assert n == want2[0] and (a == want2[1]).all()
+    assert not (want2[1] == oracle.search_by_projection(k, d, bounds, sf, occ, xy, level, viewcos, flags, mdesc, 3.0, 0.8)[1]).all()
+    # stale device rows really are stale: the same search WITHOUT the flags gives the old descriptors' result
+    n, a = m.search_by_projection_rows(fr, sf, occ, xy, level, viewcos, flags, tab, rows, 3.0, 0.8)
+    old = oracle.search_by_projection(k, d, bounds, sf, occ, xy, level, viewcos, flags, mdesc, 3.0, 0.8)
+    assert n == old[0] and (a == old[1]).all()
+    # after the asynchronous upload of the changed rows the plain indices see the new bytes
+    for s_ in np.sort(slot[changed]):
+        tab.upload(m, int(s_), int(s_) + 1)
+    n, a = m.search_by_projection_rows(fr, sf, occ, xy, level, viewcos, flags, tab, rows, 3.0, 0.8)
+    assert n == want2[0] and (a == want2[1]).all()
+    # page-locked index array, read in place
+    pr = api.PinnedArray(rows.shape, np.int32)
+    pr.a[:] = rows2
+    n, a = m.search_by_projection_rows(fr, sf, occ, xy, level, viewcos, flags, tab, pr.a, 3.0, 0.8)
+    assert n == want2[0] and (a == want2[1]).all()
+    # the marshalled route gathers the rows from the mirror
+    monkeypatch.setenv('ORBFE_FRAME_ZEROCOPY', '0')
+    n, a = m.search_by_projection_rows(fr, sf, occ, xy, level, viewcos, flags, tab, rows2, 3.0, 0.8)
+    monkeypatch.delenv('ORBFE_FRAME_ZEROCOPY')
+    assert n == want2[0] and (a == want2[1]).all()
+    m.synchronize()
+    tab.free()
+
+
+def test_device_pointers_are_refused_for_host_read_arrays(api, oracle):
+    """include/orbfe.h: of a `_frame` search's input arrays only the descriptor rows may live in device memory -- the
+    library reads the others on the host too (level range, largest radius).  A device pointer for one of them must come back
+    as ORBFE_ERR_INVALID before anything dereferences it (it used to be dereferenced: a segfault); device-resident
+    descriptor rows of the bag-of-words search that the kernels cannot take (misaligned) are refused, not memcpy'd."""
+    import ctypes as C
+    W, H, N = 960, 540, 800
+    ex = api.Extractor(N, 1.2, 8, 20, 7)
+    k, d = ex(synth(15, W, H))
+    bounds = (0.0, float(W), 0.0, float(H))
+    sf = ex.tables()['sf']
+    m = api.Matcher()
+    rng = np.random.default_rng(3)
+    xy, level, viewcos, flags, mdesc = _mappoints(k, d, 500, rng)
+    occ = np.zeros(len(k), np.uint8)
+    fr = api.Frame.from_host(m, k, d, bounds)
+    L = m.L
+    dev = C.c_void_p()
+    api._check(L.orbfe_device_malloc(0, 1 << 16, C.byref(dev)))
+    assigned = np.full(len(k), -1, np.int32)
+    n = C.c_int(0)
+    args = [api._p(occ), api._p(xy), api._p(level.astype(np.int32)), api._p(viewcos), api._p(flags)]
+    keep = [level.astype(np.int32)]
+    args[2] = api._p(keep[0])
+    for bad in range(5):
+        a = list(args)
+        a[bad] = dev
+        rc = L.orbfe_search_by_projection_frame(m.h, fr.h, api._p(sf), len(sf), a[0], a[1], a[2], a[3], a[4], api._p(mdesc), 500,
+                                                C.c_float(1.0), C.c_float(0.8), api._p(assigned), C.byref(n))
+        assert rc != 0 and b'device memory' in L.orbfe_last_error(), bad
+    # the untouched call still works and equals the oracle
+    rc = L.orbfe_search_by_projection_frame(m.h, fr.h, api._p(sf), len(sf), *args, api._p(mdesc), 500, C.c_float(1.0), C.c_float(0.8),
+                                            api._p(assigned), C.byref(n))
+    on, oa = oracle.search_by_projection(k, d, bounds, sf, occ, xy, level, viewcos, flags, mdesc, 1.0, 0.8)
+    assert rc == 0 and n.value == on and (assigned == oa).all()
+    # bag of words: misaligned device rows
+    fv = (np.zeros(1, np.uint32), np.array([0, 1], np.uint32), np.zeros(1, np.uint32))
+    m12 = np.full(len(k), -1, np.int32)
+    ang = np.zeros(len(k), np.float32)
+    valid = np.ones(len(k), np.uint8)
+    rc = L.orbfe_search_by_bow(m.h, C.c_void_p(dev.value + 4), api._p(ang), api._p(valid), 8, api._p(fv[0]), api._p(fv[1]), api._p(fv[2]), 1,
+                               api._p(d), api._p(ang), None, 8, api._p(fv[0]), api._p(fv[1]), api._p(fv[2]), 1, C.c_float(0.7), 0, 0,
+                               api._p(m12), C.byref(n))
+    assert rc != 0 and b'16-byte aligned' in L.orbfe_last_error()
+    L.orbfe_device_free(0, dev)

@@ -122,6 +122,26 @@ def test_tiny_quotas_and_wide_strips(api, oracle):
     assert len(want[0]) > 0
 
 
+@pytest.mark.parametrize('cfg', [(225, 300, 300, 8), (110, 150, 120, 4), (229, 320, 250, 8)])
+def test_batch_with_a_level_one_tile_wide(api, oracle, cfg):
+    """Portrait images whose top pyramid level is at most 64 px wide but taller than 64 px: ONE tile column, several tile
+    rows (tilesX == 1) -- in batches larger than ORBFE_CONE_MAX_FRAMES, i.e. through the per-level resize launches.  The
+    XCD-consecutive tile mapping of k_resize_fixed divides by tilesX with a multiply-high that is exact only for
+    tilesX >= 2; such levels must take the generic kernel.  Every level pixel-exact for every frame of the batch."""
+    W, H, N, nl = cfg
+    imgs = [synth(300 + i, W, H) for i in range(4)]
+    ex = api.Extractor(N, 1.2, nl, 20, 7)
+    ox = OracleExtractor(N, 1.2, nl, 20, 7, oracle)
+    got = ex.extract_batch(imgs)
+    lh, lw = ex.level(nl - 1).shape
+    assert lw <= 64 < lh, (lw, lh)
+    for i, im in enumerate(imgs):
+        want = ox.extract(im)
+        for l in range(nl):
+            assert (ex.level(l, frame=i) == ox.level(l)).all(), 'frame %d pyramid level %d' % (i, l)
+        _cmp_extract(got[i], want)
+
+
 def test_edge_cases(api, oracle):
     ex = api.Extractor(500, 1.2, 8, 20, 7)
     k, d = ex(np.zeros((0, 0), np.uint8))                       # empty image: silent, no output
