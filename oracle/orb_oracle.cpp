@@ -1947,5 +1947,14 @@ void orc_image_bounds(int cols, int rows, int mode, float fx, float fy, float cx
   }
 }
 
+// The small-matrix arithmetic of the pose-driven searches, exported for the live-OpenCV cross-check (tests/test_opencv_live.py):
+// op 0 gemm3 (alpha * A * b + beta * c; c may be NULL), 1 gemmT3 (alpha * A^T * b), 2 norm3 (out[0], as double), 3 dot3.
+void orc_cv_small(int op, const float* A, const float* b, double alpha, const float* c, double beta, float* out3, double* out1) {
+  if (op == 0) cvGemm3(A, b, alpha, c, beta, out3);
+  else if (op == 1) cvGemmT3(A, b, alpha, out3);
+  else if (op == 2) *out1 = cvNorm3(b);
+  else *out1 = cvDot3(A, b);
+}
+
 }  // extern "C"
 

@@ -287,6 +287,19 @@ class Oracle:
                                          _p(f2[2]), len(f2[0]), nnratio, int(check_ori), _p(m12))
         return nm, m12[:n1]
 
+    def cv_small(self, op, A, b, alpha=1.0, c=None, beta=0.0):
+        """The restated small-matrix OpenCV arithmetic: op 'gemm' (alpha*A*b + beta*c), 'gemmT' (alpha*A.t()*b), 'norm' (of b),
+        'dot' (A[:3] . b)."""
+        A = np.ascontiguousarray(A, np.float32)
+        b = np.ascontiguousarray(b, np.float32)
+        cc = None if c is None else np.ascontiguousarray(c, np.float32)
+        out3, out1 = np.zeros(3, np.float32), C.c_double(0)
+        self.L.orc_cv_small.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_double, C.c_void_p,
+                                        C.POINTER(C.c_double)]
+        self.L.orc_cv_small({'gemm': 0, 'gemmT': 1, 'norm': 2, 'dot': 3}[op], _p(A), _p(b), alpha, None if cc is None else _p(cc),
+                            beta, _p(out3), C.byref(out1))
+        return out3 if op in ('gemm', 'gemmT') else out1.value
+
     def undistort_pinhole(self, xy, fx, fy, cx, cy, dist):
         xy = np.ascontiguousarray(xy, np.float32).copy()
         d = np.ascontiguousarray(dist, np.float32)

@@ -131,3 +131,27 @@ def test_bench_stream_definition():
     k['x'][1] = 1
     assert a != wl.frame_digest(k, np.zeros((3, 32), np.uint8), 3)
     assert wl.match_digest(2, np.array([1, -1, 0]), 3) != wl.match_digest(2, np.array([1, 0, -1]), 3)
+
+
+def test_shim_restated_ops_equal_the_oracle_restatement(oracle):
+    """orbfe::detail::RestatedOps (include/orbfe/orb_shim.hpp: what the cv-free shim computes for `Rcw*x3Dw+tcw`,
+    `-Rcw.t()*tcw`, cv::norm, Mat::dot, ORBmatcher.cc:293-298, 322-348, 1326-1343) and the oracle's cvGemm3 / cvGemmT3 /
+    cvNorm3 / cvDot3 are two statements of the same recalled OpenCV arithmetic: they must agree bit for bit on random inputs
+    over six decades (tests/test_opencv_live.py compares both with a real OpenCV where one exists)."""
+    from test_opencv_live import _restated_ops
+    shim = _restated_ops()
+    rng = np.random.default_rng(11)
+    for it in range(3000):
+        sc = 10.0 ** rng.integers(-3, 4)
+        A = (rng.standard_normal((3, 3)) * sc).astype(np.float32)
+        b = (rng.standard_normal(3) * sc).astype(np.float32)
+        c = (rng.standard_normal(3) * sc).astype(np.float32)
+        al, be = float(rng.choice([1.0, -1.0, 0.5, 1.37])), float(rng.choice([1.0, 0.0, -1.0]))
+        assert shim('gemm', A, b, al, c, be).tobytes() == oracle.cv_small('gemm', A, b, al, c, be).tobytes()
+        assert shim('gemm', A, b, al, None, 0.0).tobytes() == oracle.cv_small('gemm', A, b, al, None, 0.0).tobytes()
+        assert shim('gemmT', A, b, al).tobytes() == oracle.cv_small('gemmT', A, b, al).tobytes()
+        assert shim('norm', A, b) == oracle.cv_small('norm', A, b)
+        assert shim('dot', A.ravel()[:3], b) == oracle.cv_small('dot', A.ravel()[:3], b)
+        s = float(rng.uniform(0.3, 3.0))
+        assert (shim('scale', A, b, s) == A.ravel() * np.float32(s)).all()
+        assert (shim('divide', A, b, s) == A.ravel() * np.float32(1.0 / s)).all()

@@ -23,9 +23,41 @@ def _cv2():
     return cv2
 
 
+def _restated_ops():
+    """orbfe::detail::RestatedOps (include/orbfe/orb_shim.hpp) behind a C entry point, compiled on the spot."""
+    import ctypes as C
+    import os
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(tempfile.mkdtemp(), 'librestated_ops.so')
+    subprocess.check_call(['g++', '-std=c++17', '-O2', '-ffp-contract=off', '-shared', '-fPIC', '-I' + os.path.join(root, 'include'),
+                           os.path.join(root, 'tests', 'cpp', 'restated_ops_export.cpp'), '-o', so])
+    L = C.CDLL(so)
+    L.shim_cv_small.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_double, C.c_void_p, C.POINTER(C.c_double),
+                                C.c_int]
+
+    def call(op, A, b, alpha=1.0, c=None, beta=0.0):
+        A = np.ascontiguousarray(A, np.float32)
+        b = np.ascontiguousarray(b, np.float32)
+        cc = None if c is None else np.ascontiguousarray(c, np.float32)
+        n = A.size
+        out, out1 = np.zeros(max(n, 3), np.float32), C.c_double(0)
+        L.shim_cv_small({'gemm': 0, 'gemmT': 1, 'norm': 2, 'dot': 3, 'scale': 4, 'divide': 5}[op], A.ctypes.data, b.ctypes.data, alpha,
+                        None if cc is None else cc.ctypes.data, beta, out.ctypes.data, C.byref(out1), n)
+        if op in ('gemm', 'gemmT'):
+            return out[:3]
+        return out[:n] if op in ('scale', 'divide') else out1.value
+    return call
+
+
 def _check_against_opencv(oracle):
     cv2 = _cv2()
     print('OpenCV version under test:', cv2.__version__)
+    info = cv2.getBuildInformation()
+    for line in info.splitlines():      # what decides bit-exactness besides the version: IPP, the CPU baseline / dispatch lists
+        if any(key in line for key in ('IPP', 'Baseline', 'Dispatched', 'requested')):
+            print('  build:', ' '.join(line.split()))
     # optimisation paths (IPP / OpenCL) are not bit-exact by OpenCV's own account; the reference links the plain library,
     # compare against the generic code paths
     cv2.setUseOptimized(True)
@@ -57,6 +89,52 @@ def _check_against_opencv(oracle):
             got15, got14 = oracle.cvt_gray(img, rgb, 0), oracle.cvt_gray(img, rgb, 1)
             bad += not ((got15 == want).all() or (got14 == want).all())
     report['cvtColor'] = bad
+
+    # ---- the small-matrix arithmetic of the pose-driven searches (ORBmatcher.cc:293-298, 322-348, 1326-1343): the
+    # reference's cv::Mat expressions as OpenCV evaluates them -- `Rcw*x3Dw+tcw` = gemm(A, b, 1, c, 1), `-Rcw.t()*tcw` =
+    # gemm(A, b, -1, noArray, 0, GEMM_1_T), `-sR21*t12` = gemm(A, b, -1, ...), cv::norm -- against the oracle's restatement
+    # (cvGemm3 / cvGemmT3 / cvNorm3) AND the shim's (orbfe::detail::RestatedOps).  Mat::dot and MatExpr scale / divide have no
+    # Python binding (three-float loops; pinned only by an integrated build, whose CvOps evaluates them with its own OpenCV).
+    shim = _restated_ops()
+    bad = {'gemm': 0, 'gemm_neg': 0, 'gemmT': 0, 'norm': 0}
+    for it in range(4000):
+        sc = 10.0 ** rng.integers(-2, 3)
+        A = (rng.standard_normal((3, 3)) * sc).astype(np.float32)
+        b = (rng.standard_normal((3, 1)) * sc).astype(np.float32)
+        c = (rng.standard_normal((3, 1)) * sc).astype(np.float32)
+        want = cv2.gemm(A, b, 1.0, c, 1.0).astype(np.float32).ravel()
+        bad['gemm'] += want.tobytes() != oracle.cv_small('gemm', A, b, 1.0, c, 1.0).tobytes()
+        bad['gemm'] += want.tobytes() != shim('gemm', A, b, 1.0, c, 1.0).tobytes()
+        want = cv2.gemm(A, b, -1.0, None, 0.0).astype(np.float32).ravel()
+        bad['gemm_neg'] += want.tobytes() != oracle.cv_small('gemm', A, b, -1.0, None, 0.0).tobytes()
+        bad['gemm_neg'] += want.tobytes() != shim('gemm', A, b, -1.0, None, 0.0).tobytes()
+        want = cv2.gemm(A, b, -1.0, None, 0.0, flags=cv2.GEMM_1_T).astype(np.float32).ravel()
+        bad['gemmT'] += want.tobytes() != oracle.cv_small('gemmT', A, b, -1.0).tobytes()
+        bad['gemmT'] += want.tobytes() != shim('gemmT', A, b, -1.0).tobytes()
+        want = float(cv2.norm(b))
+        bad['norm'] += want != oracle.cv_small('norm', A, b) or want != shim('norm', A, b)
+    report.update({'cv_' + k_: v_ for k_, v_ in bad.items()})
+
+    # ---- cv::undistortPoints(mat, mat, mK, mDistCoef, Mat(), mK) as Frame::UndistortKeyPoints / ComputeImageBounds call it
+    # (Frame.cc:286-353): 4-, 5- and 8-coefficient models, points over and beyond the image, against the oracle AND the product's
+    # host routine (orbfe_undistort_pinhole, the same double arithmetic; loads without a GPU)
+    fx, fy, cx, cy = 458.654, 457.296, 367.215, 248.375
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], np.float32)
+    pts = np.stack([rng.uniform(-40, 800, 3000), rng.uniform(-40, 520, 3000)], 1).astype(np.float32)
+    bad = 0
+    for dist in ([-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05], [-0.28, 0.07, 2e-4, 2e-5, -0.01],
+                 [0.1, -0.05, 1e-3, -1e-3, 0.01, 0.02, -0.01, 0.003]):
+        d = np.array(dist, np.float32)
+        want = cv2.undistortPoints(pts.reshape(-1, 1, 2), K, d, None, K).reshape(-1, 2).astype(np.float32)
+        got = oracle.undistort_pinhole(pts, np.float32(fx), np.float32(fy), np.float32(cx), np.float32(cy), d)
+        bad += int((got.view(np.uint32) != want.view(np.uint32)).any(axis=1).sum())
+        try:
+            from os1_amd import api
+            got2 = api.undistort_pinhole(pts, np.float32(fx), np.float32(fy), np.float32(cx), np.float32(cy), d)
+            bad += int((got2.view(np.uint32) != want.view(np.uint32)).any(axis=1).sum())
+        except OSError:
+            pass                         # liborbfe.so needs the HIP runtime to load; the oracle comparison stands
+    report['undistortPoints'] = bad
 
     for seed, W, H, N in ((1, 640, 480, 1000), (2, 1920, 1080, 2000)):
         img = synth(seed, W, H)
