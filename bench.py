@@ -364,9 +364,26 @@ def run_rank(args):
                     'frac_if_all_ops_were_2_cycle': round(rate / (1024 * 2.4e9 / 2.0), 4),
                     'note': 'wave64 VALU instructions (SQ_INSTS_VALU, separate rocprofv3 --pmc pass); peak = 1024 SIMDs x 2.4 GHz / cycles_per_inst'}
         step_ms = np.diff(head_pops[subs - 1::subs]) * 1e3 if len(head_pops) >= 3 * subs else None
+        value_p50 = round(world * args.pool / (float(np.percentile(step_ms, 50)) * 1e-3), 2) if step_ms is not None and len(step_ms) > 1 else None
+        # the WHOLE path against both roofs (not only its dominant kernel): SURVEY.md s8(d)'s algorithmic 30.03 MB per frame x
+        # frames/s against HBM, and the vector instructions of all kernels of a batch (SQ_INSTS_VALU summed over every dispatch of
+        # the committed --pmc pass, profiles/counters.json) / (batch period x issue roof at the pipeline's own measured cycles
+        # per instruction)
+        batch_period_s = elapsed / max(args.steps * subs, 1)
+        pipeline = {'hbm': {'algorithmic_MB_per_frame': 30.03, 'achieved_GBps_per_gpu': round(30.03e6 * fps / world / 1e9, 2),
+                            'frac': round(30.03e6 * fps / world / (HBM_PEAK_GBS * 1e9), 5),
+                            'note': 'SURVEY.md s8(d): pyramid build + FAST + full-level blur + descriptor patches per 1080p frame, resident input'}}
+        if prof.get('pipeline_valu_insts_per_batch'):
+            pcpi = prof.get('pipeline_valu_cycles_per_inst') or 4.0
+            ppeak = 1024 * 2.4e9 / pcpi
+            prate = prof['pipeline_valu_insts_per_batch'] / batch_period_s
+            pipeline['valu'] = {'insts_per_batch': prof['pipeline_valu_insts_per_batch'], 'batch_period_ms': round(batch_period_s * 1e3, 4),
+                                'cycles_per_inst': pcpi, 'issue_peak_per_s': round(ppeak, 1), 'achieved_per_s': round(prate, 1),
+                                'frac': round(prate / ppeak, 4), 'by_kernel': prof.get('pipeline_valu_insts_per_batch_by_kernel'),
+                                'note': 'all kernels of one %d-frame submission (extract + SearchForInitialization), counters from %s' % (B, str(prof.get('source', ''))[:40])}
         out = {
             'metric': 'frames/sec extract+match, 1920x1080 @ 2000 ORB feats',
-            'value': round(fps, 2), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'value': round(fps, 2), 'value_p50': value_p50, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
             'config': {'workload': '1080p_2000feat_8lv_1.2_extract%s%s_stream' % ('' if args.no_match else '+SearchForInitialization', '+ComputeBoW' if args.bow else ''),
@@ -377,6 +394,8 @@ def run_rank(args):
                        'input': {'hbm': 'frames resident in HBM (pool of %d distinct frames, %d MB, walked forwards and backwards)' % (args.pool, args.pool * W * H >> 20),
                                  'pinned': 'frames in page-locked host memory (PCIe-inclusive)',
                                  'pageable': 'frames in pageable host memory (PCIe-inclusive)'}[head_source] + '; keypoints/descriptors/matches returned to host',
+                       'value_is': ('the RESIDENT rate (frames in HBM when the timed region starts, the bench contract); SURVEY.md s8(d) puts the H2D of every '
+                                    'frame inside its metric: that figure is pcie_inclusive.value' if head_source == 'hbm' else 'a PCIe-inclusive rate (developer run)'),
                        'numa': {'node_of_gpu': numa_node, 'cpus_bound': numa_cpus}},
             'verified': verify['verified'], 'outputs_sha256': verify['outputs_sha256'], 'verify': verify,
             'pcie_inclusive': pcie,
@@ -397,7 +416,7 @@ def run_rank(args):
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
                          'traffic_source': prof.get('source'),
                          'algorithmic_bytes_per_launch': fast_bytes_per_frame * B,
-                         'launch_ms': round(fast_ms_per_launch, 4), 'valu': valu},
+                         'launch_ms': round(fast_ms_per_launch, 4), 'valu': valu, 'pipeline': pipeline},
         }
         if world == 1 and not args.no_latency:
             out['config5_search_by_projection'] = config5_leg(api, local_rank, args.cpu_frames > 0)
@@ -465,7 +484,11 @@ def tracking_step_leg(api, device, frames, W, H, wl, with_oracle_check=True):
     kbuf = np.zeros((1, ex.cap), api.KP_DTYPE)
     dbuf = np.zeros((1, ex.cap, 32), np.uint8)
     rng = np.random.default_rng(3)
-    t_ex, t_fr, t_ff, t_ffd, t_mp, nm1, nm2 = [], [], [], [], [], [], []
+    t_ex, t_fr, t_ff, t_ffd, t_mp, t_mpt, nm1, nm2 = [], [], [], [], [], [], [], []
+    tab = api.DescTable(4096, device)
+    tperm = np.random.default_rng(4).permutation(4096)[:3000]
+    trow = api.PinnedArray((3000,), np.int32)
+    trow.a[:] = tperm
     prev = None
     prev_fr = None
     for i in range(nfr):
@@ -517,6 +540,18 @@ def tracking_step_leg(api, device, frames, W, H, wl, with_oracle_check=True):
             if rc:
                 raise SystemExit('bench: SearchByProjection failed')
             b = (nmc.value, asg[:len(k)].copy())
+            # ... and with the local map's descriptors in the device table orb_shim.hpp keeps across frames (steady state: no
+            # MapPoint's descriptor changed since the last frame, every row is read from device memory)
+            tab.host.a[tperm] = md
+            tab.upload(m, 0, 4096)
+            m.synchronize()
+            tb_args = (m.h, fr.h, P(sf), len(sf), P(occ2), P(mxy), P(lvl), P(vcos), P(fl), C.c_void_p(tab.dev), C.c_void_p(tab.host.base),
+                       P(trow.a), 3000, C.c_float(3.0), C.c_float(0.8), P(asg2), C.byref(nmc))
+            t7 = time.perf_counter()
+            rc = m.L.orbfe_search_by_projection_frame_rows(*tb_args)
+            t_mpt.append(time.perf_counter() - t7)
+            if rc or nmc.value != b[0] or not (asg2[:len(k)] == b[1]).all():
+                raise SystemExit('bench: SearchByProjection with the descriptor table differs from the plain rows')
             if i == 1 and with_oracle_check:   # one frame of the sequence against the oracle (the parity tests cover the rest)
                 from oracle.pyoracle import Oracle
                 o = Oracle()
@@ -532,11 +567,16 @@ def tracking_step_leg(api, device, frames, W, H, wl, with_oracle_check=True):
         prev_fr = fr
     prev_fr.close()
     pin.free()
+    m.synchronize()
+    tab.free()
     med = lambda v: round(float(np.median(v)) * 1e3, 4)
     return {'extract_host_frame_ms': med(t_ex), 'resident_frame_from_extract_ms': med(t_fr), 'search_by_projection_last_frame_ms': med(t_ff), 'search_by_projection_last_frame_device_rows_ms': med(t_ffd),
-            'search_by_projection_mappoints_ms': med(t_mp), 'front_end_total_ms': round(med(t_ex) + med(t_fr) + med(t_ff) + med(t_mp), 4),
+            'search_by_projection_mappoints_ms': med(t_mpt), 'search_by_projection_mappoints_host_rows_ms': med(t_mp),
+            'front_end_total_ms': round(med(t_ex) + med(t_fr) + med(t_ff) + med(t_mpt), 4),
             'matches_last_frame_median': int(np.median(nm1)), 'matches_mappoints_median': int(np.median(nm2)),
-            'note': '1080p / 2000 features, 60 frames; blocking C calls (extract from a page-locked host frame; searches with prepared arguments)'}
+            'note': '1080p / 2000 features, 60 frames; blocking C calls (extract from a page-locked host frame; searches with prepared arguments); '
+                    'search_by_projection_mappoints_ms = the 3 000 MapPoints\' descriptors in the device table include/orbfe/orb_shim.hpp keeps across '
+                    'frames (orbfe_search_by_projection_frame_rows, no row changed), _host_rows_ms = 32-byte rows handed over from host memory'}
 
 
 def bow_leg(api, device, frames, W, H, wl, with_oracle):
@@ -631,6 +671,13 @@ def config5_leg(api, device, with_oracle):
     # the pointer arguments are converted once, as a C++ caller would hold them (ctypes' per-call conversion is not the library's)
     args = (m.h, fr.h, P(sf), len(sf), P(occ), P(mxy), P(level), P(viewcos), P(flags), P(mdesc), n_mp)
     outs = (P(assigned), C.byref(nmat))
+    tab = api.DescTable(n_mp + 2048, device)
+    perm = rng.permutation(n_mp + 2048)[:n_mp]           # MapPoint i's row: unrelated to its position in the query vector
+    tab.host.a[perm] = mdesc
+    tab.upload(m, 0, n_mp + 2048)
+    m.synchronize()
+    trow = api.PinnedArray((n_mp,), np.int32)
+    trow.a[:] = perm
     for th in (1.0, 5.0):
         lat = []
         for _ in range(110):
@@ -640,6 +687,19 @@ def config5_leg(api, device, with_oracle):
             assert rc == 0
         lat = np.array(lat[10:]) * 1e3
         row = {'gpu_ms_median': round(float(np.median(lat)), 4), 'gpu_ms_p90': round(float(np.percentile(lat, 90)), 4), 'matches': int(nmat.value)}
+        # the local map's descriptors in a device table (orbfe_search_by_projection_frame_rows, what orb_shim.hpp's MatcherContext
+        # maintains across frames): 4 bytes of row index per MapPoint cross PCIe instead of 32 of descriptor
+        ref_assigned, ref_n = assigned.copy(), nmat.value
+        lat = []
+        for _ in range(110):
+            t0 = time.perf_counter()
+            rc = m.L.orbfe_search_by_projection_frame_rows(*args[:9], C.c_void_p(tab.dev), C.c_void_p(tab.host.base), P(trow.a), n_mp, th, 0.8, *outs)
+            lat.append(time.perf_counter() - t0)
+            assert rc == 0
+        if nmat.value != ref_n or not (assigned == ref_assigned).all():
+            raise SystemExit('bench: config 5 with the descriptor table differs from the plain rows')
+        lat = np.array(lat[10:]) * 1e3
+        row['gpu_ms_median_descriptor_table'] = round(float(np.median(lat)), 4)
         if with_oracle:
             t0 = time.perf_counter()
             for _ in range(3):

@@ -46,6 +46,12 @@ with open(os.path.join(dst, tag + '_pmc_summary.csv'), 'w') as f:
             if v:
                 f.write('%s,%s,%d,%.3f\n' % (k, c, len(v), steady(v)))
 fast = [k for k in agg if 'k_fast' in k][0]
+# the whole pipeline: vector instructions of ALL kernels per full batch = sum over every dispatch of the SQ pass / batches in it
+nb = len([x for x in agg[fast]['SQ_INSTS_VALU'] if x >= 0.8 * max(agg[fast]['SQ_INSTS_VALU'])])
+pipe_valu = sum(sum(agg[k].get('SQ_INSTS_VALU', [])) for k in agg) / max(nb, 1)
+pipe_active = sum(sum(agg[k].get('SQ_ACTIVE_INST_VALU', [])) for k in agg) / max(nb, 1)
+pipe_by_kernel = {k.replace('(anonymous namespace)::', '').replace('orbfe::', '')[:40]: int(sum(agg[k].get('SQ_INSTS_VALU', [])) / max(nb, 1)) for k in sorted(agg)
+                  if agg[k].get('SQ_INSTS_VALU')}
 fetch, write = steady(agg[fast]['FETCH_SIZE']) * 1024, steady(agg[fast]['WRITE_SIZE']) * 1024
 valu, waves = steady(agg[fast]['SQ_INSTS_VALU']), steady(agg[fast]['SQ_WAVES'])
 # SQ_ACTIVE_INST_VALU counts quad-cycles (4 shader cycles) a SIMD spends issuing vector instructions: 4 * ACTIVE / INSTS is
@@ -71,6 +77,8 @@ out = {
     'valu_insts_per_launch': int(valu), 'valu_insts_per_cell_wave': round(valu / waves, 1), 'waves_per_launch': int(waves),
     'valu_cycles_per_inst': round(4.0 * active / valu, 3) if valu and active else None,
     'valu_busy_frac_under_profiler': round(4.0 * active / 1024.0 / gui, 4) if gui and active else None,
+    'pipeline_valu_insts_per_batch': int(pipe_valu), 'pipeline_valu_cycles_per_inst': round(4.0 * pipe_active / pipe_valu, 3) if pipe_valu else None,
+    'pipeline_valu_insts_per_batch_by_kernel': pipe_by_kernel,
     'source': 'profiles/%s_pmc_summary.csv (rocprofv3 --pmc, separate passes over `python3 bench.py`), measured at commit %s' % (tag, commit),
 }
 json.dump(out, open(os.path.join(dst, 'counters.json'), 'w'), indent=1)
