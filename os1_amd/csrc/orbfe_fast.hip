@@ -26,6 +26,7 @@
 // share ROI halos and cache lines in that XCD's L2.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "orbfe_internal.h"
@@ -47,8 +48,10 @@ __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmc
 
 // NPX = pixels per lane in the pre-test (8 or 16); tpPad = extra bytes of tile pitch (LDS bank spreading)
 // PAIRS = false: every task is a single cell (the default task table); the second cell's bookkeeping compiles away
-template <int NPX, bool PAIRS>
-__global__ __launch_bounds__(64) void k_fast_tasks(PyramidParams P, int tpPad) {
+// ABL (measurement only, ORBFE_FAST_ABLATE=1..3, tools/fast_ablation.sh): the kernel stops after its set-up + ROI load (1),
+// after the pre-test and its compaction (2), after the score stage (3) -- every cell then reports no candidate; 0 = the product
+template <int NPX, bool PAIRS, int ABL = 0>
+__global__ __launch_bounds__(64) void k_fast_tasks(PyramidParams P, int tpPad, int dma) {
   extern __shared__ __align__(16) uint8_t lds[];
   const int chunk = (P.ntasks + 7) >> 3;
   const int tix = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
@@ -88,7 +91,23 @@ __global__ __launch_bounds__(64) void k_fast_tasks(PyramidParams P, int tpPad) {
   // once per batch, not once per element.  Rows are fetched as aligned dwords when the row pitch allows it; `a` is the
   // byte offset of the ROI inside its first dword.
   const int a = (int)(reinterpret_cast<uintptr_t>(roi) & 3);
-  if ((stride & 3) == 0) {
+  if ((stride & 3) == 0 && dma) {
+    // LDS-DMA (global_load_lds_dword): the tile's aligned dwords go from memory straight into LDS -- no register round
+    // trip, no ds_write, and no per-element address arithmetic: one instruction moves `rpi` whole tile rows (lane = (row,
+    // dword column) over the tile pitch; lane L's dword lands at the instruction's LDS base + 4 L, so the lanes of a row group
+    // are contiguous in LDS exactly as the tile wants them), the global base and the LDS base advance on the scalar unit.
+    const int ndw = (a + rw + 3) >> 2, ndwT = TP >> 2;
+    const int rpi = 64 / ndwT;                                  // tile rows per instruction (5 or 6 for a single cell)
+    const int lrow = (int)(((float)lane + 0.5f) * (1.0f / (float)ndwT)), lcol = lane - m24(lrow, ndwT);
+    const bool on = lrow < rpi && lcol < ndw;
+    const unsigned voff = (unsigned)(m24(lrow, istr) + 4 * lcol);
+    const uint8_t* gb = roi - a;                               // wave-uniform
+    for (int r = 0; r < rh; r += rpi) {
+      if (on && lrow < rh - r)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + (long long)r * stride + voff),
+                                         (__attribute__((address_space(3))) void*)(tile + m24(r, TP)), 4, 0, 0);
+    }
+  } else if ((stride & 3) == 0) {
     // lane (c, r0) copies dword column c of rows r0, r0 + rstep, ...: 16 columns x 4 rows per sweep for a single cell,
     // 32 columns x 2 rows for a pair (up to 19 dword columns)
     const int ndw = (a + rw + 3) >> 2;
@@ -138,7 +157,15 @@ __global__ __launch_bounds__(64) void k_fast_tasks(PyramidParams P, int tpPad) {
     const int nz = (SP * (eh + 2) + 3) >> 2;
     for (int i = lane; i < nz; i += 64) z[i] = 0u;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the LDS-DMA writes are tracked by vmcnt)
   wave_lds_fence();
+  if constexpr (ABL == 1) {   // keep the ROI load alive: fold the tile into a word nobody reads as a candidate
+    unsigned acc = 0;
+    for (int i = lane; i < (TP * rh) >> 2; i += 64) acc ^= reinterpret_cast<const uint32_t*>(tile - a)[i];
+    if (acc == 0x9e3779b9u && lane == 63) cnt[0] = 0;
+    if (lane == 0) cnt[0] = 0;
+    return;
+  }
 
   const unsigned long long below = (1ull << lane) - 1ull;
   uint32_t* slot0 = P.slots + (long long)f * P.slotsPerFrame + tk.slotOff0;
@@ -245,6 +272,12 @@ __global__ __launch_bounds__(64) void k_fast_tasks(PyramidParams P, int tpPad) {
       default: stage1(std::integral_constant<int, 3>{}); break;
     }
     wave_lds_fence();
+    if constexpr (ABL == 2) {
+      unsigned acc = 0;
+      for (int i = lane; i < nq; i += 64) acc ^= queue[i];
+      if (lane == 0) cnt[0] = (acc == 0xffffffffu) ? 1u : 0u;   // (never 1: queue entries are 16-bit)
+      return;
+    }
     // ---- stage 2: score of every stage-1 survivor; survivors of the arc test stay in the queue --------------------
     // S = max(max_arc min(v - ring), max_arc min(ring - v)) decides both "is a corner at tlo" (S > tlo) and the
     // OpenCV score (S - 1).  Both polarities are evaluated at once: each register holds (v - r, r - v) as two signed
@@ -296,6 +329,12 @@ __global__ __launch_bounds__(64) void k_fast_tasks(PyramidParams P, int tpPad) {
       nq2 += __popcll(mk);
     }
     wave_lds_fence();
+    if constexpr (ABL == 3) {
+      unsigned acc = 0;
+      for (int i = lane; i < nq2; i += 64) acc ^= queue[i] ^ sc[i];
+      if (lane == 0) cnt[0] = (acc == 0xffffffffu) ? 1u : 0u;
+      return;
+    }
     // ---- stage 3: NMS inside each cell's emit region and ordered emission (every survivor has score >= tlo) --------
     for (int i0 = 0; i0 < nq2; i0 += 64) {
       const int i = i0 + lane;
@@ -356,10 +395,18 @@ void launch_fast(const PyramidParams& P, int nframes, hipStream_t st) {
   const dim3 grid(8 * ((P.ntasks + 7) / 8), nframes);
   bool pairs = false;
   for (int l = 0; l < P.nlevels; l++) pairs = pairs || P.lv[l].fastW != P.lv[l].wCell;
+  static const int ablate = [] { const char* e = getenv("ORBFE_FAST_ABLATE"); return e ? atoi(e) : 0; }();   // measurement only
+  static const int dma = [] { const char* e = getenv("ORBFE_FAST_DMA"); return e ? atoi(e) : 1; }();         // 0: ROI through registers (A/B)
   if (pairs)
-    hipLaunchKernelGGL((k_fast_tasks<16, true>), grid, dim3(64), fast_lds_bytes(P, 0), st, P, 0);
+    hipLaunchKernelGGL((k_fast_tasks<16, true>), grid, dim3(64), fast_lds_bytes(P, 0), st, P, 0, dma);
+  else if (ablate == 1)
+    hipLaunchKernelGGL((k_fast_tasks<16, false, 1>), grid, dim3(64), fast_lds_bytes(P, 0), st, P, 0, dma);
+  else if (ablate == 2)
+    hipLaunchKernelGGL((k_fast_tasks<16, false, 2>), grid, dim3(64), fast_lds_bytes(P, 0), st, P, 0, dma);
+  else if (ablate == 3)
+    hipLaunchKernelGGL((k_fast_tasks<16, false, 3>), grid, dim3(64), fast_lds_bytes(P, 0), st, P, 0, dma);
   else
-    hipLaunchKernelGGL((k_fast_tasks<16, false>), grid, dim3(64), fast_lds_bytes(P, 0), st, P, 0);
+    hipLaunchKernelGGL((k_fast_tasks<16, false>), grid, dim3(64), fast_lds_bytes(P, 0), st, P, 0, dma);
 }
 
 }  // namespace orbfe

@@ -647,6 +647,43 @@ constexpr int ic_count() {
 static_assert(ic_count() == kIcCount, "circular patch must have 749 pixels");
 __constant__ IcTab c_icTab = make_ic_tab();
 
+// The blur only where the descriptor can look.  A test location (x, y) of the pattern, |x|, |y| <= 13, radius <= 18.385
+// ((-13, -13)), is rotated and rounded per coordinate (ORBextractor.cc:147-151): it lands on an integer point within 18.385 +
+// sqrt(1/2) = 19.092 of the keypoint -- the 37 x 37 box minus its corners, 1 125 of 1 369 pixels.  Vertical-pass items (column x,
+// 4 rows) that hold at least one such pixel: 308 of 370 -> 5 wave iterations instead of 6; horizontal-pass items (row r, 4
+// columns) that feed at least one such pixel (blurred (x, yb) reads hb rows yb .. yb + 6): 368 of 430 -> 6 instead of 7.
+// Outputs outside the disc are computed from whatever the skipped items left in LDS and never sampled.
+constexpr int kDiscR2x4 = 1458;   // 4 * 19.092^2 = 1458.02: x^2 + y^2 <= 364 (integer points: 4 (x^2 + y^2) <= 1458)
+constexpr bool in_disc(int x, int yb) { return 4 * ((x - kBlurRad) * (x - kBlurRad) + (yb - kBlurRad) * (yb - kBlurRad)) <= kDiscR2x4; }
+struct BlurItems { uint16_t h[448]; uint16_t v[320]; int nh, nv; };
+constexpr BlurItems make_blur_items() {
+  BlurItems t{};
+  // vertical: (x, yq) -> outputs (x, 4yq .. 4yq+3)
+  bool vneed[kBlurW][10] = {};
+  for (int x = 0; x < kBlurW; x++)
+    for (int yq = 0; yq < 10; yq++)
+      for (int j = 0; j < 4; j++)
+        if (4 * yq + j < kBlurW && in_disc(x, 4 * yq + j)) vneed[x][yq] = true;
+  for (int x = 0; x < kBlurW; x++)
+    for (int yq = 0; yq < 10; yq++)
+      if (vneed[x][yq]) t.v[t.nv++] = (uint16_t)(x << 4 | yq);
+  // horizontal: (row r of the raw patch, g) -> hb columns 4g .. 4g+3 of row r; needed by the disc's pixels only
+  bool hneed[kRawW][10] = {};
+  for (int x = 0; x < kBlurW; x++)
+    for (int yb = 0; yb < kBlurW; yb++)
+      if (in_disc(x, yb))
+        for (int r = yb; r < yb + 7; r++) hneed[r][x >> 2] = true;
+  for (int r = 0; r < kRawW; r++)
+    for (int g = 0; g < 10; g++)
+      if (hneed[r][g]) t.h[t.nh++] = (uint16_t)(r << 4 | g);
+  for (int i = t.nh; i < 448; i++) t.h[i] = t.h[0];
+  for (int i = t.nv; i < 320; i++) t.v[i] = t.v[0];
+  return t;
+}
+constexpr BlurItems kBlurItemsHost = make_blur_items();
+static_assert(kBlurItemsHost.nh == 368 && kBlurItemsHost.nv == 308, "blur item lists: 6 and 5 wave iterations");
+__constant__ BlurItems c_blurItems = make_blur_items();
+
 // sum over the wave (wave-uniform result): DPP row rotations, then one value per row of 16 lanes
 __device__ __forceinline__ int wave_sum_i32(int v) {
   v += __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false);   // row_ror:8
@@ -794,8 +831,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_describe(PyramidParams P, const 
   // taps in one dword and runs on v_dot2_u32_u16 (4 outputs per lane, one dword store into the transposed patch).
   {
     const unsigned K0 = 0x38302212u, K1 = 0x00122230u;   // taps 0..3 and 4..6 as bytes
-    for (int i = tid; i < kRawW * 10; i += NT) {
-      const int y = (int)(mulu24((unsigned)i, 205u) >> 11), g = i - y * 10;   // i / 10 for i < 1029
+    for (int i = tid; i < kBlurItemsHost.nh; i += NT) {
+      const unsigned code = c_blurItems.h[i];
+      const int y = (int)(code >> 4), g = (int)(code & 15u);
       const uint32_t* rp = reinterpret_cast<const uint32_t*>(raw + m24(y, kRawP) + 4 * g);
       const uint32_t d0 = rp[0], d1 = rp[1], d2 = rp[2], d3 = rp[3];
       const uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, pa), a1 = __builtin_amdgcn_alignbyte(d2, d1, pa),
@@ -814,8 +852,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_describe(PyramidParams P, const 
     // (lo, hi) tap pairs for an output whose first tap is the LOW half of p0 (even) or the HIGH half (odd)
     const u16x2 E0 = {18, 34}, E1 = {48, 56}, E2 = {48, 34}, E3 = {18, 0};
     const u16x2 O0 = {0, 18}, O1 = {34, 48}, O2 = {56, 48}, O3 = {34, 18};
-    for (int i = tid; i < kBlurW * 10; i += NT) {
-      const int x = (int)(mulu24((unsigned)i, 205u) >> 11), yq = i - x * 10;
+    for (int i = tid; i < kBlurItemsHost.nv; i += NT) {
+      const unsigned code = c_blurItems.v[i];
+      const int x = (int)(code >> 4), yq = (int)(code & 15u);
       const uint32_t* cp = reinterpret_cast<const uint32_t*>(hbT + m24(x, kHPT) + 4 * yq);
       u16x2 p[5];
 #pragma unroll
