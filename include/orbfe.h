@@ -194,6 +194,10 @@ int orbfe_debug_kernel_ms(orbfe_extractor* h, double out_ms[5], long long* batch
  * so orbfe_debug_kernel_ms reports frames = 0 for them.  enable != 0 also times the other groups, at the price of an
  * event (a few microseconds of stream gap) between them.  Env: ORBFE_PROFILE_KERNELS=1. */
 int orbfe_debug_set_profiling(orbfe_extractor* h, int enable);
+/* Measurement only (ORBFE_FAST_ABLATE=4 selects a build of the FAST kernel with s_memtime stamps between its phases): shader
+ * cycles summed over every wave since the last reset -- [0] entry -> geometry known, [1] -> ROI in LDS, [2] -> pre-test done,
+ * [3] -> scores done, [4] -> end, [5] = waves counted.  tools/fast_phases.py prints the per-wave averages. */
+int orbfe_debug_fast_stamps(orbfe_extractor* h, unsigned long long out[8], int reset);
 /* Device-side restatement of (cosf, sinf)(angle_deg * pi/180) used by the rBRIEF kernel, evaluated
  * on the GPU for n angles (parity test against host libm). */
 int orbfe_debug_sincos(orbfe_extractor* h, const float* angle_deg, int n, float* cos_out, float* sin_out);

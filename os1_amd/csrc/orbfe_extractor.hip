@@ -520,6 +520,9 @@ struct orbfe_extractor {
           t.ex0 = c0.ex0; t.ey0 = c0.ey0; t.level = (uint8_t)l;
           t.cell0 = (uint32_t)(L.cellBase + i * L.nCols + j);
           t.slotOff0 = c0.slotOff;
+          t.roiOff = l == 0 ? 0u : (uint32_t)(L.off + (long long)((int)c0.ey0 - 3) * L.pitch + ((int)c0.ex0 - 3));
+          t.pitch = l == 0 ? 0u : (uint32_t)L.pitch;
+          t.fastW = (uint8_t)L.fastW; t.hCell = (uint8_t)L.hCell; t.slotCap = (uint16_t)L.slotCap;
           const bool valid0 = c0.ew > 0 && c0.eh > 0;
           t.ew0 = valid0 ? (uint8_t)c0.ew : 0;
           t.eh = valid0 ? (uint8_t)c0.eh : 0;
@@ -1436,6 +1439,14 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
 void orbfe_extractor_destroy(orbfe_extractor* h) { delete h; }
 int orbfe_extractor_levels(const orbfe_extractor* h) { return h ? h->nlevels : 0; }
 int orbfe_extractor_device(const orbfe_extractor* h) { return h ? h->device : -1; }
+extern "C++" { namespace orbfe { int fast_stamps(unsigned long long out[8], int reset); } }
+int orbfe_debug_fast_stamps(orbfe_extractor* h, unsigned long long out[8], int reset) {
+  if (!h || !out) { set_err("NULL argument"); return ORBFE_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  if (orbfe::fast_stamps(out, reset)) { set_err("reading the stamp counters failed"); return ORBFE_ERR_HIP; }
+  return ORBFE_OK;
+}
 float orbfe_extractor_scale_factor(const orbfe_extractor* h) { return h ? (float)h->scaleFactor : 0.f; }
 int orbfe_extractor_scale_tables(const orbfe_extractor* h, float* a, float* b, float* c, float* d) {
   if (!h) { set_err("handle is NULL"); return ORBFE_ERR_INVALID; }

@@ -28,6 +28,7 @@
 
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 #include "orbfe_internal.h"
 
@@ -49,48 +50,68 @@ __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmc
 // NPX = pixels per lane in the pre-test (8 or 16); tpPad = extra bytes of tile pitch (LDS bank spreading)
 // PAIRS = false: every task is a single cell (the default task table); the second cell's bookkeeping compiles away
 // ABL (measurement only, ORBFE_FAST_ABLATE=1..3, tools/fast_ablation.sh): the kernel stops after its set-up + ROI load (1),
-// after the pre-test and its compaction (2), after the score stage (3) -- every cell then reports no candidate; 0 = the product
+// after the pre-test and its compaction (2), after the score stage (3) -- every cell then reports no candidate; 0 = the product;
+// 4 = the product with s_memtime stamps between its phases, summed over all waves into g_fastStamps (orbfe_debug_fast_stamps)
+__device__ uint32_t* g_fastStampBuf;   // [waves of the launch][8]
 template <int NPX, bool PAIRS, int ABL = 0>
 __global__ __launch_bounds__(64) void k_fast_tasks(PyramidParams P, int tpPad, int dma) {
   extern __shared__ __align__(16) uint8_t lds[];
+  unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
+  if constexpr (ABL == 4) stamp[0] = __builtin_amdgcn_s_memtime();
   const int chunk = (P.ntasks + 7) >> 3;
   const int tix = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
   if (tix >= P.ntasks) return;
   const int f = P.frameBase + blockIdx.y;
   const int lane = threadIdx.x;
-  const FastTask tk = P.tasks[tix];
-  const int level = tk.level;
-  const LevelGeom& L = P.lv[level];
-  const int ex0 = tk.ex0, ey0 = tk.ey0, ew0 = tk.ew0, ew1 = PAIRS ? tk.ew1 : 0, eh = tk.eh;
-  uint32_t* cnt = P.cellCount + (long long)f * P.ncells + tk.cell0;
+  // A wave's life begins with memory round trips it cannot overlap with anything: keep that chain SHORT.  The task record
+  // (32 bytes: cell, slots AND the level's geometry) and the level-0 pointer of the frame come by two SCALAR loads issued
+  // together -- one round trip through the scalar cache -- and then the ROI loads go out.  (Before round 4: the task by vector
+  // loads because of its sub-dword fields, a second vector round trip for the rest of it, the level table by a dependent
+  // scalar load, the frame pointer by a dependent flat load: eight dependent round trips, 2-3 us of a 7 us wave.)
+  typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  const u32x8 tw = *reinterpret_cast<const u32x8 __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(P.tasks + tix));
+  u32x2 fpw;
+  if (P.frame0) {
+    fpw = *reinterpret_cast<const u32x2 __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(P.frame0 + f));
+  } else {   // one- and two-frame calls carry the level-0 pointers in the kernel arguments
+    const unsigned long long v = reinterpret_cast<unsigned long long>((f & 1) ? P.frameInline[1] : P.frameInline[0]);
+    fpw.x = (uint32_t)v;
+    fpw.y = (uint32_t)(v >> 32);
+  }
+  const int ex0 = (int)(tw[0] & 0xffffu), ey0 = (int)(tw[0] >> 16);
+  const int ew0 = (int)(tw[1] & 0xffu), ew1 = PAIRS ? (int)((tw[1] >> 8) & 0xffu) : 0, eh = (int)((tw[1] >> 16) & 0xffu), level = (int)(tw[1] >> 24);
+  const uint32_t cell0 = tw[2], slotOff0 = tw[3], roiOff = tw[4], pitchL = tw[5];
+  const int fastW = (int)(tw[6] & 0xffu), hCell = (int)((tw[6] >> 8) & 0xffu), slotCap = (int)(tw[6] >> 16);
+  uint32_t* cnt = P.cellCount + (long long)f * P.ncells + cell0;
   if (ew0 == 0) {
     if (lane == 0) cnt[0] = 0;
     return;
   }
   const int W2 = ew0 + ew1;   // emit width of the task
-  const uint8_t* img;
   long long stride;
+  const uint8_t* roi;
   if (level == 0) {
-    img = level0_of(P, f);
     stride = P.stride0;
+    roi = reinterpret_cast<const uint8_t*>(((unsigned long long)fpw.y << 32) | fpw.x) + (long long)(ey0 - 3) * stride + (ex0 - 3);
   } else {
-    img = P.slab + (long long)f * P.slabBytes + L.off;
-    stride = L.pitch;
+    stride = (long long)pitchL;
+    roi = P.slab + (long long)f * P.slabBytes + roiOff;
   }
   // LDS carve (level-uniform): ROI tile, score tile with a zero ring, queue (y<<8|x)
-  const int TP = ((L.fastW + 6 + 3 + 3) & ~3) + tpPad;
-  const int SP = L.fastW + 2;
+  const int TP = ((fastW + 6 + 3 + 3) & ~3) + tpPad;
+  const int SP = fastW + 2;
   uint8_t* tile = lds;
-  uint8_t* sc = tile + TP * (L.hCell + 6);
-  uint16_t* queue = reinterpret_cast<uint16_t*>(lds + ((TP * (L.hCell + 6) + SP * (L.hCell + 2) + 3) & ~3));
+  uint8_t* sc = tile + TP * (hCell + 6);
+  uint16_t* queue = reinterpret_cast<uint16_t*>(lds + ((TP * (hCell + 6) + SP * (hCell + 2) + 3) & ~3));
 
   const int rw = W2 + 6, rh = eh + 6;
   const int istr = (int)stride;
-  const uint8_t* roi = img + (long long)(ey0 - 3) * stride + (ex0 - 3);
   // ROI -> LDS.  Loads are issued in batches of 12 per lane before the first LDS write so the wave waits for memory
   // once per batch, not once per element.  Rows are fetched as aligned dwords when the row pitch allows it; `a` is the
   // byte offset of the ROI inside its first dword.
   const int a = (int)(reinterpret_cast<uintptr_t>(roi) & 3);
+  if constexpr (ABL == 4) { asm volatile("" ::"s"(a), "s"(istr), "s"(TP) : "memory"); stamp[1] = __builtin_amdgcn_s_memtime(); }
   if ((stride & 3) == 0 && dma) {
     // LDS-DMA (global_load_lds_dword): the tile's aligned dwords go from memory straight into LDS -- no register round
     // trip, no ds_write, and no per-element address arithmetic: one instruction moves `rpi` whole tile rows (lane = (row,
@@ -159,6 +180,7 @@ __global__ __launch_bounds__(64) void k_fast_tasks(PyramidParams P, int tpPad, i
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the LDS-DMA writes are tracked by vmcnt)
   wave_lds_fence();
+  if constexpr (ABL == 4) stamp[2] = __builtin_amdgcn_s_memtime();
   if constexpr (ABL == 1) {   // keep the ROI load alive: fold the tile into a word nobody reads as a candidate
     unsigned acc = 0;
     for (int i = lane; i < (TP * rh) >> 2; i += 64) acc ^= reinterpret_cast<const uint32_t*>(tile - a)[i];
@@ -168,8 +190,8 @@ __global__ __launch_bounds__(64) void k_fast_tasks(PyramidParams P, int tpPad, i
   }
 
   const unsigned long long below = (1ull << lane) - 1ull;
-  uint32_t* slot0 = P.slots + (long long)f * P.slotsPerFrame + tk.slotOff0;
-  uint32_t* slot1 = slot0 + L.slotCap;
+  uint32_t* slot0 = P.slots + (long long)f * P.slotsPerFrame + slotOff0;
+  uint32_t* slot1 = slot0 + slotCap;
   int base0 = 0, base1 = 0;
   bool emit0 = true, emit1 = ew1 > 0;
   for (int pass = 0; pass < 2; pass++) {
@@ -272,6 +294,7 @@ __global__ __launch_bounds__(64) void k_fast_tasks(PyramidParams P, int tpPad, i
       default: stage1(std::integral_constant<int, 3>{}); break;
     }
     wave_lds_fence();
+    if constexpr (ABL == 4) { if (pass == 0) stamp[3] = __builtin_amdgcn_s_memtime(); }
     if constexpr (ABL == 2) {
       unsigned acc = 0;
       for (int i = lane; i < nq; i += 64) acc ^= queue[i];
@@ -329,6 +352,7 @@ __global__ __launch_bounds__(64) void k_fast_tasks(PyramidParams P, int tpPad, i
       nq2 += __popcll(mk);
     }
     wave_lds_fence();
+    if constexpr (ABL == 4) { if (pass == 0) stamp[4] = __builtin_amdgcn_s_memtime(); }
     if constexpr (ABL == 3) {
       unsigned acc = 0;
       for (int i = lane; i < nq2; i += 64) acc ^= queue[i] ^ sc[i];
@@ -375,6 +399,44 @@ __global__ __launch_bounds__(64) void k_fast_tasks(PyramidParams P, int tpPad, i
     cnt[0] = (uint32_t)base0;
     if (ew1) cnt[1] = (uint32_t)base1;
   }
+  if constexpr (ABL == 4) {
+    stamp[5] = __builtin_amdgcn_s_memtime();
+    // one record per wave, plain stores (same-address atomics from 200 000 waves back up the memory pipeline and inflate the
+    // very latencies being measured)
+    if (lane == 0 && g_fastStampBuf) {
+      uint32_t* rec = g_fastStampBuf + 8ull * ((unsigned long long)blockIdx.y * gridDim.x + blockIdx.x);
+      for (int k = 0; k < 5; k++) rec[k] = (uint32_t)(stamp[k + 1] - stamp[k]);
+      rec[5] = 1u;
+    }
+  }
+}
+
+// measurement only (ORBFE_FAST_ABLATE=4): per-wave phase cycles of the LAST launch, summed on the host: entry -> geometry
+// known, -> ROI in LDS, -> pre-test done, -> scores done, -> end; [5] = waves
+static uint32_t* s_stampBuf = nullptr;
+static size_t s_stampWaves = 0;
+int fast_stamps(unsigned long long out[8], int reset) {
+  for (int k = 0; k < 8; k++) out[k] = 0;
+  if (!s_stampBuf || !s_stampWaves) return 0;
+  std::vector<uint32_t> h(8 * s_stampWaves);
+  if (hipMemcpy(h.data(), s_stampBuf, h.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+  for (size_t w = 0; w < s_stampWaves; w++)
+    if (h[8 * w + 5]) {
+      for (int k = 0; k < 5; k++) out[k] += h[8 * w + k];
+      out[5]++;
+    }
+  if (reset && hipMemset(s_stampBuf, 0, h.size() * 4) != hipSuccess) return 1;
+  return 0;
+}
+static void stamp_buffer_for(size_t waves) {
+  if (waves > s_stampWaves) {
+    if (s_stampBuf) (void)hipFree(s_stampBuf);
+    s_stampBuf = nullptr;
+    if (hipMalloc((void**)&s_stampBuf, waves * 32) != hipSuccess) { s_stampWaves = 0; return; }
+    s_stampWaves = waves;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fastStampBuf), &s_stampBuf, sizeof s_stampBuf);
+  }
+  (void)hipMemset(s_stampBuf, 0, s_stampWaves * 32);
 }
 
 size_t fast_lds_bytes(const PyramidParams& P, int tpPad) {
@@ -405,6 +467,10 @@ void launch_fast(const PyramidParams& P, int nframes, hipStream_t st) {
     hipLaunchKernelGGL((k_fast_tasks<16, false, 2>), grid, dim3(64), fast_lds_bytes(P, 0), st, P, 0, dma);
   else if (ablate == 3)
     hipLaunchKernelGGL((k_fast_tasks<16, false, 3>), grid, dim3(64), fast_lds_bytes(P, 0), st, P, 0, dma);
+  else if (ablate == 4) {
+    stamp_buffer_for((size_t)grid.x * grid.y);
+    hipLaunchKernelGGL((k_fast_tasks<16, false, 4>), grid, dim3(64), fast_lds_bytes(P, 0), st, P, 0, dma);
+  }
   else
     hipLaunchKernelGGL((k_fast_tasks<16, false>), grid, dim3(64), fast_lds_bytes(P, 0), st, P, 0, dma);
 }

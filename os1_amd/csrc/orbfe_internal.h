@@ -49,7 +49,15 @@ struct FastTask {
   uint8_t eh, level;
   uint32_t cell0;        // index of cell 0 in the per-frame cell arrays (cell 1 = cell0 + 1)
   uint32_t slotOff0;     // first slot of cell 0 (cell 1: + the level's slotCap)
+  // the level's geometry as far as the FAST wave needs it, so that ONE 32-byte scalar load gives a wave everything it needs
+  // to issue its ROI loads (the level table in the kernel arguments cost a second, dependent scalar round trip per wave):
+  uint32_t roiOff;       // levels >= 1: byte offset of ROI pixel (ex0 - 3, ey0 - 3) inside one frame's pyramid slab
+  uint32_t pitch;        // levels >= 1: row pitch of the level in the slab (level 0: the caller's stride, PyramidParams::stride0)
+  uint8_t fastW, hCell;  // LevelGeom::fastW / hCell of the level (tile pitch and LDS carve)
+  uint16_t slotCap;      // LevelGeom::slotCap
+  uint32_t pad;
 };
+static_assert(sizeof(FastTask) == 32, "one s_load_dwordx8 per FAST wave");
 
 struct PyramidParams {
   LevelGeom lv[kMaxLevels];
