@@ -511,6 +511,7 @@ struct orbfe_extractor {
     tasks.reserve(Q.ncells);
     for (int l = 0; l < nlevels; l++) {
       LevelGeom& L = Q.lv[l];
+      Q.taskStart[l] = (int)tasks.size();
       const bool pairOk = pairCells && 2 * L.wCell <= 64 && L.nCols >= 2;
       L.fastW = pairOk ? 2 * L.wCell : L.wCell;
       for (int i = 0; i < L.nRows; i++)
@@ -535,6 +536,7 @@ struct orbfe_extractor {
           j += used;
         }
     }
+    for (int l = nlevels; l <= kMaxLevels; l++) Q.taskStart[l] = (int)tasks.size();
     if ((rc = d_tasks.ensure(tasks.size()))) return rc;
     HIP_TRY(hipMemcpyAsync(d_tasks.p, tasks.data(), sizeof(FastTask) * tasks.size(), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));

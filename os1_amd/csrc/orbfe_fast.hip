@@ -26,6 +26,7 @@
 // share ROI halos and cache lines in that XCD's L2.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 #include <vector>
@@ -54,13 +55,15 @@ __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmc
 // 4 = the product with s_memtime stamps between its phases, summed over all waves into g_fastStamps (orbfe_debug_fast_stamps)
 __device__ uint32_t* g_fastStampBuf;   // [waves of the launch][8]
 template <int NPX, bool PAIRS, int ABL = 0>
-__global__ __launch_bounds__(64) void k_fast_tasks(PyramidParams P, int tpPad, int dma) {
+__global__ __launch_bounds__(64) void k_fast_tasks(PyramidParams P, int tpPad, int dma, int t0, int nt) {
   extern __shared__ __align__(16) uint8_t lds[];
   unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
   if constexpr (ABL == 4) stamp[0] = __builtin_amdgcn_s_memtime();
-  const int chunk = (P.ntasks + 7) >> 3;
-  const int tix = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-  if (tix >= P.ntasks) return;
+  // this launch works on tasks [t0, t0 + nt): the levels of one LDS class (launch_fast)
+  const int chunk = (nt + 7) >> 3;
+  const int tloc = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (tloc >= nt) return;
+  const int tix = t0 + tloc;
   const int f = P.frameBase + blockIdx.y;
   const int lane = threadIdx.x;
   // A wave's life begins with memory round trips it cannot overlap with anything: keep that chain SHORT.  The task record
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(64) void k_fast_tasks(PyramidParams P, int tpPad, i
     // one record per wave, plain stores (same-address atomics from 200 000 waves back up the memory pipeline and inflate the
     // very latencies being measured)
     if (lane == 0 && g_fastStampBuf) {
-      uint32_t* rec = g_fastStampBuf + 8ull * ((unsigned long long)blockIdx.y * gridDim.x + blockIdx.x);
+      uint32_t* rec = g_fastStampBuf + 8ull * ((unsigned long long)blockIdx.y * (P.ntasks + 64) + t0 + blockIdx.x);
       for (int k = 0; k < 5; k++) rec[k] = (uint32_t)(stamp[k + 1] - stamp[k]);
       rec[5] = 1u;
     }
@@ -439,40 +442,62 @@ static void stamp_buffer_for(size_t waves) {
   (void)hipMemset(s_stampBuf, 0, s_stampWaves * 32);
 }
 
+static size_t fast_lds_bytes_level(const LevelGeom& L, int tpPad) {
+  const size_t TP = ((L.fastW + 6 + 3 + 3) & ~3) + tpPad;
+  const size_t b = ((TP * (L.hCell + 6) + (size_t)(L.fastW + 2) * (L.hCell + 2) + 3) & ~(size_t)3) +
+                   2 * (size_t)L.fastW * L.hCell + 64;  // tile + score tile + u16 queue + slack for the group over-read
+  return (b + 15) & ~(size_t)15;
+}
 size_t fast_lds_bytes(const PyramidParams& P, int tpPad) {
   size_t mx = 0;
-  for (int l = 0; l < P.nlevels; l++) {
-    const LevelGeom& L = P.lv[l];
-    const size_t TP = ((L.fastW + 6 + 3 + 3) & ~3) + tpPad;
-    const size_t b = ((TP * (L.hCell + 6) + (size_t)(L.fastW + 2) * (L.hCell + 2) + 3) & ~(size_t)3) +
-                     2 * (size_t)L.fastW * L.hCell + 64;  // tile + score tile + u16 queue + slack for the group over-read
-    mx = b > mx ? b : mx;
-  }
-  return (mx + 15) & ~(size_t)15;
+  for (int l = 0; l < P.nlevels; l++) mx = std::max(mx, fast_lds_bytes_level(P.lv[l], tpPad));
+  return mx;
 }
 
 void launch_fast(const PyramidParams& P, int nframes, hipStream_t st) {
   // 16 pixels per lane in the pre-test: one wave iteration covers a 31 x 31 cell (8 pixels per lane take two and are
   // equal in time, 9.9 us per 1080p frame, with more instructions)
-  const dim3 grid(8 * ((P.ntasks + 7) / 8), nframes);
-  bool pairs = false;
-  for (int l = 0; l < P.nlevels; l++) pairs = pairs || P.lv[l].fastW != P.lv[l].wCell;
   static const int ablate = [] { const char* e = getenv("ORBFE_FAST_ABLATE"); return e ? atoi(e) : 0; }();   // measurement only
   static const int dma = [] { const char* e = getenv("ORBFE_FAST_DMA"); return e ? atoi(e) : 1; }();         // 0: ROI through registers (A/B)
-  if (pairs)
-    hipLaunchKernelGGL((k_fast_tasks<16, true>), grid, dim3(64), fast_lds_bytes(P, 0), st, P, 0, dma);
-  else if (ablate == 1)
-    hipLaunchKernelGGL((k_fast_tasks<16, false, 1>), grid, dim3(64), fast_lds_bytes(P, 0), st, P, 0, dma);
-  else if (ablate == 2)
-    hipLaunchKernelGGL((k_fast_tasks<16, false, 2>), grid, dim3(64), fast_lds_bytes(P, 0), st, P, 0, dma);
-  else if (ablate == 3)
-    hipLaunchKernelGGL((k_fast_tasks<16, false, 3>), grid, dim3(64), fast_lds_bytes(P, 0), st, P, 0, dma);
-  else if (ablate == 4) {
-    stamp_buffer_for((size_t)grid.x * grid.y);
-    hipLaunchKernelGGL((k_fast_tasks<16, false, 4>), grid, dim3(64), fast_lds_bytes(P, 0), st, P, 0, dma);
+  static const int split = [] { const char* e = getenv("ORBFE_FAST_LDS_CLASSES"); return e ? atoi(e) : 1; }();   // 0: one launch, the largest level's LDS
+  bool pairs = false;
+  for (int l = 0; l < P.nlevels; l++) pairs = pairs || P.lv[l].fastW != P.lv[l].wCell;
+  // LDS CLASSES (round 4).  LDS is handed out in 1 KB granules and a CU has 160 of them: a one-wave workgroup that asks for up
+  // to 5 120 bytes leaves room for 32 waves per CU (8 per SIMD), one that asks for 5 121 .. 6 144 for 26 (6.5 per SIMD) --
+  // measured with tools/ubench/dispatch_rate.hip: 7.35 / 5.85 / 4.96 resident waves per SIMD at 4 608 / 5 632 / 6 656 bytes.
+  // At 1080p the seven lower levels have 31 x 30..32 cells (4.4 - 4.7 KB per wave) and only the top level's 32 x 34 cells need
+  // 5.2 KB: sizing every wave for those 2 % of the cells cost the other 98 % a fifth of their residency, and a FAST wave spends
+  // 40 % of its life waiting for its ROI -- residency is what hides that.  So consecutive levels that fit 5 KB go out as one
+  // launch with 5 KB of LDS, the others as launches of their own.
+  constexpr size_t kLdsFull = 5120;
+  int l = 0;
+  while (l < P.nlevels) {
+    int e = l + 1;
+    size_t need = fast_lds_bytes_level(P.lv[l], 0);
+    if (split) {
+      const bool small = need <= kLdsFull;
+      while (e < P.nlevels && (fast_lds_bytes_level(P.lv[e], 0) <= kLdsFull) == small) { need = std::max(need, fast_lds_bytes_level(P.lv[e], 0)); e++; }
+    } else {
+      while (e < P.nlevels) { need = std::max(need, fast_lds_bytes_level(P.lv[e], 0)); e++; }
+    }
+    const int t0 = P.taskStart[l], nt = P.taskStart[e] - t0;
+    l = e;
+    if (nt <= 0) continue;
+    const dim3 grid(8 * ((nt + 7) / 8), nframes);
+    if (pairs)
+      hipLaunchKernelGGL((k_fast_tasks<16, true>), grid, dim3(64), need, st, P, 0, dma, t0, nt);
+    else if (ablate == 1)
+      hipLaunchKernelGGL((k_fast_tasks<16, false, 1>), grid, dim3(64), need, st, P, 0, dma, t0, nt);
+    else if (ablate == 2)
+      hipLaunchKernelGGL((k_fast_tasks<16, false, 2>), grid, dim3(64), need, st, P, 0, dma, t0, nt);
+    else if (ablate == 3)
+      hipLaunchKernelGGL((k_fast_tasks<16, false, 3>), grid, dim3(64), need, st, P, 0, dma, t0, nt);
+    else if (ablate == 4) {
+      if (t0 == 0) stamp_buffer_for((size_t)(P.ntasks + 64) * nframes);
+      hipLaunchKernelGGL((k_fast_tasks<16, false, 4>), grid, dim3(64), need, st, P, 0, dma, t0, nt);
+    } else
+      hipLaunchKernelGGL((k_fast_tasks<16, false>), grid, dim3(64), need, st, P, 0, dma, t0, nt);
   }
-  else
-    hipLaunchKernelGGL((k_fast_tasks<16, false>), grid, dim3(64), fast_lds_bytes(P, 0), st, P, 0, dma);
 }
 
 }  // namespace orbfe

@@ -77,8 +77,9 @@ struct PyramidParams {
   uint32_t* cand;                   // [nframes][candCap]  packed x | y<<12 | score<<24 (level coords)
   uint32_t* levelStart;             // [nframes][kMaxLevels+1]
   const CellInfo* cells;            // [ncells]
-  const FastTask* tasks;            // [ntasks] work items of k_fast_tasks
+  const FastTask* tasks;            // [ntasks] work items of k_fast_tasks, level-major
   int ntasks;
+  int taskStart[kMaxLevels + 1];    // first task of each level (host side of launch_fast: LDS classes)
   int iniTh, minTh;
   int frameBase;                    // first frame of this launch (sub-batch pipelining)
 };
