@@ -474,7 +474,7 @@ void launch_fast(const PyramidParams& P, int nframes, hipStream_t st) {
   while (l < P.nlevels) {
     int e = l + 1;
     size_t need = fast_lds_bytes_level(P.lv[l], 0);
-    if (split) {
+    if (split && nframes > 2) {   // (a one- or two-frame call is latency-bound: one launch less is worth more than residency there)
       const bool small = need <= kLdsFull;
       while (e < P.nlevels && (fast_lds_bytes_level(P.lv[e], 0) <= kLdsFull) == small) { need = std::max(need, fast_lds_bytes_level(P.lv[e], 0)); e++; }
     } else {
