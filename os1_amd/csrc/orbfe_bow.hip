@@ -14,6 +14,7 @@
 // indices by node, and the rotation-histogram pruning.
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <mutex>
 #include <chrono>
 
 #include <algorithm>
@@ -148,8 +149,96 @@ __global__ void __launch_bounds__(256) k_bow_descend(const uint4* __restrict__ d
 // are visited in order; for each, lanes scan the node's frame-2 features (skipping matched / invalid ones), the wave
 // takes best (first minimum) and second-best distance, applies the reference's acceptance test and marks the winner
 // matched (LDS bitmap) before the next frame-1 feature.
-struct BowPair { int b1, e1, b2, e2, base1; };   // [b,e) ranges into fv1_feat / fv2_feat; base1 = first descriptor row of side 1's
+struct BowPair { int b1, e1, b2, e2, base1, tk; };   // [b,e) ranges into fv1_feat / fv2_feat; base1 = first descriptor row of side 1's
                                                    // frame in desc1 / valid1 / matches12 (several keyframes against one frame in one launch)
+
+// LARGE NODES (round 4): more than kBowSide features of either frame under one vocabulary node -- a vocabulary with no more
+// levels than `levelsup` puts EVERY feature under the root; low-texture frames pile features into few words.  The reference's
+// loop over the node's frame-1 features is sequential only through "which frame-2 feature is already matched"
+// (ORBmatcher.cc:196-222): feature i takes the least-distance frame-2 feature that is still free (first on ties) if it is
+// <= TH_LOW and passes the ratio test against the next least free one.  So k_bow_topk computes, for every frame-1 feature of
+// a large node and in parallel over the whole chip, its kBowTopK least keys (distance << 16 | position in the node's frame-2
+// list) in ascending order; the walk (one wave, in k_bow_match) then decides feature after feature from those eight keys and
+// the matched bitmap -- the first two free keys are best and second best; only a feature that finds its list exhausted
+// (seven of its eight nearest already taken and the ratio test not decided by the eighth) rescans the node.  2 000 x 2 000
+// features under one node: 6.8 ms -> 0.25 ms.
+constexpr int kBowTopK = 8;
+constexpr int kTopkRows = 8;          // frame-1 features per block of k_bow_topk (two per wave)
+constexpr int kTopkRegs = 32;         // keys a lane keeps in registers (nodes of up to 2 048 frame-2 features)
+constexpr int kTopkLdsFeatures = 4096; // frame-2 features of a node staged in LDS (36 bytes each); larger nodes read them from memory
+struct TopkItem { int pair, row0; };
+__global__ void __launch_bounds__(256) k_bow_topk(const uint4* __restrict__ desc1, const uint8_t* __restrict__ valid1,
+                                                  const uint32_t* __restrict__ feat1, const uint4* __restrict__ desc2,
+                                                  const uint8_t* __restrict__ valid2, const uint32_t* __restrict__ feat2,
+                                                  const BowPair* __restrict__ pairs, const TopkItem* __restrict__ items,
+                                                  uint32_t* __restrict__ topk) {
+  extern __shared__ uint4 ldsTopk[];   // [2 * nStage] descriptors, then [nStage] row words (| 0x80000000: not valid)
+  const TopkItem it = items[blockIdx.x];
+  const BowPair P = pairs[it.pair];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n1g = P.e1 - P.b1, n2g = P.e2 - P.b2;
+  const int nStage = min(n2g, kTopkLdsFeatures);
+  uint32_t* rowS = reinterpret_cast<uint32_t*>(ldsTopk + 2 * nStage);
+  for (int p = tid; p < nStage; p += 256) {
+    const unsigned idx2 = feat2[P.b2 + p];
+    rowS[p] = idx2 | ((valid2 && !valid2[idx2]) ? 0x80000000u : 0u);
+    ldsTopk[2 * p] = desc2[2 * (size_t)idx2];
+    ldsTopk[2 * p + 1] = desc2[2 * (size_t)idx2 + 1];
+  }
+  __syncthreads();
+  for (int r = it.row0 + wave; r < min(n1g, it.row0 + kTopkRows); r += 4) {
+    uint32_t* out = topk + ((size_t)P.tk + r) * kBowTopK;
+    const unsigned idx1 = (unsigned)P.base1 + feat1[P.b1 + r];
+    if (!valid1[idx1]) {   // wave-uniform: the walk skips the feature, its list is never read
+      if (lane < kBowTopK) out[lane] = 0xffffffffu;
+      continue;
+    }
+    const uint4 a0 = desc1[2 * (size_t)idx1], a1 = desc1[2 * (size_t)idx1 + 1];
+    auto keyAt = [&](int p) -> unsigned {   // 0xffffffff: not a candidate
+      if (p < nStage) {
+        if (rowS[p] & 0x80000000u) return 0xffffffffu;
+        return ((unsigned)hamming256(a0, a1, ldsTopk[2 * p], ldsTopk[2 * p + 1]) << 16) | (unsigned)p;
+      }
+      const unsigned idx2 = feat2[P.b2 + p];
+      if (valid2 && !valid2[idx2]) return 0xffffffffu;
+      return ((unsigned)hamming256(a0, a1, desc2[2 * (size_t)idx2], desc2[2 * (size_t)idx2 + 1]) << 16) | (unsigned)p;
+    };
+    unsigned lo = 0;           // keys below `lo` are already in the list
+    if (n2g <= 64 * kTopkRegs) {
+      // the lane's (up to 32) keys once, in registers; the eight selection passes then cost three instructions per key
+      unsigned kreg[kTopkRegs];
+#pragma unroll
+      for (int j = 0; j < kTopkRegs; j++) kreg[j] = (lane + 64 * j < n2g) ? keyAt(lane + 64 * j) : 0xffffffffu;
+      for (int k = 0; k < kBowTopK; k++) {
+        unsigned cur = 0xffffffffu;
+#pragma unroll
+        for (int j = 0; j < kTopkRegs; j++) cur = (kreg[j] >= lo && kreg[j] < cur) ? kreg[j] : cur;
+        cur = wave_min(cur);
+        if (lane == 0) out[k] = cur;
+        if (cur == 0xffffffffu) {
+          if (lane > k && lane < kBowTopK) out[lane] = 0xffffffffu;
+          break;
+        }
+        lo = cur + 1u;
+      }
+      continue;
+    }
+    for (int k = 0; k < kBowTopK; k++) {
+      unsigned cur = 0xffffffffu;
+      for (int p = lane; p < n2g; p += 64) {
+        const unsigned key = keyAt(p);
+        if (key >= lo && key < cur) cur = key;
+      }
+      cur = wave_min(cur);
+      if (lane == 0) out[k] = cur;
+      if (cur == 0xffffffffu) {   // fewer than kBowTopK valid frame-2 features: the rest of the list is empty
+        if (lane > k && lane < kBowTopK) out[lane] = 0xffffffffu;
+        break;
+      }
+      lo = cur + 1u;
+    }
+  }
+}
 
 // Round 3: the distances of a node's pairs do not depend on the bookkeeping, so they are computed first, all pairs in
 // parallel by the block's four waves, into an LDS matrix (nodes of up to kBowMatrix pairs; larger ones compute them inside
@@ -164,7 +253,7 @@ __global__ void __launch_bounds__(kBowThreads) k_bow_match(const uint4* __restri
                                                            const uint8_t* __restrict__ valid2, const uint32_t* __restrict__ feat2,
                                                            const BowPair* __restrict__ pairs, int maxDist, float nnratio,
                                                            int32_t* __restrict__ matches12, unsigned* doneCounter, int* doneHost,
-                                                           int doneSeq) {
+                                                           int doneSeq, const uint32_t* __restrict__ topk) {
   __shared__ unsigned matched[(kMaxGroup + 1) / 32];
   __shared__ uint16_t dmat[kBowMatrix];
   __shared__ uint32_t row1[kBowSide], row2[kBowSide];   // descriptor rows of the node's features; | 0x80000000: not valid
@@ -268,46 +357,128 @@ __global__ void __launch_bounds__(kBowThreads) k_bow_match(const uint4* __restri
     return;
   }
   __syncthreads();
-  // larger nodes: the walk computes its distances itself, all four waves scanning the node's frame-2 features for ONE frame-1
-  // feature at a time (least / second-least key per wave, then across the waves through LDS: two barriers per feature)
-  __shared__ unsigned wk[2][kBowThreads / 64];
-  const int wave = tid >> 6;
-  for (int i1 = P.b1; i1 < P.e1; i1++) {
-    const unsigned idx1 = (unsigned)P.base1 + feat1[i1];
-    if (!valid1[idx1]) continue;   // block-uniform
-    const uint4 a0 = desc1[2 * (size_t)idx1], a1 = desc1[2 * (size_t)idx1 + 1];
-    unsigned k1 = (256u << 16) | 0xffffu, k2 = k1;
-    for (int p = tid; p < n2g; p += kBowThreads) {
-      const unsigned idx2 = feat2[P.b2 + p];
-      const bool skip = ((matched[p >> 5] >> (p & 31)) & 1u) || (valid2 && !valid2[idx2]);
-      if (skip) continue;
-      const unsigned key = ((unsigned)hamming256(a0, a1, desc2[2 * (size_t)idx2], desc2[2 * (size_t)idx2 + 1]) << 16) | (unsigned)p;
-      if (key < k1) { k2 = k1; k1 = key; }
-      else if (key < k2) k2 = key;
+  // larger nodes: the walk by ONE wave over the lists k_bow_topk prepared (see there).  Eight frame-1 features at a time: lane
+  // (f, k) = (lane >> 3, lane & 7) holds key k of feature f.  ONE read of the matched bitmap per group gives every lane its
+  // candidate's state before the group; inside the group a feature that takes candidate q marks the later lanes that hold q
+  // (a compare, no LDS trip), so the eight decisions cost a ballot, two lane reads and a few scalar operations each.  The
+  // winners' positions go to LDS; frame-2 indices are looked up and matches12 written by all lanes afterwards.  (A feature
+  // without a MapPoint has an all-empty list -- k_bow_topk wrote it -- and decides "no match" by itself.)
+  if (tid >= 64) { done(); return; }
+  const uint32_t* tkRows = topk + (size_t)P.tk * kBowTopK;
+  uint16_t* sel = dmat;   // [n1g] winner position + 1, 0 = none (n1g <= kMaxGroup < 2^16; dmat is free on this path: 12 288 entries ...
+  int32_t* selBig = nullptr;   // ... larger nodes keep the winners in matches12 itself, as positions, and translate in place)
+  const bool selInLds = n1g <= kBowMatrix;
+  for (int i = lane; i < n1g && selInLds; i += 64) sel[i] = 0;
+  unsigned keyN = (lane >> 3) < n1g ? tkRows[lane] : 0xffffffffu;   // keys of the first group
+  for (int i0 = 0; i0 < n1g; i0 += 8) {
+    const int f = lane >> 3;
+    const unsigned key = keyN;
+    if (i0 + 8 < n1g) {   // the next group's keys travel while this one is decided
+      const int rowN = i0 + 8 + f;
+      keyN = rowN < n1g ? tkRows[(size_t)rowN * kBowTopK + (lane & 7)] : 0xffffffffu;
     }
-    const unsigned wbest = wave_min(k1);
-    if (lane == 0) wk[0][wave] = wbest;
-    __syncthreads();
-    unsigned best = wk[0][0];
+    const unsigned q = key & 0xffffu;
+    bool free_ = key != 0xffffffffu && !((matched[(q >> 5) & 2047u] >> (q & 31)) & 1u);   // (index masked: an empty key reads word 2047, harmless)
+    const int nf = min(8, n1g - i0);
+    {
+      // ALL EIGHT decisions at once, as if the group's features did not interfere -- then a check that they do not: a feature's
+      // outcome depends on its first two free candidates only, so the parallel outcomes are the sequential ones unless some
+      // feature of the group accepts a candidate that is another feature's first or second free one (or a feature's list is
+      // exhausted).  Such groups -- rare outside near-duplicate descriptors -- take the one-by-one loop below.
+      const unsigned long long fb = __ballot(free_);
+      const unsigned m8 = (unsigned)(fb >> (8 * f)) & 0xffu;
+      const unsigned m2 = m8 & (m8 - 1u);
+      const int kb = m8 ? __builtin_ctz(m8) : 0, k2i = m2 ? __builtin_ctz(m2) : 0;
+      const unsigned last = (unsigned)__shfl((int)key, 8 * f + 7);
+      const unsigned kbest = (unsigned)__shfl((int)key, 8 * f + kb), ksec = (unsigned)__shfl((int)key, 8 * f + k2i);
+      const bool none = m8 == 0 && last == 0xffffffffu;
+      const int bestDist = (int)(kbest >> 16), bqp = (int)(kbest & 0xffffu);
+      int second = 256;
+      bool decided = none;
+      if (m8) {
+        if (bestDist > maxDist) decided = true;
+        else if (m2) { second = (int)(ksec >> 16); decided = true; }
+        else if (last == 0xffffffffu) decided = true;
+        else if (static_cast<float>(bestDist) < nnratio * static_cast<float>((int)(last >> 16))) { second = (int)(last >> 16); decided = true; }
+      }
+      const bool accept = decided && m8 && bestDist <= maxDist && static_cast<float>(bestDist) < nnratio * static_cast<float>(second);
+      const bool rel = free_ && ((lane & 7) == kb || (m2 && (lane & 7) == k2i));   // this lane's key is its feature's first / second free one
+      bool conflict = !decided;
 #pragma unroll
-    for (int w = 1; w < kBowThreads / 64; w++) best = min(best, wk[0][w]);
-    const unsigned wsecond = wave_min(k1 == best ? k2 : k1);   // least key among everything but the winner, per wave
-    if (lane == 0) wk[1][wave] = wsecond;
-    __syncthreads();
-    unsigned second = wk[1][0];
-#pragma unroll
-    for (int w = 1; w < kBowThreads / 64; w++) second = min(second, wk[1][w]);
-    second >>= 16;
-    const int bestDist = (int)(best >> 16);
-    if (bestDist <= maxDist && static_cast<float>(bestDist) < nnratio * static_cast<float>((int)second)) {
-      const int q = (int)(best & 0xffffu);
-      if (tid == 0) {
-        matches12[idx1] = (int32_t)feat2[P.b2 + q];
-        matched[q >> 5] |= 1u << (q & 31);
+      for (int g = 0; g < 8; g++) {
+        const int accG = __builtin_amdgcn_readlane(accept ? 1 : 0, 8 * g), bqG = __builtin_amdgcn_readlane(bqp, 8 * g);
+        if (accG && g != f && rel && q == (unsigned)bqG) conflict = true;
+      }
+      if (__ballot(conflict) == 0ull) {
+        if ((lane & 7) == 0 && accept) {
+          atomicOr(&matched[bqp >> 5], 1u << (bqp & 31));
+          if (selInLds) sel[i0 + f] = (uint16_t)(bqp + 1);
+          else matches12[(unsigned)P.base1 + feat1[P.b1 + i0 + f]] = (int32_t)feat2[P.b2 + bqp];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        continue;
       }
     }
-    __syncthreads();   // (the matched bit and the exchange words are settled before the next feature)
+    for (int ff = 0; ff < nf; ff++) {
+      const unsigned m8 = (unsigned)((__ballot(free_) >> (8 * ff)) & 0xffull);
+      const unsigned last = (unsigned)__builtin_amdgcn_readlane((int)key, 8 * ff + 7);   // the list's largest key (0xffffffff: list not full)
+      if (m8 == 0 && last == 0xffffffffu) continue;   // nothing free and nothing beyond the list (also: a feature without a MapPoint)
+      int bestDist = 256, second = 256, bq = -1;
+      bool decided = false;
+      if (m8) {
+        const int kb = __builtin_ctz(m8);
+        const unsigned kbest = (unsigned)__builtin_amdgcn_readlane((int)key, 8 * ff + kb);
+        bestDist = (int)(kbest >> 16);
+        bq = (int)(kbest & 0xffffu);
+        const unsigned m2 = m8 & (m8 - 1u);
+        if (bestDist > maxDist) decided = true;   // the best free candidate of the list IS the node's best free one: nothing to accept
+        else if (m2) {
+          second = (int)((unsigned)__builtin_amdgcn_readlane((int)key, 8 * ff + __builtin_ctz(m2)) >> 16);
+          decided = true;
+        } else if (last == 0xffffffffu) {
+          decided = true;                          // the list holds every valid candidate: no second one is free (bestDist2 stays 256)
+        } else if (static_cast<float>(bestDist) < nnratio * static_cast<float>((int)(last >> 16))) {
+          second = (int)(last >> 16);              // the true second best is at least the list's largest: the ratio test passes either way
+          decided = true;
+        }
+      }
+      if (!decided) {
+        // the list is exhausted: rescan the node for this feature (rare: seven of its eight nearest taken already); the bitmap
+        // in LDS is current up to the previous GROUP, this group's winners so far are in `sel`
+        const int row = i0 + ff;
+        const unsigned idx1 = (unsigned)P.base1 + feat1[P.b1 + row];
+        const uint4 a0 = desc1[2 * (size_t)idx1], a1 = desc1[2 * (size_t)idx1 + 1];
+        unsigned k1 = (256u << 16) | 0xffffu, k2 = k1;
+        for (int p = lane; p < n2g; p += 64) {
+          const unsigned idx2 = feat2[P.b2 + p];
+          if (((matched[p >> 5] >> (p & 31)) & 1u) || (valid2 && !valid2[idx2])) continue;
+          const unsigned kk = ((unsigned)hamming256(a0, a1, desc2[2 * (size_t)idx2], desc2[2 * (size_t)idx2 + 1]) << 16) | (unsigned)p;
+          if (kk < k1) { k2 = k1; k1 = kk; }
+          else if (kk < k2) k2 = kk;
+        }
+        const unsigned best = wave_min(k1);
+        second = (int)(wave_min(k1 == best ? k2 : k1) >> 16);
+        bestDist = (int)(best >> 16);
+        bq = (int)(best & 0xffffu);
+      }
+      if (bestDist <= maxDist && static_cast<float>(bestDist) < nnratio * static_cast<float>(second)) {
+        if (free_ && q == (unsigned)bq) free_ = false;   // later features of this group that list the same candidate
+        if (lane == 0) {
+          matched[bq >> 5] |= 1u << (bq & 31);          // (visible to the rescans of this group and to the next group's read)
+          if (selInLds) sel[i0 + ff] = (uint16_t)(bq + 1);
+          else matches12[(unsigned)P.base1 + feat1[P.b1 + i0 + ff]] = (int32_t)feat2[P.b2 + bq];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the group's bits are in LDS before the next group reads the bitmap
   }
+  if (selInLds)
+    for (int i = lane; i < n1g; i += 64) {
+      const unsigned w = sel[i];
+      if (w) matches12[(unsigned)P.base1 + feat1[P.b1 + i]] = (int32_t)feat2[P.b2 + (int)w - 1];
+    }
+  (void)selBig;
   done();
 }
 
@@ -685,6 +856,8 @@ struct BowScratch {
   DevBuf<OrbfeKeyPoint> d_kps1, d_kps2;
   DevBuf<uint8_t> d_arena;    // batched search: everything that goes up in one copy
   PinBuf<uint8_t> h_arena;
+  DevBuf<uint32_t> d_topk;    // large nodes: kBowTopK least keys per frame-1 feature (k_bow_topk)
+  DevBuf<TopkItem> d_items;
   DevBuf<unsigned> d_done;    // route without copy commands: block counter, the call's number (page-locked)
   PinBuf<int> h_done;
   int seq = 0;
@@ -697,7 +870,7 @@ int common_nodes(const uint32_t* fv1_nodes, const uint32_t* fv1_offsets, int n_f
   pairs.clear();
   for (int a = 0, b = 0; a < n_fv1 && b < n_fv2;) {
     if (fv1_nodes[a] == fv2_nodes[b]) {
-      BowPair p = {(int)fv1_offsets[a], (int)fv1_offsets[a + 1], (int)fv2_offsets[b], (int)fv2_offsets[b + 1], 0};
+      BowPair p = {(int)fv1_offsets[a], (int)fv1_offsets[a + 1], (int)fv2_offsets[b], (int)fv2_offsets[b + 1], 0, -1};
       if (p.e2 - p.b2 > kMaxGroup) { set_err("a vocabulary node holds %d features (max %d)", p.e2 - p.b2, kMaxGroup); return ORBFE_ERR_OVERFLOW; }
       if (p.e1 > p.b1 && p.e2 > p.b2) pairs.push_back(p);
       a++; b++;
@@ -780,6 +953,19 @@ static int bow_batch_core(orbfe_matcher* m, int n_kf, const uint8_t* const* desc
     featBase[k + 1] = featBase[k] + (size_t)nf1;
   }
   if (all.empty()) return ORBFE_OK;
+  // large nodes (more than kBowSide features of either frame): their frame-1 features get a top-K list first (k_bow_topk)
+  std::vector<TopkItem> items;
+  size_t topkRows = 0;
+  int maxStage = 0;
+  for (size_t i = 0; i < all.size(); i++) {
+    BowPair& p = all[i];
+    const int n1g = p.e1 - p.b1, n2g = p.e2 - p.b2;
+    if (n1g <= kBowSide && n2g <= kBowSide) continue;
+    p.tk = (int)topkRows;
+    topkRows += (size_t)n1g;
+    maxStage = std::max(maxStage, std::min(n2g, kTopkLdsFeatures));
+    for (int r = 0; r < n1g; r += kTopkRows) items.push_back(TopkItem{(int)i, r});
+  }
   const size_t rows1 = rowBase[n_kf], feats1 = featBase[n_kf];
   HIP_TRY(hipSetDevice(orbfe::matcher_device(m)));
   std::shared_ptr<void>& slot = orbfe::matcher_bow_slot(m);
@@ -822,7 +1008,7 @@ static int bow_batch_core(orbfe_matcher* m, int n_kf, const uint8_t* const* desc
     hipLaunchKernelGGL(k_bow_match, dim3((unsigned)all.size()), dim3(kBowThreads), 0, st, dev1 ? dev1 : (const uint4*)(H + oD1), (const uint8_t*)(H + oV1),
                        (const uint32_t*)(H + oF1), dev2 ? dev2 : (const uint4*)(H + oD2), valid2 ? (const uint8_t*)(H + oV2) : (const uint8_t*)nullptr,
                        (const uint32_t*)(H + oF2), (const BowPair*)(H + oP), strict_threshold ? TH_LOW - 1 : TH_LOW, nnratio, S->h_m12.p,
-                       S->d_done.p, S->h_done.p, S->seq);
+                       S->d_done.p, S->h_done.p, S->seq, (const uint32_t*)nullptr);
     HIP_TRY(hipGetLastError());
     const volatile int* flag = S->h_done.p;
     bool seen = false;
@@ -838,10 +1024,29 @@ static int bow_batch_core(orbfe_matcher* m, int n_kf, const uint8_t* const* desc
     uint8_t* D = S->d_arena.p;
     HIP_TRY(hipMemcpyAsync(D, H, total, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(S->d_m12.p, 0xff, sizeof(int32_t) * rows1, st));
+    if (!items.empty()) {
+      if ((rc = S->d_topk.ensure(topkRows * kBowTopK)) || (rc = S->d_items.ensure(items.size()))) return rc;
+      HIP_TRY(hipMemcpyAsync(S->d_items.p, items.data(), sizeof(TopkItem) * items.size(), hipMemcpyHostToDevice, st));   // (waited for below)
+      const size_t ldsBytes = (size_t)maxStage * 36 + 16;
+      static std::mutex mu;
+      static size_t attr[64] = {};
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        const int dv = orbfe::matcher_device(m);
+        if (dv >= 0 && dv < 64 && ldsBytes > attr[dv]) {
+          HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bow_topk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+          attr[dv] = ldsBytes;
+        }
+      }
+      hipLaunchKernelGGL(k_bow_topk, dim3((unsigned)items.size()), dim3(256), ldsBytes, st, dev1 ? dev1 : (const uint4*)(D + oD1), (const uint8_t*)(D + oV1),
+                         (const uint32_t*)(D + oF1), dev2 ? dev2 : (const uint4*)(D + oD2), valid2 ? (const uint8_t*)(D + oV2) : (const uint8_t*)nullptr,
+                         (const uint32_t*)(D + oF2), (const BowPair*)(D + oP), (const TopkItem*)S->d_items.p, S->d_topk.p);
+      HIP_TRY(hipGetLastError());
+    }
     hipLaunchKernelGGL(k_bow_match, dim3((unsigned)all.size()), dim3(kBowThreads), 0, st, dev1 ? dev1 : (const uint4*)(D + oD1), (const uint8_t*)(D + oV1),
                        (const uint32_t*)(D + oF1), dev2 ? dev2 : (const uint4*)(D + oD2), valid2 ? (const uint8_t*)(D + oV2) : (const uint8_t*)nullptr,
                        (const uint32_t*)(D + oF2), (const BowPair*)(D + oP), strict_threshold ? TH_LOW - 1 : TH_LOW, nnratio, S->d_m12.p,
-                       (unsigned*)nullptr, (int*)nullptr, 0);
+                       (unsigned*)nullptr, (int*)nullptr, 0, (const uint32_t*)S->d_topk.p);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(S->h_m12.p, S->d_m12.p, sizeof(int32_t) * rows1, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

@@ -183,3 +183,35 @@ def test_search_by_bow_matches_python_restatement(oracle, levelsup):
         nm, m12 = oracle.search_by_bow(d1, a1, v1, fv1, d2, a2, v2, fv2, ratio, ori)
         want = _py_search_by_bow(d1, a1, v1, fv1, d2, a2, v2, fv2, ratio, ori, True)
         assert {i: int(j) for i, j in enumerate(m12) if j >= 0} == want and nm == len(want)
+
+
+def _with_trailing_duplicate(image):
+    """What the reference's loadFromBinaryFile BUILDS from a vocabulary file (Thirdparty/DBoW2/DBoW2/TemplatedVocabulary.h:
+    1604-1640): it loops `while(!f.eof())`, and eof is only raised by the read AFTER the last record -- that read fails, leaves
+    the 45-byte buffer as it was and one more node is appended: a copy of the last record (same parent, leaf flag, descriptor,
+    weight).  As a file image: the last record twice."""
+    return image + image[-45:]
+
+
+@pytest.mark.parametrize('k,L', [(10, 3), (4, 4), (7, 2)])
+def test_reference_loader_trailing_duplicate_changes_nothing(oracle, k, L):
+    """The duplicate node sits behind its original among the children of their parent, and the descent takes a child only on a
+    STRICTLY smaller distance (TemplatedVocabulary.h:1328-1336): it can never be chosen -- BowVector, FeatureVector and the
+    per-feature (word, node) pairs of a vocabulary loaded the reference's way equal those of the file as written, also for
+    descriptors that ARE the last word's descriptor (distance 0 to both copies)."""
+    image = synth_vocabulary(5 + k, k, L)
+    dup = _with_trailing_duplicate(image)
+    assert len(dup) == len(image) + 45
+    a, b = oracle.vocabulary(image), oracle.vocabulary(dup)
+    d = _descs(3, image, 1200)
+    last_word = np.frombuffer(image[-45 + 5:-45 + 37], np.uint8)
+    d[:40] = last_word                                   # exact hits of the duplicated word
+    for i in range(40, 80):                              # ... and near misses
+        d[i] = last_word
+        d[i, i % 32] ^= np.uint8(1 << (i % 8))
+    for lu in (0, 1, L, L + 2):
+        ta, tb = a.transform(d, lu), b.transform(d, lu)
+        assert ta[0].tobytes() == tb[0].tobytes() and ta[1].tobytes() == tb[1].tobytes()
+        for x, y in zip(ta[2], tb[2]):
+            assert x.tobytes() == y.tobytes()
+        assert ta[3].tobytes() == tb[3].tobytes() and ta[4].tobytes() == tb[4].tobytes()

@@ -246,3 +246,99 @@ def test_stream_runner_with_vocabulary(api, oracle):
             _same_transform(v.assemble(leaf, node), ov.transform(desc[i, :n[i]], 2))
     st.close()
     v.close()
+
+
+def test_search_by_bow_large_nodes_and_exhausted_candidate_lists(api, oracle):
+    """Nodes beyond 256 features per side take k_bow_topk + the single-wave walk (round 4): every frame-1 feature's eight least
+    keys are computed in parallel, the in-order walk (ORBmatcher.cc:196-222) then decides from them and the matched bitmap.
+    (a) 2 000 x 2 000 features under ONE node -- the degenerate grouping of a vocabulary with L <= levelsup, which used to cost
+    6.8 ms; (b) heavy competition: 40 distinct descriptors in ~15 near-copies each on both sides, so that most features find
+    seven or eight of their eight nearest already taken and rescan the node (the fallback); (c) several large nodes and small
+    ones in one call, an invalid-flag mix, nodes larger than the 4 096 features k_bow_topk stages in LDS."""
+    import time
+    m = api.Matcher()
+    rng = np.random.default_rng(77)
+
+    def one_node(n):
+        return (np.array([3], np.uint32), np.array([0, n], np.uint32), np.arange(n, dtype=np.uint32))
+
+    def noisy(base, flips):
+        d = base.copy()
+        for i in range(len(d)):
+            for b in rng.integers(0, 256, rng.integers(0, flips + 1)):
+                d[i, b >> 3] ^= np.uint8(1 << (b & 7))
+        return d
+
+    # (a) 2000 x 2000, mostly true correspondences with 0-30 flipped bits
+    n = 2000
+    d1 = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    d2 = noisy(d1[rng.permutation(n)], 30)
+    a1 = rng.uniform(0, 360, n).astype(np.float32)
+    a2 = rng.uniform(0, 360, n).astype(np.float32)
+    v1 = (rng.random(n) < 0.9).astype(np.uint8)
+    v2 = (rng.random(n) < 0.9).astype(np.uint8)
+    for ratio, ori, valid2, strict in [(0.7, False, None, False), (0.9, True, v2, True)]:
+        got = m.search_by_bow(d1, a1, v1, one_node(n), d2, a2, valid2, one_node(n), ratio, ori, strict)
+        want = oracle.search_by_bow(d1, a1, v1, one_node(n), d2, a2, valid2, one_node(n), ratio, ori)
+        assert got[0] == want[0] and got[1].tobytes() == want[1].tobytes() and got[0] > 300
+    t = []
+    for _ in range(12):
+        t0 = time.perf_counter()
+        m.search_by_bow(d1, a1, v1, one_node(n), d2, a2, None, one_node(n), 0.7, False, False)
+        t.append(time.perf_counter() - t0)
+    ms = float(np.median(t[2:])) * 1e3
+    print('SearchByBoW, 2000 x 2000 features under one node: %.3f ms per call' % ms)
+    assert ms < 1.0          # 6.8 ms before round 4; measured 0.2 - 0.3 ms
+    # (b) competition: few distinct descriptors, many near-copies -> exhausted lists
+    proto = rng.integers(0, 256, (40, 32), dtype=np.uint8)
+    n1, n2 = 620, 580
+    d1 = noisy(proto[rng.integers(0, 40, n1)], 3)
+    d2 = noisy(proto[rng.integers(0, 40, n2)], 3)
+    a1 = rng.uniform(0, 360, n1).astype(np.float32)
+    a2 = rng.uniform(0, 360, n2).astype(np.float32)
+    v1 = np.ones(n1, np.uint8)
+    for ratio in (0.95, 1.0, 0.6):
+        got = m.search_by_bow(d1, a1, v1, one_node(n1), d2, a2, None, one_node(n2), ratio, False, False)
+        want = oracle.search_by_bow(d1, a1, v1, one_node(n1), d2, a2, None, one_node(n2), ratio, False)
+        assert got[0] == want[0] and got[1].tobytes() == want[1].tobytes(), ratio
+    # (c) three large nodes (one beyond the LDS staging limit) and forty small ones in one call
+    sizes1 = [300, 5000, 700] + [int(x) for x in rng.integers(1, 40, 40)]
+    sizes2 = [900, 4500, 260] + [int(x) for x in rng.integers(1, 40, 40)]
+    n1, n2 = sum(sizes1), sum(sizes2)
+    d1 = rng.integers(0, 256, (n1, 32), dtype=np.uint8)
+    src = rng.integers(0, n1, n2)
+    d2 = noisy(d1[src], 25)
+    p1, p2 = rng.permutation(n1).astype(np.uint32), rng.permutation(n2).astype(np.uint32)
+    fv1 = (np.arange(len(sizes1), dtype=np.uint32) * 2 + 1, np.concatenate([[0], np.cumsum(sizes1)]).astype(np.uint32), p1)
+    fv2 = (np.arange(len(sizes2), dtype=np.uint32) * 2 + 1, np.concatenate([[0], np.cumsum(sizes2)]).astype(np.uint32), p2)
+    # the reference's lists hold ascending feature indices inside a node
+    for fv, sizes in ((fv1, sizes1), (fv2, sizes2)):
+        o = fv[1]
+        for i in range(len(sizes)):
+            fv[2][o[i]:o[i + 1]].sort()
+    a1 = rng.uniform(0, 360, n1).astype(np.float32)
+    a2 = rng.uniform(0, 360, n2).astype(np.float32)
+    v1 = (rng.random(n1) < 0.8).astype(np.uint8)
+    v2 = (rng.random(n2) < 0.8).astype(np.uint8)
+    for valid2, strict in [(None, False), (v2, True)]:
+        got = m.search_by_bow(d1, a1, v1, fv1, d2, a2, valid2, fv2, 0.8, True, strict)
+        want = oracle.search_by_bow(d1, a1, v1, fv1, d2, a2, valid2, fv2, 0.8, True)
+        assert got[0] == want[0] and got[1].tobytes() == want[1].tobytes()
+
+
+def test_vocabulary_image_with_the_reference_loaders_trailing_duplicate(api, oracle):
+    """orbfe_vocabulary_create_from_image on a file image as the reference's loadFromBinaryFile effectively sees it -- the last
+    record twice (its `while(!eof)` loop appends a copy of the last node, TemplatedVocabulary.h:1604-1640): the descent can never
+    choose the copy (strict `<`), so the GPU transform equals the transform of the plain image and the oracle's."""
+    from test_bow_oracle import _with_trailing_duplicate
+    image = synth_vocabulary(9, 10, 4)
+    dup = _with_trailing_duplicate(image)
+    v, vd, ov = api.Vocabulary(image), api.Vocabulary(dup), oracle.vocabulary(image)
+    assert vd.info()['n_nodes'] == v.info()['n_nodes'] + 1
+    d = _descs(5, image, 1500)
+    d[:30] = np.frombuffer(image[-45 + 5:-45 + 37], np.uint8)
+    for lu in (0, 2, 4):
+        want = ov.transform(d, lu)
+        _same_transform(v.transform(d, lu), want)
+        _same_transform(vd.transform(d, lu), want)
+    v.close(); vd.close()
