@@ -32,6 +32,11 @@ One JSON line on rank 0 (see the task's bench contract) with extra objects:
 import argparse
 import json
 import os
+
+# Four extraction batches in flight need more than the HIP runtime's default of 4 hardware queues (two streams folded onto one
+# queue serialise; every rank also has its upload lane): must be in the environment BEFORE the process's first HIP call -- i.e.
+# before torch / liborbfe are loaded.  A value the caller exported wins.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 import socket
 import subprocess
 import sys
@@ -60,7 +65,8 @@ def parse_args():
     ap.add_argument('--no-latency', action='store_true', help='skip the blocking single-frame latency leg (profiling runs: keeps every launch a full batch)')
     ap.add_argument('--host-input', nargs='?', const='pageable', default=None, choices=['pageable', 'pinned'],
                     help='headline leg from HOST frames instead (developer aid; never the contract value)')
-    ap.add_argument('--depth', type=int, default=3, help='extraction batches in flight inside the stream runner')
+    ap.add_argument('--depth', type=int, default=4, help='extraction batches in flight inside the stream runner (4 with 8 hardware queues: '
+                    '66.7 k frames/s against 63.6 k at 3; 5 and 6 are slower -- DESIGN.md s5)')
     ap.add_argument('--prewarm-seconds', type=float, default=1.5,
                     help='untimed stream work in front of the W warm-up steps (a box that has just been started runs its first second slower: clocks, first-touch pages)')
     ap.add_argument('--plumbing-only', action='store_true',
@@ -396,6 +402,7 @@ def run_rank(args):
                                  'pageable': 'frames in pageable host memory (PCIe-inclusive)'}[head_source] + '; keypoints/descriptors/matches returned to host',
                        'value_is': ('the RESIDENT rate (frames in HBM when the timed region starts, the bench contract); SURVEY.md s8(d) puts the H2D of every '
                                     'frame inside its metric: that figure is pcie_inclusive.value' if head_source == 'hbm' else 'a PCIe-inclusive rate (developer run)'),
+                       'batches_in_flight': max(1, args.depth), 'hip_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES'),
                        'numa': {'node_of_gpu': numa_node, 'cpus_bound': numa_cpus}},
             'verified': verify['verified'], 'outputs_sha256': verify['outputs_sha256'], 'verify': verify,
             'pcie_inclusive': pcie,
