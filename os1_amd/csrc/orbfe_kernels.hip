@@ -190,7 +190,7 @@ __device__ __forceinline__ unsigned pk_round2(unsigned x, unsigned y) {
 // adjacent footprints share are fetched into one L2 once instead of into two L2s (profiles/r02n_pmc_summary.csv: the
 // plain (x, y, frame) grid fetched 2.3x the level it reads).  tile -> (tx, ty) by a scalar multiply-high.
 template <int LP, int RH>
-__global__ __launch_bounds__(256) void k_resize_fixed(PyramidParams P, int level, int tilesX, int ntiles, unsigned rcpTilesX) {
+__global__ __launch_bounds__(256) void k_resize_fixed(PyramidParams P, int level, int tilesX, int ntiles, unsigned rcpTilesX, int dma) {
   __shared__ __align__(16) uint8_t rz[LP * RH];
   __shared__ __align__(16) uint16_t H[RH * 64];
   const LevelGeom& D = P.lv[level];
@@ -230,7 +230,33 @@ __global__ __launch_bounds__(256) void k_resize_fixed(PyramidParams P, int level
   const int istr = (int)sstride;
   const uint8_t* rbase = uniform_ptr(src + (long long)ry0 * sstride + rx0);   // the same for the whole block
   const int a = (int)(reinterpret_cast<uintptr_t>(rbase) & 3);
-  if ((sstride & 3) == 0) {
+  if ((sstride & 3) == 0 && dma) {
+    // LDS-DMA staging (round 4): global_load_lds_dwordx4 moves 16 bytes per lane from memory straight into LDS -- lane L's
+    // bytes land at the instruction's LDS base + 16 L, so with 6 lanes per 96-byte tile row one instruction of 60 lanes fills TEN
+    // rows: the whole 80-row footprint is 8 instructions per BLOCK (2 per wave) instead of 10 loads + 10 ds_write per THREAD, no
+    // staging registers, no per-element address arithmetic (the global side needs dword alignment only).  Rows past the footprint
+    // are not fetched (nobody reads their H).  A 16-byte piece may reach up to 12 bytes past the footprint's last needed byte:
+    // inside the row's pitch or the next row everywhere except on the LAST row of a caller-owned level-0 frame, which
+    // therefore comes in by plain dword loads.
+    static_assert(LP == 96 && RH % 10 == 0, "LDS-DMA staging layout");
+    const uint8_t* gb = rbase - a;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int lrow = (int)(((unsigned)lane * 43u) >> 8), lcol = lane - lrow * 6;   // lane / 6 for lane < 64
+    const bool lastSpecial = level == 1 && ry1 == S.h - 1;
+    const int rhDma = lastSpecial ? rh - 1 : rh;
+    const bool on = lrow < 10 && 16 * lcol < a + rw;
+    const unsigned voff = (unsigned)(m24(lrow, istr) + 16 * lcol);
+#pragma unroll
+    for (int u = 0; u < RH / 40; u++) {
+      const int r = (wave * (RH / 40) + u) * 10;
+      if (on && r + lrow < rhDma)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + (long long)r * sstride + voff),
+                                         (__attribute__((address_space(3))) void*)(rz + r * LP), 16, 0, 0);
+    }
+    if (lastSpecial && tid < ((a + rw + 3) >> 2))
+      *reinterpret_cast<uint32_t*>(rz + (rh - 1) * LP + 4 * tid) = (uint32_t)ld32(gb, (unsigned)(4 * tid + m24(rh - 1, istr)));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else if ((sstride & 3) == 0) {
     // thread (c, r0) = (tid % 32, tid / 32) copies dword column c (LP / 4 <= 32 columns) of rows r0, r0 + 8, ...: all RH / 8
     // loads are issued before the first LDS write; rows past the footprint repeat its last row (never read back)
     static_assert(LP <= 128 && RH % 8 == 0, "staging layout");
@@ -989,7 +1015,8 @@ int launch_pyramid(const PyramidParams& P, int nframes, hipStream_t st, const Co
       const int tilesX = (int)grid.x, ntiles = (int)(grid.x * grid.y);
       const unsigned rcp = (unsigned)(0x100000000ull / (unsigned)tilesX) + 1u;   // floor(t * rcp / 2^32) = t / tilesX for t * tilesX < 2^32
       if ((unsigned long long)ntiles * tilesX < (1ull << 31)) {
-        hipLaunchKernelGGL((k_resize_fixed<96, 80>), dim3(8 * ((ntiles + 7) / 8), nframes), dim3(256), 0, st, P, l, tilesX, ntiles, rcp);
+        static const int dma = [] { const char* e = getenv("ORBFE_RESIZE_DMA"); return e ? atoi(e) : 1; }();   // 0: staging through registers (A/B)
+        hipLaunchKernelGGL((k_resize_fixed<96, 80>), dim3(8 * ((ntiles + 7) / 8), nframes), dim3(256), 0, st, P, l, tilesX, ntiles, rcp, dma);
         continue;
       }
     }
