@@ -230,6 +230,7 @@ struct orbfe_extractor {
   int coneMaxFrames = 2;   // batches up to this size build the pyramid with k_pyramid_cone
   DevBuf<CellInfo> d_cells;
   DevBuf<FastTask> d_tasks;
+  DevBuf<uint8_t> d_zeros;
   bool pairCells = false;  // ORBFE_FAST_PAIRS=1: two adjacent cells per wave (7 % fewer vector instructions, but 10 % slower: DESIGN.md s5)
   DevBuf<uint32_t> d_cellCount, d_cellOff, d_slots, d_cand;
   DevBuf<const uint8_t*> d_frame0;
@@ -291,7 +292,7 @@ struct orbfe_extractor {
     d_bow.release(); h_bow.release();
     d_tables.release(); d_coneTab.release(); d_slab.release(); d_in.release(); d_cellCount.release(); d_cellOff.release();
     d_sfiOrder.release(); d_sfiOrderCount.release(); d_sfiPool.release(); d_sfiPcount.release();
-    d_cells.release(); d_tasks.release(); d_slots.release(); d_cand.release(); d_frame0.release(); d_gray.release(); d_outArena.release(); h_outArena.release();
+    d_cells.release(); d_tasks.release(); d_zeros.release(); d_slots.release(); d_cand.release(); d_frame0.release(); d_gray.release(); d_outArena.release(); h_outArena.release();
     d_f32tmp.release();
     h_frame0.release(); h_cand.release();
     for (auto& es : ev) for (auto& e : es) if (e) (void)hipEventDestroy(e);
@@ -538,6 +539,11 @@ struct orbfe_extractor {
     }
     for (int l = nlevels; l <= kMaxLevels; l++) Q.taskStart[l] = (int)tasks.size();
     if ((rc = d_tasks.ensure(tasks.size()))) return rc;
+    if (!d_zeros.p) {
+      if ((rc = d_zeros.ensure(256))) return rc;
+      HIP_TRY(hipMemsetAsync(d_zeros.p, 0, 256, stream));
+    }
+    Q.zeros = d_zeros.p;
     HIP_TRY(hipMemcpyAsync(d_tasks.p, tasks.data(), sizeof(FastTask) * tasks.size(), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     Q.cells = d_cells.p;

@@ -105,8 +105,9 @@ __global__ __launch_bounds__(64) void k_fast_tasks(PyramidParams P, int tpPad, i
   const int TP = ((fastW + 6 + 3 + 3) & ~3) + tpPad;
   const int SP = fastW + 2;
   uint8_t* tile = lds;
-  uint8_t* sc = tile + TP * (hCell + 6);
-  uint16_t* queue = reinterpret_cast<uint16_t*>(lds + ((TP * (hCell + 6) + SP * (hCell + 2) + 3) & ~3));
+  const int scOff = (TP * (hCell + 6) + 15) & ~15;   // 16-byte aligned: it is cleared by 16-byte LDS-DMA pieces
+  uint8_t* sc = tile + scOff;
+  uint16_t* queue = reinterpret_cast<uint16_t*>(lds + ((scOff + SP * (hCell + 2) + 15) & ~15));
 
   const int rw = W2 + 6, rh = eh + 6;
   const int istr = (int)stride;
@@ -176,7 +177,16 @@ __global__ __launch_bounds__(64) void k_fast_tasks(PyramidParams P, int tpPad, i
     }
   }
   tile += a;  // ROI pixel (x, y) lives at tile[y * TP + x]
-  {  // zero the score tile with dword stores (sc is 4-byte aligned: TP*(hCell+6) is a multiple of 4)
+  if (dma && P.zeros) {
+    // the score tile is cleared by LDS-DMA too: every lane fetches the same 16 zero bytes (one cache line for the whole chip) and
+    // lane L's copy lands at base + 16 L -- two instructions for the 1.1 KB tile, no vector instruction, no ds_write.  (The last
+    // piece may run up to 15 bytes into the queue, which stage 1 writes later.)
+    const int pieces = (SP * (eh + 2) + 15) >> 4;
+    for (int p0 = 0; p0 < pieces; p0 += 64)
+      if (lane < pieces - p0)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)P.zeros,
+                                         (__attribute__((address_space(3))) void*)(sc + 16 * p0), 16, 0, 0);
+  } else {  // zero the score tile with dword stores
     uint32_t* z = reinterpret_cast<uint32_t*>(sc);
     const int nz = (SP * (eh + 2) + 3) >> 2;
     for (int i = lane; i < nz; i += 64) z[i] = 0u;
@@ -444,7 +454,8 @@ static void stamp_buffer_for(size_t waves) {
 
 static size_t fast_lds_bytes_level(const LevelGeom& L, int tpPad) {
   const size_t TP = ((L.fastW + 6 + 3 + 3) & ~3) + tpPad;
-  const size_t b = ((TP * (L.hCell + 6) + (size_t)(L.fastW + 2) * (L.hCell + 2) + 3) & ~(size_t)3) +
+  const size_t scOff = (TP * (L.hCell + 6) + 15) & ~(size_t)15;
+  const size_t b = ((scOff + (size_t)(L.fastW + 2) * (L.hCell + 2) + 15) & ~(size_t)15) +
                    2 * (size_t)L.fastW * L.hCell + 64;  // tile + score tile + u16 queue + slack for the group over-read
   return (b + 15) & ~(size_t)15;
 }

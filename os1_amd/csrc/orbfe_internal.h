@@ -80,6 +80,7 @@ struct PyramidParams {
   const FastTask* tasks;            // [ntasks] work items of k_fast_tasks, level-major
   int ntasks;
   int taskStart[kMaxLevels + 1];    // first task of each level (host side of launch_fast: LDS classes)
+  const uint8_t* zeros;             // 256 zero bytes in device memory: source of the LDS-DMA that clears a FAST wave's score tile
   int iniTh, minTh;
   int frameBase;                    // first frame of this launch (sub-batch pipelining)
 };

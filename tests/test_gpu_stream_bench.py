@@ -1,5 +1,5 @@
 """-m gpu: the workload bench.py measures (BASELINE.json configs[3]: stream seed 100+g, 1920x1080, 2000 features,
-32-frame submissions, depth 3, SearchForInitialization chained frame to frame and across submissions) against the
+32-frame submissions, 4 batches in flight, SearchForInitialization chained frame to frame and across submissions) against the
 CPU oracle -- live, frame by frame, and through the committed digests bench.py itself checks."""
 import json
 import os
@@ -23,7 +23,7 @@ def api():
     return a
 
 
-def _run_stream(api, seed, nsub, depth=3, source='hbm'):
+def _run_stream(api, seed, nsub, depth=4, source='hbm'):
     sf = wl.StreamFrames(seed)
     idx = [wl.pool_index(p) for p in range(nsub * wl.BATCH)]
     frames = {i: sf.frame(i) for i in sorted(set(idx))}
@@ -52,7 +52,7 @@ def _run_stream(api, seed, nsub, depth=3, source='hbm'):
 
 
 def test_bench_stream_matches_oracle_frame_by_frame(api, oracle):
-    """4 submissions of stream 100 at the bench's exact configuration (all 3 handles used, the SearchForInitialization
+    """4 submissions of stream 100 at the bench's exact configuration (all 4 handles used, the SearchForInitialization
     chain crosses 3 submission boundaries): every keypoint field, descriptor byte and vnMatches12 entry of the first 64
     frames against the live oracle, and all 128 frames against the committed digests."""
     from oracle.stream_ref import oracle_stream_steps
