@@ -295,10 +295,13 @@ def run_rank(args):
     head_pops = np.array(pop_times)
     head_matches = nmatch_total[0]
 
-    pcie = None
-    if not args.no_pcie and head_source == 'hbm':
-        # host frames: a batch computes only after its whole upload, so one batch fewer in flight serves the link better (26.4 k
-        # frames/s with 3, 25.3 k with 4); a runner of its own for this leg
+    def pcie_leg():
+        """The same stream from page-locked HOST frames, H2D of every frame inside the timed region (SURVEY.md s8(d)'s figure).
+        Host frames: a batch computes only after its whole upload, so one batch fewer in flight serves the link better (26.2 k
+        frames/s with 3, 25.3 k with 4) -- a runner of its own for this leg."""
+        nonlocal st, lookahead
+        if args.no_pcie or head_source != 'hbm':
+            return None
         pdepth = min(3, max(1, args.depth))
         if pdepth != max(1, args.depth):
             st.close()
@@ -309,12 +312,17 @@ def run_rank(args):
         link = api.h2d_rate_gbs(local_rank, pinned.base, pinned.frame_bytes * B)
         pel = timed(psteps, pwarm, 'pinned')
         pfps = world * args.pool * psteps / pel
-        pcie = {'value': round(pfps, 2), 'unit': 'frames/s', 'steps': psteps, 'warmup': pwarm,
+        return {'value': round(pfps, 2), 'unit': 'frames/s', 'steps': psteps, 'warmup': pwarm,
                 'ms_per_step': round(pel / psteps * 1e3, 4),
                 'input': 'the same %d-frame pool in page-locked host memory (orbfe_host_alloc); H2D of every frame inside the timed region' % args.pool,
                 'batches_in_flight': pdepth,
                 'h2d_link_gbs_rank0': round(link, 2), 'h2d_link_frames_per_s_rank0': round(link * 1e9 / (W * H), 1),
                 'frac_of_link_rank0': round(pfps / world * W * H / (link * 1e9), 4) if link > 0 else None}
+
+    # N > 1: every rank runs the leg now (it has a barrier inside).  N = 1: after the blocking single-call legs below -- a second
+    # runner adds streams to the process and shifts the stream -> hardware-queue mapping of whatever is created after it (the
+    # page-locked single-frame call read 0.195 instead of 0.170 ms behind it: its upload lane and its compute stream on different queues)
+    pcie = pcie_leg() if world > 1 else None
 
     if rank == 0:
         frames_done = world * args.pool * args.steps
@@ -445,6 +453,8 @@ def run_rank(args):
             out['config5_search_by_projection'] = config5_leg(api, local_rank, args.cpu_frames > 0)
             out['tracking_step'] = tracking_step_leg(api, local_rank, frames, W, H, wl, args.cpu_frames > 0)
             out['bow'] = bow_leg(api, local_rank, frames, W, H, wl, args.cpu_frames > 0)
+        if world == 1:
+            out['pcie_inclusive'] = pcie_leg()
         if world == 1 and args.cpu_frames > 0:
             out['cpu_baseline'] = cpu_baseline(frames, args.cpu_frames, not args.no_match)
             out['cpu_baseline_all_cores'] = cpu_baseline_all_cores(frames, not args.no_match)
