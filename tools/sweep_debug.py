@@ -41,6 +41,19 @@ for it in range(count):
     wk, wd = ox.extract(img)
     gk, gd = ex(img)
     ok = gk.tobytes() == wk.tobytes() and gd.tobytes() == wd.tobytes()
-    print(it, W, H, N, sf, nl, ini, mn, mode, len(wk), 'OK' if ok else 'MISMATCH', flush=True)
-    bad += not ok
+    # the BATCH route too (per-level resize launches with LDS-DMA staging, FAST launched per LDS class): four frames, from
+    # host memory and from device memory with a row stride that is / is not a multiple of 4
+    imgs = [img, np.ascontiguousarray(img[::-1]), np.ascontiguousarray(img[:, ::-1]), img]
+    want = [(wk, wd), ox.extract(imgs[1]), ox.extract(imgs[2]), (wk, wd)]
+    okb = True
+    for g, w in zip(ex.extract_batch(imgs), want):
+        okb = okb and g[0].tobytes() == w[0].tobytes() and g[1].tobytes() == w[1].tobytes()
+    stride = W + int(rng.choice([0, 3, 4, 61, 64]))
+    dev = api.DeviceFrames(imgs, 0, stride=stride)
+    kps, desc, n = ex.extract_batch_ptrs(dev.ptrs, H, W, stride, True)
+    for i, w in enumerate(want):
+        okb = okb and kps[i, :n[i]].tobytes() == w[0].tobytes() and desc[i, :n[i]].tobytes() == w[1].tobytes()
+    dev.free()
+    print(it, W, H, N, sf, nl, ini, mn, mode, len(wk), 'OK' if ok else 'MISMATCH', 'batch', stride - W, 'OK' if okb else 'MISMATCH', flush=True)
+    bad += (not ok) + (not okb)
 print('mismatches', bad)
