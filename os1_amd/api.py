@@ -291,7 +291,7 @@ class Extractor:
             desc = np.zeros((B, self.cap, 32), np.uint8)
         n = np.zeros(B, np.int32)
         _check(self.L.orbfe_extract_batch(self.h, B, arr, int(on_device), rows, cols, stride, _p(kps), _p(desc),
-                                          self.cap, _p(n)))
+                                          int(kps.shape[1]), _p(n)))   # cap = what the caller's buffers hold per frame
         return kps, desc, n
 
     def submit_ptrs(self, ptrs, rows, cols, stride, on_device):

@@ -9,9 +9,13 @@
 #include <vector>
 #include <algorithm>
 
-template <int VG>
+template <int VG, int SG = 0>
 __global__ __launch_bounds__(512) void k_spin(unsigned* out, int cycles, int touch) {
   extern __shared__ unsigned lds[];
+  if (SG >= 1) asm volatile("" ::: "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59",
+                            "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79");
+  if (SG >= 2) asm volatile("" ::: "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95");
+  if (SG >= 3) asm volatile("" ::: "s96", "s97", "s98", "s99", "s100", "s101");
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   unsigned v[VG];
 #pragma unroll
@@ -47,7 +51,7 @@ int main(int argc, char** argv) {
       best = std::min(best, ms);
     }
     const double us = best * 1e3, waveUs = cyc / 2400.0;
-    printf("%-8s waves/WG %d  lds %5d  spin %6d cyc  %8.1f us   ideal(8/SIMD) %7.1f us   residency %.2f waves/SIMD\n", name, wpb, lds, cyc, us,
+    printf("%-11s waves/WG %d  lds %5d  spin %6d cyc  %8.1f us   ideal(8/SIMD) %7.1f us   residency %.2f waves/SIMD\n", name, wpb, lds, cyc, us,
            waves * waveUs / 8192.0, waves * waveUs / us / 1024.0);
   };
   for (int cyc : {8000, 16000}) {
@@ -61,6 +65,9 @@ int main(int argc, char** argv) {
     run(k_spin<28>, "VG=28", 1, 4608, cyc);
     run(k_spin<32>, "VG=32", 1, 4608, cyc);
     run(k_spin<40>, "VG=40", 1, 4608, cyc);
+    run(k_spin<24, 1>, "VG=24 S80", 1, 4608, cyc);
+    run(k_spin<24, 2>, "VG=24 S96", 1, 4608, cyc);
+    run(k_spin<24, 3>, "VG=24 S102", 1, 4608, cyc);
   }
   return 0;
 }
