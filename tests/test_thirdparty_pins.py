@@ -222,3 +222,64 @@ def test_steered_brief_against_scikit_image(oracle, tmp_path):
     print('descriptors %d, identical %d, differing bits %d of %d' % (ndesc, nexact, nbad, nbits))
     assert ndesc > 500
     assert nbad <= nbits * 2e-4 and nexact >= 0.97 * ndesc
+
+
+@pytest.mark.gpu
+def test_product_against_third_parties_directly(tmp_path):
+    """The HIP path with NO oracle in between: keypoints, angles and descriptors of a GPU extraction against scikit-image / scipy
+    evaluated on the product's own pyramid levels -- every keypoint passes scikit-image's FAST-9 test with response = the
+    largest passing threshold, its angle is corner_orientations' within fastAtan2's 0.3 degrees, and its descriptor is what
+    scikit-image's steered-BRIEF loop reads from scipy's integer Gaussian of the level."""
+    from os1_amd import api
+    assert api.device_count() >= 1, 'no GPU visible: the product has no CPU fallback'
+    img = np.kron(_textured(21, 120, 160), np.ones((4, 4), np.uint8))
+    img = (img.astype(np.int32) + np.random.RandomState(4).randint(-8, 9, img.shape)).clip(0, 255).astype(np.uint8)
+    ex = api.Extractor(1200, 1.2, 8, 20, 7)
+    kps, desc = ex(img)
+    sf = ex.tables()['sf']
+    assert len(kps) > 800 and len(set(kps['octave'].tolist())) == 8
+    factor = np.float32(3.1415926535897932384626433832795 / 180.0)
+    arrays = {}
+    for l in range(8):
+        k = kps[kps['octave'] == l]
+        arrays['lv%d' % l] = ex.level(l)
+        arrays['rc%d' % l] = np.stack([np.rint(k['y'] / sf[l]), np.rint(k['x'] / sf[l])], 1).astype(np.int64)
+        arrays['an%d' % l] = (k['angle'].astype(np.float32) * factor).astype(np.float64)
+    d = _run39('''
+        import numpy as np, skimage
+        from scipy import ndimage
+        from skimage.feature import corner_fast, corner_orientations
+        from skimage.feature.orb import OFAST_MASK
+        from skimage.feature.orb_cy import _orb_loop
+        k7 = np.array([18, 34, 48, 56, 48, 34, 18], np.int64)
+        for l in range(8):
+            lv = np.load('lv%d.npy' % l)
+            rc = np.ascontiguousarray(np.load('rc%d.npy' % l).astype(np.intp))
+            f = lv.astype(np.float64)
+            # largest threshold each keypoint still passes at (monotone: bisect per keypoint over full-image runs)
+            score = np.zeros(len(rc), np.int32)
+            for t in range(1, 255):
+                m = corner_fast(f, n=9, threshold=float(t))[rc[:, 0], rc[:, 1]] > 0
+                if not m.any():
+                    break
+                score[m] = t
+            np.save('score%d.npy' % l, score)
+            np.save('ang%d.npy' % l, np.rad2deg(corner_orientations(f, rc, OFAST_MASK)))
+            blur = ((ndimage.correlate(lv.astype(np.int64), np.outer(k7, k7), mode='mirror') + 32768) >> 16).astype(np.float64)
+            bits = np.asarray(_orb_loop(np.ascontiguousarray(blur), rc, np.ascontiguousarray(np.load('an%d.npy' % l))))
+            np.save('bits%d.npy' % l, bits.astype(np.uint8).reshape(len(rc), 256))
+        print('scikit-image', skimage.__version__)
+        ''', tmp_path, **arrays)
+    ndesc = 0
+    for l in range(8):
+        sel = kps['octave'] == l
+        k = kps[sel]
+        score = np.load(d / ('score%d.npy' % l))
+        assert (score >= 7).all(), 'level %d: a keypoint that is no FAST-9 corner at the minimum threshold' % l
+        assert np.array_equal(score.astype(np.float32), k['response']), 'level %d: response is not the largest passing threshold' % l
+        want = np.load(d / ('ang%d.npy' % l)) % 360.0
+        diff = np.abs((k['angle'].astype(np.float64) - want + 180.0) % 360.0 - 180.0)
+        assert diff.max() <= 0.3, (l, diff.max())
+        assert np.array_equal(np.unpackbits(desc[sel], axis=1, bitorder='little'), np.load(d / ('bits%d.npy' % l))), 'level %d' % l
+        ndesc += len(k)
+    print('GPU keypoints checked against scikit-image / scipy:', ndesc)
