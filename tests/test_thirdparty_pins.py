@@ -283,3 +283,24 @@ def test_product_against_third_parties_directly(tmp_path):
         assert np.array_equal(np.unpackbits(desc[sel], axis=1, bitorder='little'), np.load(d / ('bits%d.npy' % l))), 'level %d' % l
         ndesc += len(k)
     print('GPU keypoints checked against scikit-image / scipy:', ndesc)
+
+
+def test_gray_conversion_against_pillow(oracle, tmp_path):
+    """cvtColor(RGB2GRAY / BGR2GRAY) (Tracking.cc:96-109): which channel takes which of the ITU-R 601 weights, against Pillow's
+    convert('L') (16-bit fixed point where OpenCV uses 14 or 15 bits: the values agree within one gray level; a swapped channel
+    order differs by up to 47)."""
+    rgb = np.random.RandomState(3).randint(0, 256, (48, 64, 3)).astype(np.uint8)
+    rgb[:8] = [255, 0, 0]; rgb[8:16] = [0, 255, 0]; rgb[16:24] = [0, 0, 255]
+    d = _run39('''
+        import numpy as np, PIL
+        from PIL import Image
+        np.save('gray.npy', np.asarray(Image.fromarray(np.load('rgb.npy'), 'RGB').convert('L')))
+        print('Pillow', PIL.__version__)
+        ''', tmp_path, rgb=rgb)
+    want = np.load(d / 'gray.npy').astype(np.int32)
+    for variant in (0, 1):
+        got = oracle.cvt_gray(rgb, rgb_order=True, variant=variant).astype(np.int32)
+        assert np.abs(got - want).max() <= 1
+        got = oracle.cvt_gray(np.ascontiguousarray(rgb[..., ::-1]), rgb_order=False, variant=variant).astype(np.int32)
+        assert np.abs(got - want).max() <= 1
+    assert np.abs(oracle.cvt_gray(rgb, rgb_order=False).astype(np.int32) - want).max() > 30   # the check has teeth
