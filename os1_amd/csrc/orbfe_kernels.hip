@@ -735,7 +735,7 @@ struct SlotInfo {
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_describe(PyramidParams P, const SelKp* __restrict__ sel, int nsel,
                                                           float* __restrict__ angleOut, uint8_t* __restrict__ descOut,
-                                                          SlotInfo SI) {
+                                                          SlotInfo SI, int dma) {
   constexpr int NT = 64 * WAVES;
   __shared__ int icSum[3 * WAVES];
   __shared__ __align__(16) uint8_t raw[kRawW * kRawP + 16];   // + 16: the last row's 4-dword reads
@@ -778,7 +778,30 @@ __global__ __launch_bounds__(64 * WAVES) void k_describe(PyramidParams P, const 
   // Border keypoints: byte loads with the level's own reflect-101 indexing (GaussianBlur's border).
   int pa = 0;
   const int istr = (int)stride;
-  if (cx >= kRawRad && cy >= kRawRad && cx + kRawRad < L.w && cy + kRawRad < L.h && (stride & 3) == 0) {
+  const bool interior = cx >= kRawRad && cy >= kRawRad && cx + kRawRad < L.w && cy + kRawRad < L.h && (stride & 3) == 0;
+  // LDS-DMA (round 4, as the pyramid's staging): global_load_lds_dwordx4 moves 16 bytes per lane straight into LDS, lane L's
+  // piece landing at the instruction's LDS base + 16 L -- with 3 pieces per 48-byte patch row one instruction of 63 lanes fills
+  // 21 rows, the 43-row patch is 3 instructions per wave (1 for each of four waves) instead of 11 loads + 11 ds_write per lane,
+  // no staging registers and no per-element address arithmetic.  A row's third piece reaches up to 5 bytes past the last pixel
+  // the patch needs: inside the row's pitch or the next row everywhere except on the LAST row of a caller-owned level-0 frame,
+  // whose keypoints keep the path through registers.
+  if (interior && dma && (level != 0 || cy + kRawRad < L.h - 1)) {
+    const uint8_t* rbase = uniform_ptr(img + m24(cy - kRawRad, istr) + (cx - kRawRad));   // the same for the whole block
+    pa = (int)(reinterpret_cast<uintptr_t>(rbase) & 3);
+    const uint8_t* gb = rbase - pa;
+    constexpr int RPI = WAVES == 1 ? 21 : 11, NI = WAVES == 1 ? 3 : 1;   // rows per instruction, instructions per wave
+    static_assert(RPI * NI * WAVES >= kRawW && 3 * RPI <= 64 && kRawP == 48, "LDS-DMA patch layout");
+    const int lrow = (lane * 171) >> 9, lcol = lane - 3 * lrow;          // lane / 3 for lane < 64
+    const unsigned voff = (unsigned)(m24(lrow, istr) + 16 * lcol);
+#pragma unroll
+    for (int u = 0; u < NI; u++) {
+      const int r = (wave * NI + u) * RPI;
+      if (lrow < RPI && r + lrow < kRawW)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + (long long)r * stride + voff),
+                                         (__attribute__((address_space(3))) void*)(raw + r * kRawP), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else if (interior) {
     const uint8_t* rbase = img + m24(cy - kRawRad, istr) + (cx - kRawRad);
     pa = (int)(reinterpret_cast<uintptr_t>(rbase) & 3);
     const int ndw = (pa + kRawW + 3) >> 2;  // 11 or 12
@@ -1032,12 +1055,17 @@ void launch_compact(const PyramidParams& P, int nframes, hipStream_t st) {
   hipLaunchKernelGGL(k_compact, dim3((P.ncells + 63) / 64, nframes), dim3(64), 0, st, P);
 }
 
+static int describe_dma() {   // ORBFE_DESCRIBE_DMA=0: the raw patch staged through registers (A/B)
+  static const int v = [] { const char* e = getenv("ORBFE_DESCRIBE_DMA"); return e ? atoi(e) : 1; }();
+  return v;
+}
+
 void launch_describe(const PyramidParams& P, const SelKp* sel, int nsel, float* angle, uint8_t* desc,
                      hipStream_t st) {
   if (nsel <= 0) return;
   SlotInfo si{};
   si.selCount = nullptr;
-  hipLaunchKernelGGL(k_describe<1>, dim3(8 * ((nsel + 7) / 8)), dim3(64), 0, st, P, sel, nsel, angle, desc, si);
+  hipLaunchKernelGGL(k_describe<1>, dim3(8 * ((nsel + 7) / 8)), dim3(64), 0, st, P, sel, nsel, angle, desc, si, describe_dma());
 }
 
 // sel/angle/desc point at the first slot of frame P.frameBase; nslots = nframes * selPerFrame
@@ -1049,8 +1077,8 @@ void launch_describe_slots(const PyramidParams& P, const SelKp* sel, int nslots,
   si.selPerFrame = selPerFrame;
   si.nlevels = P.nlevels;
   for (int l = 0; l <= P.nlevels; l++) si.selOff[l] = selOff[l];
-  if (fourWaves) hipLaunchKernelGGL(k_describe<4>, dim3(8 * ((nslots + 7) / 8)), dim3(256), 0, st, P, sel, nslots, angle, desc, si);
-  else hipLaunchKernelGGL(k_describe<1>, dim3(8 * ((nslots + 7) / 8)), dim3(64), 0, st, P, sel, nslots, angle, desc, si);
+  if (fourWaves) hipLaunchKernelGGL(k_describe<4>, dim3(8 * ((nslots + 7) / 8)), dim3(256), 0, st, P, sel, nslots, angle, desc, si, describe_dma());
+  else hipLaunchKernelGGL(k_describe<1>, dim3(8 * ((nslots + 7) / 8)), dim3(64), 0, st, P, sel, nslots, angle, desc, si, describe_dma());
 }
 
 void launch_sincos(const float* deg, int n, float* c, float* s, hipStream_t st) {

@@ -167,6 +167,22 @@ def test_edge_cases(api, oracle):
     _cmp_extract(ex(noise), OracleExtractor(500, 1.2, 8, 20, 7, oracle).extract(noise))
 
 
+def test_maximum_frame_size(api, oracle):
+    """The largest frame the coordinate packing admits (4095 x 4095) is extracted bit-exactly -- keypoints up to
+    x, y = 4075 on level 0, 18 000 FAST cells on it -- and one pixel more in either direction is refused, not truncated."""
+    W = H = 4095
+    img = synth(17, W, H)
+    ex = api.Extractor(6000, 1.2, 8, 20, 7)
+    k, d = ex(img)
+    _cmp_extract((k, d), OracleExtractor(6000, 1.2, 8, 20, 7, oracle).extract(img))
+    assert len(k) >= 5900 and k['x'].max() > 4000 and k['y'].max() > 4000
+    for shape in ((100, 4096), (4096, 100)):
+        with pytest.raises(api.OrbfeError) as e:
+            ex(np.zeros(shape, np.uint8))
+        assert e.value.code == -1 and '4095' in str(e.value)
+    _cmp_extract(ex(img[:600, :800].copy()), OracleExtractor(6000, 1.2, 8, 20, 7, oracle).extract(img[:600, :800].copy()))
+
+
 def test_device_sincos_matches_host_libm(api, oracle):
     ex = api.Extractor(100, 1.2, 8, 20, 7)
     rng = np.random.default_rng(0)
