@@ -596,9 +596,17 @@ __global__ __launch_bounds__(64) void k_compact(PyramidParams P) {
 // Fixed-point blur: horizontal sum(k*p) in 16 bits, vertical (sum(k*h) + 32768) >> 16, k =
 // [18,34,48,56,48,34,18].
 // ------------------------------------------------------------------------------------------------
-__constant__ int8_t c_pattern[1024] = {
+constexpr int8_t kPattern[1024] = {
 #include "brief_pattern.inc"
 };
+// the 256 test pairs as floats (x1, y1, x2, y2): the rotation of computeOrbDescriptor is float arithmetic
+struct PatternF { float v[1024]; };
+constexpr PatternF make_pattern_f() {
+  PatternF t{};
+  for (int i = 0; i < 1024; i++) t.v[i] = (float)kPattern[i];
+  return t;
+}
+__constant__ PatternF c_patternF = make_pattern_f();
 
 __device__ __forceinline__ float fast_atan2_deg(float y, float x) {  // cv::fastAtan2, SURVEY.md B.4
   const float scale = (float)(180 / 3.1415926535897932384626433832795);
@@ -642,7 +650,7 @@ constexpr int kBPT = 40;     // pitch (bytes) of the TRANSPOSED blurred patch bl
 constexpr int kIcCount = 749;
 constexpr int kIcItems = 31 * 8;
 struct IcW { uint32_t w1, w2, w3, pad; };
-struct IcTab { IcW e[kIcItems]; };
+struct IcTab { IcW e[256]; };   // 248 items + 8 of weight zero (row 31 of the walk: inside the 43-row raw patch)
 constexpr IcTab make_ic_tab() {
   IcTab t{};
   const int um[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
@@ -708,7 +716,16 @@ constexpr BlurItems make_blur_items() {
 }
 constexpr BlurItems kBlurItemsHost = make_blur_items();
 static_assert(kBlurItemsHost.nh == 368 && kBlurItemsHost.nv == 308, "blur item lists: 6 and 5 wave iterations");
-__constant__ BlurItems c_blurItems = make_blur_items();
+// one dword per item index: low half = horizontal-pass item, high half = vertical-pass item (both padded with their first item)
+struct BlurCodes { uint32_t c[512]; };
+constexpr BlurCodes make_blur_codes() {
+  BlurCodes t{};
+  const BlurItems b = make_blur_items();
+  for (int i = 0; i < 512; i++) t.c[i] = (uint32_t)b.h[i < 448 ? i : 0] | ((uint32_t)b.v[i < 320 ? i : 0] << 16);
+  return t;
+}
+__constant__ BlurCodes c_blurCodes = make_blur_codes();
+
 
 // sum over the wave (wave-uniform result): DPP row rotations, then one value per row of 16 lanes
 __device__ __forceinline__ int wave_sum_i32(int v) {
@@ -737,6 +754,22 @@ __global__ __launch_bounds__(64 * WAVES) void k_describe(PyramidParams P, const 
                                                           float* __restrict__ angleOut, uint8_t* __restrict__ descOut,
                                                           SlotInfo SI, int dma) {
   constexpr int NT = 64 * WAVES;
+  // Every table a lane will need depends on its lane number only: ALL of them are requested here, before the first wait of
+  // the kernel, instead of one dependent round trip per pass iteration (4 + 6 + 5 of them for one wave) -- round 4.
+  constexpr int NIC = (kIcItems + NT - 1) / NT, NH = (kBlurItemsHost.nh + NT - 1) / NT, NV = (kBlurItemsHost.nv + NT - 1) / NT;
+  static_assert(NIC * NT <= 256 && NH * NT <= 512 && NV <= NH, "table padding");
+  uint32_t icw[NIC][3], bcode[NH];
+#pragma unroll
+  for (int it = 0; it < NIC; it++) {
+    const IcW w = c_icTab.e[it * NT + threadIdx.x];
+    icw[it][0] = w.w1; icw[it][1] = w.w2; icw[it][2] = w.w3;
+  }
+#pragma unroll
+  for (int it = 0; it < NH; it++) bcode[it] = c_blurCodes.c[it * NT + threadIdx.x];
+#pragma unroll
+  for (int it = 0; it < NIC; it++) asm volatile("" : "+v"(icw[it][0]), "+v"(icw[it][1]), "+v"(icw[it][2]));   // issued HERE, not sunk to their uses
+#pragma unroll
+  for (int it = 0; it < NH; it++) asm volatile("" : "+v"(bcode[it]));
   __shared__ int icSum[3 * WAVES];
   __shared__ __align__(16) uint8_t raw[kRawW * kRawP + 16];   // + 16: the last row's 4-dword reads
   __shared__ __align__(16) uint16_t hbT[40 * kHPT];            // horizontal pass, transposed: hbT[x][y]
@@ -759,7 +792,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_describe(PyramidParams P, const 
     const int frameAbs = P.frameBase + fr;
     if ((uint32_t)(within - SI.selOff[l]) >= SI.selCount[(long long)frameAbs * kMaxLevels + l]) return;
   }
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = WAVES == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
   const SelKp s = sel[k];
   const int cx = s.xy & 0xffff, cy = s.xy >> 16;
   const int level = s.lf & 0xff, f = (s.lf >> 8) & 0xffff;
@@ -797,7 +830,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_describe(PyramidParams P, const 
     for (int u = 0; u < NI; u++) {
       const int r = (wave * NI + u) * RPI;
       if (lrow < RPI && r + lrow < kRawW)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + (long long)r * stride + voff),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + (voff + (unsigned)m24(r, istr))),   // scalar base + 32-bit lane offset
                                          (__attribute__((address_space(3))) void*)(raw + r * kRawP), 16, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -849,17 +882,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_describe(PyramidParams P, const 
   const int sIc = (pa + 6) & 3, qIc = (pa + 6) & ~3;   // patch column u = -15 is raw byte pa + 6 of a row
   int S1 = 0, S2 = 0, S3 = 0;
 #pragma unroll
-  for (int it = 0; it < (kIcItems + NT - 1) / NT; it++) {
+  for (int it = 0; it < NIC; it++) {   // (items 248 .. 255 have weight zero)
     const int i = it * NT + tid;
-    if (i < kIcItems) {
-      const int r = i >> 3, kk = i & 7;
-      const uint32_t* rp = reinterpret_cast<const uint32_t*>(raw + m24(r + (kRawRad - 15), kRawP) + qIc + 4 * kk);
-      const uint32_t e = __builtin_amdgcn_alignbyte(rp[1], rp[0], sIc);
-      const IcW w = c_icTab.e[i];
-      S1 = (int)__builtin_amdgcn_udot4(e, w.w1, (unsigned)S1, false);
-      S2 = (int)__builtin_amdgcn_udot4(e, w.w2, (unsigned)S2, false);
-      S3 = (int)__builtin_amdgcn_udot4(e, w.w3, (unsigned)S3, false);
-    }
+    const int r = i >> 3, kk = i & 7;
+    const uint32_t* rp = reinterpret_cast<const uint32_t*>(raw + m24(r + (kRawRad - 15), kRawP) + qIc + 4 * kk);
+    const uint32_t e = __builtin_amdgcn_alignbyte(rp[1], rp[0], sIc);
+    S1 = (int)__builtin_amdgcn_udot4(e, icw[it][0], (unsigned)S1, false);
+    S2 = (int)__builtin_amdgcn_udot4(e, icw[it][1], (unsigned)S2, false);
+    S3 = (int)__builtin_amdgcn_udot4(e, icw[it][2], (unsigned)S3, false);
   }
   S1 = wave_sum_i32(S1);
   S2 = wave_sum_i32(S2);
@@ -880,8 +910,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_describe(PyramidParams P, const 
   // taps in one dword and runs on v_dot2_u32_u16 (4 outputs per lane, one dword store into the transposed patch).
   {
     const unsigned K0 = 0x38302212u, K1 = 0x00122230u;   // taps 0..3 and 4..6 as bytes
-    for (int i = tid; i < kBlurItemsHost.nh; i += NT) {
-      const unsigned code = c_blurItems.h[i];
+#pragma unroll
+    for (int it = 0; it < NH; it++) {
+      if ((it + 1) * NT > kBlurItemsHost.nh && it * NT + tid >= kBlurItemsHost.nh) break;   // only the last iteration is partial
+      const unsigned code = bcode[it] & 0xffffu;
       const int y = (int)(code >> 4), g = (int)(code & 15u);
       const uint32_t* rp = reinterpret_cast<const uint32_t*>(raw + m24(y, kRawP) + 4 * g);
       const uint32_t d0 = rp[0], d1 = rp[1], d2 = rp[2], d3 = rp[3];
@@ -901,8 +933,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_describe(PyramidParams P, const 
     // (lo, hi) tap pairs for an output whose first tap is the LOW half of p0 (even) or the HIGH half (odd)
     const u16x2 E0 = {18, 34}, E1 = {48, 56}, E2 = {48, 34}, E3 = {18, 0};
     const u16x2 O0 = {0, 18}, O1 = {34, 48}, O2 = {56, 48}, O3 = {34, 18};
-    for (int i = tid; i < kBlurItemsHost.nv; i += NT) {
-      const unsigned code = c_blurItems.v[i];
+#pragma unroll
+    for (int it = 0; it < NV; it++) {
+      if ((it + 1) * NT > kBlurItemsHost.nv && it * NT + tid >= kBlurItemsHost.nv) break;
+      const unsigned code = bcode[it] >> 16;
       const int x = (int)(code >> 4), yq = (int)(code & 15u);
       const uint32_t* cp = reinterpret_cast<const uint32_t*>(hbT + m24(x, kHPT) + 4 * yq);
       u16x2 p[5];
@@ -935,8 +969,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_describe(PyramidParams P, const 
   for (int j = 0; j < 4; j++) {
     if (WAVES == 4 && j != wave) continue;   // four waves: wave j tests bits 64 j .. 64 j + 63
     const int bit = j * 64 + lane;
-    const int8_t* p = &c_pattern[4 * bit];
-    const float x1 = (float)p[0], y1 = (float)p[1], x2 = (float)p[2], y2 = (float)p[3];
+    const float4 p = *reinterpret_cast<const float4*>(&c_patternF.v[4 * bit]);
+    const float x1 = p.x, y1 = p.y, x2 = p.z, y2 = p.w;
     const int t0 = center[__float2int_rn(x1 * a - y1 * b) * kBPT + __float2int_rn(x1 * b + y1 * a)];
     const int t1 = center[__float2int_rn(x2 * a - y2 * b) * kBPT + __float2int_rn(x2 * b + y2 * a)];
     words[j] = __ballot(t0 < t1);
