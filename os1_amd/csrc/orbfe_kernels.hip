@@ -716,12 +716,20 @@ constexpr BlurItems make_blur_items() {
 }
 constexpr BlurItems kBlurItemsHost = make_blur_items();
 static_assert(kBlurItemsHost.nh == 368 && kBlurItemsHost.nv == 308, "blur item lists: 6 and 5 wave iterations");
-// one dword per item index: low half = horizontal-pass item, high half = vertical-pass item (both padded with their first item)
-struct BlurCodes { uint32_t c[512]; };
+// The item lists as the kernel wants them: LDS byte offsets instead of coordinates, so that a lane decodes an item with one
+// AND and one shift.  h[i]: low half = first raw byte the item reads (row y, dword 4g of the raw patch), high half = byte offset of
+// its first output in the transposed u16 image; v[i]: low half = first byte of column x at row 4yq of that image, high half =
+// byte offset of its output dword in the transposed blurred patch.  Both padded with their first item.
+struct BlurCodes { uint32_t h[512], v[512]; };
 constexpr BlurCodes make_blur_codes() {
   BlurCodes t{};
   const BlurItems b = make_blur_items();
-  for (int i = 0; i < 512; i++) t.c[i] = (uint32_t)b.h[i < 448 ? i : 0] | ((uint32_t)b.v[i < 320 ? i : 0] << 16);
+  for (int i = 0; i < 512; i++) {
+    const int hc = b.h[i < b.nh ? i : 0], y = hc >> 4, g = hc & 15;
+    t.h[i] = (uint32_t)(y * kRawP + 4 * g) | ((uint32_t)((4 * g * kHPT + y) * 2) << 16);
+    const int vc = b.v[i < b.nv ? i : 0], x = vc >> 4, yq = vc & 15;
+    t.v[i] = (uint32_t)((x * kHPT + 4 * yq) * 2) | ((uint32_t)(x * kBPT + 4 * yq) << 16);
+  }
   return t;
 }
 __constant__ BlurCodes c_blurCodes = make_blur_codes();
@@ -735,6 +743,21 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
   v += __builtin_amdgcn_update_dpp(v, v, 0x121, 0xf, 0xf, false);   // row_ror:1
   return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
          __builtin_amdgcn_readlane(v, 48);
+}
+
+// three sums at once: the row rotations as v_add_u32_dpp proper (the compiler's form of the function above is move + DPP move +
+// add per step), the three chains interleaved so that each DPP read is two instructions behind the write it depends on (the wait
+// states the hardware asks for between a vector write and a DPP read of the same register)
+__device__ __forceinline__ void wave_sum3_i32(int& a, int& b, int& c) {
+#define ORBFE_ROR3(n)                                                          \
+  "v_add_u32_dpp %0, %0, %0 row_ror:" #n " row_mask:0xf bank_mask:0xf\n\t"     \
+  "v_add_u32_dpp %1, %1, %1 row_ror:" #n " row_mask:0xf bank_mask:0xf\n\t"     \
+  "v_add_u32_dpp %2, %2, %2 row_ror:" #n " row_mask:0xf bank_mask:0xf\n\t"
+  asm volatile("s_nop 1\n\t" ORBFE_ROR3(8) ORBFE_ROR3(4) ORBFE_ROR3(2) ORBFE_ROR3(1) : "+v"(a), "+v"(b), "+v"(c));
+#undef ORBFE_ROR3
+  a = __builtin_amdgcn_readlane(a, 0) + __builtin_amdgcn_readlane(a, 16) + __builtin_amdgcn_readlane(a, 32) + __builtin_amdgcn_readlane(a, 48);
+  b = __builtin_amdgcn_readlane(b, 0) + __builtin_amdgcn_readlane(b, 16) + __builtin_amdgcn_readlane(b, 32) + __builtin_amdgcn_readlane(b, 48);
+  c = __builtin_amdgcn_readlane(c, 0) + __builtin_amdgcn_readlane(c, 16) + __builtin_amdgcn_readlane(c, 32) + __builtin_amdgcn_readlane(c, 48);
 }
 
 // Slot mode (GPU quadtree): `sel` is laid out [frame][selPerFrame] with per-level sub-regions; slot k is
@@ -758,18 +781,16 @@ __global__ __launch_bounds__(64 * WAVES) void k_describe(PyramidParams P, const 
   // the kernel, instead of one dependent round trip per pass iteration (4 + 6 + 5 of them for one wave) -- round 4.
   constexpr int NIC = (kIcItems + NT - 1) / NT, NH = (kBlurItemsHost.nh + NT - 1) / NT, NV = (kBlurItemsHost.nv + NT - 1) / NT;
   static_assert(NIC * NT <= 256 && NH * NT <= 512 && NV <= NH, "table padding");
-  uint32_t icw[NIC][3], bcode[NH];
+  uint32_t icw[NIC][3], bh[NH], bv[NV];
 #pragma unroll
   for (int it = 0; it < NIC; it++) {
     const IcW w = c_icTab.e[it * NT + threadIdx.x];
     icw[it][0] = w.w1; icw[it][1] = w.w2; icw[it][2] = w.w3;
   }
 #pragma unroll
-  for (int it = 0; it < NH; it++) bcode[it] = c_blurCodes.c[it * NT + threadIdx.x];
+  for (int it = 0; it < NH; it++) bh[it] = c_blurCodes.h[it * NT + threadIdx.x];
 #pragma unroll
-  for (int it = 0; it < NIC; it++) asm volatile("" : "+v"(icw[it][0]), "+v"(icw[it][1]), "+v"(icw[it][2]));   // issued HERE, not sunk to their uses
-#pragma unroll
-  for (int it = 0; it < NH; it++) asm volatile("" : "+v"(bcode[it]));
+  for (int it = 0; it < NV; it++) bv[it] = c_blurCodes.v[it * NT + threadIdx.x];
   __shared__ int icSum[3 * WAVES];
   __shared__ __align__(16) uint8_t raw[kRawW * kRawP + 16];   // + 16: the last row's 4-dword reads
   __shared__ __align__(16) uint16_t hbT[40 * kHPT];            // horizontal pass, transposed: hbT[x][y]
@@ -785,17 +806,36 @@ __global__ __launch_bounds__(64 * WAVES) void k_describe(PyramidParams P, const 
   const int chunk = (nsel + 7) >> 3;
   const int k = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
   if (k >= nsel) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = WAVES == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
+  // A wave's life begins with memory round trips nothing can overlap: keep that chain SHORT (as k_fast_tasks does).  In slot mode
+  // the slot index alone gives frame and level, so the liveness count, the keypoint record, the level's geometry and the level-0
+  // pointer are four INDEPENDENT scalar loads -- one round trip, then the patch goes out.  (Before round 4: the level by a
+  // loop of dependent argument loads, the count, then the record, then the level table indexed by the record's level, then the
+  // frame pointer by a vector load: ten dependent round trips.)
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  int level, f;
+  u32x2 sw;
   if (SI.selCount) {
     const int fr = k / SI.selPerFrame, within = k - fr * SI.selPerFrame;
-    int l = 0;
-    while (l + 1 < SI.nlevels && within >= SI.selOff[l + 1]) l++;
-    const int frameAbs = P.frameBase + fr;
-    if ((uint32_t)(within - SI.selOff[l]) >= SI.selCount[(long long)frameAbs * kMaxLevels + l]) return;
+    int l = 0, lbase = 0;
+#pragma unroll
+    for (int j = 1; j < kMaxLevels; j++) {   // selOff ascends: the last level region that starts at or before `within`
+      const int o = SI.selOff[j];
+      if (j < SI.nlevels && within >= o) { l = j; lbase = o; }
+    }
+    level = l;
+    f = P.frameBase + fr;
+    const uint32_t live = *reinterpret_cast<const uint32_t __attribute__((address_space(4)))*>(
+        reinterpret_cast<uintptr_t>(SI.selCount + (long long)f * kMaxLevels + l));
+    sw = *reinterpret_cast<const u32x2 __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(sel + k));
+    asm volatile("" ::"s"(sw.x), "s"(live));   // both requested before the test below
+    if ((uint32_t)(within - lbase) >= live) return;
+  } else {
+    sw = *reinterpret_cast<const u32x2 __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(sel + k));
+    level = (int)(sw.y & 0xffu);
+    f = (int)((sw.y >> 8) & 0xffffu);
   }
-  const int tid = threadIdx.x, lane = tid & 63, wave = WAVES == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
-  const SelKp s = sel[k];
-  const int cx = s.xy & 0xffff, cy = s.xy >> 16;
-  const int level = s.lf & 0xff, f = (s.lf >> 8) & 0xffff;
+  const int cx = (int)(sw.x & 0xffffu), cy = (int)(sw.x >> 16);
   const LevelGeom& L = P.lv[level];
   const uint8_t* img;
   long long stride;
@@ -891,9 +931,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_describe(PyramidParams P, const 
     S2 = (int)__builtin_amdgcn_udot4(e, icw[it][1], (unsigned)S2, false);
     S3 = (int)__builtin_amdgcn_udot4(e, icw[it][2], (unsigned)S3, false);
   }
-  S1 = wave_sum_i32(S1);
-  S2 = wave_sum_i32(S2);
-  S3 = wave_sum_i32(S3);
+  wave_sum3_i32(S1, S2, S3);
   if (WAVES > 1) {   // the waves' partial sums meet in LDS
     if (lane == 0) { icSum[3 * wave] = S1; icSum[3 * wave + 1] = S2; icSum[3 * wave + 2] = S3; }
     __syncthreads();
@@ -913,13 +951,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_describe(PyramidParams P, const 
 #pragma unroll
     for (int it = 0; it < NH; it++) {
       if ((it + 1) * NT > kBlurItemsHost.nh && it * NT + tid >= kBlurItemsHost.nh) break;   // only the last iteration is partial
-      const unsigned code = bcode[it] & 0xffffu;
-      const int y = (int)(code >> 4), g = (int)(code & 15u);
-      const uint32_t* rp = reinterpret_cast<const uint32_t*>(raw + m24(y, kRawP) + 4 * g);
+      const uint32_t* rp = reinterpret_cast<const uint32_t*>(raw + (bh[it] & 0xffffu));
       const uint32_t d0 = rp[0], d1 = rp[1], d2 = rp[2], d3 = rp[3];
       const uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, pa), a1 = __builtin_amdgcn_alignbyte(d2, d1, pa),
                      a2 = __builtin_amdgcn_alignbyte(d3, d2, pa);   // raw pixels 4g .. 4g+11 of row y
-      uint16_t* o = hbT + m24(4 * g, kHPT) + y;
+      uint16_t* o = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(hbT) + (bh[it] >> 16));
       o[0] = (uint16_t)__builtin_amdgcn_udot4(a1, K1, __builtin_amdgcn_udot4(a0, K0, 0u, false), false);
 #pragma unroll
       for (int j = 1; j < 4; j++) {
@@ -936,13 +972,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_describe(PyramidParams P, const 
 #pragma unroll
     for (int it = 0; it < NV; it++) {
       if ((it + 1) * NT > kBlurItemsHost.nv && it * NT + tid >= kBlurItemsHost.nv) break;
-      const unsigned code = bcode[it] >> 16;
-      const int x = (int)(code >> 4), yq = (int)(code & 15u);
-      const uint32_t* cp = reinterpret_cast<const uint32_t*>(hbT + m24(x, kHPT) + 4 * yq);
+      const uint32_t* cp = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(hbT) + (bv[it] & 0xffffu));
       u16x2 p[5];
 #pragma unroll
       for (int t = 0; t < 5; t++) p[t] = as_u16x2(cp[t]);   // rows 4yq .. 4yq+9 of column x
-      uint32_t packed = 0;
+      unsigned r4[4];   // (sum + 32768): the blurred pixel is byte 2 of each (sum <= 255 * 65536)
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         unsigned e = 32768u, o = 32768u;
@@ -950,9 +984,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_describe(PyramidParams P, const 
         e = __builtin_amdgcn_udot2(p[h + 1], E1, e, false); o = __builtin_amdgcn_udot2(p[h + 1], O1, o, false);
         e = __builtin_amdgcn_udot2(p[h + 2], E2, e, false); o = __builtin_amdgcn_udot2(p[h + 2], O2, o, false);
         e = __builtin_amdgcn_udot2(p[h + 3], E3, e, false); o = __builtin_amdgcn_udot2(p[h + 3], O3, o, false);
-        packed |= ((e >> 16) | ((o >> 16) << 8)) << (16 * h);
+        r4[2 * h] = e;
+        r4[2 * h + 1] = o;
       }
-      *reinterpret_cast<uint32_t*>(blT + m24(x, kBPT) + 4 * yq) = packed;   // rows 37..39 are padding
+      // bytes 2 of the four sums -> one dword, by two byte permutes (v_perm_b32: selector 0..3 = second operand, 4..7 = first)
+      const unsigned packed = __builtin_amdgcn_perm(r4[1], r4[0], 0x0c0c0602u) | __builtin_amdgcn_perm(r4[3], r4[2], 0x06020c0cu);
+      *reinterpret_cast<uint32_t*>(blT + (bv[it] >> 16)) = packed;   // rows 37..39 are padding
     }
   }
   __syncthreads();
@@ -964,15 +1001,26 @@ __global__ __launch_bounds__(64 * WAVES) void k_describe(PyramidParams P, const 
   const float rad = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, angle * factorPI)));
   sincosf_glibc(rad, &b, &a);  // a = cos, b = sin
   const uint8_t* center = blT + kBlurRad * kBPT + kBlurRad;   // center[x * kBPT + y]
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  const f32x2 AB = {a, b}, NBA = {-b, a}, kRoundMagic = {12582912.0f, 12582912.0f};
   unsigned long long words[4] = {0ull, 0ull, 0ull, 0ull};
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     if (WAVES == 4 && j != wave) continue;   // four waves: wave j tests bits 64 j .. 64 j + 63
     const int bit = j * 64 + lane;
     const float4 p = *reinterpret_cast<const float4*>(&c_patternF.v[4 * bit]);
-    const float x1 = p.x, y1 = p.y, x2 = p.z, y2 = p.w;
-    const int t0 = center[__float2int_rn(x1 * a - y1 * b) * kBPT + __float2int_rn(x1 * b + y1 * a)];
-    const int t1 = center[__float2int_rn(x2 * a - y2 * b) * kBPT + __float2int_rn(x2 * b + y2 * a)];
+    // (column, row) = (x a - y b, x b + y a) (ORBextractor.cc:147-151), both coordinates per packed-float instruction: the products
+    // and the sum are the reference's own operations (x a + (-(y b)) is x a - y b exactly), unfused.  cvRound by the float adder:
+    // t + 1.5 * 2^23 is rounded to an integer, ties to even, and that integer sits in the low mantissa bits (|t| <= 19).
+    const f32x2 c1 = (f32x2){p.x, p.x} * AB + (f32x2){p.y, p.y} * NBA + kRoundMagic;
+    const f32x2 c2 = (f32x2){p.z, p.z} * AB + (f32x2){p.w, p.w} * NBA + kRoundMagic;
+    // low 24 bits of a rounded float = 0x400000 + n: (0x400000 + col) * kBPT + (0x4B400000 + row) - K = col * kBPT + row
+    constexpr unsigned K = 0x400000u * (unsigned)kBPT + 0x4B400000u;
+    // (elements copied to plain floats first: this compiler's __builtin_bit_cast of a vector ELEMENT reads element 0 whatever the index)
+    const float c1x = c1.x, c1y = c1.y, c2x = c2.x, c2y = c2.y;
+    const int i1 = (int)(__umul24(__float_as_uint(c1x), (unsigned)kBPT) + __float_as_uint(c1y) - K);
+    const int i2 = (int)(__umul24(__float_as_uint(c2x), (unsigned)kBPT) + __float_as_uint(c2y) - K);
+    const int t0 = center[i1], t1 = center[i2];
     words[j] = __ballot(t0 < t1);
   }
   if (WAVES == 4) {
