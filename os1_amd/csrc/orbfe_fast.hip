@@ -44,6 +44,18 @@ __device__ __forceinline__ unsigned as_u32(u16x2 v) { return __builtin_bit_cast(
 __device__ __forceinline__ s16x2 as_s16x2(unsigned v) { return __builtin_bit_cast(s16x2, v); }
 }  // namespace
 
+// integer min / max of three packed 16-bit values whose bit patterns are normal positive half floats (see stage 2)
+__device__ __forceinline__ unsigned pk_min3_h(unsigned a, unsigned b, unsigned c) {
+  unsigned r;
+  asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ unsigned pk_max3_h(unsigned a, unsigned b, unsigned c) {
+  unsigned r;
+  asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 // LDS traffic of one wave needs no s_barrier (a block is one wave; LDS operations of a wave execute in order): a
 // compiler-level memory fence plus the LDS counter is enough.
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -328,34 +340,31 @@ __global__ __launch_bounds__(64) void k_fast_tasks(PyramidParams P, int tpPad, i
         const int y = e >> 8, x = e & 0xff;
         const uint8_t* c = tile + m24(y + 3, TP) + (x + 3);
         const unsigned vv = c[0];
-        s16x2 d[16];
-        // d[k] = (v - r_k, r_k - v) in the two 16-bit lanes by ONE packed multiply-add per ring pixel:
-        // r_k (low half, used by both lanes) * (-1, +1) + (v, -v)
-        const unsigned VV = vv | ((0u - vv) << 16);
-#define RING(k, off) { unsigned dd; asm("v_pk_mad_i16 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(dd) : "v"((unsigned)c[off]), "v"(0x0001ffffu), "v"(VV)); \
-          d[k] = as_s16x2(dd); }
+        // xr[k] = (B + v - r_k, B + r_k - v) in the two 16-bit lanes by ONE packed multiply-add per ring pixel:
+        // r_k (low half, used by both lanes) * (-1, +1) + (B + v, B - v).  The bias B = 2048 makes every value the bit pattern of
+        // a NORMAL, positive half float (0x0701 .. 0x08ff), and positive floats order like their bit patterns: the minima and
+        // maxima below are integer minima and maxima taken by gfx950's THREE-input packed half-float instructions
+        // (v_pk_minimum3_f16 / v_pk_maximum3_f16; there is no packed integer min3).
+        constexpr unsigned B = 2048u;
+        unsigned xr[16];
+        const unsigned VV = (B + vv) | ((B - vv) << 16);
+#define RING(k, off) asm("v_pk_mad_i16 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(xr[k]) : "v"((unsigned)c[off]), "v"(0x0001ffffu), "v"(VV));
         RING(0, 3 * TP);       RING(1, 3 * TP + 1);   RING(2, 2 * TP + 2);    RING(3, TP + 3);
         RING(4, 3);            RING(5, -TP + 3);      RING(6, -2 * TP + 2);   RING(7, -3 * TP + 1);
         RING(8, -3 * TP);      RING(9, -3 * TP - 1);  RING(10, -2 * TP - 2);  RING(11, -TP - 3);
         RING(12, -3);          RING(13, TP - 3);      RING(14, 2 * TP - 2);   RING(15, 3 * TP - 1);
 #undef RING
-        // min over every arc of 9 consecutive ring pixels: the ring is cut into two blocks of 8; an arc starting at k
-        // is a suffix of its block plus a prefix of the next one (van Herk / Gil-Werman): 28 + 16 packed minima
-        s16x2 sA[8], pA[8], sB[8], pB[8];
-        sA[7] = d[7]; sB[7] = d[15]; pA[0] = d[0]; pB[0] = d[8];
+        // min over every arc of 9 consecutive ring pixels, both polarities per instruction: t[k] = min of pixels k .. k+2,
+        // arc[k] = min(t[k], t[k+3], t[k+6]) (indices mod 16): 16 + 16 three-input minima, then 8 three-input maxima
+        unsigned t[16], arc[16];
 #pragma unroll
-        for (int k = 6; k >= 0; k--) { sA[k] = __builtin_elementwise_min(d[k], sA[k + 1]); sB[k] = __builtin_elementwise_min(d[8 + k], sB[k + 1]); }
+        for (int k = 0; k < 16; k++) t[k] = pk_min3_h(xr[k], xr[(k + 1) & 15], xr[(k + 2) & 15]);
 #pragma unroll
-        for (int k = 1; k < 8; k++) { pA[k] = __builtin_elementwise_min(pA[k - 1], d[k]); pB[k] = __builtin_elementwise_min(pB[k - 1], d[8 + k]); }
-        s16x2 w[16];
-#pragma unroll
-        for (int k = 0; k < 8; k++) { w[k] = __builtin_elementwise_min(sA[k], pB[k]); w[8 + k] = __builtin_elementwise_min(sB[k], pA[k]); }
-#pragma unroll
-        for (int k = 0; k < 8; k++) w[k] = __builtin_elementwise_max(w[k], w[k + 8]);
-#pragma unroll
-        for (int k = 0; k < 4; k++) w[k] = __builtin_elementwise_max(w[k], w[k + 4]);
-        const s16x2 best = __builtin_elementwise_max(__builtin_elementwise_max(w[0], w[2]), __builtin_elementwise_max(w[1], w[3]));
-        const int S = max((int)best.x, (int)best.y);
+        for (int k = 0; k < 16; k++) arc[k] = pk_min3_h(t[k], t[(k + 3) & 15], t[(k + 6) & 15]);
+        const unsigned m0 = pk_max3_h(arc[0], arc[1], arc[2]), m1 = pk_max3_h(arc[3], arc[4], arc[5]), m2 = pk_max3_h(arc[6], arc[7], arc[8]);
+        const unsigned m3 = pk_max3_h(arc[9], arc[10], arc[11]), m4 = pk_max3_h(arc[12], arc[13], arc[14]);
+        const unsigned best = pk_max3_h(pk_max3_h(m0, m1, m2), pk_max3_h(m3, m4, arc[15]), arc[15]);
+        const int S = (int)max(best & 0xffffu, best >> 16) - (int)B;
         ok = S > tlo;
         if (ok) sc[m24(y + 1, SP) + (x + 1)] = (uint8_t)(S - 1);  // tlo <= S-1 <= 254
       }
