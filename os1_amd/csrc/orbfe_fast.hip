@@ -134,15 +134,25 @@ __global__ __launch_bounds__(64) void k_fast_tasks(PyramidParams P, int tpPad, i
     // dword column) over the tile pitch; lane L's dword lands at the instruction's LDS base + 4 L, so the lanes of a row group
     // are contiguous in LDS exactly as the tile wants them), the global base and the LDS base advance on the scalar unit.
     const int ndw = (a + rw + 3) >> 2, ndwT = TP >> 2;
-    const int rpi = 64 / ndwT;                                  // tile rows per instruction (5 or 6 for a single cell)
-    const int lrow = (int)(((float)lane + 0.5f) * (1.0f / (float)ndwT)), lcol = lane - m24(lrow, ndwT);
+    // lane / ndwT by the hardware reciprocal (1 ulp; the quotient sits at least 0.5 / ndwT away from an integer): an exact
+    // division costs eleven vector instructions
+    const float rn = __builtin_amdgcn_rcpf((float)ndwT);
+    const int rpi = 64 / ndwT;                                  // tile rows per instruction (5 or 6 for a single cell); scalar
+    const int lrow = (int)(((float)lane + 0.5f) * rn), lcol = lane - m24(lrow, ndwT);
     const bool on = lrow < rpi && lcol < ndw;
     const unsigned voff = (unsigned)(m24(lrow, istr) + 4 * lcol);
-    const uint8_t* gb = roi - a;                               // wave-uniform
-    for (int r = 0; r < rh; r += rpi) {
-      if (on && lrow < rh - r)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + (long long)r * stride + voff),
-                                         (__attribute__((address_space(3))) void*)(tile + m24(r, TP)), 4, 0, 0);
+    const uint8_t* gp = roi - a;                               // wave-uniform: scalar base + the lane's constant 32-bit offset
+    const long long gstep = (long long)rpi * stride;
+    const int lstep = m24(rpi, TP);
+    uint8_t* lp = tile;
+    for (int left = rh; left > 0; left -= rpi, gp += gstep, lp += lstep) {
+      // keep the row base in scalar registers and the lane offset 32 bits wide: scalar base + vector offset is an addressing
+      // mode; left to itself the compiler builds a 64-bit per-lane address and advances it with a vector add per iteration
+      unsigned vo = voff;
+      asm volatile("" : "+s"(gp), "+v"(vo));
+      if (on && lrow < left)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + vo),
+                                         (__attribute__((address_space(3))) void*)lp, 4, 0, 0);
     }
   } else if ((stride & 3) == 0) {
     // lane (c, r0) copies dword column c of rows r0, r0 + rstep, ...: 16 columns x 4 rows per sweep for a single cell,
@@ -255,7 +265,7 @@ __global__ __launch_bounds__(64) void k_fast_tasks(PyramidParams P, int tpPad, i
         fo = flag[0];
         fe = flag[1];
       };
-      int y = (int)(((float)lane + 0.5f) / (float)G), g = lane - m24(y, G);
+      int y = (int)(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)G)), g = lane - m24(y, G);   // lane / G (see the ROI load)
       int ro = m24(y, TP) + (g << GS);               // byte offset of (row y, column NPX*g) in the tile
       const int roStep = m24(stepY, TP) + (stepG << GS), roCarry = TP - (G << GS);
       const uint8_t* t0 = tile - A;
@@ -393,9 +403,9 @@ __global__ __launch_bounds__(64) void k_fast_tasks(PyramidParams P, int tpPad, i
         const int sv = q[0];
         // neighbours on the other side of the boundary between the two cells count 0 (each cell is its own cv::FAST ROI)
         const int lm = (ew1 && x == ew0) ? 0 : 0xff, rm = (ew1 && x == ew0 - 1) ? 0 : 0xff;
-        if (sv > 0 && sv > (q[-1] & lm) && sv > (q[1] & rm) && sv > (q[-SP - 1] & lm) && sv > q[-SP] && sv > (q[-SP + 1] & rm) &&
-            sv > (q[SP - 1] & lm) && sv > q[SP] && sv > (q[SP + 1] & rm))
-          keep = sv;
+        // strictly greater than all eight neighbours = greater than their maximum (three-input maxima: 4 instructions for 8 values)
+        const int nmax = max(max(max(q[-1] & lm, q[-SP - 1] & lm), q[SP - 1] & lm), max(max(max(q[1] & rm, q[-SP + 1] & rm), q[SP + 1] & rm), max((int)q[-SP], (int)q[SP])));
+        if (sv > nmax) keep = sv;   // (sv > 0 follows: nmax >= 0)
       }
       const bool in1 = x >= ew0;
       const uint32_t rec = (uint32_t)(ex0 + x) | ((uint32_t)(ey0 + y) << 12) | ((uint32_t)keep << 24);
