@@ -310,11 +310,30 @@ __global__ __launch_bounds__(64) void k_fast_tasks(PyramidParams P, int tpPad, i
         incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);   // row_shr:8
         incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
         incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
-        int pos = nq + incl - c;
+        const int pos = nq + incl - c;
         const unsigned e = (unsigned)((y << 8) | (g << GS));
-#pragma unroll
-        for (int k = 0; k < NPX; k++)
-          if (m & (1u << k)) queue[pos++] = (uint16_t)(e + k);
+        // Ordered emission of the lane's set bits, three vector instructions per bit position instead of five: the mask is
+        // bit-reversed once, so that `rev + rev` shifts the next bit out as the carry -- v_add_co writes it straight into VCC, which
+        // masks the store and the advance of the lane's write address; the entry counts up unconditionally.
+        {
+          unsigned rev = __builtin_bitreverse32(m) >> (16 - NPX), ent = e;   // bit k of m -> bit 31 - k ... (NPX = 8: bits 0..7 -> 31..24)
+          rev <<= (16 - NPX);
+          unsigned addr = (unsigned)(uintptr_t)(queue + pos);   // LDS byte address
+          unsigned long long saved;
+          asm volatile(
+              "s_mov_b64 %3, exec\n\t"
+              ".rept %4\n\t"
+              "v_add_co_u32 %0, vcc, %0, %0\n\t"
+              "s_and_b64 exec, %3, vcc\n\t"
+              "ds_write_b16 %1, %2\n\t"
+              "v_add_u32 %1, 2, %1\n\t"
+              "s_mov_b64 exec, %3\n\t"
+              "v_add_u32 %2, 1, %2\n\t"
+              ".endr"
+              : "+v"(rev), "+v"(addr), "+v"(ent), "=&s"(saved)
+              : "n"(NPX)
+              : "vcc", "memory");
+        }
         nq += __builtin_amdgcn_readlane(incl, 63);
         y += stepY;
         g += stepG;
