@@ -189,28 +189,57 @@ __device__ __forceinline__ unsigned pk_round2(unsigned x, unsigned y) {
 // XCD a CONSECUTIVE run of the frame's tiles in row-major order (a horizontal band): the 128-byte lines two horizontally
 // adjacent footprints share are fetched into one L2 once instead of into two L2s (profiles/r02n_pmc_summary.csv: the
 // plain (x, y, frame) grid fetched 2.3x the level it reads).  tile -> (tx, ty) by a scalar multiply-high.
+// Everything the kernel needs about its level as PLAIN kernel arguments (fixed offsets: one scalar load up front) instead of
+// PyramidParams indexed by a run-time level -- that cost a chain of nine dependent scalar round trips (level record, frame
+// pointer, footprint corners one by one) before the first byte of the tile was requested; now: arguments, then the footprint
+// corners + coefficients + frame pointer together, then the tile (round 4).
+struct ResizeLevel {
+  int dw, dh, dpitch;        // destination level
+  int sw, sh;                // source level
+  long long sstride;         // source row stride (level 1: the frames' stride)
+  long long doff, soff;      // byte offsets inside a frame's pyramid slab (soff unused when the source is level 0)
+  const int* xofs;
+  const short* xalpha;
+  const int* yofs;
+  const short* ybeta;
+  const uint8_t* const* frame0;     // source is level 0: the frames' pointers (or the two inline ones)
+  const uint8_t* frameInline[2];
+  uint8_t* slab;
+  long long slabBytes;
+  int frameBase;
+  int fromLevel0;
+};
+
 template <int LP, int RH>
-__global__ __launch_bounds__(256) void k_resize_fixed(PyramidParams P, int level, int tilesX, int ntiles, unsigned rcpTilesX, int dma) {
+__global__ __launch_bounds__(256) void k_resize_fixed(ResizeLevel R, int tilesX, int ntiles, unsigned rcpTilesX, int dma) {
   __shared__ __align__(16) uint8_t rz[LP * RH];
   __shared__ __align__(16) uint16_t H[RH * 64];
-  const LevelGeom& D = P.lv[level];
-  const LevelGeom& S = P.lv[level - 1];
-  const int f = P.frameBase + blockIdx.y;
+  struct { int w, h, pitch; const int* xofs; const short* xalpha; const int* yofs; const short* ybeta; } D = {R.dw, R.dh, R.dpitch, R.xofs, R.xalpha, R.yofs, R.ybeta};
+  struct { int w, h; } S = {R.sw, R.sh};
+  const int f = R.frameBase + blockIdx.y;
   const int chunk = (ntiles + 7) >> 3;
   const int tileIx = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
   if (tileIx >= ntiles) return;
   const int tyI = (int)(((unsigned long long)(unsigned)tileIx * rcpTilesX) >> 32);   // tileIx / tilesX (exact: host-checked range)
   const int tx0 = (tileIx - tyI * tilesX) * kRzTile, ty0 = tyI * kRzTile;
   const int tx1 = min(tx0 + kRzTile, D.w) - 1, ty1 = min(ty0 + kRzTile, D.h) - 1;
-  const uint8_t* src;
-  long long sstride;
-  if (level == 1) {
-    src = level0_of(P, f);
-    sstride = P.stride0;
-  } else {
-    src = P.slab + (long long)f * P.slabBytes + S.off;
-    sstride = S.pitch;
+  const int level = R.fromLevel0 ? 1 : 2;   // (only "is the source a caller-owned frame" matters below)
+  // one round trip: the four footprint corners and the frame pointer (scalar), the lanes' coefficients (vector, below)
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  u32x2 fpw = {0u, 0u};
+  if (R.fromLevel0) {
+    if (R.frame0) {
+      fpw = *reinterpret_cast<const u32x2 __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(R.frame0 + f));
+    } else {
+      const unsigned long long v = reinterpret_cast<unsigned long long>((f & 1) ? R.frameInline[1] : R.frameInline[0]);
+      fpw.x = (uint32_t)v;
+      fpw.y = (uint32_t)(v >> 32);
+    }
   }
+  const int cxa = *reinterpret_cast<const int __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(D.xofs + tx0));
+  const int cxb = *reinterpret_cast<const int __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(D.xofs + tx1));
+  const int cya = *reinterpret_cast<const int __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(D.yofs + ty0));
+  const int cyb = *reinterpret_cast<const int __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(D.yofs + ty1));
   const int tid = threadIdx.x;
   const int hc = tid & 63;
   const int hx = min(tx0 + hc, D.w - 1);
@@ -224,8 +253,16 @@ __global__ __launch_bounds__(256) void k_resize_fixed(PyramidParams P, int level
     syv[i] = ld32(D.yofs, y);
     be[i] = ld32(D.ybeta, y);
   }
-  const int rx0 = D.xofs[tx0], rx1 = min(D.xofs[tx1] + 1, S.w - 1);
-  const int ry0 = min(max(D.yofs[ty0], 0), S.h - 1), ry1 = min(max(D.yofs[ty1] + 1, 0), S.h - 1);
+  asm volatile("" ::"s"(cxa), "s"(cxb), "s"(cya), "s"(cyb), "s"(fpw.x), "s"(fpw.y));   // everything above is requested before the first wait
+  const uint8_t* src;
+  const long long sstride = R.sstride;
+  if (R.fromLevel0) {
+    src = reinterpret_cast<const uint8_t*>(((unsigned long long)fpw.y << 32) | fpw.x);
+  } else {
+    src = R.slab + (long long)f * R.slabBytes + R.soff;
+  }
+  const int rx0 = cxa, rx1 = min(cxb + 1, S.w - 1);
+  const int ry0 = min(max(cya, 0), S.h - 1), ry1 = min(max(cyb + 1, 0), S.h - 1);
   const int rw = rx1 - rx0 + 1, rh = ry1 - ry0 + 1;
   const int istr = (int)sstride;
   const uint8_t* rbase = uniform_ptr(src + (long long)ry0 * sstride + rx0);   // the same for the whole block
@@ -294,7 +331,7 @@ __global__ __launch_bounds__(256) void k_resize_fixed(PyramidParams P, int level
   __syncthreads();
   // ---- column pass ----
   if (cx > tx1 || cy > ty1) return;
-  uint8_t* dst = P.slab + (long long)f * P.slabBytes + D.off;
+  uint8_t* dst = R.slab + (long long)f * R.slabBytes + R.doff;
   const uint16_t* hcol = H + (cx - tx0);
 #pragma unroll
   for (int j = 0; j < 4; j++) {
@@ -1121,7 +1158,15 @@ int launch_pyramid(const PyramidParams& P, int nframes, hipStream_t st, const Co
       const unsigned rcp = (unsigned)(0x100000000ull / (unsigned)tilesX) + 1u;   // floor(t * rcp / 2^32) = t / tilesX for t * tilesX < 2^32
       if ((unsigned long long)ntiles * tilesX < (1ull << 31)) {
         static const int dma = [] { const char* e = getenv("ORBFE_RESIZE_DMA"); return e ? atoi(e) : 1; }();   // 0: staging through registers (A/B)
-        hipLaunchKernelGGL((k_resize_fixed<96, 80>), dim3(8 * ((ntiles + 7) / 8), nframes), dim3(256), 0, st, P, l, tilesX, ntiles, rcp, dma);
+        ResizeLevel R{};
+        R.dw = P.lv[l].w; R.dh = P.lv[l].h; R.dpitch = P.lv[l].pitch;
+        R.sw = P.lv[l - 1].w; R.sh = P.lv[l - 1].h;
+        R.sstride = l == 1 ? P.stride0 : (long long)P.lv[l - 1].pitch;
+        R.doff = P.lv[l].off; R.soff = P.lv[l - 1].off;
+        R.xofs = P.lv[l].xofs; R.xalpha = P.lv[l].xalpha; R.yofs = P.lv[l].yofs; R.ybeta = P.lv[l].ybeta;
+        R.frame0 = P.frame0; R.frameInline[0] = P.frameInline[0]; R.frameInline[1] = P.frameInline[1];
+        R.slab = P.slab; R.slabBytes = P.slabBytes; R.frameBase = P.frameBase; R.fromLevel0 = l == 1;
+        hipLaunchKernelGGL((k_resize_fixed<96, 80>), dim3(8 * ((ntiles + 7) / 8), nframes), dim3(256), 0, st, R, tilesX, ntiles, rcp, dma);
         continue;
       }
     }
