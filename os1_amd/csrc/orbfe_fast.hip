@@ -64,7 +64,8 @@ __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmc
 // PAIRS = false: every task is a single cell (the default task table); the second cell's bookkeeping compiles away
 // ABL (measurement only, ORBFE_FAST_ABLATE=1..3, tools/fast_ablation.sh): the kernel stops after its set-up + ROI load (1),
 // after the pre-test and its compaction (2), after the score stage (3) -- every cell then reports no candidate; 0 = the product;
-// 4 = the product with s_memtime stamps between its phases, summed over all waves into g_fastStamps (orbfe_debug_fast_stamps)
+// 4 = the product with s_memtime stamps between its phases, summed over all waves into g_fastStamps (orbfe_debug_fast_stamps);
+// 5 = the product without the second pass at minThFAST (what that pass costs)
 __device__ uint32_t* g_fastStampBuf;   // [waves of the launch][8]
 template <int NPX, bool PAIRS, int ABL = 0>
 __global__ __launch_bounds__(64) void k_fast_tasks(PyramidParams P, int tpPad, int dma, int t0, int nt) {
@@ -440,6 +441,7 @@ __global__ __launch_bounds__(64) void k_fast_tasks(PyramidParams P, int tpPad, i
       }
     }
     if (pass == 1 || P.minTh == P.iniTh) break;
+    if constexpr (ABL == 5) break;   // measurement: what the second pass costs
     // ORBextractor.cc:850-856: a cell whose first cv::FAST call returned nothing is detected again at minThFAST
     emit0 = base0 == 0;
     emit1 = ew1 > 0 && base1 == 0;
@@ -541,6 +543,8 @@ void launch_fast(const PyramidParams& P, int nframes, hipStream_t st) {
       hipLaunchKernelGGL((k_fast_tasks<16, false, 2>), grid, dim3(64), need, st, P, 0, dma, t0, nt);
     else if (ablate == 3)
       hipLaunchKernelGGL((k_fast_tasks<16, false, 3>), grid, dim3(64), need, st, P, 0, dma, t0, nt);
+    else if (ablate == 5)
+      hipLaunchKernelGGL((k_fast_tasks<16, false, 5>), grid, dim3(64), need, st, P, 0, dma, t0, nt);
     else if (ablate == 4) {
       if (t0 == 0) stamp_buffer_for((size_t)(P.ntasks + 64) * nframes);
       hipLaunchKernelGGL((k_fast_tasks<16, false, 4>), grid, dim3(64), need, st, P, 0, dma, t0, nt);

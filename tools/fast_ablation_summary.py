@@ -6,9 +6,9 @@ import sys
 
 d = sys.argv[1]
 names = {0: 'full kernel', 1: 'set-up + ROI load (+ score-tile zeroing)', 2: '+ stage 1: pre-test and ordered compaction',
-         3: '+ stage 2: arc score'}
+         3: '+ stage 2: arc score', 5: 'full kernel without the second pass (minThFAST)'}
 rows = {}
-for a in range(4):
+for a in (0, 1, 2, 3, 5):
     agg = collections.defaultdict(list)
     for f in glob.glob('%s/pmc_%d/**/*counter_collection.csv' % (d, a), recursive=True):
         for r in csv.DictReader(open(f)):
@@ -31,10 +31,13 @@ for a in range(4):
                    wait=mean('SQ_WAIT_ANY') / mean('SQ_WAVE_CYCLES'), us=dur[len(dur) // 2], n=len(keep))
 print('k_fast_tasks stage ablation, 32 x 1080p frames per launch, kernel alone (tools/quick_bench.py 32); per cell-wave:')
 print('%-46s %9s %7s %7s %7s %9s %9s' % ('stages run', 'VALU', 'LDS', 'SALU', 'cyc/VALU', 'wait frac', 'launch us'))
-for a in (1, 2, 3, 0):
+for a in (1, 2, 3, 5, 0):
     if a in rows:
         r = rows[a]
         print('%-46s %9.1f %7.1f %7.1f %7.2f %9.2f %9.1f   (%d launches, %d waves each)' % (names[a], r['valu'], r['lds'], r['salu'], r['cpi'], r['wait'], r['us'], r['n'], r['waves']))
 if all(a in rows for a in range(4)):
     print('increments (VALU per cell-wave): set-up %.0f | stage 1 %.0f | stage 2 %.0f | stage 3 (NMS + emission) %.0f' % (
         rows[1]['valu'], rows[2]['valu'] - rows[1]['valu'], rows[3]['valu'] - rows[2]['valu'], rows[0]['valu'] - rows[3]['valu']))
+if 5 in rows and 0 in rows:
+    print('second pass (cells without a keypoint at iniThFAST, again at minThFAST): %.0f VALU per cell-wave on average; stage 3 of the first pass alone: %.0f' % (
+        rows[0]['valu'] - rows[5]['valu'], rows[5]['valu'] - rows[3]['valu']))
