@@ -360,7 +360,7 @@ struct orbfe_extractor {
         L.pitch = (int)align_up(L.w, 64);
         L.off = off;
         off += align_up((long long)L.pitch * L.h, 256);
-        tableBytes += align_up(L.w * 4, 16) + align_up(L.w * 4, 16) + align_up(L.h * 4, 16) + align_up(L.h * 4, 16);
+        tableBytes += align_up(L.w * 4, 16) + align_up(L.w * 4, 16) + align_up(L.h * 4, 16) + align_up(L.h * 4, 16) + align_up(L.h * 4, 16);
       }
     }
     Q.ncells = cellBase;
@@ -394,6 +394,9 @@ struct orbfe_extractor {
       short* yb = (short*)(tab.data() + cur);
       L.ybeta = (const short*)(d_tables.p + cur);
       cur += align_up(dh * 4, 16);
+      unsigned* yc = (unsigned*)(tab.data() + cur);
+      L.yofc = (const unsigned*)(d_tables.p + cur);
+      cur += align_up(dh * 4, 16);
       for (int dx = 0; dx < dw; dx++) {
         float fx = (float)((dx + 0.5) * scale_x - 0.5);
         int sx = cv_floor_f(fx);
@@ -409,6 +412,7 @@ struct orbfe_extractor {
         int sy = cv_floor_f(fy);
         fy -= sy;
         yofs[dy] = sy;
+        yc[dy] = (unsigned)std::min(std::max(sy, 0), sh - 1) | ((unsigned)std::min(std::max(sy + 1, 0), sh - 1) << 16);
         yb[2 * dy] = sat_short(cv_round_f((1.f - fy) * 2048));
         yb[2 * dy + 1] = sat_short(cv_round_f(fy * 2048));
       }

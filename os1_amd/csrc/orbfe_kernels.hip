@@ -165,6 +165,16 @@ __device__ __forceinline__ unsigned mulu24_w1(unsigned b, unsigned hh) {   // b 
   return r;
 }
 
+template <int WA, int WB>
+__device__ __forceinline__ unsigned mulu24_hh(unsigned a, unsigned b) {   // (half WA of a) * (half WB of b)
+  unsigned r;
+  if (WA == 0 && WB == 0) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0" : "=v"(r) : "v"(a), "v"(b));
+  if (WA == 0 && WB == 1) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(r) : "v"(a), "v"(b));
+  if (WA == 1 && WB == 0) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_0" : "=v"(r) : "v"(a), "v"(b));
+  if (WA == 1 && WB == 1) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // scalar base + 32-bit lane byte offset: one address register, no 64-bit lane arithmetic
 __device__ __forceinline__ int ld32(const void* base, unsigned byteOff) {
   return *reinterpret_cast<const int*>(reinterpret_cast<const char*>(base) + byteOff);
@@ -200,7 +210,7 @@ struct ResizeLevel {
   long long doff, soff;      // byte offsets inside a frame's pyramid slab (soff unused when the source is level 0)
   const int* xofs;
   const short* xalpha;
-  const int* yofs;
+  const unsigned* yofc;      // clamped source rows, packed (LevelGeom::yofc)
   const short* ybeta;
   const uint8_t* const* frame0;     // source is level 0: the frames' pointers (or the two inline ones)
   const uint8_t* frameInline[2];
@@ -214,7 +224,7 @@ template <int LP, int RH>
 __global__ __launch_bounds__(256) void k_resize_fixed(ResizeLevel R, int tilesX, int ntiles, unsigned rcpTilesX, int dma) {
   __shared__ __align__(16) uint8_t rz[LP * RH];
   __shared__ __align__(16) uint16_t H[RH * 64];
-  struct { int w, h, pitch; const int* xofs; const short* xalpha; const int* yofs; const short* ybeta; } D = {R.dw, R.dh, R.dpitch, R.xofs, R.xalpha, R.yofs, R.ybeta};
+  struct { int w, h, pitch; const int* xofs; const short* xalpha; const unsigned* yofc; const short* ybeta; } D = {R.dw, R.dh, R.dpitch, R.xofs, R.xalpha, R.yofc, R.ybeta};
   struct { int w, h; } S = {R.sw, R.sh};
   const int f = R.frameBase + blockIdx.y;
   const int chunk = (ntiles + 7) >> 3;
@@ -238,8 +248,8 @@ __global__ __launch_bounds__(256) void k_resize_fixed(ResizeLevel R, int tilesX,
   }
   const int cxa = *reinterpret_cast<const int __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(D.xofs + tx0));
   const int cxb = *reinterpret_cast<const int __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(D.xofs + tx1));
-  const int cya = *reinterpret_cast<const int __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(D.yofs + ty0));
-  const int cyb = *reinterpret_cast<const int __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(D.yofs + ty1));
+  const unsigned cya = *reinterpret_cast<const unsigned __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(D.yofc + ty0));
+  const unsigned cyb = *reinterpret_cast<const unsigned __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(D.yofc + ty1));
   const int tid = threadIdx.x;
   const int hc = tid & 63;
   const int hx = min(tx0 + hc, D.w - 1);
@@ -250,7 +260,7 @@ __global__ __launch_bounds__(256) void k_resize_fixed(ResizeLevel R, int tilesX,
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     const unsigned y = (unsigned)min(cy + i, D.h - 1) << 2;
-    syv[i] = ld32(D.yofs, y);
+    syv[i] = ld32(D.yofc, y);
     be[i] = ld32(D.ybeta, y);
   }
   asm volatile("" ::"s"(cxa), "s"(cxb), "s"(cya), "s"(cyb), "s"(fpw.x), "s"(fpw.y));   // everything above is requested before the first wait
@@ -262,7 +272,7 @@ __global__ __launch_bounds__(256) void k_resize_fixed(ResizeLevel R, int tilesX,
     src = R.slab + (long long)f * R.slabBytes + R.soff;
   }
   const int rx0 = cxa, rx1 = min(cxb + 1, S.w - 1);
-  const int ry0 = min(max(cya, 0), S.h - 1), ry1 = min(max(cyb + 1, 0), S.h - 1);
+  const int ry0 = (int)(cya & 0xffffu), ry1 = (int)(cyb >> 16);   // first source row of the tile's first row, second of its last
   const int rw = rx1 - rx0 + 1, rh = ry1 - ry0 + 1;
   const int istr = (int)sstride;
   const uint8_t* rbase = uniform_ptr(src + (long long)ry0 * sstride + rx0);   // the same for the whole block
@@ -319,36 +329,43 @@ __global__ __launch_bounds__(256) void k_resize_fixed(ResizeLevel R, int tilesX,
   __syncthreads();
   // ---- row pass: all RH rows, unconditionally (rows past the footprint hold stale bytes nobody reads the H of) ----
   {
-    const int a0 = (short)hal, a1 = hal >> 16;
+    // H = (p0 a0 + p1 a1) >> 4 as the HIGH half of (p0 (a0 << 12) + p1 (a1 << 12)): the store takes the high half of the
+    // register by itself (ds_write_b16_d16_hi), so an element is two vector instructions, not three.  a0 + a1 = 2048, both >= 0:
+    // a << 12 <= 2^23 fits the 24-bit multiplier, the sum is at most 255 * 2048 * 4096 < 2^31.
+    const unsigned a0 = (unsigned)(int)(short)hal << 12, a1 = (unsigned)(hal >> 16) << 12;
     const int o0 = a + hsx - rx0, o1 = a + min(hsx + 1, S.w - 1) - rx0;
     const uint8_t* p0 = rz + (tid >> 6) * LP + o0;
     const uint8_t* p1 = rz + (tid >> 6) * LP + o1;
     uint16_t* h = H + (tid >> 6) * 64 + hc;
 #pragma unroll
     for (int i = 0; i < RH / 4; i++)
-      h[i * 4 * 64] = (uint16_t)((m24(p0[i * 4 * LP], a0) + m24(p1[i * 4 * LP], a1)) >> 4);
+      h[i * 4 * 64] = (uint16_t)((__umul24(p0[i * 4 * LP], a0) + __umul24(p1[i * 4 * LP], a1)) >> 16);
   }
   __syncthreads();
   // ---- column pass ----
   if (cx > tx1 || cy > ty1) return;
-  uint8_t* dst = R.slab + (long long)f * R.slabBytes + R.doff;
-  const uint16_t* hcol = H + (cx - tx0);
+  uint8_t* dst = R.slab + (long long)f * R.slabBytes + R.doff;   // scalar; the lane's byte offset is 32 bits
+  unsigned doffs = (unsigned)(m24(cy, D.pitch) + cx);
+  const unsigned hx2 = (unsigned)(cx - tx0) * 2u, ry0s = (unsigned)ry0 << 7;
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     const int y = cy + j;
     if (y > ty1) break;
-    const int sy = syv[j];
-    const int sy0 = min(max(sy, 0), S.h - 1) - ry0, sy1 = min(max(sy + 1, 0), S.h - 1) - ry0;
-    const unsigned b0 = (unsigned)(int)(short)be[j], b1 = (unsigned)(be[j] >> 16);
-    const uint2 q0 = *reinterpret_cast<const uint2*>(hcol + sy0 * 64), q1 = *reinterpret_cast<const uint2*>(hcol + sy1 * 64);
-    // b <= 2048, h <= 32640: the products fit 27 bits.  The high halves of two columns' products are gathered into one
-    // register (v_perm) and the rounding runs on both at once: (x + y + 2) >> 2 in packed 16-bit arithmetic.
-    const unsigned x01 = __builtin_amdgcn_perm(mulu24_w1(b0, q0.x), mulu24_w0(b0, q0.x), 0x07060302u);
-    const unsigned y01 = __builtin_amdgcn_perm(mulu24_w1(b1, q1.x), mulu24_w0(b1, q1.x), 0x07060302u);
-    const unsigned x23 = __builtin_amdgcn_perm(mulu24_w1(b0, q0.y), mulu24_w0(b0, q0.y), 0x07060302u);
-    const unsigned y23 = __builtin_amdgcn_perm(mulu24_w1(b1, q1.y), mulu24_w0(b1, q1.y), 0x07060302u);
+    // the row's two source rows come clamped and packed from the host's table (row0 | row1 << 16): H row = source row - ry0, 128 bytes each
+    const unsigned r0 = ((unsigned)syv[j] & 0xffffu) << 7, r1 = ((unsigned)syv[j] >> 16) << 7;
+    const uint8_t* hb = reinterpret_cast<const uint8_t*>(H) + hx2 - ry0s;
+    const uint2 q0 = *reinterpret_cast<const uint2*>(hb + r0), q1 = *reinterpret_cast<const uint2*>(hb + r1);
+    // b <= 2048, h <= 32640: the products fit 27 bits.  The weights are taken as the halves of their packed word and the H values as
+    // the halves of theirs by SDWA selects; the high halves of two columns' products are gathered into one register (v_perm) and the
+    // rounding runs on both at once: (x + y + 2) >> 2 in packed 16-bit arithmetic.
+    const unsigned bw = (unsigned)be[j];
+    const unsigned x01 = __builtin_amdgcn_perm(mulu24_hh<0, 1>(bw, q0.x), mulu24_hh<0, 0>(bw, q0.x), 0x07060302u);
+    const unsigned y01 = __builtin_amdgcn_perm(mulu24_hh<1, 1>(bw, q1.x), mulu24_hh<1, 0>(bw, q1.x), 0x07060302u);
+    const unsigned x23 = __builtin_amdgcn_perm(mulu24_hh<0, 1>(bw, q0.y), mulu24_hh<0, 0>(bw, q0.y), 0x07060302u);
+    const unsigned y23 = __builtin_amdgcn_perm(mulu24_hh<1, 1>(bw, q1.y), mulu24_hh<1, 0>(bw, q1.y), 0x07060302u);
     const unsigned v01 = pk_round2(x01, y01), v23 = pk_round2(x23, y23);
-    *reinterpret_cast<uint32_t*>(dst + m24(y, D.pitch) + cx) = __builtin_amdgcn_perm(v23, v01, 0x06040200u);  // pitch % 64 == 0: in bounds
+    *reinterpret_cast<uint32_t*>(dst + doffs) = __builtin_amdgcn_perm(v23, v01, 0x06040200u);  // pitch % 64 == 0: in bounds
+    doffs += (unsigned)D.pitch;
   }
 }
 
@@ -1163,7 +1180,7 @@ int launch_pyramid(const PyramidParams& P, int nframes, hipStream_t st, const Co
         R.sw = P.lv[l - 1].w; R.sh = P.lv[l - 1].h;
         R.sstride = l == 1 ? P.stride0 : (long long)P.lv[l - 1].pitch;
         R.doff = P.lv[l].off; R.soff = P.lv[l - 1].off;
-        R.xofs = P.lv[l].xofs; R.xalpha = P.lv[l].xalpha; R.yofs = P.lv[l].yofs; R.ybeta = P.lv[l].ybeta;
+        R.xofs = P.lv[l].xofs; R.xalpha = P.lv[l].xalpha; R.yofc = P.lv[l].yofc; R.ybeta = P.lv[l].ybeta;
         R.frame0 = P.frame0; R.frameInline[0] = P.frameInline[0]; R.frameInline[1] = P.frameInline[1];
         R.slab = P.slab; R.slabBytes = P.slabBytes; R.frameBase = P.frameBase; R.fromLevel0 = l == 1;
         hipLaunchKernelGGL((k_resize_fixed<96, 80>), dim3(8 * ((ntiles + 7) / 8), nframes), dim3(256), 0, st, R, tilesX, ntiles, rcp, dma);
