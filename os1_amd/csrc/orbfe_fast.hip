@@ -68,7 +68,9 @@ __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmc
 // 5 = the product without the second pass at minThFAST (what that pass costs)
 __device__ uint32_t* g_fastStampBuf;   // [waves of the launch][8]
 template <int NPX, bool PAIRS, int ABL = 0>
-__global__ __launch_bounds__(64) void k_fast_tasks(PyramidParams P, int tpPad, int dma, int t0, int nt) {
+// (amdgpu_num_sgpr(96): the kernel asks for 105 scalar registers by itself, which caps a SIMD at 6 waves; 94 with 3 values parked in
+// a vector register allow 7 -- +1 % in the pipeline, 80 / 88 measured the same)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fast_tasks(PyramidParams P, int tpPad, int dma, int t0, int nt) {
   extern __shared__ __align__(16) uint8_t lds[];
   unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
   if constexpr (ABL == 4) stamp[0] = __builtin_amdgcn_s_memtime();
