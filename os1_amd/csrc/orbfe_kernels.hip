@@ -789,6 +789,29 @@ constexpr BlurCodes make_blur_codes() {
 __constant__ BlurCodes c_blurCodes = make_blur_codes();
 
 
+// the 8.8 Gaussian taps [18,34,48,56,48,34,18] laid over dword q of a row whose 7-tap window starts at byte s: byte b of the
+// word weighs byte 4q + b, i.e. tap 4q + b - s (0 outside the window)
+constexpr unsigned blur_tap_word(int s, int q) {
+  const unsigned taps[7] = {18, 34, 48, 56, 48, 34, 18};
+  unsigned w = 0;
+  for (int b = 0; b < 4; b++) {
+    const int t = 4 * q + b - s;
+    if (t >= 0 && t <= 6) w |= taps[t] << (8 * b);
+  }
+  return w;
+}
+
+template <int S>
+__device__ __forceinline__ unsigned blur_row_out(const uint32_t (&d)[4]) {   // the 7-tap sum whose window starts at byte S of d
+  constexpr unsigned w0 = blur_tap_word(S, 0), w1 = blur_tap_word(S, 1), w2 = blur_tap_word(S, 2), w3 = blur_tap_word(S, 3);
+  unsigned acc = 0u;
+  if constexpr (w0 != 0u) acc = __builtin_amdgcn_udot4(d[0], w0, acc, false);
+  if constexpr (w1 != 0u) acc = __builtin_amdgcn_udot4(d[1], w1, acc, false);
+  if constexpr (w2 != 0u) acc = __builtin_amdgcn_udot4(d[2], w2, acc, false);
+  if constexpr (w3 != 0u) acc = __builtin_amdgcn_udot4(d[3], w3, acc, false);
+  return acc;
+}
+
 // sum over the wave (wave-uniform result): DPP row rotations, then one value per row of 16 lanes
 __device__ __forceinline__ int wave_sum_i32(int v) {
   v += __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false);   // row_ror:8
@@ -1001,21 +1024,29 @@ __global__ __launch_bounds__(64 * WAVES) void k_describe(PyramidParams P, const 
   // v_dot4_u32_u8, 4 outputs per lane, written TRANSPOSED as u16 so that the vertical pass finds vertically adjacent
   // taps in one dword and runs on v_dot2_u32_u16 (4 outputs per lane, one dword store into the transposed patch).
   {
-    const unsigned K0 = 0x38302212u, K1 = 0x00122230u;   // taps 0..3 and 4..6 as bytes
+    // The byte alignment `pa` of the patch is the same for the whole block: one of four instantiations of the loop is taken by a
+    // scalar branch, and in each the seven taps of output j sit at FIXED bytes pa + j .. pa + j + 6 of the item's four dwords -- the
+    // tap weights are laid over those dwords as constants (zero elsewhere), so an item is 10 v_dot4 and nothing else: no funnel
+    // shifts to align the data (3 + 6 of them before round 4's second half).
+    auto hpass = [&](auto paTag) {
+      constexpr int PA = decltype(paTag)::value;
 #pragma unroll
-    for (int it = 0; it < NH; it++) {
-      if ((it + 1) * NT > kBlurItemsHost.nh && it * NT + tid >= kBlurItemsHost.nh) break;   // only the last iteration is partial
-      const uint32_t* rp = reinterpret_cast<const uint32_t*>(raw + (bh[it] & 0xffffu));
-      const uint32_t d0 = rp[0], d1 = rp[1], d2 = rp[2], d3 = rp[3];
-      const uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, pa), a1 = __builtin_amdgcn_alignbyte(d2, d1, pa),
-                     a2 = __builtin_amdgcn_alignbyte(d3, d2, pa);   // raw pixels 4g .. 4g+11 of row y
-      uint16_t* o = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(hbT) + (bh[it] >> 16));
-      o[0] = (uint16_t)__builtin_amdgcn_udot4(a1, K1, __builtin_amdgcn_udot4(a0, K0, 0u, false), false);
-#pragma unroll
-      for (int j = 1; j < 4; j++) {
-        const uint32_t lo = __builtin_amdgcn_alignbyte(a1, a0, j), hi = __builtin_amdgcn_alignbyte(a2, a1, j);
-        o[j * kHPT] = (uint16_t)__builtin_amdgcn_udot4(hi, K1, __builtin_amdgcn_udot4(lo, K0, 0u, false), false);
+      for (int it = 0; it < NH; it++) {
+        if ((it + 1) * NT > kBlurItemsHost.nh && it * NT + tid >= kBlurItemsHost.nh) break;   // only the last iteration is partial
+        const uint32_t* rp = reinterpret_cast<const uint32_t*>(raw + (bh[it] & 0xffffu));
+        const uint32_t d[4] = {rp[0], rp[1], rp[2], rp[3]};   // raw bytes 4g .. 4g+15 of row y; pixel x of the row is byte PA + x
+        uint16_t* o = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(hbT) + (bh[it] >> 16));
+        o[0] = (uint16_t)blur_row_out<PA + 0>(d);
+        o[kHPT] = (uint16_t)blur_row_out<PA + 1>(d);
+        o[2 * kHPT] = (uint16_t)blur_row_out<PA + 2>(d);
+        o[3 * kHPT] = (uint16_t)blur_row_out<PA + 3>(d);
       }
+    };
+    switch (pa) {
+      case 0: hpass(std::integral_constant<int, 0>{}); break;
+      case 1: hpass(std::integral_constant<int, 1>{}); break;
+      case 2: hpass(std::integral_constant<int, 2>{}); break;
+      default: hpass(std::integral_constant<int, 3>{}); break;
     }
   }
   __syncthreads();
