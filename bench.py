@@ -55,7 +55,7 @@ def parse_args():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=None, help='frames per submission to the stream runner (default: stream_workload.BATCH)')
+    ap.add_argument('--batch', type=int, default=None, help='frames per submission to the stream runner (default: stream_workload.SUBMIT = 64; the digests are per 32 frames whatever this is)')
     ap.add_argument('--pool', type=int, default=256, help='distinct frames per stream (= frames per step)')
     ap.add_argument('--cpu-frames', type=int, default=64, help='frames of the CPU-oracle baseline sample (0 = skip)')
     ap.add_argument('--bow', action='store_true', help='also run Frame::ComputeBoW (k=10, L=6 synthetic vocabulary) behind the descriptor kernel (not the headline value)')
@@ -170,9 +170,10 @@ def run_rank(args):
     numa_node = api.device_numa_node(local_rank)
     numa_cpus = api.bind_thread_to_device(local_rank)
 
-    W, H, B = wl.W, wl.H, (args.batch or wl.BATCH)
+    W, H, B = wl.W, wl.H, (args.batch or wl.SUBMIT)
     assert args.pool % B == 0, '--pool must be a multiple of --batch'
     subs = args.pool // B                       # submissions per step
+    cur = {'B': B, 'subs': subs}                # (the PCIe-inclusive leg runs its own runner with 32-frame submissions)
     seed = wl.stream_seed(rank)                 # config 4: stream g -> GPU g, seeds 100+g
     sf = wl.StreamFrames(seed, W, H, args.pool)
     frames = sf.frames()
@@ -181,8 +182,8 @@ def run_rank(args):
     pinned = api.PinnedFrames(frames) if want_pinned else None
 
     # native stream runner: `depth` extractor handles, GPU-resident matching, C++ worker thread
-    def make_runner(depth):
-        r = api.Stream(wl.NFEAT, wl.SCALE, wl.NLEVELS, wl.INI_TH, wl.MIN_TH, local_rank, B, max(1, depth))
+    def make_runner(depth, batch=None):
+        r = api.Stream(wl.NFEAT, wl.SCALE, wl.NLEVELS, wl.INI_TH, wl.MIN_TH, local_rank, batch or B, max(1, depth))
         r.set_matching(wl.BOUNDS, 0 if args.no_match else wl.WINDOW, wl.NNRATIO, wl.CHECK_ORI)
         if args.bow:
             r.set_vocabulary(voc, 4)
@@ -197,8 +198,8 @@ def run_rank(args):
     pos = [0]                                   # stream position of the next pushed frame
 
     def push(source):
-        idx = [wl.pool_index(pos[0] + i, args.pool) for i in range(B)]
-        pos[0] += B
+        idx = [wl.pool_index(pos[0] + i, args.pool) for i in range(cur['B'])]
+        pos[0] += cur['B']
         if source == 'hbm':
             st.push_ptrs([dev.ptrs[i] for i in idx], H, W, dev.stride, True)
         elif source == 'pinned':
@@ -244,10 +245,10 @@ def run_rank(args):
     def prewarm(source, seconds):
         t_end = time.perf_counter() + seconds
         while time.perf_counter() < t_end:
-            run(subs, source)
+            run(cur['subs'], source)
 
     def timed(nsteps, nwarm, source):
-        run(nwarm * subs, source)
+        run(nwarm * cur['subs'], source)
         del pop_times[:]
         st.kernel_ms(reset=True)
         st.stats(reset=True)
@@ -257,7 +258,7 @@ def run_rank(args):
             dist.barrier()
         t0 = time.perf_counter()
         c0 = time.process_time()
-        run(nsteps * subs, source)
+        run(nsteps * cur['subs'], source)
         sync()
         host_cpu[0] = time.process_time() - c0      # CPU seconds of this rank's threads inside the timed region
         if dist is not None:
@@ -271,8 +272,8 @@ def run_rank(args):
 
     # ---- self-check: the first steps of the stream against the committed oracle digests (outside the timed region)
     verify = {'verified': None, 'outputs_sha256': None}
-    if not args.no_verify and not args.no_match and not args.bow and args.pool == wl.POOL and B == wl.BATCH:
-        verify = verify_first_steps(wl, seed, lambda n, cb: run(n, 'hbm', cb))
+    if not args.no_verify and not args.no_match and not args.bow and args.pool == wl.POOL:
+        verify = verify_first_steps(wl, seed, B, lambda n, cb: run(n, 'hbm', cb))
     if dist is not None:                        # every rank checks its own stream; rank 0 reports the conjunction
         flag = torch.tensor([1 if verify['verified'] else 0, 1 if verify['verified'] is None else 0], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.SUM)
@@ -303,19 +304,21 @@ def run_rank(args):
         if args.no_pcie or head_source != 'hbm':
             return None
         pdepth = min(3, max(1, args.depth))
-        if pdepth != max(1, args.depth):
+        pB = min(B, wl.BATCH)                     # a batch computes only after its whole upload: 32-frame submissions serve the link better than 64
+        if pdepth != max(1, args.depth) or pB != B:
             st.close()
-            st = make_runner(pdepth)
+            st = make_runner(pdepth, pB)
+            cur['B'], cur['subs'] = pB, args.pool // pB
             st.set_queue_slots(want_lookahead + 2)
             lookahead = min(want_lookahead, st.queue_slots() - 2)
         psteps, pwarm = max(2, min(args.steps, 40)), max(1, min(args.warmup, 3))
-        link = api.h2d_rate_gbs(local_rank, pinned.base, pinned.frame_bytes * B)
+        link = api.h2d_rate_gbs(local_rank, pinned.base, pinned.frame_bytes * pB)
         pel = timed(psteps, pwarm, 'pinned')
         pfps = world * args.pool * psteps / pel
         return {'value': round(pfps, 2), 'unit': 'frames/s', 'steps': psteps, 'warmup': pwarm,
                 'ms_per_step': round(pel / psteps * 1e3, 4),
                 'input': 'the same %d-frame pool in page-locked host memory (orbfe_host_alloc); H2D of every frame inside the timed region' % args.pool,
-                'batches_in_flight': pdepth,
+                'batches_in_flight': pdepth, 'frames_per_submission': pB,
                 'h2d_link_gbs_rank0': round(link, 2), 'h2d_link_frames_per_s_rank0': round(link * 1e9 / (W * H), 1),
                 'frac_of_link_rank0': round(pfps / world * W * H / (link * 1e9), 4) if link > 0 else None}
 
@@ -465,7 +468,7 @@ def run_rank(args):
         dist.destroy_process_group()
 
 
-def verify_first_steps(wl, seed, run):
+def verify_first_steps(wl, seed, B, run):
     """Push the first steps of the stream through the runner, hash every frame's outputs and compare with the
     oracle's digests (tests/golden/stream1080_digests.json <- tools/gen_stream_digests.py)."""
     path = os.path.join(ROOT, 'tests', 'golden', 'stream1080_digests.json')
@@ -476,11 +479,12 @@ def verify_first_steps(wl, seed, run):
     if not ref:
         return {'verified': None, 'outputs_sha256': None, 'note': 'no committed digest for seed %d' % seed}
     hasher = wl.StepHasher()
-    run(len(ref['steps']), lambda res: hasher.add(*res))
-    ok = hasher.steps == ref['steps']
+    nsub = -(-len(ref['steps']) * wl.BATCH // B)     # submissions of B frames that cover the committed 32-frame steps
+    run(nsub, lambda res: hasher.add(*res))
+    ok = hasher.steps[:len(ref['steps'])] == ref['steps'] and len(hasher.steps) >= len(ref['steps'])
     import hashlib
     return {'verified': bool(ok), 'outputs_sha256': hashlib.sha256(''.join(hasher.steps).encode()).hexdigest(),
-            'submissions_checked': len(ref['steps']), 'frames_checked': len(ref['steps']) * wl.BATCH,
+            'submissions_checked': nsub, 'frames_per_submission': B, 'frames_checked': len(ref['steps']) * wl.BATCH,
             'matches_in_checked_frames': hasher.nmatches, 'oracle_matches': ref.get('nmatches'),
             'digest_file': 'tests/golden/stream1080_digests.json', 'seed': seed}
 

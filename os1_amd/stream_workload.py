@@ -17,7 +17,8 @@ from .synth import splitmix64, synth
 W, H, NFEAT, NLEVELS, SCALE, INI_TH, MIN_TH = 1920, 1080, 2000, 8, 1.2, 20, 7
 WINDOW, NNRATIO, CHECK_ORI = 100, 0.9, True          # Tracking.cc:383-384
 POOL = 256
-BATCH = 32
+BATCH = 32      # frames per DIGEST step: what one entry of tests/golden/stream1080_digests.json covers (and the submission size of the parity tests)
+SUBMIT = 64     # frames per submission the bench hands to the stream runner (any size: StepHasher folds the frames into 32-frame steps)
 BOUNDS = (0.0, float(W), 0.0, float(H))
 
 
@@ -84,20 +85,23 @@ def step_digest(frame_hex, match_hex):
 
 
 class StepHasher:
-    """Folds popped batches (Stream.pop() tuples) into per-step digests; carries the predecessor's keypoint count
-    across batches (vnMatches12 of frame i has as many entries as frame i-1 has keypoints)."""
+    """Folds popped batches (Stream.pop() tuples) of ANY size into digests of BATCH-frame steps (frames in stream order); carries the
+    predecessor's keypoint count across batches (vnMatches12 of frame i has as many entries as frame i-1 has keypoints)."""
 
-    def __init__(self):
+    def __init__(self, step=BATCH):
         self.prev_n = 0
         self.steps = []
         self.nmatches = 0
+        self.step = step
+        self._fh, self._mh = [], []
 
     def add(self, kps, desc, n, m12, nm):
-        fh, mh = [], []
         for i in range(len(n)):
-            fh.append(frame_digest(kps[i], desc[i], int(n[i])))
-            mh.append(match_digest(int(nm[i]), m12[i], self.prev_n))
+            self._fh.append(frame_digest(kps[i], desc[i], int(n[i])))
+            self._mh.append(match_digest(int(nm[i]), m12[i], self.prev_n))
             self.prev_n = int(n[i])
             self.nmatches += int(nm[i])
-        self.steps.append(step_digest(fh, mh))
-        return self.steps[-1]
+            if len(self._fh) == self.step:
+                self.steps.append(step_digest(self._fh, self._mh))
+                self._fh, self._mh = [], []
+        return self.steps[-1] if self.steps else None

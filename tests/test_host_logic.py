@@ -155,3 +155,26 @@ def test_shim_restated_ops_equal_the_oracle_restatement(oracle):
         s = float(rng.uniform(0.3, 3.0))
         assert (shim('scale', A, b, s) == A.ravel() * np.float32(s)).all()
         assert (shim('divide', A, b, s) == A.ravel() * np.float32(1.0 / s)).all()
+
+
+def test_step_hasher_folds_any_submission_size():
+    """The committed stream digests are per 32 frames; the bench submits 64 (stream_workload.SUBMIT).  StepHasher must give the same
+    steps however the frames arrive."""
+    from os1_amd import stream_workload as wl
+    from oracle.pyoracle import KP_DTYPE
+    rng = np.random.default_rng(5)
+    nfr = 96
+    n = rng.integers(3, 9, nfr)
+    kps = np.zeros((nfr, 8), KP_DTYPE)
+    kps['x'] = rng.random((nfr, 8))
+    desc = rng.integers(0, 256, (nfr, 8, 32), dtype=np.uint8)
+    nm = rng.integers(0, 3, nfr)
+    m12 = rng.integers(-1, 5, (nfr, 8)).astype(np.int32)
+    want = None
+    for sub in (32, 64, 16, 96, 24):
+        h = wl.StepHasher()
+        for a in range(0, nfr, sub):
+            h.add(kps[a:a + sub], desc[a:a + sub], n[a:a + sub], m12[a:a + sub], nm[a:a + sub])
+        assert len(h.steps) == nfr // wl.BATCH
+        want = want or h.steps
+        assert h.steps == want and h.nmatches == int(nm.sum())
