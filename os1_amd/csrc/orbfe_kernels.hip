@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void k_resize_fixed(ResizeLevel R, int tilesX,
     // therefore comes in by plain dword loads.
     static_assert(LP == 96 && RH % 10 == 0, "LDS-DMA staging layout");
     const uint8_t* gb = rbase - a;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the row group's base stays on the scalar unit
     const int lrow = (int)(((unsigned)lane * 43u) >> 8), lcol = lane - lrow * 6;   // lane / 6 for lane < 64
     const bool lastSpecial = level == 1 && ry1 == S.h - 1;
     const int rhDma = lastSpecial ? rh - 1 : rh;
@@ -296,8 +296,11 @@ __global__ __launch_bounds__(256) void k_resize_fixed(ResizeLevel R, int tilesX,
 #pragma unroll
     for (int u = 0; u < RH / 40; u++) {
       const int r = (wave * (RH / 40) + u) * 10;
+      const uint8_t* gbr = gb + (long long)r * sstride;   // scalar base of the row group + the lane's constant 32-bit offset
+      unsigned vo = voff;
+      asm volatile("" : "+s"(gbr), "+v"(vo));             // (kept apart: together they become a 64-bit per-lane address)
       if (on && r + lrow < rhDma)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb + (long long)r * sstride + voff),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbr + vo),
                                          (__attribute__((address_space(3))) void*)(rz + r * LP), 16, 0, 0);
     }
     if (lastSpecial && tid < ((a + rw + 3) >> 2))
