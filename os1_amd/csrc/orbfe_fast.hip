@@ -261,8 +261,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fas
           const u16x2 r8 = h ? as_u16x2(U4) << 8 : as_u16x2(U4), r12 = h ? as_u16x2(L4) << 8 : as_u16x2(L4);
           const u16x2 mx = __builtin_elementwise_min(__builtin_elementwise_max(r0, r8), __builtin_elementwise_max(r4, r12));
           const u16x2 mn = __builtin_elementwise_max(__builtin_elementwise_min(r0, r8), __builtin_elementwise_min(r4, r12));
-          const u16x2 hi = __builtin_elementwise_add_sat(v2, T2), lo = __builtin_elementwise_sub_sat(v2, T2);
-          const unsigned e = as_u32(__builtin_elementwise_sub_sat(mx, hi)) | as_u32(__builtin_elementwise_sub_sat(lo, mn));
+          // brighter by more than t or darker by more than t: max(mx - v, v - mn) > t, all saturating (one instruction fewer than
+          // comparing mx with v + t and mn with v - t separately; the junk low bytes still only turn a tie into a pass)
+          const u16x2 dd = __builtin_elementwise_max(__builtin_elementwise_sub_sat(mx, v2), __builtin_elementwise_sub_sat(v2, mn));
+          const unsigned e = as_u32(__builtin_elementwise_sub_sat(dd, T2));
           asm("v_pk_min_u16 %0, %1, %2" : "=v"(flag[h]) : "v"(e), "v"(0x00010001u));   // 1 per passing 16-bit lane
         }
         fo = flag[0];
