@@ -1001,11 +1001,11 @@ __global__ __launch_bounds__(64 * WAVES) void k_describe(PyramidParams P, const 
   // IC-angle moments (ORBextractor.cc:86-113) of the UNBLURRED patch: 31 rows x 8 dwords, three v_dot4_u32_u8 each
   const int sIc = (pa + 6) & 3, qIc = (pa + 6) & ~3;   // patch column u = -15 is raw byte pa + 6 of a row
   int S1 = 0, S2 = 0, S3 = 0;
+  // item it * NT + tid = (row it * NT / 8 + tid / 8, dword tid % 8): one address per lane, the iterations are constant offsets
+  const uint8_t* icBase = raw + m24((tid >> 3) + (kRawRad - 15), kRawP) + qIc + 4 * (tid & 7);
 #pragma unroll
   for (int it = 0; it < NIC; it++) {   // (items 248 .. 255 have weight zero)
-    const int i = it * NT + tid;
-    const int r = i >> 3, kk = i & 7;
-    const uint32_t* rp = reinterpret_cast<const uint32_t*>(raw + m24(r + (kRawRad - 15), kRawP) + qIc + 4 * kk);
+    const uint32_t* rp = reinterpret_cast<const uint32_t*>(icBase + it * (NT / 8) * kRawP);
     const uint32_t e = __builtin_amdgcn_alignbyte(rp[1], rp[0], sIc);
     S1 = (int)__builtin_amdgcn_udot4(e, icw[it][0], (unsigned)S1, false);
     S2 = (int)__builtin_amdgcn_udot4(e, icw[it][1], (unsigned)S2, false);
