@@ -416,6 +416,13 @@ struct orbfe_extractor {
         yb[2 * dy] = sat_short(cv_round_f((1.f - fy) * 2048));
         yb[2 * dy + 1] = sat_short(cv_round_f(fy * 2048));
       }
+      // k_resize_fixed fetches the four rows of a thread (4k .. 4k + 3) as ONE 16-byte piece of each table: the padding up to a
+      // multiple of four rows repeats the last row
+      for (int dy = dh; dy < (int)align_up(dh, 4); dy++) {
+        yc[dy] = yc[dh - 1];
+        yb[2 * dy] = yb[2 * (dh - 1)];
+        yb[2 * dy + 1] = yb[2 * (dh - 1) + 1];
+      }
       // largest source footprint of a 64x64 output tile (k_resize stages it in LDS)
       int maxW = 1, maxH = 1;
       for (int x0 = 0; x0 < dw; x0 += 64) {

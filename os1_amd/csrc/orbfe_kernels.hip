@@ -256,13 +256,10 @@ __global__ __launch_bounds__(256) void k_resize_fixed(ResizeLevel R, int tilesX,
   const int hsx = ld32(D.xofs, (unsigned)hx << 2);
   const int hal = ld32(D.xalpha, (unsigned)hx << 2);
   const int cx = tx0 + (tid & 15) * 4, cy = ty0 + (tid >> 4) * 4;
-  int syv[4], be[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const unsigned y = (unsigned)min(cy + i, D.h - 1) << 2;
-    syv[i] = ld32(D.yofc, y);
-    be[i] = ld32(D.ybeta, y);
-  }
+  // the thread's four rows cy .. cy + 3 (cy % 4 == 0) as one 16-byte piece of each table (the host pads both to a multiple of four rows)
+  const int4 syq = *reinterpret_cast<const int4*>(reinterpret_cast<const char*>(D.yofc) + ((unsigned)cy << 2));
+  const int4 beq = *reinterpret_cast<const int4*>(reinterpret_cast<const char*>(D.ybeta) + ((unsigned)cy << 2));
+  const int syv[4] = {syq.x, syq.y, syq.z, syq.w}, be[4] = {beq.x, beq.y, beq.z, beq.w};
   asm volatile("" ::"s"(cxa), "s"(cxb), "s"(cya), "s"(cyb), "s"(fpw.x), "s"(fpw.y));   // everything above is requested before the first wait
   const uint8_t* src;
   const long long sstride = R.sstride;
