@@ -19,7 +19,13 @@ for it in range(count):
     ini, mn = [(20, 7), (7, 20), (12, 12), (40, 5), (9, 3), (100, 60), (1, 1)][it % 7]
     while min(W, H) / sf ** (nl - 1) < 66:
         nl -= 1
-    if any(round((W / sf ** l - 32) / (H / sf ** l - 32)) < 1 for l in range(nl)):
+    # the exact level sizes (cvRound(cols * invScale), float32 as ORBextractor.cc:975-976) and the reference's nIni =
+    # round(width / height) (ORBextractor.cc:574): nIni == 0 is a division by zero in the reference AND in its restatement
+    isf = OracleExtractor(N, sf, nl, ini, mn, oracle).tables()['isf']
+    def n_ini(l):
+        w, h = int(np.rint(np.float32(W) * isf[l])), int(np.rint(np.float32(H) * isf[l]))
+        return int(np.floor(np.float32(w - 32) / np.float32(h - 32) + np.float32(0.5))) if h > 32 else 0
+    if any(n_ini(l) < 1 for l in range(nl)):
         print(it, 'skipped: a level has no quadtree root (the reference divides by zero)')
         continue
     img = synth(seed * 1000 + it, W, H)
