@@ -117,7 +117,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fas
     roi = P.slab + (long long)f * P.slabBytes + roiOff;
   }
   // LDS carve (level-uniform): ROI tile, score tile with a zero ring, queue (y<<8|x)
-  const int TP = ((fastW + 6 + 3 + 3) & ~3) + tpPad;
+  // (dma == 2: 16-byte LDS-DMA pieces -- the pitch is a multiple of 16 that holds alignment offset + widest ROI row)
+  const int TP = dma == 2 ? ((fastW + 6 + 3 + 15) & ~15) : ((fastW + 6 + 3 + 3) & ~3) + tpPad;
   const int SP = fastW + 2;
   uint8_t* tile = lds;
   const int scOff = (TP * (hCell + 6) + 15) & ~15;   // 16-byte aligned: it is cleared by 16-byte LDS-DMA pieces
@@ -131,7 +132,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fas
   // byte offset of the ROI inside its first dword.
   const int a = (int)(reinterpret_cast<uintptr_t>(roi) & 3);
   if constexpr (ABL == 4) { asm volatile("" ::"s"(a), "s"(istr), "s"(TP) : "memory"); stamp[1] = __builtin_amdgcn_s_memtime(); }
-  if ((stride & 3) == 0 && dma) {
+  if ((stride & 3) == 0 && dma == 2) {
+    // 16 bytes per lane (global_load_lds_dwordx4): TP / 16 pieces per tile row, 64 / pieces rows per instruction -- the 37-row tile
+    // of a single cell is TWO instructions (seven with one dword per lane); the global side needs dword alignment only, a row's last
+    // piece may reach up to 11 bytes past the ROI: inside the level's row (an emit region stays 16 pixels off the border)
+    const int ppr = TP >> 4;
+    const float rn = __builtin_amdgcn_rcpf((float)ppr);
+    const int rpi = 64 / ppr;
+    const int lrow = (int)(((float)lane + 0.5f) * rn), lcol = lane - m24(lrow, ppr);
+    const bool on = lrow < rpi && 16 * lcol < a + rw;
+    const unsigned voff = (unsigned)(m24(lrow, istr) + 16 * lcol);
+    const uint8_t* gp = roi - a;
+    const long long gstep = (long long)rpi * stride;
+    const int lstep = m24(rpi, TP);
+    uint8_t* lp = tile;
+    for (int left = rh; left > 0; left -= rpi, gp += gstep, lp += lstep) {
+      unsigned vo = voff;
+      asm volatile("" : "+s"(gp), "+v"(vo));
+      if (on && lrow < left)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + vo),
+                                         (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
+    }
+  } else if ((stride & 3) == 0 && dma) {
     // LDS-DMA (global_load_lds_dword): the tile's aligned dwords go from memory straight into LDS -- no register round
     // trip, no ds_write, and no per-element address arithmetic: one instruction moves `rpi` whole tile rows (lane = (row,
     // dword column) over the tile pitch; lane L's dword lands at the instruction's LDS base + 4 L, so the lanes of a row group
@@ -497,8 +519,12 @@ static void stamp_buffer_for(size_t waves) {
   (void)hipMemset(s_stampBuf, 0, s_stampWaves * 32);
 }
 
+static int fast_dma_mode() {   // ORBFE_FAST_DMA: 0 ROI through registers, 1 LDS-DMA one dword per lane, 2 LDS-DMA 16 bytes per lane
+  static const int dma = [] { const char* e = getenv("ORBFE_FAST_DMA"); return e ? atoi(e) : 2; }();
+  return dma;
+}
 static size_t fast_lds_bytes_level(const LevelGeom& L, int tpPad) {
-  const size_t TP = ((L.fastW + 6 + 3 + 3) & ~3) + tpPad;
+  const size_t TP = fast_dma_mode() == 2 ? ((L.fastW + 6 + 3 + 15) & ~15) : ((L.fastW + 6 + 3 + 3) & ~3) + tpPad;
   const size_t scOff = (TP * (L.hCell + 6) + 15) & ~(size_t)15;
   const size_t b = ((scOff + (size_t)(L.fastW + 2) * (L.hCell + 2) + 15) & ~(size_t)15) +
                    2 * (size_t)L.fastW * L.hCell + 64;  // tile + score tile + u16 queue + slack for the group over-read
@@ -514,7 +540,7 @@ void launch_fast(const PyramidParams& P, int nframes, hipStream_t st) {
   // 16 pixels per lane in the pre-test: one wave iteration covers a 31 x 31 cell (8 pixels per lane take two and are
   // equal in time, 9.9 us per 1080p frame, with more instructions)
   static const int ablate = [] { const char* e = getenv("ORBFE_FAST_ABLATE"); return e ? atoi(e) : 0; }();   // measurement only
-  static const int dma = [] { const char* e = getenv("ORBFE_FAST_DMA"); return e ? atoi(e) : 1; }();         // 0: ROI through registers (A/B)
+  const int dma = fast_dma_mode();
   static const int split = [] { const char* e = getenv("ORBFE_FAST_LDS_CLASSES"); return e ? atoi(e) : 1; }();   // 0: one launch, the largest level's LDS
   bool pairs = false;
   for (int l = 0; l < P.nlevels; l++) pairs = pairs || P.lv[l].fastW != P.lv[l].wCell;

@@ -669,3 +669,46 @@ def test_stream_matching_dense_clusters(api, oracle, seq, monkeypatch):
         monkeypatch.delenv('ORBFE_SFI_SEQUENTIAL')
     if seq.startswith('cap'):
         monkeypatch.delenv('ORBFE_SFI_MAX_ROUNDS')
+
+
+_STAGING_VARIANT_SCRIPT = r'''
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from os1_amd import api
+from os1_amd.synth import synth, shifted
+from oracle.pyoracle import Oracle, OracleExtractor
+o = Oracle()
+for seed, W, H, N in ((71, 1280, 720, 1500), (72, 803, 601, 700)):
+    img = synth(seed, W, H)
+    imgs = [img, shifted(img, 3, 2, seed + 1), np.ascontiguousarray(img[::-1]), shifted(img, 7, 5, seed + 2)]
+    ox = OracleExtractor(N, 1.2, 8, 20, 7, o)
+    want = [ox.extract(im) for im in imgs]
+    ex = api.Extractor(N, 1.2, 8, 20, 7)
+    for stride_pad in (0, 4, 3):            # a row stride that is / is not a multiple of 4 (the byte-wise staging paths)
+        dev = api.DeviceFrames(imgs, 0, stride=W + stride_pad)
+        kps, desc, n = ex.extract_batch_ptrs(dev.ptrs, H, W, W + stride_pad, True)
+        for i, (wk, wd) in enumerate(want):
+            assert kps[i, :n[i]].tobytes() == wk.tobytes() and desc[i, :n[i]].tobytes() == wd.tobytes(), (seed, stride_pad, i)
+        dev.free()
+    gk, gd = ex(img)
+    assert gk.tobytes() == want[0][0].tobytes() and gd.tobytes() == want[0][1].tobytes()
+print('OK')
+'''
+
+
+@pytest.mark.parametrize('env', [{'ORBFE_FAST_DMA': '0'}, {'ORBFE_FAST_DMA': '1'}, {'ORBFE_DESCRIBE_DMA': '0'}, {'ORBFE_RESIZE_DMA': '0'},
+                                 {'ORBFE_FAST_LDS_CLASSES': '0'}, {'ORBFE_FAST_DMA': '0', 'ORBFE_DESCRIBE_DMA': '0', 'ORBFE_RESIZE_DMA': '0'}])
+def test_staging_variants_agree(env):
+    """How the tiles reach LDS -- LDS-DMA with 16 bytes per lane (default), one dword per lane (ORBFE_FAST_DMA=1), through registers
+    (=0, and ORBFE_DESCRIBE_DMA=0 / ORBFE_RESIZE_DMA=0) -- and one FAST launch instead of one per LDS class: each switch is read once
+    per process, so every setting runs in a process of its own; four-frame batches at two sizes and three row strides, and the one-frame
+    route, against the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, '-c', _STAGING_VARIANT_SCRIPT % root], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith('OK'), (env, r.stdout[-500:], r.stderr[-1500:])
