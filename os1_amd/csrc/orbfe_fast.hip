@@ -66,11 +66,36 @@ __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmc
 // after the pre-test and its compaction (2), after the score stage (3) -- every cell then reports no candidate; 0 = the product;
 // 4 = the product with s_memtime stamps between its phases, summed over all waves into g_fastStamps (orbfe_debug_fast_stamps);
 // 5 = the product without the second pass at minThFAST (what that pass costs)
+// What the kernel needs of PyramidParams, as a compact argument block of its own (136 bytes): the whole of it arrives with the
+// first scalar load of a wave; out of the 1.4 KB PyramidParams the fields came in three dependent groups, the last one behind
+// the task fetch.
+struct FastArgs {
+  const FastTask* tasks;
+  const uint8_t* const* frame0;
+  const uint8_t* frameInline[2];
+  long long stride0;
+  uint8_t* slab;
+  long long slabBytes;
+  uint32_t* cellCount;
+  uint32_t* slots;
+  long long slotsPerFrame;
+  const uint8_t* zeros;
+  int ncells, ntasks, iniTh, minTh, frameBase;
+};
+static FastArgs fast_args(const PyramidParams& P) {
+  FastArgs A{};
+  A.tasks = P.tasks; A.frame0 = P.frame0; A.frameInline[0] = P.frameInline[0]; A.frameInline[1] = P.frameInline[1];
+  A.stride0 = P.stride0; A.slab = P.slab; A.slabBytes = P.slabBytes; A.cellCount = P.cellCount; A.slots = P.slots;
+  A.slotsPerFrame = P.slotsPerFrame; A.zeros = P.zeros; A.ncells = P.ncells; A.ntasks = P.ntasks; A.iniTh = P.iniTh; A.minTh = P.minTh;
+  A.frameBase = P.frameBase;
+  return A;
+}
+
 __device__ uint32_t* g_fastStampBuf;   // [waves of the launch][8]
 template <int NPX, bool PAIRS, int ABL = 0>
 // (amdgpu_num_sgpr(96): the kernel asks for 105 scalar registers by itself, which caps a SIMD at 6 waves; 94 with 3 values parked in
 // a vector register allow 7 -- +1 % in the pipeline, 80 / 88 measured the same)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fast_tasks(PyramidParams P, int tpPad, int dma, int t0, int nt) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fast_tasks(FastArgs P, int tpPad, int dma, int t0, int nt) {
   extern __shared__ __align__(16) uint8_t lds[];
   unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
   if constexpr (ABL == 4) stamp[0] = __builtin_amdgcn_s_memtime();
@@ -541,6 +566,7 @@ void launch_fast(const PyramidParams& P, int nframes, hipStream_t st) {
   // equal in time, 9.9 us per 1080p frame, with more instructions)
   static const int ablate = [] { const char* e = getenv("ORBFE_FAST_ABLATE"); return e ? atoi(e) : 0; }();   // measurement only
   const int dma = fast_dma_mode();
+  const FastArgs FA = fast_args(P);
   static const int split = [] { const char* e = getenv("ORBFE_FAST_LDS_CLASSES"); return e ? atoi(e) : 1; }();   // 0: one launch, the largest level's LDS
   bool pairs = false;
   for (int l = 0; l < P.nlevels; l++) pairs = pairs || P.lv[l].fastW != P.lv[l].wCell;
@@ -567,20 +593,20 @@ void launch_fast(const PyramidParams& P, int nframes, hipStream_t st) {
     if (nt <= 0) continue;
     const dim3 grid(8 * ((nt + 7) / 8), nframes);
     if (pairs)
-      hipLaunchKernelGGL((k_fast_tasks<16, true>), grid, dim3(64), need, st, P, 0, dma, t0, nt);
+      hipLaunchKernelGGL((k_fast_tasks<16, true>), grid, dim3(64), need, st, FA, 0, dma, t0, nt);
     else if (ablate == 1)
-      hipLaunchKernelGGL((k_fast_tasks<16, false, 1>), grid, dim3(64), need, st, P, 0, dma, t0, nt);
+      hipLaunchKernelGGL((k_fast_tasks<16, false, 1>), grid, dim3(64), need, st, FA, 0, dma, t0, nt);
     else if (ablate == 2)
-      hipLaunchKernelGGL((k_fast_tasks<16, false, 2>), grid, dim3(64), need, st, P, 0, dma, t0, nt);
+      hipLaunchKernelGGL((k_fast_tasks<16, false, 2>), grid, dim3(64), need, st, FA, 0, dma, t0, nt);
     else if (ablate == 3)
-      hipLaunchKernelGGL((k_fast_tasks<16, false, 3>), grid, dim3(64), need, st, P, 0, dma, t0, nt);
+      hipLaunchKernelGGL((k_fast_tasks<16, false, 3>), grid, dim3(64), need, st, FA, 0, dma, t0, nt);
     else if (ablate == 5)
-      hipLaunchKernelGGL((k_fast_tasks<16, false, 5>), grid, dim3(64), need, st, P, 0, dma, t0, nt);
+      hipLaunchKernelGGL((k_fast_tasks<16, false, 5>), grid, dim3(64), need, st, FA, 0, dma, t0, nt);
     else if (ablate == 4) {
       if (t0 == 0) stamp_buffer_for((size_t)(P.ntasks + 64) * nframes);
-      hipLaunchKernelGGL((k_fast_tasks<16, false, 4>), grid, dim3(64), need, st, P, 0, dma, t0, nt);
+      hipLaunchKernelGGL((k_fast_tasks<16, false, 4>), grid, dim3(64), need, st, FA, 0, dma, t0, nt);
     } else
-      hipLaunchKernelGGL((k_fast_tasks<16, false>), grid, dim3(64), need, st, P, 0, dma, t0, nt);
+      hipLaunchKernelGGL((k_fast_tasks<16, false>), grid, dim3(64), need, st, FA, 0, dma, t0, nt);
   }
 }
 
