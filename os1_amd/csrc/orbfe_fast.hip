@@ -100,6 +100,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fas
   unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
   if constexpr (ABL == 4) stamp[0] = __builtin_amdgcn_s_memtime();
   // this launch works on tasks [t0, t0 + nt): the levels of one LDS class (launch_fast)
+  // the whole argument block is requested by the wave's first scalar loads, before anything waits (left alone the compiler
+  // fetches t0 / nt, tests the bound below, and only then asks for the rest)
+  asm volatile("" ::"s"(P.tasks), "s"(P.frame0), "s"(P.frameInline[0]), "s"(P.frameInline[1]), "s"(P.stride0), "s"(P.slab), "s"(P.slabBytes),
+               "s"(P.cellCount), "s"(P.slots), "s"(P.slotsPerFrame), "s"(P.zeros), "s"(P.ncells), "s"(P.iniTh), "s"(P.minTh), "s"(P.frameBase),
+               "s"(t0), "s"(nt), "s"(dma), "s"(tpPad));
   const int chunk = (nt + 7) >> 3;
   const int tloc = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
   if (tloc >= nt) return;
