@@ -847,12 +847,28 @@ struct SlotInfo {
   int nlevels;
 };
 
+// What the kernel needs, as one compact argument block (328 bytes instead of PyramidParams + SlotInfo, 1.6 KB): its scalar fields arrive
+// with the wave's first loads, the level record by one indexed load off the argument segment.
+struct DescribeLevel { int w, h, pitch, pad; long long off, pad2; };   // 32 bytes: one s_load_dwordx8
+struct DescribeArgs {
+  DescribeLevel lv[kMaxLevels];
+  const SelKp* sel;
+  const uint32_t* selCount;          // slot mode: [nframes][kMaxLevels]; nullptr: dense mode
+  float* angleOut;
+  uint8_t* descOut;
+  const uint8_t* const* frame0;
+  const uint8_t* frameInline[2];
+  long long stride0;
+  uint8_t* slab;
+  long long slabBytes;
+  int nsel, selPerFrame, nlevels, frameBase, dma;
+  int selOff[kMaxLevels + 1];
+};
+
 // WAVES = 1: one wave per keypoint (batches: throughput).  WAVES = 4: the same passes spread over a block of four waves
 // (one- and two-frame calls: a keypoint's 760 dependent-ish instructions are the latency of the whole kernel there).
 template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void k_describe(PyramidParams P, const SelKp* __restrict__ sel, int nsel,
-                                                          float* __restrict__ angleOut, uint8_t* __restrict__ descOut,
-                                                          SlotInfo SI, int dma) {
+__global__ __launch_bounds__(64 * WAVES) void k_describe(DescribeArgs A) {
   constexpr int NT = 64 * WAVES;
   // Every table a lane will need depends on its lane number only: ALL of them are requested here, before the first wait of
   // the kernel, instead of one dependent round trip per pass iteration (4 + 6 + 5 of them for one wave) -- round 4.
@@ -880,48 +896,74 @@ __global__ __launch_bounds__(64 * WAVES) void k_describe(PyramidParams P, const 
   // frame's level meet in one L2, where each 128-byte line of the level is fetched once however many 43-byte patch
   // rows touch it (the plain mapping spread neighbouring keypoints over all eight L2s: 3.1x the algorithmic bytes,
   // profiles/r02n_pmc_summary.csv)
+  // A wave's life begins with memory round trips nothing can overlap: keep that chain SHORT (as k_fast_tasks does).  The scalar
+  // fields of the argument block are requested by the first loads (pinned below: left alone the compiler fetches them where they are
+  // used, a dependent wait each).  In slot mode the slot index alone gives frame and level, so the liveness count, the keypoint
+  // record, the level-0 pointer (three scalar loads from memory) and the level record (off the argument segment) go out TOGETHER --
+  // one round trip, then the patch request.  (Before round 4: ten dependent round trips; mid-round: three from memory and eight
+  // from the argument segment.)
+  asm volatile("" ::"s"(A.sel), "s"(A.selCount), "s"(A.angleOut), "s"(A.descOut), "s"(A.frame0), "s"(A.frameInline[0]), "s"(A.frameInline[1]),
+               "s"(A.stride0), "s"(A.slab), "s"(A.slabBytes), "s"(A.nsel), "s"(A.selPerFrame), "s"(A.nlevels), "s"(A.frameBase), "s"(A.dma),
+               "s"(A.selOff[1]), "s"(A.selOff[2]), "s"(A.selOff[3]), "s"(A.selOff[4]), "s"(A.selOff[5]), "s"(A.selOff[6]), "s"(A.selOff[7]));
+  const int nsel = A.nsel, dma = A.dma;
+  const SelKp* sel = A.sel;
+  float* angleOut = A.angleOut;
+  uint8_t* descOut = A.descOut;
   const int chunk = (nsel + 7) >> 3;
   const int k = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
   if (k >= nsel) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = WAVES == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
-  // A wave's life begins with memory round trips nothing can overlap: keep that chain SHORT (as k_fast_tasks does).  In slot mode
-  // the slot index alone gives frame and level, so the liveness count, the keypoint record, the level's geometry and the level-0
-  // pointer are four INDEPENDENT scalar loads -- one round trip, then the patch goes out.  (Before round 4: the level by a
-  // loop of dependent argument loads, the count, then the record, then the level table indexed by the record's level, then the
-  // frame pointer by a vector load: ten dependent round trips.)
   typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+  const char __attribute__((address_space(4)))* ka = (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
   int level, f;
-  u32x2 sw;
-  if (SI.selCount) {
-    const int fr = k / SI.selPerFrame, within = k - fr * SI.selPerFrame;
+  u32x2 sw, fpw = {0u, 0u};
+  u32x8 lw;
+  auto frame_ptr_words = [&](int fa) -> u32x2 {   // the level-0 pointer of frame fa as two scalar words
+    u32x2 r;
+    if (A.frame0) {
+      r = *reinterpret_cast<const u32x2 __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(A.frame0 + fa));
+    } else {
+      const unsigned long long v = reinterpret_cast<unsigned long long>((fa & 1) ? A.frameInline[1] : A.frameInline[0]);
+      r.x = (uint32_t)v;
+      r.y = (uint32_t)(v >> 32);
+    }
+    return r;
+  };
+  if (A.selCount) {
+    const int fr = k / A.selPerFrame, within = k - fr * A.selPerFrame;
     int l = 0, lbase = 0;
 #pragma unroll
     for (int j = 1; j < kMaxLevels; j++) {   // selOff ascends: the last level region that starts at or before `within`
-      const int o = SI.selOff[j];
-      if (j < SI.nlevels && within >= o) { l = j; lbase = o; }
+      const int o = A.selOff[j];
+      if (j < A.nlevels && within >= o) { l = j; lbase = o; }
     }
     level = l;
-    f = P.frameBase + fr;
+    f = A.frameBase + fr;
     const uint32_t live = *reinterpret_cast<const uint32_t __attribute__((address_space(4)))*>(
-        reinterpret_cast<uintptr_t>(SI.selCount + (long long)f * kMaxLevels + l));
+        reinterpret_cast<uintptr_t>(A.selCount + (long long)f * kMaxLevels + l));
     sw = *reinterpret_cast<const u32x2 __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(sel + k));
-    asm volatile("" ::"s"(sw.x), "s"(live));   // both requested before the test below
+    fpw = frame_ptr_words(f);
+    lw = *reinterpret_cast<const u32x8 __attribute__((address_space(4)))*>(ka + offsetof(DescribeArgs, lv) + 32 * (unsigned)l);
+    asm volatile("" ::"s"(sw.x), "s"(live), "s"(fpw.x), "s"(lw[0]));   // all four requested before the test below
     if ((uint32_t)(within - lbase) >= live) return;
   } else {
     sw = *reinterpret_cast<const u32x2 __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(sel + k));
     level = (int)(sw.y & 0xffu);
     f = (int)((sw.y >> 8) & 0xffffu);
+    fpw = frame_ptr_words(f);
+    lw = *reinterpret_cast<const u32x8 __attribute__((address_space(4)))*>(ka + offsetof(DescribeArgs, lv) + 32 * (unsigned)level);
   }
   const int cx = (int)(sw.x & 0xffffu), cy = (int)(sw.x >> 16);
-  const LevelGeom& L = P.lv[level];
+  struct { int w, h; } L = {(int)lw[0], (int)lw[1]};
   const uint8_t* img;
   long long stride;
   if (level == 0) {
-    img = level0_of(P, f);
-    stride = P.stride0;
+    img = reinterpret_cast<const uint8_t*>(((unsigned long long)fpw.y << 32) | fpw.x);
+    stride = A.stride0;
   } else {
-    img = P.slab + (long long)f * P.slabBytes + L.off;
-    stride = L.pitch;
+    img = A.slab + (long long)f * A.slabBytes + (long long)(((unsigned long long)lw[5] << 32) | lw[4]);
+    stride = (long long)(int)lw[2];
   }
   // 43x43 raw patch -> LDS.  Interior keypoints (all but those within 21 px of the level border): aligned
   // dword loads, 9 in flight per lane, the patch keeps the byte alignment `pa` of its first pixel.
@@ -1235,25 +1277,35 @@ static int describe_dma() {   // ORBFE_DESCRIBE_DMA=0: the raw patch staged thro
   return v;
 }
 
+static DescribeArgs describe_args(const PyramidParams& P, const SelKp* sel, int nsel, float* angle, uint8_t* desc) {
+  DescribeArgs A{};
+  for (int l = 0; l < kMaxLevels; l++) {
+    A.lv[l].w = P.lv[l].w; A.lv[l].h = P.lv[l].h; A.lv[l].pitch = P.lv[l].pitch; A.lv[l].off = P.lv[l].off;
+  }
+  A.sel = sel; A.selCount = nullptr; A.angleOut = angle; A.descOut = desc;
+  A.frame0 = P.frame0; A.frameInline[0] = P.frameInline[0]; A.frameInline[1] = P.frameInline[1];
+  A.stride0 = P.stride0; A.slab = P.slab; A.slabBytes = P.slabBytes;
+  A.nsel = nsel; A.selPerFrame = 1; A.nlevels = P.nlevels; A.frameBase = P.frameBase; A.dma = describe_dma();
+  return A;
+}
+
 void launch_describe(const PyramidParams& P, const SelKp* sel, int nsel, float* angle, uint8_t* desc,
                      hipStream_t st) {
   if (nsel <= 0) return;
-  SlotInfo si{};
-  si.selCount = nullptr;
-  hipLaunchKernelGGL(k_describe<1>, dim3(8 * ((nsel + 7) / 8)), dim3(64), 0, st, P, sel, nsel, angle, desc, si, describe_dma());
+  const DescribeArgs A = describe_args(P, sel, nsel, angle, desc);
+  hipLaunchKernelGGL(k_describe<1>, dim3(8 * ((nsel + 7) / 8)), dim3(64), 0, st, A);
 }
 
 // sel/angle/desc point at the first slot of frame P.frameBase; nslots = nframes * selPerFrame
 void launch_describe_slots(const PyramidParams& P, const SelKp* sel, int nslots, float* angle, uint8_t* desc,
                            const uint32_t* selCount, int selPerFrame, const int* selOff, hipStream_t st, bool fourWaves) {
   if (nslots <= 0) return;
-  SlotInfo si{};
-  si.selCount = selCount;
-  si.selPerFrame = selPerFrame;
-  si.nlevels = P.nlevels;
-  for (int l = 0; l <= P.nlevels; l++) si.selOff[l] = selOff[l];
-  if (fourWaves) hipLaunchKernelGGL(k_describe<4>, dim3(8 * ((nslots + 7) / 8)), dim3(256), 0, st, P, sel, nslots, angle, desc, si, describe_dma());
-  else hipLaunchKernelGGL(k_describe<1>, dim3(8 * ((nslots + 7) / 8)), dim3(64), 0, st, P, sel, nslots, angle, desc, si, describe_dma());
+  DescribeArgs A = describe_args(P, sel, nslots, angle, desc);
+  A.selCount = selCount;
+  A.selPerFrame = selPerFrame;
+  for (int l = 0; l <= P.nlevels; l++) A.selOff[l] = selOff[l];
+  if (fourWaves) hipLaunchKernelGGL(k_describe<4>, dim3(8 * ((nslots + 7) / 8)), dim3(256), 0, st, A);
+  else hipLaunchKernelGGL(k_describe<1>, dim3(8 * ((nslots + 7) / 8)), dim3(64), 0, st, A);
 }
 
 void launch_sincos(const float* deg, int n, float* c, float* s, hipStream_t st) {
