@@ -439,6 +439,7 @@ def run_rank(args):
             # always timed (roofline), the others appear with ORBFE_PROFILE_KERNELS=1 (costs about 1 % of the rate)
             'gpu_kernel_ms_per_frame': {k: round(v / max(kframes, 1), 5) for k, v in
                                         zip(('pyramid', 'fast_cells', 'compaction', 'describe', 'quadtree'), kms) if v > 0},
+            'ms_per_step_series': [round(float(v), 3) for v in step_ms] if (step_ms is not None and os.environ.get('ORBFE_BENCH_SERIES')) else None,
             'ms_per_step_percentiles': (lambda d: {'p10': round(float(np.percentile(d, 10)), 4), 'p50': round(float(np.percentile(d, 50)), 4),
                                                     'p90': round(float(np.percentile(d, 90)), 4), 'max': round(float(d.max()), 4)})(step_ms) if step_ms is not None and len(step_ms) > 1 else None,
             # CPU time of rank 0's threads over the timed region / its wall time: what a rank needs from the host when
