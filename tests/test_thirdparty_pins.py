@@ -304,3 +304,33 @@ def test_gray_conversion_against_pillow(oracle, tmp_path):
         got = oracle.cvt_gray(np.ascontiguousarray(rgb[..., ::-1]), rgb_order=False, variant=variant).astype(np.int32)
         assert np.abs(got - want).max() <= 1
     assert np.abs(oracle.cvt_gray(rgb, rgb_order=False).astype(np.int32) - want).max() > 30   # the check has teeth
+
+
+def test_committed_thirdparty_vectors(oracle):
+    """The same third-party checks from COMMITTED vectors (tests/golden/thirdparty_vectors.npz <- tools/gen_thirdparty_golden.py, which
+    runs scikit-image 0.18.3 / scipy 1.7.1 under the image's Anaconda python3.9): they hold wherever that interpreter is absent."""
+    import hashlib
+    from oracle.pyoracle import OracleExtractor
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = np.load(os.path.join(root, 'tests', 'golden', 'thirdparty_vectors.npz'))
+    img = g['img']
+    assert np.array_equal(img, _textured(7, 72, 88))
+    want = g['fast_score']
+    for th in (1, 7, 20, 45):
+        got = np.zeros_like(want)
+        k = oracle.fast9(img, th, nms=False)
+        got[k[:, 1], k[:, 0]] = k[:, 2]
+        assert np.array_equal(got, np.where(want >= th, want, 0)), th
+    assert np.array_equal(oracle.gauss7(img), g['blur'])
+    big = np.kron(_textured(9, 96, 128), np.ones((4, 4), np.uint8))
+    big = (big.astype(np.int32) + np.random.RandomState(2).randint(-8, 9, big.shape)).clip(0, 255).astype(np.uint8)
+    assert hashlib.sha256(big.tobytes()).hexdigest() == str(g['big_sha256'][0])
+    kps, desc = OracleExtractor(800, 1.2, 8, 20, 7, oracle).extract(big)
+    n = 0
+    for l in range(8):
+        sel = kps['octave'] == l
+        assert np.array_equal(desc[sel], g['bits%d' % l]), 'level %d: descriptors differ from scikit-image steered BRIEF' % l
+        diff = np.abs((kps[sel]['angle'].astype(np.float64) - g['orient%d' % l] % 360.0 + 180.0) % 360.0 - 180.0)
+        assert diff.max() <= 0.3, (l, diff.max())
+        n += int(sel.sum())
+    assert n == len(kps) > 500
