@@ -389,7 +389,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fas
               ".endr"
               : "+v"(rev), "+v"(addr), "+v"(ent), "=&s"(saved)
               : "n"(NPX)
-              : "vcc", "memory");
+              : "vcc", "scc", "memory");   // (s_and_b64 writes SCC)
         }
         nq += __builtin_amdgcn_readlane(incl, 63);
         if (i0 + 64 >= nItems) break;   // (a single cell is one iteration: its bookkeeping for the next would be ten wasted instructions)
