@@ -334,3 +334,24 @@ def test_committed_thirdparty_vectors(oracle):
         assert diff.max() <= 0.3, (l, diff.max())
         n += int(sel.sum())
     assert n == len(kps) > 500
+
+
+@pytest.mark.gpu
+def test_product_against_committed_thirdparty_vectors():
+    """The HIP path against the COMMITTED scikit-image vectors (no oracle, no second interpreter): descriptors bit for bit, orientations
+    within fastAtan2's 0.3 degrees, for every keypoint of an 8-level extraction."""
+    from os1_amd import api
+    assert api.device_count() >= 1, 'no GPU visible: the product has no CPU fallback'
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = np.load(os.path.join(root, 'tests', 'golden', 'thirdparty_vectors.npz'))
+    big = np.kron(_textured(9, 96, 128), np.ones((4, 4), np.uint8))
+    big = (big.astype(np.int32) + np.random.RandomState(2).randint(-8, 9, big.shape)).clip(0, 255).astype(np.uint8)
+    kps, desc = api.Extractor(800, 1.2, 8, 20, 7)(big)
+    n = 0
+    for l in range(8):
+        sel = kps['octave'] == l
+        assert np.array_equal(desc[sel], g['bits%d' % l]), 'level %d' % l
+        diff = np.abs((kps[sel]['angle'].astype(np.float64) - g['orient%d' % l] % 360.0 + 180.0) % 360.0 - 180.0)
+        assert diff.max() <= 0.3, (l, diff.max())
+        n += int(sel.sum())
+    assert n == len(kps) > 500
