@@ -5,18 +5,22 @@ Metric (BASELINE.json): frames/sec extract+match, 1920x1080 @ 2000 ORB features,
 Workload = BASELINE.json configs[3] per GPU (SURVEY.md s8(d) "Config 4", os1_amd/stream_workload.py): camera stream
 g (seed 100+g) -> GPU g, a pool of 256 DISTINCT 1080p frames (530 MB, larger than the 256 MB Infinity Cache), each
 frame = its predecessor shifted by (2,1) px; the stream walks the pool forwards and backwards.
-A "step" is one pass of the hot path over one batch of 256 frames of the stream (8 submissions of 32 frames to the
-native stream runner): ORBextractor::operator() on every frame and ORBmatcher::SearchForInitialization of every
-frame against its predecessor (window 100, nnratio 0.9, checkOrientation).  Keypoints / descriptors / match indices
+A "step" is one pass of the hot path over one batch of 2 048 frames of the stream (--passes 8 walks over the 256-frame pool, 32
+submissions of 64 frames to the native stream runner; a 256-frame step had become a 3 ms measurement): ORBextractor::operator()
+on every frame and ORBmatcher::SearchForInitialization of every frame against its predecessor (window 100, nnratio 0.9,
+checkOrientation).  Keypoints / descriptors / match indices
 come back to host memory inside the timed region (they are the path's outputs).
 
 `value`: frames resident in HBM when the timed region starts (the task's bench contract).  The same run also times
 the stream with the frames starting in page-locked HOST memory (`pcie_inclusive`: H2D of every frame inside the timed
 region, the figure SURVEY.md s8(d) defines) and prints it next to the measured link rate.
 
-Before anything is timed, the first 4 x 32 frames are pushed through the same runner and their outputs are hashed and
-compared with the oracle-generated digests in tests/golden/stream1080_digests.json: "verified": true means every
-keypoint, descriptor and vnMatches12 entry of those frames is bit-identical to the CPU oracle's.
+Self-check against the oracle's per-position digests (tests/golden/stream1080_digests.json), twice: (1) before anything is
+timed the WHOLE forwards-and-backwards period of the stream (510 positions: every pool frame, the turn-around, every backward
+pair) goes through the same runner; (2) INSIDE the timed region the batch popped last in every step is copied, and after the
+clock has stopped every frame of those copies is checked at its stream position (`verify.timed_verified`,
+`verify.timed_frames_checked`).  "verified": true means every keypoint, descriptor and vnMatches12 entry of both sets is
+bit-identical to the CPU oracle's.
 
 Multi-GPU: independent streams, one process + one stream runner per GPU, no data-path collective; the only cross-rank
 traffic is the barrier and the max-over-ranks of the elapsed time (gloo, CPU tensors).  Started either by the driver
@@ -30,6 +34,7 @@ One JSON line on rank 0 (see the task's bench contract) with extra objects:
   pcie_inclusive -- the same stream from page-locked host frames
 """
 import argparse
+import collections
 import json
 import os
 
@@ -56,7 +61,8 @@ def parse_args():
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=None, help='frames per submission to the stream runner (default: stream_workload.SUBMIT = 64; the digests are per 32 frames whatever this is)')
-    ap.add_argument('--pool', type=int, default=256, help='distinct frames per stream (= frames per step)')
+    ap.add_argument('--pool', type=int, default=256, help='distinct frames per stream')
+    ap.add_argument('--passes', type=int, default=None, help='walks over the pool in one step (default stream_workload.PASSES = 8: a step = 2 048 frames)')
     ap.add_argument('--cpu-frames', type=int, default=64, help='frames of the CPU-oracle baseline sample (0 = skip)')
     ap.add_argument('--bow', action='store_true', help='also run Frame::ComputeBoW (k=10, L=6 synthetic vocabulary) behind the descriptor kernel (not the headline value)')
     ap.add_argument('--no-match', action='store_true', help='extract only (configs[1])')
@@ -172,8 +178,10 @@ def run_rank(args):
 
     W, H, B = wl.W, wl.H, (args.batch or wl.SUBMIT)
     assert args.pool % B == 0, '--pool must be a multiple of --batch'
-    subs = args.pool // B                       # submissions per step
-    cur = {'B': B, 'subs': subs}                # (the PCIe-inclusive leg runs its own runner with 32-frame submissions)
+    passes = args.passes or wl.PASSES
+    step_frames = passes * args.pool            # frames of one step (per GPU)
+    subs = step_frames // B                     # submissions per step
+    cur = {'B': B, 'subs': subs, 'first': True}  # (the PCIe-inclusive leg runs its own runner with 32-frame submissions)
     seed = wl.stream_seed(rank)                 # config 4: stream g -> GPU g, seeds 100+g
     sf = wl.StreamFrames(seed, W, H, args.pool)
     frames = sf.frames()
@@ -196,9 +204,11 @@ def run_rank(args):
     st = make_runner(args.depth)
 
     pos = [0]                                   # stream position of the next pushed frame
+    pending = collections.deque()               # first stream position of every batch pushed and not yet popped
 
     def push(source):
         idx = [wl.pool_index(pos[0] + i, args.pool) for i in range(cur['B'])]
+        pending.append(pos[0])
         pos[0] += cur['B']
         if source == 'hbm':
             st.push_ptrs([dev.ptrs[i] for i in idx], H, W, dev.stride, True)
@@ -228,8 +238,11 @@ def run_rank(args):
         for _ in range(nbatches):
             res = st.pop()
             pop_times.append(time.perf_counter())
+            p0 = pending.popleft()
             if on_pop:
-                on_pop(res)
+                on_pop(p0, res, cur['first'])
+            cur['first'] = False                # the runner has seen a frame: from now on every frame has a predecessor
+            cur['last_n'] = int(res[2][-1])     # vnMatches12 of the next batch's first frame has this many entries
             nmatch_total[0] += int(res[4].sum())
             if pushed < nbatches:
                 push(source)
@@ -247,9 +260,21 @@ def run_rank(args):
         while time.perf_counter() < t_end:
             run(cur['subs'], source)
 
+    samples = []                                # copies of batches popped inside the timed region, checked after the clock stops
+    MAX_SAMPLES = 32
+
     def timed(nsteps, nwarm, source):
         run(nwarm * cur['subs'], source)
         del pop_times[:]
+        del samples[:]
+        every = -(-nsteps // MAX_SAMPLES)           # the last submission of every step (of every 2nd ... when there are more than 32 steps)
+        popped = [0]
+
+        def sample(p0, res, first):
+            popped[0] += 1
+            k, last = divmod(popped[0], cur['subs'])
+            if last == 0 and (k - 1) % every == 0 and table is not None:
+                samples.append((p0, tuple(a.copy() for a in res), cur.get('last_n', 0)))
         st.kernel_ms(reset=True)
         st.stats(reset=True)
         nmatch_total[0] = 0
@@ -258,7 +283,7 @@ def run_rank(args):
             dist.barrier()
         t0 = time.perf_counter()
         c0 = time.process_time()
-        run(nsteps * cur['subs'], source)
+        run(nsteps * cur['subs'], source, sample)
         sync()
         host_cpu[0] = time.process_time() - c0      # CPU seconds of this rank's threads inside the timed region
         if dist is not None:
@@ -270,10 +295,13 @@ def run_rank(args):
             el = float(t[0])
         return el
 
-    # ---- self-check: the first steps of the stream against the committed oracle digests (outside the timed region)
+    # ---- self-check 1: the whole forwards-and-backwards period of the stream against the committed oracle digests (before the
+    # timed region; self-check 2 -- the batches popped INSIDE the timed region -- follows it, see check_samples)
     verify = {'verified': None, 'outputs_sha256': None}
+    table = None
     if not args.no_verify and not args.no_match and not args.bow and args.pool == wl.POOL:
-        verify = verify_first_steps(wl, seed, B, lambda n, cb: run(n, 'hbm', cb))
+        table = load_digest_table(seed)
+        verify = verify_period(wl, table, seed, B, lambda n, cb: run(n, 'hbm', cb))
     if dist is not None:                        # every rank checks its own stream; rank 0 reports the conjunction
         flag = torch.tensor([1 if verify['verified'] else 0, 1 if verify['verified'] is None else 0], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.SUM)
@@ -281,10 +309,33 @@ def run_rank(args):
         if verify['verified'] is not None:
             verify['verified'] = int(flag[0]) == world
 
+    def check_samples():
+        """Self-check 2: every frame of the batches copied inside the timed region against the digests of its stream position."""
+        if table is None:
+            return {'timed_verified': None, 'timed_frames_checked': 0}
+        chk = wl.PositionChecker(table, args.pool)
+        for p0, res, prev_n in samples:
+            chk.check(p0, *res, prev_n=prev_n)
+        out = {'timed_verified': bool(not chk.bad and chk.frames > 0), 'timed_frames_checked': chk.frames,
+               'timed_batches_checked': len(samples), 'timed_distinct_period_positions': len(chk.positions),
+               'timed_stream_positions': [int(samples[0][0]), int(samples[-1][0]) + cur['B'] - 1] if samples else None,
+               'timed_mismatches': chk.bad[:8]}
+        del samples[:]
+        if dist is not None:
+            flag = torch.tensor([1 if out['timed_verified'] else 0, chk.frames], dtype=torch.int64)
+            dist.all_reduce(flag, op=dist.ReduceOp.SUM)
+            out['timed_ranks_verified'], out['timed_frames_checked_all_ranks'] = int(flag[0]), int(flag[1])
+            out['timed_verified'] = int(flag[0]) == world
+        return out
+
     head_source = {'pinned': 'pinned', 'pageable': 'pageable', None: 'hbm'}[args.host_input]
     if args.prewarm_seconds > 0:
         prewarm(head_source, args.prewarm_seconds)
     elapsed = timed(args.steps, args.warmup, head_source)
+    verify.update(check_samples())
+    if verify.get('verified') is not None and verify.get('timed_verified') is not None:
+        verify['verified_before_timing'] = verify['verified']
+        verify['verified'] = bool(verify['verified'] and verify['timed_verified'])
     head_cpu = host_cpu[0]
     cpu_all = head_cpu                            # CPU seconds of every rank's threads inside the timed region, summed
     if dist is not None:
@@ -308,14 +359,17 @@ def run_rank(args):
         if pdepth != max(1, args.depth) or pB != B:
             st.close()
             st = make_runner(pdepth, pB)
-            cur['B'], cur['subs'] = pB, args.pool // pB
+            cur['B'], cur['subs'], cur['first'] = pB, step_frames // pB, True
+            pending.clear()
             st.set_queue_slots(want_lookahead + 2)
             lookahead = min(want_lookahead, st.queue_slots() - 2)
-        psteps, pwarm = max(2, min(args.steps, 40)), max(1, min(args.warmup, 3))
+        psteps, pwarm = max(2, min(args.steps, 12)), max(1, min(args.warmup, 2))
         link = api.h2d_rate_gbs(local_rank, pinned.base, pinned.frame_bytes * pB)
         pel = timed(psteps, pwarm, 'pinned')
-        pfps = world * args.pool * psteps / pel
+        pchk = check_samples()
+        pfps = world * step_frames * psteps / pel
         return {'value': round(pfps, 2), 'unit': 'frames/s', 'steps': psteps, 'warmup': pwarm,
+                'timed_verified': pchk['timed_verified'], 'timed_frames_checked': pchk['timed_frames_checked'],
                 'ms_per_step': round(pel / psteps * 1e3, 4),
                 'input': 'the same %d-frame pool in page-locked host memory (orbfe_host_alloc); H2D of every frame inside the timed region' % args.pool,
                 'batches_in_flight': pdepth, 'frames_per_submission': pB,
@@ -328,7 +382,7 @@ def run_rank(args):
     pcie = pcie_leg() if world > 1 else None
 
     if rank == 0:
-        frames_done = world * args.pool * args.steps
+        frames_done = world * step_frames * args.steps
         fps = frames_done / elapsed
         # roofline of the dominant kernel: k_fast_tasks reads every pyramid pixel once (sum of level
         # sizes) and writes 4 B per surviving candidate; algorithmic bytes per launch = that x B.
@@ -397,7 +451,7 @@ def run_rank(args):
                     'frac_if_all_ops_were_2_cycle': round(rate / (1024 * 2.4e9 / 2.0), 4),
                     'note': 'wave64 VALU instructions (SQ_INSTS_VALU, separate rocprofv3 --pmc pass); peak = 1024 SIMDs x 2.4 GHz / cycles_per_inst'}
         step_ms = np.diff(head_pops[subs - 1::subs]) * 1e3 if len(head_pops) >= 3 * subs else None
-        value_p50 = round(world * args.pool / (float(np.percentile(step_ms, 50)) * 1e-3), 2) if step_ms is not None and len(step_ms) > 1 else None
+        value_p50 = round(world * step_frames / (float(np.percentile(step_ms, 50)) * 1e-3), 2) if step_ms is not None and len(step_ms) > 1 else None
         # the WHOLE path against both roofs (not only its dominant kernel): SURVEY.md s8(d)'s algorithmic 30.03 MB per frame x
         # frames/s against HBM, and the vector instructions of all kernels of a batch (SQ_INSTS_VALU summed over every dispatch of
         # the committed --pmc pass, profiles/counters.json) / (batch period x issue roof at the pipeline's own measured cycles
@@ -420,10 +474,10 @@ def run_rank(args):
             'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
             'config': {'workload': '1080p_2000feat_8lv_1.2_extract%s%s_stream' % ('' if args.no_match else '+SearchForInitialization', '+ComputeBoW' if args.bow else ''),
-                       'frames_per_step_per_gpu': args.pool, 'frames_per_submission': B, 'distinct_frames_per_gpu': args.pool,
+                       'frames_per_step_per_gpu': step_frames, 'passes_over_the_pool_per_step': passes, 'frames_per_submission': B, 'distinct_frames_per_gpu': args.pool,
                        'image': '%dx%d' % (W, H), 'nfeatures': wl.NFEAT, 'nlevels': wl.NLEVELS,
                        'parallelism': 'independent streams, 1 per GPU (no collective)' if world > 1 else 'single GPU',
-                       'matches_per_frame': round(head_matches / max(args.pool * args.steps, 1), 1),
+                       'matches_per_frame': round(head_matches / max(step_frames * args.steps, 1), 1),
                        'input': {'hbm': 'frames resident in HBM (pool of %d distinct frames, %d MB, walked forwards and backwards)' % (args.pool, args.pool * W * H >> 20),
                                  'pinned': 'frames in page-locked host memory (PCIe-inclusive)',
                                  'pageable': 'frames in pageable host memory (PCIe-inclusive)'}[head_source] + '; keypoints/descriptors/matches returned to host',
@@ -469,24 +523,30 @@ def run_rank(args):
         dist.destroy_process_group()
 
 
-def verify_first_steps(wl, seed, B, run):
-    """Push the first steps of the stream through the runner, hash every frame's outputs and compare with the
-    oracle's digests (tests/golden/stream1080_digests.json <- tools/gen_stream_digests.py)."""
+def load_digest_table(seed):
     path = os.path.join(ROOT, 'tests', 'golden', 'stream1080_digests.json')
     try:
-        ref = json.load(open(path))['streams'].get(str(seed))
+        d = json.load(open(path))
+        return d['streams'].get(str(seed)) if d.get('format') == 2 else None
     except Exception:
-        ref = None
-    if not ref:
-        return {'verified': None, 'outputs_sha256': None, 'note': 'no committed digest for seed %d' % seed}
-    hasher = wl.StepHasher()
-    nsub = -(-len(ref['steps']) * wl.BATCH // B)     # submissions of B frames that cover the committed 32-frame steps
-    run(nsub, lambda res: hasher.add(*res))
-    ok = hasher.steps[:len(ref['steps'])] == ref['steps'] and len(hasher.steps) >= len(ref['steps'])
-    import hashlib
-    return {'verified': bool(ok), 'outputs_sha256': hashlib.sha256(''.join(hasher.steps).encode()).hexdigest(),
-            'submissions_checked': nsub, 'frames_per_submission': B, 'frames_checked': len(ref['steps']) * wl.BATCH,
-            'matches_in_checked_frames': hasher.nmatches, 'oracle_matches': ref.get('nmatches'),
+        return None
+
+
+def verify_period(wl, table, seed, B, run):
+    """Push the first period of the stream (510 positions: the pool forwards, the turn-around, the pool backwards) through the runner
+    and compare every frame's outputs with the oracle's digests of its position (tests/golden/stream1080_digests.json <-
+    tools/gen_stream_digests.py).  The runner is fresh: position 0 has no predecessor."""
+    if not table:
+        return {'verified': None, 'outputs_sha256': None, 'note': 'no committed digest table for seed %d' % seed}
+    chk = wl.PositionChecker(table)
+    nsub = -(-wl.PERIOD // B)                        # submissions of B frames that cover the period
+    run(nsub, lambda p0, res, first: chk.check(p0, *res, first_of_runner=first))
+    want = sum(wl.expected_digests(table, p)[2] for p in range(nsub * B))
+    ok = not chk.bad and chk.frames >= wl.PERIOD and len(chk.positions) == wl.PERIOD
+    return {'verified': bool(ok), 'outputs_sha256': chk.outputs_sha256(wl.PERIOD),
+            'submissions_checked': nsub, 'frames_per_submission': B, 'frames_checked': chk.frames,
+            'distinct_period_positions': len(chk.positions), 'period': wl.PERIOD,
+            'matches_in_checked_frames': chk.nmatches, 'oracle_matches': want, 'mismatches': chk.bad[:8],
             'digest_file': 'tests/golden/stream1080_digests.json', 'seed': seed}
 
 

@@ -34,3 +34,26 @@ def oracle_stream_steps(seed, nsteps, batch=wl.BATCH, w=wl.W, h=wl.H, nfeat=wl.N
             prev = (k, d)
         steps.append(wl.step_digest(fh, mh))
     return (steps, total, kept) if keep else (steps, total)
+
+
+def oracle_stream_table(seed, pool=wl.POOL, w=wl.W, h=wl.H, nfeat=wl.NFEAT, keep=False):
+    """Per-position table of stream `seed` (os1_amd.stream_workload.expected_digests): extraction digests of the `pool` frames, match
+    digests of every frame against its predecessor walking forwards (fwd[i]: pred = i-1; fwd[0] = no predecessor) and backwards
+    (bwd[i]: pred = i+1), and the match counts.  About 256 oracle extractions + 510 searches = a minute per stream on one core."""
+    o = Oracle()
+    ox = OracleExtractor(nfeat, wl.SCALE, wl.NLEVELS, wl.INI_TH, wl.MIN_TH, o)
+    sf = wl.StreamFrames(seed, w, h, pool)
+    bounds = (0.0, float(w), 0.0, float(h))
+    ext = [ox.extract(sf.frame(i)) for i in range(pool)]
+
+    def sfi(pred, cur):
+        pk, pd = ext[pred]
+        k, d = ext[cur]
+        nm, m12, _ = o.search_for_initialization(pk, pd, k, d, bounds, np.stack([pk['x'], pk['y']], 1).reshape(-1, 2),
+                                                 wl.WINDOW, wl.NNRATIO, wl.CHECK_ORI)
+        return int(nm), wl.match_digest(nm, m12, len(pk))
+    fwd = [(0, wl.match_digest(0, np.zeros(0, np.int32), 0))] + [sfi(i - 1, i) for i in range(1, pool)]
+    bwd = [sfi(i + 1, i) for i in range(pool - 1)]
+    table = {'frames': [wl.frame_digest(k, d, len(k)) for k, d in ext], 'nkeys': [int(len(k)) for k, _ in ext],
+             'fwd': [m for _, m in fwd], 'nm_fwd': [n for n, _ in fwd], 'bwd': [m for _, m in bwd], 'nm_bwd': [n for n, _ in bwd]}
+    return (table, ext) if keep else table

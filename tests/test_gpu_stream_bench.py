@@ -1,6 +1,7 @@
-"""-m gpu: the workload bench.py measures (BASELINE.json configs[3]: stream seed 100+g, 1920x1080, 2000 features,
-32-frame submissions, 4 batches in flight, SearchForInitialization chained frame to frame and across submissions) against the
-CPU oracle -- live, frame by frame, and through the committed digests bench.py itself checks."""
+"""-m gpu: the workload bench.py measures (BASELINE.json configs[3]: stream seed 100+g, 1920x1080, 2000 features, 4 batches in
+flight, SearchForInitialization chained frame to frame and across submissions) against the CPU oracle -- live, frame by frame, and
+through the committed per-position digests bench.py itself checks: the WHOLE forwards-and-backwards period (510 positions) with 32-
+and with 64-frame submissions (the bench submits 64)."""
 import json
 import os
 import subprocess
@@ -23,21 +24,30 @@ def api():
     return a
 
 
-def _run_stream(api, seed, nsub, depth=4, source='hbm'):
+def _table(seed):
+    assert DIGESTS['format'] == 2
+    return DIGESTS['streams'][str(seed)]
+
+
+def _steps(seed, nsteps):
+    return wl.expected_steps(_table(seed), nsteps)
+
+
+def _run_stream(api, seed, nsub, depth=4, source='hbm', batch=wl.BATCH):
     sf = wl.StreamFrames(seed)
-    idx = [wl.pool_index(p) for p in range(nsub * wl.BATCH)]
+    idx = [wl.pool_index(p) for p in range(nsub * batch)]
     frames = {i: sf.frame(i) for i in sorted(set(idx))}
     order = sorted(frames)
     stack = [frames[i] for i in order]
     dev = api.DeviceFrames(stack, 0) if source == 'hbm' else api.PinnedFrames(stack)
     at = {i: dev.ptrs[k] for k, i in enumerate(order)}
-    st = api.Stream(wl.NFEAT, wl.SCALE, wl.NLEVELS, wl.INI_TH, wl.MIN_TH, 0, wl.BATCH, depth)
+    st = api.Stream(wl.NFEAT, wl.SCALE, wl.NLEVELS, wl.INI_TH, wl.MIN_TH, 0, batch, depth)
     st.set_matching(wl.BOUNDS, wl.WINDOW, wl.NNRATIO, wl.CHECK_ORI)
     pushed = 0
 
     def push():
         nonlocal pushed
-        ptrs = [at[i] for i in idx[pushed * wl.BATCH:(pushed + 1) * wl.BATCH]]
+        ptrs = [at[i] for i in idx[pushed * batch:(pushed + 1) * batch]]
         st.push_ptrs(ptrs, wl.H, wl.W, wl.W, source == 'hbm')
         pushed += 1
     while pushed < min(depth + 2, nsub):
@@ -58,7 +68,7 @@ def test_bench_stream_matches_oracle_frame_by_frame(api, oracle):
     from oracle.stream_ref import oracle_stream_steps
     nlive = 2
     steps, total, kept = oracle_stream_steps(100, nlive, keep=True)
-    assert steps == DIGESTS['streams']['100']['steps'][:nlive], 'committed digests are stale: run tools/gen_stream_digests.py'
+    assert steps == _steps(100, nlive)[0], 'committed digests are stale: run tools/gen_stream_digests.py'
     got = _run_stream(api, 100, 4)
     hasher = wl.StepHasher()
     prev_n = 0
@@ -74,17 +84,40 @@ def test_bench_stream_matches_oracle_frame_by_frame(api, oracle):
                 assert (m12[i, :prev_n] == wm12).all(), (s, i)
                 prev_n = int(n[i])
         hasher.add(kps, desc, n, m12, nm)
-    assert hasher.steps == DIGESTS['streams']['100']['steps']
-    assert hasher.nmatches == DIGESTS['streams']['100']['nmatches'] and hasher.nmatches > 20000
+    want, total = _steps(100, 4)
+    assert hasher.steps == want
+    assert hasher.nmatches == total and hasher.nmatches > 20000
 
 
-@pytest.mark.parametrize('seed', [101, 107])
-def test_other_ranks_streams_against_digests(api, seed):
-    got = _run_stream(api, seed, 4)
+def _check_period(api, seed, batch, **kw):
+    """The whole period (and the first frames of the next one: position 510 = frame 0 WITH predecessor 1) through the runner."""
+    nsub = -(-(wl.PERIOD + 2) // batch)
+    got = _run_stream(api, seed, nsub, batch=batch, **kw)
+    chk = wl.PositionChecker(_table(seed))
     hasher = wl.StepHasher()
-    for res in got:
+    for s, res in enumerate(got):
+        chk.check(s * batch, *res, first_of_runner=(s == 0))
         hasher.add(*res)
-    assert hasher.steps == DIGESTS['streams'][str(seed)]['steps']
+    assert not chk.bad, chk.bad[:10]
+    assert chk.frames == nsub * batch >= wl.PERIOD + 2 and len(chk.positions) == wl.PERIOD
+    want, total = _steps(seed, nsub * batch // wl.BATCH)
+    assert hasher.steps == want and hasher.nmatches == total == chk.nmatches
+    return chk
+
+
+def test_whole_stream_period_against_digests(api):
+    """Stream 100, all 510 positions of the forwards-and-backwards walk -- frames 128..255, the turn-around and every backward pair
+    (frame i matched against i+1) included -- at the parity tests' 32-frame submissions and at the bench's 64 (`stream_workload.SUBMIT`);
+    both must also return the same bytes (outputs digest independent of the submission size)."""
+    a = _check_period(api, 100, wl.BATCH)
+    b = _check_period(api, 100, wl.SUBMIT)
+    assert a.outputs_sha256(wl.PERIOD) == b.outputs_sha256(wl.PERIOD)
+
+
+@pytest.mark.parametrize('seed', [101, 102, 103, 104, 105, 106, 107])
+def test_other_ranks_streams_against_digests(api, seed):
+    """Every other rank's stream: the whole period too (the table holds all 8 streams), 64-frame submissions."""
+    _check_period(api, seed, wl.SUBMIT)
 
 
 def test_host_input_stream_against_digests(api):
@@ -93,7 +126,7 @@ def test_host_input_stream_against_digests(api):
     hasher = wl.StepHasher()
     for res in got:
         hasher.add(*res)
-    assert hasher.steps == DIGESTS['streams']['100']['steps']
+    assert hasher.steps == _steps(100, 4)[0]
 
 
 def _bench(args, extra_env=None):
@@ -107,8 +140,11 @@ def _bench(args, extra_env=None):
 def test_bench_line_is_self_verified(api):
     res = _bench(['--steps', '2', '--warmup', '1', '--cpu-frames', '0'])
     assert res['n_gpus'] == 1 and res['verified'] is True and len(res['outputs_sha256']) == 64
-    assert res['verify']['frames_checked'] == 128
-    assert res['config']['distinct_frames_per_gpu'] == 256 and res['config']['frames_per_step_per_gpu'] == 256
+    v = res['verify']
+    assert v['frames_checked'] >= 510 and v['distinct_period_positions'] == 510 and v['verified_before_timing'] is True
+    assert v['timed_verified'] is True and v['timed_frames_checked'] == 2 * 64 and v['timed_stream_positions'][0] > 2048
+    assert res['pcie_inclusive']['timed_verified'] is True and res['pcie_inclusive']['timed_frames_checked'] > 0
+    assert res['config']['distinct_frames_per_gpu'] == 256 and res['config']['frames_per_step_per_gpu'] == 2048
     assert res['value'] > 1000 and res['pcie_inclusive']['value'] > 1000
     assert res['roofline']['frac'] > 0 and res['roofline']['launch_ms'] > 0
 
@@ -118,7 +154,7 @@ def test_bench_two_ranks_on_one_gpu(api):
     Each rank runs its own stream (seeds 100, 101) through the product and checks it against that seed's digests."""
     res = _bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--no-pcie'], {'ORBFE_BENCH_DEVICE': '0'})
     assert res['n_gpus'] == 2
-    assert res['verified'] is True and res['verify']['ranks_verified'] == 2
+    assert res['verified'] is True and res['verify']['ranks_verified'] == 2 and res['verify']['timed_ranks_verified'] == 2
     assert res['value'] > 1000 and res['config']['parallelism'].startswith('independent streams')
 
 
@@ -130,7 +166,7 @@ def test_bench_eight_ranks_on_one_gpu(api):
     res = _bench(['--gpus', '8', '--steps', '1', '--warmup', '1', '--no-pcie', '--no-latency', '--cpu-frames', '0', '--prewarm-seconds', '0'],
                  {'ORBFE_BENCH_DEVICE': '0'})
     assert res['n_gpus'] == 8
-    assert res['verified'] is True and res['verify']['ranks_verified'] == 8
+    assert res['verified'] is True and res['verify']['ranks_verified'] == 8 and res['verify']['timed_ranks_verified'] == 8
     assert res['value'] > 1000 and res['config']['parallelism'].startswith('independent streams')
     assert 0 < res['host_cpu_cores_used_all_ranks'] < 64
 

@@ -122,9 +122,23 @@ def test_bench_stream_definition():
     assert all(abs(a - b) == 1 for a, b in zip(seq, seq[1:]))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     d = json.load(open(os.path.join(root, 'tests', 'golden', 'stream1080_digests.json')))
-    assert sorted(d['streams']) == [str(wl.stream_seed(g)) for g in range(8)]
-    assert all(len(v['steps']) == 4 and v['nmatches'] > 20000 for v in d['streams'].values())
-    assert d['workload']['batch'] == wl.BATCH and d['workload']['image'] == [wl.W, wl.H]
+    assert sorted(d['streams']) == [str(wl.stream_seed(g)) for g in range(8)] and d['format'] == 2
+    for v in d['streams'].values():      # per-position table: every pool frame, every forward and every backward pair
+        assert len(v['frames']) == wl.POOL == len(v['fwd']) == len(v['nm_fwd']) and len(v['bwd']) == wl.POOL - 1 == len(v['nm_bwd'])
+        assert len(set(v['frames'])) == wl.POOL and min(v['nm_fwd'][1:]) > 100 and min(v['nm_bwd']) > 100 and v['nm_fwd'][0] == 0
+    assert d['workload']['batch'] == wl.BATCH and d['workload']['image'] == [wl.W, wl.H] and d['workload']['period'] == wl.PERIOD == 510
+    # position -> (frame, predecessor): forwards, the turn-around at 255, backwards, the second period starts WITH a predecessor
+    t = d['streams']['100']
+    assert wl.expected_digests(t, 0) == (t['frames'][0], t['fwd'][0], 0)
+    assert wl.expected_digests(t, 7)[:2] == (t['frames'][7], t['fwd'][7])
+    assert wl.expected_digests(t, 255)[:2] == (t['frames'][255], t['fwd'][255])
+    assert wl.expected_digests(t, 256)[:2] == (t['frames'][254], t['bwd'][254])
+    assert wl.expected_digests(t, 509)[:2] == (t['frames'][1], t['bwd'][1])
+    assert wl.expected_digests(t, 510)[:2] == (t['frames'][0], t['bwd'][0])
+    assert wl.expected_digests(t, 511)[:2] == (t['frames'][1], t['fwd'][1])
+    assert wl.expected_digests(t, 300, first_of_runner=True)[:2] == (t['frames'][wl.pool_index(300)], t['fwd'][0])
+    steps, total = wl.expected_steps(t, 16)
+    assert len(set(steps)) == 16 and total > 100000
     # digest helpers: order and content sensitive
     k = np.zeros(3, dtype=[('x', 'f4'), ('y', 'f4')])
     a = wl.frame_digest(k, np.zeros((3, 32), np.uint8), 3)
@@ -178,3 +192,55 @@ def test_step_hasher_folds_any_submission_size():
         assert len(h.steps) == nfr // wl.BATCH
         want = want or h.steps
         assert h.steps == want and h.nmatches == int(nm.sum())
+
+
+def test_position_checker_finds_what_step_digests_cannot_place():
+    """PositionChecker (what bench.py uses for the period check and for the batches popped inside its timed region): a synthetic
+    stream over a 6-frame pool whose outputs depend on (frame, predecessor) the way the runner's do.  Any submission size, a batch
+    picked from the middle of the stream (with the predecessor's keypoint count handed in), a fresh runner in mid-stream; a flipped
+    descriptor bit or match entry is reported at its position."""
+    from os1_amd import stream_workload as wl
+    from oracle.pyoracle import KP_DTYPE
+    pool, cap = 6, 12
+    rng = np.random.default_rng(9)
+    nk = rng.integers(4, cap, pool)
+    K = np.zeros((pool, cap), KP_DTYPE)
+    K['x'] = rng.random((pool, cap))
+    D = rng.integers(0, 256, (pool, cap, 32), dtype=np.uint8)
+
+    def match(pred, cur):
+        if pred is None:
+            return 0, np.zeros(cap, np.int32)
+        r = np.random.default_rng(pred * 16 + cur)
+        return int(r.integers(1, 4)), r.integers(-1, 5, cap).astype(np.int32)
+    table = {'frames': [wl.frame_digest(K[i], D[i], nk[i]) for i in range(pool)],
+             'fwd': [wl.match_digest(*match(None, 0), 0)] + [wl.match_digest(*match(i - 1, i), nk[i - 1]) for i in range(1, pool)],
+             'nm_fwd': [0] + [match(i - 1, i)[0] for i in range(1, pool)],
+             'bwd': [wl.match_digest(*match(i + 1, i), nk[i + 1]) for i in range(pool - 1)], 'nm_bwd': [match(i + 1, i)[0] for i in range(pool - 1)]}
+
+    def batch(p0, nb, fresh=False):
+        idx = [wl.pool_index(p, pool) for p in range(p0, p0 + nb)]
+        pred = [None if (p == 0 or (fresh and p == p0)) else wl.pool_index(p - 1, pool) for p in range(p0, p0 + nb)]
+        mm = [match(a, b) for a, b in zip(pred, idx)]
+        return K[idx].copy(), D[idx].copy(), nk[idx].astype(np.int32), np.stack([m for _, m in mm]), np.array([n for n, _ in mm], np.int32)
+    for sub in (1, 3, 4, 10):
+        c = wl.PositionChecker(table, pool)
+        for p0 in range(0, 40, sub):
+            c.check(p0, *batch(p0, sub), first_of_runner=(p0 == 0))
+        assert not c.bad and c.frames >= 40 and len(c.positions) == 2 * pool - 2
+    c = wl.PositionChecker(table, pool)
+    assert c.check(23, *batch(23, 5), prev_n=int(nk[wl.pool_index(22, pool)])) and c.frames == 5
+    assert wl.PositionChecker(table, pool).check(17, *batch(17, 4, fresh=True), first_of_runner=True)
+    assert not wl.PositionChecker(table, pool).check(17, *batch(17, 4), first_of_runner=True)       # has a predecessor, checker told otherwise
+    k, d, n, m, nm = batch(8, 4)
+    d[2, 1, 5] ^= 4
+    m[3, 0] += 1
+    c = wl.PositionChecker(table, pool)
+    c.check(8, k, d, n, m, nm, prev_n=int(nk[wl.pool_index(7, pool)]))
+    assert c.bad == [(10, 'frame'), (11, 'match')]
+    a = wl.PositionChecker(table, pool); b = wl.PositionChecker(table, pool)
+    for p0 in range(0, 12, 3):
+        a.check(p0, *batch(p0, 3), first_of_runner=(p0 == 0))
+    for p0 in range(0, 12, 4):
+        b.check(p0, *batch(p0, 4), first_of_runner=(p0 == 0))
+    assert a.outputs_sha256(10) == b.outputs_sha256(10) and a.outputs_sha256(10) != a.outputs_sha256(9)
