@@ -127,6 +127,19 @@ enum { ORBFE_INPUT_GRAY8 = 0, ORBFE_INPUT_RGB8 = 1, ORBFE_INPUT_BGR8 = 2, ORBFE_
 enum { ORBFE_GRAY_Q15 = 0, ORBFE_GRAY_Q14 = 1 };
 int orbfe_extractor_set_input_format(orbfe_extractor* h, int format, int gray_variant);
 
+/* Which cv::GaussianBlur(7x7, sigma 2) the descriptors are sampled from (src/ORBextractor.cc:949-950 -- it decides every descriptor
+ * bit).  OpenCV's 8-bit path is 8.8 fixed point; the taps depend on the release the reference was BUILT with (nothing in the
+ * reference pins it: .cproject:40 names "opencv4", README.md:18 dates the project Feb 2019 = the 4.0.x era):
+ *   ORBFE_GAUSS_ED       [18,34,48,56,48,34,18] / 256, rounding error diffused so that the taps add up to 256 -- OpenCV >= 4.1.1
+ *                        (and 3.4.7+); the default;
+ *   ORBFE_GAUSS_ROUNDED  [18,34,49,55,49,34,18] (sum 257), every tap rounded on its own, and the saturating final cast that
+ *                        arithmetic needs: min(255, (sum + 32768) >> 16) -- OpenCV 4.0.0 - 4.1.0 (and 3.4.2 - 3.4.6).
+ * Both are restated from upstream from memory (parity unpinned); tests/test_opencv_live.py picks the expected one
+ * from cv2.__version__ wherever an OpenCV exists.  The environment variable ORBFE_GAUSS_VARIANT=0|1 presets it for every
+ * extractor created afterwards (for a caller that cannot be recompiled). */
+enum { ORBFE_GAUSS_ED = 0, ORBFE_GAUSS_ROUNDED = 1 };
+int orbfe_extractor_set_blur_variant(orbfe_extractor* h, int variant);
+
 /* void ORBextractor::operator()(InputArray image, InputArray mask, vector<KeyPoint>& keypoints,
  *                               OutputArray descriptors)
  * (include/ORBextractor.h:185-187, src/ORBextractor.cc:907-969).
@@ -234,6 +247,8 @@ int orbfe_stream_set_matching(orbfe_stream* s, const float bounds[4], int window
                               int check_orientation);
 /* orbfe_extractor_set_input_format for every extractor of the runner (only while no batch is in flight). */
 int orbfe_stream_set_input_format(orbfe_stream* s, int format, int gray_variant);
+/* orbfe_extractor_set_blur_variant for every extractor of the runner (only while no batch is in flight). */
+int orbfe_stream_set_blur_variant(orbfe_stream* s, int variant);
 /* orbfe_extractor_set_vocabulary for every extractor of the runner (only while no batch is in flight); afterwards
  * orbfe_stream_bow_raw returns, for frame `frame` of the LAST POPPED batch, the per-keypoint (leaf node, level node)
  * pairs (pointers into the runner's buffers, valid until the next pop; feed them to orbfe_bow_assemble). */

@@ -7,10 +7,24 @@
 #error "include/orbfe/ORBextractor.h needs OpenCV headers; use include/orbfe/orb_shim.hpp (cv-free) instead"
 #else
 #include <opencv2/core/core.hpp>
+#if __has_include(<opencv2/core/version.hpp>)
+#include <opencv2/core/version.hpp>
+#endif
 
+#include <cstdlib>
 #include <vector>
 
 #include "orb_shim.hpp"
+
+// cv::GaussianBlur's 8-bit taps changed between OpenCV releases (orbfe.h, orbfe_extractor_set_blur_variant): reproduce the blur of
+// the OpenCV this translation unit is compiled against -- the one the reference's own ORBextractor.cc:950 would have called.
+// 4.0.0 - 4.1.0 and 3.4.2 - 3.4.6: taps rounded one by one (sum 257); later releases: error-diffused taps (sum 256).
+#if defined(CV_VERSION_MAJOR) && ((CV_VERSION_MAJOR == 4 && (CV_VERSION_MINOR == 0 || (CV_VERSION_MINOR == 1 && CV_VERSION_REVISION == 0))) || \
+                                  (CV_VERSION_MAJOR == 3 && CV_VERSION_MINOR == 4 && CV_VERSION_REVISION >= 2 && CV_VERSION_REVISION <= 6))
+#define ORBFE_FACADE_GAUSS_VARIANT ORBFE_GAUSS_ROUNDED
+#else
+#define ORBFE_FACADE_GAUSS_VARIANT ORBFE_GAUSS_ED
+#endif
 
 namespace ORB_SLAM2 {
 
@@ -19,6 +33,7 @@ class ORBextractor {
   ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
       : impl_(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, orbfe::detail::defaultDevice()) {   // ORBFE_DEVICE, as the matcher
     mvImagePyramid.resize(nlevels);  // kept for source compatibility; the pyramid lives in HBM
+    if (!std::getenv("ORBFE_GAUSS_VARIANT")) impl_.SetBlurVariant(ORBFE_FACADE_GAUSS_VARIANT);   // the environment wins (orbfe.h)
   }
   ~ORBextractor() {}
 

@@ -107,6 +107,13 @@ class Extractor {
   Extractor(const Extractor&) = delete;
   Extractor& operator=(const Extractor&) = delete;
 
+  // Which cv::GaussianBlur the descriptors are sampled from (ORBextractor.cc:949-950): ORBFE_GAUSS_ED = OpenCV >= 4.1.1 (default),
+  // ORBFE_GAUSS_ROUNDED = OpenCV 4.0.0 - 4.1.0.  The cv-typed facade calls this with the variant of the OpenCV it is compiled against.
+  void SetBlurVariant(int variant) {
+    std::lock_guard<std::mutex> g(mu_);
+    check(orbfe_extractor_set_blur_variant(h_, variant));
+  }
+
   // operator() core: KeyPointT must have cv::KeyPoint's 28-byte layout.
   template <class KeyPointT>
   void extract(const uint8_t* gray, int rows, int cols, size_t step, std::vector<KeyPointT>& keypoints,

@@ -16,14 +16,19 @@
 //       7x7 s=2, cv::fastAtan2, cvRound/cvFloor/cvCeil) restate OpenCV 4.x's *published
 //       generic (non-IPP, non-FMA) algorithms*; the variant chosen is:
 //         - GaussianBlur: 8.8 fixed-point kernel, error-diffused rounding (OpenCV >= 4.1.1):
-//           [18,34,48,56,48,34,18]/256, reflect-101, (S + 32768) >> 16;
+//           [18,34,48,56,48,34,18]/256, reflect-101, (S + 32768) >> 16 -- the default; variant 1
+//           (orc_extractor_set_gauss_variant) is the plainly rounded kernel of OpenCV 4.0.0 - 4.1.0
+//           (and 3.4.2 - 3.4.6), [18,34,49,55,49,34,18] (sum 257), with the final saturation its
+//           ufixedpoint arithmetic needs: min(255, (S + 32768) >> 16);
 //         - resize: INTER_RESIZE_COEF_BITS = 11 fixed-point bilinear;
 //         - fastAtan2: 7th-order odd polynomial, float32, no FMA contraction;
 //         - cosf/sinf: this image's glibc (2.35) float routines;
 //       they are pinned by first-principles known-answer tests in tests/test_oracle_kat.py.
 //   Hazard H1: the reference breaks ties between equal-sized quadtree nodes by
 //   heap address (ORBextractor.cc:716); this oracle uses node creation order instead
-//   (later-created node == "larger pointer").
+//   (later-created node == "larger pointer").  orc_extractor_set_tie_rule selects the opposite
+//   rule, the real addresses of this process's list nodes, or a seeded random order, so that
+//   tools/h1_sensitivity.py can MEASURE how much of the output hangs on that tie-break.
 //
 // Build: g++ -O3 -std=gnu++17 -ffp-contract=off (mirrors the reference's -O3, no arch flags;
 // contraction off so x*b+y*a and the atan polynomial round like separate mul/add).
@@ -159,15 +164,32 @@ void gauss_kernel_fixed_ed(int n, double sigma, int out[]) {
   out[n / 2] = 256 - 2 * isum;
 }
 
+// Variant 1: OpenCV 4.0.0 - 4.1.0 (3.4.2 - 3.4.6).  getFixedpointGaussianKernel there converts every normalised tap on its own,
+// ufixedpoint16(double) = cvRound(v * 256): [18,34,49,55,49,34,18], sum 257.  (Recalled from upstream, like variant 0: unpinned.)
+void gauss_kernel_fixed_rounded(int n, double sigma, int out[]) {
+  std::vector<double> k(n);
+  double sum = 0;
+  for (int i = 0; i < n; i++) {
+    double x = i - (n - 1) * 0.5;
+    k[i] = std::exp(-0.5 * x * x / (sigma * sigma));
+    sum += k[i];
+  }
+  for (int i = 0; i < n; i++) out[i] = cv_round(k[i] / sum * 256.0);
+}
+
 inline int reflect101(int i, int n) {
   if (n == 1) return 0;
   while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
   return i;
 }
 
-void gauss7_u8(const View& s, uint8_t* dst, ptrdiff_t dstride) {
+// variant 0: error-diffused taps (sum 256: no intermediate or final saturation can occur).  variant 1: rounded taps (sum 257): the
+// horizontal sums reach at most 257 * 255 = 65 535 (still a ufixedpoint16 without saturation), the vertical ones 257 * 65 535 < 2^32,
+// and the rounded result can be 256 or 257 over an (almost) white neighbourhood: saturate_cast<uchar> clips it to 255.
+void gauss7_u8(const View& s, uint8_t* dst, ptrdiff_t dstride, int variant = 0) {
   int k[7];
-  gauss_kernel_fixed_ed(7, 2.0, k);
+  if (variant == 1) gauss_kernel_fixed_rounded(7, 2.0, k);
+  else gauss_kernel_fixed_ed(7, 2.0, k);
   const int w = s.w, h = s.h;
   std::vector<uint16_t> hb((size_t)w * h);
   for (int y = 0; y < h; y++) {
@@ -183,7 +205,8 @@ void gauss7_u8(const View& s, uint8_t* dst, ptrdiff_t dstride) {
     for (int x = 0; x < w; x++) {
       uint32_t acc = 0;
       for (int t = 0; t < 7; t++) acc += (uint32_t)k[t] * hb[(size_t)reflect101(y + t - 3, h) * w + x];
-      D[x] = (uint8_t)((acc + 32768u) >> 16);
+      const uint32_t v = (acc + 32768u) >> 16;
+      D[x] = (uint8_t)(v > 255u ? 255u : v);
     }
   }
 }
@@ -348,7 +371,9 @@ struct Node {
   int ULx, ULy, URx, URy, BLx, BLy, BRx, BRy;
   std::list<Node>::iterator lit;
   bool noMore = false;
-  long seq = 0;  // creation order: stands in for the heap address in the (size, ptr) sort (H1)
+  int32_t seq = 0;  // creation order: stands in for the heap address in the (size, ptr) sort (H1).  In the padding behind the flag:
+                    // sizeof(Node) == 72 == sizeof(ExtractorNode) (vector + 4 Point2i + iterator + bool), so tie rule 2 compares
+                    // addresses of heap blocks of the reference's size class
 
   void divide(Node& n1, Node& n2, Node& n3, Node& n4) const {
     const int halfX = (int)std::ceil(static_cast<float>(URx - ULx) / 2);
@@ -369,6 +394,8 @@ struct Node {
     n4.URx = n2.BRx; n4.URy = n2.BRy;
     n4.BLx = n3.BRx; n4.BLy = n3.BRy;
     n4.BRx = BRx; n4.BRy = BRy;
+    // ORBextractor.cc:524,530,536,542: no effect on the result; kept so that the heap sees the reference's allocation pattern (tie rule 2)
+    n1.keys.reserve(keys.size()); n2.keys.reserve(keys.size()); n3.keys.reserve(keys.size()); n4.keys.reserve(keys.size());
     for (size_t i = 0; i < keys.size(); i++) {
       const OrcKeyPoint& kp = keys[i];
       if (kp.x < n1.URx) {
@@ -383,10 +410,21 @@ struct Node {
   }
 };
 
+static_assert(sizeof(Node) == 72, "Node must have the size of the reference's ExtractorNode (tie rule 2)");
+
+// How `sort(vPrevSizeAndPointerToNode)` (ORBextractor.cc:716) orders nodes of EQUAL size -- the reference compares heap addresses (H1):
+//   0  creation order, a later node counts as the larger pointer (the pinned rule of this oracle and of the product)
+//   1  the opposite: an earlier node counts as the larger pointer
+//   2  the real addresses of the std::list nodes of THIS process (same node size and allocation pattern as the reference; what the
+//      reference does on this allocator -- a function of the heap's history, not of the image)
+//   3+ a seeded pseudo-random order (seed = rule)
+struct TieStats { long sorts = 0, sorted_nodes = 0, nodes_in_ties = 0, breaks = 0, breaks_inside_a_tie = 0; };
+TieStats g_tieStats;
+
 // DistributeOctTree -- ORBextractor.cc:571-795.
 std::vector<OrcKeyPoint> distribute_octtree(const std::vector<OrcKeyPoint>& vToDistributeKeys, int minX,
-                                            int maxX, int minY, int maxY, int N) {
-  long seq = 0;
+                                            int maxX, int minY, int maxY, int N, int tieRule = 0) {
+  int32_t seq = 0;
   const int nIni = (int)std::round(static_cast<float>(maxX - minX) / (maxY - minY));
   const float hX = static_cast<float>(maxX - minX) / nIni;
   std::list<Node> lNodes;
@@ -398,6 +436,7 @@ std::vector<OrcKeyPoint> distribute_octtree(const std::vector<OrcKeyPoint>& vToD
     ni.BLx = ni.ULx; ni.BLy = maxY - minY;
     ni.BRx = ni.URx; ni.BRy = maxY - minY;
     ni.seq = seq++;
+    ni.keys.reserve(vToDistributeKeys.size());   // ORBextractor.cc:590
     lNodes.push_back(ni);
     vpIniNodes[i] = &lNodes.back();
   }
@@ -413,10 +452,22 @@ std::vector<OrcKeyPoint> distribute_octtree(const std::vector<OrcKeyPoint>& vToD
 
   bool bFinish = false;
   typedef std::pair<int, Node*> SizeNode;
-  auto by_size_then_age = [](const SizeNode& a, const SizeNode& b) {
-    return a.first != b.first ? a.first < b.first : a.second->seq < b.second->seq;
+  auto scramble = [tieRule](int32_t q) {
+    uint64_t z = ((uint64_t)(uint32_t)q + 1) * 0x9E3779B97F4A7C15ull + (uint64_t)tieRule * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+  };
+  auto by_size_then_age = [&](const SizeNode& a, const SizeNode& b) {
+    if (a.first != b.first) return a.first < b.first;
+    switch (tieRule) {
+      case 0: return a.second->seq < b.second->seq;
+      case 1: return a.second->seq > b.second->seq;
+      case 2: return std::less<const Node*>()(a.second, b.second);
+      default: return scramble(a.second->seq) < scramble(b.second->seq);
+    }
   };
   std::vector<SizeNode> vSizeAndPointerToNode;
+  vSizeAndPointerToNode.reserve(lNodes.size() * 4);   // ORBextractor.cc:625
 
   // push children n1..n4 to the front (those with keys), recording the ones with >1 key
   auto push_children = [&](Node* ch[4], int& nToExpand) {
@@ -455,6 +506,11 @@ std::vector<OrcKeyPoint> distribute_octtree(const std::vector<OrcKeyPoint>& vToD
         std::vector<SizeNode> vPrev = vSizeAndPointerToNode;
         vSizeAndPointerToNode.clear();
         std::sort(vPrev.begin(), vPrev.end(), by_size_then_age);
+        g_tieStats.sorts++;
+        g_tieStats.sorted_nodes += (long)vPrev.size();
+        for (size_t q = 0; q < vPrev.size(); q++)
+          if ((q > 0 && vPrev[q - 1].first == vPrev[q].first) || (q + 1 < vPrev.size() && vPrev[q + 1].first == vPrev[q].first))
+            g_tieStats.nodes_in_ties++;
         for (int j = (int)vPrev.size() - 1; j >= 0; j--) {
           Node n1, n2, n3, n4;
           vPrev[j].second->divide(n1, n2, n3, n4);
@@ -462,7 +518,11 @@ std::vector<OrcKeyPoint> distribute_octtree(const std::vector<OrcKeyPoint>& vToD
           int dummy = 0;
           push_children(ch, dummy);
           lNodes.erase(vPrev[j].second->lit);
-          if ((int)lNodes.size() >= N) break;
+          if ((int)lNodes.size() >= N) {
+            g_tieStats.breaks++;
+            if (j > 0 && vPrev[j - 1].first == vPrev[j].first) g_tieStats.breaks_inside_a_tie++;   // an equal-sized node stays undivided
+            break;
+          }
         }
         if ((int)lNodes.size() >= N || (int)lNodes.size() == prevSize) bFinish = true;
       }
@@ -494,6 +554,8 @@ struct Extractor {
   std::vector<Image> pyramid;                         // mvImagePyramid (without the dead 19-px border)
   std::vector<std::vector<OrcKeyPoint>> lastCandidates;  // per level, pre-quadtree (for stage tests)
   std::vector<Image> lastBlurred;
+  int gaussVariant = 0;   // 0: error-diffused taps (OpenCV >= 4.1.1), 1: rounded taps + saturation (4.0.0 - 4.1.0)
+  int tieRule = 0;        // H1, see distribute_octtree
 
   Extractor(int nf, float sf, int nl, int ini, int mn)
       : nfeatures(nf), scaleFactor(sf), nlevels(nl), iniThFAST(ini), minThFAST(mn) {
@@ -597,7 +659,7 @@ struct Extractor {
       lastCandidates[level] = vToDistributeKeys;
       std::vector<OrcKeyPoint>& keypoints = allKeypoints[level];
       keypoints = distribute_octtree(vToDistributeKeys, minBorderX, maxBorderX, minBorderY, maxBorderY,
-                                     mnFeaturesPerLevel[level]);
+                                     mnFeaturesPerLevel[level], tieRule);
       const int scaledPatchSize = PATCH_SIZE * mvScaleFactor[level];
       for (OrcKeyPoint& kp : keypoints) {
         kp.x += minBorderX;
@@ -632,7 +694,7 @@ struct Extractor {
       if (nkeypointsLevel == 0) continue;
       Image& working = lastBlurred[level];
       working.alloc(pyramid[level].w, pyramid[level].h);
-      gauss7_u8(pyramid[level].view(), working.d.data(), working.w);
+      gauss7_u8(pyramid[level].view(), working.d.data(), working.w, gaussVariant);
       const View wv = working.view();
       for (int i = 0; i < nkeypointsLevel; i++) orb_descriptor(keypoints[i], wv, &desc[(size_t)(offset + i) * 32]);
       offset += nkeypointsLevel;
@@ -759,6 +821,21 @@ void orc_sincos_host(float angle_deg, float* a, float* b) {
   *b = sinf(ang);
 }
 void orc_gauss_kernel(int n, double sigma, int* out) { gauss_kernel_fixed_ed(n, sigma, out); }
+void orc_gauss_kernel_variant(int n, double sigma, int variant, int* out) {
+  if (variant == 1) gauss_kernel_fixed_rounded(n, sigma, out);
+  else gauss_kernel_fixed_ed(n, sigma, out);
+}
+void orc_gauss7_u8_variant(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride, int variant) {
+  gauss7_u8(View{src, w, h, sstride}, dst, dstride, variant);
+}
+void orc_extractor_set_gauss_variant(void* h, int variant) { ((Extractor*)h)->gaussVariant = variant; }
+void orc_extractor_set_tie_rule(void* h, int rule) { ((Extractor*)h)->tieRule = rule; }
+// {sorts, nodes sorted, nodes that had an equal-sized neighbour, early breaks, breaks that left an equal-sized node undivided}
+void orc_tie_stats(long* out5, int reset) {
+  out5[0] = g_tieStats.sorts; out5[1] = g_tieStats.sorted_nodes; out5[2] = g_tieStats.nodes_in_ties;
+  out5[3] = g_tieStats.breaks; out5[4] = g_tieStats.breaks_inside_a_tie;
+  if (reset) g_tieStats = TieStats();
+}
 
 void orc_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride, uint8_t* dst, int dw, int dh,
                           int dstride) {

@@ -43,6 +43,11 @@ class Oracle:
         L.orc_gauss_kernel.argtypes = [C.c_int, C.c_double, C.c_void_p]
         L.orc_resize_linear_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orc_gauss7_u8.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.orc_gauss7_u8_variant.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.orc_gauss_kernel_variant.argtypes = [C.c_int, C.c_double, C.c_int, C.c_void_p]
+        L.orc_extractor_set_gauss_variant.argtypes = [C.c_void_p, C.c_int]
+        L.orc_extractor_set_tie_rule.argtypes = [C.c_void_p, C.c_int]
+        L.orc_tie_stats.argtypes = [C.c_void_p, C.c_int]
         L.orc_fast9.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.orc_fast_score_bruteforce.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         L.orc_distribute_octtree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -107,10 +112,17 @@ class Oracle:
         self.L.orc_sincos_host(angle_deg, C.byref(a), C.byref(b))
         return a.value, b.value
 
-    def gauss_kernel(self, n=7, sigma=2.0):
+    def gauss_kernel(self, n=7, sigma=2.0, variant=0):
+        """variant 0: error-diffused 8.8 taps (OpenCV >= 4.1.1); 1: plainly rounded taps (4.0.0 - 4.1.0)."""
         k = np.zeros(n, np.int32)
-        self.L.orc_gauss_kernel(n, sigma, _p(k))
+        self.L.orc_gauss_kernel_variant(n, sigma, variant, _p(k))
         return k
+
+    def tie_stats(self, reset=True):
+        """H1 bookkeeping of every quadtree run since the last reset: dict(sorts, sorted_nodes, nodes_in_ties, breaks, breaks_inside_a_tie)."""
+        out = np.zeros(5, np.int64)
+        self.L.orc_tie_stats(_p(out), int(reset))
+        return dict(zip(('sorts', 'sorted_nodes', 'nodes_in_ties', 'breaks', 'breaks_inside_a_tie'), (int(v) for v in out)))
 
     def resize(self, src, dw, dh):
         src = np.ascontiguousarray(src, np.uint8)
@@ -118,10 +130,10 @@ class Oracle:
         self.L.orc_resize_linear_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dw, dh, dw)
         return dst
 
-    def gauss7(self, src):
+    def gauss7(self, src, variant=0):
         src = np.ascontiguousarray(src, np.uint8)
         dst = np.zeros_like(src)
-        self.L.orc_gauss7_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dst.strides[0])
+        self.L.orc_gauss7_u8_variant(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dst.strides[0], variant)
         return dst
 
     def fast9(self, img, threshold, nms=True):
@@ -362,6 +374,15 @@ class OracleExtractor:
             self.o.L.orc_extractor_destroy(self.h)
         except Exception:
             pass
+
+    def set_gauss_variant(self, variant):
+        """0: GaussianBlur of OpenCV >= 4.1.1 (error-diffused taps, the default); 1: of OpenCV 4.0.0 - 4.1.0 (rounded taps, saturating)."""
+        self.o.L.orc_extractor_set_gauss_variant(self.h, int(variant))
+
+    def set_tie_rule(self, rule):
+        """H1: order of equal-sized quadtree nodes in the final phase's sort.  0 creation order (pinned), 1 reversed, 2 real heap
+        addresses of this process, >= 3 seeded random."""
+        self.o.L.orc_extractor_set_tie_rule(self.h, int(rule))
 
     def tables(self):
         n = self.nlevels

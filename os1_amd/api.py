@@ -122,6 +122,8 @@ def load_library():
     L.orbfe_extract_bow.argtypes = [vp, ci, vp, vp, C.POINTER(ci), vp, vp, vp, C.POINTER(ci), vp, vp]
     L.orbfe_extractor_set_input_format.argtypes = [vp, ci, ci]
     L.orbfe_stream_set_input_format.argtypes = [vp, ci, ci]
+    L.orbfe_extractor_set_blur_variant.argtypes = [vp, ci]
+    L.orbfe_stream_set_blur_variant.argtypes = [vp, ci]
     L.orbfe_vocabulary_create.argtypes = [ci, ci, ci, ci, ci, vp, ci, C.POINTER(vp)]
     L.orbfe_vocabulary_create_from_image.argtypes = [ci, vp, C.c_size_t, C.POINTER(vp)]
     L.orbfe_vocabulary_destroy.argtypes = [vp]
@@ -246,6 +248,10 @@ class Extractor:
         return kps[:n.value].copy(), desc[:n.value].copy()
 
     FORMATS = {'gray': 0, 'rgb': 1, 'bgr': 2, 'rgba': 3, 'bgra': 4}
+
+    def set_blur_variant(self, variant):
+        """0 = ORBFE_GAUSS_ED (GaussianBlur of OpenCV >= 4.1.1, the default), 1 = ORBFE_GAUSS_ROUNDED (OpenCV 4.0.0 - 4.1.0)."""
+        _check(self.L.orbfe_extractor_set_blur_variant(self.h, int(variant)))
 
     def set_input_format(self, fmt='gray', variant=0):
         """Frames of later calls are interleaved 8-bit `fmt` pixels; variant 0 = 15-bit, 1 = 14-bit coefficients."""
@@ -1002,6 +1008,9 @@ class Stream:
     def set_matching(self, bounds, window=100, nnratio=0.9, check_ori=True):
         b = np.asarray(bounds, np.float32)
         _check(self.L.orbfe_stream_set_matching(self.h, _p(b), window, nnratio, int(check_ori)))
+
+    def set_blur_variant(self, variant):
+        _check(self.L.orbfe_stream_set_blur_variant(self.h, int(variant)))
 
     def set_vocabulary(self, voc, levelsup=4):
         self._voc = voc

@@ -254,6 +254,7 @@ struct orbfe_extractor {
   PinBuf<uint32_t> h_cand;
   long long inPitch = 0;
   int inFormat = ORBFE_INPUT_GRAY8, grayVariant = ORBFE_GRAY_Q15;   // orbfe_extractor_set_input_format
+  int gaussVariant = ORBFE_GAUSS_ED;                                // orbfe_extractor_set_blur_variant (ORBFE_GAUSS_VARIANT presets it)
   long long grayPitch = 0;
   DevBuf<uint8_t> d_gray;   // level 0 of colour input
   bool inLinear = false;   // host frames are uploaded with linear copies (inPitch == host stride)
@@ -753,6 +754,7 @@ struct orbfe_extractor {
     const long long rawStride = onDevice ? (long long)stride : inPitch;
     P.stride0 = ch == 1 ? rawStride : grayPitch;
     P.frameBase = 0;
+    P.gaussVariant = gaussVariant;
     if (ch == 1 && nframes <= 2) {   // the level-0 pointers travel in the kernel arguments
       P.frame0 = nullptr;
       P.frameInline[0] = h_frame0.p[0];
@@ -1331,6 +1333,13 @@ int orbfe_extractor_set_wait_mode(orbfe_extractor* h, int poll_us) {
   return ORBFE_OK;
 }
 
+int orbfe_extractor_set_blur_variant(orbfe_extractor* h, int variant) {
+  if (!h || (variant != ORBFE_GAUSS_ED && variant != ORBFE_GAUSS_ROUNDED)) { set_err("bad blur variant"); return ORBFE_ERR_INVALID; }
+  if (h->pendingFrames) { set_err("a submitted batch has not been collected yet"); return ORBFE_ERR_INVALID; }
+  h->gaussVariant = variant;
+  return ORBFE_OK;
+}
+
 int orbfe_extractor_set_input_format(orbfe_extractor* h, int format, int gray_variant) {
   if (!h || format < ORBFE_INPUT_GRAY8 || format > ORBFE_INPUT_BGRA8 || (gray_variant != ORBFE_GRAY_Q15 && gray_variant != ORBFE_GRAY_Q14)) {
     set_err("bad input format");
@@ -1434,6 +1443,7 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
   if (const char* qj = getenv("ORBFE_QT_JUMP")) h->qtJump = atoi(qj) != 0;
   if (const char* cv = getenv("ORBFE_CONE_TILE")) h->coneTile = atoi(cv) <= 0 ? 0 : std::max(8, atoi(cv)) & ~3;
   if (const char* pv = getenv("ORBFE_PROFILE_KERNELS")) h->profileKernels = atoi(pv) != 0;
+  if (const char* gv = getenv("ORBFE_GAUSS_VARIANT")) h->gaussVariant = atoi(gv) == ORBFE_GAUSS_ROUNDED ? ORBFE_GAUSS_ROUNDED : ORBFE_GAUSS_ED;
   h->selPerFrame = 0;
   for (int l = 0; l < nlevels; l++) {
     h->selOff[l] = h->selPerFrame;

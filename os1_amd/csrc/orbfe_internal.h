@@ -84,6 +84,7 @@ struct PyramidParams {
   const uint8_t* zeros;             // 256 zero bytes in device memory: source of the LDS-DMA that clears a FAST wave's score tile
   int iniTh, minTh;
   int frameBase;                    // first frame of this launch (sub-batch pipelining)
+  int gaussVariant;                 // ORBFE_GAUSS_ED / ORBFE_GAUSS_ROUNDED: which GaussianBlur k_describe reproduces
 };
 
 // Small batches build the pyramid in ONE launch (k_pyramid_cone): a block owns a tile of the top level and computes

@@ -789,21 +789,28 @@ constexpr BlurCodes make_blur_codes() {
 __constant__ BlurCodes c_blurCodes = make_blur_codes();
 
 
-// the 8.8 Gaussian taps [18,34,48,56,48,34,18] laid over dword q of a row whose 7-tap window starts at byte s: byte b of the
-// word weighs byte 4q + b, i.e. tap 4q + b - s (0 outside the window)
-constexpr unsigned blur_tap_word(int s, int q) {
-  const unsigned taps[7] = {18, 34, 48, 56, 48, 34, 18};
+// The 8.8 Gaussian taps of cv::GaussianBlur(7x7, sigma 2) on CV_8U.  GAUSS = ORBFE_GAUSS_ED (0): [18,34,48,56,48,34,18], the
+// error-diffused kernel of OpenCV >= 4.1.1 (sum 256).  GAUSS = ORBFE_GAUSS_ROUNDED (1): [18,34,49,55,49,34,18], every tap rounded on
+// its own as OpenCV 4.0.0 - 4.1.0 did (sum 257: the horizontal sums still fit 16 bits -- 257 * 255 = 65 535 -- and the one place its
+// saturating ufixedpoint arithmetic acts is the final cast: a rounded result of 256 or 257 becomes 255).
+template <int GAUSS> constexpr unsigned blur_tap(int t) {
+  constexpr unsigned ed[7] = {18, 34, 48, 56, 48, 34, 18}, rounded[7] = {18, 34, 49, 55, 49, 34, 18};
+  return GAUSS == 1 ? rounded[t] : ed[t];
+}
+// ... laid over dword q of a row whose 7-tap window starts at byte s: byte b of the word weighs byte 4q + b, i.e. tap 4q + b - s (0
+// outside the window)
+template <int GAUSS> constexpr unsigned blur_tap_word(int s, int q) {
   unsigned w = 0;
   for (int b = 0; b < 4; b++) {
     const int t = 4 * q + b - s;
-    if (t >= 0 && t <= 6) w |= taps[t] << (8 * b);
+    if (t >= 0 && t <= 6) w |= blur_tap<GAUSS>(t) << (8 * b);
   }
   return w;
 }
 
-template <int S>
+template <int S, int GAUSS>
 __device__ __forceinline__ unsigned blur_row_out(const uint32_t (&d)[4]) {   // the 7-tap sum whose window starts at byte S of d
-  constexpr unsigned w0 = blur_tap_word(S, 0), w1 = blur_tap_word(S, 1), w2 = blur_tap_word(S, 2), w3 = blur_tap_word(S, 3);
+  constexpr unsigned w0 = blur_tap_word<GAUSS>(S, 0), w1 = blur_tap_word<GAUSS>(S, 1), w2 = blur_tap_word<GAUSS>(S, 2), w3 = blur_tap_word<GAUSS>(S, 3);
   unsigned acc = 0u;
   if constexpr (w0 != 0u) acc = __builtin_amdgcn_udot4(d[0], w0, acc, false);
   if constexpr (w1 != 0u) acc = __builtin_amdgcn_udot4(d[1], w1, acc, false);
@@ -863,11 +870,12 @@ struct DescribeArgs {
   long long slabBytes;
   int nsel, selPerFrame, nlevels, frameBase, dma;
   int selOff[kMaxLevels + 1];
+  int gauss;                         // host side only: which instantiation is launched
 };
 
 // WAVES = 1: one wave per keypoint (batches: throughput).  WAVES = 4: the same passes spread over a block of four waves
 // (one- and two-frame calls: a keypoint's 760 dependent-ish instructions are the latency of the whole kernel there).
-template <int WAVES>
+template <int WAVES, int GAUSS>
 __global__ __launch_bounds__(64 * WAVES) void k_describe(DescribeArgs A) {
   constexpr int NT = 64 * WAVES;
   // Every table a lane will need depends on its lane number only: ALL of them are requested here, before the first wait of
@@ -1078,10 +1086,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_describe(DescribeArgs A) {
         const uint32_t* rp = reinterpret_cast<const uint32_t*>(raw + (bh[it] & 0xffffu));
         const uint32_t d[4] = {rp[0], rp[1], rp[2], rp[3]};   // raw bytes 4g .. 4g+15 of row y; pixel x of the row is byte PA + x
         uint16_t* o = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(hbT) + (bh[it] >> 16));
-        o[0] = (uint16_t)blur_row_out<PA + 0>(d);
-        o[kHPT] = (uint16_t)blur_row_out<PA + 1>(d);
-        o[2 * kHPT] = (uint16_t)blur_row_out<PA + 2>(d);
-        o[3 * kHPT] = (uint16_t)blur_row_out<PA + 3>(d);
+        o[0] = (uint16_t)blur_row_out<PA + 0, GAUSS>(d);
+        o[kHPT] = (uint16_t)blur_row_out<PA + 1, GAUSS>(d);
+        o[2 * kHPT] = (uint16_t)blur_row_out<PA + 2, GAUSS>(d);
+        o[3 * kHPT] = (uint16_t)blur_row_out<PA + 3, GAUSS>(d);
       }
     };
     switch (pa) {
@@ -1094,8 +1102,9 @@ __global__ __launch_bounds__(64 * WAVES) void k_describe(DescribeArgs A) {
   __syncthreads();
   {
     // (lo, hi) tap pairs for an output whose first tap is the LOW half of p0 (even) or the HIGH half (odd)
-    const u16x2 E0 = {18, 34}, E1 = {48, 56}, E2 = {48, 34}, E3 = {18, 0};
-    const u16x2 O0 = {0, 18}, O1 = {34, 48}, O2 = {56, 48}, O3 = {34, 18};
+    constexpr uint16_t T0 = blur_tap<GAUSS>(0), T1 = blur_tap<GAUSS>(1), T2 = blur_tap<GAUSS>(2), T3 = blur_tap<GAUSS>(3);
+    const u16x2 E0 = {T0, T1}, E1 = {T2, T3}, E2 = {T2, T1}, E3 = {T0, 0};
+    const u16x2 O0 = {0, T0}, O1 = {T1, T2}, O2 = {T3, T2}, O3 = {T1, T0};
 #pragma unroll
     for (int it = 0; it < NV; it++) {
       if ((it + 1) * NT > kBlurItemsHost.nv && it * NT + tid >= kBlurItemsHost.nv) break;
@@ -1103,7 +1112,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_describe(DescribeArgs A) {
       u16x2 p[5];
 #pragma unroll
       for (int t = 0; t < 5; t++) p[t] = as_u16x2(cp[t]);   // rows 4yq .. 4yq+9 of column x
-      unsigned r4[4];   // (sum + 32768): the blurred pixel is byte 2 of each (sum <= 255 * 65536)
+      unsigned r4[4];   // (sum + 32768): the blurred pixel is byte 2 of each (ED taps: sum <= 255 * 65536)
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         unsigned e = 32768u, o = 32768u;
@@ -1111,6 +1120,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_describe(DescribeArgs A) {
         e = __builtin_amdgcn_udot2(p[h + 1], E1, e, false); o = __builtin_amdgcn_udot2(p[h + 1], O1, o, false);
         e = __builtin_amdgcn_udot2(p[h + 2], E2, e, false); o = __builtin_amdgcn_udot2(p[h + 2], O2, o, false);
         e = __builtin_amdgcn_udot2(p[h + 3], E3, e, false); o = __builtin_amdgcn_udot2(p[h + 3], O3, o, false);
+        if constexpr (GAUSS == 1) {   // saturate_cast<uchar>: (sum + 32768) >> 16 can be 256 or 257 with taps that add up to 257
+          e = e < 0x00ffffffu ? e : 0x00ffffffu;
+          o = o < 0x00ffffffu ? o : 0x00ffffffu;
+        }
         r4[2 * h] = e;
         r4[2 * h + 1] = o;
       }
@@ -1286,6 +1299,7 @@ static DescribeArgs describe_args(const PyramidParams& P, const SelKp* sel, int 
   A.frame0 = P.frame0; A.frameInline[0] = P.frameInline[0]; A.frameInline[1] = P.frameInline[1];
   A.stride0 = P.stride0; A.slab = P.slab; A.slabBytes = P.slabBytes;
   A.nsel = nsel; A.selPerFrame = 1; A.nlevels = P.nlevels; A.frameBase = P.frameBase; A.dma = describe_dma();
+  A.gauss = P.gaussVariant;
   return A;
 }
 
@@ -1293,7 +1307,8 @@ void launch_describe(const PyramidParams& P, const SelKp* sel, int nsel, float* 
                      hipStream_t st) {
   if (nsel <= 0) return;
   const DescribeArgs A = describe_args(P, sel, nsel, angle, desc);
-  hipLaunchKernelGGL(k_describe<1>, dim3(8 * ((nsel + 7) / 8)), dim3(64), 0, st, A);
+  if (A.gauss == 1) hipLaunchKernelGGL((k_describe<1, 1>), dim3(8 * ((nsel + 7) / 8)), dim3(64), 0, st, A);
+  else hipLaunchKernelGGL((k_describe<1, 0>), dim3(8 * ((nsel + 7) / 8)), dim3(64), 0, st, A);
 }
 
 // sel/angle/desc point at the first slot of frame P.frameBase; nslots = nframes * selPerFrame
@@ -1304,8 +1319,14 @@ void launch_describe_slots(const PyramidParams& P, const SelKp* sel, int nslots,
   A.selCount = selCount;
   A.selPerFrame = selPerFrame;
   for (int l = 0; l <= P.nlevels; l++) A.selOff[l] = selOff[l];
-  if (fourWaves) hipLaunchKernelGGL(k_describe<4>, dim3(8 * ((nslots + 7) / 8)), dim3(256), 0, st, A);
-  else hipLaunchKernelGGL(k_describe<1>, dim3(8 * ((nslots + 7) / 8)), dim3(64), 0, st, A);
+  const dim3 grid(8 * ((nslots + 7) / 8));
+  if (fourWaves) {
+    if (A.gauss == 1) hipLaunchKernelGGL((k_describe<4, 1>), grid, dim3(256), 0, st, A);
+    else hipLaunchKernelGGL((k_describe<4, 0>), grid, dim3(256), 0, st, A);
+  } else {
+    if (A.gauss == 1) hipLaunchKernelGGL((k_describe<1, 1>), grid, dim3(64), 0, st, A);
+    else hipLaunchKernelGGL((k_describe<1, 0>), grid, dim3(64), 0, st, A);
+  }
 }
 
 void launch_sincos(const float* deg, int n, float* c, float* s, hipStream_t st) {

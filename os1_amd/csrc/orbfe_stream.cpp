@@ -364,6 +364,17 @@ int orbfe_stream_set_input_format(orbfe_stream* s, int format, int gray_variant)
   return ORBFE_OK;
 }
 
+int orbfe_stream_set_blur_variant(orbfe_stream* s, int variant) {
+  if (!s) { set_err("invalid arguments"); return ORBFE_ERR_INVALID; }
+  std::lock_guard<std::mutex> lk(s->mu);
+  if (s->pushSeq != s->popSeq) { set_err("batches are still in flight"); return ORBFE_ERR_INVALID; }
+  for (orbfe_extractor* e : s->ext) {
+    const int rc = orbfe_extractor_set_blur_variant(e, variant);
+    if (rc) return rc;
+  }
+  return ORBFE_OK;
+}
+
 int orbfe_stream_set_vocabulary(orbfe_stream* s, orbfe_vocabulary* v, int levelsup) {
   if (!s) { set_err("invalid arguments"); return ORBFE_ERR_INVALID; }
   std::lock_guard<std::mutex> lk(s->mu);

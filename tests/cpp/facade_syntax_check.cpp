@@ -8,6 +8,14 @@
 
 using namespace ORB_SLAM2;
 
+// The facade reproduces the GaussianBlur of the OpenCV it is compiled against (ORBextractor.cc:950): the test compiles this file
+// once per release named on the command line (-DCV_VERSION_MAJOR=.. -DEXPECT_GAUSS=..).
+#ifdef EXPECT_GAUSS
+static_assert(ORBFE_FACADE_GAUSS_VARIANT == EXPECT_GAUSS, "blur variant chosen from CV_VERSION_*");
+#else
+static_assert(ORBFE_FACADE_GAUSS_VARIANT == ORBFE_GAUSS_ED, "no version macros: the default");
+#endif
+
 int useEverything(Frame& F, Frame& F2, KeyFrame* pKF, KeyFrame* pKF2, std::vector<MapPoint*>& vp, std::set<MapPoint*>& sp,
                   cv::Mat& im, cv::Mat& Scw, std::vector<cv::Point2f>& prev, std::vector<int>& m12,
                   std::vector<std::pair<size_t, size_t> >& pairs) {

@@ -102,6 +102,54 @@ def test_colour_input_parity(api, oracle):
         _cmp_extract(ex(gray), ox.extract(gray))
 
 
+def test_legacy_gaussian_variant_parity(api, oracle):
+    """orbfe_extractor_set_blur_variant(ORBFE_GAUSS_ROUNDED): GaussianBlur of OpenCV 4.0.0 - 4.1.0 (taps [18,34,49,55,49,34,18], sum 257, one
+    saturating cast; ORBextractor.cc:949-950 decides every descriptor bit).  Both variants against the oracle's, on every route a frame
+    can take -- one-frame call (four waves per keypoint, results written to host memory), batch (one wave per keypoint), stream runner --
+    and on an over-exposed frame where (sum + 32768) >> 16 reaches 256 / 257 and must clip to 255.  Keypoints and angles do not depend
+    on the blur; the descriptors of the two variants differ."""
+    imgs = [synth(61, 800, 600), synth(62, 800, 600)]
+    hot = np.clip(synth(63, 800, 600).astype(np.int32) * 2 + 30, 0, 255).astype(np.uint8)       # large areas at 255, textured rims
+    assert (hot == 255).mean() > 0.15
+    imgs.append(hot)
+    ex = api.Extractor(1200, 1.2, 8, 20, 7)
+    ox = OracleExtractor(1200, 1.2, 8, 20, 7, oracle)
+    per_variant = {}
+    for variant in (1, 0, 1):
+        ex.set_blur_variant(variant)
+        ox.set_gauss_variant(variant)
+        want = [ox.extract(im) for im in imgs]
+        if variant == 1:      # the saturation is reached inside a descriptor's reach on the over-exposed frame
+            lv0 = ox.level(0)
+            k7 = np.array([18, 34, 49, 55, 49, 34, 18], np.int64)
+            p = np.pad(lv0.astype(np.int64), 3, mode='reflect')
+            v = sum(k7[t] * sum(k7[u] * p[:, u:u + lv0.shape[1]] for u in range(7))[t:t + lv0.shape[0], :] for t in range(7))
+            assert ((v + 32768) >> 16).max() >= 256
+            assert (ox.level(0, blurred=True) == np.minimum((v + 32768) >> 16, 255)).all()
+        for im, w in zip(imgs, want):
+            _cmp_extract(ex(im), w)                                   # one-frame route
+        for g, w in zip(ex.extract_batch(imgs + imgs[:1]), want + want[:1]):
+            _cmp_extract(g, w)                                        # batch route
+        per_variant[variant] = want
+    for (k0, d0), (k1, d1) in zip(per_variant[0], per_variant[1]):
+        assert k0.tobytes() == k1.tobytes() and (d0 != d1).any()
+    # stream runner: every extractor handle of the runner switches
+    dev = api.DeviceFrames(imgs + imgs[:1], 0)
+    st = api.Stream(1200, 1.2, 8, 20, 7, 0, 2, 2)
+    st.set_blur_variant(1)
+    st.set_matching((0.0, 800.0, 0.0, 600.0), 0, 0.9, True)
+    for b in range(2):
+        st.push_ptrs(dev.ptrs[2 * b:2 * b + 2], 600, 800, dev.stride, True)
+    for b in range(2):
+        kps, desc, n, _, _ = st.pop(copy=True)
+        for i in range(2):
+            wk, wd = per_variant[1][(2 * b + i) % 3]
+            assert kps[i, :n[i]].tobytes() == wk.tobytes() and desc[i, :n[i]].tobytes() == wd.tobytes()
+    st.close()
+    with pytest.raises(Exception):
+        ex.set_blur_variant(2)
+
+
 def test_other_parameters(api, oracle):
     img = synth(7, 960, 540)
     for (N, sf, nl, ini, mn) in [(1500, 1.2, 8, 20, 7), (300, 1.5, 4, 30, 10), (1000, 1.1, 6, 12, 5), (50, 1.2, 3, 40, 40)]:

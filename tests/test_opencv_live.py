@@ -15,6 +15,17 @@ from oracle.pyoracle import OracleExtractor
 from os1_amd.synth import synth
 
 
+def _gauss_variant(cv2):
+    """Which 8-bit GaussianBlur this OpenCV has (include/orbfe.h, orbfe_extractor_set_blur_variant): 1 = taps rounded one by one
+    (4.0.0 - 4.1.0 and 3.4.2 - 3.4.6), 0 = error-diffused taps (every later release).  The same rule as include/orbfe/ORBextractor.h."""
+    v = tuple(int(''.join(ch for ch in x if ch.isdigit()) or 0) for x in cv2.__version__.split('.')[:3])
+    if v[0] == 4 and (v[1] == 0 or (v[1] == 1 and v[2] == 0)):
+        return 1
+    if v[0] == 3 and v[1] == 4 and 2 <= v[2] <= 6:
+        return 1
+    return 0
+
+
 def _cv2():
     try:
         import cv2
@@ -153,8 +164,9 @@ def _check_against_opencv(oracle):
         bad = 0
         for l in range(8):
             want = cv2.GaussianBlur(levels[l].copy(), (7, 7), 2, 2, borderType=cv2.BORDER_REFLECT_101)
-            bad += int((oracle.gauss7(levels[l]) != want).sum())
+            bad += int((oracle.gauss7(levels[l], _gauss_variant(cv2)) != want).sum())
         report['GaussianBlur_%dx%d' % (W, H)] = bad
+        report['GaussianBlur_variant_expected_for_this_cv2'] = _gauss_variant(cv2)
         # ---- cv::FAST(ROI, th, nms=true) on the reference's cell ROIs of every level (ORBextractor.cc:826-856)
         bad = 0
         det = {t: cv2.FastFeatureDetector_create(threshold=t, nonmaxSuppression=True, type=cv2.FAST_FEATURE_DETECTOR_TYPE_9_16)

@@ -97,6 +97,40 @@ def test_blur_random_vs_numpy(oracle):
     assert (oracle.gauss7(img) == want).all()
 
 
+def test_legacy_gaussian_variant(oracle):
+    """Variant 1 = GaussianBlur of OpenCV 4.0.0 - 4.1.0 (the era the reference dates from, README.md:18): every 8.8 tap rounded on its
+    own, [18,34,49,55,49,34,18] = cvRound(k_i * 256), sum 257; exact integer sums (257 * 255 = 65 535 still fits the 16-bit row pass)
+    and ONE saturation at the final cast.  Against an independent numpy restatement, on noise, on a bright image where the cast
+    saturates, and on constants (a constant c maps to min(255, (c * 257 * 257 + 32768) >> 16), not to c)."""
+    k = oracle.gauss_kernel(7, 2.0, 1)
+    x = np.arange(7) - 3.0
+    g = np.exp(-x * x / 8.0)
+    assert k.tolist() == [18, 34, 49, 55, 49, 34, 18] == np.rint(g / g.sum() * 256).astype(int).tolist() and k.sum() == 257
+    assert oracle.gauss_kernel(7, 2.0, 0).tolist() == [18, 34, 48, 56, 48, 34, 18]
+    k = k.astype(np.int64)
+
+    def ref(img):
+        h_, w_ = img.shape
+        p = np.pad(img.astype(np.int64), 3, mode='reflect')
+        h = sum(k[t] * p[:, t:t + w_] for t in range(7))
+        assert h.max() <= 65535
+        v = sum(k[t] * h[t:t + h_, :] for t in range(7))
+        return np.minimum((v + 32768) >> 16, 255).astype(np.uint8)
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (41, 57), dtype=np.uint8)
+    assert (oracle.gauss7(img, 1) == ref(img)).all()
+    assert (oracle.gauss7(img, 1) != oracle.gauss7(img, 0)).mean() > 0.3            # the two releases really differ
+    bright = np.clip(rng.integers(235, 300, (41, 57)), 0, 255).astype(np.uint8)        # mostly 255: (sum + 32768) >> 16 reaches 256, 257
+    out = oracle.gauss7(bright, 1)
+    assert (out == ref(bright)).all() and (out == 255).any()
+    p = np.pad(bright.astype(np.int64), 3, mode='reflect')
+    h = sum(k[t] * p[:, t:t + 57] for t in range(7))
+    v = sum(k[t] * h[t:t + 41, :] for t in range(7))
+    assert ((v + 32768) >> 16).max() >= 256                                          # the saturation is exercised, not just present
+    for c in (0, 1, 100, 137, 254, 255):
+        assert (oracle.gauss7(np.full((20, 20), c, np.uint8), 1) == min(255, (c * 257 * 257 + 32768) >> 16)).all()
+
+
 def test_resize_constant_ramp_and_numpy(oracle):
     img = np.full((60, 72), 91, np.uint8)
     assert (oracle.resize(img, 60, 50) == 91).all()

@@ -225,19 +225,26 @@ def test_steered_brief_against_scikit_image(oracle, tmp_path):
 
 
 @pytest.mark.gpu
-def test_product_against_third_parties_directly(tmp_path):
+@pytest.mark.parametrize('which', ['textured', 'photograph'])
+def test_product_against_third_parties_directly(tmp_path, which):
     """The HIP path with NO oracle in between: keypoints, angles and descriptors of a GPU extraction against scikit-image / scipy
     evaluated on the product's own pyramid levels -- every keypoint passes scikit-image's FAST-9 test with response = the
     largest passing threshold, its angle is corner_orientations' within fastAtan2's 0.3 degrees, and its descriptor is what
-    scikit-image's steered-BRIEF loop reads from scipy's integer Gaussian of the level."""
+    scikit-image's steered-BRIEF loop reads from scipy's integer Gaussian of the level.  `photograph`: scikit-image's own `camera`
+    sample image (tests/golden/natural_images.npz), where a fifth of the keypoints come from the minThFAST pass."""
     from os1_amd import api
     assert api.device_count() >= 1, 'no GPU visible: the product has no CPU fallback'
-    img = np.kron(_textured(21, 120, 160), np.ones((4, 4), np.uint8))
-    img = (img.astype(np.int32) + np.random.RandomState(4).randint(-8, 9, img.shape)).clip(0, 255).astype(np.uint8)
+    if which == 'textured':
+        img = np.kron(_textured(21, 120, 160), np.ones((4, 4), np.uint8))
+        img = (img.astype(np.int32) + np.random.RandomState(4).randint(-8, 9, img.shape)).clip(0, 255).astype(np.uint8)
+    else:
+        img = np.ascontiguousarray(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'natural_images.npz'))['camera'])
     ex = api.Extractor(1200, 1.2, 8, 20, 7)
     kps, desc = ex(img)
     sf = ex.tables()['sf']
     assert len(kps) > 800 and len(set(kps['octave'].tolist())) == 8
+    if which == 'photograph':
+        assert (kps['response'] < 20).sum() > 50      # keypoints that only the minThFAST pass of their cell produced
     factor = np.float32(3.1415926535897932384626433832795 / 180.0)
     arrays = {}
     for l in range(8):
