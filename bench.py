@@ -644,7 +644,7 @@ def tracking_step_leg(api, device, frames, W, H, wl, with_oracle_check=True):
             tab.upload(m, 0, 4096)
             m.synchronize()
             tb_args = (m.h, fr.h, P(sf), len(sf), P(occ2), P(mxy), P(lvl), P(vcos), P(fl), C.c_void_p(tab.dev), C.c_void_p(tab.host.base),
-                       P(trow.a), 3000, C.c_float(3.0), C.c_float(0.8), P(asg2), C.byref(nmc))
+                       P(trow.a), 4096, 3000, C.c_float(3.0), C.c_float(0.8), P(asg2), C.byref(nmc))
             t7 = time.perf_counter()
             rc = m.L.orbfe_search_by_projection_frame_rows(*tb_args)
             t_mpt.append(time.perf_counter() - t7)
@@ -791,7 +791,7 @@ def config5_leg(api, device, with_oracle):
         lat = []
         for _ in range(110):
             t0 = time.perf_counter()
-            rc = m.L.orbfe_search_by_projection_frame_rows(*args[:9], C.c_void_p(tab.dev), C.c_void_p(tab.host.base), P(trow.a), n_mp, th, 0.8, *outs)
+            rc = m.L.orbfe_search_by_projection_frame_rows(*args[:9], C.c_void_p(tab.dev), C.c_void_p(tab.host.base), P(trow.a), n_mp + 2048, n_mp, th, 0.8, *outs)
             lat.append(time.perf_counter() - t0)
             assert rc == 0
         if nmat.value != ref_n or not (assigned == ref_assigned).all():

@@ -477,12 +477,14 @@ int orbfe_search_by_projection_frame(orbfe_matcher* m, orbfe_frame* f, const flo
  * orbfe_host_alloc; complete and current).  MapPoint i's descriptor is row (mp_desc_row[i] & 0x7fffffff): read from the
  * device copy when bit 31 is clear, from the host copy -- over PCIe, in place -- when it is set (a row the device has not
  * received yet; the caller sends it afterwards with orbfe_matcher_upload_async).  Per MapPoint 4 bytes of index cross PCIe
- * instead of 32 of descriptor.  mp_desc_row is host memory (page-locked: read in place).  Same results as the plain form. */
+ * instead of 32 of descriptor.  mp_desc_row is host memory (page-locked: read in place).  n_rows = rows both copies of the table
+ * hold: an in-view, not-bad MapPoint whose row index is >= n_rows fails the call with ORBFE_ERR_INVALID (as an out-of-range level
+ * does) instead of reading outside the table.  Same results as the plain form. */
 int orbfe_search_by_projection_frame_rows(orbfe_matcher* m, orbfe_frame* f, const float* scale_factors, int nlevels,
                                           const uint8_t* kp_occupied, const float* mp_proj_xy, const int32_t* mp_level,
                                           const float* mp_viewcos, const uint8_t* mp_flags, const uint8_t* desc_table_device,
-                                          const uint8_t* desc_table_host, const int32_t* mp_desc_row, int n_mp, float th,
-                                          float nnratio, int32_t* kp_assigned, int* nmatches);
+                                          const uint8_t* desc_table_host, const int32_t* mp_desc_row, int n_rows, int n_mp,
+                                          float th, float nnratio, int32_t* kp_assigned, int* nmatches);
 int orbfe_search_by_projection_uv_frame(orbfe_matcher* m, orbfe_frame* f, const float* scale_factors, int nlevels,
                                         const uint8_t* kp_occupied, const float* src_uv, const int32_t* src_level,
                                         const float* src_angle, const uint8_t* src_flags, const uint8_t* src_valid,

@@ -316,9 +316,14 @@ class MatcherContext {
   void tableBegin(size_t nQueries) {
     DescTable& t = table_;
     if (t.pending) { check(orbfe_matcher_synchronize(m_)); t.pending = false; }
-    if (t.slotOf.size() > std::max<size_t>(16384, 4 * std::max(nQueries, t.lastQueries))) { t.slotOf.clear(); t.used = 0; }
+    if (t.slotOf.size() > std::max<size_t>(16384, 4 * std::max(nQueries, t.lastQueries))) {
+      t.slotOf.clear(); t.used = 0;
+      t.dirty.clear();                                     // the rows start over: nothing of the old assignment is owed to the device
+      std::fill(t.notOnDevice.begin(), t.notOnDevice.end(), (uint8_t)0);
+    }
     t.lastQueries = nQueries;
-    t.dirty.clear();
+    // t.dirty is NOT cleared here: rows a previous snapshot rewrote in the mirror and never sent (its search threw before
+    // tableCommit) are still owed to the device; until then rowFor hands them out as mirror rows (notOnDevice)
     if (t.cap == 0) growTable(1);
   }
   int32_t rowFor(const void* pMP, const uint8_t* bytes) {
@@ -326,35 +331,47 @@ class MatcherContext {
     auto it = t.slotOf.find(pMP);
     uint32_t slot;
     if (it == t.slotOf.end()) {
-      slot = (uint32_t)t.used++;
-      if (t.used > t.cap) growTable(t.used);
+      slot = (uint32_t)t.used;
+      if (t.used + 1 > t.cap) growTable(t.used + 1);
+      t.used++;
       t.slotOf.emplace(pMP, slot);
     } else {
       slot = it->second;
-      if (std::memcmp(t.mirror + (size_t)slot * 32, bytes, 32) == 0) { t.rowsFromDevice++; return (int32_t)slot; }
+      if (std::memcmp(t.mirror + (size_t)slot * 32, bytes, 32) == 0) {
+        // equal bytes in the MIRROR say nothing about the device row while an upload of this row has not been enqueued yet: the same
+        // MapPoint twice in one vpMapPoints (the reference tolerates that), or a row of a snapshot whose search never committed
+        if (t.notOnDevice[slot]) return (int32_t)(slot | 0x80000000u);
+        t.rowsFromDevice++;
+        return (int32_t)slot;
+      }
     }
     std::memcpy(t.mirror + (size_t)slot * 32, bytes, 32);
-    t.dirty.push_back(slot);
+    if (!t.notOnDevice[slot]) { t.notOnDevice[slot] = 1; t.dirty.push_back(slot); }
     return (int32_t)(slot | 0x80000000u);
   }
   const uint8_t* tableDevice() const { return table_.rows; }
   const uint8_t* tableMirror() const { return table_.mirror; }
+  size_t tableRowCapacity() const { return table_.cap; }
   void tableCommit() {
     DescTable& t = table_;
     if (t.dirty.empty()) { t.cleanSearches++; return; }
     std::sort(t.dirty.begin(), t.dirty.end());
-    t.dirty.erase(std::unique(t.dirty.begin(), t.dirty.end()), t.dirty.end());
     size_t i = 0;
     while (i < t.dirty.size()) {   // runs of changed rows at most 32 rows apart travel as one copy
       size_t j = i;
       while (j + 1 < t.dirty.size() && t.dirty[j + 1] - t.dirty[j] <= 32) j++;
       const size_t lo = t.dirty[i], hi = (size_t)t.dirty[j] + 1;
-      check(orbfe_matcher_upload_async(m_, t.rows + lo * 32, t.mirror + lo * 32, (hi - lo) * 32));
+      t.pending = true;
+      if (orbfe_matcher_upload_async(m_, t.rows + lo * 32, t.mirror + lo * 32, (hi - lo) * 32) != ORBFE_OK) {
+        t.dirty.erase(t.dirty.begin(), t.dirty.begin() + (std::ptrdiff_t)i);   // rows i.. stay owed (and stay mirror rows)
+        check(ORBFE_ERR_HIP);
+      }
+      for (size_t k = i; k <= j; k++) t.notOnDevice[t.dirty[k]] = 0;   // enqueued on the matcher's stream: in order before the next search
       t.copies++;
       i = j + 1;
     }
     t.rowsChanged += t.dirty.size();
-    t.pending = true;
+    t.dirty.clear();
   }
   size_t tableRowsChanged() const { return table_.rowsChanged; }        // rows that went to the device (first sight or new bytes)
   size_t tableCleanSearches() const { return table_.cleanSearches; }    // searches that read every descriptor from device memory
@@ -403,7 +420,8 @@ class MatcherContext {
     uint8_t *rows = nullptr, *mirror = nullptr;   // device rows; page-locked host mirror (complete and current)
     size_t cap = 0, used = 0, lastQueries = 0;
     std::unordered_map<const void*, uint32_t> slotOf;   // MapPoint address -> row
-    std::vector<uint32_t> dirty;                  // rows rewritten by the current snapshot
+    std::vector<uint32_t> dirty;                  // rows rewritten in the mirror whose upload has not been enqueued yet (each once)
+    std::vector<uint8_t> notOnDevice;             // [cap] 1: the row is in `dirty` -- rowFor hands it out as a mirror row whatever the bytes
     size_t rowsChanged = 0, rowsFromDevice = 0, cleanSearches = 0, copies = 0;
     bool pending = false;                         // an upload from the mirror may still be in flight
   };
@@ -422,6 +440,7 @@ class MatcherContext {
     t.mirror = static_cast<uint8_t*>(h);
     t.rows = static_cast<uint8_t*>(d);
     t.cap = cap;
+    t.notOnDevice.resize(cap, 0);
   }
   DescTable table_;
 };
@@ -523,8 +542,8 @@ inline int SearchByProjection(MatcherContext& ctx, float mfNNratio, FrameT& F,
   int nmatches = 0;
   if (rf) {
     check(orbfe_search_by_projection_frame_rows(ctx.get(), rf, F.mvScaleFactors.data(), (int)F.mvScaleFactors.size(), occ, xy, lvl,
-                                                vcos, flags, ctx.tableDevice(), ctx.tableMirror(), drow, nmp, th, mfNNratio,
-                                                assigned, &nmatches));
+                                                vcos, flags, ctx.tableDevice(), ctx.tableMirror(), drow, (int)ctx.tableRowCapacity(), nmp, th,
+                                                mfNNratio, assigned, &nmatches));
     ctx.tableCommit();
   } else
     check(orbfe_search_by_projection(ctx.get(), reinterpret_cast<const OrbfeKeyPoint*>(F.mvKeysUn.data()),

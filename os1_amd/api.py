@@ -83,7 +83,7 @@ def load_library():
     L.orbfe_frame_descriptors_device.restype = vp
     L.orbfe_frame_download.argtypes = [vp, vp, vp, vp, vp]
     L.orbfe_search_by_projection_frame.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp, C.POINTER(ci)]
-    L.orbfe_search_by_projection_frame_rows.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, ci, cf, cf, vp,
+    L.orbfe_search_by_projection_frame_rows.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, cf, cf, vp,
                                                         C.POINTER(ci)]
     L.orbfe_matcher_upload_async.argtypes = [vp, vp, vp, C.c_size_t]
     L.orbfe_matcher_synchronize.argtypes = [vp]
@@ -537,7 +537,7 @@ class Matcher:
         n = C.c_int(0)
         _check(self.L.orbfe_search_by_projection_frame_rows(self.h, frame.h, _p(sf), len(sf), _p(occ), _p(mp_xy), _p(mp_level),
                                                             _p(mp_viewcos), _p(mp_flags), C.c_void_p(table.dev), C.c_void_p(table.host.base),
-                                                            _p(rows), len(mp_level), th, nnratio, _p(assigned), C.byref(n)))
+                                                            _p(rows), table.cap, len(mp_level), th, nnratio, _p(assigned), C.byref(n)))
         return n.value, assigned[:len(frame)]
 
     def upload_async(self, dst_device, src_host_ptr, nbytes):

@@ -586,7 +586,9 @@ struct orbfe_extractor {
   int setBatch(int nframes, bool hostInput, size_t hostStride = 0) {
     int rc;
     if (nframes > batchCap) {
-      if ((rc = d_slab.ensure((size_t)P.slabBytes * nframes))) return rc;
+      // + 64 bytes: k_describe's LDS-DMA fetches 48 bytes per patch row from the dword-aligned-down start, i.e. up to 5 bytes past the
+      // last pixel it needs; on the last row of the last level of the last frame that is past the slab
+      if ((rc = d_slab.ensure((size_t)P.slabBytes * nframes + 64))) return rc;
       if ((rc = d_cellCount.ensure((size_t)P.ncells * nframes))) return rc;
       if ((rc = d_cellOff.ensure((size_t)P.ncells * nframes))) return rc;
       if ((rc = d_slots.ensure((size_t)P.slotsPerFrame * nframes))) return rc;

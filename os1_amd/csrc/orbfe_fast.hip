@@ -514,7 +514,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fas
     // one record per wave, plain stores (same-address atomics from 200 000 waves back up the memory pipeline and inflate the
     // very latencies being measured)
     if (lane == 0 && g_fastStampBuf) {
-      uint32_t* rec = g_fastStampBuf + 8ull * ((unsigned long long)blockIdx.y * (P.ntasks + 64) + t0 + blockIdx.x);
+      // indexed by the TASK (unique across the LDS-class launches of a batch), not by the block: blocks are dealt XCD-consecutively,
+      // so blockIdx.x runs up to 8 * ceil(nt / 8) - 1 and the tail of one class used to land on the first records of the next
+      uint32_t* rec = g_fastStampBuf + 8ull * ((unsigned long long)blockIdx.y * (P.ntasks + 64) + tix);
       for (int k = 0; k < 5; k++) rec[k] = (uint32_t)(stamp[k + 1] - stamp[k]);
       rec[5] = 1u;
     }
@@ -522,7 +524,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fas
 }
 
 // measurement only (ORBFE_FAST_ABLATE=4): per-wave phase cycles of the LAST launch, summed on the host: entry -> geometry
-// known, -> ROI in LDS, -> pre-test done, -> scores done, -> end; [5] = waves
+// known, -> ROI in LDS, -> pre-test done, -> scores done, -> end; [5] = waves.  ONE buffer per process (g_fastStampBuf is a
+// device symbol): meant for a single extractor on a single device, as tools/fast_phases.py uses it.
 static uint32_t* s_stampBuf = nullptr;
 static size_t s_stampWaves = 0;
 int fast_stamps(unsigned long long out[8], int reset) {

@@ -1183,9 +1183,22 @@ int orbfe_search_by_projection_frame(orbfe_matcher* m, orbfe_frame* f, const flo
 int orbfe_search_by_projection_frame_rows(orbfe_matcher* m, orbfe_frame* f, const float* scale_factors, int nlevels,
                                           const uint8_t* kp_occupied, const float* mp_proj_xy, const int32_t* mp_level,
                                           const float* mp_viewcos, const uint8_t* mp_flags, const uint8_t* desc_table_device,
-                                          const uint8_t* desc_table_host, const int32_t* mp_desc_row, int n_mp, float th,
-                                          float nnratio, int32_t* kp_assigned, int* nmatches) {
-  if (!mp_desc_row || !desc_table_host || !desc_table_device) { set_err("bad argument"); return ORBFE_ERR_INVALID; }
+                                          const uint8_t* desc_table_host, const int32_t* mp_desc_row, int n_rows, int n_mp,
+                                          float th, float nnratio, int32_t* kp_assigned, int* nmatches) {
+  if (!mp_desc_row || !desc_table_host || !desc_table_device || n_rows < 0) { set_err("bad argument"); return ORBFE_ERR_INVALID; }
+  if (n_mp > 0 && mp_flags) {
+    // a row index is an address: validated like the levels (one branch-free sweep; only if that finds an index outside the table, a
+    // second one that looks at the MapPoints that are actually searched -- absent ones may carry anything)
+    if (gpu_readable(mp_desc_row, m ? m->device : 0) == 2) { set_err("descriptor row indices must be host memory"); return ORBFE_ERR_INVALID; }
+    unsigned hi = 0;
+    for (int i = 0; i < n_mp; i++) hi = std::max(hi, (unsigned)mp_desc_row[i] & 0x7fffffffu);
+    if (hi >= (unsigned)n_rows)
+      for (int i = 0; i < n_mp; i++)
+        if ((mp_flags[i] & ORBFE_MP_IN_VIEW) && !(mp_flags[i] & ORBFE_MP_BAD) && ((unsigned)mp_desc_row[i] & 0x7fffffffu) >= (unsigned)n_rows) {
+          set_err("MapPoint %d: descriptor row %u outside the table (%d rows)", i, (unsigned)mp_desc_row[i] & 0x7fffffffu, n_rows);
+          return ORBFE_ERR_INVALID;
+        }
+  }
   return sbp_frame_impl(m, f, scale_factors, nlevels, kp_occupied, mp_proj_xy, mp_level, mp_viewcos, mp_flags, desc_table_device,
                         mp_desc_row, desc_table_host, n_mp, th, nnratio, kp_assigned, nmatches);
 }

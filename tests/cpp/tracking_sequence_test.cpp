@@ -143,7 +143,7 @@ int main(int argc, char** argv) {
   Frame last, ini;
   int state = 0;                         // 0 = no initial frame, 1 = initial frame stored, 2 = tracking
   std::vector<Point2f> vbPrevMatched;
-  int framesSearched = 0, retries = 0, sbpCalls = 0, localCalls = 0, totalLast = 0, totalLocal = 0;
+  int framesSearched = 0, retries = 0, sbpCalls = 0, localCalls = 0, totalLast = 0, totalLocal = 0, failedSearches = 0, duplicates = 0;
   std::vector<KeyPoint> okps(nfeat + 256);
   std::vector<unsigned char> odesc((size_t)(nfeat + 256) * 32);
 
@@ -296,13 +296,46 @@ int main(int argc, char** argv) {
     }
     {
       const float thLocal = (k - (k >= R ? R : 0)) < 4 ? 3.f : 1.f;              // th = 3 / 5 shortly after a relocalisation (:818-822)
-      const int nmp = (int)local.size();
+      // Two things the descriptor table must survive.  (a) k % 4 == 1: descriptors change, then a search FAILS after
+      // its snapshot rewrote the table's mirror rows (an out-of-range level makes the C call return ORBFE_ERR_INVALID, the shim
+      // throws, tableCommit never runs): the next search must not read those rows from the device.  (b) k % 4 == 3: the same MapPoint
+      // twice in vpMapPoints (the reference tolerates it) right after its descriptor changed: the second occurrence must not read the
+      // device row either.
+      std::vector<MapPoint*> searched = local;
+      if (k % 4 == 1 || k % 4 == 3) {
+        int changedRows = 0;
+        for (MapPoint* p : local)
+          if (p->mbTrackInView && !p->bad && rng.uni() < 0.2) { for (int b = 0; b < 32; b += 3) p->desc[b] ^= (unsigned char)(1 + rng.below(255)); changedRows++; }
+        expect(changedRows > 0, "descriptors changed in front of the table stress", k, changedRows, 1);
+      }
+      if (k % 4 == 1) {
+        MapPoint* victim = nullptr;
+        for (MapPoint* p : local) if (p->mbTrackInView && !p->bad) victim = p;
+        if (victim) {
+          const int keep = victim->mnTrackScaleLevel;
+          victim->mnTrackScaleLevel = 99;
+          std::vector<MapPoint*> before = cur.mvpMapPoints;
+          bool threw = false;
+          try { orbfe::SearchByProjection(ctx, 0.8f, cur, local, thLocal); } catch (const std::exception&) { threw = true; }
+          victim->mnTrackScaleLevel = keep;
+          expect(threw, "a MapPoint level outside the pyramid fails the search", k, threw, 1);
+          expect(before == cur.mvpMapPoints, "a failed search leaves F.mvpMapPoints untouched", k, 0, 0);
+          failedSearches++;
+        }
+      }
+      if (k % 4 == 3) {
+        std::vector<MapPoint*> dup;
+        for (MapPoint* p : local) if (p->mbTrackInView && !p->bad && rng.uni() < 0.1) dup.push_back(p);
+        for (MapPoint* p : dup) searched.insert(searched.begin() + rng.below((int)searched.size() + 1), p);
+        duplicates += (int)dup.size();
+      }
+      const int nmp = (int)searched.size();
       std::vector<float> xy(2 * (size_t)nmp, 0.f), vcos(nmp, 0.f);
       std::vector<int> lvl(nmp, 0), assigned(cur.N, -1);
       std::vector<uint8_t> flags(nmp, 0), mdesc(32 * (size_t)nmp, 0), occ(cur.N, 0);
       for (int i = 0; i < cur.N; i++) occ[i] = cur.mvpMapPoints[i] && cur.mvpMapPoints[i]->nObs > 0;
       for (int i = 0; i < nmp; i++) {
-        MapPoint* p = local[i];
+        MapPoint* p = searched[i];
         flags[i] = (p->mbTrackInView ? 1 : 0) | (p->bad ? 2 : 0) | (p->plCandidato ? 4 : 0) | (p->nObs > 0 ? 8 : 0);
         if (!p->mbTrackInView) continue;
         xy[2 * i] = p->mTrackProjX; xy[2 * i + 1] = p->mTrackProjY; lvl[i] = p->mnTrackScaleLevel; vcos[i] = p->mTrackViewCos;
@@ -312,9 +345,9 @@ int main(int argc, char** argv) {
                                                 sf.data(), occ.data(), xy.data(), lvl.data(), vcos.data(), flags.data(), mdesc.data(), nmp,
                                                 thLocal, 0.8f, assigned.data());
       std::vector<MapPoint*> before = cur.mvpMapPoints;
-      const int got = orbfe::SearchByProjection(ctx, 0.8f, cur, local, thLocal);
+      const int got = orbfe::SearchByProjection(ctx, 0.8f, cur, searched, thLocal);
       bool same = got == want;
-      for (int i = 0; i < cur.N && same; i++) same = cur.mvpMapPoints[i] == (assigned[i] >= 0 ? local[assigned[i]] : before[i]);
+      for (int i = 0; i < cur.N && same; i++) same = cur.mvpMapPoints[i] == (assigned[i] >= 0 ? searched[assigned[i]] : before[i]);
       expect(same, "SearchByProjection(Cur, LocalMapPoints, th)", k, got, want);
       localCalls++;
       totalLocal += got;
@@ -357,6 +390,7 @@ int main(int argc, char** argv) {
   expect(ctx.residentUploads() == 0, "a frame's features were uploaded although the extractor held them", -1, (int)ctx.residentUploads(), 0);
   expect((int)ctx.residentFromExtract() == framesSearched, "frames built from the extractor's arena", -1, (int)ctx.residentFromExtract(), framesSearched);
   expect(retries >= 2, "the 2*th retry was exercised", -1, retries, 2);
+  expect(failedSearches >= 2 && duplicates >= 10, "the descriptor table was stressed: failed searches / duplicated MapPoints", -1, failedSearches, duplicates);
   // the local map's descriptors: most reads are served by the device table (a row crosses PCIe when it is new or its bytes changed)
   expect(ctx.tableRowsFromDevice() > 2 * ctx.tableRowsChanged(), "descriptor reads served by the device table vs rows sent", -1,
          (int)ctx.tableRowsFromDevice(), (int)ctx.tableRowsChanged());

@@ -475,6 +475,22 @@ def test_search_by_projection_indexed_descriptor_table(api, oracle, monkeypatch)
     n, a = m.search_by_projection_rows(fr, sf, occ, xy, level, viewcos, flags, tab, rows2, 3.0, 0.8)
     monkeypatch.delenv('ORBFE_FRAME_ZEROCOPY')
     assert n == want2[0] and (a == want2[1]).all()
+    # a row index outside the table is refused for a MapPoint that is searched (both routes), ignored for one that is not
+    bad = rows2.copy()
+    victim = int(np.nonzero((flags & 1) != 0)[0][7])
+    for r in (6000, 6000 | -0x80000000, 0x7fffffff):
+        bad[victim] = np.array([r], np.int64).astype(np.int32)[0] if r >= 0 else np.int32(r)
+        for zc in ('1', '0'):
+            monkeypatch.setenv('ORBFE_FRAME_ZEROCOPY', zc)
+            with pytest.raises(api.OrbfeError) as e:
+                m.search_by_projection_rows(fr, sf, occ, xy, level, viewcos, flags, tab, bad, 3.0, 0.8)
+            assert e.value.code == -1 and 'outside the table' in str(e.value)
+        monkeypatch.delenv('ORBFE_FRAME_ZEROCOPY')
+    fl2 = flags.copy()
+    fl2[victim] = 0                                     # not in view: its row index is never used
+    w3 = oracle.search_by_projection(k, d, bounds, sf, occ, xy, level, viewcos, fl2, mdesc2, 3.0, 0.8)
+    n, a = m.search_by_projection_rows(fr, sf, occ, xy, level, viewcos, fl2, tab, bad, 3.0, 0.8)
+    assert n == w3[0] and (a == w3[1]).all()
     m.synchronize()
     tab.free()
 
