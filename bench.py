@@ -154,17 +154,22 @@ def run_rank(args):
         # max-over-ranks of the elapsed time -- exercised here without a GPU, with a rank-dependent fake duration
         if dist is not None:
             dist.barrier()
-        el = 0.01 * (rank + 1)
+        own = 0.01 * (rank + 1)
+        el = own
         seeds = [wl.stream_seed(rank)]
+        mine = rank_record(rank, local_rank, None, 1000.0 / own, 1000.0 / own, None, 0.0, own, None, wl.stream_seed(rank))
+        per_rank = [mine]
         if dist is not None:
             t = torch.tensor([el], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t[0])
             seeds = [None] * world
             dist.all_gather_object(seeds, wl.stream_seed(rank))
+            per_rank = [None] * world
+            dist.all_gather_object(per_rank, mine)
         if rank == 0:
             print(json.dumps({'plumbing_only': True, 'value': None, 'n_gpus': world, 'max_elapsed': el, 'seeds': seeds,
-                              'steps': args.steps, 'warmup': args.warmup}), flush=True)
+                              'steps': args.steps, 'warmup': args.warmup, **per_rank_summary(per_rank, world * 1000.0 / el)}), flush=True)
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -254,6 +259,7 @@ def run_rank(args):
             torch.cuda.synchronize()
 
     host_cpu = [0.0]
+    own_elapsed = [0.0]
 
     def prewarm(source, seconds):
         t_end = time.perf_counter() + seconds
@@ -285,10 +291,12 @@ def run_rank(args):
         c0 = time.process_time()
         run(nsteps * cur['subs'], source, sample)
         sync()
+        t_own = time.perf_counter()
         host_cpu[0] = time.process_time() - c0      # CPU seconds of this rank's threads inside the timed region
         if dist is not None:
             dist.barrier()
         el = time.perf_counter() - t0
+        own_elapsed[0] = t_own - t0                # this rank's own time (before it waited for the others)
         if dist is not None:
             t = torch.tensor([el], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -302,6 +310,7 @@ def run_rank(args):
     if not args.no_verify and not args.no_match and not args.bow and args.pool == wl.POOL:
         table = load_digest_table(seed)
         verify = verify_period(wl, table, seed, B, lambda n, cb: run(n, 'hbm', cb))
+    verify['verified_own'] = verify['verified']
     if dist is not None:                        # every rank checks its own stream; rank 0 reports the conjunction
         flag = torch.tensor([1 if verify['verified'] else 0, 1 if verify['verified'] is None else 0], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.SUM)
@@ -316,6 +325,7 @@ def run_rank(args):
         chk = wl.PositionChecker(table, args.pool)
         for p0, res, prev_n in samples:
             chk.check(p0, *res, prev_n=prev_n)
+        verify['verified_own'] = bool(verify.get('verified_own') and not chk.bad and chk.frames > 0) if verify.get('verified_own') is not None else None
         out = {'timed_verified': bool(not chk.bad and chk.frames > 0), 'timed_frames_checked': chk.frames,
                'timed_batches_checked': len(samples), 'timed_distinct_period_positions': len(chk.positions),
                'timed_stream_positions': [int(samples[0][0]), int(samples[-1][0]) + cur['B'] - 1] if samples else None,
@@ -346,6 +356,10 @@ def run_rank(args):
     wstats = st.stats()
     head_pops = np.array(pop_times)
     head_matches = nmatch_total[0]
+    head_own = own_elapsed[0]
+    own_step_ms = np.diff(head_pops[subs - 1::subs]) * 1e3 if len(head_pops) >= 3 * subs else None
+
+    pcie_own = {}
 
     def pcie_leg():
         """The same stream from page-locked HOST frames, H2D of every frame inside the timed region (SURVEY.md s8(d)'s figure).
@@ -364,8 +378,11 @@ def run_rank(args):
             st.set_queue_slots(want_lookahead + 2)
             lookahead = min(want_lookahead, st.queue_slots() - 2)
         psteps, pwarm = max(2, min(args.steps, 12)), max(1, min(args.warmup, 2))
+        if dist is not None:
+            dist.barrier()                        # all ranks measure their link at the same time: root-complex contention is the expected limiter
         link = api.h2d_rate_gbs(local_rank, pinned.base, pinned.frame_bytes * pB)
         pel = timed(psteps, pwarm, 'pinned')
+        pcie_own['link'], pcie_own['fps'] = link, step_frames * psteps / max(own_elapsed[0], 1e-9)
         pchk = check_samples()
         pfps = world * step_frames * psteps / pel
         return {'value': round(pfps, 2), 'unit': 'frames/s', 'steps': psteps, 'warmup': pwarm,
@@ -380,6 +397,16 @@ def run_rank(args):
     # runner adds streams to the process and shifts the stream -> hardware-queue mapping of whatever is created after it (the
     # page-locked single-frame call read 0.195 instead of 0.170 ms behind it: its upload lane and its compute stream on different queues)
     pcie = pcie_leg() if world > 1 else None
+
+    # ---- every rank's own figures (N > 1: one all_gather_object): which rank / NUMA node lagged, and by how much
+    mine = rank_record(rank, local_rank, numa_node, step_frames * args.steps / max(head_own, 1e-9),
+                       (step_frames / (float(np.percentile(own_step_ms, 50)) * 1e-3)) if own_step_ms is not None and len(own_step_ms) > 1 else None,
+                       verify.get('verified_own'), head_cpu / max(head_own, 1e-9), head_own, pcie_own.get('link'), seed,
+                       pcie_own.get('fps'), numa_cpus)
+    per_rank = [mine]
+    if dist is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     if rank == 0:
         frames_done = world * step_frames * args.steps
@@ -486,6 +513,7 @@ def run_rank(args):
                        'batches_in_flight': max(1, args.depth), 'hip_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES'),
                        'numa': {'node_of_gpu': numa_node, 'cpus_bound': numa_cpus}},
             'verified': verify['verified'], 'outputs_sha256': verify['outputs_sha256'], 'verify': verify,
+            **per_rank_summary(per_rank, fps),
             'pcie_inclusive': pcie,
             'single_frame_latency': single,
             'single_frame_latency_host': single_host,
@@ -521,6 +549,30 @@ def run_rank(args):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def rank_record(rank, device, numa_node, value, p50, verified, host_cores, own_elapsed_s, h2d_link_gbs, seed, pcie_value=None, cpus_bound=None):
+    """One rank's own figures for the `per_rank` list of the bench line."""
+    r = lambda v, n=2: None if v is None else round(float(v), n)
+    return {'rank': rank, 'device': device, 'numa_node': numa_node, 'cpus_bound': cpus_bound, 'stream_seed': seed, 'value': r(value), 'p50': r(p50),
+            'verified': verified, 'host_cores': r(host_cores), 'own_elapsed_s': r(own_elapsed_s, 4), 'h2d_link_gbs': r(h2d_link_gbs),
+            'pcie_inclusive_value': r(pcie_value), 'host': socket.gethostname()}
+
+
+def per_rank_summary(per_rank, aggregate):
+    """`per_rank` (every rank's own rate over its own elapsed time, its NUMA node, its link) and what waiting for the slowest rank
+    costs: the whole-job value is N x the slowest rank's rate (max-over-ranks timing), so value / sum of the ranks' own rates = 1 for a
+    balanced node and drops when one rank (one NUMA node, one root complex) lags."""
+    per_rank = sorted([p for p in per_rank if p], key=lambda p: p['rank'])
+    vals = [p['value'] for p in per_rank if p.get('value')]
+    out = {'per_rank': per_rank}
+    if vals:
+        slow = min(per_rank, key=lambda p: p['value'] if p.get('value') else float('inf'))
+        out['scaling_efficiency_vs_min_rank'] = round(len(vals) * min(vals) / sum(vals), 4)
+        out['rank_value_min_max'] = [round(min(vals), 2), round(max(vals), 2)]
+        out['slowest_rank'] = {'rank': slow['rank'], 'device': slow['device'], 'numa_node': slow['numa_node']}
+        out['aggregate_over_sum_of_rank_rates'] = round(aggregate / sum(vals), 4) if aggregate else None
+    return out
 
 
 def load_digest_table(seed):

@@ -235,7 +235,12 @@ int orbfe_debug_sincos_host_check(uint32_t lo_bits, uint32_t hi_bits, uint32_t s
  * orbfe_search_for_initialization frame by frame.
  * ------------------------------------------------------------------------------------------- */
 typedef struct orbfe_stream orbfe_stream;
-/* batch = frames per push; depth = extraction batches in flight (1..8). */
+/* batch = frames per push; depth = extraction batches in flight (1..8).
+ * HARDWARE QUEUES: each batch in flight has its own HIP stream and the HIP runtime folds a process's streams onto GPU_MAX_HW_QUEUES
+ * hardware queues (default 4); two streams that share a queue serialise.  depth >= 4 therefore needs the ENVIRONMENT variable
+ * GPU_MAX_HW_QUEUES=8, set before the process makes its first HIP call (the runtime reads it once at start-up: a library cannot set
+ * it for its host process; bench.py sets it before importing torch).  Without it depth 4 runs at the rate of depth 3 (63.6 k instead of
+ * 66.7 k frames/s when measured); orbfe_stream_create says so on stderr once (ORBFE_QUIET=1 silences it). */
 int orbfe_stream_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device_id,
                         int batch, int depth, orbfe_stream** out);
 /* Batches the GPU is working on are waited for; batches still queued are dropped without being submitted.  Frames of

