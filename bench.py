@@ -477,6 +477,21 @@ def run_rank(args):
                     'issue_peak_per_s': round(peak, 1), 'achieved_per_s': round(rate, 1), 'frac': round(rate / peak, 4),
                     'frac_if_all_ops_were_2_cycle': round(rate / (1024 * 2.4e9 / 2.0), 4),
                     'note': 'wave64 VALU instructions (SQ_INSTS_VALU, separate rocprofv3 --pmc pass); peak = 1024 SIMDs x 2.4 GHz / cycles_per_inst'}
+        # ... and the scalar port beside it (round 5): a CU has ONE scalar ALU, visited round-robin by its four SIMDs -- a SIMD's scalar port
+        # takes one SALU instruction per ~4.25 cycles (tools/ubench/salu_rate.hip, profiles/r05_salu_rate.txt) and issues side by side
+        # with the vector port when the two instructions come from different waves (same file, "mix" rows)
+        salu = None
+        if prof.get('salu_insts_per_launch') and fast_ms_per_launch > 0:
+            scpi = prof.get('salu_cycles_per_inst') or 4.25
+            speak = 1024 * 2.4e9 / scpi
+            srate = (prof['salu_insts_per_launch'] + prof.get('smem_insts_per_launch', 0)) / (fast_ms_per_launch * 1e-3)
+            salu = {'insts_per_launch': prof['salu_insts_per_launch'], 'smem_insts_per_launch': prof.get('smem_insts_per_launch'),
+                    'insts_per_cell_wave': prof.get('salu_insts_per_cell_wave'), 'cycles_per_inst': scpi,
+                    'issue_peak_per_s': round(speak, 1), 'achieved_per_s': round(srate, 1), 'frac': round(srate / speak, 4),
+                    'scalar_over_vector_port_time': round((prof['salu_insts_per_launch'] + prof.get('smem_insts_per_launch', 0)) * scpi /
+                                                          (prof['valu_insts_per_launch'] * (prof.get('valu_cycles_per_inst') or 4.0)), 4) if prof.get('valu_insts_per_launch') else None,
+                    'note': 'SQ_INSTS_SALU + SQ_INSTS_SMEM (separate --pmc pass); peak = 1024 SIMDs x 2.4 GHz / 4.25 cycles per scalar instruction per SIMD '
+                            '(measured, profiles/r05_salu_rate.txt); the scalar and the vector port issue side by side (different waves), so the two fractions do not add'}
         step_ms = np.diff(head_pops[subs - 1::subs]) * 1e3 if len(head_pops) >= 3 * subs else None
         value_p50 = round(world * step_frames / (float(np.percentile(step_ms, 50)) * 1e-3), 2) if step_ms is not None and len(step_ms) > 1 else None
         # the WHOLE path against both roofs (not only its dominant kernel): SURVEY.md s8(d)'s algorithmic 30.03 MB per frame x
@@ -495,6 +510,11 @@ def run_rank(args):
                                 'cycles_per_inst': pcpi, 'issue_peak_per_s': round(ppeak, 1), 'achieved_per_s': round(prate, 1),
                                 'frac': round(prate / ppeak, 4), 'by_kernel': prof.get('pipeline_valu_insts_per_batch_by_kernel'),
                                 'note': 'all kernels of one %d-frame submission (extract + SearchForInitialization), counters from %s' % (B, str(prof.get('source', ''))[:40])}
+        if prof.get('pipeline_salu_insts_per_batch'):
+            scpi = prof.get('salu_cycles_per_inst') or 4.25
+            n_s = prof['pipeline_salu_insts_per_batch'] + prof.get('pipeline_smem_insts_per_batch', 0)
+            pipeline['salu'] = {'insts_per_batch': n_s, 'cycles_per_inst': scpi, 'issue_peak_per_s': round(1024 * 2.4e9 / scpi, 1),
+                                'achieved_per_s': round(n_s / batch_period_s, 1), 'frac': round(n_s / batch_period_s / (1024 * 2.4e9 / scpi), 4)}
         out = {
             'metric': 'frames/sec extract+match, 1920x1080 @ 2000 ORB feats',
             'value': round(fps, 2), 'value_p50': value_p50, 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -533,7 +553,7 @@ def run_rank(args):
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
                          'traffic_source': prof.get('source'),
                          'algorithmic_bytes_per_launch': fast_bytes_per_frame * B,
-                         'launch_ms': round(fast_ms_per_launch, 4), 'valu': valu, 'pipeline': pipeline},
+                         'launch_ms': round(fast_ms_per_launch, 4), 'valu': valu, 'salu': salu, 'pipeline': pipeline},
         }
         if world == 1 and not args.no_latency:
             out['config5_search_by_projection'] = config5_leg(api, local_rank, args.cpu_frames > 0)

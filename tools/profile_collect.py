@@ -23,13 +23,13 @@ shutil.copy(stats[0], os.path.join(dst, tag + '_kernel_stats.csv'))
 if os.path.exists(os.path.join(src, 'fetch_calibration.txt')):
     shutil.copy(os.path.join(src, 'fetch_calibration.txt'), os.path.join(dst, tag + '_fetch_calibration.txt'))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for d in ('pmc_FETCH_SIZE', 'pmc_WRITE_SIZE', 'pmc_SQ'):
+for d in ('pmc_FETCH_SIZE', 'pmc_WRITE_SIZE', 'pmc_SQ', 'pmc_SQ2'):
     for f in glob.glob(os.path.join(src, d, '**', '*counter_collection.csv'), recursive=True):
         for r in csv.DictReader(open(f)):
             k = r['Kernel_Name'].split('(')[0].replace('void ', '')
             agg[k][r['Counter_Name']].append(float(r['Counter_Value']))
 names = ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_WAVES', 'SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_INSTS_LDS', 'SQ_ACTIVE_INST_VALU', 'SQ_WAVE_CYCLES',
-         'SQ_BUSY_CYCLES', 'GRBM_GUI_ACTIVE')
+         'SQ_BUSY_CYCLES', 'GRBM_GUI_ACTIVE', 'SQ_INSTS_SMEM', 'SQ_ACTIVE_INST_SCA', 'SQ_INST_CYCLES_SALU', 'SQ_ACTIVE_INST_ANY', 'SQ_WAIT_INST_ANY')
 
 
 def steady(v):
@@ -74,12 +74,25 @@ if os.path.exists(cal):
             calib = ('FETCH_SIZE*1024 / bytes streamed = %.3f for dword-per-lane loads of a 1 GiB buffer (tools/ubench/fetch_calib, '
                      'same profile round): the counter tallies 128-B requests at 64 B for this width too' % ratio)
 commit = subprocess.run(['git', '-C', root, 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip()
-# the whole pipeline: vector instructions of ALL kernels per full batch = sum over every dispatch of the SQ pass / batches in it
-nb = len([x for x in agg[fast]['SQ_INSTS_VALU'] if x >= 0.8 * max(agg[fast]['SQ_INSTS_VALU'])])
-pipe_valu = sum(sum(agg[k].get('SQ_INSTS_VALU', [])) for k in agg) / max(nb, 1)
-pipe_active = sum(sum(agg[k].get('SQ_ACTIVE_INST_VALU', [])) for k in agg) / max(nb, 1)
+# the whole pipeline: instructions of ALL kernels per full batch = sum over every dispatch that collected the counter / batches among them
+# (a counter may have been collected in more than one pass: each counter is normalised by its own number of full FAST launches)
+def nbc(counter):
+    v = agg[fast].get(counter) or []
+    return max(len([x for x in v if x >= 0.8 * max(v)]), 1) if v else 1
+
+
+def pipe(counter):
+    return sum(sum(agg[k].get(counter, [])) for k in agg) / nbc(counter)
+
+
+nb = nbc('SQ_INSTS_VALU')
+pipe_valu, pipe_active = pipe('SQ_INSTS_VALU'), pipe('SQ_ACTIVE_INST_VALU')
 pipe_by_kernel = {k.replace('(anonymous namespace)::', '').replace('orbfe::', '')[:40]: int(sum(agg[k].get('SQ_INSTS_VALU', [])) / max(nb, 1)) for k in sorted(agg)
                   if agg[k].get('SQ_INSTS_VALU')}
+# the scalar unit: SALU + SMEM instructions of the dominant kernel and of all kernels of a batch (counters of pmc_SQ and pmc_SQ2 are
+# collected in different passes of the same command: a counter present in both is averaged over both)
+salu, smem, sca = per_batch('SQ_INSTS_SALU'), per_batch('SQ_INSTS_SMEM'), per_batch('SQ_ACTIVE_INST_SCA')
+pipe_salu, pipe_smem = pipe('SQ_INSTS_SALU'), pipe('SQ_INSTS_SMEM')
 out = {
     'batch': B,
     'kernel': fast,
@@ -91,6 +104,12 @@ out = {
     'valu_busy_frac_under_profiler': round(4.0 * active / 1024.0 / gui, 4) if gui and active else None,
     'pipeline_valu_insts_per_batch': int(pipe_valu), 'pipeline_valu_cycles_per_inst': round(4.0 * pipe_active / pipe_valu, 3) if pipe_valu else None,
     'pipeline_valu_insts_per_batch_by_kernel': pipe_by_kernel,
+    'salu_insts_per_launch': int(salu), 'smem_insts_per_launch': int(smem), 'salu_insts_per_cell_wave': round(salu / waves, 1) if waves else None,
+    'scalar_active_quadcycles_per_launch': int(sca),
+    # tools/ubench/salu_rate.hip (profiles/r05_salu_rate.txt): a SIMD's scalar port takes one SALU instruction per 4.2 - 4.9 cycles whatever
+    # the opcode and the number of waves (a CU's one scalar ALU serves its four SIMDs round-robin); 4.25 = the 4- and 8-wave rows
+    'salu_cycles_per_inst': 4.25,
+    'pipeline_salu_insts_per_batch': int(pipe_salu), 'pipeline_smem_insts_per_batch': int(pipe_smem),
     'source': 'profiles/%s_pmc_summary.csv (rocprofv3 --pmc, separate passes over `python3 bench.py`), measured at commit %s' % (tag, commit),
 }
 json.dump(out, open(os.path.join(dst, 'counters.json'), 'w'), indent=1)
