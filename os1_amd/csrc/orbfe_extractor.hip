@@ -35,6 +35,7 @@ int launch_pyramid(const PyramidParams& P, int nframes, hipStream_t st, const Co
 void launch_to_gray(const uint8_t* const* raw, long long rawStride, const uint8_t* const* gray, long long grayPitch, int rows,
                     int cols, int channels, const int coef[3], int shift, bool aligned, int nframes, hipStream_t st);
 void launch_fast(const PyramidParams& P, int nframes, hipStream_t st);
+uint32_t fast_task_geo(int fastW, int hCell);
 void launch_compact(const PyramidParams& P, int nframes, hipStream_t st);
 void launch_describe(const PyramidParams& P, const SelKp* sel, int nsel, float* angle, uint8_t* desc,
                      hipStream_t st);
@@ -522,11 +523,14 @@ struct orbfe_extractor {
     // pixels wide (queue entries hold x in 8 bits, the pre-test handles 4 groups of 16 pixels per row)
     std::vector<FastTask> tasks;
     tasks.reserve(Q.ncells);
+    Q.fastLean = 1;
     for (int l = 0; l < nlevels; l++) {
       LevelGeom& L = Q.lv[l];
       Q.taskStart[l] = (int)tasks.size();
       const bool pairOk = pairCells && 2 * L.wCell <= 64 && L.nCols >= 2;
       L.fastW = pairOk ? 2 * L.wCell : L.wCell;
+      const uint32_t geo = fast_task_geo(L.fastW, L.hCell);
+      if (geo == 0u && L.nRows * L.nCols > 0) Q.fastLean = 0;
       for (int i = 0; i < L.nRows; i++)
         for (int j = 0; j < L.nCols;) {
           const CellInfo& c0 = cells[L.cellBase + i * L.nCols + j];
@@ -537,6 +541,7 @@ struct orbfe_extractor {
           t.roiOff = l == 0 ? 0u : (uint32_t)(L.off + (long long)((int)c0.ey0 - 3) * L.pitch + ((int)c0.ex0 - 3));
           t.pitch = l == 0 ? 0u : (uint32_t)L.pitch;
           t.fastW = (uint8_t)L.fastW; t.hCell = (uint8_t)L.hCell; t.slotCap = (uint16_t)L.slotCap;
+          t.geo = geo;
           const bool valid0 = c0.ew > 0 && c0.eh > 0;
           t.ew0 = valid0 ? (uint8_t)c0.ew : 0;
           t.eh = valid0 ? (uint8_t)c0.eh : 0;

@@ -92,7 +92,13 @@ static FastArgs fast_args(const PyramidParams& P) {
 }
 
 __device__ uint32_t* g_fastStampBuf;   // [waves of the launch][8]
-template <int NPX, bool PAIRS, int ABL = 0>
+// LEAN (round 5): the prologue for the case every batch launch is in -- LDS-DMA with 16 bytes per lane, row pitches that are
+// multiples of 4, the zero line present, and every per-frame offset (frame * slab bytes, frame * slots, frame * cells) below 4 GiB,
+// all checked on the HOST (launch_fast) instead of by every wave: no staging-mode branches, the LDS carve and the rows-per-instruction
+// quotient come precomputed in the task record (FastTask::geo), pointer arithmetic is 32-bit offsets on 64-bit bases.  The set-up was
+// 242 of the wave's 339 scalar instructions (profiles/r04_fast_ablation.txt); the scalar port is a shared resource of the CU
+// (profiles/r05_salu_rate.txt) and those instructions sit in front of the wave's first memory request.
+template <int NPX, bool PAIRS, int ABL = 0, bool LEAN = false>
 // (amdgpu_num_sgpr(96): the kernel asks for 105 scalar registers by itself, which caps a SIMD at 6 waves; 94 with 3 values parked in
 // a vector register allow 7 -- +1 % in the pipeline, 80 / 88 measured the same)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fast_tasks(FastArgs P, int tpPad, int dma, int t0, int nt) {
@@ -131,7 +137,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fas
   const int ew0 = (int)(tw[1] & 0xffu), ew1 = PAIRS ? (int)((tw[1] >> 8) & 0xffu) : 0, eh = (int)((tw[1] >> 16) & 0xffu), level = (int)(tw[1] >> 24);
   const uint32_t cell0 = tw[2], slotOff0 = tw[3], roiOff = tw[4], pitchL = tw[5];
   const int fastW = (int)(tw[6] & 0xffu), hCell = (int)((tw[6] >> 8) & 0xffu), slotCap = (int)(tw[6] >> 16);
-  uint32_t* cnt = P.cellCount + (long long)f * P.ncells + cell0;
+  uint32_t* cnt;
+  if constexpr (LEAN) cnt = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(P.cellCount) + 4u * ((uint32_t)f * (uint32_t)P.ncells + cell0));
+  else cnt = P.cellCount + (long long)f * P.ncells + cell0;
   if (ew0 == 0) {
     if (lane == 0) cnt[0] = 0;
     return;
@@ -139,7 +147,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fas
   const int W2 = ew0 + ew1;   // emit width of the task
   long long stride;
   const uint8_t* roi;
-  if (level == 0) {
+  if constexpr (LEAN) {
+    // 32-bit offsets (the host has checked that they fit) on the two possible 64-bit bases, selected without a branch
+    const bool l0 = level == 0;
+    const uint32_t st32 = l0 ? (uint32_t)P.stride0 : pitchL;
+    const uint32_t off = l0 ? (uint32_t)(ey0 - 3) * st32 + (uint32_t)(ex0 - 3) : (uint32_t)f * (uint32_t)P.slabBytes + roiOff;
+    const uint8_t* base = l0 ? reinterpret_cast<const uint8_t*>(((unsigned long long)fpw.y << 32) | fpw.x) : P.slab;
+    stride = (long long)st32;
+    roi = base + off;
+  } else if (level == 0) {
     stride = P.stride0;
     roi = reinterpret_cast<const uint8_t*>(((unsigned long long)fpw.y << 32) | fpw.x) + (long long)(ey0 - 3) * stride + (ex0 - 3);
   } else {
@@ -148,12 +164,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fas
   }
   // LDS carve (level-uniform): ROI tile, score tile with a zero ring, queue (y<<8|x)
   // (dma == 2: 16-byte LDS-DMA pieces -- the pitch is a multiple of 16 that holds alignment offset + widest ROI row)
-  const int TP = dma == 2 ? ((fastW + 6 + 3 + 15) & ~15) : ((fastW + 6 + 3 + 3) & ~3) + tpPad;
+  // LEAN: the carve comes with the task (FastTask::geo = pieces per tile row | rows per instruction << 3 | score tile offset / 16 << 8 |
+  // queue offset / 16 << 18, written by fast_task_geo() below from the same formulas)
+  const uint32_t geo = tw[7];
+  const int TP = LEAN ? (int)(geo & 7u) << 4 : dma == 2 ? ((fastW + 6 + 3 + 15) & ~15) : ((fastW + 6 + 3 + 3) & ~3) + tpPad;
   const int SP = fastW + 2;
   uint8_t* tile = lds;
-  const int scOff = (TP * (hCell + 6) + 15) & ~15;   // 16-byte aligned: it is cleared by 16-byte LDS-DMA pieces
+  const int scOff = LEAN ? (int)((geo >> 8) & 0x3ffu) << 4 : (TP * (hCell + 6) + 15) & ~15;   // 16-byte aligned: it is cleared by 16-byte LDS-DMA pieces
   uint8_t* sc = tile + scOff;
-  uint16_t* queue = reinterpret_cast<uint16_t*>(lds + ((scOff + SP * (hCell + 2) + 15) & ~15));
+  uint16_t* queue = reinterpret_cast<uint16_t*>(lds + (LEAN ? (int)((geo >> 18) & 0x7ffu) << 4 : ((scOff + SP * (hCell + 2) + 15) & ~15)));
 
   const int rw = W2 + 6, rh = eh + 6;
   const int istr = (int)stride;
@@ -162,7 +181,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fas
   // byte offset of the ROI inside its first dword.
   const int a = (int)(reinterpret_cast<uintptr_t>(roi) & 3);
   if constexpr (ABL == 4) { asm volatile("" ::"s"(a), "s"(istr), "s"(TP) : "memory"); stamp[1] = __builtin_amdgcn_s_memtime(); }
-  if ((stride & 3) == 0 && dma == 2) {
+  if constexpr (LEAN) {
+    // the dma == 2 staging below with everything wave-uniform taken from the task: pieces per row, rows per instruction
+    const int ppr = (int)(geo & 7u), rpi = (int)((geo >> 3) & 31u);
+    const float rn = __builtin_amdgcn_rcpf((float)ppr);
+    const int lrow = (int)(((float)lane + 0.5f) * rn), lcol = lane - m24(lrow, ppr);
+    const bool on = lrow < rpi && 16 * lcol < a + rw;
+    const unsigned voff = (unsigned)(m24(lrow, istr) + 16 * lcol);
+    const uint8_t* gp = roi - a;
+    const uint32_t gstep = (uint32_t)rpi * (uint32_t)istr;
+    const int lstep = rpi * TP;
+    uint8_t* lp = tile;
+#pragma nounroll
+    for (int left = rh; left > 0; left -= rpi, gp += gstep, lp += lstep) {
+      unsigned vo = voff;
+      asm volatile("" : "+s"(gp), "+v"(vo));
+      if (on && lrow < left)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + vo),
+                                         (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
+    }
+  } else if ((stride & 3) == 0 && dma == 2) {
     // 16 bytes per lane (global_load_lds_dwordx4): TP / 16 pieces per tile row, 64 / pieces rows per instruction -- the 37-row tile
     // of a single cell is TWO instructions (seven with one dword per lane); the global side needs dword alignment only, a row's last
     // piece may reach up to 11 bytes past the ROI: inside the level's row (an emit region stays 16 pixels off the border)
@@ -254,7 +292,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fas
     }
   }
   tile += a;  // ROI pixel (x, y) lives at tile[y * TP + x]
-  if (dma && P.zeros) {
+  if constexpr (LEAN) {
+    // (as below; the loop is kept a loop: unrolled eight times by the compiler it was thirty scalar instructions of preamble for a
+    // trip count of one or two)
+    const int pieces = (SP * (eh + 2) + 15) >> 4;
+#pragma nounroll
+    for (int p0 = 0; p0 < pieces; p0 += 64)
+      if (lane < pieces - p0)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)P.zeros,
+                                         (__attribute__((address_space(3))) void*)(sc + 16 * p0), 16, 0, 0);
+  } else if (dma && P.zeros) {
     // the score tile is cleared by LDS-DMA too: every lane fetches the same 16 zero bytes (one cache line for the whole chip) and
     // lane L's copy lands at base + 16 L -- two instructions for the 1.1 KB tile, no vector instruction, no ds_write.  (The last
     // piece may run up to 15 bytes into the queue, which stage 1 writes later.)
@@ -280,7 +327,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fas
   }
 
   const unsigned long long below = (1ull << lane) - 1ull;
-  uint32_t* slot0 = P.slots + (long long)f * P.slotsPerFrame + slotOff0;
+  uint32_t* slot0;
+  if constexpr (LEAN) slot0 = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(P.slots) + 4u * ((uint32_t)f * (uint32_t)P.slotsPerFrame + slotOff0));
+  else slot0 = P.slots + (long long)f * P.slotsPerFrame + slotOff0;
   uint32_t* slot1 = slot0 + slotCap;
   int base0 = 0, base1 = 0;
   bool emit0 = true, emit1 = ew1 > 0;
@@ -293,7 +342,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fas
     int nq = 0;
     constexpr int GS = NPX == 16 ? 4 : 3, NS = NPX / 4;   // log2(NPX), 4-pixel windows per lane
     const int G = (W2 + NPX - 1) >> GS, nItems = G * eh;
-    const int stepY = 64 / G, stepG = 64 - stepY * G;   // item i+64 = (y + stepY, g + stepG) with one carry
+    // item i+64 = (y + stepY, g + stepG) with one carry.  64 / G from a byte table for G = 1..4 (all there is with 16 pixels per lane
+    // and tasks at most 64 pixels wide): the generic quotient is a 25-instruction reciprocal sequence per wave and pass
+    const int stepY = NPX == 16 ? (int)((0x10152040u >> ((G - 1) << 3)) & 0xffu) : 64 / G, stepG = 64 - stepY * G;
     auto stage1 = [&](auto aTag) {
       constexpr int A = decltype(aTag)::value;
       // The test is CONSERVATIVE (a superset of "two adjacent compass points of one polarity", stage 2 decides
@@ -563,6 +614,19 @@ static size_t fast_lds_bytes_level(const LevelGeom& L, int tpPad) {
                    2 * (size_t)L.fastW * L.hCell + 64;  // tile + score tile + u16 queue + slack for the group over-read
   return (b + 15) & ~(size_t)15;
 }
+// FastTask::geo of a level (the LEAN prologue's LDS carve and staging constants); 0: not representable / not the 16-byte LDS-DMA mode
+// -> the level's launches take the generic prologue
+uint32_t fast_task_geo(int fastW, int hCell) {
+  if (fast_dma_mode() != 2) return 0u;
+  const uint32_t TP = (uint32_t)((fastW + 6 + 3 + 15) & ~15), ppr = TP >> 4;
+  if (ppr == 0 || ppr > 7) return 0u;
+  const uint32_t rpi = 64u / ppr;
+  const uint32_t scOff = (TP * (uint32_t)(hCell + 6) + 15u) & ~15u;
+  const uint32_t qOff = (scOff + (uint32_t)(fastW + 2) * (uint32_t)(hCell + 2) + 15u) & ~15u;
+  if (rpi > 31u || (scOff >> 4) > 0x3ffu || (qOff >> 4) > 0x7ffu) return 0u;
+  return ppr | (rpi << 3) | ((scOff >> 4) << 8) | ((qOff >> 4) << 18);
+}
+
 size_t fast_lds_bytes(const PyramidParams& P, int tpPad) {
   size_t mx = 0;
   for (int l = 0; l < P.nlevels; l++) mx = std::max(mx, fast_lds_bytes_level(P.lv[l], tpPad));
@@ -600,7 +664,20 @@ void launch_fast(const PyramidParams& P, int nframes, hipStream_t st) {
     l = e;
     if (nt <= 0) continue;
     const dim3 grid(8 * ((nt + 7) / 8), nframes);
-    if (pairs)
+    // the LEAN prologue's preconditions, checked once per launch instead of by every wave
+    static const int leanEnv = [] { const char* e = getenv("ORBFE_FAST_LEAN"); return e ? atoi(e) : 1; }();
+    const unsigned long long frames = (unsigned long long)P.frameBase + (unsigned long long)nframes;
+    const bool lean = leanEnv && P.fastLean && dma == 2 && P.zeros && (P.stride0 & 3) == 0 && P.stride0 > 0 && P.stride0 < (1ll << 31) &&
+                      frames * (unsigned long long)P.slabBytes < (1ull << 32) && frames * (unsigned long long)P.slotsPerFrame * 4ull < (1ull << 32) &&
+                      frames * (unsigned long long)P.ncells * 4ull < (1ull << 32) && (unsigned long long)P.stride0 * 65536ull < (1ull << 32) * 16ull;
+    if (lean && !pairs && ablate == 0)
+      hipLaunchKernelGGL((k_fast_tasks<16, false, 0, true>), grid, dim3(64), need, st, FA, 0, dma, t0, nt);
+    else if (lean && !pairs && ablate == 4) {
+      if (t0 == 0) stamp_buffer_for((size_t)(P.ntasks + 64) * nframes);
+      hipLaunchKernelGGL((k_fast_tasks<16, false, 4, true>), grid, dim3(64), need, st, FA, 0, dma, t0, nt);
+    } else if (lean && !pairs && ablate == 1)
+      hipLaunchKernelGGL((k_fast_tasks<16, false, 1, true>), grid, dim3(64), need, st, FA, 0, dma, t0, nt);
+    else if (pairs)
       hipLaunchKernelGGL((k_fast_tasks<16, true>), grid, dim3(64), need, st, FA, 0, dma, t0, nt);
     else if (ablate == 1)
       hipLaunchKernelGGL((k_fast_tasks<16, false, 1>), grid, dim3(64), need, st, FA, 0, dma, t0, nt);

@@ -56,7 +56,7 @@ struct FastTask {
   uint32_t pitch;        // levels >= 1: row pitch of the level in the slab (level 0: the caller's stride, PyramidParams::stride0)
   uint8_t fastW, hCell;  // LevelGeom::fastW / hCell of the level (tile pitch and LDS carve)
   uint16_t slotCap;      // LevelGeom::slotCap
-  uint32_t pad;
+  uint32_t geo;          // the LEAN prologue's LDS carve and staging constants of the level (fast_task_geo(); 0: generic prologue only)
 };
 static_assert(sizeof(FastTask) == 32, "one s_load_dwordx8 per FAST wave");
 
@@ -85,6 +85,7 @@ struct PyramidParams {
   int iniTh, minTh;
   int frameBase;                    // first frame of this launch (sub-batch pipelining)
   int gaussVariant;                 // ORBFE_GAUSS_ED / ORBFE_GAUSS_ROUNDED: which GaussianBlur k_describe reproduces
+  int fastLean;                     // every task carries FastTask::geo: k_fast_tasks may take its LEAN prologue (launch_fast decides per launch)
 };
 
 // Small batches build the pyramid in ONE launch (k_pyramid_cone): a block owns a tile of the top level and computes
