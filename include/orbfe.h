@@ -211,6 +211,10 @@ int orbfe_debug_set_profiling(orbfe_extractor* h, int enable);
  * cycles summed over every wave since the last reset -- [0] entry -> geometry known, [1] -> ROI in LDS, [2] -> pre-test done,
  * [3] -> scores done, [4] -> end, [5] = waves counted.  tools/fast_phases.py prints the per-wave averages. */
 int orbfe_debug_fast_stamps(orbfe_extractor* h, unsigned long long out[8], int reset);
+/* Measurement only (environment ORBFE_SFI_DEBUG=1 when the process starts): one record of 8 ints per pair the GPU-resident
+ * SearchForInitialization resolved since the last reset -- frame in its batch, rounds of the fixed point, candidate entries, 1 if
+ * the serial finish ran, shader cycles of the block, n1, n2, 1 if the candidate pool fitted LDS (tools/sfi_rounds.py). */
+int orbfe_debug_sfi_records(orbfe_extractor* h, int32_t* out, int cap_records, int* n_out, int reset);
 /* Device-side restatement of (cosf, sinf)(angle_deg * pi/180) used by the rBRIEF kernel, evaluated
  * on the GPU for n angles (parity test against host libm). */
 int orbfe_debug_sincos(orbfe_extractor* h, const float* angle_deg, int n, float* cos_out, float* sin_out);

@@ -1483,6 +1483,16 @@ int orbfe_debug_fast_stamps(orbfe_extractor* h, unsigned long long out[8], int r
   if (orbfe::fast_stamps(out, reset)) { set_err("reading the stamp counters failed"); return ORBFE_ERR_HIP; }
   return ORBFE_OK;
 }
+extern "C++" { namespace orbfe { int sfi_debug_read(int* out, int capRecords, int reset); } }
+int orbfe_debug_sfi_records(orbfe_extractor* h, int32_t* out, int cap_records, int* n_out, int reset) {
+  if (!h || !out || !n_out || cap_records < 0) { set_err("NULL argument"); return ORBFE_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipDeviceSynchronize());
+  const int n = orbfe::sfi_debug_read(out, cap_records, reset);
+  if (n < 0) { set_err("reading the SearchForInitialization records failed"); return ORBFE_ERR_HIP; }
+  *n_out = n;
+  return ORBFE_OK;
+}
 float orbfe_extractor_scale_factor(const orbfe_extractor* h) { return h ? (float)h->scaleFactor : 0.f; }
 int orbfe_extractor_scale_tables(const orbfe_extractor* h, float* a, float* b, float* c, float* d) {
   if (!h) { set_err("handle is NULL"); return ORBFE_ERR_INVALID; }

@@ -297,7 +297,13 @@ __global__ __launch_bounds__(64) void k_sfi_resolve_seq(SfiParams S) {
 // keypoint from a still later one ...) are a handful long.  Afterwards vnMatches12[j] survives iff j is the last
 // query that took its keypoint (steal-back, :457-461) and the rotation histogram holds every accepted match, stolen
 // or not (:468-478 push without ever removing).
-constexpr int kSfiThreads = 512;
+// (threads per pair: a template parameter of k_sfi_resolve -- 512 = one query per thread at 1080p / 2000 features, launch_sfi)
+
+// measurement only (ORBFE_SFI_DEBUG=1, tools/sfi_rounds.py): one record per resolved pair -- {frame, rounds of the fixed point,
+// candidate entries, 1 if the serial finish ran, shader cycles of the block}; [0] of the buffer counts the records.  One buffer per
+// process (a device symbol), like the FAST phase stamps.
+__device__ int* g_sfiDbg;
+constexpr int kSfiDbgRecords = 1 << 16;
 
 // Serial replay of :430-466 by ONE wave, lanes over a query's candidates: the outcome M[i1] (i2 | dist << 16, -1 = none)
 // of every query in order, vMatchedDistance in `vmd`.  k_sfi_resolve falls back to it when the fixed point has not
@@ -348,9 +354,12 @@ __device__ void sfi_serial_outcomes(int lane, int n1, const int* pcnt, PoolAt po
   }
 }
 
+template <int kSfiThreads>
 __global__ __launch_bounds__(kSfiThreads) void k_sfi_resolve(SfiParams S, int ldsPool, int maxRounds) {
   extern __shared__ int sm[];
   const int fr = blockIdx.x, tid = threadIdx.x;
+  const unsigned long long tStart = g_sfiDbg ? __builtin_amdgcn_s_memtime() : 0ull;
+  int dbgSerial = 0;
   const int f = S.frameBase + fr;
   const SfiFrame F2 = sfi_frame(S, f);
   const SfiFrame F1 = sfi_frame(S, fr == 0 ? -1 : f - 1);
@@ -440,6 +449,7 @@ __global__ __launch_bounds__(kSfiThreads) void k_sfi_resolve(SfiParams S, int ld
     cur ^= 1;
     if (!any) break;
     if (++rounds >= maxRounds) {   // long steal chains: finish with one serial pass, then rebuild the taker lists from it
+      dbgSerial = 1;
       int* M2 = Mbuf[cur];
       int* vmd = head;             // [cap] >= n2 entries, lists are rebuilt below
       for (int i = tid; i < n2; i += kSfiThreads) vmd[i] = 0x7fffffff;
@@ -510,6 +520,35 @@ __global__ __launch_bounds__(kSfiThreads) void k_sfi_resolve(SfiParams S, int ld
   if ((tid & 63) == 0 && nm) atomicAdd(&misc[0], nm);
   __syncthreads();
   if (tid == 0) S.nmatches[f] = misc[0];
+  if (g_sfiDbg && tid == 0) {
+    const int r = atomicAdd(&g_sfiDbg[0], 1);
+    if (r < kSfiDbgRecords) {
+      int* rec = g_sfiDbg + 8 + 8 * r;
+      rec[0] = f; rec[1] = rounds; rec[2] = total; rec[3] = dbgSerial;
+      rec[4] = (int)(__builtin_amdgcn_s_memtime() - tStart); rec[5] = n1; rec[6] = n2; rec[7] = inLds;
+    }
+  }
+}
+
+static int* s_sfiDbg = nullptr;
+static void sfi_debug_setup() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  if (!getenv("ORBFE_SFI_DEBUG")) return;
+  if (hipMalloc((void**)&s_sfiDbg, sizeof(int) * (8 + 8 * kSfiDbgRecords)) != hipSuccess) { s_sfiDbg = nullptr; return; }
+  (void)hipMemset(s_sfiDbg, 0, sizeof(int) * (8 + 8 * kSfiDbgRecords));
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sfiDbg), &s_sfiDbg, sizeof s_sfiDbg);
+}
+// -> records copied (8 ints each: frame, rounds, candidate entries, serial finish, cycles, n1, n2, pool in LDS); reset clears the buffer
+int sfi_debug_read(int* out, int capRecords, int reset) {
+  if (!s_sfiDbg) return 0;
+  int n = 0;
+  if (hipMemcpy(&n, s_sfiDbg, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  n = std::min(std::min(n, kSfiDbgRecords), capRecords);
+  if (n > 0 && hipMemcpy(out, s_sfiDbg + 8, sizeof(int) * 8 * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (reset) (void)hipMemset(s_sfiDbg, 0, sizeof(int));
+  return n;
 }
 
 // Hand the level-0 data of the batch's last frame to the next batch (one small kernel instead of four D2D copies).
@@ -532,6 +571,7 @@ void launch_sfi_carry(const SfiParams& S, int lastFrame, SelKp* cSel, float* cAn
 }
 
 void launch_sfi(const SfiParams& S, int nframes, hipStream_t st) {
+  sfi_debug_setup();
   hipLaunchKernelGGL(k_sfi_sort, dim3(nframes), dim3(256), sizeof(int) * 3 * S.n0cap, st, S);
   hipLaunchKernelGGL(k_sfi_candidates, dim3(S.n0cap, nframes), dim3(64), 0, st, S);
   const bool seq = getenv("ORBFE_SFI_SEQUENTIAL") != nullptr;   // the serial replay, kept for A/B runs and tests
@@ -542,13 +582,17 @@ void launch_sfi(const SfiParams& S, int nframes, hipStream_t st) {
   const int fixedWords = 6 * S.n0cap + 1 + 32 + 2;
   int ldsPool = (60 * 1024 / 4) - fixedWords;   // candidate entries kept in LDS; longer pools are read from HBM
   if (ldsPool > 8192) ldsPool = 8192;
+  if (const char* e = getenv("ORBFE_SFI_LDS_POOL")) ldsPool = std::min(ldsPool, std::max(0, atoi(e)));
   if (ldsPool < 0) ldsPool = 0;
   // rounds of the fixed point before the kernel finishes with one serial pass on the device (typical inputs settle in
   // 3-6 rounds; a round costs O(queries x candidates x takers), so a cap keeps adversarial steal chains bounded)
   int maxRounds = 32;
   if (const char* e = getenv("ORBFE_SFI_MAX_ROUNDS")) maxRounds = atoi(e) < 1 ? 1 : atoi(e);
-  hipLaunchKernelGGL(k_sfi_resolve, dim3(nframes), dim3(kSfiThreads), sizeof(int) * (fixedWords + ldsPool), st, S, ldsPool,
-                     maxRounds);
+  static const int threads = [] { const char* e = getenv("ORBFE_SFI_THREADS"); return e ? atoi(e) : 512; }();
+  if (threads == 256)
+    hipLaunchKernelGGL(k_sfi_resolve<256>, dim3(nframes), dim3(256), sizeof(int) * (fixedWords + ldsPool), st, S, ldsPool, maxRounds);
+  else
+    hipLaunchKernelGGL(k_sfi_resolve<512>, dim3(nframes), dim3(512), sizeof(int) * (fixedWords + ldsPool), st, S, ldsPool, maxRounds);
 }
 
 }  // namespace orbfe
