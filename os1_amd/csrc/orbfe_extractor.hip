@@ -32,6 +32,7 @@
 
 namespace orbfe {
 int launch_pyramid(const PyramidParams& P, int nframes, hipStream_t st, const ConeParams* cone);
+void launch_ingest(const uint8_t* src, long long sstride, uint8_t* dst, long long dpitch, int rowBytes, int rows, hipStream_t st);
 void launch_to_gray(const uint8_t* const* raw, long long rawStride, const uint8_t* const* gray, long long grayPitch, int rows,
                     int cols, int channels, const int coef[3], int shift, bool aligned, int nframes, hipStream_t st);
 void launch_fast(const PyramidParams& P, int nframes, hipStream_t st);
@@ -227,6 +228,7 @@ struct orbfe_extractor {
   int qtLdsBudget = 120 * 1024;   // LDS bytes a quadtree problem may use for its candidates in small batches
   int pollWaitUs = 0;             // > 0: collect polls the stream and sleeps this long between polls
   bool zeroCopyOut = true;        // small plain batches: results written to host memory by the kernels
+  bool ingestKernel = true;       // small batches from page-locked host memory: fetched by a kernel on the compute stream (ORBFE_INGEST_KERNEL=0: copy command)
   int coneTile = 0;        // tile edge on the top level (0 = chosen from the level's size)
   int coneMaxFrames = 2;   // batches up to this size build the pyramid with k_pyramid_cone
   DevBuf<CellInfo> d_cells;
@@ -743,6 +745,16 @@ struct orbfe_extractor {
     if (!onDevice && !pinned) {
       (void)hipGetLastError();   // pageable memory: the runtime stages the copy synchronously; keep it on this handle's stream
       if ((rc = uploadFrames(0, nframes, gray, stride, r, rowBytes, st, devAt.data()))) return rc;
+    } else if (!onDevice && ingestKernel && nframes <= coneMaxFrames &&
+               ((((uintptr_t)gray[0] | (uintptr_t)gray[nframes - 1] | (uintptr_t)stride | (uintptr_t)rowBytes) & 3) == 0)) {   // (byte-aligned views: the copy engine)
+      // a one- or two-frame call from page-locked memory: the compute stream fetches the frame itself (k_ingest) -- no copy command
+      // on another queue, no event between the queues
+      for (int f = 0; f < nframes; f++) {
+        uint8_t* d = d_in.p + (size_t)inPitch * rows * f;
+        launch_ingest(gray[f], (long long)stride, d, inPitch, rowBytes, r, st);
+        devAt[f] = d;
+      }
+      HIP_TRY(hipGetLastError());
     } else if (!onDevice) {
       UploadLane* lane = upload_lane(device);
       if (!lane) { set_err("cannot create the upload stream"); return ORBFE_ERR_HIP; }
@@ -1446,6 +1458,7 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
   if (const char* pv = getenv("ORBFE_POLL_WAIT_US")) h->pollWaitUs = atoi(pv);
   if (const char* dw = getenv("ORBFE_DESCRIBE_WAVES")) h->describe4 = atoi(dw) != 1;
   if (const char* zv = getenv("ORBFE_ZERO_COPY")) h->zeroCopyOut = atoi(zv) != 0;
+  if (const char* iv = getenv("ORBFE_INGEST_KERNEL")) h->ingestKernel = atoi(iv) != 0;
   if (const char* qv = getenv("ORBFE_QT_LDS_BYTES")) h->qtLdsBudget = atoi(qv);
   if (const char* qj = getenv("ORBFE_QT_JUMP")) h->qtJump = atoi(qj) != 0;
   if (const char* cv = getenv("ORBFE_CONE_TILE")) h->coneTile = atoi(cv) <= 0 ? 0 : std::max(8, atoi(cv)) & ~3;

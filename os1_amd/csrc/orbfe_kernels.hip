@@ -1237,6 +1237,59 @@ void launch_to_gray(const uint8_t* const* raw, long long rawStride, const uint8_
 // ------------------------------------------------------------------------------------------------
 // Launchers (called by the host engine).
 // ------------------------------------------------------------------------------------------------
+// ---- k_ingest: a page-locked HOST frame -> its device copy, by a kernel on the compute stream ---------------------------------
+// The one-frame call of Frame.cc:133 hands over a host cv::Mat.  A copy command on the upload lane followed by an event the compute
+// stream waits for costs the copy (43 us for 2 MB) plus 18.5 us between the copy's end and the first kernel's start (two queues, one
+// signal).  Here the kernels' own stream reads the frame over PCIe itself: 16 bytes per lane, four requests in flight per lane, every
+// wave-instruction a contiguous kilobyte of a row; the next kernel starts behind it like behind any other kernel.
+// V = bytes per lane and request (16: pointers, strides and the row length are multiples of 16; 4: multiples of 4; 1 otherwise).
+template <int V, int U>
+__global__ __launch_bounds__(256) void k_ingest(const uint8_t* __restrict__ src, long long sstride, uint8_t* __restrict__ dst, long long dpitch,
+                                                int rowBytes, int rows) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef typename std::conditional<V == 16, u32x4, typename std::conditional<V == 4, uint32_t, uint8_t>::type>::type T;
+  const int perRow = (rowBytes + V - 1) / V;                       // V == 1 / 4 / 16: exact by the launcher's choice of V
+  const int total = perRow * rows;
+  const float rcpRow = 1.0f / (float)perRow;
+  const int i0 = blockIdx.x * 256 + threadIdx.x, step = gridDim.x * 256;
+  // U independent requests per lane before the first store
+  long long so[U], dof[U];
+  bool ok[U];
+  T v[U];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int i = i0 + u * step;
+    ok[u] = i < total;
+    const int ii = ok[u] ? i : 0;
+    int yy = (int)(((float)ii + 0.5f) * rcpRow);
+    int xx = ii - yy * perRow;
+    if (xx < 0) { yy--; xx += perRow; }                             // the float quotient may be one off near a row boundary
+    if (xx >= perRow) { yy++; xx -= perRow; }
+    so[u] = (long long)yy * sstride + (long long)V * xx;
+    dof[u] = (long long)yy * dpitch + (long long)V * xx;
+  }
+#pragma unroll
+  for (int u = 0; u < U; u++)
+    if (ok[u]) v[u] = __builtin_nontemporal_load(reinterpret_cast<const T*>(src + so[u]));
+#pragma unroll
+  for (int u = 0; u < U; u++)
+    if (ok[u]) *reinterpret_cast<T*>(dst + dof[u]) = v[u];
+}
+
+// host (page-locked, device-readable) frame -> device copy on `st`
+void launch_ingest(const uint8_t* src, long long sstride, uint8_t* dst, long long dpitch, int rowBytes, int rows, hipStream_t st) {
+  const uintptr_t all = (uintptr_t)src | (uintptr_t)dst | (uintptr_t)sstride | (uintptr_t)dpitch | (uintptr_t)rowBytes;
+  const int V = (all & 15) == 0 ? 16 : (all & 3) == 0 ? 4 : 1;
+  static const int U = [] { const char* e = getenv("ORBFE_INGEST_U"); return e ? atoi(e) : 4; }();   // requests in flight per lane (A/B)
+  const long long total = (long long)((rowBytes + V - 1) / V) * rows;
+  const int blocks = (int)std::max<long long>(1, (total + 256 * U - 1) / (256 * U));
+#define ORBFE_INGEST(VV, UU) hipLaunchKernelGGL((k_ingest<VV, UU>), dim3(blocks), dim3(256), 0, st, src, sstride, dst, dpitch, rowBytes, rows)
+  if (V == 16) { if (U == 2) ORBFE_INGEST(16, 2); else if (U == 8) ORBFE_INGEST(16, 8); else if (U == 1) ORBFE_INGEST(16, 1); else ORBFE_INGEST(16, 4); }
+  else if (V == 4) ORBFE_INGEST(4, 4);
+  else ORBFE_INGEST(1, 4);
+#undef ORBFE_INGEST
+}
+
 int launch_pyramid(const PyramidParams& P, int nframes, hipStream_t st, const ConeParams* cone) {
   const int last = cone ? cone->base : P.nlevels - 1;   // levels built one launch each
   if (cone) {
