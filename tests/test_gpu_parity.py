@@ -641,11 +641,12 @@ def test_latency_path_variants_agree(api, oracle, monkeypatch):
     """One- and two-frame calls take their own kernels (k_pyramid_cone, LDS-resident quadtree candidates, results written
     straight to the host arena, level-0 pointers in the kernel arguments).  Every switch of that path, alone and
     together, reproduces the oracle: cone tile sizes, the per-level pyramid kernels, candidates in HBM, the copied
-    result arena."""
+    result arena, page-locked host frames fetched by the compute stream's own kernel (k_ingest: widths that are multiples of 16, of 4,
+    and odd ones that go through the copy engine) or by a copy command (ORBFE_INGEST_KERNEL=0)."""
     cases = [(31, 1920, 1080, 2000, 1.2, 8), (32, 641, 479, 700, 1.2, 8), (33, 1280, 720, 1200, 1.3, 5), (34, 500, 400, 300, 1.5, 3),
              (35, 900, 500, 400, 2.0, 3)]      # scale 2.0: outside the cone kernel's range, per-level kernels by themselves
     settings = [{}, {'ORBFE_CONE_MAX_FRAMES': '0'}, {'ORBFE_QT_LDS_BYTES': '0'}, {'ORBFE_ZERO_COPY': '0'}, {'ORBFE_DESCRIBE_WAVES': '1'}, {'ORBFE_QT_JUMP': '0'}, {'ORBFE_CONE_TILE': '16'},
-                {'ORBFE_CONE_TILE': '48'}, {'ORBFE_QT_LDS_BYTES': '20000'},
+                {'ORBFE_CONE_TILE': '48'}, {'ORBFE_QT_LDS_BYTES': '20000'}, {'ORBFE_INGEST_KERNEL': '0'},
                 {'ORBFE_CONE_MAX_FRAMES': '0', 'ORBFE_QT_LDS_BYTES': '0', 'ORBFE_ZERO_COPY': '0'}]
     for seed, W, H, N, sf, nl in cases:
         img = synth(seed, W, H)
