@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, 'liborbfe.so')
+_SO = os.environ.get('ORBFE_LIB') or os.path.join(_HERE, 'liborbfe.so')   # ORBFE_LIB: an A/B build of the library (developer aid)
 
 KP_DTYPE = np.dtype([('x', 'f4'), ('y', 'f4'), ('size', 'f4'), ('angle', 'f4'), ('response', 'f4'),
                      ('octave', 'i4'), ('class_id', 'i4')])

@@ -103,6 +103,9 @@ template <int NPX, bool PAIRS, int ABL = 0, bool LEAN = false>
 // a vector register allow 7 -- +1 % in the pipeline, 80 / 88 measured the same)
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fast_tasks(FastArgs P, int tpPad, int dma, int t0, int nt) {
   extern __shared__ __align__(16) uint8_t lds[];
+#if defined(ORBFE_FAST_PRIO) && ORBFE_FAST_PRIO
+  __builtin_amdgcn_s_setprio(ORBFE_FAST_PRIO);   // experiment (round 5): the long kernel's waves win instruction arbitration
+#endif
   unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
   if constexpr (ABL == 4) stamp[0] = __builtin_amdgcn_s_memtime();
   // this launch works on tasks [t0, t0 + nt): the levels of one LDS class (launch_fast)

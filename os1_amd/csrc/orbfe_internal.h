@@ -100,6 +100,16 @@ struct ConeParams {
   const ConeRange* regY;            // [tilesY][kMaxLevels]
 };
 
+// Wave priority of the kernels that are NOT the long vector-issue-bound FAST launch (experiment, round 5: -DORBFE_TAIL_PRIO=1..3 makes
+// their waves win instruction arbitration on a SIMD they share with another batch's FAST waves; 0 = off, the default build)
+#ifndef ORBFE_TAIL_PRIO
+#define ORBFE_TAIL_PRIO 0
+#endif
+#if ORBFE_TAIL_PRIO
+#define ORBFE_TAIL_PRIO_SET() __builtin_amdgcn_s_setprio(ORBFE_TAIL_PRIO)
+#else
+#define ORBFE_TAIL_PRIO_SET() ((void)0)
+#endif
 #ifdef __HIPCC__
 // Level-0 pointer of frame f, in SCALAR registers (f is uniform for a block): a lane-held base would turn every load
 // of the frame into 64-bit vector address arithmetic.

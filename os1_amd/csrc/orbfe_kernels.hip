@@ -222,6 +222,7 @@ struct ResizeLevel {
 
 template <int LP, int RH>
 __global__ __launch_bounds__(256) void k_resize_fixed(ResizeLevel R, int tilesX, int ntiles, unsigned rcpTilesX, int dma) {
+  ORBFE_TAIL_PRIO_SET();
   __shared__ __align__(16) uint8_t rz[LP * RH];
   __shared__ __align__(16) uint16_t H[RH * 64];
   struct { int w, h, pitch; const int* xofs; const short* xalpha; const unsigned* yofc; const short* ybeta; } D = {R.dw, R.dh, R.dpitch, R.xofs, R.xalpha, R.yofc, R.ybeta};
@@ -592,6 +593,7 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 }
 
 __global__ __launch_bounds__(64) void k_compact(PyramidParams P) {
+  ORBFE_TAIL_PRIO_SET();
   const int cell0 = blockIdx.x * 64, lane = threadIdx.x, f = P.frameBase + blockIdx.y;
   const uint32_t* cnt = P.cellCount + (long long)f * P.ncells;
   const int cell = cell0 + lane;
@@ -877,6 +879,7 @@ struct DescribeArgs {
 // (one- and two-frame calls: a keypoint's 760 dependent-ish instructions are the latency of the whole kernel there).
 template <int WAVES, int GAUSS>
 __global__ __launch_bounds__(64 * WAVES) void k_describe(DescribeArgs A) {
+  ORBFE_TAIL_PRIO_SET();
   constexpr int NT = 64 * WAVES;
   // Every table a lane will need depends on its lane number only: ALL of them are requested here, before the first wait of
   // the kernel, instead of one dependent round trip per pass iteration (4 + 6 + 5 of them for one wave) -- round 4.

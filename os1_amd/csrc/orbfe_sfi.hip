@@ -51,6 +51,7 @@ __device__ __forceinline__ SfiFrame sfi_frame(const SfiParams& S, int f) {
 
 // ---- per frame: candidate enumeration order -------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_sfi_sort(SfiParams S) {
+  ORBFE_TAIL_PRIO_SET();
   // counting sort by grid cell; inside a cell by keypoint index (the order mGrid's vectors were filled in)
   constexpr int kCells = kSfiGridCols * kSfiGridRows, kPer = kCells / 256;
   static_assert(kCells % 256 == 0, "cells per thread");
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(256) void k_sfi_sort(SfiParams S) {
 
 // ---- per (pair, query): ordered candidate list with distances -------------------------------------------------
 __global__ __launch_bounds__(64) void k_sfi_candidates(SfiParams S) {
+  ORBFE_TAIL_PRIO_SET();
   const int i1 = blockIdx.x, fr = blockIdx.y, lane = threadIdx.x;
   const int f = S.frameBase + fr;
   const SfiFrame F2 = sfi_frame(S, f);
@@ -356,6 +358,7 @@ __device__ void sfi_serial_outcomes(int lane, int n1, const int* pcnt, PoolAt po
 
 template <int kSfiThreads>
 __global__ __launch_bounds__(kSfiThreads) void k_sfi_resolve(SfiParams S, int ldsPool, int maxRounds) {
+  ORBFE_TAIL_PRIO_SET();
   extern __shared__ int sm[];
   const int fr = blockIdx.x, tid = threadIdx.x;
   const unsigned long long tStart = g_sfiDbg ? __builtin_amdgcn_s_memtime() : 0ull;
