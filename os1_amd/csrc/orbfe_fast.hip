@@ -666,6 +666,10 @@ void launch_fast(const PyramidParams& P, int nframes, hipStream_t st) {
     const int t0 = P.taskStart[l], nt = P.taskStart[e] - t0;
     l = e;
     if (nt <= 0) continue;
+    // experiment (round 5): a batch launch may ask for MORE LDS than it needs so that fewer FAST waves are resident and another
+    // batch's multi-wave workgroups (pyramid tiles: 256 threads, 15 - 20 KB of LDS) find room beside them
+    static const int ldsFloor = [] { const char* e2 = getenv("ORBFE_FAST_LDS_FLOOR"); return e2 ? atoi(e2) : 0; }();
+    if (nframes > 2 && ldsFloor > 0) need = std::max(need, (size_t)ldsFloor);
     const dim3 grid(8 * ((nt + 7) / 8), nframes);
     // the LEAN prologue's preconditions, checked once per launch instead of by every wave
     static const int leanEnv = [] { const char* e = getenv("ORBFE_FAST_LEAN"); return e ? atoi(e) : 1; }();
