@@ -214,6 +214,13 @@ struct orbfe_extractor {
   DevBuf<uint16_t> d_own;   // node id per candidate (quadtree)
   hipEvent_t evQt[2] = {};
   hipStream_t qtStream = nullptr;       // high-priority stream for the latency-bound quadtree kernel
+  // The TAIL of a matched batch -- SearchForInitialization's four small kernels and the result copy -- on a high-priority stream of
+  // its own (round 5, ORBFE_TAIL_STREAM=1): their few multi-wave workgroups queue behind another batch's 400 000 single-wave FAST
+  // workgroups on an ordinary queue (profiles/r05_sfi_resolve_tail.txt) and every microsecond of tail latency is throughput with a
+  // fixed number of batches in flight.  One hand-over (event) per batch; the chain ends on that stream, collect waits for it.
+  hipStream_t tailStream = nullptr;
+  hipEvent_t evTailIn = nullptr;
+  bool tailOwnStream = false, pendingTail = false;
   hipEvent_t evQtIn = nullptr, evQtOut = nullptr;
   bool qtOwnStream = false;  // measured slower on MI355X (cross-stream event waits cost more than the overlap gains); ORBFE_QT_STREAM=1 enables
   std::vector<int> frameKpBase, frameKpCount;
@@ -305,6 +312,8 @@ struct orbfe_extractor {
     if (evQtIn) (void)hipEventDestroy(evQtIn);
     if (evQtOut) (void)hipEventDestroy(evQtOut);
     if (qtStream) (void)hipStreamDestroy(qtStream);
+    if (tailStream) (void)hipStreamDestroy(tailStream);
+    if (evTailIn) (void)hipEventDestroy(evTailIn);
     d_own.release();
     if (evFrame0) (void)hipEventDestroy(evFrame0);
     if (evUpload) (void)hipEventDestroy(evUpload);
@@ -866,6 +875,7 @@ struct orbfe_extractor {
       pendingBow = true;
     }
     pendingMatched = false;
+    pendingTail = false;
     if (ms && ms->chain) {
       // SearchForInitialization of every frame against its predecessor, on the data that is already in HBM
       orbfe_sfi_chain& ch = *ms->chain;
@@ -887,15 +897,31 @@ struct orbfe_extractor {
       SP.window = (float)ms->window; SP.nnratio = ms->nnratio; SP.checkOri = ms->checkOri;
       SP.order = d_sfiOrder.p; SP.orderCount = d_sfiOrderCount.p; SP.pool = d_sfiPool.p; SP.pcount = d_sfiPcount.p;
       SP.matches12 = d_m12.p; SP.nmatches = d_nm.p;
-      if (ch.seq > 0) HIP_TRY(hipStreamWaitEvent(st, ch.ready[prev], 0));
-      launch_sfi(SP, nframes, st);
+      // (see tailStream above) everything from here to the end of the batch on the tail stream
+      const bool tail = tailOwnStream && tailStream && nframes > coneMaxFrames && !zeroCopy;
+      hipStream_t ts = tail ? tailStream : st;
+      if (tail) {
+        HIP_TRY(hipEventRecord(evTailIn, st));
+        HIP_TRY(hipStreamWaitEvent(ts, evTailIn, 0));
+      }
+      pendingTail = tail;
+      if (ch.seq > 0) HIP_TRY(hipStreamWaitEvent(ts, ch.ready[prev], 0));
+      launch_sfi(SP, nframes, ts);
       HIP_TRY(hipGetLastError());
       // hand the last frame's level-0 data to the next batch
-      launch_sfi_carry(SP, nframes - 1, ch.sel[cur].p, ch.angle[cur].p, ch.desc[cur].p, ch.count.p + cur, st);
+      launch_sfi_carry(SP, nframes - 1, ch.sel[cur].p, ch.angle[cur].p, ch.desc[cur].p, ch.count.p + cur, ts);
       HIP_TRY(hipGetLastError());
-      HIP_TRY(hipEventRecord(ch.ready[cur], st));
+      HIP_TRY(hipEventRecord(ch.ready[cur], ts));
       ch.seq++;
       pendingMatched = true;
+      if (tail) {
+        HIP_TRY(hipMemcpyAsync(h_outArena.p, d_outArena.p, outArenaBytes, hipMemcpyDeviceToHost, ts));
+        submitProfiled = prof;
+        tSubmit0 = t0;
+        tSubmit1 = now_ms();
+        pendingFrames = nframes;
+        return ORBFE_OK;
+      }
     }
     if (!zeroCopy) HIP_TRY(hipMemcpyAsync(h_outArena.p, d_outArena.p, outArenaBytes, hipMemcpyDeviceToHost, st));   // all results, one copy
     submitProfiled = prof;
@@ -911,7 +937,7 @@ struct orbfe_extractor {
     HIP_TRY(hipSetDevice(device));
     const int nframes = pendingFrames;
     pendingFrames = 0;
-    hipStream_t st = streams[0];
+    hipStream_t st = pendingTail ? tailStream : streams[0];   // a matched batch ends on the tail stream (everything on streams[0] precedes it)
     const double t0 = tSubmit0, t1 = tSubmit1;
     const double t1b = now_ms();
     if (pollWaitUs > 0) {   // sleep-poll instead of the runtime's spinning wait (pipelined callers: the wake-up delay is hidden)
@@ -1451,6 +1477,14 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
            hipEventCreateWithFlags(&h->evQtIn, hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&h->evQtOut, hipEventDisableTiming) == hipSuccess;
     if (!evOk) { set_err("creating the quadtree stream failed"); delete h; return ORBFE_ERR_HIP; }
+    if (const char* tv = getenv("ORBFE_TAIL_STREAM")) h->tailOwnStream = atoi(tv) != 0;
+    if (h->tailOwnStream) {
+      const int prio = getenv("ORBFE_TAIL_PRIORITY") ? atoi(getenv("ORBFE_TAIL_PRIORITY")) : greatest;
+      if (hipStreamCreateWithPriority(&h->tailStream, hipStreamNonBlocking, prio) != hipSuccess ||
+          hipEventCreateWithFlags(&h->evTailIn, hipEventDisableTiming) != hipSuccess) {
+        set_err("creating the tail stream failed"); delete h; return ORBFE_ERR_HIP;
+      }
+    }
   }
   if (const char* hv = getenv("ORBFE_HOST_QUADTREE")) h->gpuQuadtree = atoi(hv) == 0;
   if (const char* pv = getenv("ORBFE_FAST_PAIRS")) h->pairCells = atoi(pv) != 0;
