@@ -221,6 +221,11 @@ struct orbfe_extractor {
   hipStream_t tailStream = nullptr;
   hipEvent_t evTailIn = nullptr;
   bool tailOwnStream = false, pendingTail = false;
+  // ... and the PYRAMID of a batch on a stream of its own (ORBFE_PYR_STREAM=1, ORBFE_PYR_PRIORITY): the next FAST launch cannot start
+  // before its batch's seven resize launches are done, and beside another batch's FAST launch they take 770 us instead of 269
+  hipStream_t pyrStream = nullptr;
+  hipEvent_t evPyrDone = nullptr;
+  bool pyrOwnStream = false;
   hipEvent_t evQtIn = nullptr, evQtOut = nullptr;
   bool qtOwnStream = false;  // measured slower on MI355X (cross-stream event waits cost more than the overlap gains); ORBFE_QT_STREAM=1 enables
   std::vector<int> frameKpBase, frameKpCount;
@@ -313,6 +318,8 @@ struct orbfe_extractor {
     if (evQtOut) (void)hipEventDestroy(evQtOut);
     if (qtStream) (void)hipStreamDestroy(qtStream);
     if (tailStream) (void)hipStreamDestroy(tailStream);
+    if (pyrStream) (void)hipStreamDestroy(pyrStream);
+    if (evPyrDone) (void)hipEventDestroy(evPyrDone);
     if (evTailIn) (void)hipEventDestroy(evTailIn);
     d_own.release();
     if (evFrame0) (void)hipEventDestroy(evFrame0);
@@ -749,6 +756,8 @@ struct orbfe_extractor {
     for (int f = 0; f < nframes; f++)
       if (!gray[f]) { set_err("frame %d is NULL", f); return ORBFE_ERR_INVALID; }
     devAt.resize(nframes);
+    const bool pyrOwn = pyrOwnStream && pyrStream && nframes > coneMaxFrames && !frontLane;
+    hipStream_t fs = pyrOwn ? pyrStream : st;   // the stream the pyramid (and what feeds it) runs on
     hipPointerAttribute_t attr;
     const bool pinned = !onDevice && hipPointerGetAttributes(&attr, gray[0]) == hipSuccess && attr.type == hipMemoryTypeHost;
     if (!onDevice && !pinned) {
@@ -770,7 +779,7 @@ struct orbfe_extractor {
       std::lock_guard<std::mutex> lk(lane->mu);
       if ((rc = uploadFrames(0, nframes, gray, stride, r, rowBytes, lane->stream, devAt.data()))) return rc;
       HIP_TRY(hipEventRecord(evUpload, lane->stream));
-      HIP_TRY(hipStreamWaitEvent(st, evUpload, 0));
+      HIP_TRY(hipStreamWaitEvent(fs, evUpload, 0));
     }
     bool rawAligned = ((onDevice ? (long long)stride : inPitch) & 3) == 0;
     for (int f = 0; f < nframes; f++) {
@@ -789,7 +798,7 @@ struct orbfe_extractor {
       P.frameInline[1] = h_frame0.p[nframes - 1];
     } else {
       P.frame0 = d_frame0.p;
-      HIP_TRY(hipMemcpyAsync(d_frame0.p, h_frame0.p, sizeof(void*) * nframes * (ch == 1 ? 1 : 2), hipMemcpyHostToDevice, st));
+      HIP_TRY(hipMemcpyAsync(d_frame0.p, h_frame0.p, sizeof(void*) * nframes * (ch == 1 ? 1 : 2), hipMemcpyHostToDevice, fs));
     }
     if (ch > 1) {
       // OpenCV RGB2Gray<uchar>: 15-bit coefficients {R 9798, G 19235, B 3735} (>= 4.1.1) or 14-bit {4899, 9617, 1868}
@@ -797,7 +806,7 @@ struct orbfe_extractor {
       const int cr = q15 ? 9798 : 4899, cg = q15 ? 19235 : 9617, cb = q15 ? 3735 : 1868;
       const bool rgb = inFormat == ORBFE_INPUT_RGB8 || inFormat == ORBFE_INPUT_RGBA8;
       const int coef[3] = {rgb ? cr : cb, cg, rgb ? cb : cr};
-      launch_to_gray(d_frame0.p + nframes, rawStride, d_frame0.p, grayPitch, r, c, ch, coef, q15 ? 15 : 14, rawAligned, nframes, st);
+      launch_to_gray(d_frame0.p + nframes, rawStride, d_frame0.p, grayPitch, r, c, ch, coef, q15 ? 15 : 14, rawAligned, nframes, fs);
     }
     const bool prof = profileKernels;
     {
@@ -809,7 +818,11 @@ struct orbfe_extractor {
         if (w && w != evFront && w != evPyr) HIP_TRY(hipStreamWaitEvent(st, w, 0));
       }
       if (prof) HIP_TRY(hipEventRecord(ev[0][0], st));
-      if (launch_pyramid(P, nframes, st, coneOk && nframes <= coneMaxFrames ? &cone : nullptr)) { set_err("cannot configure the pyramid kernel"); return ORBFE_ERR_HIP; }
+      if (launch_pyramid(P, nframes, fs, coneOk && nframes <= coneMaxFrames ? &cone : nullptr)) { set_err("cannot configure the pyramid kernel"); return ORBFE_ERR_HIP; }
+      if (pyrOwn) {
+        HIP_TRY(hipEventRecord(evPyrDone, fs));
+        HIP_TRY(hipStreamWaitEvent(st, evPyrDone, 0));
+      }
       if (fl && frontSplit) {
         HIP_TRY(hipEventRecord(evPyr, st));
         fl->lastPyr = evPyr;
@@ -1477,6 +1490,14 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
            hipEventCreateWithFlags(&h->evQtIn, hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&h->evQtOut, hipEventDisableTiming) == hipSuccess;
     if (!evOk) { set_err("creating the quadtree stream failed"); delete h; return ORBFE_ERR_HIP; }
+    if (const char* pv = getenv("ORBFE_PYR_STREAM")) h->pyrOwnStream = atoi(pv) != 0;
+    if (h->pyrOwnStream) {
+      const int prio = getenv("ORBFE_PYR_PRIORITY") ? atoi(getenv("ORBFE_PYR_PRIORITY")) : greatest;
+      if (hipStreamCreateWithPriority(&h->pyrStream, hipStreamNonBlocking, prio) != hipSuccess ||
+          hipEventCreateWithFlags(&h->evPyrDone, hipEventDisableTiming) != hipSuccess) {
+        set_err("creating the pyramid stream failed"); delete h; return ORBFE_ERR_HIP;
+      }
+    }
     if (const char* tv = getenv("ORBFE_TAIL_STREAM")) h->tailOwnStream = atoi(tv) != 0;
     if (h->tailOwnStream) {
       const int prio = getenv("ORBFE_TAIL_PRIORITY") ? atoi(getenv("ORBFE_TAIL_PRIORITY")) : greatest;
