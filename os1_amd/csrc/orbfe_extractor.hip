@@ -936,7 +936,10 @@ struct orbfe_extractor {
         return ORBFE_OK;
       }
     }
-    if (!zeroCopy) HIP_TRY(hipMemcpyAsync(h_outArena.p, d_outArena.p, outArenaBytes, hipMemcpyDeviceToHost, st));   // all results, one copy
+    // (ORBFE_DEBUG_SKIP_RESULT_COPY=1: measurement only -- the upper bound of what writing the results from the kernels would buy; the
+    // caller then reads stale results)
+    static const bool skipCopy = getenv("ORBFE_DEBUG_SKIP_RESULT_COPY") && atoi(getenv("ORBFE_DEBUG_SKIP_RESULT_COPY")) != 0;
+    if (!zeroCopy && !skipCopy) HIP_TRY(hipMemcpyAsync(h_outArena.p, d_outArena.p, outArenaBytes, hipMemcpyDeviceToHost, st));   // all results, one copy
     submitProfiled = prof;
     tSubmit0 = t0;
     tSubmit1 = now_ms();
