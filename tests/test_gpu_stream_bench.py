@@ -203,3 +203,20 @@ def test_stream_runner_4k_4000_features(api, oracle):
             total += on
     assert total > 1000
     st.close()
+
+
+def test_stream_create_warns_about_hardware_queues(api):
+    """Four batches in flight need GPU_MAX_HW_QUEUES=8 in the process's environment before its first HIP call (include/orbfe.h,
+    INTEGRATION.md): a library cannot set it for its host, so orbfe_stream_create says so on stderr -- once, only for depth >= 4, and
+    not when the variable is set (bench.py sets it) or ORBFE_QUIET=1."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from os1_amd import api\n"
+            "for d in (3, 4, 4):\n"
+            "    api.Stream(500, 1.2, 8, 20, 7, 0, 2, d).close()\n") % ROOT
+    base = {k: v for k, v in os.environ.items() if k not in ('GPU_MAX_HW_QUEUES', 'ORBFE_QUIET')}
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=base)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stderr.count('GPU_MAX_HW_QUEUES') >= 1 and r.stderr.count('liborbfe: orbfe_stream_create(depth = 4)') == 1
+    for extra in ({'GPU_MAX_HW_QUEUES': '8'}, {'ORBFE_QUIET': '1'}):
+        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=dict(base, **extra))
+        assert r.returncode == 0 and 'liborbfe: orbfe_stream_create' not in r.stderr
