@@ -454,6 +454,18 @@ def run_rank(args):
                     lat.append(time.perf_counter() - t_a)
                 lat = np.array(lat[10:]) * 1e3
                 single_host[name] = {'ms_median': round(float(np.median(lat)), 4), 'ms_p90': round(float(np.percentile(lat, 90)), 4)}
+            # (c) the caller's OWN pageable buffer registered once (orbfe_host_register: a capture ring, a long-lived cv::Mat): page-locked route
+            ring = np.stack([frames[i % len(frames)] for i in range(nlat)])
+            reg = api.RegisteredArray(ring)
+            lat = []
+            for i in range(nlat + 10):
+                p = ring[i % nlat].ctypes.data
+                t_a = time.perf_counter()
+                ex.extract_batch_ptrs([p], H, W, W, False, kbuf, dbuf)
+                lat.append(time.perf_counter() - t_a)
+            reg.close()
+            lat = np.array(lat[10:]) * 1e3
+            single_host['registered'] = {'ms_median': round(float(np.median(lat)), 4), 'ms_p90': round(float(np.percentile(lat, 90)), 4)}
             single_host['call'] = ('blocking orbfe_extract_batch of ONE 1080p frame in HOST memory (the cv::Mat of Frame.cc:133), '
                                    'keypoints + descriptors returned to host memory, %d calls on distinct frames' % nlat)
             pin_lat.free()

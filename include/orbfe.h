@@ -67,6 +67,13 @@ int orbfe_device_synchronize(int device_id);
  * writes into it directly. */
 int orbfe_host_alloc(size_t bytes, void** out);
 int orbfe_host_free(void* ptr);
+/* The same for a buffer the caller already owns (a capture ring, a decoder's output, the data of a long-lived cv::Mat): page-locks
+ * [ptr, ptr + bytes) and maps it for the GPU (hipHostRegister); frames inside it then take the page-locked route -- for the one-frame
+ * call of Frame.cc:133 that is 0.15 ms instead of 0.19 ms at 1080p.  Registering costs hundreds of microseconds: do it once per
+ * buffer, not per frame, and unregister BEFORE the memory is freed (a freed-and-reallocated range that is still registered would be
+ * read through its old pages). */
+int orbfe_host_register(void* ptr, size_t bytes);
+int orbfe_host_unregister(void* ptr);
 /* NUMA placement for multi-GPU hosts (one process or thread group per GPU): the NUMA node the
  * device hangs off (sysfs numa_node of its PCI function; -1 = unknown), and a helper that restricts the CALLING
  * thread to that node's CPUs (intersected with its current mask).  Threads created and page-locked buffers first

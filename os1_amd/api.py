@@ -142,6 +142,8 @@ def load_library():
     L.orbfe_device_upload.argtypes = [ci, vp, vp, C.c_size_t]
     L.orbfe_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     L.orbfe_host_free.argtypes = [vp]
+    L.orbfe_host_register.argtypes = [vp, C.c_size_t]
+    L.orbfe_host_unregister.argtypes = [vp]
     L.orbfe_device_synchronize.argtypes = [ci]
     L.orbfe_device_numa_node.argtypes = [ci]
     L.orbfe_bind_thread_to_device.argtypes = [ci]
@@ -893,6 +895,28 @@ class DescTable:
             self.L.orbfe_device_free(self.device, C.c_void_p(self.dev))
             self.dev = None
             self.host.free()
+
+
+class RegisteredArray:
+    """A numpy array the caller owns, page-locked and mapped for the GPU in place (orbfe_host_register); unregistered by close()."""
+
+    def __init__(self, a):
+        assert a.flags['C_CONTIGUOUS']
+        self.L = load_library()
+        self.a = a
+        _check(self.L.orbfe_host_register(C.c_void_p(a.ctypes.data), a.nbytes))
+        self.live = True
+
+    def close(self):
+        if self.live:
+            self.L.orbfe_host_unregister(C.c_void_p(self.a.ctypes.data))
+            self.live = False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class PinnedFrames:

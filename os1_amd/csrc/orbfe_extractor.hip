@@ -769,7 +769,14 @@ struct orbfe_extractor {
       // on another queue, no event between the queues
       for (int f = 0; f < nframes; f++) {
         uint8_t* d = d_in.p + (size_t)inPitch * rows * f;
-        launch_ingest(gray[f], (long long)stride, d, inPitch, rowBytes, r, st);
+        // the address the GPU reads the frame at: the host address itself for orbfe_host_alloc memory, the mapping of a buffer the
+        // caller registered (orbfe_host_register) otherwise
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, const_cast<uint8_t*>(gray[f]), 0) != hipSuccess || !dp) {
+          (void)hipGetLastError();
+          dp = const_cast<uint8_t*>(gray[f]);
+        }
+        launch_ingest(static_cast<const uint8_t*>(dp), (long long)stride, d, inPitch, rowBytes, r, st);
         devAt[f] = d;
       }
       HIP_TRY(hipGetLastError());
@@ -1302,6 +1309,16 @@ int orbfe_host_alloc(size_t bytes, void** out) {
 }
 int orbfe_host_free(void* ptr) {
   HIP_TRY(hipHostFree(ptr));
+  return ORBFE_OK;
+}
+int orbfe_host_register(void* ptr, size_t bytes) {
+  if (!ptr || bytes == 0) { set_err("bad argument"); return ORBFE_ERR_INVALID; }
+  HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterPortable | hipHostRegisterMapped));
+  return ORBFE_OK;
+}
+int orbfe_host_unregister(void* ptr) {
+  if (!ptr) { set_err("bad argument"); return ORBFE_ERR_INVALID; }
+  HIP_TRY(hipHostUnregister(ptr));
   return ORBFE_OK;
 }
 int orbfe_device_synchronize(int device_id) {

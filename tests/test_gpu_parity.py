@@ -674,6 +674,52 @@ def test_latency_path_variants_agree(api, oracle, monkeypatch):
                 monkeypatch.delenv(k)
 
 
+def test_registered_host_buffers_take_the_page_locked_route(api, oracle):
+    """orbfe_host_register: a buffer the CALLER owns (a capture ring, a long-lived cv::Mat) page-locked and mapped in place; frames inside it
+    are fetched by the compute stream like orbfe_host_alloc memory (one- and two-frame calls: k_ingest reads them through the mapping;
+    batches: copy commands).  Frames at different offsets of one registered block, aligned and not; after unregistering the same memory is
+    ordinary pageable memory again."""
+    import time
+    W, H, N = 1280, 720, 1200
+    imgs = [synth(81, W, H), shifted(synth(81, W, H), 4, 2, 82), synth(83, W, H)]
+    ox = OracleExtractor(N, 1.2, 8, 20, 7, oracle)
+    want = [ox.extract(im) for im in imgs]
+    ring = np.zeros(3 * W * H + 64, np.uint8)                      # the caller's buffer: three frames back to back, then 64 spare bytes
+    reg = api.RegisteredArray(ring)
+    ex = api.Extractor(N, 1.2, 8, 20, 7)
+    for off in (0, 16, 4, 1):                                      # 16-byte / dword aligned frames (k_ingest), an odd address (copy engine)
+        view = ring[off:off + 3 * W * H].reshape(3, H, W)
+        view[:] = np.stack(imgs)
+        ptrs = [view[i].ctypes.data for i in range(3)]
+        for i in range(3):
+            kps, desc, n = ex.extract_batch_ptrs(ptrs[i:i + 1], H, W, W, False)
+            _cmp_extract((kps[0, :n[0]], desc[0, :n[0]]), want[i])
+        kps, desc, n = ex.extract_batch_ptrs(ptrs[:2], H, W, W, False)
+        for i in range(2):
+            _cmp_extract((kps[i, :n[i]], desc[i, :n[i]]), want[i])
+        kps, desc, n = ex.extract_batch_ptrs(ptrs, H, W, W, False)      # three frames: the batch route
+        for i in range(3):
+            _cmp_extract((kps[i, :n[i]], desc[i, :n[i]]), want[i])
+    # the registered route is the fast one (k_ingest instead of the runtime's staging copy)
+    view = ring[:3 * W * H].reshape(3, H, W)
+    view[:] = np.stack(imgs)
+    kb, db = np.zeros((1, ex.cap), api.KP_DTYPE), np.zeros((1, ex.cap, 32), np.uint8)
+
+    def med(ptr):
+        ts = []
+        for _ in range(40):
+            t0 = time.perf_counter()
+            ex.extract_batch_ptrs([ptr], H, W, W, False, kb, db)
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts[8:]))
+    t_reg = med(view[1].ctypes.data)
+    reg.close()
+    t_page = med(view[1].ctypes.data)
+    _cmp_extract(ex(view[2]), want[2])                               # ... and still correct as pageable memory
+    print('one 720p frame: registered %.3f ms, pageable %.3f ms' % (t_reg * 1e3, t_page * 1e3))
+    assert t_reg < t_page
+
+
 @pytest.mark.parametrize('seq', ['0', '1', 'cap1', 'cap3'])
 def test_stream_matching_dense_clusters(api, oracle, seq, monkeypatch):
     """SearchForInitialization bookkeeping under stress: many level-0 keypoints in a small image, a window that covers a
