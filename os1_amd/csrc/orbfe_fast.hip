@@ -379,7 +379,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fas
       int y = (int)(((float)lane + 0.5f) * __builtin_amdgcn_rcpf((float)G)), g = lane - m24(y, G);   // lane / G (see the ROI load)
       int ro = m24(y, TP) + (g << GS);               // byte offset of (row y, column NPX*g) in the tile
       const int roStep = m24(stepY, TP) + (stepG << GS), roCarry = TP - (G << GS);
-      const uint8_t* t0 = tile - A;
+      const uint8_t* t0 = tile - a;   // (A == a: written with the run-time value so that the four alignment variants share their row bases instead of each hoisting its own set out of the pass loop)
       for (int i0 = 0; i0 < nItems; i0 += 64) {
         unsigned m = 0;   // bit k = pixel NPX*g + k passes
         if (i0 + lane < nItems) {
