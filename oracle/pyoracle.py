@@ -394,7 +394,9 @@ class OracleExtractor:
 
     def extract(self, img):
         img = np.ascontiguousarray(img, np.uint8)
-        cap = self.nfeatures + 8 * self.nlevels + 64
+        # a level returns at most max(N_l + 2, 4 * roots) keypoints (ORBextractor.cc:620-773): strips many roots wide with a tiny quota
+        # return far more than nfeatures (found by tools/sweep_debug.py, round 5)
+        cap = self.nfeatures + 64 + 520 * self.nlevels
         kps = np.zeros(cap, KP_DTYPE)
         desc = np.zeros((cap, 32), np.uint8)
         n = self.o.L.orc_extract(self.h, _p(img), img.shape[0], img.shape[1], img.strides[0], _p(kps), _p(desc), cap)

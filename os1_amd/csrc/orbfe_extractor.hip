@@ -1078,6 +1078,7 @@ struct orbfe_extractor {
       h_frame0.p[f] = onDevice ? gray[f] : d_in.p + (size_t)inPitch * rows * f;
     }
     P.stride0 = onDevice ? (long long)stride : inPitch;
+    P.gaussVariant = gaussVariant;   // (the host-quadtree route describes with launch_describe: same kernel, same variant)
     P.frame0 = d_frame0.p;
     HIP_TRY(hipMemcpyAsync(d_frame0.p, h_frame0.p, sizeof(void*) * nframes, hipMemcpyHostToDevice, streams[0]));
     HIP_TRY(hipEventRecord(evFrame0, streams[0]));

@@ -148,6 +148,19 @@ def test_legacy_gaussian_variant_parity(api, oracle):
     st.close()
     with pytest.raises(Exception):
         ex.set_blur_variant(2)
+    # the HOST-quadtree route (strips with more than 4 roots per level, more than 2 044 features on a level) describes through
+    # launch_describe: the variant must reach it too (tools/sweep_debug.py found that it did not, round 5)
+    for (W, H, N, nl) in [(1266, 290, 56, 2), (604, 514, 2759, 1)]:
+        img = synth(64, W, H)
+        for variant in (1, 0):
+            ex = api.Extractor(N, 1.25, nl, 20, 7)
+            ox = OracleExtractor(N, 1.25, nl, 20, 7, oracle)
+            ex.set_blur_variant(variant)
+            ox.set_gauss_variant(variant)
+            want = ox.extract(img)
+            _cmp_extract(ex(img), want)
+            for g in ex.extract_batch([img, img, img]):
+                _cmp_extract(g, want)
 
 
 def test_other_parameters(api, oracle):

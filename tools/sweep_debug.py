@@ -1,4 +1,5 @@
-"""Exploratory parity sweep (GPU box): random sizes / parameters, product vs oracle.  usage: sweep_debug.py seed count"""
+"""Exploratory parity sweep (GPU box): random sizes / parameters, product vs oracle.  usage: sweep_debug.py seed count [blur_variant=0]
+(blur_variant 1: the OpenCV 4.0-era GaussianBlur on both sides, orbfe_extractor_set_blur_variant / orc_extractor_set_gauss_variant)"""
 import sys
 sys.path.insert(0, '.')
 import numpy as np
@@ -7,6 +8,7 @@ from os1_amd.synth import synth
 from oracle.pyoracle import Oracle, OracleExtractor
 
 seed, count = int(sys.argv[1]), int(sys.argv[2])
+blur = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 oracle = Oracle()
 rng = np.random.default_rng(seed)
 bad = 0
@@ -40,10 +42,12 @@ for it in range(count):
         img = np.clip(img.astype(np.int32) * 3 - 200, 0, 255).astype(np.uint8)   # saturated
     try:
         ex = api.Extractor(N, sf, nl, ini, mn)
+        ex.set_blur_variant(blur)
     except api.OrbfeError as e:
         print(it, 'create refused:', e)
         continue
     ox = OracleExtractor(N, sf, nl, ini, mn, oracle)
+    ox.set_gauss_variant(blur)
     wk, wd = ox.extract(img)
     gk, gd = ex(img)
     ok = gk.tobytes() == wk.tobytes() and gd.tobytes() == wd.tobytes()
