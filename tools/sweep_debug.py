@@ -67,6 +67,27 @@ for it in range(count):
     for i, w in enumerate(want):
         okb = okb and kps[i, :n[i]].tobytes() == w[0].tobytes() and desc[i, :n[i]].tobytes() == w[1].tobytes()
     dev.free()
+    # one- and two-frame calls from page-locked memory (k_ingest where the alignment allows it, the copy engine otherwise) and from a
+    # buffer of the caller's that was registered in place (orbfe_host_register), at a random byte offset
+    pin = api.PinnedFrames(imgs[:2])
+    kb1, db1, kb2, db2 = kb[:1].copy(), db[:1].copy(), kb[:2].copy(), db[:2].copy()
+    k1, d1, n1 = ex.extract_batch_ptrs(pin.ptrs[:1], H, W, W, False, kb1, db1)
+    okb = okb and k1[0, :n1[0]].tobytes() == want[0][0].tobytes() and d1[0, :n1[0]].tobytes() == want[0][1].tobytes()
+    k2, d2, n2 = ex.extract_batch_ptrs(pin.ptrs, H, W, W, False, kb2, db2)
+    for i in range(2):
+        okb = okb and k2[i, :n2[i]].tobytes() == want[i][0].tobytes() and d2[i, :n2[i]].tobytes() == want[i][1].tobytes()
+    pin.free()
+    off = int(rng.choice([0, 4, 16, 1, 2]))
+    ring = np.zeros(2 * W * H + 64, np.uint8)
+    reg = api.RegisteredArray(ring)
+    view = ring[off:off + 2 * W * H].reshape(2, H, W)
+    view[:] = np.stack(imgs[:2])
+    k2, d2, n2 = ex.extract_batch_ptrs([view[0].ctypes.data, view[1].ctypes.data], H, W, W, False, kb2, db2)
+    for i in range(2):
+        okb = okb and k2[i, :n2[i]].tobytes() == want[i][0].tobytes() and d2[i, :n2[i]].tobytes() == want[i][1].tobytes()
+    k1, d1, n1 = ex.extract_batch_ptrs([view[1].ctypes.data], H, W, W, False, kb1, db1)
+    okb = okb and k1[0, :n1[0]].tobytes() == want[1][0].tobytes() and d1[0, :n1[0]].tobytes() == want[1][1].tobytes()
+    reg.close()
     print(it, W, H, N, sf, nl, ini, mn, mode, len(wk), 'OK' if ok else 'MISMATCH', 'batch', stride - W, 'OK' if okb else 'MISMATCH', flush=True)
     bad += (not ok) + (not okb)
 print('mismatches', bad)
