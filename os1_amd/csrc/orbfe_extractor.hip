@@ -456,6 +456,19 @@ struct orbfe_extractor {
       }
       L.rzPitch = (maxW + 3 + 3) & ~3;
       L.rzRows = maxH;
+      // ... and of a 32x32 one (k_resize_w1: one wave per tile)
+      int maxW32 = 1, maxH32 = 1;
+      for (int x0 = 0; x0 < dw; x0 += 32) {
+        const int x1 = std::min(x0 + 32, dw) - 1;
+        maxW32 = std::max(maxW32, std::min(xofs[x1] + 1, sw - 1) - xofs[x0] + 1);
+      }
+      for (int y0 = 0; y0 < dh; y0 += 32) {
+        const int y1 = std::min(y0 + 32, dh) - 1;
+        const int r0 = std::min(std::max(yofs[y0], 0), sh - 1), r1 = std::min(std::max(yofs[y1] + 1, 0), sh - 1);
+        maxH32 = std::max(maxH32, r1 - r0 + 1);
+      }
+      L.rz32W = maxW32;
+      L.rz32H = maxH32;
     }
     HIP_TRY(hipMemcpyAsync(d_tables.p, tab.data(), tableBytes, hipMemcpyHostToDevice, stream));
     // one-launch pyramid for small batches (k_pyramid_cone): per tile column / row of the top level, the range of every

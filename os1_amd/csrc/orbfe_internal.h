@@ -29,6 +29,7 @@ struct LevelGeom {
   const short* ybeta;      // [2*h] 11-bit weights (b0,b1)
   const unsigned* yofc;    // [h]   the two source rows of a destination row, clamped to the source: row0 | row1 << 16 (k_resize_fixed)
   int rzPitch, rzRows;     // LDS pitch / rows of the largest 64x64-tile source footprint (k_resize)
+  int rz32W, rz32H;        // width / rows of the largest 32x32-tile source footprint (k_resize_w1)
   int fastW;               // widest emit region of a FAST task on this level (2 * wCell when cells are paired, else wCell)
 };
 

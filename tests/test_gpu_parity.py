@@ -807,11 +807,12 @@ print('OK')
 
 @pytest.mark.parametrize('env', [{'ORBFE_FAST_DMA': '0'}, {'ORBFE_FAST_DMA': '1'}, {'ORBFE_DESCRIBE_DMA': '0'}, {'ORBFE_RESIZE_DMA': '0'},
                                  {'ORBFE_FAST_LDS_CLASSES': '0'}, {'ORBFE_FAST_DMA': '0', 'ORBFE_DESCRIBE_DMA': '0', 'ORBFE_RESIZE_DMA': '0'},
-                                 {'ORBFE_FAST_LEAN': '0'}])
+                                 {'ORBFE_FAST_LEAN': '0'}, {'ORBFE_RESIZE_WAVE': '1'}])
 def test_staging_variants_agree(env):
     """How the tiles reach LDS -- LDS-DMA with 16 bytes per lane (default), one dword per lane (ORBFE_FAST_DMA=1), through registers
     (=0, and ORBFE_DESCRIBE_DMA=0 / ORBFE_RESIZE_DMA=0) -- one FAST launch instead of one per LDS class, and the FAST kernel's generic
-    prologue instead of the LEAN one (ORBFE_FAST_LEAN=0; the script's odd row stride takes the generic one anyway): each switch is read once
+    prologue instead of the LEAN one (ORBFE_FAST_LEAN=0; the script's odd row stride takes the generic one anyway), the pyramid by one-wave
+    32x32 tiles (ORBFE_RESIZE_WAVE=1, k_resize_w1): each switch is read once
     per process, so every setting runs in a process of its own; four-frame batches at two sizes and three row strides, and the one-frame
     route, against the oracle."""
     import os
