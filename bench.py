@@ -181,6 +181,24 @@ def run_rank(args):
     numa_node = api.device_numa_node(local_rank)
     numa_cpus = api.bind_thread_to_device(local_rank)
 
+    # How the runner's worker waits for the GPU (orbfe_extractor_set_wait_mode): sleeping 50 us between polls saves 0.4 host core per
+    # rank, spinning is worth +1 % and steadier steps (DESIGN_NOTES E.5).  Spin where the rank has cores to spare -- at least four of its
+    # own, counting the cgroup's quota and the ranks sharing the node; ORBFE_POLL_WAIT_US in the environment wins.
+    def cores_for_this_rank():
+        n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+        total = os.cpu_count() or n
+        try:
+            q, period = open('/sys/fs/cgroup/cpu.max').read().split()
+            if q != 'max':
+                total = min(total, max(1, int(float(q) / float(period) + 0.5)))
+        except Exception:
+            pass
+        return min(n, total / max(int(os.environ.get('LOCAL_WORLD_SIZE', world)), 1))
+    wait_mode = os.environ.get('ORBFE_POLL_WAIT_US')
+    if wait_mode is None:
+        wait_mode = '0' if cores_for_this_rank() >= 4 else '50'
+        os.environ['ORBFE_POLL_WAIT_US'] = wait_mode
+
     W, H, B = wl.W, wl.H, (args.batch or wl.SUBMIT)
     assert args.pool % B == 0, '--pool must be a multiple of --batch'
     passes = args.passes or wl.PASSES
@@ -543,6 +561,7 @@ def run_rank(args):
                        'value_is': ('the RESIDENT rate (frames in HBM when the timed region starts, the bench contract); SURVEY.md s8(d) puts the H2D of every '
                                     'frame inside its metric: that figure is pcie_inclusive.value' if head_source == 'hbm' else 'a PCIe-inclusive rate (developer run)'),
                        'batches_in_flight': max(1, args.depth), 'hip_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES'),
+                       'worker_wait': 'spin' if wait_mode == '0' else 'sleep-poll %s us' % wait_mode,
                        'numa': {'node_of_gpu': numa_node, 'cpus_bound': numa_cpus}},
             'verified': verify['verified'], 'outputs_sha256': verify['outputs_sha256'], 'verify': verify,
             **per_rank_summary(per_rank, fps),
