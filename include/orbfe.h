@@ -175,6 +175,10 @@ int orbfe_extract_batch(orbfe_extractor* h, int nframes, const uint8_t* const* g
 int orbfe_extract_batch_submit(orbfe_extractor* h, int nframes, const uint8_t* const* gray, int in_device_memory,
                                int rows, int cols, size_t stride_bytes);
 int orbfe_extract_batch_collect(orbfe_extractor* h, OrbfeKeyPoint* kps, uint8_t* desc, int cap, int* n_out);
+/* Waits until the GPU has finished the submitted batch WITHOUT collecting it: a pipelined caller submits its next batch on another
+ * handle between this call and the collect, so that the host-side assembly of the results (0.25 ms for 64 1080p frames) does not
+ * leave a gap in the GPU's queue (the stream runner does; orbfe_stream_*).  The collect call that follows returns without waiting. */
+int orbfe_extract_batch_wait(orbfe_extractor* h);
 
 /* Extraction + GPU-resident matching for consecutive frames of ONE stream.  A chain carries the predecessor
  * (the previous batch's last frame, kept in HBM) across batches; the batches of a stream may alternate between

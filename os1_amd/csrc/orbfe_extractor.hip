@@ -967,6 +967,20 @@ struct orbfe_extractor {
     return ORBFE_OK;
   }
 
+  // the GPU side of the submitted batch only (orbfe_extract_batch_wait): the caller collects later
+  int waitOnly() {
+    if (!pendingFrames) return ORBFE_OK;
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = pendingTail ? tailStream : streams[0];
+    if (pollWaitUs > 0) {
+      hipError_t q;
+      while ((q = hipStreamQuery(st)) == hipErrorNotReady) usleep((useconds_t)pollWaitUs);
+      if (q != hipSuccess) HIP_TRY(q);
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    return ORBFE_OK;
+  }
+
   int waitGpuQt(OrbfeKeyPoint* kps, uint8_t* desc, int cap, int* n_out, int32_t* matches12 = nullptr,
                 int* nmatches = nullptr) {
     if (!pendingFrames) { set_err("no submitted batch to collect"); return ORBFE_ERR_INVALID; }
@@ -1757,6 +1771,12 @@ int orbfe_extract_batch_submit(orbfe_extractor* h, int nframes, const uint8_t* c
   }
   if (h->deferredFrames) { set_err("a submitted batch has not been collected yet"); return ORBFE_ERR_INVALID; }
   return h->submitGpuQt(nframes, gray, in_device_memory != 0, rows, cols, stride_bytes);
+}
+
+int orbfe_extract_batch_wait(orbfe_extractor* h) {
+  if (!h) { set_err("invalid arguments"); return ORBFE_ERR_INVALID; }
+  if (h->deferredFrames) return ORBFE_OK;   // (a batch that took the blocking host-quadtree route at submit time is done already)
+  return h->waitOnly();
 }
 
 int orbfe_extract_batch_collect(orbfe_extractor* h, OrbfeKeyPoint* kps, uint8_t* desc, int cap, int* n_out) {
