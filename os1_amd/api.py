@@ -62,6 +62,7 @@ def load_library():
     L.orbfe_extract.argtypes = [vp, vp, ci, ci, C.c_size_t, vp, vp, ci, C.POINTER(ci)]
     L.orbfe_extract_batch.argtypes = [vp, ci, vp, ci, ci, ci, C.c_size_t, vp, vp, ci, vp]
     L.orbfe_extract_batch_submit.argtypes = [vp, ci, vp, ci, ci, ci, C.c_size_t]
+    L.orbfe_extract_batch_wait.argtypes = [vp]
     L.orbfe_extract_batch_collect.argtypes = [vp, vp, vp, ci, vp]
     L.orbfe_debug_level_size.argtypes = [vp, ci, C.POINTER(ci), C.POINTER(ci)]
     L.orbfe_debug_level_copy.argtypes = [vp, ci, ci, vp]
@@ -308,6 +309,10 @@ class Extractor:
         self._pending = (C.c_void_p * B)(*ptrs)          # keep the pointer array alive
         self._pendingB = B
         _check(self.L.orbfe_extract_batch_submit(self.h, B, self._pending, int(on_device), rows, cols, stride))
+
+    def wait(self):
+        """orbfe_extract_batch_wait: the GPU side of the submitted batch is done when this returns; collect() then only assembles."""
+        _check(self.L.orbfe_extract_batch_wait(self.h))
 
     def collect(self, kps=None, desc=None):
         B = self._pendingB

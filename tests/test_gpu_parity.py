@@ -687,6 +687,40 @@ def test_latency_path_variants_agree(api, oracle, monkeypatch):
                 monkeypatch.delenv(k)
 
 
+def test_submit_wait_collect_on_two_handles(api, oracle):
+    """orbfe_extract_batch_submit / _wait / _collect: two handles pipelined the way a throughput caller does it -- the second batch is
+    submitted between the first one's wait and its collect; a wait without a pending batch and a second wait are no-ops; the blocking
+    host-quadtree route (a strip with more than four roots) goes through the same calls."""
+    imgs = [synth(91 + i, 960, 540) for i in range(6)]
+    ox = OracleExtractor(900, 1.2, 8, 20, 7, oracle)
+    want = [ox.extract(im) for im in imgs]
+    dev = api.DeviceFrames(imgs, 0)
+    a, b = api.Extractor(900, 1.2, 8, 20, 7), api.Extractor(900, 1.2, 8, 20, 7)
+    a.wait()                                             # nothing pending: returns at once
+    a.submit_ptrs(dev.ptrs[0:3], 540, 960, dev.stride, True)
+    a.wait()
+    b.submit_ptrs(dev.ptrs[3:6], 540, 960, dev.stride, True)
+    a.wait()
+    ka, da, na = a.collect()
+    b.wait()
+    kb, db, nb = b.collect()
+    for i in range(3):
+        _cmp_extract((ka[i, :na[i]], da[i, :na[i]]), want[i])
+        _cmp_extract((kb[i, :nb[i]], db[i, :nb[i]]), want[3 + i])
+    strip = synth(97, 1500, 260)
+    sx = api.Extractor(200, 1.2, 3, 20, 7)
+    sdev = api.DeviceFrames([strip, strip, strip], 0)
+    sx.submit_ptrs(sdev.ptrs, 260, 1500, sdev.stride, True)
+    sx.wait()
+    cap = sx.L.orbfe_extractor_max_keypoints_for_size(sx.h, 260, 1500)
+    kk, dd = np.zeros((3, max(cap, sx.cap)), api.KP_DTYPE), np.zeros((3, max(cap, sx.cap), 32), np.uint8)
+    sx.cap = max(cap, sx.cap)
+    ks, ds, ns = sx.collect(kk, dd)
+    ws = OracleExtractor(200, 1.2, 3, 20, 7, oracle).extract(strip)
+    for i in range(3):
+        _cmp_extract((ks[i, :ns[i]], ds[i, :ns[i]]), ws)
+
+
 def test_registered_host_buffers_take_the_page_locked_route(api, oracle):
     """orbfe_host_register: a buffer the CALLER owns (a capture ring, a long-lived cv::Mat) page-locked and mapped in place; frames inside it
     are fetched by the compute stream like orbfe_host_alloc memory (one- and two-frame calls: k_ingest reads them through the mapping;
