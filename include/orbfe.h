@@ -216,13 +216,15 @@ int orbfe_debug_kernel_ms(orbfe_extractor* h, double out_ms[5], long long* batch
 /* k_fast_tasks (the dominant kernel) is timed in every call of MORE than ORBFE_CONE_MAX_FRAMES (default 2) frames;
  * calls with one or two frames take the latency route, which records no events (each costs a dependent-launch gap),
  * so orbfe_debug_kernel_ms reports frames = 0 for them.  enable != 0 also times the other groups, at the price of an
- * event (a few microseconds of stream gap) between them.  Env: ORBFE_PROFILE_KERNELS=1. */
+ * event (a few microseconds of stream gap) between them. */
 int orbfe_debug_set_profiling(orbfe_extractor* h, int enable);
-/* Measurement only (ORBFE_FAST_ABLATE=4 selects a build of the FAST kernel with s_memtime stamps between its phases): shader
+/* Measurement only: needs a library built with `make EXPERIMENTS=1` (-DORBFE_EXPERIMENTS) and ORBFE_FAST_ABLATE=4 in the environment,
+ * which selects an instantiation of the FAST kernel with s_memtime stamps between its phases (a default build returns ORBFE_ERR_INVALID): shader
  * cycles summed over every wave since the last reset -- [0] entry -> geometry known, [1] -> ROI in LDS, [2] -> pre-test done,
  * [3] -> scores done, [4] -> end, [5] = waves counted.  tools/fast_phases.py prints the per-wave averages. */
 int orbfe_debug_fast_stamps(orbfe_extractor* h, unsigned long long out[8], int reset);
-/* Measurement only (environment ORBFE_SFI_DEBUG=1 when the process starts): one record of 8 ints per pair the GPU-resident
+/* Measurement only (a `make EXPERIMENTS=1` build with ORBFE_SFI_DEBUG=1 in the environment when the process starts; a default build
+ * reports no records): one record of 8 ints per pair the GPU-resident
  * SearchForInitialization resolved since the last reset -- frame in its batch, rounds of the fixed point, candidate entries, 1 if
  * the serial finish ran, shader cycles of the block, n1, n2, 1 if the candidate pool fitted LDS (tools/sfi_rounds.py). */
 int orbfe_debug_sfi_records(orbfe_extractor* h, int32_t* out, int cap_records, int* n_out, int reset);
@@ -286,8 +288,7 @@ int orbfe_stream_capacity(const orbfe_stream* s);
 int orbfe_stream_set_queue_slots(orbfe_stream* s, int nslots);
 int orbfe_stream_queue_slots(const orbfe_stream* s);
 /* Enqueue one batch (`batch` frame pointers; device pointers if in_device_memory != 0).  Returns at once unless every
- * result slot is taken (see orbfe_stream_set_queue_slots; the environment variable ORBFE_STREAM_SLOTS sets the initial
- * number).  The frames must stay valid until their batch is popped. */
+ * result slot is taken (see orbfe_stream_set_queue_slots).  The frames must stay valid until their batch is popped. */
 int orbfe_stream_push(orbfe_stream* s, const uint8_t* const* gray, int in_device_memory, int rows, int cols,
                       size_t stride_bytes);
 /* Wait for the oldest batch; ORBFE_ERR_INVALID if no pushed batch is outstanding.  Output pointers stay valid until
@@ -484,7 +485,7 @@ int orbfe_frame_download(orbfe_frame* f, OrbfeKeyPoint* kps_un, uint8_t* desc, i
  * arena (a plain memcpy each -- there is no per-query loop on the host); a device pointer for one of them is refused with
  * ORBFE_ERR_INVALID before anything is read.  ORBFE_FRAME_ZEROCOPY=0: marshal the queries on
  * the host and upload them instead.  The call returns when the kernel's last store -- the call's number, into page-locked
- * memory -- has been seen (ORBFE_FRAME_POLL=0: wait on the stream instead).  Limits: at most 65 535 keypoints per frame,
+ * memory -- has been seen (or, failing that for 2 ms, when the stream has drained).  Limits: at most 65 535 keypoints per frame,
  * 1 048 574 queries per search, 32 pyramid levels for the in-place route (more: the queries are marshalled on the host). */
 int orbfe_search_by_projection_frame(orbfe_matcher* m, orbfe_frame* f, const float* scale_factors, int nlevels,
                                      const uint8_t* kp_occupied, const float* mp_proj_xy, const int32_t* mp_level,

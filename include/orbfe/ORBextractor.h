@@ -16,11 +16,16 @@
 
 #include "orb_shim.hpp"
 
-// cv::GaussianBlur's 8-bit taps changed between OpenCV releases (orbfe.h, orbfe_extractor_set_blur_variant): reproduce the blur of
-// the OpenCV this translation unit is compiled against -- the one the reference's own ORBextractor.cc:950 would have called.
-// 4.0.0 - 4.1.0 and 3.4.2 - 3.4.6: taps rounded one by one (sum 257); later releases: error-diffused taps (sum 256).
-#if defined(CV_VERSION_MAJOR) && ((CV_VERSION_MAJOR == 4 && (CV_VERSION_MINOR == 0 || (CV_VERSION_MINOR == 1 && CV_VERSION_REVISION == 0))) || \
-                                  (CV_VERSION_MAJOR == 3 && CV_VERSION_MINOR == 4 && CV_VERSION_REVISION >= 2 && CV_VERSION_REVISION <= 6))
+// cv::GaussianBlur's 8-bit taps changed between OpenCV releases (orbfe.h, orbfe_extractor_set_blur_variant).  The facade reproduces
+// the error-diffused taps (sum 256, ORBFE_GAUSS_ED: every release since 4.1.1 / 3.4.7) unless the integrator opts in to the
+// version-based choice with -DORBFE_FACADE_GAUSS_BY_CV_VERSION: then a translation unit compiled against 4.0.0 - 4.1.0 or
+// 3.4.2 - 3.4.6 gets the taps rounded one by one (sum 257, ORBFE_GAUSS_ROUNDED) -- the blur the reference's own
+// ORBextractor.cc:950 would have called there.  Opt-in, because those taps, the version boundaries and the saturation at 255 are
+// restated from the upstream sources and have not met a real OpenCV 4.0.x build on this pool; pin them with one
+// GaussianBlur known-answer vector from such a build before relying on the switch.
+#if defined(ORBFE_FACADE_GAUSS_BY_CV_VERSION) && defined(CV_VERSION_MAJOR) &&                                                     \
+    ((CV_VERSION_MAJOR == 4 && (CV_VERSION_MINOR == 0 || (CV_VERSION_MINOR == 1 && CV_VERSION_REVISION == 0))) ||               \
+     (CV_VERSION_MAJOR == 3 && CV_VERSION_MINOR == 4 && CV_VERSION_REVISION >= 2 && CV_VERSION_REVISION <= 6))
 #define ORBFE_FACADE_GAUSS_VARIANT ORBFE_GAUSS_ROUNDED
 #else
 #define ORBFE_FACADE_GAUSS_VARIANT ORBFE_GAUSS_ED

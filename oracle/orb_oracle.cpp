@@ -419,7 +419,7 @@ static_assert(sizeof(Node) == 72, "Node must have the size of the reference's Ex
 //      reference does on this allocator -- a function of the heap's history, not of the image)
 //   3+ a seeded pseudo-random order (seed = rule)
 struct TieStats { long sorts = 0, sorted_nodes = 0, nodes_in_ties = 0, breaks = 0, breaks_inside_a_tie = 0; };
-TieStats g_tieStats;
+thread_local TieStats g_tieStats;   // per thread: the cpu_baseline legs run one oracle extractor per thread; orc_tie_stats reports the calling thread's
 
 // DistributeOctTree -- ORBextractor.cc:571-795.
 std::vector<OrcKeyPoint> distribute_octtree(const std::vector<OrcKeyPoint>& vToDistributeKeys, int minX,

@@ -8,7 +8,7 @@
 // (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, sincosf.h -- the ARM "optimized routines" sincosf) is
 // a short double-precision polynomial; this header restates its published algorithm for the
 // range the rBRIEF kernel needs (|x| < 120; the argument is angle_deg*pi/180 in [0, 2*pi)).
-// tests/test_sincos.py checks it exhaustively (every float in [0, 6.3]) against the host libm on
+// tests/test_host_logic.py (test_sincos_restatement_matches_libm_exhaustively) checks it exhaustively (every float in [0, 6.3]) against the host libm on
 // CPU, and tests/test_gpu_parity.py checks the device build against host libm on the GPU box.
 // Plain mul/add and fused variants both agree with glibc bit-for-bit over that range, so the
 // result does not depend on -ffp-contract.

@@ -35,7 +35,7 @@ int launch_pyramid(const PyramidParams& P, int nframes, hipStream_t st, const Co
 void launch_ingest(const uint8_t* src, long long sstride, uint8_t* dst, long long dpitch, int rowBytes, int rows, hipStream_t st);
 void launch_to_gray(const uint8_t* const* raw, long long rawStride, const uint8_t* const* gray, long long grayPitch, int rows,
                     int cols, int channels, const int coef[3], int shift, bool aligned, int nframes, hipStream_t st);
-void launch_fast(const PyramidParams& P, int nframes, hipStream_t st);
+void launch_fast(const PyramidParams& P, int nframes, hipStream_t st, int level0 = 0, int level1 = kMaxLevels);
 uint32_t fast_task_geo(int fastW, int hCell);
 void launch_compact(const PyramidParams& P, int nframes, hipStream_t st);
 void launch_describe(const PyramidParams& P, const SelKp* sel, int nsel, float* angle, uint8_t* desc,
@@ -161,24 +161,6 @@ static UploadLane* upload_lane(int device) {
   return lanes[device];
 }
 
-// Per device, the VALU-bound front of every batch (colour conversion, pyramid, FAST, candidate compaction) is chained
-// across extractor handles in submission order: batch k+1's front starts when batch k's front is done, so it runs
-// beside batch k's latency-bound tail (quadtree, descriptors, matching, D2H) instead of beside another front.  Without
-// the chain two handles drift into lock-step: both fronts share the CUs, then both tails leave them idle.
-struct FrontLane {
-  std::mutex mu;
-  hipEvent_t last = nullptr;    // recorded after the most recently submitted front (owned by that handle)
-  hipEvent_t lastPyr = nullptr; // recorded after its pyramid (two-link mode)
-};
-static FrontLane* front_lane(int device) {
-  static std::mutex mu;
-  static FrontLane* lanes[64] = {};
-  if (device < 0 || device >= 64) return nullptr;
-  std::lock_guard<std::mutex> lk(mu);
-  if (!lanes[device]) lanes[device] = new FrontLane;   // lives for the process
-  return lanes[device];
-}
-
 struct orbfe_extractor {
   int nfeatures, nlevels, iniTh, minTh, device;
   double scaleFactor;  // the reference keeps the float ctor argument in a double member (ORBextractor.h:313)
@@ -187,12 +169,8 @@ struct orbfe_extractor {
   static constexpr int kMaxSub = 4;
   hipStream_t stream = nullptr;          // == streams[0]
   hipStream_t streams[kMaxSub] = {};
-  int subBatches = 4;
+  static constexpr int subBatches = 4;   // host-quadtree route: sub-batches in flight (one HIP stream each)
   hipEvent_t evUpload = nullptr;
-  hipEvent_t evFront = nullptr;   // end of this handle's last front (FrontLane)
-  hipEvent_t evPyr = nullptr;     // end of this handle's last pyramid (FrontLane, two-link mode)
-  bool frontSplit = true;         // pyramid and FAST are separate links of the chain (ORBFE_FRONT_SPLIT=0: one link)
-  bool frontLane = false;         // ORBFE_FRONT_LANE=1 chains the fronts of consecutive batches (default until the pyramid got 40 % cheaper)
   hipEvent_t evFrame0 = nullptr, evS1[kMaxSub] = {};
   int subSel[kMaxSub] = {};
   size_t candHostCap = 0;
@@ -213,21 +191,6 @@ struct orbfe_extractor {
   int selPerFrame = 0;
   DevBuf<uint16_t> d_own;   // node id per candidate (quadtree)
   hipEvent_t evQt[2] = {};
-  hipStream_t qtStream = nullptr;       // high-priority stream for the latency-bound quadtree kernel
-  // The TAIL of a matched batch -- SearchForInitialization's four small kernels and the result copy -- on a high-priority stream of
-  // its own (round 5, ORBFE_TAIL_STREAM=1): their few multi-wave workgroups queue behind another batch's 400 000 single-wave FAST
-  // workgroups on an ordinary queue (profiles/r05_sfi_resolve_tail.txt) and every microsecond of tail latency is throughput with a
-  // fixed number of batches in flight.  One hand-over (event) per batch; the chain ends on that stream, collect waits for it.
-  hipStream_t tailStream = nullptr;
-  hipEvent_t evTailIn = nullptr;
-  bool tailOwnStream = false, pendingTail = false;
-  // ... and the PYRAMID of a batch on a stream of its own (ORBFE_PYR_STREAM=1, ORBFE_PYR_PRIORITY): the next FAST launch cannot start
-  // before its batch's seven resize launches are done, and beside another batch's FAST launch they take 770 us instead of 269
-  hipStream_t pyrStream = nullptr;
-  hipEvent_t evPyrDone = nullptr;
-  bool pyrOwnStream = false;
-  hipEvent_t evQtIn = nullptr, evQtOut = nullptr;
-  bool qtOwnStream = false;  // measured slower on MI355X (cross-stream event waits cost more than the overlap gains); ORBFE_QT_STREAM=1 enables
   std::vector<int> frameKpBase, frameKpCount;
 
   int rows = 0, cols = 0, batchCap = 0;
@@ -314,25 +277,9 @@ struct orbfe_extractor {
     for (auto& es : ev) for (auto& e : es) if (e) (void)hipEventDestroy(e);
     for (auto& e : evS1) if (e) (void)hipEventDestroy(e);
     for (auto& e : evQt) if (e) (void)hipEventDestroy(e);
-    if (evQtIn) (void)hipEventDestroy(evQtIn);
-    if (evQtOut) (void)hipEventDestroy(evQtOut);
-    if (qtStream) (void)hipStreamDestroy(qtStream);
-    if (tailStream) (void)hipStreamDestroy(tailStream);
-    if (pyrStream) (void)hipStreamDestroy(pyrStream);
-    if (evPyrDone) (void)hipEventDestroy(evPyrDone);
-    if (evTailIn) (void)hipEventDestroy(evTailIn);
     d_own.release();
     if (evFrame0) (void)hipEventDestroy(evFrame0);
     if (evUpload) (void)hipEventDestroy(evUpload);
-    if (evFront) {
-      if (FrontLane* fl = front_lane(device)) {
-        std::lock_guard<std::mutex> lk(fl->mu);
-        if (fl->last == evFront) fl->last = nullptr;
-        if (fl->lastPyr == evPyr) fl->lastPyr = nullptr;
-      }
-      (void)hipEventDestroy(evFront);
-      if (evPyr) (void)hipEventDestroy(evPyr);
-    }
     for (auto& st : streams) if (st) (void)hipStreamDestroy(st);
   }
 
@@ -456,19 +403,6 @@ struct orbfe_extractor {
       }
       L.rzPitch = (maxW + 3 + 3) & ~3;
       L.rzRows = maxH;
-      // ... and of a 32x32 one (k_resize_w1: one wave per tile)
-      int maxW32 = 1, maxH32 = 1;
-      for (int x0 = 0; x0 < dw; x0 += 32) {
-        const int x1 = std::min(x0 + 32, dw) - 1;
-        maxW32 = std::max(maxW32, std::min(xofs[x1] + 1, sw - 1) - xofs[x0] + 1);
-      }
-      for (int y0 = 0; y0 < dh; y0 += 32) {
-        const int y1 = std::min(y0 + 32, dh) - 1;
-        const int r0 = std::min(std::max(yofs[y0], 0), sh - 1), r1 = std::min(std::max(yofs[y1] + 1, 0), sh - 1);
-        maxH32 = std::max(maxH32, r1 - r0 + 1);
-      }
-      L.rz32W = maxW32;
-      L.rz32H = maxH32;
     }
     HIP_TRY(hipMemcpyAsync(d_tables.p, tab.data(), tableBytes, hipMemcpyHostToDevice, stream));
     // one-launch pyramid for small batches (k_pyramid_cone): per tile column / row of the top level, the range of every
@@ -769,27 +703,40 @@ struct orbfe_extractor {
     for (int f = 0; f < nframes; f++)
       if (!gray[f]) { set_err("frame %d is NULL", f); return ORBFE_ERR_INVALID; }
     devAt.resize(nframes);
-    const bool pyrOwn = pyrOwnStream && pyrStream && nframes > coneMaxFrames && !frontLane;
-    hipStream_t fs = pyrOwn ? pyrStream : st;   // the stream the pyramid (and what feeds it) runs on
-    hipPointerAttribute_t attr;
-    const bool pinned = !onDevice && hipPointerGetAttributes(&attr, gray[0]) == hipSuccess && attr.type == hipMemoryTypeHost;
+    // Where the host frames live decides how they travel.  EVERY frame is looked at (a one- or two-frame call may mix a
+    // page-locked frame with a pageable one, or hand over a view that runs past a registered range):
+    //   mapped   = page-locked (orbfe_host_alloc) or registered (orbfe_host_register) over its whole extent: the GPU can read it in place;
+    //   pinned   = all frames mapped -> asynchronous copy commands on the upload lane are truly asynchronous;
+    //   otherwise the runtime stages the copy synchronously on this handle's stream.
+    bool pinned = !onDevice;
+    std::vector<const uint8_t*>& mappedAt = devAt;   // (re-used below: device-visible address of every mapped host frame)
+    if (!onDevice) {
+      const size_t extent = stride * (size_t)(r - 1) + (size_t)rowBytes;
+      // (a batch for the copy engine needs no mapping: frame 0 decides the route, a pageable straggler is merely staged)
+      const int ncheck = nframes <= coneMaxFrames ? nframes : 1;
+      for (int f = 0; f < ncheck && pinned; f++) {
+        hipPointerAttribute_t attr;
+        void* dp = nullptr;
+        void* dpEnd = nullptr;
+        const bool ok = hipPointerGetAttributes(&attr, gray[f]) == hipSuccess && attr.type == hipMemoryTypeHost &&
+                        hipHostGetDevicePointer(&dp, const_cast<uint8_t*>(gray[f]), 0) == hipSuccess && dp &&
+                        hipHostGetDevicePointer(&dpEnd, const_cast<uint8_t*>(gray[f]) + extent - 1, 0) == hipSuccess &&
+                        (const uint8_t*)dpEnd - (const uint8_t*)dp == (ptrdiff_t)(extent - 1);
+        if (!ok) { (void)hipGetLastError(); pinned = false; break; }
+        mappedAt[f] = static_cast<const uint8_t*>(dp);
+      }
+    }
     if (!onDevice && !pinned) {
-      (void)hipGetLastError();   // pageable memory: the runtime stages the copy synchronously; keep it on this handle's stream
+      // pageable (or partly pageable) memory: the runtime stages the copy synchronously; keep it on this handle's stream
       if ((rc = uploadFrames(0, nframes, gray, stride, r, rowBytes, st, devAt.data()))) return rc;
     } else if (!onDevice && ingestKernel && nframes <= coneMaxFrames &&
                ((((uintptr_t)gray[0] | (uintptr_t)gray[nframes - 1] | (uintptr_t)stride | (uintptr_t)rowBytes) & 3) == 0)) {   // (byte-aligned views: the copy engine)
       // a one- or two-frame call from page-locked memory: the compute stream fetches the frame itself (k_ingest) -- no copy command
-      // on another queue, no event between the queues
+      // on another queue, no event between the queues.  The kernel reads the frame at the address the GPU sees it at: the host
+      // address itself for orbfe_host_alloc memory, the mapping of a buffer the caller registered (orbfe_host_register) otherwise.
       for (int f = 0; f < nframes; f++) {
         uint8_t* d = d_in.p + (size_t)inPitch * rows * f;
-        // the address the GPU reads the frame at: the host address itself for orbfe_host_alloc memory, the mapping of a buffer the
-        // caller registered (orbfe_host_register) otherwise
-        void* dp = nullptr;
-        if (hipHostGetDevicePointer(&dp, const_cast<uint8_t*>(gray[f]), 0) != hipSuccess || !dp) {
-          (void)hipGetLastError();
-          dp = const_cast<uint8_t*>(gray[f]);
-        }
-        launch_ingest(static_cast<const uint8_t*>(dp), (long long)stride, d, inPitch, rowBytes, r, st);
+        launch_ingest(mappedAt[f], (long long)stride, d, inPitch, rowBytes, r, st);
         devAt[f] = d;
       }
       HIP_TRY(hipGetLastError());
@@ -799,7 +746,7 @@ struct orbfe_extractor {
       std::lock_guard<std::mutex> lk(lane->mu);
       if ((rc = uploadFrames(0, nframes, gray, stride, r, rowBytes, lane->stream, devAt.data()))) return rc;
       HIP_TRY(hipEventRecord(evUpload, lane->stream));
-      HIP_TRY(hipStreamWaitEvent(fs, evUpload, 0));
+      HIP_TRY(hipStreamWaitEvent(st, evUpload, 0));
     }
     bool rawAligned = ((onDevice ? (long long)stride : inPitch) & 3) == 0;
     for (int f = 0; f < nframes; f++) {
@@ -818,7 +765,7 @@ struct orbfe_extractor {
       P.frameInline[1] = h_frame0.p[nframes - 1];
     } else {
       P.frame0 = d_frame0.p;
-      HIP_TRY(hipMemcpyAsync(d_frame0.p, h_frame0.p, sizeof(void*) * nframes * (ch == 1 ? 1 : 2), hipMemcpyHostToDevice, fs));
+      HIP_TRY(hipMemcpyAsync(d_frame0.p, h_frame0.p, sizeof(void*) * nframes * (ch == 1 ? 1 : 2), hipMemcpyHostToDevice, st));
     }
     if (ch > 1) {
       // OpenCV RGB2Gray<uchar>: 15-bit coefficients {R 9798, G 19235, B 3735} (>= 4.1.1) or 14-bit {4899, 9617, 1868}
@@ -826,42 +773,20 @@ struct orbfe_extractor {
       const int cr = q15 ? 9798 : 4899, cg = q15 ? 19235 : 9617, cb = q15 ? 3735 : 1868;
       const bool rgb = inFormat == ORBFE_INPUT_RGB8 || inFormat == ORBFE_INPUT_RGBA8;
       const int coef[3] = {rgb ? cr : cb, cg, rgb ? cb : cr};
-      launch_to_gray(d_frame0.p + nframes, rawStride, d_frame0.p, grayPitch, r, c, ch, coef, q15 ? 15 : 14, rawAligned, nframes, fs);
+      launch_to_gray(d_frame0.p + nframes, rawStride, d_frame0.p, grayPitch, r, c, ch, coef, q15 ? 15 : 14, rawAligned, nframes, st);
     }
     const bool prof = profileKernels;
-    {
-      FrontLane* fl = frontLane ? front_lane(device) : nullptr;
-      std::unique_lock<std::mutex> lk;
-      if (fl) {
-        lk = std::unique_lock<std::mutex>(fl->mu);
-        hipEvent_t w = frontSplit ? fl->lastPyr : fl->last;
-        if (w && w != evFront && w != evPyr) HIP_TRY(hipStreamWaitEvent(st, w, 0));
-      }
-      if (prof) HIP_TRY(hipEventRecord(ev[0][0], st));
-      if (launch_pyramid(P, nframes, fs, coneOk && nframes <= coneMaxFrames ? &cone : nullptr)) { set_err("cannot configure the pyramid kernel"); return ORBFE_ERR_HIP; }
-      if (pyrOwn) {
-        HIP_TRY(hipEventRecord(evPyrDone, fs));
-        HIP_TRY(hipStreamWaitEvent(st, evPyrDone, 0));
-      }
-      if (fl && frontSplit) {
-        HIP_TRY(hipEventRecord(evPyr, st));
-        fl->lastPyr = evPyr;
-        if (fl->last && fl->last != evFront) HIP_TRY(hipStreamWaitEvent(st, fl->last, 0));
-      }
-      // the dominant kernel is timed in every batch (bench.py roofline); a latency-bound one- or two-frame call does
-      // without the two markers (each costs a few microseconds of dependent-launch gap) unless profiling is on
-      const bool timeFast = prof || nframes > coneMaxFrames;
-      fastTimed = timeFast;
-      if (timeFast) HIP_TRY(hipEventRecord(ev[0][1], st));
-      launch_fast(P, nframes, st);
-      if (timeFast) HIP_TRY(hipEventRecord(ev[0][2], st));
-      launch_compact(P, nframes, st);
-      if (prof) HIP_TRY(hipEventRecord(ev[0][3], st));
-      if (fl) {
-        HIP_TRY(hipEventRecord(evFront, st));
-        fl->last = evFront;
-      }
-    }
+    if (prof) HIP_TRY(hipEventRecord(ev[0][0], st));
+    if (launch_pyramid(P, nframes, st, coneOk && nframes <= coneMaxFrames ? &cone : nullptr)) { set_err("cannot configure the pyramid kernel"); return ORBFE_ERR_HIP; }
+    // the dominant kernel is timed in every batch (bench.py roofline); a latency-bound one- or two-frame call does
+    // without the two markers (each costs a few microseconds of dependent-launch gap) unless profiling is on
+    const bool timeFast = prof || nframes > coneMaxFrames;
+    fastTimed = timeFast;
+    if (timeFast) HIP_TRY(hipEventRecord(ev[0][1], st));
+    launch_fast(P, nframes, st);
+    if (timeFast) HIP_TRY(hipEventRecord(ev[0][2], st));
+    launch_compact(P, nframes, st);
+    if (prof) HIP_TRY(hipEventRecord(ev[0][3], st));
     QP.cand = d_cand.p; QP.levelStart = d_levelStart.p; QP.candCap = P.candCap; QP.nlevels = nlevels; QP.frameBase = 0;
     QP.own = d_own.p;
     QP.sel = d_sel.p; QP.selCount = d_selCount.p; QP.selPerFrame = selPerFrame;
@@ -876,23 +801,10 @@ struct orbfe_extractor {
     for (int l = 0; l < nlevels; l++) {
       QP.levW[l] = P.lv[l].w; QP.levH[l] = P.lv[l].h; QP.nfeat[l] = nfeat[l]; QP.selOff[l] = selOff[l];
     }
-    // k_quadtree is latency-bound (dependent scans, one block per (frame, level)) and leaves most issue
-    // slots idle, so it runs on its own high-priority stream: with two batches in flight it overlaps the
-    // other batch's VALU-bound kernels instead of queueing behind them.
-    const bool ownQs = qtOwnStream && nframes > coneMaxFrames;   // nothing to overlap with in a single-frame call
-    hipStream_t qs = ownQs ? qtStream : st;
-    if (ownQs) {
-      HIP_TRY(hipEventRecord(evQtIn, st));
-      HIP_TRY(hipStreamWaitEvent(qs, evQtIn, 0));
-    }
-    if (prof) HIP_TRY(hipEventRecord(evQt[0], qs));
+    if (prof) HIP_TRY(hipEventRecord(evQt[0], st));
     // a one- or two-frame call is latency-bound and alone on the chip: the quadtree keeps its candidates in LDS
-    if (launch_quadtree(QP, nframes, qs, nframes <= coneMaxFrames ? qtLdsBudget : 0)) { set_err("cannot configure the quadtree kernel"); return ORBFE_ERR_HIP; }
-    if (prof) HIP_TRY(hipEventRecord(evQt[1], qs));
-    if (ownQs) {
-      HIP_TRY(hipEventRecord(evQtOut, qs));
-      HIP_TRY(hipStreamWaitEvent(st, evQtOut, 0));
-    }
+    if (launch_quadtree(QP, nframes, st, nframes <= coneMaxFrames ? qtLdsBudget : 0)) { set_err("cannot configure the quadtree kernel"); return ORBFE_ERR_HIP; }
+    if (prof) HIP_TRY(hipEventRecord(evQt[1], st));
     const int nslots = nframes * selPerFrame;
     if (prof) HIP_TRY(hipEventRecord(ev[0][4], st));
     // a one- or two-frame call is alone on the chip and waits for single keypoints: four waves share each one
@@ -908,7 +820,6 @@ struct orbfe_extractor {
       pendingBow = true;
     }
     pendingMatched = false;
-    pendingTail = false;
     if (ms && ms->chain) {
       // SearchForInitialization of every frame against its predecessor, on the data that is already in HBM
       orbfe_sfi_chain& ch = *ms->chain;
@@ -930,36 +841,17 @@ struct orbfe_extractor {
       SP.window = (float)ms->window; SP.nnratio = ms->nnratio; SP.checkOri = ms->checkOri;
       SP.order = d_sfiOrder.p; SP.orderCount = d_sfiOrderCount.p; SP.pool = d_sfiPool.p; SP.pcount = d_sfiPcount.p;
       SP.matches12 = d_m12.p; SP.nmatches = d_nm.p;
-      // (see tailStream above) everything from here to the end of the batch on the tail stream
-      const bool tail = tailOwnStream && tailStream && nframes > coneMaxFrames && !zeroCopy;
-      hipStream_t ts = tail ? tailStream : st;
-      if (tail) {
-        HIP_TRY(hipEventRecord(evTailIn, st));
-        HIP_TRY(hipStreamWaitEvent(ts, evTailIn, 0));
-      }
-      pendingTail = tail;
-      if (ch.seq > 0) HIP_TRY(hipStreamWaitEvent(ts, ch.ready[prev], 0));
-      launch_sfi(SP, nframes, ts);
+      if (ch.seq > 0) HIP_TRY(hipStreamWaitEvent(st, ch.ready[prev], 0));
+      launch_sfi(SP, nframes, st);
       HIP_TRY(hipGetLastError());
       // hand the last frame's level-0 data to the next batch
-      launch_sfi_carry(SP, nframes - 1, ch.sel[cur].p, ch.angle[cur].p, ch.desc[cur].p, ch.count.p + cur, ts);
+      launch_sfi_carry(SP, nframes - 1, ch.sel[cur].p, ch.angle[cur].p, ch.desc[cur].p, ch.count.p + cur, st);
       HIP_TRY(hipGetLastError());
-      HIP_TRY(hipEventRecord(ch.ready[cur], ts));
+      HIP_TRY(hipEventRecord(ch.ready[cur], st));
       ch.seq++;
       pendingMatched = true;
-      if (tail) {
-        HIP_TRY(hipMemcpyAsync(h_outArena.p, d_outArena.p, outArenaBytes, hipMemcpyDeviceToHost, ts));
-        submitProfiled = prof;
-        tSubmit0 = t0;
-        tSubmit1 = now_ms();
-        pendingFrames = nframes;
-        return ORBFE_OK;
-      }
     }
-    // (ORBFE_DEBUG_SKIP_RESULT_COPY=1: measurement only -- the upper bound of what writing the results from the kernels would buy; the
-    // caller then reads stale results)
-    static const bool skipCopy = getenv("ORBFE_DEBUG_SKIP_RESULT_COPY") && atoi(getenv("ORBFE_DEBUG_SKIP_RESULT_COPY")) != 0;
-    if (!zeroCopy && !skipCopy) HIP_TRY(hipMemcpyAsync(h_outArena.p, d_outArena.p, outArenaBytes, hipMemcpyDeviceToHost, st));   // all results, one copy
+    if (!zeroCopy) HIP_TRY(hipMemcpyAsync(h_outArena.p, d_outArena.p, outArenaBytes, hipMemcpyDeviceToHost, st));   // all results, one copy
     submitProfiled = prof;
     tSubmit0 = t0;
     tSubmit1 = now_ms();
@@ -971,7 +863,7 @@ struct orbfe_extractor {
   int waitOnly() {
     if (!pendingFrames) return ORBFE_OK;
     HIP_TRY(hipSetDevice(device));
-    hipStream_t st = pendingTail ? tailStream : streams[0];
+    hipStream_t st = streams[0];
     if (pollWaitUs > 0) {
       hipError_t q;
       while ((q = hipStreamQuery(st)) == hipErrorNotReady) usleep((useconds_t)pollWaitUs);
@@ -987,7 +879,7 @@ struct orbfe_extractor {
     HIP_TRY(hipSetDevice(device));
     const int nframes = pendingFrames;
     pendingFrames = 0;
-    hipStream_t st = pendingTail ? tailStream : streams[0];   // a matched batch ends on the tail stream (everything on streams[0] precedes it)
+    hipStream_t st = streams[0];
     const double t0 = tSubmit0, t1 = tSubmit1;
     const double t1b = now_ms();
     if (pollWaitUs > 0) {   // sleep-poll instead of the runtime's spinning wait (pipelined callers: the wake-up delay is hidden)
@@ -1519,53 +1411,23 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
   }
   h->stream = h->streams[0];
   bool evOk = hipEventCreate(&h->evFrame0) == hipSuccess &&
-              hipEventCreateWithFlags(&h->evUpload, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&h->evFront, hipEventDisableTiming) == hipSuccess &&
-              hipEventCreateWithFlags(&h->evPyr, hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&h->evUpload, hipEventDisableTiming) == hipSuccess;
   for (auto& e : h->evS1) evOk = evOk && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
   for (auto& es : h->ev) for (auto& e : es) evOk = evOk && hipEventCreate(&e) == hipSuccess;
   if (!evOk) { set_err("hipEventCreate failed"); delete h; return ORBFE_ERR_HIP; }
-  if (const char* sv = getenv("ORBFE_SUB_BATCHES")) h->subBatches = atoi(sv);
   for (auto& e : h->evQt) evOk = evOk && hipEventCreate(&e) == hipSuccess;
   if (!evOk) { set_err("hipEventCreate failed"); delete h; return ORBFE_ERR_HIP; }
-  {
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    if (const char* qv = getenv("ORBFE_QT_STREAM")) h->qtOwnStream = atoi(qv) != 0;
-    if (const char* fv = getenv("ORBFE_FRONT_LANE")) h->frontLane = atoi(fv) != 0;
-    if (const char* fv = getenv("ORBFE_FRONT_SPLIT")) h->frontSplit = atoi(fv) != 0;
-    evOk = (!h->qtOwnStream || hipStreamCreateWithPriority(&h->qtStream, hipStreamNonBlocking, greatest) == hipSuccess) &&
-           hipEventCreateWithFlags(&h->evQtIn, hipEventDisableTiming) == hipSuccess &&
-           hipEventCreateWithFlags(&h->evQtOut, hipEventDisableTiming) == hipSuccess;
-    if (!evOk) { set_err("creating the quadtree stream failed"); delete h; return ORBFE_ERR_HIP; }
-    if (const char* pv = getenv("ORBFE_PYR_STREAM")) h->pyrOwnStream = atoi(pv) != 0;
-    if (h->pyrOwnStream) {
-      const int prio = getenv("ORBFE_PYR_PRIORITY") ? atoi(getenv("ORBFE_PYR_PRIORITY")) : greatest;
-      if (hipStreamCreateWithPriority(&h->pyrStream, hipStreamNonBlocking, prio) != hipSuccess ||
-          hipEventCreateWithFlags(&h->evPyrDone, hipEventDisableTiming) != hipSuccess) {
-        set_err("creating the pyramid stream failed"); delete h; return ORBFE_ERR_HIP;
-      }
-    }
-    if (const char* tv = getenv("ORBFE_TAIL_STREAM")) h->tailOwnStream = atoi(tv) != 0;
-    if (h->tailOwnStream) {
-      const int prio = getenv("ORBFE_TAIL_PRIORITY") ? atoi(getenv("ORBFE_TAIL_PRIORITY")) : greatest;
-      if (hipStreamCreateWithPriority(&h->tailStream, hipStreamNonBlocking, prio) != hipSuccess ||
-          hipEventCreateWithFlags(&h->evTailIn, hipEventDisableTiming) != hipSuccess) {
-        set_err("creating the tail stream failed"); delete h; return ORBFE_ERR_HIP;
-      }
-    }
-  }
   if (const char* hv = getenv("ORBFE_HOST_QUADTREE")) h->gpuQuadtree = atoi(hv) == 0;
   if (const char* pv = getenv("ORBFE_FAST_PAIRS")) h->pairCells = atoi(pv) != 0;
   if (const char* cv = getenv("ORBFE_CONE_MAX_FRAMES")) h->coneMaxFrames = atoi(cv);
   if (const char* pv = getenv("ORBFE_POLL_WAIT_US")) h->pollWaitUs = atoi(pv);
-  if (const char* dw = getenv("ORBFE_DESCRIBE_WAVES")) h->describe4 = atoi(dw) != 1;
+  if (const char* dw = ORBFE_EXP_ENV("ORBFE_DESCRIBE_WAVES")) h->describe4 = atoi(dw) != 1;
   if (const char* zv = getenv("ORBFE_ZERO_COPY")) h->zeroCopyOut = atoi(zv) != 0;
   if (const char* iv = getenv("ORBFE_INGEST_KERNEL")) h->ingestKernel = atoi(iv) != 0;
   if (const char* qv = getenv("ORBFE_QT_LDS_BYTES")) h->qtLdsBudget = atoi(qv);
   if (const char* qj = getenv("ORBFE_QT_JUMP")) h->qtJump = atoi(qj) != 0;
-  if (const char* cv = getenv("ORBFE_CONE_TILE")) h->coneTile = atoi(cv) <= 0 ? 0 : std::max(8, atoi(cv)) & ~3;
-  if (const char* pv = getenv("ORBFE_PROFILE_KERNELS")) h->profileKernels = atoi(pv) != 0;
+  if (const char* cv = ORBFE_EXP_ENV("ORBFE_CONE_TILE")) h->coneTile = atoi(cv) <= 0 ? 0 : std::max(8, atoi(cv)) & ~3;
+  if (const char* pv = ORBFE_EXP_ENV("ORBFE_PROFILE_KERNELS")) h->profileKernels = atoi(pv) != 0;
   if (const char* gv = getenv("ORBFE_GAUSS_VARIANT")) h->gaussVariant = atoi(gv) == ORBFE_GAUSS_ROUNDED ? ORBFE_GAUSS_ROUNDED : ORBFE_GAUSS_ED;
   h->selPerFrame = 0;
   for (int l = 0; l < nlevels; l++) {
@@ -1596,6 +1458,10 @@ int orbfe_debug_fast_stamps(orbfe_extractor* h, unsigned long long out[8], int r
   if (!h || !out) { set_err("NULL argument"); return ORBFE_ERR_INVALID; }
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipDeviceSynchronize());
+#ifndef ORBFE_EXPERIMENTS
+  set_err("orbfe_debug_fast_stamps needs a library built with make EXPERIMENTS=1");
+  return ORBFE_ERR_INVALID;
+#endif
   if (orbfe::fast_stamps(out, reset)) { set_err("reading the stamp counters failed"); return ORBFE_ERR_HIP; }
   return ORBFE_OK;
 }

@@ -37,11 +37,9 @@ namespace orbfe {
 
 namespace {
 __device__ __forceinline__ int m24(int a, int b) { return __mul24(a, b); }
-typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u16x2 as_u16x2(unsigned v) { return __builtin_bit_cast(u16x2, v); }
 __device__ __forceinline__ unsigned as_u32(u16x2 v) { return __builtin_bit_cast(unsigned, v); }
-__device__ __forceinline__ s16x2 as_s16x2(unsigned v) { return __builtin_bit_cast(s16x2, v); }
 }  // namespace
 
 // integer min / max of three packed 16-bit values whose bit patterns are normal positive half floats (see stage 2)
@@ -60,12 +58,13 @@ __device__ __forceinline__ unsigned pk_max3_h(unsigned a, unsigned b, unsigned c
 // compiler-level memory fence plus the LDS counter is enough.
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-// NPX = pixels per lane in the pre-test (8 or 16); tpPad = extra bytes of tile pitch (LDS bank spreading)
+// NPX = pixels per lane in the pre-test (8 or 16)
 // PAIRS = false: every task is a single cell (the default task table); the second cell's bookkeeping compiles away
-// ABL (measurement only, ORBFE_FAST_ABLATE=1..3, tools/fast_ablation.sh): the kernel stops after its set-up + ROI load (1),
-// after the pre-test and its compaction (2), after the score stage (3) -- every cell then reports no candidate; 0 = the product;
-// 4 = the product with s_memtime stamps between its phases, summed over all waves into g_fastStamps (orbfe_debug_fast_stamps);
-// 5 = the product without the second pass at minThFAST (what that pass costs)
+// ABL = 0 is the product, and the only instantiation of a default build.  A build with -DORBFE_EXPERIMENTS (make EXPERIMENTS=1)
+// also instantiates the measurement modes ORBFE_FAST_ABLATE selects (tools/fast_ablation.sh, tools/fast_phases.py): the kernel stops
+// after its set-up + ROI load (1), after the pre-test and its compaction (2), after the score stage (3) -- every cell then reports no
+// candidate; 4 = the product with s_memtime stamps between its phases, one record per wave (orbfe_debug_fast_stamps); 5 = the product
+// without the second pass at minThFAST (what that pass costs)
 // What the kernel needs of PyramidParams, as a compact argument block of its own (136 bytes): the whole of it arrives with the
 // first scalar load of a wave; out of the 1.4 KB PyramidParams the fields came in three dependent groups, the last one behind
 // the task fetch.
@@ -101,11 +100,8 @@ __device__ uint32_t* g_fastStampBuf;   // [waves of the launch][8]
 template <int NPX, bool PAIRS, int ABL = 0, bool LEAN = false>
 // (amdgpu_num_sgpr(96): the kernel asks for 105 scalar registers by itself, which caps a SIMD at 6 waves; 94 with 3 values parked in
 // a vector register allow 7 -- +1 % in the pipeline, 80 / 88 measured the same)
-__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fast_tasks(FastArgs P, int tpPad, int dma, int t0, int nt) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fast_tasks(FastArgs P, int t0, int nt) {
   extern __shared__ __align__(16) uint8_t lds[];
-#if defined(ORBFE_FAST_PRIO) && ORBFE_FAST_PRIO
-  __builtin_amdgcn_s_setprio(ORBFE_FAST_PRIO);   // experiment (round 5): the long kernel's waves win instruction arbitration
-#endif
   unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
   if constexpr (ABL == 4) stamp[0] = __builtin_amdgcn_s_memtime();
   // this launch works on tasks [t0, t0 + nt): the levels of one LDS class (launch_fast)
@@ -113,7 +109,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fas
   // fetches t0 / nt, tests the bound below, and only then asks for the rest)
   asm volatile("" ::"s"(P.tasks), "s"(P.frame0), "s"(P.frameInline[0]), "s"(P.frameInline[1]), "s"(P.stride0), "s"(P.slab), "s"(P.slabBytes),
                "s"(P.cellCount), "s"(P.slots), "s"(P.slotsPerFrame), "s"(P.zeros), "s"(P.ncells), "s"(P.iniTh), "s"(P.minTh), "s"(P.frameBase),
-               "s"(t0), "s"(nt), "s"(dma), "s"(tpPad));
+               "s"(t0), "s"(nt));
   const int chunk = (nt + 7) >> 3;
   const int tloc = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
   if (tloc >= nt) return;
@@ -166,11 +162,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fas
     roi = P.slab + (long long)f * P.slabBytes + roiOff;
   }
   // LDS carve (level-uniform): ROI tile, score tile with a zero ring, queue (y<<8|x)
-  // (dma == 2: 16-byte LDS-DMA pieces -- the pitch is a multiple of 16 that holds alignment offset + widest ROI row)
+  // (the tile pitch is a multiple of 16 -- the ROI arrives in 16-byte LDS-DMA pieces -- that holds alignment offset + widest ROI row)
   // LEAN: the carve comes with the task (FastTask::geo = pieces per tile row | rows per instruction << 3 | score tile offset / 16 << 8 |
   // queue offset / 16 << 18, written by fast_task_geo() below from the same formulas)
   const uint32_t geo = tw[7];
-  const int TP = LEAN ? (int)(geo & 7u) << 4 : dma == 2 ? ((fastW + 6 + 3 + 15) & ~15) : ((fastW + 6 + 3 + 3) & ~3) + tpPad;
+  const int TP = LEAN ? (int)(geo & 7u) << 4 : ((fastW + 6 + 3 + 15) & ~15);
   const int SP = fastW + 2;
   uint8_t* tile = lds;
   const int scOff = LEAN ? (int)((geo >> 8) & 0x3ffu) << 4 : (TP * (hCell + 6) + 15) & ~15;   // 16-byte aligned: it is cleared by 16-byte LDS-DMA pieces
@@ -179,13 +175,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fas
 
   const int rw = W2 + 6, rh = eh + 6;
   const int istr = (int)stride;
-  // ROI -> LDS.  Loads are issued in batches of 12 per lane before the first LDS write so the wave waits for memory
-  // once per batch, not once per element.  Rows are fetched as aligned dwords when the row pitch allows it; `a` is the
-  // byte offset of the ROI inside its first dword.
+  // ROI -> LDS by LDS-DMA where the row pitch is a multiple of 4 (every level of the pyramid slab; level 0 when the caller's
+  // stride allows it), byte by byte otherwise.  `a` is the byte offset of the ROI inside its first dword.
   const int a = (int)(reinterpret_cast<uintptr_t>(roi) & 3);
   if constexpr (ABL == 4) { asm volatile("" ::"s"(a), "s"(istr), "s"(TP) : "memory"); stamp[1] = __builtin_amdgcn_s_memtime(); }
   if constexpr (LEAN) {
-    // the dma == 2 staging below with everything wave-uniform taken from the task: pieces per row, rows per instruction
+    // the staging below with everything wave-uniform taken from the task: pieces per row, rows per instruction
     const int ppr = (int)(geo & 7u), rpi = (int)((geo >> 3) & 31u);
     const float rn = __builtin_amdgcn_rcpf((float)ppr);
     const int lrow = (int)(((float)lane + 0.5f) * rn), lcol = lane - m24(lrow, ppr);
@@ -203,7 +198,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fas
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + vo),
                                          (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
     }
-  } else if ((stride & 3) == 0 && dma == 2) {
+  } else if ((stride & 3) == 0) {
     // 16 bytes per lane (global_load_lds_dwordx4): TP / 16 pieces per tile row, 64 / pieces rows per instruction -- the 37-row tile
     // of a single cell is TWO instructions (seven with one dword per lane); the global side needs dword alignment only, a row's last
     // piece may reach up to 11 bytes past the ROI: inside the level's row (an emit region stays 16 pixels off the border)
@@ -223,52 +218,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fas
       if (on && lrow < left)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + vo),
                                          (__attribute__((address_space(3))) void*)lp, 16, 0, 0);
-    }
-  } else if ((stride & 3) == 0 && dma) {
-    // LDS-DMA (global_load_lds_dword): the tile's aligned dwords go from memory straight into LDS -- no register round
-    // trip, no ds_write, and no per-element address arithmetic: one instruction moves `rpi` whole tile rows (lane = (row,
-    // dword column) over the tile pitch; lane L's dword lands at the instruction's LDS base + 4 L, so the lanes of a row group
-    // are contiguous in LDS exactly as the tile wants them), the global base and the LDS base advance on the scalar unit.
-    const int ndw = (a + rw + 3) >> 2, ndwT = TP >> 2;
-    // lane / ndwT by the hardware reciprocal (1 ulp; the quotient sits at least 0.5 / ndwT away from an integer): an exact
-    // division costs eleven vector instructions
-    const float rn = __builtin_amdgcn_rcpf((float)ndwT);
-    const int rpi = 64 / ndwT;                                  // tile rows per instruction (5 or 6 for a single cell); scalar
-    const int lrow = (int)(((float)lane + 0.5f) * rn), lcol = lane - m24(lrow, ndwT);
-    const bool on = lrow < rpi && lcol < ndw;
-    const unsigned voff = (unsigned)(m24(lrow, istr) + 4 * lcol);
-    const uint8_t* gp = roi - a;                               // wave-uniform: scalar base + the lane's constant 32-bit offset
-    const long long gstep = (long long)rpi * stride;
-    const int lstep = m24(rpi, TP);
-    uint8_t* lp = tile;
-    for (int left = rh; left > 0; left -= rpi, gp += gstep, lp += lstep) {
-      // keep the row base in scalar registers and the lane offset 32 bits wide: scalar base + vector offset is an addressing
-      // mode; left to itself the compiler builds a 64-bit per-lane address and advances it with a vector add per iteration
-      unsigned vo = voff;
-      asm volatile("" : "+s"(gp), "+v"(vo));
-      if (on && lrow < left)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gp + vo),
-                                         (__attribute__((address_space(3))) void*)lp, 4, 0, 0);
-    }
-  } else if ((stride & 3) == 0) {
-    // lane (c, r0) copies dword column c of rows r0, r0 + rstep, ...: 16 columns x 4 rows per sweep for a single cell,
-    // 32 columns x 2 rows for a pair (up to 19 dword columns)
-    const int ndw = (a + rw + 3) >> 2;
-    const uint8_t* base = roi - a;
-    const int cshift = ndw > 16 ? 5 : 4;
-    const int c = lane & ((1 << cshift) - 1), r0 = lane >> cshift, rstep = 64 >> cshift;
-    if (c < ndw) {
-      const uint8_t* g = base + 4 * c + m24(r0, istr);
-      uint8_t* l = tile + 4 * c + m24(r0, TP);
-      const int gstep = m24(rstep, istr), lstep = m24(rstep, TP);
-      for (int r = r0; r < rh; r += 12 * rstep, g += 12 * gstep, l += 12 * lstep) {
-        uint32_t v[12];
-#pragma unroll
-        for (int u = 0; u < 12; u++) v[u] = (r + u * rstep < rh) ? *reinterpret_cast<const uint32_t*>(g + u * gstep) : 0u;
-#pragma unroll
-        for (int u = 0; u < 12; u++)
-          if (r + u * rstep < rh) *reinterpret_cast<uint32_t*>(l + u * lstep) = v[u];
-      }
     }
   } else {
     const float rcpRw = 1.0f / (float)rw;
@@ -304,7 +253,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fas
       if (lane < pieces - p0)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)P.zeros,
                                          (__attribute__((address_space(3))) void*)(sc + 16 * p0), 16, 0, 0);
-  } else if (dma && P.zeros) {
+  } else {
     // the score tile is cleared by LDS-DMA too: every lane fetches the same 16 zero bytes (one cache line for the whole chip) and
     // lane L's copy lands at base + 16 L -- two instructions for the 1.1 KB tile, no vector instruction, no ds_write.  (The last
     // piece may run up to 15 bytes into the queue, which stage 1 writes later.)
@@ -313,10 +262,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fas
       if (lane < pieces - p0)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)P.zeros,
                                          (__attribute__((address_space(3))) void*)(sc + 16 * p0), 16, 0, 0);
-  } else {  // zero the score tile with dword stores
-    uint32_t* z = reinterpret_cast<uint32_t*>(sc);
-    const int nz = (SP * (eh + 2) + 3) >> 2;
-    for (int i = lane; i < nz; i += 64) z[i] = 0u;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the LDS-DMA writes are tracked by vmcnt)
   wave_lds_fence();
@@ -577,6 +522,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_sgpr(96))) void k_fas
   }
 }
 
+#ifdef ORBFE_EXPERIMENTS
 // measurement only (ORBFE_FAST_ABLATE=4): per-wave phase cycles of the LAST launch, summed on the host: entry -> geometry
 // known, -> ROI in LDS, -> pre-test done, -> scores done, -> end; [5] = waves.  ONE buffer per process (g_fastStampBuf is a
 // device symbol): meant for a single extractor on a single device, as tools/fast_phases.py uses it.
@@ -605,22 +551,23 @@ static void stamp_buffer_for(size_t waves) {
   }
   (void)hipMemset(s_stampBuf, 0, s_stampWaves * 32);
 }
-
-static int fast_dma_mode() {   // ORBFE_FAST_DMA: 0 ROI through registers, 1 LDS-DMA one dword per lane, 2 LDS-DMA 16 bytes per lane
-  static const int dma = [] { const char* e = getenv("ORBFE_FAST_DMA"); return e ? atoi(e) : 2; }();
-  return dma;
+#else
+int fast_stamps(unsigned long long out[8], int) {   // (a default build has no stamped instantiation)
+  for (int k = 0; k < 8; k++) out[k] = 0;
+  return 1;
 }
-static size_t fast_lds_bytes_level(const LevelGeom& L, int tpPad) {
-  const size_t TP = fast_dma_mode() == 2 ? ((L.fastW + 6 + 3 + 15) & ~15) : ((L.fastW + 6 + 3 + 3) & ~3) + tpPad;
+#endif
+
+static size_t fast_lds_bytes_level(const LevelGeom& L) {
+  const size_t TP = (size_t)((L.fastW + 6 + 3 + 15) & ~15);
   const size_t scOff = (TP * (L.hCell + 6) + 15) & ~(size_t)15;
   const size_t b = ((scOff + (size_t)(L.fastW + 2) * (L.hCell + 2) + 15) & ~(size_t)15) +
                    2 * (size_t)L.fastW * L.hCell + 64;  // tile + score tile + u16 queue + slack for the group over-read
   return (b + 15) & ~(size_t)15;
 }
-// FastTask::geo of a level (the LEAN prologue's LDS carve and staging constants); 0: not representable / not the 16-byte LDS-DMA mode
-// -> the level's launches take the generic prologue
+// FastTask::geo of a level (the LEAN prologue's LDS carve and staging constants); 0: not representable -> the level's launches
+// take the generic prologue
 uint32_t fast_task_geo(int fastW, int hCell) {
-  if (fast_dma_mode() != 2) return 0u;
   const uint32_t TP = (uint32_t)((fastW + 6 + 3 + 15) & ~15), ppr = TP >> 4;
   if (ppr == 0 || ppr > 7) return 0u;
   const uint32_t rpi = 64u / ppr;
@@ -630,19 +577,11 @@ uint32_t fast_task_geo(int fastW, int hCell) {
   return ppr | (rpi << 3) | ((scOff >> 4) << 8) | ((qOff >> 4) << 18);
 }
 
-size_t fast_lds_bytes(const PyramidParams& P, int tpPad) {
-  size_t mx = 0;
-  for (int l = 0; l < P.nlevels; l++) mx = std::max(mx, fast_lds_bytes_level(P.lv[l], tpPad));
-  return mx;
-}
-
-void launch_fast(const PyramidParams& P, int nframes, hipStream_t st) {
+void launch_fast(const PyramidParams& P, int nframes, hipStream_t st, int level0, int level1) {
   // 16 pixels per lane in the pre-test: one wave iteration covers a 31 x 31 cell (8 pixels per lane take two and are
-  // equal in time, 9.9 us per 1080p frame, with more instructions)
-  static const int ablate = [] { const char* e = getenv("ORBFE_FAST_ABLATE"); return e ? atoi(e) : 0; }();   // measurement only
-  const int dma = fast_dma_mode();
+  // equal in time, 9.9 us per 1080p frame, with more instructions).  Levels [level0, level1) of every frame.
   const FastArgs FA = fast_args(P);
-  static const int split = [] { const char* e = getenv("ORBFE_FAST_LDS_CLASSES"); return e ? atoi(e) : 1; }();   // 0: one launch, the largest level's LDS
+  if (level1 > P.nlevels) level1 = P.nlevels;
   bool pairs = false;
   for (int l = 0; l < P.nlevels; l++) pairs = pairs || P.lv[l].fastW != P.lv[l].wCell;
   // LDS CLASSES (round 4).  LDS is handed out in 1 KB granules and a CU has 160 of them: a one-wave workgroup that asks for up
@@ -653,52 +592,54 @@ void launch_fast(const PyramidParams& P, int nframes, hipStream_t st) {
   // 40 % of its life waiting for its ROI -- residency is what hides that.  So consecutive levels that fit 5 KB go out as one
   // launch with 5 KB of LDS, the others as launches of their own.
   constexpr size_t kLdsFull = 5120;
-  int l = 0;
-  while (l < P.nlevels) {
+  // ORBFE_FAST_LEAN=0 forces the generic prologue (the one odd strides and unusual cell sizes take) on every launch: tests/test_gpu_parity.py
+  static const int leanEnv = [] { const char* e = getenv("ORBFE_FAST_LEAN"); return e ? atoi(e) : 1; }();
+#ifdef ORBFE_EXPERIMENTS
+  static const int ablate = [] { const char* e = ORBFE_EXP_ENV("ORBFE_FAST_ABLATE"); return e ? atoi(e) : 0; }();   // measurement only
+#endif
+  int l = level0;
+  while (l < level1) {
     int e = l + 1;
-    size_t need = fast_lds_bytes_level(P.lv[l], 0);
-    if (split && nframes > 2) {   // (a one- or two-frame call is latency-bound: one launch less is worth more than residency there)
+    size_t need = fast_lds_bytes_level(P.lv[l]);
+    if (nframes > 2) {   // (a one- or two-frame call is latency-bound: one launch less is worth more than residency there)
       const bool small = need <= kLdsFull;
-      while (e < P.nlevels && (fast_lds_bytes_level(P.lv[e], 0) <= kLdsFull) == small) { need = std::max(need, fast_lds_bytes_level(P.lv[e], 0)); e++; }
+      while (e < level1 && (fast_lds_bytes_level(P.lv[e]) <= kLdsFull) == small) { need = std::max(need, fast_lds_bytes_level(P.lv[e])); e++; }
     } else {
-      while (e < P.nlevels) { need = std::max(need, fast_lds_bytes_level(P.lv[e], 0)); e++; }
+      while (e < level1) { need = std::max(need, fast_lds_bytes_level(P.lv[e])); e++; }
     }
     const int t0 = P.taskStart[l], nt = P.taskStart[e] - t0;
     l = e;
     if (nt <= 0) continue;
-    // experiment (round 5): a batch launch may ask for MORE LDS than it needs so that fewer FAST waves are resident and another
-    // batch's multi-wave workgroups (pyramid tiles: 256 threads, 15 - 20 KB of LDS) find room beside them
-    static const int ldsFloor = [] { const char* e2 = getenv("ORBFE_FAST_LDS_FLOOR"); return e2 ? atoi(e2) : 0; }();
-    if (nframes > 2 && ldsFloor > 0) need = std::max(need, (size_t)ldsFloor);
     const dim3 grid(8 * ((nt + 7) / 8), nframes);
-    // the LEAN prologue's preconditions, checked once per launch instead of by every wave
-    static const int leanEnv = [] { const char* e = getenv("ORBFE_FAST_LEAN"); return e ? atoi(e) : 1; }();
+    // the LEAN prologue's preconditions, checked once per launch instead of by every wave (level 0: the ROI offset
+    // (ey0 - 3) * stride0 + ex0 - 3 of the last cell row must fit 32 bits)
     const unsigned long long frames = (unsigned long long)P.frameBase + (unsigned long long)nframes;
-    const bool lean = leanEnv && P.fastLean && dma == 2 && P.zeros && (P.stride0 & 3) == 0 && P.stride0 > 0 && P.stride0 < (1ll << 31) &&
+    const bool lean = leanEnv && P.fastLean && P.zeros && (P.stride0 & 3) == 0 && P.stride0 > 0 && P.stride0 < (1ll << 31) &&
                       frames * (unsigned long long)P.slabBytes < (1ull << 32) && frames * (unsigned long long)P.slotsPerFrame * 4ull < (1ull << 32) &&
-                      frames * (unsigned long long)P.ncells * 4ull < (1ull << 32) && (unsigned long long)P.stride0 * 65536ull < (1ull << 32) * 16ull;
-    if (lean && !pairs && ablate == 0)
-      hipLaunchKernelGGL((k_fast_tasks<16, false, 0, true>), grid, dim3(64), need, st, FA, 0, dma, t0, nt);
-    else if (lean && !pairs && ablate == 4) {
-      if (t0 == 0) stamp_buffer_for((size_t)(P.ntasks + 64) * nframes);
-      hipLaunchKernelGGL((k_fast_tasks<16, false, 4, true>), grid, dim3(64), need, st, FA, 0, dma, t0, nt);
-    } else if (lean && !pairs && ablate == 1)
-      hipLaunchKernelGGL((k_fast_tasks<16, false, 1, true>), grid, dim3(64), need, st, FA, 0, dma, t0, nt);
-    else if (pairs)
-      hipLaunchKernelGGL((k_fast_tasks<16, true>), grid, dim3(64), need, st, FA, 0, dma, t0, nt);
-    else if (ablate == 1)
-      hipLaunchKernelGGL((k_fast_tasks<16, false, 1>), grid, dim3(64), need, st, FA, 0, dma, t0, nt);
-    else if (ablate == 2)
-      hipLaunchKernelGGL((k_fast_tasks<16, false, 2>), grid, dim3(64), need, st, FA, 0, dma, t0, nt);
-    else if (ablate == 3)
-      hipLaunchKernelGGL((k_fast_tasks<16, false, 3>), grid, dim3(64), need, st, FA, 0, dma, t0, nt);
-    else if (ablate == 5)
-      hipLaunchKernelGGL((k_fast_tasks<16, false, 5>), grid, dim3(64), need, st, FA, 0, dma, t0, nt);
-    else if (ablate == 4) {
-      if (t0 == 0) stamp_buffer_for((size_t)(P.ntasks + 64) * nframes);
-      hipLaunchKernelGGL((k_fast_tasks<16, false, 4>), grid, dim3(64), need, st, FA, 0, dma, t0, nt);
-    } else
-      hipLaunchKernelGGL((k_fast_tasks<16, false>), grid, dim3(64), need, st, FA, 0, dma, t0, nt);
+                      frames * (unsigned long long)P.ncells * 4ull < (1ull << 32) &&
+                      (unsigned long long)P.lv[0].h * (unsigned long long)P.stride0 < (1ull << 32);
+#ifdef ORBFE_EXPERIMENTS
+    if (ablate && !pairs) {
+      if (ablate == 4 && t0 == 0) stamp_buffer_for((size_t)(P.ntasks + 64) * nframes);
+#define ORBFE_FAST_ABL(A)                                                                                              \
+  do {                                                                                                                 \
+    if (lean) hipLaunchKernelGGL((k_fast_tasks<16, false, A, true>), grid, dim3(64), need, st, FA, t0, nt);            \
+    else hipLaunchKernelGGL((k_fast_tasks<16, false, A, false>), grid, dim3(64), need, st, FA, t0, nt);                \
+  } while (0)
+      switch (ablate) {
+        case 1: ORBFE_FAST_ABL(1); break;
+        case 2: ORBFE_FAST_ABL(2); break;
+        case 3: ORBFE_FAST_ABL(3); break;
+        case 4: ORBFE_FAST_ABL(4); break;
+        default: ORBFE_FAST_ABL(5); break;
+      }
+#undef ORBFE_FAST_ABL
+      continue;
+    }
+#endif
+    if (pairs) hipLaunchKernelGGL((k_fast_tasks<16, true, 0, false>), grid, dim3(64), need, st, FA, t0, nt);
+    else if (lean) hipLaunchKernelGGL((k_fast_tasks<16, false, 0, true>), grid, dim3(64), need, st, FA, t0, nt);
+    else hipLaunchKernelGGL((k_fast_tasks<16, false, 0, false>), grid, dim3(64), need, st, FA, t0, nt);
   }
 }
 

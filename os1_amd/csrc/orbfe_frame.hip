@@ -939,7 +939,7 @@ int run_search(orbfe_matcher* m, orbfe_frame* f, const SearchPlan& P, const uint
     // that word (the end-of-kernel signal + hipStreamSynchronize's wake-up arrive microseconds later) and falls back to the
     // stream when it does not show up within 2 ms (ORBFE_FRAME_POLL=0: always the stream).
     {
-      static const bool poll = [] { const char* e = getenv("ORBFE_FRAME_POLL"); return !(e && atoi(e) == 0); }();
+      static const bool poll = [] { const char* e = ORBFE_EXP_ENV("ORBFE_FRAME_POLL"); return !(e && atoi(e) == 0); }();
       bool seen = false;
       if (poll) {
         const volatile int* done = m->h_r.p + 5;

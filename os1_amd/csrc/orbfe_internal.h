@@ -29,7 +29,6 @@ struct LevelGeom {
   const short* ybeta;      // [2*h] 11-bit weights (b0,b1)
   const unsigned* yofc;    // [h]   the two source rows of a destination row, clamped to the source: row0 | row1 << 16 (k_resize_fixed)
   int rzPitch, rzRows;     // LDS pitch / rows of the largest 64x64-tile source footprint (k_resize)
-  int rz32W, rz32H;        // width / rows of the largest 32x32-tile source footprint (k_resize_w1)
   int fastW;               // widest emit region of a FAST task on this level (2 * wCell when cells are paired, else wCell)
 };
 
@@ -101,15 +100,13 @@ struct ConeParams {
   const ConeRange* regY;            // [tilesY][kMaxLevels]
 };
 
-// Wave priority of the kernels that are NOT the long vector-issue-bound FAST launch (experiment, round 5: -DORBFE_TAIL_PRIO=1..3 makes
-// their waves win instruction arbitration on a SIMD they share with another batch's FAST waves; 0 = off, the default build)
-#ifndef ORBFE_TAIL_PRIO
-#define ORBFE_TAIL_PRIO 0
-#endif
-#if ORBFE_TAIL_PRIO
-#define ORBFE_TAIL_PRIO_SET() __builtin_amdgcn_s_setprio(ORBFE_TAIL_PRIO)
+// Measurement switches of the lab notebook (DESIGN_NOTES.md) exist only in a build with -DORBFE_EXPERIMENTS (make EXPERIMENTS=1);
+// a default build reads none of them: every environment variable the shipped library looks at is listed in DESIGN.md s4 and
+// enumerated by tests/test_switches.py.
+#ifdef ORBFE_EXPERIMENTS
+#define ORBFE_EXP_ENV(name) getenv(name)
 #else
-#define ORBFE_TAIL_PRIO_SET() ((void)0)
+#define ORBFE_EXP_ENV(name) (static_cast<const char*>(nullptr))
 #endif
 #ifdef __HIPCC__
 // Level-0 pointer of frame f, in SCALAR registers (f is uniform for a block): a lane-held base would turn every load

@@ -222,7 +222,6 @@ struct ResizeLevel {
 
 template <int LP, int RH>
 __global__ __launch_bounds__(256) void k_resize_fixed(ResizeLevel R, int tilesX, int ntiles, unsigned rcpTilesX, int dma) {
-  ORBFE_TAIL_PRIO_SET();
   __shared__ __align__(16) uint8_t rz[LP * RH];
   __shared__ __align__(16) uint16_t H[RH * 64];
   struct { int w, h, pitch; const int* xofs; const short* xalpha; const unsigned* yofc; const short* ybeta; } D = {R.dw, R.dh, R.dpitch, R.xofs, R.xalpha, R.yofc, R.ybeta};
@@ -366,121 +365,6 @@ __global__ __launch_bounds__(256) void k_resize_fixed(ResizeLevel R, int tilesX,
     const unsigned y23 = __builtin_amdgcn_perm(mulu24_hh<1, 1>(bw, q1.y), mulu24_hh<1, 0>(bw, q1.y), 0x07060302u);
     const unsigned v01 = pk_round2(x01, y01), v23 = pk_round2(x23, y23);
     *reinterpret_cast<uint32_t*>(dst + doffs) = __builtin_amdgcn_perm(v23, v01, 0x06040200u);  // pitch % 64 == 0: in bounds
-    doffs += (unsigned)D.pitch;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_resize_w1 (round 5): the same resize with ONE WAVE per workgroup -- a 32x32 output tile, 4.7 KB of LDS.  Why: a batch's pyramid runs
-// beside another batch's FAST launch, whose 400 000 single-wave workgroups (5 KB of LDS each) take every wave slot and every kilobyte of
-// LDS the moment it frees up; a 256-thread tile block that needs four slots and 18 KB on ONE CU at the same instant waits until that
-// launch has run dry (the seven resize launches of a batch take 770 us in the pipeline, 269 us alone, and the next FAST launch cannot
-// start before they are done).  A one-wave workgroup of FAST's own footprint competes on equal terms.  Arithmetic, tables and staging
-// as in k_resize_fixed (footprint by 16-byte LDS-DMA pieces: 3 per 48-byte tile row, 21 rows per instruction); the smaller tile
-// re-reads 1.6x instead of 1.5x the level and runs the row pass over 42 instead of 40 rows per 32 output rows.
-// ------------------------------------------------------------------------------------------------
-constexpr int kRz1Tile = 32, kRz1LP = 48, kRz1RH = 42;
-
-__global__ __launch_bounds__(64) void k_resize_w1(ResizeLevel R, int tilesX, int ntiles, unsigned rcpTilesX) {
-  __shared__ __align__(16) uint8_t rz[kRz1LP * kRz1RH];
-  __shared__ __align__(16) uint16_t H[kRz1RH * kRz1Tile];
-  struct { int w, h, pitch; const int* xofs; const short* xalpha; const unsigned* yofc; const short* ybeta; } D = {R.dw, R.dh, R.dpitch, R.xofs, R.xalpha, R.yofc, R.ybeta};
-  struct { int w, h; } S = {R.sw, R.sh};
-  const int f = R.frameBase + blockIdx.y;
-  const int chunk = (ntiles + 7) >> 3;
-  const int tileIx = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-  if (tileIx >= ntiles) return;
-  const int tyI = (int)(((unsigned long long)(unsigned)tileIx * rcpTilesX) >> 32);   // tileIx / tilesX (exact: host-checked range)
-  const int tx0 = (tileIx - tyI * tilesX) * kRz1Tile, ty0 = tyI * kRz1Tile;
-  const int tx1 = min(tx0 + kRz1Tile, D.w) - 1, ty1 = min(ty0 + kRz1Tile, D.h) - 1;
-  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-  u32x2 fpw = {0u, 0u};
-  if (R.fromLevel0) {
-    if (R.frame0) {
-      fpw = *reinterpret_cast<const u32x2 __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(R.frame0 + f));
-    } else {
-      const unsigned long long v = reinterpret_cast<unsigned long long>((f & 1) ? R.frameInline[1] : R.frameInline[0]);
-      fpw.x = (uint32_t)v;
-      fpw.y = (uint32_t)(v >> 32);
-    }
-  }
-  const int cxa = *reinterpret_cast<const int __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(D.xofs + tx0));
-  const int cxb = *reinterpret_cast<const int __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(D.xofs + tx1));
-  const unsigned cya = *reinterpret_cast<const unsigned __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(D.yofc + ty0));
-  const unsigned cyb = *reinterpret_cast<const unsigned __attribute__((address_space(4)))*>(reinterpret_cast<uintptr_t>(D.yofc + ty1));
-  const int lane = threadIdx.x;
-  const int hc = lane & 31;
-  const int hx = min(tx0 + hc, D.w - 1);
-  const int hsx = ld32(D.xofs, (unsigned)hx << 2);
-  const int hal = ld32(D.xalpha, (unsigned)hx << 2);
-  const int cx = tx0 + (lane & 7) * 4, cy = ty0 + (lane >> 3) * 4;
-  const int4 syq = *reinterpret_cast<const int4*>(reinterpret_cast<const char*>(D.yofc) + ((unsigned)cy << 2));
-  const int4 beq = *reinterpret_cast<const int4*>(reinterpret_cast<const char*>(D.ybeta) + ((unsigned)cy << 2));
-  const int syv[4] = {syq.x, syq.y, syq.z, syq.w}, be[4] = {beq.x, beq.y, beq.z, beq.w};
-  asm volatile("" ::"s"(cxa), "s"(cxb), "s"(cya), "s"(cyb), "s"(fpw.x), "s"(fpw.y));   // everything above is requested before the first wait
-  const uint8_t* src;
-  const long long sstride = R.sstride;
-  if (R.fromLevel0) src = reinterpret_cast<const uint8_t*>(((unsigned long long)fpw.y << 32) | fpw.x);
-  else src = R.slab + (long long)f * R.slabBytes + R.soff;
-  const int rx0 = cxa, rx1 = min(cxb + 1, S.w - 1);
-  const int ry0 = (int)(cya & 0xffffu), ry1 = (int)(cyb >> 16);
-  const int rw = rx1 - rx0 + 1, rh = ry1 - ry0 + 1;
-  const int istr = (int)sstride;
-  const uint8_t* rbase = uniform_ptr(src + (long long)ry0 * sstride + rx0);
-  const int a = (int)(reinterpret_cast<uintptr_t>(rbase) & 3);
-  {
-    // (the launcher has checked: row strides are multiples of 4, a + rw <= 48, rh <= 42)
-    const uint8_t* gb = rbase - a;
-    const int lrow = (int)(((unsigned)lane * 171u) >> 9), lcol = lane - lrow * 3;   // lane / 3 for lane < 64
-    const bool lastSpecial = R.fromLevel0 && ry1 == S.h - 1;   // a 16-byte piece may reach past the end of a caller-owned frame's last row
-    const int rhDma = lastSpecial ? rh - 1 : rh;
-    const bool on = lrow < 21 && 16 * lcol < a + rw;
-    const unsigned voff = (unsigned)(m24(lrow, istr) + 16 * lcol);
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-      const int r = u * 21;
-      const uint8_t* gbr = gb + (long long)r * sstride;
-      unsigned vo = voff;
-      asm volatile("" : "+s"(gbr), "+v"(vo));
-      if (on && r + lrow < rhDma)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbr + vo),
-                                         (__attribute__((address_space(3))) void*)(rz + r * kRz1LP), 16, 0, 0);
-    }
-    if (lastSpecial && lane < ((a + rw + 3) >> 2))
-      *reinterpret_cast<uint32_t*>(rz + (rh - 1) * kRz1LP + 4 * lane) = (uint32_t)ld32(gb, (unsigned)(4 * lane + m24(rh - 1, istr)));
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // one wave: its LDS operations execute in order, no barrier
-  }
-  // ---- row pass: 21 rows per half-wave (rows past the footprint hold stale bytes nobody reads the H of) ----
-  {
-    const unsigned a0 = (unsigned)(int)(short)hal << 12, a1 = (unsigned)(hal >> 16) << 12;
-    const int o0 = a + hsx - rx0, o1 = a + min(hsx + 1, S.w - 1) - rx0;
-    const uint8_t* p0 = rz + (lane >> 5) * kRz1LP + o0;
-    const uint8_t* p1 = rz + (lane >> 5) * kRz1LP + o1;
-    uint16_t* h = H + (lane >> 5) * kRz1Tile + hc;
-#pragma unroll
-    for (int i = 0; i < kRz1RH / 2; i++)
-      h[i * 2 * kRz1Tile] = (uint16_t)((__umul24(p0[i * 2 * kRz1LP], a0) + __umul24(p1[i * 2 * kRz1LP], a1)) >> 16);
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  // ---- column pass ----
-  if (cx > tx1 || cy > ty1) return;
-  uint8_t* dst = R.slab + (long long)f * R.slabBytes + R.doff;
-  unsigned doffs = (unsigned)(m24(cy, D.pitch) + cx);
-  const unsigned hx2 = (unsigned)(cx - tx0) * 2u, ry0s = (unsigned)ry0 << 6;
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int y = cy + j;
-    if (y > ty1) break;
-    const unsigned r0 = ((unsigned)syv[j] & 0xffffu) << 6, r1 = ((unsigned)syv[j] >> 16) << 6;   // H rows are 64 bytes here
-    const uint8_t* hb = reinterpret_cast<const uint8_t*>(H) + hx2 - ry0s;
-    const uint2 q0 = *reinterpret_cast<const uint2*>(hb + r0), q1 = *reinterpret_cast<const uint2*>(hb + r1);
-    const unsigned bw = (unsigned)be[j];
-    const unsigned x01 = __builtin_amdgcn_perm(mulu24_hh<0, 1>(bw, q0.x), mulu24_hh<0, 0>(bw, q0.x), 0x07060302u);
-    const unsigned y01 = __builtin_amdgcn_perm(mulu24_hh<1, 1>(bw, q1.x), mulu24_hh<1, 0>(bw, q1.x), 0x07060302u);
-    const unsigned x23 = __builtin_amdgcn_perm(mulu24_hh<0, 1>(bw, q0.y), mulu24_hh<0, 0>(bw, q0.y), 0x07060302u);
-    const unsigned y23 = __builtin_amdgcn_perm(mulu24_hh<1, 1>(bw, q1.y), mulu24_hh<1, 0>(bw, q1.y), 0x07060302u);
-    const unsigned v01 = pk_round2(x01, y01), v23 = pk_round2(x23, y23);
-    *reinterpret_cast<uint32_t*>(dst + doffs) = __builtin_amdgcn_perm(v23, v01, 0x06040200u);
     doffs += (unsigned)D.pitch;
   }
 }
@@ -708,7 +592,6 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
 }
 
 __global__ __launch_bounds__(64) void k_compact(PyramidParams P) {
-  ORBFE_TAIL_PRIO_SET();
   const int cell0 = blockIdx.x * 64, lane = threadIdx.x, f = P.frameBase + blockIdx.y;
   const uint32_t* cnt = P.cellCount + (long long)f * P.ncells;
   const int cell = cell0 + lane;
@@ -994,7 +877,6 @@ struct DescribeArgs {
 // (one- and two-frame calls: a keypoint's 760 dependent-ish instructions are the latency of the whole kernel there).
 template <int WAVES, int GAUSS>
 __global__ __launch_bounds__(64 * WAVES) void k_describe(DescribeArgs A) {
-  ORBFE_TAIL_PRIO_SET();
   constexpr int NT = 64 * WAVES;
   // Every table a lane will need depends on its lane number only: ALL of them are requested here, before the first wait of
   // the kernel, instead of one dependent round trip per pass iteration (4 + 6 + 5 of them for one wave) -- round 4.
@@ -1355,6 +1237,14 @@ void launch_to_gray(const uint8_t* const* raw, long long rawStride, const uint8_
 // ------------------------------------------------------------------------------------------------
 // Launchers (called by the host engine).
 // ------------------------------------------------------------------------------------------------
+// ORBFE_LDS_DMA=0 sends the pyramid footprints and the descriptor patches through registers instead of LDS-DMA: the route a
+// frame's last row and strides that are not multiples of 4 take anyway, forced everywhere (tests/test_gpu_parity.py runs it in a
+// process of its own).
+static int lds_dma_enabled() {
+  static const int v = [] { const char* e = getenv("ORBFE_LDS_DMA"); return e ? (atoi(e) != 0 ? 1 : 0) : 1; }();
+  return v;
+}
+
 // ---- k_ingest: a page-locked HOST frame -> its device copy, by a kernel on the compute stream ---------------------------------
 // The one-frame call of Frame.cc:133 hands over a host cv::Mat.  A copy command on the upload lane followed by an event the compute
 // stream waits for costs the copy (43 us for 2 MB) plus 18.5 us between the copy's end and the first kernel's start (two queues, one
@@ -1398,11 +1288,11 @@ __global__ __launch_bounds__(256) void k_ingest(const uint8_t* __restrict__ src,
 void launch_ingest(const uint8_t* src, long long sstride, uint8_t* dst, long long dpitch, int rowBytes, int rows, hipStream_t st) {
   const uintptr_t all = (uintptr_t)src | (uintptr_t)dst | (uintptr_t)sstride | (uintptr_t)dpitch | (uintptr_t)rowBytes;
   const int V = (all & 15) == 0 ? 16 : (all & 3) == 0 ? 4 : 1;
-  static const int U = [] { const char* e = getenv("ORBFE_INGEST_U"); return e ? atoi(e) : 4; }();   // requests in flight per lane (A/B)
+  constexpr int U = 4;   // requests in flight per lane (1 / 2 / 4 / 8 measured: 0.157 / 0.156 / 0.149 / 0.149 ms per call)
   const long long total = (long long)((rowBytes + V - 1) / V) * rows;
   const int blocks = (int)std::max<long long>(1, (total + 256 * U - 1) / (256 * U));
 #define ORBFE_INGEST(VV, UU) hipLaunchKernelGGL((k_ingest<VV, UU>), dim3(blocks), dim3(256), 0, st, src, sstride, dst, dpitch, rowBytes, rows)
-  if (V == 16) { if (U == 2) ORBFE_INGEST(16, 2); else if (U == 8) ORBFE_INGEST(16, 8); else if (U == 1) ORBFE_INGEST(16, 1); else ORBFE_INGEST(16, 4); }
+  if (V == 16) ORBFE_INGEST(16, 4);
   else if (V == 4) ORBFE_INGEST(4, 4);
   else ORBFE_INGEST(1, 4);
 #undef ORBFE_INGEST
@@ -1423,26 +1313,7 @@ int launch_pyramid(const PyramidParams& P, int nframes, hipStream_t st, const Co
       attrBytes[dev] = cone->ldsBytes;
     }
   }
-  static const int wave1 = [] { const char* e = getenv("ORBFE_RESIZE_WAVE"); return e ? atoi(e) : 0; }();   // 1: one-wave tiles for batches (k_resize_w1)
   for (int l = 1; l <= last; l++) {
-    if (wave1 && !cone && nframes > 2) {
-      const int tilesX = (P.lv[l].w + kRz1Tile - 1) / kRz1Tile, tilesY = (P.lv[l].h + kRz1Tile - 1) / kRz1Tile, ntiles = tilesX * tilesY;
-      const long long sstride = l == 1 ? P.stride0 : (long long)P.lv[l - 1].pitch;
-      if (P.lv[l].rz32W + 3 <= kRz1LP && P.lv[l].rz32H <= kRz1RH && tilesX >= 2 && (sstride & 3) == 0 && sstride < (1ll << 31) &&
-          (unsigned long long)ntiles * tilesX < (1ull << 31)) {
-        const unsigned rcp = (unsigned)(0x100000000ull / (unsigned)tilesX) + 1u;
-        ResizeLevel R{};
-        R.dw = P.lv[l].w; R.dh = P.lv[l].h; R.dpitch = P.lv[l].pitch;
-        R.sw = P.lv[l - 1].w; R.sh = P.lv[l - 1].h;
-        R.sstride = sstride;
-        R.doff = P.lv[l].off; R.soff = P.lv[l - 1].off;
-        R.xofs = P.lv[l].xofs; R.xalpha = P.lv[l].xalpha; R.yofc = P.lv[l].yofc; R.ybeta = P.lv[l].ybeta;
-        R.frame0 = P.frame0; R.frameInline[0] = P.frameInline[0]; R.frameInline[1] = P.frameInline[1];
-        R.slab = P.slab; R.slabBytes = P.slabBytes; R.frameBase = P.frameBase; R.fromLevel0 = l == 1;
-        hipLaunchKernelGGL(k_resize_w1, dim3(8 * ((ntiles + 7) / 8), nframes), dim3(64), 0, st, R, tilesX, ntiles, rcp);
-        continue;
-      }
-    }
     dim3 grid((P.lv[l].w + kRzTile - 1) / kRzTile, (P.lv[l].h + kRzTile - 1) / kRzTile, nframes);
     // (tilesX == 1 -- a level at most 64 px wide -- takes the generic kernel: 2^32 / 1 + 1 wraps to rcp = 1 and the multiply-high
     // below would return row 0 for every tile; exact only for tilesX >= 2)
@@ -1450,7 +1321,7 @@ int launch_pyramid(const PyramidParams& P, int nframes, hipStream_t st, const Co
       const int tilesX = (int)grid.x, ntiles = (int)(grid.x * grid.y);
       const unsigned rcp = (unsigned)(0x100000000ull / (unsigned)tilesX) + 1u;   // floor(t * rcp / 2^32) = t / tilesX for t * tilesX < 2^32
       if ((unsigned long long)ntiles * tilesX < (1ull << 31)) {
-        static const int dma = [] { const char* e = getenv("ORBFE_RESIZE_DMA"); return e ? atoi(e) : 1; }();   // 0: staging through registers (A/B)
+        const int dma = lds_dma_enabled();
         ResizeLevel R{};
         R.dw = P.lv[l].w; R.dh = P.lv[l].h; R.dpitch = P.lv[l].pitch;
         R.sw = P.lv[l - 1].w; R.sh = P.lv[l - 1].h;
@@ -1475,10 +1346,6 @@ void launch_compact(const PyramidParams& P, int nframes, hipStream_t st) {
   hipLaunchKernelGGL(k_compact, dim3((P.ncells + 63) / 64, nframes), dim3(64), 0, st, P);
 }
 
-static int describe_dma() {   // ORBFE_DESCRIBE_DMA=0: the raw patch staged through registers (A/B)
-  static const int v = [] { const char* e = getenv("ORBFE_DESCRIBE_DMA"); return e ? atoi(e) : 1; }();
-  return v;
-}
 
 static DescribeArgs describe_args(const PyramidParams& P, const SelKp* sel, int nsel, float* angle, uint8_t* desc) {
   DescribeArgs A{};
@@ -1488,7 +1355,7 @@ static DescribeArgs describe_args(const PyramidParams& P, const SelKp* sel, int 
   A.sel = sel; A.selCount = nullptr; A.angleOut = angle; A.descOut = desc;
   A.frame0 = P.frame0; A.frameInline[0] = P.frameInline[0]; A.frameInline[1] = P.frameInline[1];
   A.stride0 = P.stride0; A.slab = P.slab; A.slabBytes = P.slabBytes;
-  A.nsel = nsel; A.selPerFrame = 1; A.nlevels = P.nlevels; A.frameBase = P.frameBase; A.dma = describe_dma();
+  A.nsel = nsel; A.selPerFrame = 1; A.nlevels = P.nlevels; A.frameBase = P.frameBase; A.dma = lds_dma_enabled();
   A.gauss = P.gaussVariant;
   return A;
 }

@@ -5,6 +5,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "orbfe_internal.h"
+
 #include <algorithm>
 #include <chrono>
 #include <climits>
@@ -643,8 +645,8 @@ struct orbfe_matcher {
     });
     const double tB = nowMs();
     stageMs[0] = tB - tA;
-    // ORBFE_MATCH_ZEROCOPY=1: the kernel reads the pinned host arena directly over PCIe instead of a DMA upload
-    static const bool zeroCopy = getenv("ORBFE_MATCH_ZEROCOPY") && atoi(getenv("ORBFE_MATCH_ZEROCOPY")) != 0;
+    // (experiments build, ORBFE_MATCH_ZEROCOPY=1: the kernel reads the pinned host arena directly over PCIe instead of a DMA upload)
+    static const bool zeroCopy = ORBFE_EXP_ENV("ORBFE_MATCH_ZEROCOPY") && atoi(ORBFE_EXP_ENV("ORBFE_MATCH_ZEROCOPY")) != 0;
     if (!zeroCopy) HIP_TRY(hipMemcpyAsync(d_in.p, H, total, hipMemcpyHostToDevice, stream));
 
     const size_t outWords = 64 + 2 * nq;

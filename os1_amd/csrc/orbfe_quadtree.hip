@@ -626,7 +626,6 @@ __device__ __forceinline__ void qt3_problem(const QtParams& Q, Qt3Shared<CAP>& s
 
 template <int CAP>
 __global__ __launch_bounds__(kQt3Threads) void k_quadtree3(QtParams Q, int ldsCand) {
-  ORBFE_TAIL_PRIO_SET();
   __shared__ Qt3Shared<CAP> sh;
   extern __shared__ __align__(16) uint32_t qtDyn[];   // [ldsCand] candidate words, then [ldsCand] u16 node ids
   const uint32_t* ls = Q.levelStart + (long long)(Q.frameBase + blockIdx.y) * (kMaxLevels + 1);

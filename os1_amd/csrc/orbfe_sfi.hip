@@ -51,7 +51,6 @@ __device__ __forceinline__ SfiFrame sfi_frame(const SfiParams& S, int f) {
 
 // ---- per frame: candidate enumeration order -------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_sfi_sort(SfiParams S) {
-  ORBFE_TAIL_PRIO_SET();
   // counting sort by grid cell; inside a cell by keypoint index (the order mGrid's vectors were filled in)
   constexpr int kCells = kSfiGridCols * kSfiGridRows, kPer = kCells / 256;
   static_assert(kCells % 256 == 0, "cells per thread");
@@ -111,7 +110,6 @@ __global__ __launch_bounds__(256) void k_sfi_sort(SfiParams S) {
 
 // ---- per (pair, query): ordered candidate list with distances -------------------------------------------------
 __global__ __launch_bounds__(64) void k_sfi_candidates(SfiParams S) {
-  ORBFE_TAIL_PRIO_SET();
   const int i1 = blockIdx.x, fr = blockIdx.y, lane = threadIdx.x;
   const int f = S.frameBase + fr;
   const SfiFrame F2 = sfi_frame(S, f);
@@ -358,7 +356,6 @@ __device__ void sfi_serial_outcomes(int lane, int n1, const int* pcnt, PoolAt po
 
 template <int kSfiThreads>
 __global__ __launch_bounds__(kSfiThreads) void k_sfi_resolve(SfiParams S, int ldsPool, int maxRounds) {
-  ORBFE_TAIL_PRIO_SET();
   extern __shared__ int sm[];
   const int fr = blockIdx.x, tid = threadIdx.x;
   const unsigned long long tStart = g_sfiDbg ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -538,7 +535,7 @@ static void sfi_debug_setup() {
   static bool done = false;
   if (done) return;
   done = true;
-  if (!getenv("ORBFE_SFI_DEBUG")) return;
+  if (!ORBFE_EXP_ENV("ORBFE_SFI_DEBUG")) return;
   if (hipMalloc((void**)&s_sfiDbg, sizeof(int) * (8 + 8 * kSfiDbgRecords)) != hipSuccess) { s_sfiDbg = nullptr; return; }
   (void)hipMemset(s_sfiDbg, 0, sizeof(int) * (8 + 8 * kSfiDbgRecords));
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sfiDbg), &s_sfiDbg, sizeof s_sfiDbg);
@@ -585,13 +582,13 @@ void launch_sfi(const SfiParams& S, int nframes, hipStream_t st) {
   const int fixedWords = 6 * S.n0cap + 1 + 32 + 2;
   int ldsPool = (60 * 1024 / 4) - fixedWords;   // candidate entries kept in LDS; longer pools are read from HBM
   if (ldsPool > 8192) ldsPool = 8192;
-  if (const char* e = getenv("ORBFE_SFI_LDS_POOL")) ldsPool = std::min(ldsPool, std::max(0, atoi(e)));
+  if (const char* e = ORBFE_EXP_ENV("ORBFE_SFI_LDS_POOL")) ldsPool = std::min(ldsPool, std::max(0, atoi(e)));
   if (ldsPool < 0) ldsPool = 0;
   // rounds of the fixed point before the kernel finishes with one serial pass on the device (typical inputs settle in
   // 3-6 rounds; a round costs O(queries x candidates x takers), so a cap keeps adversarial steal chains bounded)
   int maxRounds = 32;
   if (const char* e = getenv("ORBFE_SFI_MAX_ROUNDS")) maxRounds = atoi(e) < 1 ? 1 : atoi(e);
-  static const int threads = [] { const char* e = getenv("ORBFE_SFI_THREADS"); return e ? atoi(e) : 512; }();
+  static const int threads = [] { const char* e = ORBFE_EXP_ENV("ORBFE_SFI_THREADS"); return e ? atoi(e) : 512; }();
   if (threads == 256)
     hipLaunchKernelGGL(k_sfi_resolve<256>, dim3(nframes), dim3(256), sizeof(int) * (fixedWords + ldsPool), st, S, ldsPool, maxRounds);
   else

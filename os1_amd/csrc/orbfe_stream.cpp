@@ -151,38 +151,6 @@ struct orbfe_stream {
       const int slot = inflight.front().first, e = inflight.front().second;
       inflight.pop_front();
       Slot& s = slots[slot];
-      if (s.status == ORBFE_OK && (int)ext.size() > depth) {
-        // The GPU is done with the oldest batch: BEFORE its results are assembled on the host (0.25 ms for 64 frames), the next queued
-        // batch goes out on the spare handle, so that `depth` batches stay on the GPU while this thread copies (round 5).
-        const double tw = nowMs();
-        (void)orbfe_extract_batch_wait(ext[e]);
-        int job2 = -1;
-        {
-          std::lock_guard<std::mutex> lk(mu);
-          busyCollect += nowMs() - tw;
-          if (!stop && !extractQ.empty() && (int)inflight.size() < depth) {
-            job2 = extractQ.front();
-            extractQ.pop_front();
-          }
-        }
-        if (job2 >= 0) {
-          Slot& s2 = slots[job2];
-          orbfe_extractor* h2 = ext[nextExt];
-          const double ta2 = nowMs();
-          if (gpuMatch && s2.window > 0)
-            s2.status = orbfe_extract_batch_submit_matched(h2, chain, batch, s2.frames.data(), s2.onDevice, s2.rows, s2.cols, s2.stride,
-                                                           s2.bounds, s2.window, s2.nnratio, s2.checkOri);
-          else
-            s2.status = orbfe_extract_batch_submit(h2, batch, s2.frames.data(), s2.onDevice, s2.rows, s2.cols, s2.stride);
-          {
-            std::lock_guard<std::mutex> lk(mu);
-            busySubmit += nowMs() - ta2;
-          }
-          if (s2.status != ORBFE_OK) s2.err = orbfe_last_error();
-          inflight.emplace_back(job2, nextExt);
-          nextExt = (nextExt + 1) % (int)ext.size();
-        }
-      }
       if (s.status == ORBFE_OK) {
         const double ta = nowMs();
         if (gpuMatch && s.window > 0)
@@ -319,11 +287,8 @@ int orbfe_stream_create(int nfeatures, float scaleFactor, int nlevels, int iniTh
   s->batch = batch;
   s->depth = depth;
   s->device = device_id;
-  // depth handles for the batches on the GPU.  ORBFE_STREAM_SPARE_HANDLE=1 (experiment, round 5) adds a spare one: the batch whose results
-  // are being assembled on the host keeps its handle (its page-locked result arena) while the next batch is already submitted, so that
-  // `depth` batches are on the GPU at every moment -- measured SLOWER (84.5 k against 92.0 k frames/s at depth 4: the assembly gap is a
-  // throttle the pipeline wants, DESIGN_NOTES.md E.5), hence off.
-  const int nhandles = depth + ((getenv("ORBFE_STREAM_SPARE_HANDLE") && atoi(getenv("ORBFE_STREAM_SPARE_HANDLE")) == 1) ? 1 : 0);
+  // depth handles for the batches on the GPU (a spare one for the batch being assembled on the host measured slower: DESIGN_NOTES.md E.5)
+  const int nhandles = depth;
   for (int d = 0; d < nhandles; d++) {
     orbfe_extractor* h = nullptr;
     int rc = orbfe_extractor_create(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device_id, &h);
@@ -341,7 +306,6 @@ int orbfe_stream_create(int nfeatures, float scaleFactor, int nlevels, int iniTh
   int nMatch = 0;
   if (!s->gpuMatch) {
     nMatch = 2;
-    if (const char* ev = getenv("ORBFE_MATCH_WORKERS")) nMatch = std::max(1, std::min(4, atoi(ev)));
   }
   for (int w = 0; w < nMatch; w++) {
     orbfe_matcher* mm = nullptr;
@@ -367,9 +331,7 @@ int orbfe_stream_create(int nfeatures, float scaleFactor, int nlevels, int iniTh
   // result slots: `depth` batches on the GPU, one in the caller's hands, a few queued in front of the worker.  A caller
   // whose own thread can be held up for milliseconds (bench.py's Python driver) asks for a deeper queue with
   // orbfe_stream_set_queue_slots; a slot is host memory only (4 MB at 1080p / 2000 features / 32 frames).
-  int nslots = depth + 4;
-  if (const char* sv = getenv("ORBFE_STREAM_SLOTS")) nslots = std::max(depth + 2, atoi(sv));
-  s->growSlots(nslots);
+  s->growSlots(depth + 4);
   s->tExtract = std::thread([s] { pthread_setname_np(pthread_self(), "orbfe-runner"); s->extractLoop(); });
   for (int w = 0; w < nMatch; w++) s->tMatch.emplace_back([s, w] { pthread_setname_np(pthread_self(), "orbfe-match"); s->matchLoop(w); });
   *out = s;

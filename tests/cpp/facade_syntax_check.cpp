@@ -8,10 +8,11 @@
 
 using namespace ORB_SLAM2;
 
-// The facade reproduces the GaussianBlur of the OpenCV it is compiled against (ORBextractor.cc:950): the test compiles this file
-// once per release named on the command line (-DCV_VERSION_MAJOR=.. -DEXPECT_GAUSS=..).
+// With -DORBFE_FACADE_GAUSS_BY_CV_VERSION the facade reproduces the GaussianBlur of the OpenCV it is compiled against
+// (ORBextractor.cc:950), otherwise the error-diffused taps: the test compiles this file once per release named on the command line
+// (-DCV_VERSION_MAJOR=.. -DEXPECT_GAUSS=..), with and without the opt-in.
 #ifdef EXPECT_GAUSS
-static_assert(ORBFE_FACADE_GAUSS_VARIANT == EXPECT_GAUSS, "blur variant chosen from CV_VERSION_*");
+static_assert(ORBFE_FACADE_GAUSS_VARIANT == EXPECT_GAUSS, "blur variant: error-diffused unless chosen from CV_VERSION_* by opt-in");
 #else
 static_assert(ORBFE_FACADE_GAUSS_VARIANT == ORBFE_GAUSS_ED, "no version macros: the default");
 #endif

@@ -135,12 +135,15 @@ def test_cv_facades_type_check_against_stub_headers():
            os.path.join(ROOT, 'tests', 'cpp', 'facade_syntax_check.cpp')]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
-    # the facade picks the GaussianBlur variant of the OpenCV it is compiled against (orbfe.h: ORBFE_GAUSS_ROUNDED for 4.0.0 - 4.1.0
-    # and 3.4.2 - 3.4.6, ORBFE_GAUSS_ED otherwise): a static_assert in the test file checks the choice for each release
+    # the facade reproduces the error-diffused GaussianBlur taps by default; with -DORBFE_FACADE_GAUSS_BY_CV_VERSION it picks the
+    # variant of the OpenCV it is compiled against (orbfe.h: ORBFE_GAUSS_ROUNDED for 4.0.0 - 4.1.0 and 3.4.2 - 3.4.6, ORBFE_GAUSS_ED
+    # otherwise): a static_assert in the test file checks the choice for each release, with and without the opt-in
     for ver, want in [((4, 0, 1), 1), ((4, 1, 0), 1), ((4, 1, 1), 0), ((4, 5, 4), 0), ((3, 4, 6), 1), ((3, 4, 7), 0), ((3, 4, 1), 0)]:
-        defs = ['-DCV_VERSION_MAJOR=%d' % ver[0], '-DCV_VERSION_MINOR=%d' % ver[1], '-DCV_VERSION_REVISION=%d' % ver[2], '-DEXPECT_GAUSS=%d' % want]
-        r = subprocess.run(cmd[:-1] + defs + cmd[-1:], capture_output=True, text=True)
-        assert r.returncode == 0, (ver, r.stderr[-2000:])
+        vdefs = ['-DCV_VERSION_MAJOR=%d' % ver[0], '-DCV_VERSION_MINOR=%d' % ver[1], '-DCV_VERSION_REVISION=%d' % ver[2]]
+        for optin, expect in ((True, want), (False, 0)):
+            defs = vdefs + ['-DEXPECT_GAUSS=%d' % expect] + (['-DORBFE_FACADE_GAUSS_BY_CV_VERSION'] if optin else [])
+            r = subprocess.run(cmd[:-1] + defs + cmd[-1:], capture_output=True, text=True)
+            assert r.returncode == 0, (ver, optin, r.stderr[-2000:])
     stub = open(os.path.join(ROOT, 'tests', 'cpp', 'opencv_stub', 'opencv2', 'core', 'core.hpp')).read().splitlines()
     assert len(stub) <= 100          # a declaration-level stand-in, not an OpenCV substitute
 

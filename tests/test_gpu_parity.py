@@ -653,13 +653,13 @@ def test_fast_cell_pairs_variant_bit_exact(api, oracle, monkeypatch):
 def test_latency_path_variants_agree(api, oracle, monkeypatch):
     """One- and two-frame calls take their own kernels (k_pyramid_cone, LDS-resident quadtree candidates, results written
     straight to the host arena, level-0 pointers in the kernel arguments).  Every switch of that path, alone and
-    together, reproduces the oracle: cone tile sizes, the per-level pyramid kernels, candidates in HBM, the copied
+    together, reproduces the oracle: the per-level pyramid kernels, candidates in HBM, the copied
     result arena, page-locked host frames fetched by the compute stream's own kernel (k_ingest: widths that are multiples of 16, of 4,
     and odd ones that go through the copy engine) or by a copy command (ORBFE_INGEST_KERNEL=0)."""
     cases = [(31, 1920, 1080, 2000, 1.2, 8), (32, 641, 479, 700, 1.2, 8), (33, 1280, 720, 1200, 1.3, 5), (34, 500, 400, 300, 1.5, 3),
              (35, 900, 500, 400, 2.0, 3)]      # scale 2.0: outside the cone kernel's range, per-level kernels by themselves
-    settings = [{}, {'ORBFE_CONE_MAX_FRAMES': '0'}, {'ORBFE_QT_LDS_BYTES': '0'}, {'ORBFE_ZERO_COPY': '0'}, {'ORBFE_DESCRIBE_WAVES': '1'}, {'ORBFE_QT_JUMP': '0'}, {'ORBFE_CONE_TILE': '16'},
-                {'ORBFE_CONE_TILE': '48'}, {'ORBFE_QT_LDS_BYTES': '20000'}, {'ORBFE_INGEST_KERNEL': '0'},
+    settings = [{}, {'ORBFE_CONE_MAX_FRAMES': '0'}, {'ORBFE_QT_LDS_BYTES': '0'}, {'ORBFE_ZERO_COPY': '0'}, {'ORBFE_QT_JUMP': '0'},
+                {'ORBFE_QT_LDS_BYTES': '20000'}, {'ORBFE_INGEST_KERNEL': '0'},
                 {'ORBFE_CONE_MAX_FRAMES': '0', 'ORBFE_QT_LDS_BYTES': '0', 'ORBFE_ZERO_COPY': '0'}]
     for seed, W, H, N, sf, nl in cases:
         img = synth(seed, W, H)
@@ -685,6 +685,29 @@ def test_latency_path_variants_agree(api, oracle, monkeypatch):
             pin.free()
             for k in env:
                 monkeypatch.delenv(k)
+
+
+def test_mixed_pinned_and_pageable_frames(api, oracle):
+    """A two-frame host call (the stereo shape of Frame.cc:131-134) whose frames live in different kinds of memory: one page-locked,
+    one pageable, in either order -- and a page-locked frame whose rows run past the end of the allocation's mapping would be the
+    same case.  The ingest kernel reads a frame in place only when EVERY frame of the call is mapped for the GPU over its whole
+    extent; otherwise the whole call goes through the copy route (round-5 advice: the check used to look at frame 0 only and the
+    kernel then read unmapped pageable memory)."""
+    W, H, N = 1280, 720, 1200
+    a = synth(61, W, H)
+    b = shifted(a, 4, 2, 62)
+    ox = OracleExtractor(N, 1.2, 8, 20, 7, oracle)
+    wa, wb = ox.extract(a), ox.extract(b)
+    ex = api.Extractor(N, 1.2, 8, 20, 7)
+    pin = api.PinnedFrames([a, b])
+    pa, pb = np.ascontiguousarray(a.copy()), np.ascontiguousarray(b.copy())     # pageable copies
+    for ptrs, want in (([pin.ptrs[0], pb.ctypes.data], (wa, wb)), ([pa.ctypes.data, pin.ptrs[1]], (wa, wb)),
+                       ([pb.ctypes.data, pin.ptrs[0]], (wb, wa)), ([pin.ptrs[0], pin.ptrs[1]], (wa, wb))):
+        for rep in range(2):
+            kps, desc, n = ex.extract_batch_ptrs(ptrs, H, W, W, False)
+            _cmp_extract((kps[0, :n[0]], desc[0, :n[0]]), want[0])
+            _cmp_extract((kps[1, :n[1]], desc[1, :n[1]]), want[1])
+    pin.free()
 
 
 def test_submit_wait_collect_on_two_handles(api, oracle):
@@ -839,14 +862,60 @@ print('OK')
 '''
 
 
-@pytest.mark.parametrize('env', [{'ORBFE_FAST_DMA': '0'}, {'ORBFE_FAST_DMA': '1'}, {'ORBFE_DESCRIBE_DMA': '0'}, {'ORBFE_RESIZE_DMA': '0'},
-                                 {'ORBFE_FAST_LDS_CLASSES': '0'}, {'ORBFE_FAST_DMA': '0', 'ORBFE_DESCRIBE_DMA': '0', 'ORBFE_RESIZE_DMA': '0'},
-                                 {'ORBFE_FAST_LEAN': '0'}, {'ORBFE_RESIZE_WAVE': '1'}])
+_ENV_PRESET_SCRIPT = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+from os1_amd import api
+from os1_amd.synth import synth, shifted
+from oracle.pyoracle import Oracle, OracleExtractor
+o = Oracle()
+variant = int(os.environ.get('ORBFE_GAUSS_VARIANT', '0'))
+img = synth(81, 960, 540)
+imgs = [img, shifted(img, 3, 2, 82), shifted(img, 6, 4, 83)]
+ox = OracleExtractor(900, 1.2, 8, 20, 7, o)
+ox.set_gauss_variant(variant)
+want = [ox.extract(im) for im in imgs]
+ex = api.Extractor(900, 1.2, 8, 20, 7)          # reads ORBFE_GAUSS_VARIANT / ORBFE_POLL_WAIT_US when it is created
+for im, (wk, wd) in zip(imgs, want):
+    gk, gd = ex(im)
+    assert gk.tobytes() == wk.tobytes() and gd.tobytes() == wd.tobytes()
+for (gk, gd), (wk, wd) in zip(ex.extract_batch(imgs), want):
+    assert gk.tobytes() == wk.tobytes() and gd.tobytes() == wd.tobytes()
+dev = api.DeviceFrames(imgs, 0)
+st = api.Stream(900, 1.2, 8, 20, 7, 0, 3, 2)    # the runner leaves ORBFE_POLL_WAIT_US alone when it is set
+st.set_matching((0.0, 960.0, 0.0, 540.0), 0, 0.9, True)
+for rep in range(3):
+    st.push_ptrs(dev.ptrs, 540, 960, dev.stride, True)
+for rep in range(3):
+    kps, desc, n, _, _ = st.pop(copy=True)
+    for i, (wk, wd) in enumerate(want):
+        assert kps[i, :n[i]].tobytes() == wk.tobytes() and desc[i, :n[i]].tobytes() == wd.tobytes()
+st.close()
+print('OK')
+'''
+
+
+@pytest.mark.parametrize('env', [{'ORBFE_GAUSS_VARIANT': '1'}, {'ORBFE_GAUSS_VARIANT': '0'}, {'ORBFE_POLL_WAIT_US': '20'}, {'ORBFE_POLL_WAIT_US': '0'}])
+def test_environment_presets(env):
+    """ORBFE_GAUSS_VARIANT presets the GaussianBlur variant of every extractor of the process (what an integrator without access to
+    the facade's constructor sets), ORBFE_POLL_WAIT_US how a handle waits for the GPU (sleep-poll / spin): read when a handle is
+    created, so each setting runs in a process of its own -- one-frame calls, a batch and the stream runner against the oracle."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, '-c', _ENV_PRESET_SCRIPT % root], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith('OK'), (env, r.stdout[-500:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize('env', [{'ORBFE_LDS_DMA': '0'}, {'ORBFE_FAST_LEAN': '0'}, {'ORBFE_LDS_DMA': '0', 'ORBFE_FAST_LEAN': '0'}])
 def test_staging_variants_agree(env):
-    """How the tiles reach LDS -- LDS-DMA with 16 bytes per lane (default), one dword per lane (ORBFE_FAST_DMA=1), through registers
-    (=0, and ORBFE_DESCRIBE_DMA=0 / ORBFE_RESIZE_DMA=0) -- one FAST launch instead of one per LDS class, and the FAST kernel's generic
-    prologue instead of the LEAN one (ORBFE_FAST_LEAN=0; the script's odd row stride takes the generic one anyway), the pyramid by one-wave
-    32x32 tiles (ORBFE_RESIZE_WAVE=1, k_resize_w1): each switch is read once
+    """How the tiles reach LDS: by LDS-DMA with 16 bytes per lane (default) or through registers (ORBFE_LDS_DMA=0: the pyramid footprints
+    and the descriptor patches everywhere, not only on a frame's last row), and the FAST kernel's generic prologue instead of the LEAN one
+    (ORBFE_FAST_LEAN=0; the script's odd row stride takes the generic one anyway).  Each switch is read once
     per process, so every setting runs in a process of its own; four-frame batches at two sizes and three row strides, and the one-frame
     route, against the oracle."""
     import os
