@@ -35,9 +35,10 @@ int launch_pyramid(const PyramidParams& P, int nframes, hipStream_t st, const Co
 void launch_ingest(const uint8_t* src, long long sstride, uint8_t* dst, long long dpitch, int rowBytes, int rows, hipStream_t st);
 void launch_to_gray(const uint8_t* const* raw, long long rawStride, const uint8_t* const* gray, long long grayPitch, int rows,
                     int cols, int channels, const int coef[3], int shift, bool aligned, int nframes, hipStream_t st);
-void launch_fast(const PyramidParams& P, int nframes, hipStream_t st, int level0 = 0, int level1 = kMaxLevels);
+void launch_fast(const PyramidParams& P, int nframes, hipStream_t st);
 uint32_t fast_task_geo(int fastW, int hCell);
 void launch_compact(const PyramidParams& P, int nframes, hipStream_t st);
+void launch_compact_local(const PyramidParams& P, int nframes, hipStream_t st, int level0, int level1);
 void launch_describe(const PyramidParams& P, const SelKp* sel, int nsel, float* angle, uint8_t* desc,
                      hipStream_t st);
 void launch_sincos(const float* deg, int n, float* c, float* s, hipStream_t st);
@@ -171,6 +172,8 @@ struct orbfe_extractor {
   hipStream_t streams[kMaxSub] = {};
   static constexpr int subBatches = 4;   // host-quadtree route: sub-batches in flight (one HIP stream each)
   hipEvent_t evUpload = nullptr;
+  bool lastLocalCand = false, submitLocalCand = false;   // candidate lists of the last collected / submitted batch are level-local (k_compact_local)
+  bool localLists = true;         // (experiments build, ORBFE_LOCAL_LISTS=0: the packed list of k_compact in latency-bound calls too)
   hipEvent_t evFrame0 = nullptr, evS1[kMaxSub] = {};
   int subSel[kMaxSub] = {};
   size_t candHostCap = 0;
@@ -210,7 +213,7 @@ struct orbfe_extractor {
   DevBuf<FastTask> d_tasks;
   DevBuf<uint8_t> d_zeros;
   bool pairCells = false;  // ORBFE_FAST_PAIRS=1: two adjacent cells per wave (7 % fewer vector instructions, but 10 % slower: DESIGN.md s5)
-  DevBuf<uint32_t> d_cellCount, d_cellOff, d_slots, d_cand;
+  DevBuf<uint32_t> d_cellCount, d_slots, d_cand;
   DevBuf<const uint8_t*> d_frame0;
   // results leave the GPU in ONE copy: [levelStart][selCount][sel][angle][desc] carved from one arena
   template <class T> struct View { T* p = nullptr; };
@@ -269,7 +272,7 @@ struct orbfe_extractor {
     (void)hipSetDevice(device);
     for (auto& st : streams) if (st) (void)hipStreamSynchronize(st);   // a batch may still be in flight
     d_bow.release(); h_bow.release();
-    d_tables.release(); d_coneTab.release(); d_slab.release(); d_in.release(); d_cellCount.release(); d_cellOff.release();
+    d_tables.release(); d_coneTab.release(); d_slab.release(); d_in.release(); d_cellCount.release();
     d_sfiOrder.release(); d_sfiOrderCount.release(); d_sfiPool.release(); d_sfiPcount.release();
     d_cells.release(); d_tasks.release(); d_zeros.release(); d_slots.release(); d_cand.release(); d_frame0.release(); d_gray.release(); d_outArena.release(); h_outArena.release();
     d_f32tmp.release();
@@ -280,6 +283,7 @@ struct orbfe_extractor {
     d_own.release();
     if (evFrame0) (void)hipEventDestroy(evFrame0);
     if (evUpload) (void)hipEventDestroy(evUpload);
+
     for (auto& st : streams) if (st) (void)hipStreamDestroy(st);
   }
 
@@ -320,7 +324,7 @@ struct orbfe_extractor {
       }
       L.cellBase = cellBase;
       cellBase += L.nCols * L.nRows;
-      L.slotCap = ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2);
+      L.slotCap = (((L.wCell + 1) / 2) * ((L.hCell + 1) / 2) + 3) & ~3;   // the strict-local-max bound, rounded up so that every cell's slots start 16-byte aligned
       L.slotBase = slot;
       slot += (long long)L.nCols * L.nRows * L.slotCap;
       if (l >= 1) {
@@ -560,7 +564,6 @@ struct orbfe_extractor {
       // last pixel it needs; on the last row of the last level of the last frame that is past the slab
       if ((rc = d_slab.ensure((size_t)P.slabBytes * nframes + 64))) return rc;
       if ((rc = d_cellCount.ensure((size_t)P.ncells * nframes))) return rc;
-      if ((rc = d_cellOff.ensure((size_t)P.ncells * nframes))) return rc;
       if ((rc = d_slots.ensure((size_t)P.slotsPerFrame * nframes))) return rc;
       if ((rc = d_cand.ensure((size_t)P.candCap * nframes))) return rc;
       if ((rc = d_frame0.ensure(2 * (size_t)nframes))) return rc;   // [gray level-0 pointers][raw colour pointers]
@@ -605,7 +608,6 @@ struct orbfe_extractor {
     }
     P.slab = d_slab.p;
     P.cellCount = d_cellCount.p;
-    P.cellOff = d_cellOff.p;
     P.slots = d_slots.p;
     P.cand = d_cand.p;
     P.levelStart = d_levelStart.p;
@@ -776,42 +778,53 @@ struct orbfe_extractor {
       launch_to_gray(d_frame0.p + nframes, rawStride, d_frame0.p, grayPitch, r, c, ch, coef, q15 ? 15 : 14, rawAligned, nframes, st);
     }
     const bool prof = profileKernels;
-    if (prof) HIP_TRY(hipEventRecord(ev[0][0], st));
-    if (launch_pyramid(P, nframes, st, coneOk && nframes <= coneMaxFrames ? &cone : nullptr)) { set_err("cannot configure the pyramid kernel"); return ORBFE_ERR_HIP; }
-    // the dominant kernel is timed in every batch (bench.py roofline); a latency-bound one- or two-frame call does
-    // without the two markers (each costs a few microseconds of dependent-launch gap) unless profiling is on
-    const bool timeFast = prof || nframes > coneMaxFrames;
-    fastTimed = timeFast;
-    if (timeFast) HIP_TRY(hipEventRecord(ev[0][1], st));
-    launch_fast(P, nframes, st);
-    if (timeFast) HIP_TRY(hipEventRecord(ev[0][2], st));
-    launch_compact(P, nframes, st);
-    if (prof) HIP_TRY(hipEventRecord(ev[0][3], st));
     QP.cand = d_cand.p; QP.levelStart = d_levelStart.p; QP.candCap = P.candCap; QP.nlevels = nlevels; QP.frameBase = 0;
     QP.own = d_own.p;
     QP.sel = d_sel.p; QP.selCount = d_selCount.p; QP.selPerFrame = selPerFrame;
     // Latency-bound plain extraction: the kernels write the results straight into the page-locked host arena
     // (the quadtree a second copy of its selection, the descriptor kernel its only copy), so no copy command follows
     // the last kernel.  Matching and bag-of-words read angles / descriptors on the device and keep the copy.
-    const bool zeroCopy = zeroCopyOut && nframes <= coneMaxFrames && !voc && !(ms && ms->chain);
+    const bool small = nframes <= coneMaxFrames;
+    const bool zeroCopy = zeroCopyOut && small && !voc && !(ms && ms->chain);
     submitZeroCopy = zeroCopy;
     QP.jump = qtJump ? 1 : 0;
     QP.selHost = zeroCopy ? h_sel.p : nullptr;
     QP.selCountHost = zeroCopy ? h_selCount.p : nullptr;
     for (int l = 0; l < nlevels; l++) {
       QP.levW[l] = P.lv[l].w; QP.levH[l] = P.lv[l].h; QP.nfeat[l] = nfeat[l]; QP.selOff[l] = selOff[l];
+      QP.candBase[l] = P.lv[l].slotBase;
     }
-    if (prof) HIP_TRY(hipEventRecord(evQt[0], st));
-    // a one- or two-frame call is latency-bound and alone on the chip: the quadtree keeps its candidates in LDS
-    if (launch_quadtree(QP, nframes, st, nframes <= coneMaxFrames ? qtLdsBudget : 0)) { set_err("cannot configure the quadtree kernel"); return ORBFE_ERR_HIP; }
-    if (prof) HIP_TRY(hipEventRecord(evQt[1], st));
+    float* angOut = zeroCopy ? h_angle.p : d_angle.p;
+    uint8_t* descOut = zeroCopy ? h_desc.p : d_desc.p;
+    // a one- or two-frame call is latency-bound and alone on the chip: the quadtree keeps its candidates in LDS, four waves share a keypoint
+    const int qtLds = small ? qtLdsBudget : 0;
+    const bool four = describe4 && small;
+    // a latency-bound call compacts per level (k_compact_local: level-local lists, every wave's prefix in one memory round trip)
+    const bool localCand = small && localLists;
+    submitLocalCand = localCand;
+    QP.levelLocal = localCand ? 1 : 0;
+    {
+      if (prof) HIP_TRY(hipEventRecord(ev[0][0], st));
+      if (launch_pyramid(P, nframes, st, coneOk && small ? &cone : nullptr)) { set_err("cannot configure the pyramid kernel"); return ORBFE_ERR_HIP; }
+      // the dominant kernel is timed in every batch (bench.py roofline); a latency-bound one- or two-frame call does
+      // without the two markers (each costs a few microseconds of dependent-launch gap) unless profiling is on
+      const bool timeFast = prof || !small;
+      fastTimed = timeFast;
+      if (timeFast) HIP_TRY(hipEventRecord(ev[0][1], st));
+      launch_fast(P, nframes, st);
+      if (timeFast) HIP_TRY(hipEventRecord(ev[0][2], st));
+      if (localCand) launch_compact_local(P, nframes, st, 0, nlevels);
+      else launch_compact(P, nframes, st);
+      if (prof) HIP_TRY(hipEventRecord(ev[0][3], st));
+      if (prof) HIP_TRY(hipEventRecord(evQt[0], st));
+      if (launch_quadtree(QP, nframes, st, qtLds)) { set_err("cannot configure the quadtree kernel"); return ORBFE_ERR_HIP; }
+      if (prof) HIP_TRY(hipEventRecord(evQt[1], st));
+      if (prof) HIP_TRY(hipEventRecord(ev[0][4], st));
+      launch_describe_slots(P, d_sel.p, nframes * selPerFrame, angOut, descOut, d_selCount.p, selPerFrame, selOff, st, four);
+      if (prof) HIP_TRY(hipEventRecord(ev[0][5], st));
+      HIP_TRY(hipGetLastError());
+    }
     const int nslots = nframes * selPerFrame;
-    if (prof) HIP_TRY(hipEventRecord(ev[0][4], st));
-    // a one- or two-frame call is alone on the chip and waits for single keypoints: four waves share each one
-    launch_describe_slots(P, d_sel.p, nslots, zeroCopy ? h_angle.p : d_angle.p, zeroCopy ? h_desc.p : d_desc.p, d_selCount.p,
-                          selPerFrame, selOff, st, describe4 && nframes <= coneMaxFrames);
-    if (prof) HIP_TRY(hipEventRecord(ev[0][5], st));
-    HIP_TRY(hipGetLastError());
     pendingBow = false;
     if (voc) {
       if ((rc = d_bow.ensure(nslots)) || (rc = h_bow.ensure(nslots))) return rc;
@@ -963,6 +976,7 @@ struct orbfe_extractor {
     lastFrames = nframes;
     lastGpuQt = true;
     lastZeroCopy = submitZeroCopy;
+    lastLocalCand = submitLocalCand;
     return status;
   }
 
@@ -1159,6 +1173,7 @@ struct orbfe_extractor {
     stageMs[4] = (float)(t5 - t0);
     lastFrames = nframes;
     lastGpuQt = false;
+    lastLocalCand = false;
     return status;
   }
 };
@@ -1424,6 +1439,7 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
   if (const char* dw = ORBFE_EXP_ENV("ORBFE_DESCRIBE_WAVES")) h->describe4 = atoi(dw) != 1;
   if (const char* zv = getenv("ORBFE_ZERO_COPY")) h->zeroCopyOut = atoi(zv) != 0;
   if (const char* iv = getenv("ORBFE_INGEST_KERNEL")) h->ingestKernel = atoi(iv) != 0;
+  if (const char* gv = ORBFE_EXP_ENV("ORBFE_LOCAL_LISTS")) h->localLists = atoi(gv) != 0;
   if (const char* qv = getenv("ORBFE_QT_LDS_BYTES")) h->qtLdsBudget = atoi(qv);
   if (const char* qj = getenv("ORBFE_QT_JUMP")) h->qtJump = atoi(qj) != 0;
   if (const char* cv = ORBFE_EXP_ENV("ORBFE_CONE_TILE")) h->coneTile = atoi(cv) <= 0 ? 0 : std::max(8, atoi(cv)) & ~3;
@@ -1795,11 +1811,13 @@ int orbfe_debug_candidates(orbfe_extractor* h, int frame, int level, int32_t* xy
   // read from the device: small batches hand their results over without copying the whole arena
   uint32_t ls[kMaxLevels + 1];
   HIP_TRY(hipMemcpy(ls, h->d_levelStart.p + (size_t)frame * (kMaxLevels + 1), sizeof(ls), hipMemcpyDeviceToHost));
-  const int n = (int)(ls[level + 1] - ls[level]);
+  // packed list with prefix offsets (k_compact), or level-local lists with their lengths (k_compact_local: the latency route)
+  const size_t start = h->lastLocalCand ? (size_t)h->P.lv[level].slotBase : (size_t)ls[level];
+  const int n = h->lastLocalCand ? (int)ls[level] : (int)(ls[level + 1] - ls[level]);
   *n_out = n;
   if (n <= 0 || !xys) return ORBFE_OK;
   std::vector<uint32_t> tmp(n);
-  HIP_TRY(hipMemcpy(tmp.data(), h->d_cand.p + (size_t)h->P.candCap * frame + ls[level], sizeof(uint32_t) * n,
+  HIP_TRY(hipMemcpy(tmp.data(), h->d_cand.p + (size_t)h->P.candCap * frame + start, sizeof(uint32_t) * n,
                     hipMemcpyDeviceToHost));
   for (int i = 0; i < n && i < cap; i++) {
     xys[3 * i] = (int)(tmp[i] & 0xfff) - kBorder;

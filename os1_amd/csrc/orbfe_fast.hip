@@ -577,11 +577,11 @@ uint32_t fast_task_geo(int fastW, int hCell) {
   return ppr | (rpi << 3) | ((scOff >> 4) << 8) | ((qOff >> 4) << 18);
 }
 
-void launch_fast(const PyramidParams& P, int nframes, hipStream_t st, int level0, int level1) {
+void launch_fast(const PyramidParams& P, int nframes, hipStream_t st) {
   // 16 pixels per lane in the pre-test: one wave iteration covers a 31 x 31 cell (8 pixels per lane take two and are
-  // equal in time, 9.9 us per 1080p frame, with more instructions).  Levels [level0, level1) of every frame.
+  // equal in time, 9.9 us per 1080p frame, with more instructions)
   const FastArgs FA = fast_args(P);
-  if (level1 > P.nlevels) level1 = P.nlevels;
+  const int level0 = 0, level1 = P.nlevels;
   bool pairs = false;
   for (int l = 0; l < P.nlevels; l++) pairs = pairs || P.lv[l].fastW != P.lv[l].wCell;
   // LDS CLASSES (round 4).  LDS is handed out in 1 KB granules and a CU has 160 of them: a one-wave workgroup that asks for up

@@ -73,10 +73,9 @@ struct PyramidParams {
   long long stride0;                // level-0 row stride in bytes
   uint8_t* slab;                    // [nframes][slabBytes]
   uint32_t* cellCount;              // [nframes][ncells]
-  uint32_t* cellOff;                // [nframes][ncells]
   uint32_t* slots;                  // [nframes][slotsPerFrame]
   uint32_t* cand;                   // [nframes][candCap]  packed x | y<<12 | score<<24 (level coords)
-  uint32_t* levelStart;             // [nframes][kMaxLevels+1]
+  uint32_t* levelStart;             // [nframes][kMaxLevels+1]  first candidate of every level (packed list); level-local lists: the levels' COUNTS
   const CellInfo* cells;            // [ncells]
   const FastTask* tasks;            // [ntasks] work items of k_fast_tasks, level-major
   int ntasks;
@@ -184,6 +183,10 @@ struct QtParams {
   SelKp* selHost;
   uint32_t* selCountHost;
   int jump;                    // != 0: the first passes of a dense level (every node divides) in one sweep (orbfe_quadtree.hip)
+  // != 0: level-local candidate lists (k_compact_local: one- and two-frame calls) -- level l's list starts at candBase[l] inside a
+  // frame's candidate array and levelStart[f][l] holds its LENGTH; 0: one packed list per frame, levelStart = prefix offsets (k_compact)
+  int levelLocal;
+  long long candBase[kMaxLevels];
 };
 
 

@@ -620,7 +620,6 @@ __global__ __launch_bounds__(64) void k_compact(PyramidParams P) {
   const uint32_t o = base + incl - n;
   uint32_t* ls = P.levelStart + (long long)f * (kMaxLevels + 1);
   if (valid) {
-    P.cellOff[(long long)f * P.ncells + cell] = o;
     for (int l = 0; l < P.nlevels; l++)
       if (P.lv[l].cellBase == cell) ls[l] = o;
     if (cell == P.ncells - 1) ls[P.nlevels] = o + n;
@@ -632,6 +631,67 @@ __global__ __launch_bounds__(64) void k_compact(PyramidParams P) {
   for (int u = 0; u < 16; u++)
     if ((uint32_t)u < n) dst[u] = first[u];
   for (uint32_t i = 16; __any(i < n); i += 16) {
+    uint32_t v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) v[u] = (i + u < n) ? slot[i + u] : 0u;
+#pragma unroll
+    for (int u = 0; u < 16; u++)
+      if (i + u < n) dst[i + u] = v[u];
+  }
+}
+
+// The same compaction with LEVEL-LOCAL lists (one- and two-frame calls, whose levels run as two independent launch chains:
+// level 0 needs no pyramid and runs beside the cone kernel and the other levels): level l's list starts at the fixed position
+// lv[l].slotBase of the frame's candidate array (the slot array's own layout: it cannot overflow) and levelStart[f][l] receives
+// its LENGTH.  A wave sums the counts of the earlier cells of ITS level only -- no launch looks at another chain's cells -- and
+// requests them in ONE batch (40 per lane: 2 560 cells, more than a 1080p level has) together with its cell's first slots: the call
+// waits for this kernel's single memory round trip, not for its throughput (k_compact's 16-wide batches were three dependent
+// round trips for the last wave of level 0).  grid = (waves of the largest level in [l0, l1), l1 - l0, frames).
+__global__ __launch_bounds__(64) void k_compact_local(PyramidParams P, int l0) {
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  const int level = l0 + blockIdx.y, lane = threadIdx.x, f = P.frameBase + blockIdx.z;
+  const LevelGeom& L = P.lv[level];
+  const int nc = L.nCols * L.nRows, cell0 = blockIdx.x * 64;
+  if (cell0 >= nc) return;
+  const uint32_t* cnt = P.cellCount + (long long)f * P.ncells + L.cellBase;
+  const int cell = cell0 + lane;
+  const bool valid = cell < nc;
+  // a cell's slots start 16-byte aligned (slotCap and every slotBase are multiples of 4): its first 32 arrive as eight 16-byte
+  // pieces, requested together with the counts -- a second round trip is left to cells with more than 32 keypoints
+  const uint32_t* slot = P.slots + (long long)f * P.slotsPerFrame + L.slotBase + (long long)(valid ? cell : 0) * L.slotCap;
+  constexpr int kB = 40, kF = 8;
+  uint32_t n = valid ? cnt[cell] : 0u;
+  uint32_t s = 0;
+  u32x4 first[kF];
+  {
+    uint32_t v[kB];
+#pragma unroll
+    for (int u = 0; u < kB; u++) v[u] = (lane + 64 * u < cell0) ? cnt[lane + 64 * u] : 0u;
+#pragma unroll
+    for (int u = 0; u < kF; u++) first[u] = 4 * u < L.slotCap ? reinterpret_cast<const u32x4*>(slot)[u] : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int u = 0; u < kB; u += 4) s += (v[u] + v[u + 1]) + (v[u + 2] + v[u + 3]);
+  }
+  for (int i = lane + 64 * kB; i < cell0; i += 64 * 16) {   // levels of more than 2 560 cells (4K frames)
+    uint32_t v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) v[u] = (i + 64 * u < cell0) ? cnt[i + 64 * u] : 0u;
+#pragma unroll
+    for (int u = 0; u < 16; u += 4) s += (v[u] + v[u + 1]) + (v[u + 2] + v[u + 3]);
+  }
+  const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(s), 63);
+  const uint32_t incl = wave_incl_scan(n);
+  const uint32_t o = base + incl - n;
+  if (valid && cell == nc - 1) P.levelStart[(long long)f * (kMaxLevels + 1) + level] = o + n;
+  uint32_t* dst = P.cand + (long long)f * P.candCap + L.slotBase + o;
+#pragma unroll
+  for (int u = 0; u < kF; u++) {
+    if ((uint32_t)(4 * u) < n) dst[4 * u] = first[u].x;
+    if ((uint32_t)(4 * u + 1) < n) dst[4 * u + 1] = first[u].y;
+    if ((uint32_t)(4 * u + 2) < n) dst[4 * u + 2] = first[u].z;
+    if ((uint32_t)(4 * u + 3) < n) dst[4 * u + 3] = first[u].w;
+  }
+  for (uint32_t i = 4 * kF; __any(i < n); i += 16) {
     uint32_t v[16];
 #pragma unroll
     for (int u = 0; u < 16; u++) v[u] = (i + u < n) ? slot[i + u] : 0u;
@@ -1345,7 +1405,13 @@ int launch_pyramid(const PyramidParams& P, int nframes, hipStream_t st, const Co
 void launch_compact(const PyramidParams& P, int nframes, hipStream_t st) {
   hipLaunchKernelGGL(k_compact, dim3((P.ncells + 63) / 64, nframes), dim3(64), 0, st, P);
 }
-
+void launch_compact_local(const PyramidParams& P, int nframes, hipStream_t st, int level0, int level1) {
+  if (level1 > P.nlevels) level1 = P.nlevels;
+  int maxCells = 0;
+  for (int l = level0; l < level1; l++) maxCells = std::max(maxCells, P.lv[l].nCols * P.lv[l].nRows);
+  if (maxCells <= 0) return;
+  hipLaunchKernelGGL(k_compact_local, dim3((maxCells + 63) / 64, level1 - level0, nframes), dim3(64), 0, st, P, level0);
+}
 
 static DescribeArgs describe_args(const PyramidParams& P, const SelKp* sel, int nsel, float* angle, uint8_t* desc) {
   DescribeArgs A{};

@@ -33,6 +33,17 @@
 namespace orbfe {
 
 constexpr int kQt3Threads = 512;
+
+// Experiments build only: s_memrealtime stamps (100 MHz) of one block's phases, one row of 32 per (frame 0) level: tools/qt_phases.py
+#ifdef ORBFE_EXPERIMENTS
+__device__ unsigned long long g_qtStamps[kMaxLevels][32];
+#define QT_STAMP(i)                                                                                         \
+  do {                                                                                                      \
+    if (threadIdx.x == 0 && blockIdx.y == 0) g_qtStamps[blockIdx.x][i] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define QT_STAMP(i) ((void)0)
+#endif
 constexpr int kQtEpt = 8;   // candidates per thread and sweep step (independent loads in flight)
 
 struct Qt3Node {
@@ -54,21 +65,26 @@ struct Qt3Shared {
   //                  node pass reads replica 0 after a fold;
   //   final pick     max of score << 24 | (0xffffff - candidate index) in cnt[id * 4 + rep].
   alignas(16) uint32_t cnt[CAP * 4];
-  unsigned long long sortKeys[CAP];
+  alignas(16) unsigned long long sortKeys[CAP];
   short tproc[CAP];           // index in processing order, -1 = not divided
   int wsumI[kQt3Threads / 64];
   int s_int[4];
 };
 
+__device__ __forceinline__ int wave_incl_scan_i(int x) {   // DPP: six dependent adds instead of six LDS-crossbar shuffles
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);   // row_shr:1
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);   // row_shr:2
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);   // row_shr:4
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);   // row_shr:8
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+  return x;
+}
+
 template <int CAP>
 __device__ int blockScanInt3(Qt3Shared<CAP>& sh, int v, int& total) {  // exclusive, 512 threads
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int iv = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(iv, o, 64);
-    if (lane >= o) iv += t;
-  }
+  const int iv = wave_incl_scan_i(v);
   __syncthreads();
   if (lane == 63) sh.wsumI[wv] = iv;
   __syncthreads();
@@ -86,31 +102,38 @@ template <int CAP>
 __device__ void blockSortDesc3(Qt3Shared<CAP>& sh, int n) {
   int m = 1;
   while (m < n) m <<= 1;
-  if (m <= kQt3Threads) {
-    // one key per thread, in a register: the exchange distances below a wave's width go through lane shuffles (no
-    // barrier); only distances >= 64 take a round trip through LDS
-    const int i = threadIdx.x;
-    unsigned long long key = i < n ? sh.sortKeys[i] : 0ull;
-    for (int k = 2; k <= m; k <<= 1) {
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        unsigned long long other;
-        if (j >= 64) {
-          __syncthreads();
-          sh.sortKeys[i] = key;
-          __syncthreads();
-          other = sh.sortKeys[i ^ j];
-        } else {
-          const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)key, j, 64);
-          const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(key >> 32), j, 64);
-          other = ((unsigned long long)hi << 32) | lo;
+  if (n <= kQt3Threads) {
+    // RANK sort (round 6): the keys are distinct (they carry the creation number), so key i belongs at position #{j : key j > key i}.
+    // 512 / m threads share a key (m = n rounded up to a power of two) and count over their slice of the others -- LDS reads of
+    // one address for all lanes of a wave (broadcasts), two keys per 16-byte read, eight reads in flight -- then add their counts
+    // with one LDS atomic each: a few hundred independent instructions per thread instead of the bitonic network's 28 .. 45 DEPENDENT
+    // exchange steps through the LDS crossbar (3.8 us for the 128 keys of a 1080p level, profiles/r06_qt_phases.txt).
+    const int t = threadIdx.x, i = t & (m - 1), part = t / m, parts = kQt3Threads / m;   // m <= 512: parts >= 1
+    const unsigned long long key = i < n ? sh.sortKeys[i] : 0ull;
+    uint32_t* rankAcc = sh.cnt;   // (not live between passes)
+    if (t < n) rankAcc[t] = 0u;
+    __syncthreads();
+    if (i < n) {
+      const int per = ((n + parts - 1) / parts + 15) & ~15;   // keys per slice, whole trips
+      const int j1 = min(n, (part + 1) * per);
+      int rank = 0;
+      for (int j0 = part * per; j0 < j1; j0 += 16) {
+        ulonglong2 kk[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) kk[u] = *reinterpret_cast<const ulonglong2*>(&sh.sortKeys[min(j0 + 2 * u, CAP - 2)]);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          rank += (j0 + 2 * u < j1) && (kk[u].x > key);
+          rank += (j0 + 2 * u + 1 < j1) && (kk[u].y > key);
         }
-        const bool keepMax = ((i & j) == 0) == ((i & k) == 0);   // lower index of the pair in a descending run
-        const bool otherBigger = other > key;
-        if (keepMax == otherBigger) key = other;
       }
+      if (rank) atomicAdd(&rankAcc[i], (uint32_t)rank);
     }
     __syncthreads();
-    if (i < m) sh.sortKeys[i] = key;
+    const int pos = (t < n) ? (int)rankAcc[t] : 0;
+    const unsigned long long mine = (t < n) ? sh.sortKeys[t] : 0ull;
+    __syncthreads();
+    if (t < n) sh.sortKeys[pos] = mine;
     __syncthreads();
     return;
   }
@@ -149,17 +172,16 @@ struct Qt3Cands {
 };
 
 template <int CAP, bool LC>
-__device__ __forceinline__ void qt3_problem(const QtParams& Q, Qt3Shared<CAP>& sh, uint32_t* candL, uint16_t* ownL) {
+__device__ __forceinline__ void qt3_problem(const QtParams& Q, Qt3Shared<CAP>& sh, uint32_t* candL, uint16_t* ownL, const int level, const int f,
+                                            const long long first, const int n) {
   constexpr int IPT = CAP >= kQt3Threads ? CAP / kQt3Threads : 1;   // node items per thread
-  const int level = blockIdx.x, f = Q.frameBase + blockIdx.y, tid = threadIdx.x;
-  const uint32_t* ls = Q.levelStart + (long long)f * (kMaxLevels + 1);
-  const uint32_t first = ls[level];
-  const int n = (int)(ls[level + 1] - first);
+  const int tid = threadIdx.x;
   const int N = Q.nfeat[level];
   uint32_t* selCount = Q.selCount + (long long)f * kMaxLevels + level;
   uint32_t* selCountHost = Q.selCountHost ? Q.selCountHost + (long long)f * kMaxLevels + level : nullptr;
   SelKp* selHost = Q.selHost ? Q.selHost + (long long)f * Q.selPerFrame + Q.selOff[level] : nullptr;
   SelKp* selOut = Q.sel + (long long)f * Q.selPerFrame + Q.selOff[level];
+  QT_STAMP(0);
   if (n <= 0) {
     if (tid == 0) {
       *selCount = 0;
@@ -178,6 +200,20 @@ __device__ __forceinline__ void qt3_problem(const QtParams& Q, Qt3Shared<CAP>& s
   // ---- roots (ORBextractor.cc:574-617): raw root index per candidate, counts by LDS atomics ------------------
   const int nIni = (int)roundf(static_cast<float>(maxX - kBorder) / (maxY - kBorder));
   const float hX = static_cast<float>(maxX - kBorder) / nIni;
+  // root of a candidate: min((int)((float)x / hX), nIni - 1) (ORBextractor.cc:591-594), monotone in x, so it is the number of
+  // thresholds b_k = smallest x whose quotient reaches k that lie at or below x: three compares instead of an IEEE division per candidate
+  int rootB[3];
+#pragma unroll
+  for (int k = 1; k <= 3; k++) {
+    int b = 0x7fffffff;
+    if (k < nIni) {
+      b = (int)(hX * static_cast<float>(k));   // near the threshold; settle it by the reference's own expression
+      while (b > 0 && (int)((float)(b - 1) / hX) >= k) b--;
+      while ((int)((float)b / hX) < k) b++;
+    }
+    rootB[k - 1] = b;
+  }
+  auto rootOf = [&](int x) { return (x >= rootB[0]) + (x >= rootB[1]) + (x >= rootB[2]); };
   int m = 0;
   uint32_t seq = 0;
   bool finalPhase = false;
@@ -198,25 +234,92 @@ __device__ __forceinline__ void qt3_problem(const QtParams& Q, Qt3Shared<CAP>& s
     while (T < 3 && (T == 0 || 4 * mt <= N) && mt * 4 <= CAP) { mt *= 4; T++; }
     mT = mt;
   }
+  QT_STAMP(1);
   if (T >= 2 && n >= 8 * mT) {
     int rl = 5;
     while (rl > 0 && (mT << rl) > CAP * 4) rl--;
     for (int i = tid; i < (mT << rl); i += kQt3Threads) sh.cnt[i] = 0u;
-    __syncthreads();
     const int yTop = maxY - kBorder;
+    // DivideNode halves the two axes independently, so a candidate's leaf follows from a per-COLUMN and a per-ROW table: root and
+    // the T left / right decisions for every x of the level, the T up / down decisions for every y, and one table from (root,
+    // decisions) to the leaf's creation index.  The walk itself -- T rounds of midpoints, compares and selects, 55 vector
+    // instructions -- then runs once per column and row instead of once per candidate (round 6: this sweep is bound by ONE CU's
+    // vector issue; 8.2 -> 3.x us for the 10 400 candidates of a 1080p level 0, profiles/r06_qt_phases.txt).  The tables live in
+    // the second node array, which nothing uses before the first node pass.
+    uint8_t* lutX = reinterpret_cast<uint8_t*>(sh.nodes[1]);                 // [levW]  root << 3 | x decisions (first = MSB), by RAW x (border included)
+    uint8_t* lutY = lutX + ((Q.levW[level] + 15) & ~15);                      // [levH]  y decisions
+    static_assert(sizeof(sh.nodes[1]) >= 8192 || CAP < 512, "axis tables of a 4095-pixel level");
+    uint16_t* lutC = reinterpret_cast<uint16_t*>(sh.proc);                    // [4][8][8] creation index of the leaf
+    const bool lutFits = ((Q.levW[level] + 15) & ~15) + Q.levH[level] <= (int)sizeof(sh.nodes[1]);
+    // the candidates of the NEXT step travel while the current one is processed; the first request goes out before the tables are built
+    uint32_t vNext[kQtEpt];
+    auto loadJump = [&](int b) {
+#pragma unroll
+      for (int j = 0; j < kQtEpt; j++) vNext[j] = cand[min(b + j * kQt3Threads + tid, n - 1)];
+    };
+    loadJump(0);
+    if (lutFits) {
+      for (int xr = kBorder + tid; xr < maxX; xr += kQt3Threads) {
+        const int x = xr - kBorder, r = rootOf(x);
+        int x0 = (int)(hX * static_cast<float>(r)), x1 = (int)(hX * static_cast<float>(r + 1)), bits = 0;
+        for (int t = 1; t <= T; t++) {
+          const int midX = x0 + ((x1 - x0 + 1) >> 1), qx = x < midX ? 0 : 1;
+          x0 = qx ? midX : x0; x1 = qx ? x1 : midX;
+          bits = bits * 2 + qx;
+        }
+        lutX[xr] = (uint8_t)((r << 3) | bits);
+      }
+      for (int yr = kBorder + tid; yr < maxY; yr += kQt3Threads) {
+        const int y = yr - kBorder;
+        int y0 = 0, y1 = yTop, bits = 0;
+        for (int t = 1; t <= T; t++) {
+          const int midY = y0 + ((y1 - y0 + 1) >> 1), qy = y < midY ? 0 : 1;
+          y0 = qy ? midY : y0; y1 = qy ? y1 : midY;
+          bits = bits * 2 + qy;
+        }
+        lutY[yr] = (uint8_t)bits;
+      }
+      if (tid < 256) {   // (root, x decisions, y decisions) -> creation index at pass T
+        const int r = tid >> 6, bx = (tid >> 3) & 7, by = tid & 7;
+        int pos = r, mt = nIni, created = 0;
+        for (int t = 1; t <= T; t++) {
+          const int q = ((bx >> (T - t)) & 1) + 2 * ((by >> (T - t)) & 1);
+          created = 4 * pos + q;
+          mt *= 4;
+          if (t < T) pos = (mt - 1) - created;
+        }
+        lutC[tid] = (uint16_t)created;
+      }
+    }
+    __syncthreads();
     for (int b = 0; b < n; b += kQtEpt * kQt3Threads) {
       uint32_t v[kQtEpt];
 #pragma unroll
-      for (int j = 0; j < kQtEpt; j++) {
-        const int p = b + j * kQt3Threads + tid;
-        v[j] = p < n ? cand[p] : 0u;
+      for (int j = 0; j < kQtEpt; j++) v[j] = vNext[j];
+      if (b + kQtEpt * kQt3Threads < n) loadJump(b + kQtEpt * kQt3Threads);
+      if (lutFits) {
+        unsigned ex[kQtEpt], ey[kQtEpt], cr[kQtEpt];
+#pragma unroll
+        for (int j = 0; j < kQtEpt; j++) { ex[j] = lutX[v[j] & 0xfff]; ey[j] = lutY[(v[j] >> 12) & 0xfff]; }
+#pragma unroll
+        for (int j = 0; j < kQtEpt; j++) cr[j] = lutC[((ex[j] << 3) | ey[j]) & 255u];
+#pragma unroll
+        for (int j = 0; j < kQtEpt; j++) {
+          const int p = b + j * kQt3Threads + tid;
+          if (p < n) {
+            if (LC) candL[p] = v[j];
+            ca.setOwn(p, cr[j]);          // parent's position * 4 + quadrant: what an ordinary sweep leaves
+            atomicAdd(&sh.cnt[(((unsigned)(mT - 1) - cr[j]) << rl) + (tid & ((1 << rl) - 1))], 1u);
+          }
+        }
+        continue;
       }
 #pragma unroll
       for (int j = 0; j < kQtEpt; j++) {
         const int p = b + j * kQt3Threads + tid;
         if (p < n) {
           const int x = (int)(v[j] & 0xfff) - kBorder, y = (int)((v[j] >> 12) & 0xfff) - kBorder;
-          const int r = min((int)((float)x / hX), nIni - 1);
+          const int r = rootOf(x);
           int x0 = (int)(hX * static_cast<float>(r)), x1 = (int)(hX * static_cast<float>(r + 1)), y0 = 0, y1 = yTop;
           int pos = r, mt = nIni, created = 0, q = 0;
           for (int t = 1; t <= T; t++) {
@@ -235,6 +338,7 @@ __device__ __forceinline__ void qt3_problem(const QtParams& Q, Qt3Shared<CAP>& s
       }
     }
     __syncthreads();
+    QT_STAMP(2);
     int empty = 0;
     for (int g = tid; g < mT; g += kQt3Threads) {
       uint32_t t = 0;
@@ -243,6 +347,7 @@ __device__ __forceinline__ void qt3_problem(const QtParams& Q, Qt3Shared<CAP>& s
       empty |= t == 0u;
     }
     jumped = __syncthreads_or(empty) == 0;
+    QT_STAMP(3);
     if (jumped) {
       // the nodes of the list after pass T, their child table, and the record of those with more than one candidate
       const int mPrev = mT >> 2;
@@ -293,6 +398,7 @@ __device__ __forceinline__ void qt3_problem(const QtParams& Q, Qt3Shared<CAP>& s
       nRec = totR;
       __syncthreads();
       finalPhase = m + 3 * totR > N;   // (what the end of pass T decides; m < N or m == N are handled by the loop's entry test below)
+      QT_STAMP(4);
     }
   }
   if (!jumped) {
@@ -310,7 +416,7 @@ __device__ __forceinline__ void qt3_problem(const QtParams& Q, Qt3Shared<CAP>& s
         const int p = b + j * kQt3Threads + tid;
         if (p < n) {
           const int x = (int)(v[j] & 0xfff) - kBorder;
-          const int r = min((int)((float)x / hX), nIni - 1);
+          const int r = rootOf(x);
           if (LC) candL[p] = v[j];
           ca.setOwn(p, (unsigned)r << 2);
           atomicAdd(&sh.cnt[r * 32 + (tid & 31)], 1u);
@@ -386,6 +492,7 @@ __device__ __forceinline__ void qt3_problem(const QtParams& Q, Qt3Shared<CAP>& s
     }
     __syncthreads();
     if (nproc == 0) break;
+    if (iter < 2) QT_STAMP(5 + 5 * iter);
     for (int i = tid; i < m; i += kQt3Threads) {
       const Qt3Node nd = cur[i];
       const int midX = nd.x0 + ((nd.x1 - nd.x0 + 1) >> 1), midY = nd.y0 + ((nd.y1 - nd.y0 + 1) >> 1);
@@ -396,6 +503,7 @@ __device__ __forceinline__ void qt3_problem(const QtParams& Q, Qt3Shared<CAP>& s
     while (rlog > 0 && (m << rlog) > CAP) rlog--;
     for (int i = tid; i < ((m * 4) << rlog); i += kQt3Threads) sh.cnt[i] = 0u;
     __syncthreads();
+    if (iter < 2) QT_STAMP(6 + 5 * iter);
     // ---- candidate sweep: node id in the current list (through the previous pass's child table), quadrant inside
     //      a node that is divided in this pass, one count per candidate ----------------------------------------
     {
@@ -441,6 +549,7 @@ __device__ __forceinline__ void qt3_problem(const QtParams& Q, Qt3Shared<CAP>& s
       }
     }
     __syncthreads();
+    if (iter < 2) QT_STAMP(7 + 5 * iter);
     if (rlog > 0) {   // fold the replicas into replica 0 (a group is touched by one thread only)
       for (int g = tid; g < m * 4; g += kQt3Threads) {
         uint32_t t = 0;
@@ -450,6 +559,7 @@ __device__ __forceinline__ void qt3_problem(const QtParams& Q, Qt3Shared<CAP>& s
       __syncthreads();
     }
 
+    if (iter < 2) QT_STAMP(8 + 5 * iter);
     // ---- node pass: children counts, cut, new list positions -----------------------------------------
     int C[IPT], locC = 0, locGrow = 0;
 #pragma unroll
@@ -579,11 +689,13 @@ __device__ __forceinline__ void qt3_problem(const QtParams& Q, Qt3Shared<CAP>& s
     }
     nRec = totR;
     __syncthreads();
+    if (iter < 2) QT_STAMP(9 + 5 * iter);
     if (m >= N || m == prevSize) break;
     if (!finalPhase && m + 3 * totR > N) finalPhase = true;
     if (finalPhase && nRec == 0) break;
   }
 
+  QT_STAMP(15);
   // ---- one keypoint per node: highest response, first in candidate order wins (ORBextractor.cc:774-792) --------
   __syncthreads();
   for (int i = tid; i < m * 4; i += kQt3Threads) sh.cnt[i] = 0u;
@@ -608,6 +720,7 @@ __device__ __forceinline__ void qt3_problem(const QtParams& Q, Qt3Shared<CAP>& s
     }
   }
   __syncthreads();
+  QT_STAMP(16);
   for (int i = tid; i < m; i += kQt3Threads) {
     const uint4 b4 = *reinterpret_cast<const uint4*>(&sh.cnt[i * 4]);
     const uint32_t best = max(max(b4.x, b4.y), max(b4.z, b4.w));
@@ -618,6 +731,7 @@ __device__ __forceinline__ void qt3_problem(const QtParams& Q, Qt3Shared<CAP>& s
     selOut[i] = s;
     if (selHost) selHost[i] = s;
   }
+  QT_STAMP(17);
   if (tid == 0) {
     *selCount = (uint32_t)m;
     if (selCountHost) *selCountHost = (uint32_t)m;
@@ -628,12 +742,13 @@ template <int CAP>
 __global__ __launch_bounds__(kQt3Threads) void k_quadtree3(QtParams Q, int ldsCand) {
   __shared__ Qt3Shared<CAP> sh;
   extern __shared__ __align__(16) uint32_t qtDyn[];   // [ldsCand] candidate words, then [ldsCand] u16 node ids
-  const uint32_t* ls = Q.levelStart + (long long)(Q.frameBase + blockIdx.y) * (kMaxLevels + 1);
-  const int n = (int)(ls[blockIdx.x + 1] - ls[blockIdx.x]);
-  if (n <= ldsCand)
-    qt3_problem<CAP, true>(Q, sh, qtDyn, reinterpret_cast<uint16_t*>(qtDyn + ldsCand));
-  else
-    qt3_problem<CAP, false>(Q, sh, nullptr, nullptr);
+  const int level = blockIdx.x, f = Q.frameBase + blockIdx.y;
+  const uint32_t* ls = Q.levelStart + (long long)f * (kMaxLevels + 1);
+  // packed list (k_compact: prefix offsets) or level-local lists (k_compact_local: fixed bases, lengths)
+  const long long first = Q.levelLocal ? Q.candBase[level] : (long long)ls[level];
+  const int n = Q.levelLocal ? (int)ls[level] : (int)(ls[level + 1] - ls[level]);
+  if (n <= ldsCand) qt3_problem<CAP, true>(Q, sh, qtDyn, reinterpret_cast<uint16_t*>(qtDyn + ldsCand), level, f, first, n);
+  else qt3_problem<CAP, false>(Q, sh, nullptr, nullptr, level, f, first, n);
 }
 
 // ldsBudget: bytes of LDS one problem may take for its candidates on top of the node tables (0 = keep them in HBM)
@@ -674,3 +789,15 @@ int launch_quadtree(const QtParams& Q, int nframes, hipStream_t st, int ldsBudge
 }
 
 }  // namespace orbfe
+
+#ifdef ORBFE_EXPERIMENTS
+extern "C" int orbfe_exp_qt_stamps(unsigned long long* out /* [kMaxLevels][32] */, int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(orbfe::g_qtStamps), sizeof(unsigned long long) * orbfe::kMaxLevels * 32) != hipSuccess) return 1;
+  if (reset) {
+    static unsigned long long zeros[orbfe::kMaxLevels][32] = {};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(orbfe::g_qtStamps), zeros, sizeof zeros) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif

@@ -652,7 +652,7 @@ def test_fast_cell_pairs_variant_bit_exact(api, oracle, monkeypatch):
 
 def test_latency_path_variants_agree(api, oracle, monkeypatch):
     """One- and two-frame calls take their own kernels (k_pyramid_cone, LDS-resident quadtree candidates, results written
-    straight to the host arena, level-0 pointers in the kernel arguments).  Every switch of that path, alone and
+    straight to the host arena, level-0 pointers in the kernel arguments, level-local candidate lists from k_compact_local).  Every switch of that path, alone and
     together, reproduces the oracle: the per-level pyramid kernels, candidates in HBM, the copied
     result arena, page-locked host frames fetched by the compute stream's own kernel (k_ingest: widths that are multiples of 16, of 4,
     and odd ones that go through the copy engine) or by a copy command (ORBFE_INGEST_KERNEL=0)."""
