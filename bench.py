@@ -75,6 +75,10 @@ def parse_args():
                     '66.7 k frames/s against 63.6 k at 3; 5 and 6 are slower -- DESIGN.md s5)')
     ap.add_argument('--prewarm-seconds', type=float, default=1.5,
                     help='untimed stream work in front of the W warm-up steps (a box that has just been started runs its first second slower: clocks, first-touch pages)')
+    ap.add_argument('--single-stream', action='store_true',
+                    help='SURVEY.md s8(e), the single-stream shape: ONE camera stream (seed 100) dealt batch by batch to --gpus N devices by '
+                         'one process (orbfe_stream_multi_*: in-order completion queue, host bounce of the batch-boundary predecessor); '
+                         'same JSON contract, scaling "strong" (the stream is the same whatever N is)')
     ap.add_argument('--plumbing-only', action='store_true',
                     help='CPU test aid for the N>1 control plane: rendezvous, barrier, max-over-ranks and the JSON line with NO '
                          'hot-path work and no value (tests/test_multiproc.py); never a measurement')
@@ -123,9 +127,134 @@ def launch_ranks(args):
 
 def main():
     args = parse_args()
+    if args.single_stream:
+        run_single_stream(args)
+        return
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(args))
     run_rank(args)
+
+
+def run_single_stream(args):
+    """`--single-stream --gpus N`: one process, N devices, ONE stream (seed 100).  Batch k of the stream is extracted on device k mod N
+    (frames resident in that device's HBM when the timed region starts: the pool is replicated), every frame is matched against its
+    predecessor -- inside a batch on its GPU, across a batch boundary after a host bounce -- and the batches come back in stream order.
+    A step is the same 2 048 frames as in the per-GPU-stream mode, so `value` is directly comparable; `scaling` is "strong"."""
+    import numpy as np
+    if 'WORLD_SIZE' in os.environ and int(os.environ.get('RANK', '0')) != 0:
+        return                                       # under a launcher: rank 0 drives every device, the others have nothing to do
+    os.environ.setdefault('ORBFE_POLL_WAIT_US', '50')
+    from os1_amd import api
+    from os1_amd import stream_workload as wl
+    n = args.gpus
+    if 'ORBFE_BENCH_DEVICE' in os.environ:           # testing aid: N runners on one GPU
+        devices = [int(os.environ['ORBFE_BENCH_DEVICE'])] * n
+    else:
+        devices = list(range(n))
+        if api.device_count() < n:
+            raise SystemExit('bench.py --single-stream --gpus %d: only %d GPU(s) visible (the product has no CPU fallback)' % (n, api.device_count()))
+    W, H, B = wl.W, wl.H, (args.batch or wl.SUBMIT)
+    assert args.pool % B == 0
+    passes = args.passes or wl.PASSES
+    step_frames = passes * args.pool
+    subs = step_frames // B
+    seed = wl.stream_seed(0)
+    frames = wl.StreamFrames(seed, W, H, args.pool).frames()
+    pools = {d: api.DeviceFrames(frames, d) for d in sorted(set(devices))}
+    depth = max(1, min(args.depth, 4))
+    st = api.MultiStream(wl.NFEAT, wl.SCALE, wl.NLEVELS, wl.INI_TH, wl.MIN_TH, devices, B, depth)
+    st.set_matching(wl.BOUNDS, 0 if args.no_match else wl.WINDOW, wl.NNRATIO, wl.CHECK_ORI)
+    pos = [0]
+    pending = collections.deque()
+    first = [True]
+    ahead = n * depth + 2
+
+    def push():
+        idx = [wl.pool_index(pos[0] + i, args.pool) for i in range(B)]
+        pending.append(pos[0])
+        pos[0] += B
+        pool = pools[st.device_of_next_push()]
+        st.push_ptrs([pool.ptrs[i] for i in idx], H, W, pool.stride, True)
+
+    nmatch = [0]
+    last_n = [0]
+    pop_times = []
+
+    def run(nb, on_pop=None):
+        pushed = 0
+        while pushed < min(ahead, nb):
+            push()
+            pushed += 1
+        for _ in range(nb):
+            res = st.pop()
+            pop_times.append(time.perf_counter())
+            p0 = pending.popleft()
+            if on_pop:
+                on_pop(p0, res, first[0])
+            first[0] = False
+            last_n[0] = int(res[2][-1])     # vnMatches12 of the next batch's first frame has this many entries
+            nmatch[0] += int(res[4].sum())
+            if pushed < nb:
+                push()
+                pushed += 1
+
+    def sync():
+        for d in sorted(set(devices)):
+            api.device_synchronize(d)
+
+    table = None if (args.no_verify or args.no_match or args.pool != wl.POOL) else load_digest_table(seed)
+    verify = {'verified': None}
+    if table:
+        verify = verify_period(wl, table, seed, B, lambda nb, cb: run(nb, cb))
+    t_end = time.perf_counter() + args.prewarm_seconds
+    while time.perf_counter() < t_end:
+        run(subs)
+    run(args.warmup * subs)
+    samples = []
+    every = -(-args.steps // 32)
+    popped = [0]
+
+    def sample(p0, res, fst):
+        popped[0] += 1
+        k, last = divmod(popped[0], subs)
+        if last == 0 and (k - 1) % every == 0 and table is not None:
+            samples.append((p0, tuple(a.copy() for a in res), last_n[0]))
+    del pop_times[:]
+    nmatch[0] = 0
+    sync()
+    t0 = time.perf_counter()
+    run(args.steps * subs, sample)
+    sync()
+    el = time.perf_counter() - t0
+    bad = []
+    checked = 0
+    if table is not None:
+        # a batch in the middle of the stream: its first frame's predecessor is the previous batch's last frame (the host bounce)
+        for p0, res, prev_n in samples:
+            chk = wl.PositionChecker(table)
+            chk.check(p0, *res, prev_n=prev_n, first_of_runner=False)
+            bad += chk.bad
+            checked += chk.frames
+        verify['timed_verified'] = not bad
+        verify['timed_frames_checked'] = checked
+        verify['verified'] = bool(verify.get('verified')) and not bad
+    fps = args.steps * step_frames / el
+    step_ms = np.diff(np.array(pop_times)[subs - 1::subs]) * 1e3 if len(pop_times) >= 3 * subs else None
+    out = {'metric': 'frames/sec extract+match, 1920x1080 @ 2000 ORB feats', 'value': round(fps, 2),
+           'value_p50': round(step_frames / (float(np.percentile(step_ms, 50)) * 1e-3), 2) if step_ms is not None and len(step_ms) > 1 else None,
+           'unit': 'frames/s', 'n_gpus': n, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(el / args.steps * 1e3, 4),
+           'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'u8', 'data': 'synthetic',
+           'config': {'workload': '1080p_2000feat_8lv_1.2_extract%s_ONE_stream_over_%d_devices' % ('' if args.no_match else '+SearchForInitialization', n),
+                      'frames_per_step': step_frames, 'frames_per_submission': B, 'distinct_frames': args.pool, 'devices': devices,
+                      'batches_in_flight_per_device': depth, 'parallelism': 'one stream, batch k -> device k mod N, in-order completion queue, '
+                      'host bounce of the batch-boundary predecessor (no collective)',
+                      'input': 'frames resident in HBM of the device their batch goes to (pool replicated per device)',
+                      'matches_per_frame': round(nmatch[0] / max(args.steps * step_frames, 1), 1), 'hip_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES')},
+           'verified': verify.get('verified'), 'verify': verify,
+           'roofline': None, 'cpu_baseline': None,
+           'note': 'single-stream mode (SURVEY.md s8(e)); the kernels are the per-GPU-stream mode\'s: its line carries roofline and cpu_baseline'}
+    st.close()
+    print(json.dumps(out), flush=True)
 
 
 def run_rank(args):

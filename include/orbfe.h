@@ -192,6 +192,10 @@ int orbfe_extract_batch_wait(orbfe_extractor* h);
 typedef struct orbfe_sfi_chain orbfe_sfi_chain;
 int orbfe_sfi_chain_create(const orbfe_extractor* h, orbfe_sfi_chain** out);
 void orbfe_sfi_chain_destroy(orbfe_sfi_chain* c);
+/* isolated != 0: every batch submitted with this chain stands alone -- its first frame has no predecessor (its match vector is all -1,
+ * its count 0) and its last frame is not handed on.  For callers that deal the batches of ONE stream to several devices and match the
+ * boundary pairs themselves (orbfe_stream_multi_*). */
+int orbfe_sfi_chain_set_isolated(orbfe_sfi_chain* c, int isolated);
 int orbfe_extract_batch_submit_matched(orbfe_extractor* h, orbfe_sfi_chain* chain, int nframes, const uint8_t* const* gray,
                                        int in_device_memory, int rows, int cols, size_t stride_bytes, const float bounds[4],
                                        int window_size, float nnratio, int check_orientation);
@@ -267,6 +271,9 @@ void orbfe_stream_destroy(orbfe_stream* s);
  * batch is in flight (every pushed batch popped); each batch carries the parameters in force at its push. */
 int orbfe_stream_set_matching(orbfe_stream* s, const float bounds[4], int window_size, float nnratio,
                               int check_orientation);
+/* isolated != 0: frame 0 of every pushed batch has no predecessor (orbfe_sfi_chain_set_isolated on the runner's chain); only while
+ * no batch is in flight. */
+int orbfe_stream_set_isolated_batches(orbfe_stream* s, int isolated);
 /* orbfe_extractor_set_input_format for every extractor of the runner (only while no batch is in flight). */
 int orbfe_stream_set_input_format(orbfe_stream* s, int format, int gray_variant);
 /* orbfe_extractor_set_blur_variant for every extractor of the runner (only while no batch is in flight). */
@@ -643,6 +650,32 @@ int orbfe_compute_image_bounds(int cols, int rows, int camera_mode, float fx, fl
 int orbfe_debug_features_in_area(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, int n, const float bounds[4],
                                  float x, float y, float r, int min_level, int max_level, int32_t* out, int cap,
                                  int* n_out);
+
+/* ---------------------------------------------------------------------------------------------
+ * ONE camera stream over several GPUs (the single-stream shape: "round-robin frames over GPUs with an in-order
+ * completion queue" -- what the reference itself is: one Video thread, one Tracking thread, frames strictly in order,
+ * src/main.cc:113-141, System.cc:115-152).  Batch k of the stream is extracted (and matched inside the batch) on device
+ * device_ids[k mod n] by an ordinary single-device runner with `depth` batches in flight; orbfe_stream_multi_pop returns the batches
+ * strictly in push order whatever order the devices finish in.  No collective, no device-to-device copy: the predecessor of a
+ * batch's FIRST frame (the previous batch's last frame, extracted on another device) takes a host bounce and that one pair per batch
+ * is matched by the host-array search on the batch's own device.  Results are identical to one orbfe_stream fed the same frames.
+ * A device may appear several times in device_ids (more batches in flight on it).  With in_device_memory != 0 the frames of a
+ * push must live on the device that push goes to: orbfe_stream_multi_device_of_next_push.
+ * Everything else as orbfe_stream_*: pointers returned by _pop stay valid until the next _pop; _set_* only while nothing is in flight;
+ * push from one thread, pop from one thread.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct orbfe_stream_multi orbfe_stream_multi;
+int orbfe_stream_multi_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, const int* device_ids,
+                              int n_devices, int batch, int depth, orbfe_stream_multi** out);
+void orbfe_stream_multi_destroy(orbfe_stream_multi* s);
+int orbfe_stream_multi_devices(const orbfe_stream_multi* s);
+int orbfe_stream_multi_capacity(const orbfe_stream_multi* s);
+int orbfe_stream_multi_device_of_next_push(const orbfe_stream_multi* s);
+int orbfe_stream_multi_set_matching(orbfe_stream_multi* s, const float bounds[4], int window_size, float nnratio, int check_orientation);
+int orbfe_stream_multi_set_blur_variant(orbfe_stream_multi* s, int variant);
+int orbfe_stream_multi_push(orbfe_stream_multi* s, const uint8_t* const* gray, int in_device_memory, int rows, int cols, size_t stride_bytes);
+int orbfe_stream_multi_pop(orbfe_stream_multi* s, const OrbfeKeyPoint** kps, const uint8_t** desc, const int** n_kps, const int32_t** matches12,
+                           const int** nmatches);
 
 #ifdef __cplusplus
 }

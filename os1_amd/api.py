@@ -158,6 +158,17 @@ def load_library():
     L.orbfe_stream_queue_slots.argtypes = [vp]
     L.orbfe_stream_push.argtypes = [vp, vp, ci, ci, ci, C.c_size_t]
     L.orbfe_stream_pop.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.orbfe_stream_set_isolated_batches.argtypes = [vp, ci]
+    L.orbfe_stream_multi_create.argtypes = [ci, cf, ci, ci, ci, C.POINTER(ci), ci, ci, ci, C.POINTER(vp)]
+    L.orbfe_stream_multi_destroy.argtypes = [vp]
+    L.orbfe_stream_multi_destroy.restype = None
+    L.orbfe_stream_multi_devices.argtypes = [vp]
+    L.orbfe_stream_multi_capacity.argtypes = [vp]
+    L.orbfe_stream_multi_device_of_next_push.argtypes = [vp]
+    L.orbfe_stream_multi_set_matching.argtypes = [vp, vp, ci, cf, ci]
+    L.orbfe_stream_multi_set_blur_variant.argtypes = [vp, ci]
+    L.orbfe_stream_multi_push.argtypes = [vp, vp, ci, ci, ci, C.c_size_t]
+    L.orbfe_stream_multi_pop.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.orbfe_stream_stats.argtypes = [vp, vp, ci]
     L.orbfe_stream_kernel_ms.argtypes = [vp, vp, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), ci]
     L.orbfe_debug_quadtree.argtypes = [vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, ci, C.POINTER(ci)]
@@ -1075,6 +1086,10 @@ class Stream:
         return (view(pk, KP_DTYPE, (B, cap)), view(pd, np.uint8, (B, cap, 32)), view(pn, np.int32, (B,)),
                 view(pm, np.int32, (B, cap)), view(pnm, np.int32, (B,)))
 
+    def set_isolated_batches(self, on=True):
+        """Frame 0 of every batch has no predecessor (orbfe_stream_set_isolated_batches)."""
+        _check(self.L.orbfe_stream_set_isolated_batches(self.h, int(on)))
+
     def stats(self, reset=False):
         """{submit, collect, match} worker busy ms and batches done since the last reset."""
         out = np.zeros(4, np.float64)
@@ -1086,3 +1101,59 @@ class Stream:
         b, f = C.c_longlong(0), C.c_longlong(0)
         _check(self.L.orbfe_stream_kernel_ms(self.h, _p(ms), C.byref(b), C.byref(f), int(reset)))
         return ms, b.value, f.value
+
+
+class MultiStream:
+    """ONE stream over several devices (orbfe_stream_multi_*): batch k goes to devices[k % n], pop() returns the batches strictly in
+    push order.  `devices` may name a device several times."""
+
+    def __init__(self, nfeatures, scale, nlevels, ini_th, min_th, devices, batch, depth=2):
+        self.L = load_library()
+        h = C.c_void_p()
+        ids = (C.c_int * len(devices))(*devices)
+        _check(self.L.orbfe_stream_multi_create(nfeatures, scale, nlevels, ini_th, min_th, ids, len(devices), batch, depth, C.byref(h)))
+        self.h = h
+        self.batch = batch
+        self.devices = list(devices)
+        self.cap = self.L.orbfe_stream_multi_capacity(h)
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.L.orbfe_stream_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_matching(self, bounds, window=100, nnratio=0.9, check_ori=True):
+        b = np.asarray(bounds, np.float32)
+        _check(self.L.orbfe_stream_multi_set_matching(self.h, _p(b), window, nnratio, int(check_ori)))
+
+    def set_blur_variant(self, variant):
+        _check(self.L.orbfe_stream_multi_set_blur_variant(self.h, int(variant)))
+
+    def device_of_next_push(self):
+        return int(self.L.orbfe_stream_multi_device_of_next_push(self.h))
+
+    def push_ptrs(self, ptrs, rows, cols, stride, on_device=True):
+        assert len(ptrs) == self.batch
+        arr = (C.c_void_p * self.batch)(*ptrs)
+        _check(self.L.orbfe_stream_multi_push(self.h, arr, int(on_device), rows, cols, stride))
+        self.cap = self.L.orbfe_stream_multi_capacity(self.h)
+
+    def pop(self, copy=False):
+        """-> (kps[B,cap], desc[B,cap,32], n[B], matches12[B,cap], nmatches[B]) as views valid until the next pop."""
+        pk, pd, pn, pm, pnm = (C.c_void_p() for _ in range(5))
+        _check(self.L.orbfe_stream_multi_pop(self.h, C.byref(pk), C.byref(pd), C.byref(pn), C.byref(pm), C.byref(pnm)))
+        B, cap = self.batch, self.cap
+
+        def view(ptr, dtype, shape):
+            n = int(np.prod(shape))
+            buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr.value)
+            a = np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+            return a.copy() if copy else a
+        return (view(pk, KP_DTYPE, (B, cap)), view(pd, np.uint8, (B, cap, 32)), view(pn, np.int32, (B,)),
+                view(pm, np.int32, (B, cap)), view(pnm, np.int32, (B,)))

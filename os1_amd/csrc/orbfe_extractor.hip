@@ -128,6 +128,7 @@ struct orbfe_sfi_chain {
   DevBuf<uint32_t> count;      // [0],[1]: level-0 count of the buffers; [2]: constant 0xffffffff ("none")
   hipEvent_t ready[2] = {};
   long long seq = 0;           // batches submitted so far
+  bool isolated = false;       // orbfe_sfi_chain_set_isolated: no batch has a predecessor (frame 0 of every batch reports no match)
   // host-quadtree route (geometries outside the GPU quadtree's limits): the predecessor frame lives on the host and the
   // searches go through an ordinary matcher handle
   orbfe_matcher* hostMatcher = nullptr;
@@ -847,20 +848,23 @@ struct orbfe_extractor {
       SP.selPerFrame = selPerFrame; SP.n0cap = n0cap; SP.frameBase = 0;
       const int prev = (int)((ch.seq + 1) & 1), cur = (int)(ch.seq & 1);   // buffer written by the previous / this batch
       SP.carrySel = ch.sel[prev].p; SP.carryAngle = ch.angle[prev].p; SP.carryDesc = ch.desc[prev].p;
-      SP.carryCount = ch.count.p + (ch.seq == 0 ? 2 : prev);
+      const bool iso = ch.isolated;   // every batch stands alone: no carry in, no carry out
+      SP.carryCount = ch.count.p + ((ch.seq == 0 || iso) ? 2 : prev);
       SP.minX = ms->bounds[0]; SP.minY = ms->bounds[2];
       SP.invW = static_cast<float>(64) / static_cast<float>(ms->bounds[1] - ms->bounds[0]);   // Frame.cc:98
       SP.invH = static_cast<float>(48) / static_cast<float>(ms->bounds[3] - ms->bounds[2]);   // Frame.cc:99
       SP.window = (float)ms->window; SP.nnratio = ms->nnratio; SP.checkOri = ms->checkOri;
       SP.order = d_sfiOrder.p; SP.orderCount = d_sfiOrderCount.p; SP.pool = d_sfiPool.p; SP.pcount = d_sfiPcount.p;
       SP.matches12 = d_m12.p; SP.nmatches = d_nm.p;
-      if (ch.seq > 0) HIP_TRY(hipStreamWaitEvent(st, ch.ready[prev], 0));
+      if (ch.seq > 0 && !iso) HIP_TRY(hipStreamWaitEvent(st, ch.ready[prev], 0));
       launch_sfi(SP, nframes, st);
       HIP_TRY(hipGetLastError());
-      // hand the last frame's level-0 data to the next batch
-      launch_sfi_carry(SP, nframes - 1, ch.sel[cur].p, ch.angle[cur].p, ch.desc[cur].p, ch.count.p + cur, st);
-      HIP_TRY(hipGetLastError());
-      HIP_TRY(hipEventRecord(ch.ready[cur], st));
+      if (!iso) {
+        // hand the last frame's level-0 data to the next batch
+        launch_sfi_carry(SP, nframes - 1, ch.sel[cur].p, ch.angle[cur].p, ch.desc[cur].p, ch.count.p + cur, st);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ch.ready[cur], st));
+      }
       ch.seq++;
       pendingMatched = true;
     }
@@ -1693,6 +1697,13 @@ int orbfe_sfi_chain_create(const orbfe_extractor* h, orbfe_sfi_chain** out) {
 
 void orbfe_sfi_chain_destroy(orbfe_sfi_chain* c) { delete c; }
 
+int orbfe_sfi_chain_set_isolated(orbfe_sfi_chain* c, int isolated) {
+  if (!c) { set_err("chain is NULL"); return ORBFE_ERR_INVALID; }
+  c->isolated = isolated != 0;
+  if (c->isolated) c->hostPrevValid = false;
+  return ORBFE_OK;
+}
+
 int orbfe_extract_batch_submit_matched(orbfe_extractor* h, orbfe_sfi_chain* chain, int nframes, const uint8_t* const* gray,
                                        int in_device_memory, int rows, int cols, size_t stride_bytes, const float bounds[4],
                                        int window_size, float nnratio, int check_orientation) {
@@ -1721,7 +1732,7 @@ int orbfe_extract_batch_submit_matched(orbfe_extractor* h, orbfe_sfi_chain* chai
       const uint8_t* pd;
       int pn;
       if (f == 0) {
-        if (!chain->hostPrevValid) continue;   // very first frame of the stream: no predecessor
+        if (!chain->hostPrevValid || chain->isolated) continue;   // very first frame of the stream (or isolated batches): no predecessor
         pk = chain->hostPrevKps.data(); pd = chain->hostPrevDesc.data(); pn = (int)chain->hostPrevKps.size();
       } else {
         pk = h->defKps.data() + (size_t)(f - 1) * cap; pd = h->defDesc.data() + (size_t)(f - 1) * cap * 32; pn = h->defN[f - 1];
@@ -1745,7 +1756,7 @@ int orbfe_extract_batch_submit_matched(orbfe_extractor* h, orbfe_sfi_chain* chai
     const int last = nframes - 1, ln = h->defN[last];
     chain->hostPrevKps.assign(h->defKps.begin() + (size_t)last * cap, h->defKps.begin() + (size_t)last * cap + ln);
     chain->hostPrevDesc.assign(h->defDesc.begin() + (size_t)last * cap * 32, h->defDesc.begin() + ((size_t)last * cap + ln) * 32);
-    chain->hostPrevValid = true;
+    chain->hostPrevValid = !chain->isolated;
     h->deferredMatched = true;
     return ORBFE_OK;
   }

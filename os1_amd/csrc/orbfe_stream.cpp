@@ -71,6 +71,7 @@ struct orbfe_stream {
   std::vector<orbfe_matcher*> matchers;   // one per match worker (host-side matching path)
   orbfe_sfi_chain* chain = nullptr;       // GPU-resident matching path (default)
   bool gpuMatch = true;
+  bool isolated = false;                  // orbfe_stream_set_isolated_batches: frame 0 of a batch has no predecessor
   std::vector<Slot> slots;
   void growSlots(int nslots) {     // caller holds no batch in flight (or is the constructor)
     const int old = (int)slots.size();
@@ -173,8 +174,8 @@ struct orbfe_stream {
         if (s.status != ORBFE_OK) s.err = orbfe_last_error();
       }
       if (s.status == ORBFE_OK) {
-        s.prevN = lastN;
-        if (lastN >= 0) { s.prevKps = lastKps; s.prevDesc = lastDesc; }
+        s.prevN = isolated ? -1 : lastN;
+        if (s.prevN >= 0) { s.prevKps = lastKps; s.prevDesc = lastDesc; }
         lastN = s.n[batch - 1];
         lastKps.assign(s.kps.begin() + (size_t)(batch - 1) * cap, s.kps.begin() + (size_t)(batch - 1) * cap + lastN);
         lastDesc.assign(s.desc.begin() + (size_t)(batch - 1) * cap * 32, s.desc.begin() + ((size_t)(batch - 1) * cap + lastN) * 32);
@@ -363,6 +364,15 @@ int orbfe_stream_set_matching(orbfe_stream* s, const float bounds[4], int window
   s->nnratio = nnratio;
   s->checkOri = check_orientation;
   return ORBFE_OK;
+}
+
+int orbfe_stream_set_isolated_batches(orbfe_stream* s, int isolated) {
+  if (!s) { set_err("invalid arguments"); return ORBFE_ERR_INVALID; }
+  std::lock_guard<std::mutex> lk(s->mu);
+  if (s->pushSeq != s->popSeq) { set_err("batches are still in flight"); return ORBFE_ERR_INVALID; }
+  s->isolated = isolated != 0;
+  s->lastN = -1;
+  return orbfe_sfi_chain_set_isolated(s->chain, isolated);
 }
 
 int orbfe_stream_set_input_format(orbfe_stream* s, int format, int gray_variant) {

@@ -129,6 +129,89 @@ def test_host_input_stream_against_digests(api):
     assert hasher.steps == _steps(100, 4)[0]
 
 
+def _run_multi(api, seed, nsub, devices, depth=2, batch=wl.SUBMIT, source='hbm'):
+    """The same walk through orbfe_stream_multi_*: batch k on devices[k % n], results popped in push order."""
+    sf = wl.StreamFrames(seed)
+    idx = [wl.pool_index(p) for p in range(nsub * batch)]
+    frames = {i: sf.frame(i) for i in sorted(set(idx))}
+    order = sorted(frames)
+    stack = [frames[i] for i in order]
+    pools = {}
+    for d in sorted(set(devices)):       # resident frames must live on the device their batch goes to
+        pool = api.DeviceFrames(stack, d) if source == 'hbm' else api.PinnedFrames(stack)
+        pools[d] = {i: pool.ptrs[k] for k, i in enumerate(order)}
+        pools[d]['_keep'] = pool
+    st = api.MultiStream(wl.NFEAT, wl.SCALE, wl.NLEVELS, wl.INI_TH, wl.MIN_TH, devices, batch, depth)
+    st.set_matching(wl.BOUNDS, wl.WINDOW, wl.NNRATIO, wl.CHECK_ORI)
+    pushed = 0
+
+    def push():
+        nonlocal pushed
+        at = pools[st.device_of_next_push()]
+        st.push_ptrs([at[i] for i in idx[pushed * batch:(pushed + 1) * batch]], wl.H, wl.W, wl.W, source == 'hbm')
+        pushed += 1
+    ahead = len(devices) * depth
+    while pushed < min(ahead, nsub):
+        push()
+    out = []
+    for _ in range(nsub):
+        out.append(st.pop(copy=True))
+        if pushed < nsub:
+            push()
+    st.close()
+    return out
+
+
+@pytest.mark.parametrize('devices,depth', [([0, 0, 0, 0], 2), ([0], 3), ([0, 0, 0], 1)])
+def test_single_stream_over_several_runners_against_digests(api, devices, depth):
+    """SURVEY.md s8(e), the single-stream shape: ONE camera stream dealt batch by batch to n device runners (here all on the one GPU of
+    the test box: device_ids = [0, 0, 0, 0] is what an 8-GPU node runs with [0..7]), results in push order, the SearchForInitialization
+    predecessor of every batch's first frame bounced over the host.  Stream 100, the whole forwards-and-backwards period, position by
+    position against the committed digests -- the same bytes one single-device runner returns."""
+    nsub = -(-(wl.PERIOD + 2) // wl.SUBMIT)
+    got = _run_multi(api, 100, nsub, devices, depth)
+    chk = wl.PositionChecker(_table(100))
+    hasher = wl.StepHasher()
+    for s, res in enumerate(got):
+        chk.check(s * wl.SUBMIT, *res, first_of_runner=(s == 0))
+        hasher.add(*res)
+    assert not chk.bad, chk.bad[:10]
+    assert chk.frames == nsub * wl.SUBMIT and len(chk.positions) == wl.PERIOD
+    want, total = _steps(100, nsub * wl.SUBMIT // wl.BATCH)
+    assert hasher.steps == want and hasher.nmatches == total == chk.nmatches
+
+
+def test_single_stream_runner_edge_cases(api):
+    """Host frames through the multi-device runner, matching switched off and on again between idle phases, a pop without a push, and
+    a runner destroyed with batches still in flight."""
+    got = _run_multi(api, 100, 3, [0, 0], depth=2, batch=wl.BATCH, source='pinned')
+    hasher = wl.StepHasher()
+    for res in got:
+        hasher.add(*res)
+    assert hasher.steps == _steps(100, 3)[0]
+    sf = wl.StreamFrames(100)
+    dev = api.DeviceFrames([sf.frame(i) for i in range(8)], 0)
+    st = api.MultiStream(wl.NFEAT, wl.SCALE, wl.NLEVELS, wl.INI_TH, wl.MIN_TH, [0, 0], 4, 1)
+    with pytest.raises(Exception):
+        st.pop()
+    st.set_matching(wl.BOUNDS, 0, wl.NNRATIO, wl.CHECK_ORI)            # extraction only
+    st.push_ptrs(dev.ptrs[0:4], wl.H, wl.W, dev.stride, True)
+    st.push_ptrs(dev.ptrs[4:8], wl.H, wl.W, dev.stride, True)
+    a = st.pop(copy=True)
+    b = st.pop(copy=True)
+    assert (a[4] == 0).all() and (b[4] == 0).all()
+    st.set_matching(wl.BOUNDS, wl.WINDOW, wl.NNRATIO, wl.CHECK_ORI)    # ... and with matching: same keypoints; the stream goes on, so every frame has a predecessor
+    st.push_ptrs(dev.ptrs[0:4], wl.H, wl.W, dev.stride, True)
+    st.push_ptrs(dev.ptrs[4:8], wl.H, wl.W, dev.stride, True)
+    c = st.pop(copy=True)
+    d = st.pop(copy=True)
+    assert c[0].tobytes() == a[0].tobytes() and d[1].tobytes() == b[1].tobytes()
+    assert (c[4] > 0).all() and (d[4] > 0).all()      # (frame 0 of `c` against the last frame of `b`, frame 0 of `d` against the last of `c`: over the host)
+    st.push_ptrs(dev.ptrs[0:4], wl.H, wl.W, dev.stride, True)          # never popped
+    st.push_ptrs(dev.ptrs[4:8], wl.H, wl.W, dev.stride, True)
+    st.close()
+
+
 def _bench(args, extra_env=None):
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
     env.update(extra_env or {})
@@ -220,3 +303,15 @@ def test_stream_create_warns_about_hardware_queues(api):
     for extra in ({'GPU_MAX_HW_QUEUES': '8'}, {'ORBFE_QUIET': '1'}):
         r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=dict(base, **extra))
         assert r.returncode == 0 and 'liborbfe: orbfe_stream_create' not in r.stderr
+
+
+def test_bench_single_stream_mode_on_one_gpu(api):
+    """`bench.py --single-stream --gpus 4` with the four device runners on the one GPU of the test box: the same JSON contract, the
+    whole period verified before timing and the sampled batches of the timed region (mid-stream batches: their first frame's predecessor
+    came over the host) verified after it."""
+    line = _bench(['--single-stream', '--gpus', '4', '--steps', '3', '--warmup', '1', '--prewarm-seconds', '0.2', '--depth', '2'],
+                  {'ORBFE_BENCH_DEVICE': '0'})
+    assert line['n_gpus'] == 4 and line['scaling'] == 'strong' and line['unit'] == 'frames/s' and line['value'] > 1000
+    assert line['verified'] is True and line['verify']['distinct_period_positions'] == wl.PERIOD
+    assert line['verify']['timed_verified'] is True and line['verify']['timed_frames_checked'] >= 3 * wl.SUBMIT
+    assert line['config']['devices'] == [0, 0, 0, 0]

@@ -244,3 +244,18 @@ def test_position_checker_finds_what_step_digests_cannot_place():
     for p0 in range(0, 12, 4):
         b.check(p0, *batch(p0, 4), first_of_runner=(p0 == 0))
     assert a.outputs_sha256(10) == b.outputs_sha256(10) and a.outputs_sha256(10) != a.outputs_sha256(9)
+
+
+def test_inorder_gate_under_shuffled_completion(tmp_path):
+    """The in-order completion queue of the multi-device stream runner (os1_amd/csrc/inorder_gate.h, SURVEY.md s8(e): "round-robin
+    frames over GPUs with an in-order completion queue"): producers finish in shuffled order, the consumer sees 0, 1, 2, ...; nothing is
+    recycled while the consumer holds it; closing the gate releases every waiter.  Host only."""
+    import os
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / 'inorder_gate_test')
+    subprocess.check_call(['g++', '-std=c++17', '-O1', '-Wall', '-Werror', '-pthread', '-I' + os.path.join(ROOT, 'os1_amd', 'csrc'),
+                           os.path.join(ROOT, 'tests', 'cpp', 'inorder_gate_test.cpp'), '-o', exe])
+    for lanes, total in ((1, 60), (2, 300), (4, 400), (8, 800)):
+        r = subprocess.run([exe, str(lanes), str(total)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, (lanes, r.stdout, r.stderr)

@@ -11,6 +11,7 @@ for f in orbfe_kernels orbfe_fast orbfe_quadtree orbfe_sfi orbfe_extractor orbfe
   objs="$objs ../../build/exp/$f.o"
 done
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -Wall -DORBFE_EXPERIMENTS -c -o ../../build/exp/orbfe_stream.o orbfe_stream.cpp &
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -Wall -DORBFE_EXPERIMENTS -c -o ../../build/exp/orbfe_stream_multi.o orbfe_stream_multi.cpp &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../liborbfe_exp.so $objs ../../build/exp/orbfe_stream.o -lpthread
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../liborbfe_exp.so $objs ../../build/exp/orbfe_stream.o ../../build/exp/orbfe_stream_multi.o -lpthread
 echo built os1_amd/liborbfe_exp.so
