@@ -354,6 +354,7 @@ def run_rank(args):
         from os1_amd.synth import synth_vocabulary
         voc = api.Vocabulary(synth_vocabulary(1, 10, 6), local_rank)
     st = make_runner(args.depth)
+    head_in_flight = st.batches_in_flight()   # what the runner settled on (fewer than --depth when the process has too few hardware queues)
 
     pos = [0]                                   # stream position of the next pushed frame
     pending = collections.deque()               # first stream position of every batch pushed and not yet popped
@@ -689,7 +690,7 @@ def run_rank(args):
                                  'pageable': 'frames in pageable host memory (PCIe-inclusive)'}[head_source] + '; keypoints/descriptors/matches returned to host',
                        'value_is': ('the RESIDENT rate (frames in HBM when the timed region starts, the bench contract); SURVEY.md s8(d) puts the H2D of every '
                                     'frame inside its metric: that figure is pcie_inclusive.value' if head_source == 'hbm' else 'a PCIe-inclusive rate (developer run)'),
-                       'batches_in_flight': max(1, args.depth), 'hip_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES'),
+                       'batches_in_flight': head_in_flight, 'batches_in_flight_asked': max(1, args.depth), 'hip_hw_queues': os.environ.get('GPU_MAX_HW_QUEUES'),
                        'worker_wait': 'spin' if wait_mode == '0' else 'sleep-poll %s us' % wait_mode,
                        'numa': {'node_of_gpu': numa_node, 'cpus_bound': numa_cpus}},
             'verified': verify['verified'], 'outputs_sha256': verify['outputs_sha256'], 'verify': verify,

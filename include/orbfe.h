@@ -258,10 +258,11 @@ int orbfe_debug_sincos_host_check(uint32_t lo_bits, uint32_t hi_bits, uint32_t s
 typedef struct orbfe_stream orbfe_stream;
 /* batch = frames per push; depth = extraction batches in flight (1..8).
  * HARDWARE QUEUES: each batch in flight has its own HIP stream and the HIP runtime folds a process's streams onto GPU_MAX_HW_QUEUES
- * hardware queues (default 4); two streams that share a queue serialise.  depth >= 4 therefore needs the ENVIRONMENT variable
- * GPU_MAX_HW_QUEUES=8, set before the process makes its first HIP call (the runtime reads it once at start-up: a library cannot set
- * it for its host process; bench.py sets it before importing torch).  Without it depth 4 runs at the rate of depth 3 (63.6 k instead of
- * 66.7 k frames/s when measured); orbfe_stream_create says so on stderr once (ORBFE_QUIET=1 silences it). */
+ * hardware queues (4 unless the ENVIRONMENT variable said otherwise before the process's first HIP call: the runtime reads it once,
+ * a library cannot set it for its host process; bench.py sets 8 before importing torch).  Two streams that share a queue serialise,
+ * so the runner measures at creation how many of its streams run side by side (about a millisecond) and keeps that many batches
+ * in flight: 3 in a process with the default 4 queues (0.97 of the rate of depth 4 on 8 queues), `depth` where the queues are there.
+ * orbfe_stream_batches_in_flight reports the number; a line on stderr says so once (ORBFE_QUIET=1 silences it). */
 int orbfe_stream_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device_id,
                         int batch, int depth, orbfe_stream** out);
 /* Batches the GPU is working on are waited for; batches still queued are dropped without being submitted.  Frames of
@@ -274,6 +275,7 @@ int orbfe_stream_set_matching(orbfe_stream* s, const float bounds[4], int window
 /* isolated != 0: frame 0 of every pushed batch has no predecessor (orbfe_sfi_chain_set_isolated on the runner's chain); only while
  * no batch is in flight. */
 int orbfe_stream_set_isolated_batches(orbfe_stream* s, int isolated);
+int orbfe_stream_batches_in_flight(const orbfe_stream* s);
 /* orbfe_extractor_set_input_format for every extractor of the runner (only while no batch is in flight). */
 int orbfe_stream_set_input_format(orbfe_stream* s, int format, int gray_variant);
 /* orbfe_extractor_set_blur_variant for every extractor of the runner (only while no batch is in flight). */

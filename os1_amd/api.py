@@ -159,6 +159,7 @@ def load_library():
     L.orbfe_stream_push.argtypes = [vp, vp, ci, ci, ci, C.c_size_t]
     L.orbfe_stream_pop.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.orbfe_stream_set_isolated_batches.argtypes = [vp, ci]
+    L.orbfe_stream_batches_in_flight.argtypes = [vp]
     L.orbfe_stream_multi_create.argtypes = [ci, cf, ci, ci, ci, C.POINTER(ci), ci, ci, ci, C.POINTER(vp)]
     L.orbfe_stream_multi_destroy.argtypes = [vp]
     L.orbfe_stream_multi_destroy.restype = None
@@ -1085,6 +1086,10 @@ class Stream:
             return a.copy() if copy else a
         return (view(pk, KP_DTYPE, (B, cap)), view(pd, np.uint8, (B, cap, 32)), view(pn, np.int32, (B,)),
                 view(pm, np.int32, (B, cap)), view(pnm, np.int32, (B,)))
+
+    def batches_in_flight(self):
+        """Batches the runner keeps on the GPU at a time: `depth`, or fewer when the process has fewer hardware queues than that."""
+        return int(self.L.orbfe_stream_batches_in_flight(self.h))
 
     def set_isolated_batches(self, on=True):
         """Frame 0 of every batch has no predecessor (orbfe_stream_set_isolated_batches)."""

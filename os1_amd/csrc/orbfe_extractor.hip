@@ -42,6 +42,7 @@ void launch_compact_local(const PyramidParams& P, int nframes, hipStream_t st, i
 void launch_describe(const PyramidParams& P, const SelKp* sel, int nsel, float* angle, uint8_t* desc,
                      hipStream_t st);
 void launch_sincos(const float* deg, int n, float* c, float* s, hipStream_t st);
+void launch_spin(unsigned long long ticks, hipStream_t st);
 void launch_describe_slots(const PyramidParams& P, const SelKp* sel, int nslots, float* angle, uint8_t* desc,
                            const uint32_t* selCount, int selPerFrame, const int* selOff, hipStream_t st, bool fourWaves);
 int launch_quadtree(const QtParams& Q, int nframes, hipStream_t st, int ldsBudget);
@@ -1473,6 +1474,31 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
 void orbfe_extractor_destroy(orbfe_extractor* h) { delete h; }
 int orbfe_extractor_levels(const orbfe_extractor* h) { return h ? h->nlevels : 0; }
 int orbfe_extractor_device(const orbfe_extractor* h) { return h ? h->device : -1; }
+
+// How many of the first n handles' streams run SIDE BY SIDE?  The HIP runtime folds a process's streams onto GPU_MAX_HW_QUEUES hardware
+// queues (4 unless the variable said otherwise before the runtime started) and two streams on one queue serialise -- a property of the
+// process no API reports, so it is measured: a 200 us do-nothing kernel on each of the first k streams finishes in about 200 us when the k
+// streams have queues of their own and in 400 us when two of them share one.  Returns the largest k <= n for which they all overlap
+// (at least 1), or a negative error code.  About a millisecond, once per runner (orbfe_stream_create).
+extern "C++" int orbfe_concurrent_streams(orbfe_extractor* const* hs, int n) {
+  if (!hs || n < 1) return ORBFE_ERR_INVALID;
+  HIP_TRY(hipSetDevice(hs[0]->device));
+  constexpr unsigned long long kTicks = 20000;   // 200 us of the 100 MHz reference clock
+  for (int i = 0; i < n; i++) launch_spin(100, hs[i]->streams[0]);   // (code object loaded, queues created)
+  for (int i = 0; i < n; i++) HIP_TRY(hipStreamSynchronize(hs[i]->streams[0]));
+  for (int k = n; k > 1; k--) {
+    double best = 1e30;
+    for (int rep = 0; rep < 2; rep++) {
+      const double t0 = now_ms();
+      for (int i = 0; i < k; i++) launch_spin(kTicks, hs[i]->streams[0]);
+      HIP_TRY(hipGetLastError());
+      for (int i = 0; i < k; i++) HIP_TRY(hipStreamSynchronize(hs[i]->streams[0]));
+      best = std::min(best, now_ms() - t0);
+    }
+    if (best < 0.2 * 1.6) return k;   // all k side by side (two on one queue: >= 0.4 ms)
+  }
+  return 1;
+}
 extern "C++" { namespace orbfe { int fast_stamps(unsigned long long out[8], int reset); } }
 int orbfe_debug_fast_stamps(orbfe_extractor* h, unsigned long long out[8], int reset) {
   if (!h || !out) { set_err("NULL argument"); return ORBFE_ERR_INVALID; }

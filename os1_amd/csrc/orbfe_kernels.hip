@@ -1452,6 +1452,18 @@ void launch_describe_slots(const PyramidParams& P, const SelKp* sel, int nslots,
   }
 }
 
+// One wave that does nothing for `ticks` periods of the 100 MHz reference clock: the stream runner's probe of how many of its HIP
+// streams the runtime lets run side by side (streams folded onto one hardware queue serialise).
+__global__ void k_spin(unsigned long long ticks, unsigned* sink) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  unsigned n = 0;
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) { __builtin_amdgcn_s_sleep(32); n++; }
+  if (sink && n == 0xffffffffu) *sink = n;
+}
+void launch_spin(unsigned long long ticks, hipStream_t st) {
+  hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, st, ticks, (unsigned*)nullptr);
+}
+
 void launch_sincos(const float* deg, int n, float* c, float* s, hipStream_t st) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_sincos, dim3((n + 255) / 256), dim3(256), 0, st, deg, n, c, s);

@@ -31,6 +31,7 @@
 namespace orbfe {
 void set_err(const char* fmt, ...);
 }
+int orbfe_concurrent_streams(orbfe_extractor* const* hs, int n);   // orbfe_extractor.hip
 using orbfe::set_err;
 
 namespace {
@@ -64,6 +65,7 @@ struct Slot {
 
 struct orbfe_stream {
   int batch = 0, depth = 0, cap = 0, device = 0;
+  int inFlight = 0;   // batches on the GPU at a time: depth, or fewer when the process has fewer hardware queues than that (orbfe_stream_create)
   int window = 100, checkOri = 1;
   float nnratio = 0.9f;
   float bounds[4] = {0, 0, 0, 0};
@@ -125,7 +127,7 @@ struct orbfe_stream {
         // only batches the GPU is working on are waited for
         if (stop) extractQ.clear();
         if (stop && inflight.empty()) return;
-        if (!extractQ.empty() && (int)inflight.size() < depth) {
+        if (!extractQ.empty() && (int)inflight.size() < inFlight) {
           job = extractQ.front();
           extractQ.pop_front();
         }
@@ -271,19 +273,6 @@ int orbfe_stream_create(int nfeatures, float scaleFactor, int nlevels, int iniTh
                         int batch, int depth, orbfe_stream** out) {
   if (!out || batch < 1 || depth < 1 || depth > 8) { set_err("invalid stream parameters"); return ORBFE_ERR_INVALID; }
   *out = nullptr;
-  {
-    // `depth` batches in flight run on `depth` HIP streams (+ the upload lane): the runtime folds streams onto GPU_MAX_HW_QUEUES hardware
-    // queues (default 4) and two streams on one queue serialise.  The variable is read by the HIP runtime at ITS start-up -- the library
-    // cannot set it for the process it is loaded into; say so once (measured: 66.7 k frames/s with 8 queues, 63.6 k with the default at
-    // depth 4).
-    static bool warned = false;
-    const char* q = getenv("GPU_MAX_HW_QUEUES");
-    if (depth >= 4 && (!q || atoi(q) < 8) && !warned && !getenv("ORBFE_QUIET")) {
-      warned = true;
-      fprintf(stderr, "liborbfe: orbfe_stream_create(depth = %d) with GPU_MAX_HW_QUEUES=%s: %d batches in flight need 8 hardware queues to overlap; "
-                      "export GPU_MAX_HW_QUEUES=8 before the process starts (or use depth <= 3)\n", depth, q ? q : "unset (4)", depth);
-    }
-  }
   orbfe_stream* s = new orbfe_stream();
   s->batch = batch;
   s->depth = depth;
@@ -326,6 +315,35 @@ int orbfe_stream_create(int nfeatures, float scaleFactor, int nlevels, int iniTh
       for (auto* q : s->matchers) orbfe_matcher_destroy(q);
       delete s;
       return rc;
+    }
+  }
+  // `depth` batches in flight run on `depth` HIP streams, and the HIP runtime folds a process's streams onto GPU_MAX_HW_QUEUES hardware
+  // queues (4 unless the variable said otherwise BEFORE the runtime started -- a library cannot set it for the process it is loaded
+  // into); two streams on one queue serialise, and a fourth batch that waits behind the first on its queue costs more than it
+  // overlaps (87.9 k frames/s at depth 4 on 4 queues against 89.8 k at depth 3; 93.0 k at depth 4 on 8 queues: gpurun r06j,
+  // DESIGN.md s6).  So the runner MEASURES how many of its streams run side by side and keeps that many batches in flight.
+  s->inFlight = depth;
+  if (depth > 1) {
+    const int k = orbfe_concurrent_streams(s->ext.data(), depth);
+    if (k < 0) {
+      for (auto* e : s->ext) orbfe_extractor_destroy(e);
+      for (auto* q : s->matchers) orbfe_matcher_destroy(q);
+      orbfe_sfi_chain_destroy(s->chain);
+      delete s;
+      return k;
+    }
+    s->inFlight = k;
+    while ((int)s->ext.size() > k) {   // the handles whose streams share a queue are not used (nor their memory kept)
+      orbfe_extractor_destroy(s->ext.back());
+      s->ext.pop_back();
+    }
+    static bool said = false;
+    if (k < depth && !said && !getenv("ORBFE_QUIET")) {
+      said = true;
+      const char* q = getenv("GPU_MAX_HW_QUEUES");
+      fprintf(stderr, "liborbfe: orbfe_stream_create(depth = %d): only %d of the runner's streams run side by side in this process (GPU_MAX_HW_QUEUES=%s), "
+                      "so %d batches are kept in flight; export GPU_MAX_HW_QUEUES=8 before the process starts for the last 3 %%\n",
+              depth, k, q ? q : "unset: 4", k);
     }
   }
   s->cap = orbfe_extractor_max_keypoints(s->ext[0]);
@@ -424,6 +442,7 @@ int orbfe_stream_bow_raw(orbfe_stream* s, int frame, const uint32_t** leaf_node,
 }
 
 int orbfe_stream_capacity(const orbfe_stream* s) { return s ? s->cap : 0; }
+int orbfe_stream_batches_in_flight(const orbfe_stream* s) { return s ? s->inFlight : 0; }
 
 int orbfe_stream_set_queue_slots(orbfe_stream* s, int nslots) {
   if (!s) { set_err("stream is NULL"); return ORBFE_ERR_INVALID; }

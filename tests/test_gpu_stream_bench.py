@@ -315,3 +315,17 @@ def test_bench_single_stream_mode_on_one_gpu(api):
     assert line['verified'] is True and line['verify']['distinct_period_positions'] == wl.PERIOD
     assert line['verify']['timed_verified'] is True and line['verify']['timed_frames_checked'] >= 3 * wl.SUBMIT
     assert line['config']['devices'] == [0, 0, 0, 0]
+
+
+def test_runner_adapts_to_the_default_four_hardware_queues(api):
+    """The stream runner needs no environment variable to be right: in a process whose HIP runtime has the DEFAULT four hardware
+    queues (GPU_MAX_HW_QUEUES=4 here, because bench.py exports 8 unless the caller said otherwise) a runner asked for four batches in
+    flight measures that only three of its streams run side by side, keeps three in flight, and delivers at least 0.95 of the rate of
+    the same runner in a process with eight queues -- every digest green in both."""
+    args = ['--steps', '20', '--warmup', '3', '--no-pcie', '--no-latency', '--cpu-frames', '0']
+    four = _bench(args, {'GPU_MAX_HW_QUEUES': '4', 'ORBFE_QUIET': '1'})
+    eight = _bench(args, {'GPU_MAX_HW_QUEUES': '8'})
+    assert four['verified'] is True and eight['verified'] is True
+    assert four['config']['batches_in_flight'] == 3 and four['config']['batches_in_flight_asked'] == 4
+    assert eight['config']['batches_in_flight'] == 4
+    assert four['value'] >= 0.95 * eight['value'], (four['value'], eight['value'])
