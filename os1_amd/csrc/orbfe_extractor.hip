@@ -44,7 +44,8 @@ void launch_describe(const PyramidParams& P, const SelKp* sel, int nsel, float* 
 void launch_sincos(const float* deg, int n, float* c, float* s, hipStream_t st);
 void launch_spin(unsigned long long ticks, hipStream_t st);
 void launch_describe_slots(const PyramidParams& P, const SelKp* sel, int nslots, float* angle, uint8_t* desc,
-                           const uint32_t* selCount, int selPerFrame, const int* selOff, hipStream_t st, bool fourWaves);
+                           const uint32_t* selCount, int selPerFrame, const int* selOff, hipStream_t st, bool fourWaves, float* angle2 = nullptr,
+                           uint8_t* desc2 = nullptr);
 int launch_quadtree(const QtParams& Q, int nframes, hipStream_t st, int ldsBudget);
 // orbfe_bow.hip
 int bow_launch_descend(orbfe_vocabulary* v, const uint8_t* d_desc, int n, int levelsup, uint2* d_out, hipStream_t st);
@@ -201,13 +202,17 @@ struct orbfe_extractor {
   int rows = 0, cols = 0, batchCap = 0;
   PyramidParams P{};
   DevBuf<uint8_t> d_tables, d_slab, d_in;
-  DevBuf<ConeRange> d_coneTab;
+  DevBuf<ConeRange> d_coneTab, d_coneTailTab;
+  ConeParams coneTail{};      // (experiments build, ORBFE_TAIL_CONE_BASE / _TILE: levels base + 1 .. top of a BATCH in one cone launch)
+  bool tailOk = false;
+  int tailBase = 0, tailTile = 48;
   ConeParams cone{};
   bool coneOk = false;
   bool qtJump = true;             // ORBFE_QT_JUMP=0: every pass of the quadtree is an ordinary sweep
   int qtLdsBudget = 120 * 1024;   // LDS bytes a quadtree problem may use for its candidates in small batches
   int pollWaitUs = 0;             // > 0: collect polls the stream and sleeps this long between polls
-  bool zeroCopyOut = true;        // small plain batches: results written to host memory by the kernels
+  bool zeroCopyOut = true;        // one- / two-frame calls: results written to host memory by the kernels (ORBFE_ZERO_COPY=0: one copy command behind the call)
+  bool zeroCopyBatches = false;   // ORBFE_ZERO_COPY=2: batches too
   bool ingestKernel = true;       // small batches from page-locked host memory: fetched by a kernel on the compute stream (ORBFE_INGEST_KERNEL=0: copy command)
   int coneTile = 0;        // tile edge on the top level (0 = chosen from the level's size)
   int coneMaxFrames = 2;   // batches up to this size build the pyramid with k_pyramid_cone
@@ -274,7 +279,7 @@ struct orbfe_extractor {
     (void)hipSetDevice(device);
     for (auto& st : streams) if (st) (void)hipStreamSynchronize(st);   // a batch may still be in flight
     d_bow.release(); h_bow.release();
-    d_tables.release(); d_coneTab.release(); d_slab.release(); d_in.release(); d_cellCount.release();
+    d_tables.release(); d_coneTab.release(); d_coneTailTab.release(); d_slab.release(); d_in.release(); d_cellCount.release();
     d_sfiOrder.release(); d_sfiOrderCount.release(); d_sfiPool.release(); d_sfiPcount.release();
     d_cells.release(); d_tasks.release(); d_zeros.release(); d_slots.release(); d_cand.release(); d_frame0.release(); d_gray.release(); d_outArena.release(); h_outArena.release();
     d_f32tmp.release();
@@ -413,12 +418,13 @@ struct orbfe_extractor {
     HIP_TRY(hipMemcpyAsync(d_tables.p, tab.data(), tableBytes, hipMemcpyHostToDevice, stream));
     // one-launch pyramid for small batches (k_pyramid_cone): per tile column / row of the top level, the range of every
     // lower level it depends on; the cone starts at the lowest level whose regions still fit the LDS budget
-    coneOk = false;
-    std::vector<ConeRange> coneTab;
-    if (nlevels >= 3 && scaleFactor <= 1.5f) {
+    // (the same cone from a higher base level serves an experiment of round 6: the TAIL of a batch's pyramid in one launch)
+    auto buildCone = [&](int tile, int baseMin, ConeParams& out, DevBuf<ConeRange>& tabBuf, bool& ok) -> int {
+      ok = false;
+      if (!(nlevels >= 3 && scaleFactor <= 1.5f)) return ORBFE_OK;
+      std::vector<ConeRange> coneTab;
       const int top = nlevels - 1;
       // a block is bound by its own CU's issue rate: the smallest tile that still gives every block a CU of its own
-      int tile = coneTile;
       if (tile <= 0) {
         tile = 32;
         for (int t = 16; t < 32; t += 4)
@@ -443,7 +449,7 @@ struct orbfe_extractor {
           lo = nlo; hi = nhi;
         }
       }
-      for (int base = 0; base < top - 1; base++) {
+      for (int base = std::max(0, baseMin); base < top - 1; base++) {
         // regions are padded to dword columns on both sides (k_pyramid_cone)
         auto pitchOf = [&](int l) { return (maxW[l] + 3 + 3) & ~3; };
         auto area = [&](int l) { return (size_t)align_up(pitchOf(l) * maxH[l], 16); };
@@ -456,19 +462,27 @@ struct orbfe_extractor {
         const size_t coefBytes = (size_t)kMaxLevels * 2 * coefLen * sizeof(int2);
         const size_t total = area(base) + area(base + 1) + hBytes + coefBytes;
         if (total > 128 * 1024 || coefLen > 512) continue;
-        cone.base = base; cone.top = top; cone.tile = tile; cone.tilesX = tx; cone.tilesY = ty;
-        cone.offB = (int)area(base); cone.offH = cone.offB + (int)area(base + 1); cone.offC = cone.offH + (int)hBytes;
-        cone.coefLen = coefLen; cone.ldsBytes = (int)total;
-        coneOk = true;
+        out.base = base; out.top = top; out.tile = tile; out.tilesX = tx; out.tilesY = ty;
+        out.offB = (int)area(base); out.offH = out.offB + (int)area(base + 1); out.offC = out.offH + (int)hBytes;
+        out.coefLen = coefLen; out.ldsBytes = (int)total;
+        ok = true;
         break;
       }
-      if (coneOk) {
-        if ((rc = d_coneTab.ensure(coneTab.size()))) return rc;
-        HIP_TRY(hipMemcpyAsync(d_coneTab.p, coneTab.data(), sizeof(ConeRange) * coneTab.size(), hipMemcpyHostToDevice, stream));
-        cone.regX = d_coneTab.p;
-        cone.regY = d_coneTab.p + (size_t)tx * kMaxLevels;
+      if (ok) {
+        int rc2;
+        if ((rc2 = tabBuf.ensure(coneTab.size()))) return rc2;
+        HIP_TRY(hipMemcpyAsync(tabBuf.p, coneTab.data(), sizeof(ConeRange) * coneTab.size(), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));   // (coneTab is a local)
+        out.regX = tabBuf.p;
+        out.regY = tabBuf.p + (size_t)tx * kMaxLevels;
       }
-    }
+      return ORBFE_OK;
+    };
+    if ((rc = buildCone(coneTile, 0, cone, d_coneTab, coneOk))) return rc;
+    tailOk = false;
+    if (tailBase > 0 && tailBase < nlevels - 2)
+      if ((rc = buildCone(tailTile, tailBase, coneTail, d_coneTailTab, tailOk))) return rc;
+    if (tailOk && coneTail.base != tailBase) tailOk = false;
     // per-cell geometry (emit regions of ComputeKeyPointsOctTree's cell grid, ORBextractor.cc:826-844)
     std::vector<CellInfo> cells(Q.ncells);
     for (int l = 0; l < nlevels; l++) {
@@ -790,8 +804,15 @@ struct orbfe_extractor {
     const bool zeroCopy = zeroCopyOut && small && !voc && !(ms && ms->chain);
     submitZeroCopy = zeroCopy;
     QP.jump = qtJump ? 1 : 0;
-    QP.selHost = zeroCopy ? h_sel.p : nullptr;
-    QP.selCountHost = zeroCopy ? h_selCount.p : nullptr;
+    // Batches, ORBFE_ZERO_COPY=2 (round 6): the kernels that produce a result store a second copy of it into the page-locked arena -- the
+    // quadtree its selection, the descriptor kernel angles and descriptors, SearchForInitialization its match vectors (their only copy)
+    // -- so no copy command follows the batch (16 % of the GPU's kernel time in round 5's profile); the first copies stay in HBM for the
+    // matching chain, the bag-of-words descent and resident frames.  Measured equal to the copy command (92.0 against 92.1 k frames/s
+    // with four batches in flight, 88.6 against 89.0 k with three: gpurun r06l) -- the stores cost what the copy costs -- so the copy
+    // command stays the default for batches.
+    const bool kernelOut = zeroCopyBatches && !small;
+    QP.selHost = (zeroCopy || kernelOut) ? h_sel.p : nullptr;
+    QP.selCountHost = (zeroCopy || kernelOut) ? h_selCount.p : nullptr;
     for (int l = 0; l < nlevels; l++) {
       QP.levW[l] = P.lv[l].w; QP.levH[l] = P.lv[l].h; QP.nfeat[l] = nfeat[l]; QP.selOff[l] = selOff[l];
       QP.candBase[l] = P.lv[l].slotBase;
@@ -807,7 +828,7 @@ struct orbfe_extractor {
     QP.levelLocal = localCand ? 1 : 0;
     {
       if (prof) HIP_TRY(hipEventRecord(ev[0][0], st));
-      if (launch_pyramid(P, nframes, st, coneOk && small ? &cone : nullptr)) { set_err("cannot configure the pyramid kernel"); return ORBFE_ERR_HIP; }
+      if (launch_pyramid(P, nframes, st, coneOk && small ? &cone : (tailOk && !small ? &coneTail : nullptr))) { set_err("cannot configure the pyramid kernel"); return ORBFE_ERR_HIP; }
       // the dominant kernel is timed in every batch (bench.py roofline); a latency-bound one- or two-frame call does
       // without the two markers (each costs a few microseconds of dependent-launch gap) unless profiling is on
       const bool timeFast = prof || !small;
@@ -822,7 +843,8 @@ struct orbfe_extractor {
       if (launch_quadtree(QP, nframes, st, qtLds)) { set_err("cannot configure the quadtree kernel"); return ORBFE_ERR_HIP; }
       if (prof) HIP_TRY(hipEventRecord(evQt[1], st));
       if (prof) HIP_TRY(hipEventRecord(ev[0][4], st));
-      launch_describe_slots(P, d_sel.p, nframes * selPerFrame, angOut, descOut, d_selCount.p, selPerFrame, selOff, st, four);
+      launch_describe_slots(P, d_sel.p, nframes * selPerFrame, angOut, descOut, d_selCount.p, selPerFrame, selOff, st, four,
+                            kernelOut ? h_angle.p : nullptr, kernelOut ? h_desc.p : nullptr);
       if (prof) HIP_TRY(hipEventRecord(ev[0][5], st));
       HIP_TRY(hipGetLastError());
     }
@@ -856,7 +878,7 @@ struct orbfe_extractor {
       SP.invH = static_cast<float>(48) / static_cast<float>(ms->bounds[3] - ms->bounds[2]);   // Frame.cc:99
       SP.window = (float)ms->window; SP.nnratio = ms->nnratio; SP.checkOri = ms->checkOri;
       SP.order = d_sfiOrder.p; SP.orderCount = d_sfiOrderCount.p; SP.pool = d_sfiPool.p; SP.pcount = d_sfiPcount.p;
-      SP.matches12 = d_m12.p; SP.nmatches = d_nm.p;
+      SP.matches12 = kernelOut ? h_m12.p : d_m12.p; SP.nmatches = kernelOut ? h_nm.p : d_nm.p;
       if (ch.seq > 0 && !iso) HIP_TRY(hipStreamWaitEvent(st, ch.ready[prev], 0));
       launch_sfi(SP, nframes, st);
       HIP_TRY(hipGetLastError());
@@ -869,7 +891,7 @@ struct orbfe_extractor {
       ch.seq++;
       pendingMatched = true;
     }
-    if (!zeroCopy) HIP_TRY(hipMemcpyAsync(h_outArena.p, d_outArena.p, outArenaBytes, hipMemcpyDeviceToHost, st));   // all results, one copy
+    if (!zeroCopy && !kernelOut) HIP_TRY(hipMemcpyAsync(h_outArena.p, d_outArena.p, outArenaBytes, hipMemcpyDeviceToHost, st));   // all results, one copy
     submitProfiled = prof;
     tSubmit0 = t0;
     tSubmit1 = now_ms();
@@ -1442,11 +1464,13 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
   if (const char* cv = getenv("ORBFE_CONE_MAX_FRAMES")) h->coneMaxFrames = atoi(cv);
   if (const char* pv = getenv("ORBFE_POLL_WAIT_US")) h->pollWaitUs = atoi(pv);
   if (const char* dw = ORBFE_EXP_ENV("ORBFE_DESCRIBE_WAVES")) h->describe4 = atoi(dw) != 1;
-  if (const char* zv = getenv("ORBFE_ZERO_COPY")) h->zeroCopyOut = atoi(zv) != 0;
+  if (const char* zv = getenv("ORBFE_ZERO_COPY")) { h->zeroCopyOut = atoi(zv) != 0; h->zeroCopyBatches = atoi(zv) == 2; }
   if (const char* iv = getenv("ORBFE_INGEST_KERNEL")) h->ingestKernel = atoi(iv) != 0;
   if (const char* gv = ORBFE_EXP_ENV("ORBFE_LOCAL_LISTS")) h->localLists = atoi(gv) != 0;
   if (const char* qv = getenv("ORBFE_QT_LDS_BYTES")) h->qtLdsBudget = atoi(qv);
   if (const char* qj = getenv("ORBFE_QT_JUMP")) h->qtJump = atoi(qj) != 0;
+  if (const char* tb = ORBFE_EXP_ENV("ORBFE_TAIL_CONE_BASE")) h->tailBase = atoi(tb);
+  if (const char* tt = ORBFE_EXP_ENV("ORBFE_TAIL_CONE_TILE")) h->tailTile = std::max(8, atoi(tt)) & ~3;
   if (const char* cv = ORBFE_EXP_ENV("ORBFE_CONE_TILE")) h->coneTile = atoi(cv) <= 0 ? 0 : std::max(8, atoi(cv)) & ~3;
   if (const char* pv = ORBFE_EXP_ENV("ORBFE_PROFILE_KERNELS")) h->profileKernels = atoi(pv) != 0;
   if (const char* gv = getenv("ORBFE_GAUSS_VARIANT")) h->gaussVariant = atoi(gv) == ORBFE_GAUSS_ROUNDED ? ORBFE_GAUSS_ROUNDED : ORBFE_GAUSS_ED;

@@ -923,6 +923,8 @@ struct DescribeArgs {
   const uint32_t* selCount;          // slot mode: [nframes][kMaxLevels]; nullptr: dense mode
   float* angleOut;
   uint8_t* descOut;
+  float* angleOut2;                  // optional second copy of both (batches: the first stays in HBM for the matching kernels, the second
+  uint8_t* descOut2;                 // goes straight to the page-locked result arena: no copy command behind the batch); nullptr = none
   const uint8_t* const* frame0;
   const uint8_t* frameInline[2];
   long long stride0;
@@ -1223,12 +1225,20 @@ __global__ __launch_bounds__(64 * WAVES) void k_describe(DescribeArgs A) {
     const int t0 = center[i1], t1 = center[i2];
     words[j] = __ballot(t0 < t1);
   }
+  uint8_t* descOut2 = A.descOut2;
   if (WAVES == 4) {
-    if (lane == 0) reinterpret_cast<unsigned long long*>(descOut + (long long)k * 32)[wave] = words[wave];
+    if (lane == 0) {
+      reinterpret_cast<unsigned long long*>(descOut + (long long)k * 32)[wave] = words[wave];
+      if (descOut2) reinterpret_cast<unsigned long long*>(descOut2 + (long long)k * 32)[wave] = words[wave];
+    }
   } else if (lane < 4) {
     reinterpret_cast<unsigned long long*>(descOut + (long long)k * 32)[lane] = words[lane];
+    if (descOut2) reinterpret_cast<unsigned long long*>(descOut2 + (long long)k * 32)[lane] = words[lane];
   }
-  if (tid == 0) angleOut[k] = angle;
+  if (tid == 0) {
+    angleOut[k] = angle;
+    if (A.angleOut2) A.angleOut2[k] = angle;
+  }
 }
 
 __global__ void k_sincos(const float* deg, int n, float* c, float* s) {
@@ -1418,7 +1428,7 @@ static DescribeArgs describe_args(const PyramidParams& P, const SelKp* sel, int 
   for (int l = 0; l < kMaxLevels; l++) {
     A.lv[l].w = P.lv[l].w; A.lv[l].h = P.lv[l].h; A.lv[l].pitch = P.lv[l].pitch; A.lv[l].off = P.lv[l].off;
   }
-  A.sel = sel; A.selCount = nullptr; A.angleOut = angle; A.descOut = desc;
+  A.sel = sel; A.selCount = nullptr; A.angleOut = angle; A.descOut = desc; A.angleOut2 = nullptr; A.descOut2 = nullptr;
   A.frame0 = P.frame0; A.frameInline[0] = P.frameInline[0]; A.frameInline[1] = P.frameInline[1];
   A.stride0 = P.stride0; A.slab = P.slab; A.slabBytes = P.slabBytes;
   A.nsel = nsel; A.selPerFrame = 1; A.nlevels = P.nlevels; A.frameBase = P.frameBase; A.dma = lds_dma_enabled();
@@ -1436,9 +1446,12 @@ void launch_describe(const PyramidParams& P, const SelKp* sel, int nsel, float* 
 
 // sel/angle/desc point at the first slot of frame P.frameBase; nslots = nframes * selPerFrame
 void launch_describe_slots(const PyramidParams& P, const SelKp* sel, int nslots, float* angle, uint8_t* desc,
-                           const uint32_t* selCount, int selPerFrame, const int* selOff, hipStream_t st, bool fourWaves) {
+                           const uint32_t* selCount, int selPerFrame, const int* selOff, hipStream_t st, bool fourWaves, float* angle2,
+                           uint8_t* desc2) {
   if (nslots <= 0) return;
   DescribeArgs A = describe_args(P, sel, nslots, angle, desc);
+  A.angleOut2 = angle2;
+  A.descOut2 = desc2;
   A.selCount = selCount;
   A.selPerFrame = selPerFrame;
   for (int l = 0; l <= P.nlevels; l++) A.selOff[l] = selOff[l];

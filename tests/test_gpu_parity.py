@@ -884,23 +884,34 @@ for (gk, gd), (wk, wd) in zip(ex.extract_batch(imgs), want):
     assert gk.tobytes() == wk.tobytes() and gd.tobytes() == wd.tobytes()
 dev = api.DeviceFrames(imgs, 0)
 st = api.Stream(900, 1.2, 8, 20, 7, 0, 3, 2)    # the runner leaves ORBFE_POLL_WAIT_US alone when it is set
-st.set_matching((0.0, 960.0, 0.0, 540.0), 0, 0.9, True)
+bounds = (0.0, 960.0, 0.0, 540.0)
+st.set_matching(bounds, 100, 0.9, True)
 for rep in range(3):
     st.push_ptrs(dev.ptrs, 540, 960, dev.stride, True)
+prev = None
 for rep in range(3):
-    kps, desc, n, _, _ = st.pop(copy=True)
+    kps, desc, n, m12, nm = st.pop(copy=True)
     for i, (wk, wd) in enumerate(want):
         assert kps[i, :n[i]].tobytes() == wk.tobytes() and desc[i, :n[i]].tobytes() == wd.tobytes()
+        if prev is not None:       # SearchForInitialization of every frame against its predecessor in the stream (Tracking.cc:355-357, 384)
+            pk, pd = prev
+            on, om12, _ = o.search_for_initialization(pk, pd, wk, wd, bounds, np.stack([pk['x'], pk['y']], 1), 100, 0.9, True)
+            assert nm[i] == on and (m12[i, :len(pk)] == om12).all(), (rep, i)
+        prev = (wk, wd)
 st.close()
 print('OK')
 '''
 
 
-@pytest.mark.parametrize('env', [{'ORBFE_GAUSS_VARIANT': '1'}, {'ORBFE_GAUSS_VARIANT': '0'}, {'ORBFE_POLL_WAIT_US': '20'}, {'ORBFE_POLL_WAIT_US': '0'}])
+@pytest.mark.parametrize('env', [{'ORBFE_GAUSS_VARIANT': '1'}, {'ORBFE_GAUSS_VARIANT': '0'}, {'ORBFE_POLL_WAIT_US': '20'}, {'ORBFE_POLL_WAIT_US': '0'},
+                                 {'ORBFE_ZERO_COPY': '0'}, {'ORBFE_ZERO_COPY': '2'}])
 def test_environment_presets(env):
     """ORBFE_GAUSS_VARIANT presets the GaussianBlur variant of every extractor of the process (what an integrator without access to
-    the facade's constructor sets), ORBFE_POLL_WAIT_US how a handle waits for the GPU (sleep-poll / spin): read when a handle is
-    created, so each setting runs in a process of its own -- one-frame calls, a batch and the stream runner against the oracle."""
+    the facade's constructor sets), ORBFE_POLL_WAIT_US how a handle waits for the GPU (sleep-poll / spin), ORBFE_ZERO_COPY=0 sends every
+    result through one copy command behind the call and =2 has the kernels store the results of batches into the page-locked arena too
+    (default: one- and two-frame calls only): read when a handle
+    is created, so each setting runs in a process of its own -- one-frame calls, a batch and the stream runner (with its matching chain)
+    against the oracle."""
     import os
     import subprocess
     import sys
