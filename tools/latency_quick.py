@@ -16,3 +16,10 @@ for name, ptr_of, ondev, stride in (('resident', lambda i: dev.ptrs[i], True, de
         if i < 4: assert kbuf[0, :n[0]].tobytes() == ref[i][0].tobytes() and dbuf[0, :n[0]].tobytes() == ref[i][1].tobytes(), (name, i)
     lat = np.array(lat[10:]) * 1e3
     print('%-12s median %.4f ms  p90 %.4f' % (name, np.median(lat), np.percentile(lat, 90)))
+# where the host's share goes (orbfe_debug_stage_ms of the last call form: enqueue, GPU wait inside collect, -, output assembly, total)
+st = []
+for i in range(40):
+    ex.extract_batch_ptrs([pin.ptrs[i % 64]], wl.H, wl.W, wl.W, False, kbuf, dbuf)
+    st.append(ex.stage_ms())
+st = np.array(st[5:])
+print('page_locked stage ms (median): enqueue %.4f  gpu wait %.4f  assembly %.4f  total in library %.4f' % tuple(np.median(st, 0)[[0, 1, 3, 4]]))
