@@ -381,10 +381,23 @@ __global__ __launch_bounds__(256) void k_resize_fixed(ResizeLevel R, int tilesX,
 // larger batches keep the per-level kernels.  Arithmetic identical to k_resize (same tables, same two passes).
 // ------------------------------------------------------------------------------------------------
 constexpr int kConeThreads = 1024;
+#ifdef ORBFE_EXPERIMENTS
+// experiments build: s_memrealtime stamps (100 MHz) of thread 0 of the LAST tile's block of frame 0: entry, region + coefficients in LDS, then
+// after every level (tools/cone_phases.py)
+__device__ unsigned long long g_coneStamps[32];
+#define CONE_STAMP(i)                                                                                                              \
+  do {                                                                                                                             \
+    if (threadIdx.x == 0 && blockIdx.z == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2)                         \
+      g_coneStamps[i] = __builtin_amdgcn_s_memrealtime();                                                                          \
+  } while (0)
+#else
+#define CONE_STAMP(i) ((void)0)
+#endif
 
 __global__ __launch_bounds__(kConeThreads) void k_pyramid_cone(PyramidParams P, ConeParams C) {
   extern __shared__ __align__(16) uint8_t cone[];
   const int tid = threadIdx.x, f = P.frameBase + blockIdx.z;
+  CONE_STAMP(0);
   // the block's ranges on every level: two 64-byte scalar loads, then registers (the level loops are fully unrolled)
   ConeRange rx[kMaxLevels], ry[kMaxLevels];
 #pragma unroll
@@ -485,6 +498,7 @@ __global__ __launch_bounds__(kConeThreads) void k_pyramid_cone(PyramidParams P, 
     }
   }
   __syncthreads();
+  CONE_STAMP(1);
 #pragma unroll
   for (int l = 1; l < kMaxLevels; l++) {
     if (l <= C.base || l > C.top) continue;
@@ -519,6 +533,7 @@ __global__ __launch_bounds__(kConeThreads) void k_pyramid_cone(PyramidParams P, 
       }
     }
     __syncthreads();
+    CONE_STAMP(16 + l);
     // ---- column pass: thread = 4 columns, a subset of the rows; dword stores to the next region buffer and the slab ----
     {
       uint8_t* dst = P.slab + (long long)f * P.slabBytes + D.off + (long long)dy.lo * D.pitch + (dx.lo - pad);
@@ -562,6 +577,7 @@ __global__ __launch_bounds__(kConeThreads) void k_pyramid_cone(PyramidParams P, 
       }
     }
     __syncthreads();
+    CONE_STAMP(1 + l);
     uint8_t* t = A; A = B; B = t;
     padA = pad;
     pitchA = pitch;
@@ -1483,3 +1499,10 @@ void launch_sincos(const float* deg, int n, float* c, float* s, hipStream_t st) 
 }
 
 }  // namespace orbfe
+
+#ifdef ORBFE_EXPERIMENTS
+extern "C" int orbfe_exp_cone_stamps(unsigned long long* out /* [32] */) {
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(orbfe::g_coneStamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : 1;
+}
+#endif
