@@ -1510,7 +1510,8 @@ extern "C++" int orbfe_concurrent_streams(orbfe_extractor* const* hs, int n) {
   constexpr unsigned long long kTicks = 20000;   // 200 us of the 100 MHz reference clock
   for (int i = 0; i < n; i++) launch_spin(100, hs[i]->streams[0]);   // (code object loaded, queues created)
   for (int i = 0; i < n; i++) HIP_TRY(hipStreamSynchronize(hs[i]->streams[0]));
-  for (int k = n; k > 1; k--) {
+  // do the first k streams run side by side?
+  auto overlap = [&](int k, bool& yes) -> int {
     double best = 1e30;
     for (int rep = 0; rep < 2; rep++) {
       const double t0 = now_ms();
@@ -1519,9 +1520,34 @@ extern "C++" int orbfe_concurrent_streams(orbfe_extractor* const* hs, int n) {
       for (int i = 0; i < k; i++) HIP_TRY(hipStreamSynchronize(hs[i]->streams[0]));
       best = std::min(best, now_ms() - t0);
     }
-    if (best < 0.2 * 1.6) return k;   // all k side by side (two on one queue: >= 0.4 ms)
+    yes = best < 0.2 * 1.6;   // (two on one queue: >= 0.4 ms)
+    return ORBFE_OK;
+  };
+  // Grow the overlapping prefix one stream at a time.  Which hardware queue a stream lands on depends on everything the process
+  // created before it, so a stream that shares its queue with an earlier one of ours is simply replaced by a fresh one -- a few times --
+  // before the prefix is declared final: with enough hardware queues every runner ends up with `n` streams of their own whatever the
+  // process did before.
+  int k = 1;
+  while (k < n) {
+    bool yes = false;
+    int rc = overlap(k + 1, yes);
+    if (rc) return rc;
+    for (int attempt = 0; !yes && attempt < 6; attempt++) {
+      orbfe_extractor* h = hs[k];
+      hipStream_t fresh = nullptr;
+      HIP_TRY(hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking));
+      HIP_TRY(hipStreamSynchronize(h->streams[0]));
+      (void)hipStreamDestroy(h->streams[0]);
+      h->streams[0] = fresh;
+      h->stream = fresh;
+      launch_spin(100, fresh);
+      HIP_TRY(hipStreamSynchronize(fresh));
+      if ((rc = overlap(k + 1, yes))) return rc;
+    }
+    if (!yes) break;
+    k++;
   }
-  return 1;
+  return k;
 }
 extern "C++" { namespace orbfe { int fast_stamps(unsigned long long out[8], int reset); } }
 int orbfe_debug_fast_stamps(orbfe_extractor* h, unsigned long long out[8], int reset) {
