@@ -790,6 +790,47 @@ def test_registered_host_buffers_take_the_page_locked_route(api, oracle):
     assert t_reg < t_page
 
 
+@pytest.mark.parametrize('cfg', [(640, 480, 25, 8, 2, [0, 0]), (1500, 260, 200, 3, 2, [0, 0, 0]), (1280, 720, 12000, 4, 2, [0, 0]), (800, 600, 800, 8, 3, None)])
+def test_isolated_batches_and_multi_runner_odd_geometries(api, oracle, cfg):
+    """orbfe_stream_multi_* (one stream dealt to several device runners, results in push order, the batch-boundary predecessor over the
+    host) on geometries that take different routes inside a runner -- tiny quotas, a strip with 6 quadtree roots and 12 000 features
+    (both OUTSIDE the GPU quadtree's limits: host quadtree + matcher handle, where the chain's isolated mode drops the host-side
+    predecessor) -- against the oracle frame by frame; and (devices None) a single runner with isolated batches: frame 0 of EVERY batch
+    reports no match, the other frames are matched as always."""
+    W, H, N, nl, B, devices = cfg
+    base = synth(70 + W, W, H)
+    frames = [base] + [shifted(base, 2 * i, i, 700 + i) for i in range(1, 4 * B)]
+    dev = api.DeviceFrames(frames, 0)
+    bounds = (0.0, float(W), 0.0, float(H))
+    ox = OracleExtractor(N, 1.2, nl, 20, 7, oracle)
+    want = [ox.extract(f) for f in frames]
+    if devices is None:
+        st = api.Stream(N, 1.2, nl, 20, 7, 0, B, 2)
+        st.set_isolated_batches(True)
+    else:
+        st = api.MultiStream(N, 1.2, nl, 20, 7, devices, B, 2)
+    st.set_matching(bounds, 60, 0.9, True)
+    for b in range(4):
+        st.push_ptrs(dev.ptrs[b * B:(b + 1) * B], H, W, dev.stride, True)
+    total = 0
+    for b in range(4):
+        kps, desc, n, m12, nm = st.pop(copy=True)
+        for i in range(B):
+            g = b * B + i
+            wk, wd = want[g]
+            assert n[i] == len(wk), (b, i)
+            assert kps[i, :n[i]].tobytes() == wk.tobytes() and desc[i, :n[i]].tobytes() == wd.tobytes(), (b, i)
+            if g == 0 or (devices is None and i == 0):
+                assert nm[i] == 0 and (m12[i] == -1).all(), (b, i)
+                continue
+            pk, pd = want[g - 1]
+            on, om12, _ = oracle.search_for_initialization(pk, pd, wk, wd, bounds, np.stack([pk['x'], pk['y']], 1).reshape(-1, 2), 60, 0.9, True)
+            assert nm[i] == on and (m12[i, :len(pk)] == om12).all() and (m12[i, len(pk):] == -1).all(), (b, i)
+            total += on
+    assert total > 20
+    st.close()
+
+
 @pytest.mark.parametrize('seq', ['0', '1', 'cap1', 'cap3'])
 def test_stream_matching_dense_clusters(api, oracle, seq, monkeypatch):
     """SearchForInitialization bookkeeping under stress: many level-0 keypoints in a small image, a window that covers a
