@@ -424,10 +424,11 @@ struct orbfe_extractor {
       if (!(nlevels >= 3 && scaleFactor <= 1.5f)) return ORBFE_OK;
       std::vector<ConeRange> coneTab;
       const int top = nlevels - 1;
-      // a block is bound by its own CU's issue rate: the smallest tile that still gives every block a CU of its own
+      // a block is bound by its own CU's issue rate (1 366 vector + 1 141 scalar instructions per wave, 16 waves: tools/pmc_cone.sh): the
+      // smallest tile that still gives every block a CU of its own -- 26 at 1080p: 21 x 12 = 252 blocks on 256 CUs (28: 220; round 6)
       if (tile <= 0) {
         tile = 32;
-        for (int t = 16; t < 32; t += 4)
+        for (int t = 16; t < 32; t += 2)
           if (((Q.lv[top].w + t - 1) / t) * ((Q.lv[top].h + t - 1) / t) <= 256) { tile = t; break; }
       }
       const int tx = (Q.lv[top].w + tile - 1) / tile, ty = (Q.lv[top].h + tile - 1) / tile;
@@ -733,11 +734,10 @@ struct orbfe_extractor {
       // (a batch for the copy engine needs no mapping: frame 0 decides the route, a pageable straggler is merely staged)
       const int ncheck = nframes <= coneMaxFrames ? nframes : 1;
       for (int f = 0; f < ncheck && pinned; f++) {
-        hipPointerAttribute_t attr;
         void* dp = nullptr;
         void* dpEnd = nullptr;
-        const bool ok = hipPointerGetAttributes(&attr, gray[f]) == hipSuccess && attr.type == hipMemoryTypeHost &&
-                        hipHostGetDevicePointer(&dp, const_cast<uint8_t*>(gray[f]), 0) == hipSuccess && dp &&
+        // (hipHostGetDevicePointer succeeds for page-locked and registered host memory only: no separate attribute query)
+        const bool ok = hipHostGetDevicePointer(&dp, const_cast<uint8_t*>(gray[f]), 0) == hipSuccess && dp &&
                         hipHostGetDevicePointer(&dpEnd, const_cast<uint8_t*>(gray[f]) + extent - 1, 0) == hipSuccess &&
                         (const uint8_t*)dpEnd - (const uint8_t*)dp == (ptrdiff_t)(extent - 1);
         if (!ok) { (void)hipGetLastError(); pinned = false; break; }
@@ -1471,7 +1471,7 @@ int orbfe_extractor_create(int nfeatures, float scaleFactor, int nlevels, int in
   if (const char* qj = getenv("ORBFE_QT_JUMP")) h->qtJump = atoi(qj) != 0;
   if (const char* tb = ORBFE_EXP_ENV("ORBFE_TAIL_CONE_BASE")) h->tailBase = atoi(tb);
   if (const char* tt = ORBFE_EXP_ENV("ORBFE_TAIL_CONE_TILE")) h->tailTile = std::max(8, atoi(tt)) & ~3;
-  if (const char* cv = ORBFE_EXP_ENV("ORBFE_CONE_TILE")) h->coneTile = atoi(cv) <= 0 ? 0 : std::max(8, atoi(cv)) & ~3;
+  if (const char* cv = ORBFE_EXP_ENV("ORBFE_CONE_TILE")) h->coneTile = atoi(cv) <= 0 ? 0 : std::max(8, atoi(cv));
   if (const char* pv = ORBFE_EXP_ENV("ORBFE_PROFILE_KERNELS")) h->profileKernels = atoi(pv) != 0;
   if (const char* gv = getenv("ORBFE_GAUSS_VARIANT")) h->gaussVariant = atoi(gv) == ORBFE_GAUSS_ROUNDED ? ORBFE_GAUSS_ROUNDED : ORBFE_GAUSS_ED;
   h->selPerFrame = 0;

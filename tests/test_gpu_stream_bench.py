@@ -320,182 +320,6 @@ def test_stream_create_reports_batches_in_flight(api):
     assert (err.count('liborbfe: orbfe_stream_create') == 1) == any(k < d for d, k in got)
 
 
-def _run_multi(api, seed, nsub, devices, depth=2, batch=wl.SUBMIT, source='hbm'):
-    """The same walk through orbfe_stream_multi_*: batch k on devices[k % n], results popped in push order."""
-    sf = wl.StreamFrames(seed)
-    idx = [wl.pool_index(p) for p in range(nsub * batch)]
-    frames = {i: sf.frame(i) for i in sorted(set(idx))}
-    order = sorted(frames)
-    stack = [frames[i] for i in order]
-    pools = {}
-    for d in sorted(set(devices)):       # resident frames must live on the device their batch goes to
-        pool = api.DeviceFrames(stack, d) if source == 'hbm' else api.PinnedFrames(stack)
-        pools[d] = {i: pool.ptrs[k] for k, i in enumerate(order)}
-        pools[d]['_keep'] = pool
-    st = api.MultiStream(wl.NFEAT, wl.SCALE, wl.NLEVELS, wl.INI_TH, wl.MIN_TH, devices, batch, depth)
-    st.set_matching(wl.BOUNDS, wl.WINDOW, wl.NNRATIO, wl.CHECK_ORI)
-    pushed = 0
-
-    def push():
-        nonlocal pushed
-        at = pools[st.device_of_next_push()]
-        st.push_ptrs([at[i] for i in idx[pushed * batch:(pushed + 1) * batch]], wl.H, wl.W, wl.W, source == 'hbm')
-        pushed += 1
-    ahead = len(devices) * depth
-    while pushed < min(ahead, nsub):
-        push()
-    out = []
-    for _ in range(nsub):
-        out.append(st.pop(copy=True))
-        if pushed < nsub:
-            push()
-    st.close()
-    return out
-
-
-@pytest.mark.parametrize('devices,depth', [([0, 0, 0, 0], 2), ([0], 3), ([0, 0, 0], 1)])
-def test_single_stream_over_several_runners_against_digests(api, devices, depth):
-    """SURVEY.md s8(e), the single-stream shape: ONE camera stream dealt batch by batch to n device runners (here all on the one GPU of
-    the test box: device_ids = [0, 0, 0, 0] is what an 8-GPU node runs with [0..7]), results in push order, the SearchForInitialization
-    predecessor of every batch's first frame bounced over the host.  Stream 100, the whole forwards-and-backwards period, position by
-    position against the committed digests -- the same bytes one single-device runner returns."""
-    nsub = -(-(wl.PERIOD + 2) // wl.SUBMIT)
-    got = _run_multi(api, 100, nsub, devices, depth)
-    chk = wl.PositionChecker(_table(100))
-    hasher = wl.StepHasher()
-    for s, res in enumerate(got):
-        chk.check(s * wl.SUBMIT, *res, first_of_runner=(s == 0))
-        hasher.add(*res)
-    assert not chk.bad, chk.bad[:10]
-    assert chk.frames == nsub * wl.SUBMIT and len(chk.positions) == wl.PERIOD
-    want, total = _steps(100, nsub * wl.SUBMIT // wl.BATCH)
-    assert hasher.steps == want and hasher.nmatches == total == chk.nmatches
-
-
-def test_single_stream_runner_edge_cases(api):
-    """Host frames through the multi-device runner, matching switched off and on again between idle phases, a pop without a push, and
-    a runner destroyed with batches still in flight."""
-    got = _run_multi(api, 100, 3, [0, 0], depth=2, batch=wl.BATCH, source='pinned')
-    hasher = wl.StepHasher()
-    for res in got:
-        hasher.add(*res)
-    assert hasher.steps == _steps(100, 3)[0]
-    sf = wl.StreamFrames(100)
-    dev = api.DeviceFrames([sf.frame(i) for i in range(8)], 0)
-    st = api.MultiStream(wl.NFEAT, wl.SCALE, wl.NLEVELS, wl.INI_TH, wl.MIN_TH, [0, 0], 4, 1)
-    with pytest.raises(Exception):
-        st.pop()
-    st.set_matching(wl.BOUNDS, 0, wl.NNRATIO, wl.CHECK_ORI)            # extraction only
-    st.push_ptrs(dev.ptrs[0:4], wl.H, wl.W, dev.stride, True)
-    st.push_ptrs(dev.ptrs[4:8], wl.H, wl.W, dev.stride, True)
-    a = st.pop(copy=True)
-    b = st.pop(copy=True)
-    assert (a[4] == 0).all() and (b[4] == 0).all()
-    st.set_matching(wl.BOUNDS, wl.WINDOW, wl.NNRATIO, wl.CHECK_ORI)    # ... and with matching: same keypoints; the stream goes on, so every frame has a predecessor
-    st.push_ptrs(dev.ptrs[0:4], wl.H, wl.W, dev.stride, True)
-    st.push_ptrs(dev.ptrs[4:8], wl.H, wl.W, dev.stride, True)
-    c = st.pop(copy=True)
-    d = st.pop(copy=True)
-    assert c[0].tobytes() == a[0].tobytes() and d[1].tobytes() == b[1].tobytes()
-    assert (c[4] > 0).all() and (d[4] > 0).all()      # (frame 0 of `c` against the last frame of `b`, frame 0 of `d` against the last of `c`: over the host)
-    st.push_ptrs(dev.ptrs[0:4], wl.H, wl.W, dev.stride, True)          # never popped
-    st.push_ptrs(dev.ptrs[4:8], wl.H, wl.W, dev.stride, True)
-    st.close()
-
-
-def _bench(args, extra_env=None):
-    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
-    env.update(extra_env or {})
-    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, capture_output=True, text=True, timeout=1500, env=env)
-    assert out.returncode == 0, out.stderr[-3000:]
-    return json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
-
-
-def test_bench_line_is_self_verified(api):
-    res = _bench(['--steps', '2', '--warmup', '1', '--cpu-frames', '0'])
-    assert res['n_gpus'] == 1 and res['verified'] is True and len(res['outputs_sha256']) == 64
-    v = res['verify']
-    assert v['frames_checked'] >= 510 and v['distinct_period_positions'] == 510 and v['verified_before_timing'] is True
-    assert v['timed_verified'] is True and v['timed_frames_checked'] == 2 * 64 and v['timed_stream_positions'][0] > 2048
-    assert res['pcie_inclusive']['timed_verified'] is True and res['pcie_inclusive']['timed_frames_checked'] > 0
-    assert res['config']['distinct_frames_per_gpu'] == 256 and res['config']['frames_per_step_per_gpu'] == 2048
-    assert res['value'] > 1000 and res['pcie_inclusive']['value'] > 1000
-    assert res['roofline']['frac'] > 0 and res['roofline']['launch_ms'] > 0
-
-
-def test_bench_two_ranks_on_one_gpu(api):
-    """bench.py --gpus 2 launches its two ranks itself; ORBFE_BENCH_DEVICE=0 puts both on the one GPU of this box.
-    Each rank runs its own stream (seeds 100, 101) through the product and checks it against that seed's digests."""
-    res = _bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--no-pcie'], {'ORBFE_BENCH_DEVICE': '0'})
-    assert res['n_gpus'] == 2
-    assert res['verified'] is True and res['verify']['ranks_verified'] == 2 and res['verify']['timed_ranks_verified'] == 2
-    assert res['value'] > 1000 and res['config']['parallelism'].startswith('independent streams')
-
-
-def test_bench_eight_ranks_on_one_gpu(api):
-    """The launcher at N = 8: bench.py --gpus 8 spawns eight fresh child ranks before any GPU call (never a re-exec of an
-    initialised process), ORBFE_BENCH_DEVICE=0 puts all of them on the one GPU of this box.  Every rank runs its own camera
-    stream (seeds 100..107) through the product and checks it against that seed's committed digests
-    (tests/golden/stream1080_digests.json); the line reports the host cores all ranks used together."""
-    res = _bench(['--gpus', '8', '--steps', '1', '--warmup', '1', '--no-pcie', '--no-latency', '--cpu-frames', '0', '--prewarm-seconds', '0'],
-                 {'ORBFE_BENCH_DEVICE': '0'})
-    assert res['n_gpus'] == 8
-    assert res['verified'] is True and res['verify']['ranks_verified'] == 8 and res['verify']['timed_ranks_verified'] == 8
-    assert res['value'] > 1000 and res['config']['parallelism'].startswith('independent streams')
-    assert 0 < res['host_cpu_cores_used_all_ranks'] < 64
-
-
-def test_stream_runner_4k_4000_features(api, oracle):
-    """BASELINE configs[4] geometry through the streaming path: 3840x2160, 4000 features (the 1 024-node quadtree variant,
-    869 level-0 queries per SearchForInitialization), 2-frame submissions on 2 handles, against the live oracle."""
-    from oracle.pyoracle import OracleExtractor
-    from os1_amd.synth import shifted, synth
-    W, H, N, B = 3840, 2160, 4000, 2
-    base = synth(5, W, H)
-    frames = [base] + [shifted(base, 2 * i, i, 5000 + i) for i in range(1, 3 * B)]
-    dev = api.DeviceFrames(frames, 0)
-    st = api.Stream(N, 1.2, 8, 20, 7, 0, B, 2)
-    bounds = (0.0, float(W), 0.0, float(H))
-    st.set_matching(bounds, 100, 0.9, True)
-    ox = OracleExtractor(N, 1.2, 8, 20, 7, oracle)
-    want = [ox.extract(f) for f in frames]
-    for b in range(3):
-        st.push_ptrs(dev.ptrs[b * B:(b + 1) * B], H, W, dev.stride, True)
-    total = 0
-    for b in range(3):
-        kps, desc, n, m12, nm = st.pop(copy=True)
-        for i in range(B):
-            g = b * B + i
-            wk, wd = want[g]
-            assert n[i] == len(wk)
-            assert kps[i, :n[i]].tobytes() == wk.tobytes() and desc[i, :n[i]].tobytes() == wd.tobytes()
-            if g == 0:
-                continue
-            pk, pd = want[g - 1]
-            on, om12, _ = oracle.search_for_initialization(pk, pd, wk, wd, bounds, np.stack([pk['x'], pk['y']], 1).reshape(-1, 2), 100, 0.9, True)
-            assert nm[i] == on and (m12[i, :len(pk)] == om12).all()
-            total += on
-    assert total > 1000
-    st.close()
-
-
-def test_stream_create_warns_about_hardware_queues(api):
-    """Four batches in flight need GPU_MAX_HW_QUEUES=8 in the process's environment before its first HIP call (include/orbfe.h,
-    INTEGRATION.md): a library cannot set it for its host, so orbfe_stream_create says so on stderr -- once, only for depth >= 4, and
-    not when the variable is set (bench.py sets it) or ORBFE_QUIET=1."""
-    code = ("import sys; sys.path.insert(0, %r)\n"
-            "from os1_amd import api\n"
-            "for d in (3, 4, 4):\n"
-            "    api.Stream(500, 1.2, 8, 20, 7, 0, 2, d).close()\n") % ROOT
-    base = {k: v for k, v in os.environ.items() if k not in ('GPU_MAX_HW_QUEUES', 'ORBFE_QUIET')}
-    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=base)
-    assert r.returncode == 0, r.stderr[-2000:]
-    assert r.stderr.count('GPU_MAX_HW_QUEUES') >= 1 and r.stderr.count('liborbfe: orbfe_stream_create(depth = 4)') == 1
-    for extra in ({'GPU_MAX_HW_QUEUES': '8'}, {'ORBFE_QUIET': '1'}):
-        r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600, env=dict(base, **extra))
-        assert r.returncode == 0 and 'liborbfe: orbfe_stream_create' not in r.stderr
-
-
 def test_bench_single_stream_mode_on_one_gpu(api):
     """`bench.py --single-stream --gpus 4` with the four device runners on the one GPU of the test box: the same JSON contract, the
     whole period verified before timing and the sampled batches of the timed region (mid-stream batches: their first frame's predecessor
