@@ -151,27 +151,42 @@ int orbfe_stream_multi_create(int nfeatures, float scaleFactor, int nlevels, int
   s->tail.resize((size_t)n_devices * 2);
   s->gate.reset(new orbfe::InOrderGate(n_devices));
   int rc = ORBFE_OK;
+  std::string err;
   for (int d = 0; d < n_devices && rc == ORBFE_OK; d++) {
-    orbfe_stream* sub = nullptr;
-    rc = orbfe_stream_create(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device_ids[d], batch, depth, &sub);
-    if (rc == ORBFE_OK) {
-      s->sub.push_back(sub);
-      rc = orbfe_stream_set_isolated_batches(sub, 1);
-    }
-    if (rc == ORBFE_OK) {
-      orbfe_matcher* m = nullptr;
-      rc = orbfe_matcher_create(device_ids[d], &m);
-      if (rc == ORBFE_OK) s->matcher.push_back(m);
-    }
+    // NUMA: a device's runner is created from a thread bound to the CPUs of the device's node, so that the runner's worker thread
+    // (which inherits the mask) and the page-locked arenas it allocates sit next to their GPU (the expected limiter of
+    // a multi-GPU node is the host side); orbfe_bind_thread_to_device never widens a mask, hence one helper thread per device
+    std::thread helper([&, d] {
+      (void)orbfe_bind_thread_to_device(device_ids[d]);
+      orbfe_stream* sub = nullptr;
+      int r = orbfe_stream_create(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device_ids[d], batch, depth, &sub);
+      if (r == ORBFE_OK) {
+        s->sub.push_back(sub);
+        r = orbfe_stream_set_isolated_batches(sub, 1);
+      }
+      if (r == ORBFE_OK) {
+        orbfe_matcher* m = nullptr;
+        r = orbfe_matcher_create(device_ids[d], &m);
+        if (r == ORBFE_OK) s->matcher.push_back(m);
+      }
+      if (r != ORBFE_OK) err = orbfe_last_error();   // (the message is thread-local: carry it to the caller's thread)
+      rc = r;
+    });
+    helper.join();
   }
   if (rc != ORBFE_OK) {
+    set_err("%s", err.c_str());
     for (auto* q : s->sub) orbfe_stream_destroy(q);
     for (auto* m : s->matcher) orbfe_matcher_destroy(m);
     return rc;
   }
   orbfe_stream_multi* p = s.release();
   for (int d = 0; d < n_devices; d++)
-    p->finisher.emplace_back([p, d] { pthread_setname_np(pthread_self(), "orbfe-finish"); p->finish(d); });
+    p->finisher.emplace_back([p, d] {
+      pthread_setname_np(pthread_self(), "orbfe-finish");
+      (void)orbfe_bind_thread_to_device(p->devices[(size_t)d]);
+      p->finish(d);
+    });
   *out = p;
   return ORBFE_OK;
 }
