@@ -276,6 +276,12 @@ int orbfe_stream_set_matching(orbfe_stream* s, const float bounds[4], int window
  * no batch is in flight. */
 int orbfe_stream_set_isolated_batches(orbfe_stream* s, int isolated);
 int orbfe_stream_batches_in_flight(const orbfe_stream* s);
+/* orbfe_stream_pop without the "valid until the next pop" rule: the result stays valid until orbfe_stream_release(s, *ticket).  Any
+ * number of results may be held; each keeps one of the runner's result slots (orbfe_stream_queue_slots) busy, and a push waits while no
+ * slot is free.  Do not mix with orbfe_stream_pop on the same runner. */
+int orbfe_stream_pop_hold(orbfe_stream* s, const OrbfeKeyPoint** kps, const uint8_t** desc, const int** n_kps, const int32_t** matches12,
+                          const int** nmatches, int* ticket);
+int orbfe_stream_release(orbfe_stream* s, int ticket);
 /* orbfe_extractor_set_input_format for every extractor of the runner (only while no batch is in flight). */
 int orbfe_stream_set_input_format(orbfe_stream* s, int format, int gray_variant);
 /* orbfe_extractor_set_blur_variant for every extractor of the runner (only while no batch is in flight). */
@@ -664,7 +670,8 @@ int orbfe_debug_features_in_area(orbfe_matcher* m, const OrbfeKeyPoint* kps_un, 
  * A device may appear several times in device_ids (more batches in flight on it).  With in_device_memory != 0 the frames of a
  * push must live on the device that push goes to: orbfe_stream_multi_device_of_next_push.
  * Everything else as orbfe_stream_*: pointers returned by _pop stay valid until the next _pop; _set_* only while nothing is in flight;
- * push from one thread, pop from one thread.
+ * push from one thread, pop from one thread; never push more than `depth` + 2 batches PER DEVICE ahead of the pops (a device's runner
+ * has depth + 4 result slots and finished batches wait in them for their turn).
  * ------------------------------------------------------------------------------------------- */
 typedef struct orbfe_stream_multi orbfe_stream_multi;
 int orbfe_stream_multi_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, const int* device_ids,

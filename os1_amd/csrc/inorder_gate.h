@@ -5,8 +5,9 @@
 // order the devices finish in, the consumer must see batch k before batch k + 1.
 //
 // `lanes` producers (one per device runner) own the sequence numbers d, d + lanes, d + 2 lanes, ... .  A producer publishes a
-// sequence number when its result is complete and then waits until the consumer has let go of it before it recycles the
-// storage behind it; the consumer takes sequence numbers strictly in order, and taking k + 1 is what lets go of k.
+// sequence number when its result is complete (in order within its lane; it may run ahead of the consumer) and either waits until the
+// consumer has let go of it before it recycles the storage behind it (wait_released) or leaves the recycling to the consumer; the consumer
+// takes sequence numbers strictly in order, and taking k + 1 is what lets go of k.
 #pragma once
 #include <condition_variable>
 #include <mutex>
@@ -45,8 +46,9 @@ class InOrderGate {
       cv_.notify_all();
     }
     const long long want = next_;
-    cv_.wait(lk, [&] { return closed_ || ready_[(size_t)(want % lanes_)] == want; });
-    if (ready_[(size_t)(want % lanes_)] != want) return -1;
+    // (a lane publishes its sequence numbers in order, so "the lane has reached `want`" is >=: a producer may run ahead of the consumer)
+    cv_.wait(lk, [&] { return closed_ || ready_[(size_t)(want % lanes_)] >= want; });
+    if (ready_[(size_t)(want % lanes_)] < want) return -1;
     held_ = want;
     next_ = want + 1;
     return want;

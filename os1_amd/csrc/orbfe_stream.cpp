@@ -530,6 +530,48 @@ int orbfe_stream_pop(orbfe_stream* s, const OrbfeKeyPoint** kps, const uint8_t**
   return sl.status;
 }
 
+// pop WITHOUT the "valid until the next pop" rule: the result stays where it is until orbfe_stream_release(s, *ticket) -- any number of
+// results may be held, each keeps one result slot of the runner busy (orbfe_stream_queue_slots).  For a consumer that hands results on
+// to another thread (orbfe_stream_multi's finishers) without copying them.
+int orbfe_stream_pop_hold(orbfe_stream* s, const OrbfeKeyPoint** kps, const uint8_t** desc, const int** n_kps, const int32_t** matches12,
+                          const int** nmatches, int* ticket) {
+  if (!s || !ticket) { set_err("invalid arguments"); return ORBFE_ERR_INVALID; }
+  int slot;
+  {
+    std::unique_lock<std::mutex> lk(s->mu);
+    if (s->popSeq == s->pushSeq) { set_err("no batch outstanding (every pushed batch has been popped)"); return ORBFE_ERR_INVALID; }
+    auto ready = [&]() -> int {
+      for (size_t i = 0; i < s->slots.size(); i++)
+        if (s->slots[i].done && s->slots[i].seq == s->popSeq) return (int)i;
+      return -1;
+    };
+    s->cv.wait(lk, [&] { return ready() >= 0; });
+    slot = ready();
+    s->slots[slot].done = false;
+    s->popSeq++;
+  }
+  *ticket = slot;
+  Slot& sl = s->slots[slot];
+  if (kps) *kps = sl.kps.data();
+  if (desc) *desc = sl.desc.data();
+  if (n_kps) *n_kps = sl.n.data();
+  if (matches12) *matches12 = sl.m12.data();
+  if (nmatches) *nmatches = sl.nm.data();
+  if (sl.status != ORBFE_OK) set_err("%s", sl.err.c_str());
+  return sl.status;
+}
+
+int orbfe_stream_release(orbfe_stream* s, int ticket) {
+  if (!s || ticket < 0) { set_err("invalid arguments"); return ORBFE_ERR_INVALID; }
+  {
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (ticket >= (int)s->slots.size()) { set_err("not a ticket of this runner"); return ORBFE_ERR_INVALID; }
+    s->freeQ.push_back(ticket);
+  }
+  s->cv.notify_all();
+  return ORBFE_OK;
+}
+
 int orbfe_stream_stats(orbfe_stream* s, double out[4], int reset) {
   if (!s || !out) { set_err("NULL argument"); return ORBFE_ERR_INVALID; }
   std::lock_guard<std::mutex> lk(s->mu);

@@ -10,7 +10,8 @@
 // last frame of the previous batch -- which lives on ANOTHER device -- and takes a host bounce: the finisher thread of the device that
 // popped batch k - 1 publishes that frame's keypoints and descriptors, the finisher of batch k's device matches its first frame
 // against them with the host-array search (orbfe_search_for_initialization: the same kernels) and writes row 0 of the batch's match
-// vectors.  63 of a 64-frame batch's pairs never leave their GPU.
+// vectors.  63 of a 64-frame batch's pairs never leave their GPU.  A finisher never waits for the consumer: it holds a finished batch's
+// result slot (orbfe_stream_pop_hold) and goes on to its device's next batch; the consumer gives the slot back when it lets go.
 #include <pthread.h>
 
 #include <cstring>
@@ -51,9 +52,13 @@ struct orbfe_stream_multi {
     const int32_t* m12 = nullptr;
     const int* nm = nullptr;
     int status = ORBFE_OK;
+    int ticket = -1;            // orbfe_stream_pop_hold's: the consumer releases the result slot when it lets go of the batch
     std::string err;
   };
-  std::vector<Done> done;
+  static constexpr int kRing = 256;   // >= result slots of a device runner (orbfe_stream_set_queue_slots allows at most 256)
+  std::vector<Done> done;             // [ndev][kRing]: a device's finished batches wait here for their turn
+  Done& doneOf(long long seq) { return done[(size_t)(seq % ndev) * kRing + (size_t)((seq / ndev) % kRing)]; }
+  long long heldSeq = -1;             // the batch in the consumer's hands
   // the last frame of the batches a device has popped: two generations per device, so that with one device batch k reads what
   // batch k - 1 left while it writes its own
   struct Tail {
@@ -63,6 +68,7 @@ struct orbfe_stream_multi {
     long long seq = -1;
   };
   std::vector<Tail> tail;   // [ndev][2]
+  std::vector<long long> tailRead;   // [ndev]: the latest batch of the device whose last frame the next batch's finisher has taken
   Tail& tailOf(long long seq) { return tail[(size_t)(seq % ndev) * 2 + (size_t)((seq / ndev) & 1)]; }
 
   void finish(int d) {
@@ -80,12 +86,18 @@ struct orbfe_stream_multi {
         memcpy(bounds_k, bounds, sizeof bounds_k);
       }
       Done r;
-      r.status = orbfe_stream_pop(sub[d], &r.kps, &r.desc, &r.n, &r.m12, &r.nm);
+      // (held, not "valid until the next pop": this thread goes on to the device's next batch while the consumer still reads this one)
+      r.status = orbfe_stream_pop_hold(sub[d], &r.kps, &r.desc, &r.n, &r.m12, &r.nm, &r.ticket);
       if (r.status != ORBFE_OK) r.err = orbfe_last_error();
       const int stride = orbfe_stream_capacity(sub[d]);   // keypoint slots per frame of the result arrays (grows only while the runner is idle)
-      // 1. the next batch's predecessor, before anything else: its finisher may be waiting for it
-      {
-        std::lock_guard<std::mutex> lk(mu);
+      const bool matching = window_k > 0;
+      // 1. the next batch's predecessor, before anything else: its finisher may be waiting for it.  Two generations per device: this one
+      //    overwrites batch k - 2 n's, which the finisher of batch k - 2 n + 1 must have read (a device may run several batches ahead of
+      //    its neighbour)
+      {   // (published and taken whether or not this phase of the stream matches: the hand-over stays in step when matching is switched on)
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || k < 2 * (long long)ndev || tailRead[(size_t)d] >= k - 2 * (long long)ndev; });
+        if (stop && !(k < 2 * (long long)ndev || tailRead[(size_t)d] >= k - 2 * (long long)ndev)) return;
         Tail& t = tailOf(k);
         t.n = -1;
         if (r.status == ORBFE_OK) {
@@ -98,15 +110,17 @@ struct orbfe_stream_multi {
       }
       cv.notify_all();
       // 2. this batch's first frame against ITS predecessor (batch k - 1's last frame, popped on another device)
-      if (r.status == ORBFE_OK && window_k > 0 && k > 0) {
+      if (k > 0) {
         {
           std::unique_lock<std::mutex> lk(mu);
           cv.wait(lk, [&] { return stop || tailOf(k - 1).seq == k - 1; });
           if (tailOf(k - 1).seq != k - 1) return;
-          prev = tailOf(k - 1);   // (a copy: the search runs outside the lock)
+          if (matching) prev = tailOf(k - 1);   // (a copy: the search runs outside the lock)
+          tailRead[(size_t)((k - 1) % ndev)] = k - 1;
         }
-        if (prev.n >= 0) {
-          // the runner owns the slot memory behind the pointers orbfe_stream_pop returned: row 0 of the match vectors is written in place
+        cv.notify_all();
+        if (matching && r.status == ORBFE_OK && prev.n >= 0) {
+          // the runner owns the slot memory behind the pointers orbfe_stream_pop_hold returned: row 0 of the match vectors is written in place
           int32_t* m12 = const_cast<int32_t*>(r.m12);
           int* nm = const_cast<int*>(r.nm);
           prevxy.resize((size_t)(prev.n > 0 ? prev.n : 1) * 2);
@@ -126,13 +140,21 @@ struct orbfe_stream_multi {
           }
         }
       }
-      done[d] = r;
-      gate->publish(k);
-      // 3. the slot behind `r` is recycled by the sub-runner's next pop: not before the consumer has moved on
-      if (!gate->wait_released(k)) return;
+      doneOf(k) = r;
+      gate->publish(k);   // 3. the consumer releases the runner's result slot when it lets go of the batch (orbfe_stream_multi_pop)
     }
   }
 };
+
+// the consumer lets go of the batch it holds: its runner gets the result slot back
+static void release_held_batch(orbfe_stream_multi* s) {
+  if (s->heldSeq >= 0) {
+    const orbfe_stream_multi::Done& r = s->doneOf(s->heldSeq);
+    if (r.ticket >= 0) (void)orbfe_stream_release(s->sub[(size_t)(s->heldSeq % s->ndev)], r.ticket);
+    s->heldSeq = -1;
+  }
+  s->gate->release_held();
+}
 
 extern "C" {
 
@@ -147,8 +169,9 @@ int orbfe_stream_multi_create(int nfeatures, float scaleFactor, int nlevels, int
   s->ndev = n_devices;
   s->batch = batch;
   s->devices.assign(device_ids, device_ids + n_devices);
-  s->done.resize(n_devices);
+  s->done.resize((size_t)n_devices * orbfe_stream_multi::kRing);
   s->tail.resize((size_t)n_devices * 2);
+  s->tailRead.assign((size_t)n_devices, -1);
   s->gate.reset(new orbfe::InOrderGate(n_devices));
   int rc = ORBFE_OK;
   std::string err;
@@ -200,7 +223,7 @@ void orbfe_stream_multi_destroy(orbfe_stream_multi* s) {
     s->stop = true;
   }
   s->cv.notify_all();
-  s->gate->release_held();
+  release_held_batch(s);
   s->gate->close();
   for (auto& t : s->finisher) if (t.joinable()) t.join();
   for (auto* q : s->sub) orbfe_stream_destroy(q);
@@ -221,9 +244,8 @@ int orbfe_stream_multi_set_matching(orbfe_stream_multi* s, const float bounds[4]
     std::lock_guard<std::mutex> lk(s->mu);
     if (s->pushSeq != s->popSeq) { set_err("batches are still in flight"); return ORBFE_ERR_INVALID; }
   }
-  s->gate->release_held();   // (the batch the caller still holds: its sub-runner must be idle for the calls below)
+  release_held_batch(s);   // (the batch the caller still holds)
   for (auto* q : s->sub) {
-    // a finisher that has published its batch is parked in wait_released and pops nothing: the sub-runner is idle once its pops equal its pushes
     const int rc = orbfe_stream_set_matching(q, bounds, window_size, nnratio, check_orientation);
     if (rc != ORBFE_OK) return rc;
   }
@@ -241,7 +263,7 @@ int orbfe_stream_multi_set_blur_variant(orbfe_stream_multi* s, int variant) {
     std::lock_guard<std::mutex> lk(s->mu);
     if (s->pushSeq != s->popSeq) { set_err("batches are still in flight"); return ORBFE_ERR_INVALID; }
   }
-  s->gate->release_held();
+  release_held_batch(s);
   for (auto* q : s->sub) {
     const int rc = orbfe_stream_set_blur_variant(q, variant);
     if (rc != ORBFE_OK) return rc;
@@ -273,13 +295,15 @@ int orbfe_stream_multi_pop(orbfe_stream_multi* s, const OrbfeKeyPoint** kps, con
     std::lock_guard<std::mutex> lk(s->mu);
     if (s->popSeq == s->pushSeq) { set_err("no batch outstanding (every pushed batch has been popped)"); return ORBFE_ERR_INVALID; }
   }
+  release_held_batch(s);
   const long long k = s->gate->take();
   if (k < 0) { set_err("the stream is shutting down"); return ORBFE_ERR_INVALID; }
+  s->heldSeq = k;
   {
     std::lock_guard<std::mutex> lk(s->mu);
     s->popSeq = k + 1;
   }
-  const orbfe_stream_multi::Done& r = s->done[(size_t)(k % s->ndev)];
+  const orbfe_stream_multi::Done& r = s->doneOf(k);
   if (kps) *kps = r.kps;
   if (desc) *desc = r.desc;
   if (n_kps) *n_kps = r.n;
