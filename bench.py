@@ -602,6 +602,29 @@ def run_rank(args):
                     lat.append(time.perf_counter() - t_a)
                 lat = np.array(lat[10:]) * 1e3
                 single_host[name] = {'ms_median': round(float(np.median(lat)), 4), 'ms_p90': round(float(np.percentile(lat, 90)), 4)}
+            # (b') the same page-locked call as a C caller issues it: arguments prepared once, the C entry point called directly -- what
+            # include/orbfe/orb_shim.hpp pays; the figures above include os1_amd.api's per-call ctypes / numpy marshalling (about 5 us),
+            # and the library's own clocks split the call into enqueue / GPU wait / output assembly (orbfe_debug_stage_ms)
+            import ctypes as C
+            nout = np.zeros(1, np.int32)
+            arrs = [(C.c_void_p * 1)(pin_lat.ptrs[i]) for i in range(nlat)]
+            cargs = lambda i: (ex.h, 1, arrs[i], 0, H, W, C.c_size_t(W), kbuf.ctypes.data_as(C.c_void_p), dbuf.ctypes.data_as(C.c_void_p),
+                               int(kbuf.shape[1]), nout.ctypes.data_as(C.c_void_p))
+            prepared = [cargs(i) for i in range(nlat)]
+            lat, stages = [], []
+            for i in range(nlat + 10):
+                a_ = prepared[i % nlat]
+                t_a = time.perf_counter()
+                rc_ = ex.L.orbfe_extract_batch(*a_)
+                lat.append(time.perf_counter() - t_a)
+                stages.append(ex.stage_ms())
+                if rc_:
+                    raise SystemExit('bench: orbfe_extract_batch failed')
+            lat = np.array(lat[10:]) * 1e3
+            stg = np.median(np.array(stages[10:]), 0)
+            single_host['page_locked_prepared_c_call'] = {'ms_median': round(float(np.median(lat)), 4), 'ms_p90': round(float(np.percentile(lat, 90)), 4),
+                                                          'library_stages_ms': {'enqueue': round(float(stg[0]), 4), 'gpu_wait': round(float(stg[1]), 4),
+                                                                                'output_assembly': round(float(stg[3]), 4), 'total': round(float(stg[4]), 4)}}
             # (c) the caller's OWN pageable buffer registered once (orbfe_host_register: a capture ring, a long-lived cv::Mat): page-locked route
             ring = np.stack([frames[i % len(frames)] for i in range(nlat)])
             reg = api.RegisteredArray(ring)
